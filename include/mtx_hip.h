@@ -1,0 +1,220 @@
+/*
+ * mtx_hip.h — C ABI of libmtx_hip.so, the MI355X (gfx950) kernel library under the
+ * MangaTranslator vision hot path (YOLO detect -> SAM-2.1 masks -> FLUX inpaint -> RCAN upscale).
+ *
+ * The reference (meangrinch/MangaTranslator) is pure Python and has no FFI of its own; the
+ * arithmetic this library replaces lives in third-party wheels called from:
+ *   - upscaler   model(tensor)                core/image/image_utils.py:369-374
+ *   - YOLO       model(img, conf=, imgsz=..)  core/image/detection.py:1337-1345
+ *   - SAM-2.1    sam_model(**inputs)          core/image/detection.py:494-509
+ *   - FLUX       pipeline(**kw).images[0]     core/image/inpainting.py:877-887, 1577-1589
+ * Each network is a static graph ("plan") of the ops below, built once per input shape by the
+ * Python host (mangatranslator_amd/hip/plan.py) and executed here with no Python in the loop.
+ *
+ * Conventions:
+ *   - every entry point returns 0 on success, a negative mtx_status otherwise; nothing throws
+ *     across the ABI; mtx_last_error() gives a thread-local message.
+ *   - all pointers are DEVICE pointers owned by the caller (torch tensor .data_ptr());
+ *     the library never allocates activation memory and never synchronises a stream.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - activations are channels-last: [N, H, W, C] with an explicit per-pixel stride in
+ *     elements ("ld"), so a channel slice of a wider buffer is a valid operand (concat is free).
+ *   - 16-bit element types: MTX_BF16 / MTX_F16; accumulation is always fp32.
+ */
+#ifndef MTX_HIP_H
+#define MTX_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MTX_API __attribute__((visibility("default")))
+#else
+#define MTX_API
+#endif
+
+#define MTX_ABI_VERSION 1
+
+typedef enum mtx_status {
+  MTX_OK = 0,
+  MTX_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  MTX_ERR_HIP = -2,       /* a HIP runtime call failed */
+  MTX_ERR_UNSUPPORTED = -3,
+  MTX_ERR_STATE = -4
+} mtx_status;
+
+typedef enum mtx_dtype { MTX_BF16 = 0, MTX_F16 = 1, MTX_F32 = 2, MTX_U8 = 3, MTX_I32 = 4 } mtx_dtype;
+
+typedef enum mtx_act {
+  MTX_ACT_NONE = 0, MTX_ACT_RELU = 1, MTX_ACT_SILU = 2, MTX_ACT_GELU = 3 /* erf */,
+  MTX_ACT_GELU_TANH = 4, MTX_ACT_SIGMOID = 5, MTX_ACT_LEAKY = 6 /* slope = act_param */
+} mtx_act;
+
+/* ---- op argument blocks (plain data; mirrored 1:1 by ctypes in hip/abi.py) ------------- */
+
+/* 2-D convolution, NHWC, implicit GEMM on MFMA, LDS halo tile.  ksize 1 or 3, stride 1 or 2,
+ * pad = ksize/2.  w is packed [Cout][ksize*ksize][Cin] (tap-major, channel-contiguous).
+ *   y = act(conv(x) + bias) [+ res_scale * res]
+ * pixel_shuffle = r (0 or 2): output channel (dy*r+dx)*Cout/r^2 + c is stored at
+ *   y[n, oy*r+dy, ox*r+dx, c]  (the caller permutes torch-order channels c*r^2+dy*r+dx at pack
+ *   time) — ldy/ldres then describe the shuffled tensor.
+ * chan_sum (optional, fp32 [N][tiles][Cout]): per-tile sums of the activated output (before
+ *   the residual) for a fused global average pool; tiles = mtx_conv2d_tiles().            */
+typedef struct mtx_conv2d_args {
+  const void* x; const void* w; const float* bias; const void* res; void* y; float* chan_sum;
+  int32_t n, h, w_in, cin, cout;
+  int32_t ksize, stride;
+  int32_t ldx, ldy, ldres;       /* per-pixel strides in elements */
+  int32_t act; float act_param; float res_scale;
+  int32_t pixel_shuffle;
+  int32_t dtype;
+} mtx_conv2d_args;
+
+/* C[M,N] = epilogue(A[M,K] * W[N,K]^T)   A row stride lda, C row stride ldc (elements).
+ *   v = acc + bias[n];  v = act(v);  v = v * (gate ? gate[gate_row(m), n] : 1) ;
+ *   v += res ? res[m, n] : 0
+ * gate rows: gate_row(m) = m / gate_rows_per (broadcast a per-sample modulation vector).
+ * batch > 1: strided batched GEMM (a/w/c advance by *_bstride elements).                    */
+typedef struct mtx_gemm_args {
+  const void* a; const void* w; const float* bias; const void* res; const void* gate; void* c;
+  int64_t m, n, k;
+  int64_t lda, ldw, ldc, ldres, ldgate;
+  int64_t batch, a_bstride, w_bstride, c_bstride;
+  int32_t gate_rows_per;
+  int32_t act; float act_param; float alpha;   /* acc *= alpha before bias */
+  int32_t dtype; int32_t out_dtype;            /* out_dtype: MTX_BF16/F16 (=dtype) or MTX_F32 */
+} mtx_gemm_args;
+
+/* softmax(scale * Q K^T) V, non-causal, one launch for [batch, heads].
+ * q: [batch, sq, heads, d] with strides; k,v: [batch, sk, heads, d]; o like q.
+ * Strides in elements: *_bs (batch), *_ss (sequence), *_hs (head). d <= 128, d % 8 == 0. */
+typedef struct mtx_attn_args {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t batch, heads, sq, sk, d;
+  int64_t q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
+  float scale;
+  int32_t dtype;
+} mtx_attn_args;
+
+/* row-wise normalisation over the last dim C of [rows, C] (row stride ld):
+ *  kind 0 LayerNorm (gamma,beta optional), 1 RMSNorm (gamma optional).
+ *  optional adaLN modulation: y = norm(x) * (1 + scale[r/rows_per, :]) + shift[r/rows_per, :] */
+typedef struct mtx_norm_args {
+  const void* x; void* y; const float* gamma; const float* beta;
+  const void* mod_scale; const void* mod_shift;
+  int64_t rows, c, ldx, ldy, rows_per, ldmod;
+  float eps; int32_t kind; int32_t dtype;
+} mtx_norm_args;
+
+/* GroupNorm over NHWC [N, HW, C] with G groups, optional fused SiLU. */
+typedef struct mtx_groupnorm_args {
+  const void* x; void* y; const float* gamma; const float* beta; float* workspace; /* fp32 [N*C*2 + N*G*2] */
+  int64_t n, hw, c, groups; float eps; int32_t act; int32_t dtype;
+} mtx_groupnorm_args;
+
+/* generic element-wise / data-movement ops on NHWC tensors (kind = mtx_ew_kind). */
+typedef enum mtx_ew_kind {
+  MTX_EW_SCALE_RES = 0,   /* y = a * s[n, c] + b        (RCAN channel attention + skip)      */
+  MTX_EW_ADD = 1,         /* y = a + b                                                        */
+  MTX_EW_MUL = 2,         /* y = a * b                                                        */
+  MTX_EW_ACT = 3,         /* y = act(a)                                                       */
+  MTX_EW_UPSAMPLE2X = 4,  /* nearest 2x: y[n, 2h+i, 2w+j, c] = a[n, h, w, c] (+ b if given)  */
+  MTX_EW_MAXPOOL = 5,     /* k x k, stride s, pad k/2 (i0 = k, i1 = s)                        */
+  MTX_EW_COPY = 6,        /* strided channel-slice copy                                       */
+  MTX_EW_GATE_RES = 7     /* y = b + a * g[row / rows_per, c]   (DiT gated residual)         */
+} mtx_ew_kind;
+
+typedef struct mtx_ew_args {
+  const void* a; const void* b; const void* s; void* y;
+  int64_t n, h, w, c;          /* logical INPUT dims (h*w = rows per sample) */
+  int64_t lda, ldb, ldy, lds;  /* per-pixel strides; lds = per-sample stride of s */
+  int32_t kind; int32_t act; float act_param; int32_t i0, i1; int32_t dtype;
+} mtx_ew_args;
+
+/* RCAN channel attention squeeze/excite: s[n, c] = sigmoid(W2 relu(W1 mean + b1) + b2),
+ * mean = sum over tiles of chan_sum / hw. w1: [Cr][C] fp32, w2: [C][Cr] fp32.            */
+typedef struct mtx_ca_args {
+  const float* chan_sum; const float* w1; const float* b1; const float* w2; const float* b2;
+  float* s; int32_t n, tiles, c, cr; float inv_hw;
+} mtx_ca_args;
+
+/* image <-> tensor conversions at the page boundary (core/image/image_utils.py:351-366). */
+typedef enum mtx_img_kind {
+  MTX_IMG_NCHW_F32_TO_NHWC = 0, /* [N,3,H,W] f32 -> [N,H/u,W/u,Cpad] T, x*mul + add[c], u = unshuffle */
+  MTX_IMG_NHWC_TO_NCHW_F32 = 1, /* [N,H,W,ld] T (first 3 ch) -> [N,3,H,W] f32, x*mul + add[c]     */
+  MTX_IMG_NHWC_TO_HWC_U8 = 2,   /* clamp(x*mul+add,0,1)*255 truncated -> uint8 [N,H,W,3]           */
+  MTX_IMG_HWC_U8_TO_NHWC = 3    /* uint8 [N,H,W,3] -> T  (x/255*mul + add[c])                      */
+} mtx_img_kind;
+
+typedef struct mtx_img_args {
+  const void* src; void* dst;
+  int64_t n, h, w;        /* source spatial dims */
+  int32_t c_pad;          /* channels of the NHWC side (ld) */
+  int32_t unshuffle;      /* 1 or 2 (pixel-unshuffle factor folded into the layout change) */
+  float mul; float add[4];
+  int32_t kind; int32_t dtype;
+} mtx_img_args;
+
+/* bilinear resize of fp32/T logits to page size fused with the >0 threshold
+ * (HF Sam2ImageProcessor.post_process_masks, called at core/image/detection.py:507-510). */
+typedef struct mtx_resize_thresh_args {
+  const void* src; uint8_t* dst;    /* src [N, hs, ws] ; dst [N, hd, wd] 0/1 */
+  int64_t n, hs, ws, hd, wd; float thresh; int32_t dtype;
+} mtx_resize_thresh_args;
+
+typedef enum mtx_op_kind {
+  MTX_OP_CONV2D = 1, MTX_OP_GEMM = 2, MTX_OP_ATTN = 3, MTX_OP_NORM = 4, MTX_OP_GROUPNORM = 5,
+  MTX_OP_EW = 6, MTX_OP_CA = 7, MTX_OP_IMG = 8, MTX_OP_RESIZE_THRESH = 9, MTX_OP_MEMSET = 10
+} mtx_op_kind;
+
+typedef struct mtx_memset_args { void* ptr; int64_t bytes; int32_t value; } mtx_memset_args;
+
+typedef struct mtx_op {
+  int32_t kind; int32_t reserved;
+  union {
+    mtx_conv2d_args conv; mtx_gemm_args gemm; mtx_attn_args attn; mtx_norm_args norm;
+    mtx_groupnorm_args gn; mtx_ew_args ew; mtx_ca_args ca; mtx_img_args img;
+    mtx_resize_thresh_args rt; mtx_memset_args ms;
+  } u;
+} mtx_op;
+
+/* ---- library ---------------------------------------------------------------------------- */
+MTX_API int mtx_abi_version(void);
+MTX_API size_t mtx_abi_sizeof(int op_kind);          /* sizeof the args struct; 0 = sizeof(mtx_op) */
+MTX_API const char* mtx_last_error(void);
+MTX_API int mtx_init(int device_ordinal);            /* hipSetDevice + arch check (gfx950) */
+MTX_API int mtx_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ---- op-level entry points (tests, and the building blocks of plans) --------------------- */
+MTX_API int mtx_conv2d(const mtx_conv2d_args* a, void* stream);
+MTX_API int mtx_conv2d_tiles(const mtx_conv2d_args* a);   /* spatial tiles per image (chan_sum rows) */
+MTX_API int mtx_gemm(const mtx_gemm_args* a, void* stream);
+MTX_API int mtx_attention(const mtx_attn_args* a, void* stream);
+MTX_API int mtx_norm(const mtx_norm_args* a, void* stream);
+MTX_API int mtx_groupnorm(const mtx_groupnorm_args* a, void* stream);
+MTX_API int mtx_elementwise(const mtx_ew_args* a, void* stream);
+MTX_API int mtx_channel_attention(const mtx_ca_args* a, void* stream);
+MTX_API int mtx_image_convert(const mtx_img_args* a, void* stream);
+MTX_API int mtx_resize_threshold(const mtx_resize_thresh_args* a, void* stream);
+
+/* ---- plans: a network forward as one native call ----------------------------------------- */
+MTX_API int mtx_plan_create(const mtx_op* ops, int n_ops, void** plan);
+MTX_API int mtx_plan_run(void* plan, void* stream);            /* eager launch of every op, in order */
+MTX_API int mtx_plan_run_graph(void* plan, void* stream);      /* hipGraph replay (captured on first use) */
+MTX_API int mtx_plan_num_ops(void* plan);
+MTX_API int mtx_plan_run_range(void* plan, int first, int last, void* stream);  /* debugging / parity */
+MTX_API void mtx_plan_destroy(void* plan);
+
+/* HIP-event timing helper for bench.py: records events on `stream` around plan replays
+ * and returns the average milliseconds per replay (synchronises the stream).               */
+MTX_API int mtx_plan_time(void* plan, void* stream, int iters, int use_graph, float* ms_per_iter);
+/* time only ops [first,last] of a plan: avg ms over iters (events on `stream`)              */
+MTX_API int mtx_plan_time_range(void* plan, int first, int last, void* stream, int iters, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTX_HIP_H */

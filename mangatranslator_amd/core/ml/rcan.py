@@ -1,0 +1,246 @@
+"""2x-AnimeSharpV4 (RCAN) upscaler on libmtx_hip — the model object `ModelManager.load_upscale*`
+returns (reference core/ml/model_manager.py:617-700 builds it with spandrel; the operator calls
+`model(tensor[1,3,H,W] fp32 0..1)`, reference core/image/image_utils.py:369-374).
+
+Architecture hyper-parameters come from the checkpoint's tensor shapes (as an auto-detecting
+loader does); weights are repacked ONCE at load into the kernels' layout:
+  conv weights [Cout][3x3 taps][Cin] f16 (Cin padded to 8), the pixel-shuffle convs with their
+  output channels permuted to (dy, dx, c) so PixelShuffle(2) is pure store addressing.
+A forward pass is one native `mtx_plan_run` of a static graph per input shape:
+
+  img(NCHW f32 -> NHWC f16, *rgb_range, -mean, pixel-unshuffle) -> head conv
+  per RCAB: conv+ReLU -> conv (+ per-tile channel sums fused) -> squeeze/excite MLP -> scale+skip
+  group/long skips fused into the conv epilogues -> upsampler conv(s) with fused pixel shuffle
+  -> tail conv -> img(NHWC -> NCHW f32, /rgb_range, +mean)
+
+fp16 storage / fp32 MFMA accumulation: the trunk of a 400-conv residual network loses ~1e-3
+relative accuracy per rounding with bf16 (8-bit mantissa), which does not hold PSNR >= 40 dB;
+fp16's 11-bit mantissa does, and activations are O(rgb_range) so its range suffices
+(saturating converts guard outliers).
+"""
+import math
+import re
+import threading
+
+import torch
+
+from ...hip import abi
+from ...hip.lib import get_library
+from ...hip.plan import PlanBuilder
+from ...utils.exceptions import ModelError
+
+
+def derive_rcan_hparams(sd: dict) -> dict:
+    """Architecture from tensor shapes (state-dict key layout of the EDSR-style RCAN)."""
+    try:
+        n_feats, in_ch = sd["head.0.weight"].shape[:2]
+        gb = {}
+        for k in sd:
+            m = re.match(r"body\.(\d+)\.body\.(\d+)\.", k)
+            if m:
+                g, b = int(m.group(1)), int(m.group(2))
+                gb[g] = max(gb.get(g, -1), b)
+        n_resgroups = len(gb)
+        n_resblocks = gb[0]
+        cr = sd["body.0.body.0.body.3.conv_du.0.weight"].shape[0]
+        up_keys = sorted(int(m.group(1)) for k in sd for m in [re.match(r"tail\.0\.(\d+)\.weight$", k)] if m)
+        n_colors = sd["tail.1.weight"].shape[0]
+    except KeyError as e:
+        raise ModelError(f"not an RCAN checkpoint (missing {e})") from e
+    ups = []
+    for u in up_keys:
+        ratio = sd[f"tail.0.{u}.weight"].shape[0] // n_feats
+        if ratio != 4:
+            raise ModelError(f"RCAN upsampler stage tail.0.{u} has factor^2={ratio}; only PixelShuffle(2) stages are built")
+        ups.append(u)
+    if n_colors != 3:
+        raise ModelError("RCAN: only 3-colour models are supported")
+    unshuffle = int(round(math.sqrt(in_ch // n_colors)))
+    if unshuffle not in (1, 2) or unshuffle * unshuffle * n_colors != in_ch:
+        raise ModelError(f"RCAN: unsupported head input channels {in_ch}")
+    if n_feats % 8:
+        raise ModelError("RCAN: n_feats must be a multiple of 8")
+    return dict(n_feats=int(n_feats), n_resgroups=n_resgroups, n_resblocks=n_resblocks, cr=int(cr),
+                up_keys=ups, unshuffle=unshuffle, scale=(2 ** len(ups)) // unshuffle,
+                mean_shift=("sub_mean.weight" in sd))
+
+
+def pack_conv3x3(w: torch.Tensor, dtype, shuffle: bool = False, cout_pad: int = 0) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> [Cout'][9][Cin8] (tap-major, channel-contiguous)."""
+    co, ci, kh, kw = w.shape
+    if shuffle:  # torch PixelShuffle(2) reads channel c*4 + dy*2 + dx; we emit (dy*2+dx)*C + c
+        c = co // 4
+        w = w.view(c, 4, ci, kh, kw).permute(1, 0, 2, 3, 4).reshape(co, ci, kh, kw)
+    ci8 = (ci + 7) // 8 * 8
+    co_p = max(co, cout_pad)
+    out = torch.zeros(co_p, kh * kw, ci8, dtype=torch.float32)
+    out[:co, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+    return out.to(dtype).contiguous()
+
+
+def pack_bias(b: torch.Tensor, shuffle: bool = False, cout_pad: int = 0) -> torch.Tensor:
+    if shuffle:
+        c = b.shape[0] // 4
+        b = b.view(c, 4).t().reshape(-1)
+    out = torch.zeros(max(b.shape[0], cout_pad), dtype=torch.float32)
+    out[:b.shape[0]] = b.float()
+    return out
+
+
+class RCANUpscaler:
+    """Callable like the spandrel model descriptor: `model(tensor[N,3,H,W] f32) -> [N,3,sH,sW] f32`.
+    Thread-safe (up to 20 reference worker threads share one instance)."""
+
+    def __init__(self, state_dict: dict, device="cuda", rgb_range: float = 255.0, lib=None, graph: bool = True):
+        self.lib = lib if lib is not None else get_library()
+        self.device = torch.device(device)
+        self.hp = derive_rcan_hparams(state_dict)
+        self.scale = self.hp["scale"]
+        self.rgb_range = float(rgb_range)
+        self.dtype = abi.F16
+        self._tdt = torch.float16
+        self._graph = graph and not self.lib.is_simulator
+        self._lock = threading.Lock()
+        self._plans = {}
+        self._pack(state_dict)
+
+    # ---- weights ----------------------------------------------------------------------------
+    def _pack(self, sd):
+        dev, dt, hp = self.device, self._tdt, self.hp
+        f = lambda t: t.detach().float().cpu()
+        W = {}
+
+        def conv(name, key, shuffle=False, cout_pad=0):
+            W[name] = (pack_conv3x3(f(sd[key + ".weight"]), dt, shuffle, cout_pad).to(dev),
+                       pack_bias(f(sd[key + ".bias"]), shuffle, cout_pad).to(dev) if key + ".bias" in sd
+                       else torch.zeros(max(sd[key + ".weight"].shape[0], cout_pad), device=dev))
+
+        conv("head", "head.0")
+        for g in range(hp["n_resgroups"]):
+            for b in range(hp["n_resblocks"]):
+                p = f"body.{g}.body.{b}.body"
+                conv(f"g{g}b{b}c1", p + ".0")
+                conv(f"g{g}b{b}c2", p + ".2")
+                W[f"g{g}b{b}ca"] = tuple(f(sd[p + k]).reshape(s).contiguous().to(dev) for k, s in (
+                    (".3.conv_du.0.weight", (hp["cr"], hp["n_feats"])), (".3.conv_du.0.bias", (hp["cr"],)),
+                    (".3.conv_du.2.weight", (hp["n_feats"], hp["cr"])), (".3.conv_du.2.bias", (hp["n_feats"],))))
+            conv(f"g{g}tail", f"body.{g}.body.{hp['n_resblocks']}")
+        conv("body_tail", f"body.{hp['n_resgroups']}")
+        for i, u in enumerate(hp["up_keys"]):
+            conv(f"up{i}", f"tail.0.{u}", shuffle=True)
+        conv("tail", "tail.1", cout_pad=8)
+        self.W = W
+        self.mean = [0.0, 0.0, 0.0]
+        if hp["mean_shift"]:
+            wsub, wadd = f(sd["sub_mean.weight"]).view(3, 3), f(sd["add_mean.weight"]).view(3, 3)
+            if not (torch.allclose(wsub, torch.eye(3)) and torch.allclose(wadd, torch.eye(3))):
+                raise ModelError("RCAN: MeanShift with non-identity weight is not supported")
+            self.sub_bias = [float(v) for v in f(sd["sub_mean.bias"])]
+            self.add_bias = [float(v) for v in f(sd["add_mean.bias"])]
+        else:
+            self.sub_bias = [0.0, 0.0, 0.0]
+            self.add_bias = [0.0, 0.0, 0.0]
+
+    # ---- graph ------------------------------------------------------------------------------
+    def _build(self, n, h, w):
+        hp, W = self.hp, self.W
+        u = hp["unshuffle"]
+        if h % u or w % u:
+            raise ModelError(f"RCAN(PU): image {w}x{h} must be divisible by {u}")
+        pb = PlanBuilder(self.lib, self.device, self.dtype)
+        C_ = hp["n_feats"]
+        x_in = pb.buf((n, 3, h, w), torch.float32)
+        cin_pad = (3 * u * u + 7) // 8 * 8
+        hh, ww = h // u, w // u
+        a0 = pb.act(n, hh, ww, cin_pad)
+        pb.image_convert(abi.IMG_NCHW_F32_TO_NHWC, x_in, a0.t, n, h, w, cin_pad, unshuffle=u,
+                         mul=self.rgb_range, add=self.sub_bias, label="to_nhwc")
+        head = pb.conv2d(a0, *W["head"], cout=C_, label="head")
+        tiles = pb.conv_tiles(head)
+        chan_sum = pb.buf((n, tiles, C_), torch.float32)
+        s_buf = pb.buf((n, C_), torch.float32)
+        t1 = pb.act(n, hh, ww, C_)
+        t2 = pb.act(n, hh, ww, C_)
+        ping = [pb.act(n, hh, ww, C_) for _ in range(3)]
+        cur = head
+        inv_hw = 1.0 / float(hh * ww)
+        pi = 0
+
+        def next_buf(avoid):
+            nonlocal pi
+            for _ in range(3):
+                cand = ping[pi % 3]
+                pi += 1
+                if all(cand.t is not a.t for a in avoid):
+                    return cand
+            raise AssertionError
+
+        for g in range(hp["n_resgroups"]):
+            gin = cur
+            for b in range(hp["n_resblocks"]):
+                pb.conv2d(cur, *W[f"g{g}b{b}c1"], cout=C_, act=abi.ACT_RELU, out=t1, label=f"g{g}b{b}.conv1")
+                pb.conv2d(t1, *W[f"g{g}b{b}c2"], cout=C_, out=t2, chan_sum=chan_sum, label=f"g{g}b{b}.conv2")
+                w1, b1, w2, b2 = W[f"g{g}b{b}ca"]
+                pb.channel_attention(chan_sum, w1, b1, w2, b2, s_buf, n, tiles, C_, hp["cr"], inv_hw, label=f"g{g}b{b}.ca")
+                nxt = next_buf([cur, gin, head])
+                pb.ew(abi.EW_SCALE_RES, t2, b=cur, s=s_buf, out=nxt, lds=C_, label=f"g{g}b{b}.scale_skip")
+                cur = nxt
+            nxt = next_buf([cur, gin, head])
+            pb.conv2d(cur, *W[f"g{g}tail"], cout=C_, res=gin, out=nxt, label=f"g{g}.tail")
+            cur = nxt
+        body = pb.conv2d(cur, *W["body_tail"], cout=C_, res=head, out=t1, label="body_tail")
+        up = body
+        for i in range(len(hp["up_keys"])):
+            up = pb.conv2d(up, *W[f"up{i}"], cout=4 * C_, pixel_shuffle=2, label=f"up{i}")
+        y8 = pb.conv2d(up, *W["tail"], cout=8, label="tail")
+        oh, ow = up.h, up.w
+        y_out = pb.buf((n, 3, oh, ow), torch.float32)
+        inv = 1.0 / self.rgb_range
+        pb.image_convert(abi.IMG_NHWC_TO_NCHW_F32, y8.t, y_out, n, oh, ow, 8, mul=inv,
+                         add=[v * inv for v in self.add_bias], label="to_nchw")
+        y_u8 = pb.buf((n, oh, ow, 3), torch.uint8)
+        plan = pb.build()
+        plan.x_in, plan.y_out, plan.y8, plan.y_u8 = x_in, y_out, y8, y_u8
+        plan.out_scale = (inv, [v * inv for v in self.add_bias])
+        return plan
+
+    def plan_for(self, n, h, w):
+        key = (n, h, w)
+        with self._lock:
+            if key not in self._plans:
+                self._plans[key] = self._build(n, h, w)
+            return self._plans[key]
+
+    # ---- the spandrel-model call shape -----------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ModelError(f"RCAN expects [N,3,H,W], got {tuple(x.shape)}")
+        n, _, h, w = x.shape
+        plan = self.plan_for(n, h, w)
+        with self._lock:
+            plan.x_in.copy_(x.to(device=self.device, dtype=torch.float32))
+            plan.run(graph=self._graph)
+            return plan.y_out.clone()
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    # FLOPs / algorithmic bytes of one forward, printed next to roofline numbers
+    def work(self, h, w):
+        hp = self.hp
+        u = hp["unshuffle"]
+        px = (h // u) * (w // u)
+        C_ = hp["n_feats"]
+        conv = 2 * 9 * C_ * C_ * px
+        n_body = hp["n_resgroups"] * (2 * hp["n_resblocks"] + 1) + 1
+        flops = 2 * 9 * (3 * u * u) * C_ * px + n_body * conv
+        p = px
+        for _ in hp["up_keys"]:
+            flops += 2 * 9 * C_ * 4 * C_ * p
+            p *= 4
+        flops += 2 * 9 * C_ * 3 * p
+        return dict(flops=flops, conv64_flops=conv, conv64_bytes=2 * C_ * px * 2 + 9 * C_ * C_ * 2, n_conv64=n_body)

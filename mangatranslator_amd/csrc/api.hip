@@ -1,0 +1,268 @@
+// api.hip — the extern "C" surface of libmtx_hip.so (include/mtx_hip.h) and the plan executor.
+//
+// A plan is the reference's "model object" seen from below: the Python host mirrors
+// ModelManager.load_* (core/ml/model_manager.py:617-1337), builds the op list of one network for
+// one input shape, and from then on a forward pass is ONE native call that launches the whole
+// static graph on the caller's stream (optionally replayed as a hipGraph).
+#include "mtx_device.h"
+#include <string>
+#include <cstring>
+#include <vector>
+#include <new>
+
+namespace mtx {
+int conv2d_launch(const mtx_conv2d_args*, void*, const char**);
+int conv2d_tiles(const mtx_conv2d_args*);
+int gemm_launch(const mtx_gemm_args*, void*, const char**);
+int attn_launch(const mtx_attn_args*, void*, const char**);
+int norm_launch(const mtx_norm_args*, void*, const char**);
+int groupnorm_launch(const mtx_groupnorm_args*, void*, const char**);
+int ew_launch(const mtx_ew_args*, void*, const char**);
+int ca_launch(const mtx_ca_args*, void*, const char**);
+int img_launch(const mtx_img_args*, void*, const char**);
+int resize_thresh_launch(const mtx_resize_thresh_args*, void*, const char**);
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* what) {
+  g_err = what ? what : "unknown error";
+  return code;
+}
+
+static int check_launch(int rc, const char* err) {
+  if (rc != MTX_OK) return fail(rc, err);
+#ifndef MTX_EMU
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_err = std::string("HIP launch failed: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+#endif
+  return MTX_OK;
+}
+
+struct Plan {
+  std::vector<mtx_op> ops;
+#ifndef MTX_EMU
+  hipGraphExec_t exec = nullptr;
+  hipGraph_t graph = nullptr;
+#endif
+};
+
+static int run_op(const mtx_op& op, void* stream) {
+  const char* err = nullptr;
+  int rc;
+  switch (op.kind) {
+    case MTX_OP_CONV2D: rc = conv2d_launch(&op.u.conv, stream, &err); break;
+    case MTX_OP_GEMM: rc = gemm_launch(&op.u.gemm, stream, &err); break;
+    case MTX_OP_ATTN: rc = attn_launch(&op.u.attn, stream, &err); break;
+    case MTX_OP_NORM: rc = norm_launch(&op.u.norm, stream, &err); break;
+    case MTX_OP_GROUPNORM: rc = groupnorm_launch(&op.u.gn, stream, &err); break;
+    case MTX_OP_EW: rc = ew_launch(&op.u.ew, stream, &err); break;
+    case MTX_OP_CA: rc = ca_launch(&op.u.ca, stream, &err); break;
+    case MTX_OP_IMG: rc = img_launch(&op.u.img, stream, &err); break;
+    case MTX_OP_RESIZE_THRESH: rc = resize_thresh_launch(&op.u.rt, stream, &err); break;
+    case MTX_OP_MEMSET:
+      if (hipMemsetAsync(op.u.ms.ptr, op.u.ms.value, (size_t)op.u.ms.bytes, (hipStream_t)stream) != hipSuccess) { rc = MTX_ERR_HIP; err = "memset failed"; }
+      else rc = MTX_OK;
+      break;
+    default: rc = MTX_ERR_INVALID; err = "unknown op kind"; break;
+  }
+  return check_launch(rc, err);
+}
+
+}  // namespace mtx
+
+using namespace mtx;
+
+extern "C" {
+
+int mtx_abi_version(void) { return MTX_ABI_VERSION; }
+
+size_t mtx_abi_sizeof(int kind) {
+  switch (kind) {
+    case 0: return sizeof(mtx_op);
+    case MTX_OP_CONV2D: return sizeof(mtx_conv2d_args);
+    case MTX_OP_GEMM: return sizeof(mtx_gemm_args);
+    case MTX_OP_ATTN: return sizeof(mtx_attn_args);
+    case MTX_OP_NORM: return sizeof(mtx_norm_args);
+    case MTX_OP_GROUPNORM: return sizeof(mtx_groupnorm_args);
+    case MTX_OP_EW: return sizeof(mtx_ew_args);
+    case MTX_OP_CA: return sizeof(mtx_ca_args);
+    case MTX_OP_IMG: return sizeof(mtx_img_args);
+    case MTX_OP_RESIZE_THRESH: return sizeof(mtx_resize_thresh_args);
+    case MTX_OP_MEMSET: return sizeof(mtx_memset_args);
+    default: return 0;
+  }
+}
+
+const char* mtx_last_error(void) { return g_err.c_str(); }
+
+int mtx_init(int device_ordinal) {
+#ifndef MTX_EMU
+  hipError_t e = hipSetDevice(device_ordinal);
+  if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_ordinal);
+  if (e != hipSuccess) { g_err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    g_err = std::string("libmtx_hip is built for gfx950 only; device is ") + prop.gcnArchName;
+    return MTX_ERR_UNSUPPORTED;
+  }
+#else
+  (void)device_ordinal;
+#endif
+  return MTX_OK;
+}
+
+int mtx_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len) {
+#ifndef MTX_EMU
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(MTX_ERR_HIP, "hipGetDevice failed");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(MTX_ERR_HIP, "hipGetDeviceProperties failed");
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (lds_bytes) *lds_bytes = (int)prop.sharedMemPerBlock;
+  if (arch && arch_len > 0) { strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
+#else
+  if (cu_count) *cu_count = 0;
+  if (lds_bytes) *lds_bytes = 0;
+  if (arch && arch_len > 0) { strncpy(arch, "emu", (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
+#endif
+  return MTX_OK;
+}
+
+#define MTX_OP_ENTRY(name, type, fn)                                     \
+  int name(const type* a, void* stream) {                                \
+    if (!a) return fail(MTX_ERR_INVALID, #name ": null args");           \
+    const char* err = nullptr;                                           \
+    return check_launch(fn(a, stream, &err), err);                       \
+  }
+MTX_OP_ENTRY(mtx_conv2d, mtx_conv2d_args, conv2d_launch)
+MTX_OP_ENTRY(mtx_gemm, mtx_gemm_args, gemm_launch)
+MTX_OP_ENTRY(mtx_attention, mtx_attn_args, attn_launch)
+MTX_OP_ENTRY(mtx_norm, mtx_norm_args, norm_launch)
+MTX_OP_ENTRY(mtx_groupnorm, mtx_groupnorm_args, groupnorm_launch)
+MTX_OP_ENTRY(mtx_elementwise, mtx_ew_args, ew_launch)
+MTX_OP_ENTRY(mtx_channel_attention, mtx_ca_args, ca_launch)
+MTX_OP_ENTRY(mtx_image_convert, mtx_img_args, img_launch)
+MTX_OP_ENTRY(mtx_resize_threshold, mtx_resize_thresh_args, resize_thresh_launch)
+
+int mtx_conv2d_tiles(const mtx_conv2d_args* a) {
+  if (!a) return fail(MTX_ERR_INVALID, "mtx_conv2d_tiles: null args");
+  int t = conv2d_tiles(a);
+  if (t < 0) return fail(MTX_ERR_UNSUPPORTED, "mtx_conv2d_tiles: unsupported kernel/stride");
+  return t;
+}
+
+int mtx_plan_create(const mtx_op* ops, int n_ops, void** plan) {
+  if (!ops || n_ops < 0 || !plan) return fail(MTX_ERR_INVALID, "mtx_plan_create: bad arguments");
+  Plan* p = new (std::nothrow) Plan();
+  if (!p) return fail(MTX_ERR_STATE, "mtx_plan_create: out of memory");
+  p->ops.assign(ops, ops + n_ops);
+  *plan = p;
+  return MTX_OK;
+}
+
+int mtx_plan_num_ops(void* plan) { return plan ? (int)static_cast<Plan*>(plan)->ops.size() : MTX_ERR_INVALID; }
+
+int mtx_plan_run_range(void* plan, int first, int last, void* stream) {
+  if (!plan) return fail(MTX_ERR_INVALID, "mtx_plan_run_range: null plan");
+  Plan* p = static_cast<Plan*>(plan);
+  if (first < 0) first = 0;
+  if (last >= (int)p->ops.size()) last = (int)p->ops.size() - 1;
+  for (int i = first; i <= last; ++i) {
+    int rc = run_op(p->ops[(size_t)i], stream);
+    if (rc != MTX_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
+  }
+  return MTX_OK;
+}
+
+int mtx_plan_run(void* plan, void* stream) {
+  if (!plan) return fail(MTX_ERR_INVALID, "mtx_plan_run: null plan");
+  return mtx_plan_run_range(plan, 0, (int)static_cast<Plan*>(plan)->ops.size() - 1, stream);
+}
+
+int mtx_plan_run_graph(void* plan, void* stream) {
+  if (!plan) return fail(MTX_ERR_INVALID, "mtx_plan_run_graph: null plan");
+#ifdef MTX_EMU
+  return mtx_plan_run(plan, stream);
+#else
+  Plan* p = static_cast<Plan*>(plan);
+  hipStream_t s = (hipStream_t)stream;
+  if (!p->exec) {
+    if (s == nullptr) return fail(MTX_ERR_INVALID, "mtx_plan_run_graph: capture needs a non-default stream");
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { g_err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+    int rc = mtx_plan_run(plan, stream);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(s, &g);
+    if (rc != MTX_OK) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) { g_err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+    e = hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { hipGraphDestroy(g); g_err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+    p->graph = g;
+  }
+  hipError_t e = hipGraphLaunch(p->exec, s);
+  if (e != hipSuccess) { g_err = std::string("hipGraphLaunch: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+  return MTX_OK;
+#endif
+}
+
+void mtx_plan_destroy(void* plan) {
+  if (!plan) return;
+  Plan* p = static_cast<Plan*>(plan);
+#ifndef MTX_EMU
+  if (p->exec) hipGraphExecDestroy(p->exec);
+  if (p->graph) hipGraphDestroy(p->graph);
+#endif
+  delete p;
+}
+
+int mtx_plan_time_range(void* plan, int first, int last, void* stream, int iters, float* ms) {
+  if (!plan || !ms || iters < 1) return fail(MTX_ERR_INVALID, "mtx_plan_time_range: bad arguments");
+#ifdef MTX_EMU
+  for (int i = 0; i < iters; ++i) { int rc = mtx_plan_run_range(plan, first, last, stream); if (rc) return rc; }
+  *ms = 0.f;
+  return MTX_OK;
+#else
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MTX_ERR_HIP, "hipEventCreate failed");
+  int rc = MTX_OK;
+  hipEventRecord(e0, s);
+  for (int i = 0; i < iters && rc == MTX_OK; ++i) rc = mtx_plan_run_range(plan, first, last, stream);
+  hipEventRecord(e1, s);
+  hipError_t e = hipEventSynchronize(e1);
+  float t = 0.f;
+  if (rc == MTX_OK && e == hipSuccess) { hipEventElapsedTime(&t, e0, e1); *ms = t / (float)iters; }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc != MTX_OK) return rc;
+  if (e != hipSuccess) { g_err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+  return MTX_OK;
+#endif
+}
+
+int mtx_plan_time(void* plan, void* stream, int iters, int use_graph, float* ms_per_iter) {
+  if (!plan || !ms_per_iter || iters < 1) return fail(MTX_ERR_INVALID, "mtx_plan_time: bad arguments");
+#ifdef MTX_EMU
+  (void)use_graph;
+  return mtx_plan_time_range(plan, 0, 1 << 30, stream, iters, ms_per_iter);
+#else
+  if (!use_graph) return mtx_plan_time_range(plan, 0, 1 << 30, stream, iters, ms_per_iter);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = mtx_plan_run_graph(plan, stream);   // capture + first replay, untimed
+  if (rc != MTX_OK) return rc;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MTX_ERR_HIP, "hipEventCreate failed");
+  hipEventRecord(e0, s);
+  for (int i = 0; i < iters && rc == MTX_OK; ++i) rc = mtx_plan_run_graph(plan, stream);
+  hipEventRecord(e1, s);
+  hipError_t e = hipEventSynchronize(e1);
+  float t = 0.f;
+  if (rc == MTX_OK && e == hipSuccess) { hipEventElapsedTime(&t, e0, e1); *ms_per_iter = t / (float)iters; }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc != MTX_OK) return rc;
+  if (e != hipSuccess) { g_err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return MTX_ERR_HIP; }
+  return MTX_OK;
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// attention.hip — fused softmax(scale * Q K^T) V on the gfx950 matrix cores (flash-style,
+// online softmax, nothing of size sq x sk ever reaches HBM).
+//
+// Serves the windowed / global / query-pooled attention of SAM-2.1's Hiera encoder and the
+// two-way mask decoder (transformers Sam2Model, core/image/detection.py:505) and the joint
+// text+image attention of the FLUX MMDiT (diffusers, core/image/inpainting.py:877-887).
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); 64-key K/V tiles go through LDS
+// (K as swizzled [key][d] rows, V TRANSPOSED as [d][key] so both MFMA operands are contiguous).
+// Both products are computed transposed (S^T = K Q^T, O^T = V^T P^T): a lane then owns ONE query
+// row (col = lane & 15) in S^T and in O^T, so the running max / sum / rescale are lane-local
+// (two xor-shuffles across the four 16-lane quads finish a row reduction), and P goes from the
+// S^T accumulators straight into the next MFMA's B operand without touching LDS.
+#include "mtx_device.h"
+
+namespace mtx {
+
+struct AttnParams {
+  const unsigned char* q; const unsigned char* k; const unsigned char* v; unsigned char* o;
+  long batch, heads, sq, sk, d;
+  long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
+  float scale_log2;
+  unsigned qblocks;
+};
+
+constexpr int AT_KV = 64;      // keys per tile
+constexpr int AT_QW = 32;      // query rows per wave (2 MFMA column fragments)
+constexpr int AT_QB = 128;     // query rows per workgroup
+
+// DP = head dim padded to a multiple of 32 (zero-filled); K row = SLOTS 16-byte slots.
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KST = DP / 32;                 // k-steps of the S^T product
+  constexpr int DF = DP / 16;                  // d fragments of O^T
+  constexpr int SLOTS = DP <= 64 ? 8 : 16;
+  constexpr int KROW = SLOTS * 16;             // bytes per K row in LDS
+  constexpr int K_BYTES = AT_KV * KROW;
+  constexpr int VT_BYTES = DP * 128;           // [DP rows][64 keys] T
+  __shared__ __attribute__((aligned(16))) unsigned char smem[K_BYTES + VT_BYTES];
+  unsigned char* Ks = smem;
+  unsigned char* Vt = smem + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q4 = lane >> 4;
+  const long bh = blockIdx.x / p.qblocks;
+  const long qb = blockIdx.x % p.qblocks;
+  const long b = bh / p.heads, h = bh % p.heads;
+  const long q0 = qb * AT_QB + wv * AT_QW;
+  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
+  const int dch = (int)(p.d / 8);              // valid 16-byte chunks per row
+
+  // Q fragments (B operand: col = query row, 8 consecutive d per lane), kept in registers
+  v8 qf[2][KST];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      const long qr = q0 + f * 16 + l15;
+      const int ch = ks * 4 + q4;
+      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+      if (qr < p.sq && ch < dch) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ch * 8);
+      qf[f][ks] = __builtin_bit_cast(v8, raw);
+    }
+
+  f32x4 oacc[2][DF];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int d = 0; d < DF; ++d) oacc[f][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrun[2] = {-1.0e30f, -1.0e30f};
+  float lrun[2] = {0.f, 0.f};
+
+  constexpr int KCH = AT_KV * (DP / 8);        // 16-byte chunks per K (or V) tile
+  constexpr int NLD = (KCH + 255) / 256;
+  u32x4 rk[NLD], rv[NLD];
+  auto load_tile = [&](long k0) {
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int idx = tid + it * 256;
+      const int ch = idx % (DP / 8), row = idx / (DP / 8);
+      u32x4 a = u32x4{0u, 0u, 0u, 0u}, c = u32x4{0u, 0u, 0u, 0u};
+      if (idx < KCH && k0 + row < p.sk && ch < dch) {
+        a = *reinterpret_cast<const u32x4*>(K + (k0 + row) * p.k_ss + ch * 8);
+        c = *reinterpret_cast<const u32x4*>(V + (k0 + row) * p.v_ss + ch * 8);
+      }
+      rk[it] = a; rv[it] = c;
+    }
+  };
+
+  const long ntiles = (p.sk + AT_KV - 1) / AT_KV;
+  load_tile(0);
+  for (long t = 0; t < ntiles; ++t) {
+    const long k0 = t * AT_KV;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < KCH) {
+        const int ch = idx % (DP / 8), row = idx / (DP / 8);
+        *reinterpret_cast<u32x4*>(Ks + row * KROW + ((ch ^ (row & (SLOTS - 1))) << 4)) = rk[it];
+        // V transposed: Vt[d][key], 8-byte granules (4 keys) XOR-swizzled by (d & 15)
+        const typename Traits<T>::v8 vv = __builtin_bit_cast(v8, rv[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int dr = ch * 8 + e;
+          *reinterpret_cast<T*>(Vt + dr * 128 + ((((row >> 2) ^ (dr & 15))) << 3) + ((row & 3) << 1)) = vv[e];
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < ntiles) load_tile(k0 + AT_KV);
+
+    // ---- S^T = K Q^T : sacc[f][kf] holds keys kf*16 + q4*4 + r for query f*16 + l15 -----------
+    f32x4 sacc[2][4];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) sacc[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      const int ch = ks * 4 + q4;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) {
+        const int row = kf * 16 + l15;
+        const v8 kfr = *reinterpret_cast<const v8*>(Ks + row * KROW + ((ch ^ (row & (SLOTS - 1))) << 4));
+#pragma unroll
+        for (int f = 0; f < 2; ++f) sacc[f][kf] = Traits<T>::mfma(kfr, qf[f][ks], sacc[f][kf]);
+      }
+    }
+
+    // ---- online softmax (base-2), lane-local per query row --------------------------------------
+    v8 pb[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float tmax = -1.0e30f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long key = k0 + kf * 16 + q4 * 4 + r;
+          float s = sacc[f][kf][r] * p.scale_log2;
+          if (key >= p.sk) s = -1.0e30f;
+          sacc[f][kf][r] = s;
+          tmax = s > tmax ? s : tmax;
+        }
+      { float o1 = __shfl_xor(tmax, 16, 64); tmax = o1 > tmax ? o1 : tmax; }
+      { float o2 = __shfl_xor(tmax, 32, 64); tmax = o2 > tmax ? o2 : tmax; }
+      const float mnew = tmax > mrun[f] ? tmax : mrun[f];
+      const float alpha = exp2f(mrun[f] - mnew);
+      mrun[f] = mnew;
+      float psum = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = exp2f(sacc[f][kf][r] - mnew);
+          psum += pv;
+          // B operand of O^T = V^T P^T: k-slot q4*8 + e  <->  key (kk*32) + (e<4 ? q4*4+e : 16+q4*4+e-4)
+          pb[f][kf >> 1][(kf & 1) * 4 + r] = from_f32<T>(pv);
+        }
+      lrun[f] = lrun[f] * alpha + psum;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        oacc[f][d][0] *= alpha; oacc[f][d][1] *= alpha; oacc[f][d][2] *= alpha; oacc[f][d][3] *= alpha;
+      }
+    }
+
+    // ---- O^T += V^T P^T ------------------------------------------------------------------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const int dr = d * 16 + l15;
+        const int g0 = kk * 8 + q4;            // granule of keys kk*32 + q4*4 .. +3
+        const int g1 = kk * 8 + 4 + q4;        // granule of keys kk*32 + 16 + q4*4 .. +3
+        const v4 lo = *reinterpret_cast<const v4*>(Vt + dr * 128 + ((g0 ^ (dr & 15)) << 3));
+        const v4 hi = *reinterpret_cast<const v4*>(Vt + dr * 128 + ((g1 ^ (dr & 15)) << 3));
+        v8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) oacc[f][d] = Traits<T>::mfma(vf, pb[f][kk], oacc[f][d]);
+      }
+    }
+  }
+
+  // ---- finish: row sums across the 4 quads, normalise, store 4 consecutive d per lane ----------
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    float l = lrun[f];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const long qr = q0 + f * 16 + l15;
+    if (qr < p.sq) {
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const int dc = d * 16 + q4 * 4;
+        if (dc < p.d) {
+          v4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[f][d][r] * inv);
+          *reinterpret_cast<v4*>(O + qr * p.o_ss + dc) = o;
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_attn_t(const AttnParams& p, void* stream) {
+  const unsigned grid = (unsigned)(p.batch * p.heads) * p.qblocks;
+  if (p.d <= 32) MTX_LAUNCH((attn_kernel<T, 32>), dim3(grid), dim3(256), 0, stream, p);
+  else if (p.d <= 64) MTX_LAUNCH((attn_kernel<T, 64>), dim3(grid), dim3(256), 0, stream, p);
+  else if (p.d <= 96) MTX_LAUNCH((attn_kernel<T, 96>), dim3(grid), dim3(256), 0, stream, p);
+  else MTX_LAUNCH((attn_kernel<T, 128>), dim3(grid), dim3(256), 0, stream, p);
+  return MTX_OK;
+}
+
+int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
+  if (!a->q || !a->k || !a->v || !a->o) { *err = "attention: null operand"; return MTX_ERR_INVALID; }
+  if (a->d < 8 || a->d > 128 || a->d % 8) { *err = "attention: head dim must be a multiple of 8, <= 128"; return MTX_ERR_INVALID; }
+  if (a->d % 4 || a->q_ss % 8 || a->k_ss % 8 || a->v_ss % 8 || a->o_ss % 4 || a->q_hs % 8 || a->k_hs % 8 || a->v_hs % 8 || a->o_hs % 4 ||
+      a->q_bs % 8 || a->k_bs % 8 || a->v_bs % 8 || a->o_bs % 4) { *err = "attention: strides must keep 16-byte alignment"; return MTX_ERR_INVALID; }
+  if (a->batch < 1 || a->heads < 1 || a->sq < 1 || a->sk < 1) { *err = "attention: empty problem"; return MTX_ERR_INVALID; }
+  AttnParams p;
+  p.q = (const unsigned char*)a->q; p.k = (const unsigned char*)a->k; p.v = (const unsigned char*)a->v; p.o = (unsigned char*)a->o;
+  p.batch = a->batch; p.heads = a->heads; p.sq = a->sq; p.sk = a->sk; p.d = a->d;
+  p.q_bs = a->q_bs; p.q_ss = a->q_ss; p.q_hs = a->q_hs; p.k_bs = a->k_bs; p.k_ss = a->k_ss; p.k_hs = a->k_hs;
+  p.v_bs = a->v_bs; p.v_ss = a->v_ss; p.v_hs = a->v_hs; p.o_bs = a->o_bs; p.o_ss = a->o_ss; p.o_hs = a->o_hs;
+  p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
+  if (a->dtype == MTX_BF16) return launch_attn_t<__bf16>(p, stream);
+  if (a->dtype == MTX_F16) return launch_attn_t<_Float16>(p, stream);
+  *err = "attention: dtype must be bf16 or f16";
+  return MTX_ERR_INVALID;
+}
+
+}  // namespace mtx

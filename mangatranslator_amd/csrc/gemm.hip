@@ -1,0 +1,212 @@
+// gemm.hip — C[M,N] = epilogue(A[M,K] * W[N,K]^T) on the gfx950 matrix cores.
+//
+// Every nn.Linear / 1x1 projection of the transformer parts of the hot path goes through this
+// kernel: SAM-2.1 Hiera blocks + mask decoder (transformers Sam2Model, called at
+// core/image/detection.py:505) and the FLUX MMDiT (diffusers, core/image/inpainting.py:877-887).
+//
+// 128x128 output tile per 4-wave workgroup, K slices of 64 staged through LDS as 128-byte rows
+// XOR-swizzled by (row & 7) (conflict-free ds_read_b128, same argument as conv.hip), the next
+// slice's global loads in flight behind the current slice's 32 MFMAs per wave (issue-early /
+// write-late staging).  Operands are swapped (A-operand = W rows) so a lane owns 4 consecutive
+// output columns; the tile is transposed through LDS and leaves as 16-byte row chunks with bias,
+// activation, per-sample gate (adaLN-Zero) and residual fused.
+#include "mtx_device.h"
+
+namespace mtx {
+
+struct GemmParams {
+  const unsigned char* a; const unsigned char* w; const float* bias; const unsigned char* res;
+  const unsigned char* gate; unsigned char* c;
+  long m, n, k, lda, ldw, ldc, ldres, ldgate, a_bs, w_bs, c_bs;
+  int gate_rows_per, act; float act_param, alpha;
+  int out_f32;
+  unsigned tiles_m, tiles_n;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int G_SMEM = (GBM + GBN) * 128;   // 32 KB; the output tile (128 x 256 B) aliases it
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G_SMEM];
+  unsigned char* As = smem;
+  unsigned char* Ws = smem + GBM * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int wm = wv >> 1, wn = wv & 1;
+
+  const unsigned nwg = p.tiles_m * p.tiles_n;
+  unsigned lin = xcd_remap(blockIdx.x, nwg);
+  const long m0 = (long)(lin / p.tiles_n) * GBM;
+  const long n0 = (long)(lin % p.tiles_n) * GBN;
+  const long bz = blockIdx.y;
+  const unsigned char* A = p.a + (size_t)bz * p.a_bs * sizeof(T);
+  const unsigned char* W = p.w + (size_t)bz * p.w_bs * sizeof(T);
+  unsigned char* Cp = p.c + (size_t)bz * p.c_bs * (p.out_f32 ? 4 : sizeof(T));
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lc = tid & 7;          // 16-byte chunk within the 64-wide K slice
+  const int lr = tid >> 3;         // row within a 32-row pass
+  u32x4 ra[4], rw[4];
+
+  auto load_slice = [&](long k0) {
+    const long kk = k0 + lc * 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const long r = lr + it * 32;
+      u32x4 va = u32x4{0u, 0u, 0u, 0u}, vw = u32x4{0u, 0u, 0u, 0u};
+      if (m0 + r < p.m && kk < p.k) va = *reinterpret_cast<const u32x4*>(A + ((size_t)(m0 + r) * p.lda + kk) * sizeof(T));
+      if (n0 + r < p.n && kk < p.k) vw = *reinterpret_cast<const u32x4*>(W + ((size_t)(n0 + r) * p.ldw + kk) * sizeof(T));
+      ra[it] = va; rw[it] = vw;
+    }
+  };
+
+  const long nk = (p.k + GBK - 1) / GBK;
+  load_slice(0);
+  for (long kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = lr + it * 32;
+      *reinterpret_cast<u32x4*>(As + r * 128 + ((lc ^ (r & 7)) << 4)) = ra[it];
+      *reinterpret_cast<u32x4*>(Ws + r * 128 + ((lc ^ (r & 7)) << 4)) = rw[it];
+    }
+    __syncthreads();
+    if (kt + 1 < nk) load_slice((kt + 1) * GBK);
+    const long rem = p.k - kt * GBK;
+    const int nks = rem >= 64 ? 2 : (int)((rem + 31) / 32);
+    for (int ks = 0; ks < nks; ++ks) {
+      const int cch = ks * 4 + q;
+      v8 wf[4], af[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wn * 64 + j * 16 + l15;
+        wf[j] = *reinterpret_cast<const v8*>(Ws + r * 128 + ((cch ^ (l15 & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + l15;
+        af[i] = *reinterpret_cast<const v8*>(As + r * 128 + ((cch ^ (l15 & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Traits<T>::mfma(wf[j], af[i], acc[i][j]);
+    }
+  }
+
+  // lane holds C[m = m0 + wm*64 + i*16 + l15][n = n0 + wn*64 + j*16 + q*4 + r]
+  if (p.out_f32) {
+    float* Cf = reinterpret_cast<float*>(Cp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = m0 + wm * 64 + i * 16 + l15;
+      if (m >= p.m) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long n = n0 + wn * 64 + j * 16 + q * 4 + r;
+          if (n < p.n) {
+            float v = acc[i][j][r] * p.alpha + (p.bias ? p.bias[n] : 0.f);
+            v = apply_act(v, p.act, p.act_param);
+            if (p.gate) v *= to_f32(reinterpret_cast<const T*>(p.gate)[(size_t)(m / p.gate_rows_per) * p.ldgate + n]);
+            if (p.res) v += to_f32(reinterpret_cast<const T*>(p.res)[(size_t)bz * p.c_bs + (size_t)m * p.ldres + n]);
+            Cf[(size_t)m * p.ldc + n] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  __syncthreads();
+  unsigned char* outs = smem;    // [128 rows][16 chunks of 16 B], chunk ^= (row & 15)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long nb = n0 + wn * 64 + j * 16 + q * 4;
+    float b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = (p.bias != nullptr && nb + r < p.n) ? p.bias[nb + r] : 0.f;
+    const int chunk = wn * 8 + j * 2 + (q >> 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wm * 64 + i * 16 + l15;
+      v4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act(acc[i][j][r] * p.alpha + b[r], p.act, p.act_param));
+      *reinterpret_cast<v4*>(outs + row * 256 + ((chunk ^ (row & 15)) << 4) + ((q & 1) << 3)) = o;
+    }
+  }
+  __syncthreads();
+  const int oc = tid & 15;
+  const bool vec_ok = (p.ldc % 8 == 0) && (!p.res || p.ldres % 8 == 0) && (!p.gate || p.ldgate % 8 == 0);
+  for (int it = 0; it < 8; ++it) {
+    const int row = (tid >> 4) + it * 16;
+    const long m = m0 + row, n = n0 + oc * 8;
+    if (m >= p.m || n >= p.n) continue;
+    u32x4 raw = *reinterpret_cast<const u32x4*>(outs + row * 256 + ((oc ^ (row & 15)) << 4));
+    const bool full = vec_ok && (n + 8 <= p.n);
+    if (p.gate != nullptr || p.res != nullptr || !full) {
+      float f[8];
+      unpack8<T>(raw, f);
+      const T* G = reinterpret_cast<const T*>(p.gate);
+      const T* R = reinterpret_cast<const T*>(p.res);
+      const size_t goff = (size_t)(m / (p.gate_rows_per > 0 ? p.gate_rows_per : 1)) * p.ldgate + n;
+      const size_t roff = (size_t)bz * p.c_bs + (size_t)m * p.ldres + n;
+      if (full) {
+        if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + goff), g8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
+        if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + roff), r8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += r8[e]; }
+        raw = pack8<T>(f);
+      } else {
+        T* Co = reinterpret_cast<T*>(Cp);
+        for (int e = 0; e < 8 && n + e < p.n; ++e) {
+          float v = f[e];
+          if (G) v *= to_f32(G[goff + e]);
+          if (R) v += to_f32(R[roff + e]);
+          Co[(size_t)m * p.ldc + n + e] = from_f32<T>(v);
+        }
+        continue;
+      }
+    }
+    *reinterpret_cast<u32x4*>(Cp + ((size_t)m * p.ldc + n) * sizeof(T)) = raw;
+  }
+}
+
+int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
+  if (!a->a || !a->w || !a->c) { *err = "gemm: null operand"; return MTX_ERR_INVALID; }
+  if (a->m < 1 || a->n < 1 || a->k < 1) { *err = "gemm: empty problem"; return MTX_ERR_INVALID; }
+  if (a->k % 8 || a->lda % 8 || a->ldw % 8) { *err = "gemm: K, lda, ldw must be multiples of 8 (16-byte chunks)"; return MTX_ERR_INVALID; }
+  if (a->batch > 1 && (a->a_bstride % 8 || a->w_bstride % 8 || a->c_bstride % 8)) { *err = "gemm: batch strides must be multiples of 8"; return MTX_ERR_INVALID; }
+  if (a->out_dtype != a->dtype && a->out_dtype != MTX_F32) { *err = "gemm: out_dtype must equal dtype or be f32"; return MTX_ERR_INVALID; }
+  GemmParams p;
+  p.a = (const unsigned char*)a->a; p.w = (const unsigned char*)a->w; p.bias = a->bias;
+  p.res = (const unsigned char*)a->res; p.gate = (const unsigned char*)a->gate; p.c = (unsigned char*)a->c;
+  p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
+  p.ldres = a->ldres; p.ldgate = a->ldgate;
+  p.a_bs = a->a_bstride; p.w_bs = a->w_bstride; p.c_bs = a->c_bstride;
+  p.gate_rows_per = a->gate_rows_per > 0 ? a->gate_rows_per : 1;
+  p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
+  p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;
+  p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
+  p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
+  const long batch = a->batch > 0 ? a->batch : 1;
+  dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
+  if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm_kernel<__bf16>), grid, dim3(256), 0, stream, p);
+  else if (a->dtype == MTX_F16) MTX_LAUNCH((gemm_kernel<_Float16>), grid, dim3(256), 0, stream, p);
+  else { *err = "gemm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+  return MTX_OK;
+}
+
+}  // namespace mtx

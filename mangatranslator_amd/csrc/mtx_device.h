@@ -1,0 +1,107 @@
+// mtx_device.h — shared device-side definitions for the gfx950 kernels.
+//
+// Built two ways:
+//   hipcc --offload-arch=gfx950            -> libmtx_hip.so (the product)
+//   clang++ -x c++ -DMTX_EMU (tests only)  -> tests/emu/libmtx_emu.so, a CPU SIMT simulator used
+//                                             by the CPU-only test tier to check kernel indexing.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef MTX_EMU
+#include "emu_hip.h"
+#else
+#include <hip/hip_runtime.h>
+#define MTX_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define MTX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#include "../../include/mtx_hip.h"
+
+namespace mtx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int kWave = 64;
+
+template <typename T> struct Traits;
+template <> struct Traits<__bf16> {
+  typedef bf16x8 v8; typedef bf16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Traits<_Float16> {
+  typedef f16x8 v8; typedef f16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+// _Float16 saturates instead of overflowing to inf (activations can spike on random weights)
+template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) {
+  v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+  return (_Float16)v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float p) {
+  switch (act) {
+    case MTX_ACT_RELU: return v > 0.f ? v : 0.f;
+    case MTX_ACT_SILU: return v / (1.f + __expf(-v));
+    case MTX_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case MTX_ACT_GELU_TANH: {
+      float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      return 0.5f * v * (1.f + tanhf(u));
+    }
+    case MTX_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case MTX_ACT_LEAKY: return v > 0.f ? v : v * p;
+    default: return v;
+  }
+}
+
+// 16-byte chunk (8 x 16-bit) helpers
+template <typename T>
+__device__ __forceinline__ void unpack8(const u32x4& raw, float (&f)[8]) {
+  typename Traits<T>::v8 v = __builtin_bit_cast(typename Traits<T>::v8, raw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T>
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  typename Traits<T>::v8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = from_f32<T>(f[i]);
+  return __builtin_bit_cast(u32x4, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { float o = __shfl_xor(v, m, 64); v = v > o ? v : o; }
+  return v;
+}
+
+// XCD-aware, bijective remap of a linear workgroup id: workgroup b runs on XCD b%8 (observed),
+// so give each XCD a contiguous range of tiles and neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned nx = 8;
+  if (nwg < nx * 2) return bid;
+  unsigned q = nwg / nx, r = nwg % nx, xcd = bid % nx, idx = bid / nx;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace mtx

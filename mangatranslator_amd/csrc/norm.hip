@@ -1,0 +1,191 @@
+// norm.hip — wave-reduced row normalisations (HBM-streaming: one read, one write).
+//
+//   LayerNorm / RMSNorm over [rows, C], one 64-lane wave per row, 16-byte chunks per lane held in
+//   registers between the statistics and the normalise pass (two-pass variance, fp32), with the
+//   adaLN modulation y*(1+scale)+shift of the FLUX DiT fused (diffusers AdaLayerNormZero, reached
+//   from core/image/inpainting.py:877-887) — also Hiera's LayerNorms (SAM-2.1,
+//   core/image/detection.py:505).
+//   GroupNorm(+SiLU) over NHWC for the FLUX VAE: per-channel partial sums -> per-group statistics
+//   -> apply, so activations are read twice and written once.
+#include "mtx_device.h"
+
+namespace mtx {
+
+constexpr int NORM_MAXCH = 12;   // chunks of 8 per lane -> C <= 6144
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const long nch = p.c / 8;
+  const T* X = reinterpret_cast<const T*>(p.x) + row * p.ldx;
+  T* Y = reinterpret_cast<T*>(p.y) + row * p.ldy;
+  float v[NORM_MAXCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXCH; ++i) {
+    const long ch = lane + (long)i * 64;
+    if (ch < nch) {
+      unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  float mean = 0.f;
+  if (p.kind == 0) { s = wave_sum(s); mean = s / (float)p.c; }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXCH; ++i) {
+    const long ch = lane + (long)i * 64;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = 1.0f / sqrtf(ss / (float)p.c + p.eps);
+  const T* MS = reinterpret_cast<const T*>(p.mod_scale);
+  const T* MH = reinterpret_cast<const T*>(p.mod_shift);
+  const long mrow = p.rows_per > 0 ? row / p.rows_per : 0;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXCH; ++i) {
+    const long ch = lane + (long)i * 64;
+    if (ch < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (v[i][e] - mean) * rstd;
+        if (p.gamma) t *= p.gamma[ch * 8 + e];
+        if (p.beta) t += p.beta[ch * 8 + e];
+        o[e] = t;
+      }
+      if (MS) { float g[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(MS + mrow * p.ldmod + ch * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= (1.f + g[e]); }
+      if (MH) { float g[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(MH + mrow * p.ldmod + ch * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += g[e]; }
+      *reinterpret_cast<u32x4*>(Y + ch * 8) = pack8<T>(o);
+    }
+  }
+}
+
+int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
+  if (!a->x || !a->y) { *err = "norm: null operand"; return MTX_ERR_INVALID; }
+  if (a->c % 8 || a->ldx % 8 || a->ldy % 8 || a->c > NORM_MAXCH * 64 * 8 || a->c < 8) { *err = "norm: C must be a multiple of 8, <= 6144"; return MTX_ERR_INVALID; }
+  if ((a->mod_scale || a->mod_shift) && (a->ldmod % 8 || a->rows_per < 1)) { *err = "norm: bad modulation layout"; return MTX_ERR_INVALID; }
+  if (a->kind != 0 && a->kind != 1) { *err = "norm: kind must be 0 (LayerNorm) or 1 (RMSNorm)"; return MTX_ERR_INVALID; }
+  if (a->rows < 1) return MTX_OK;
+  const unsigned blocks = (unsigned)((a->rows + 3) / 4);
+  if (a->dtype == MTX_BF16) MTX_LAUNCH((norm_kernel<__bf16>), dim3(blocks), dim3(256), 0, stream, *a);
+  else if (a->dtype == MTX_F16) MTX_LAUNCH((norm_kernel<_Float16>), dim3(blocks), dim3(256), 0, stream, *a);
+  else { *err = "norm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+  return MTX_OK;
+}
+
+// ---- GroupNorm -----------------------------------------------------------------------------------
+// workspace layout (fp32): [N][C][2] per-channel {sum, sumsq}  followed by  [N][G][2] {mean, rstd}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(mtx_groupnorm_args p, int pix_per_block) {
+  __shared__ float red[256 * 16];
+  const int C8 = (int)(p.c / 8);
+  const int tid = threadIdx.x;
+  const int col = tid % C8, sub = tid / C8, nsub = 256 / C8;
+  const long n = blockIdx.y;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  long p1 = p0 + pix_per_block; if (p1 > p.hw) p1 = p.hw;
+  const T* X = reinterpret_cast<const T*>(p.x) + n * p.hw * p.c;
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  for (long px = p0 + sub; px < p1; px += nsub) {
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(X + px * p.c + col * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = ss[e]; }
+  __syncthreads();
+  if (sub == 0) {
+    float* ws = p.workspace + (n * p.c + col * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int k = 0; k < nsub; ++k) { a += red[(k * C8 + col) * 16 + e]; b += red[(k * C8 + col) * 16 + 8 + e]; }
+      atomicAdd(ws + e * 2, a);
+      atomicAdd(ws + e * 2 + 1, b);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(mtx_groupnorm_args p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.n * p.groups) return;
+  const long n = idx / p.groups, g = idx % p.groups;
+  const long cg = p.c / p.groups;
+  const float* ws = p.workspace + (n * p.c + g * cg) * 2;
+  float s = 0.f, ss = 0.f;
+  for (long c = 0; c < cg; ++c) { s += ws[c * 2]; ss += ws[c * 2 + 1]; }
+  const float cnt = (float)(cg * p.hw);
+  const float mean = s / cnt;
+  float var = ss / cnt - mean * mean;
+  if (var < 0.f) var = 0.f;
+  float* out = p.workspace + p.n * p.c * 2 + idx * 2;
+  out[0] = mean;
+  out[1] = 1.0f / sqrtf(var + p.eps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(mtx_groupnorm_args p) {
+  const long C8 = p.c / 8;
+  const long total = p.n * p.hw * C8;
+  const long cg = p.c / p.groups;
+  const float* st = p.workspace + p.n * p.c * 2;
+  const T* X = reinterpret_cast<const T*>(p.x);
+  T* Y = reinterpret_cast<T*>(p.y);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long c0 = (idx % C8) * 8;
+    const long pix = idx / C8;
+    const long n = pix / p.hw;
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(X + pix * p.c + c0), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long g = (c0 + e) / cg;
+      const float mean = st[(n * p.groups + g) * 2], rstd = st[(n * p.groups + g) * 2 + 1];
+      float t = (f[e] - mean) * rstd;
+      if (p.gamma) t *= p.gamma[c0 + e];
+      if (p.beta) t += p.beta[c0 + e];
+      f[e] = apply_act(t, p.act, 0.f);
+    }
+    *reinterpret_cast<u32x4*>(Y + pix * p.c + c0) = pack8<T>(f);
+  }
+}
+
+int groupnorm_launch(const mtx_groupnorm_args* a, void* stream, const char** err) {
+  if (!a->x || !a->y || !a->workspace) { *err = "groupnorm: null operand"; return MTX_ERR_INVALID; }
+  const long C8 = a->c / 8;
+  if (a->c % 8 || C8 < 1 || C8 > 256 || (256 % C8) != 0 || a->groups < 1 || a->c % a->groups) {
+    *err = "groupnorm: C/8 must divide 256 and groups must divide C"; return MTX_ERR_INVALID;
+  }
+  if (a->n < 1 || a->hw < 1) return MTX_OK;
+  if (hipMemsetAsync(a->workspace, 0, (size_t)a->n * a->c * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) { *err = "groupnorm: memset failed"; return MTX_ERR_HIP; }
+  const int ppb = 1024;
+  dim3 g1((unsigned)((a->hw + ppb - 1) / ppb), (unsigned)a->n);
+  long tot = a->n * a->hw * C8;
+  long blocks = (tot + 255) / 256; if (blocks > 8192) blocks = 8192;
+  if (a->dtype == MTX_BF16) {
+    MTX_LAUNCH((gn_stats_kernel<__bf16>), g1, dim3(256), 0, stream, *a, ppb);
+    MTX_LAUNCH(gn_finalize_kernel, dim3((unsigned)((a->n * a->groups + 255) / 256)), dim3(256), 0, stream, *a);
+    MTX_LAUNCH((gn_apply_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
+  } else if (a->dtype == MTX_F16) {
+    MTX_LAUNCH((gn_stats_kernel<_Float16>), g1, dim3(256), 0, stream, *a, ppb);
+    MTX_LAUNCH(gn_finalize_kernel, dim3((unsigned)((a->n * a->groups + 255) / 256)), dim3(256), 0, stream, *a);
+    MTX_LAUNCH((gn_apply_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
+  } else { *err = "groupnorm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+  return MTX_OK;
+}
+
+}  // namespace mtx

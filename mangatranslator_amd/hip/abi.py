@@ -1,0 +1,111 @@
+"""ctypes mirror of include/mtx_hip.h (field order and types must match 1:1; checked against
+mtx_abi_sizeof() when the library is opened)."""
+import ctypes as C
+
+ABI_VERSION = 1
+
+# enums
+BF16, F16, F32, U8, I32 = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_SIGMOID, ACT_LEAKY = range(7)
+(EW_SCALE_RES, EW_ADD, EW_MUL, EW_ACT, EW_UPSAMPLE2X, EW_MAXPOOL, EW_COPY, EW_GATE_RES) = range(8)
+IMG_NCHW_F32_TO_NHWC, IMG_NHWC_TO_NCHW_F32, IMG_NHWC_TO_HWC_U8, IMG_HWC_U8_TO_NHWC = range(4)
+(OP_CONV2D, OP_GEMM, OP_ATTN, OP_NORM, OP_GROUPNORM, OP_EW, OP_CA, OP_IMG, OP_RESIZE_THRESH,
+ OP_MEMSET) = range(1, 11)
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("x", vp), ("w", vp), ("bias", vp), ("res", vp), ("y", vp), ("chan_sum", vp),
+                ("n", i32), ("h", i32), ("w_in", i32), ("cin", i32), ("cout", i32),
+                ("ksize", i32), ("stride", i32),
+                ("ldx", i32), ("ldy", i32), ("ldres", i32),
+                ("act", i32), ("act_param", f32), ("res_scale", f32),
+                ("pixel_shuffle", i32), ("dtype", i32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("a", vp), ("w", vp), ("bias", vp), ("res", vp), ("gate", vp), ("c", vp),
+                ("m", i64), ("n", i64), ("k", i64),
+                ("lda", i64), ("ldw", i64), ("ldc", i64), ("ldres", i64), ("ldgate", i64),
+                ("batch", i64), ("a_bstride", i64), ("w_bstride", i64), ("c_bstride", i64),
+                ("gate_rows_per", i32),
+                ("act", i32), ("act_param", f32), ("alpha", f32),
+                ("dtype", i32), ("out_dtype", i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("o", vp),
+                ("batch", i64), ("heads", i64), ("sq", i64), ("sk", i64), ("d", i64),
+                ("q_bs", i64), ("q_ss", i64), ("q_hs", i64), ("k_bs", i64), ("k_ss", i64), ("k_hs", i64),
+                ("v_bs", i64), ("v_ss", i64), ("v_hs", i64), ("o_bs", i64), ("o_ss", i64), ("o_hs", i64),
+                ("scale", f32), ("dtype", i32)]
+
+
+class NormArgs(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("mod_scale", vp), ("mod_shift", vp),
+                ("rows", i64), ("c", i64), ("ldx", i64), ("ldy", i64), ("rows_per", i64), ("ldmod", i64),
+                ("eps", f32), ("kind", i32), ("dtype", i32)]
+
+
+class GroupNormArgs(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("workspace", vp),
+                ("n", i64), ("hw", i64), ("c", i64), ("groups", i64),
+                ("eps", f32), ("act", i32), ("dtype", i32)]
+
+
+class EwArgs(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("s", vp), ("y", vp),
+                ("n", i64), ("h", i64), ("w", i64), ("c", i64),
+                ("lda", i64), ("ldb", i64), ("ldy", i64), ("lds", i64),
+                ("kind", i32), ("act", i32), ("act_param", f32), ("i0", i32), ("i1", i32), ("dtype", i32)]
+
+
+class CaArgs(C.Structure):
+    _fields_ = [("chan_sum", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("s", vp),
+                ("n", i32), ("tiles", i32), ("c", i32), ("cr", i32), ("inv_hw", f32)]
+
+
+class ImgArgs(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp),
+                ("n", i64), ("h", i64), ("w", i64),
+                ("c_pad", i32), ("unshuffle", i32),
+                ("mul", f32), ("add", f32 * 4),
+                ("kind", i32), ("dtype", i32)]
+
+
+class ResizeThreshArgs(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp),
+                ("n", i64), ("hs", i64), ("ws", i64), ("hd", i64), ("wd", i64),
+                ("thresh", f32), ("dtype", i32)]
+
+
+class MemsetArgs(C.Structure):
+    _fields_ = [("ptr", vp), ("bytes", i64), ("value", i32)]
+
+
+class _OpUnion(C.Union):
+    _fields_ = [("conv", ConvArgs), ("gemm", GemmArgs), ("attn", AttnArgs), ("norm", NormArgs),
+                ("gn", GroupNormArgs), ("ew", EwArgs), ("ca", CaArgs), ("img", ImgArgs),
+                ("rt", ResizeThreshArgs), ("ms", MemsetArgs)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("reserved", i32), ("u", _OpUnion)]
+
+
+ARG_TYPES = {OP_CONV2D: ConvArgs, OP_GEMM: GemmArgs, OP_ATTN: AttnArgs, OP_NORM: NormArgs,
+             OP_GROUPNORM: GroupNormArgs, OP_EW: EwArgs, OP_CA: CaArgs, OP_IMG: ImgArgs,
+             OP_RESIZE_THRESH: ResizeThreshArgs, OP_MEMSET: MemsetArgs}
+UNION_FIELD = {OP_CONV2D: "conv", OP_GEMM: "gemm", OP_ATTN: "attn", OP_NORM: "norm",
+               OP_GROUPNORM: "gn", OP_EW: "ew", OP_CA: "ca", OP_IMG: "img",
+               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms"}
+
+# every symbol include/mtx_hip.h declares (tests check the built library exports all of them)
+EXPORTS = [
+    "mtx_abi_version", "mtx_abi_sizeof", "mtx_last_error", "mtx_init", "mtx_device_info",
+    "mtx_conv2d", "mtx_conv2d_tiles", "mtx_gemm", "mtx_attention", "mtx_norm", "mtx_groupnorm",
+    "mtx_elementwise", "mtx_channel_attention", "mtx_image_convert", "mtx_resize_threshold",
+    "mtx_plan_create", "mtx_plan_run", "mtx_plan_run_graph", "mtx_plan_num_ops",
+    "mtx_plan_run_range", "mtx_plan_destroy", "mtx_plan_time", "mtx_plan_time_range",
+]

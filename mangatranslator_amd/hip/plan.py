@@ -1,0 +1,282 @@
+"""Static-graph builder: Python describes a network once, libmtx_hip executes it natively.
+
+A `PlanBuilder` allocates activation buffers as torch tensors (PyTorch is only the allocator /
+stream owner here) and records ops as `mtx_op` structs; `build()` hands the array to
+`mtx_plan_create`.  `Plan.run()` is then one C call that launches every kernel of the network on
+the caller's HIP stream (optionally as a hipGraph replay) — no Python in the per-layer loop.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from ..utils.exceptions import ModelError
+from . import abi
+
+_TORCH_DT = {abi.BF16: torch.bfloat16, abi.F16: torch.float16, abi.F32: torch.float32}
+
+
+def _ptr(t, offset_elems: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    if isinstance(t, Act):
+        return t.ptr
+    return t.data_ptr() + offset_elems * t.element_size()
+
+
+@dataclass
+class Act:
+    """Channels-last activation view: channels [c0, c0+c) of a [N, H, W, LD] buffer."""
+    t: torch.Tensor
+    n: int
+    h: int
+    w: int
+    c: int
+    c0: int = 0
+
+    @property
+    def ld(self) -> int:
+        return self.t.shape[-1]
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr() + self.c0 * self.t.element_size()
+
+    def slice(self, c0: int, c: int) -> "Act":
+        assert c0 % 8 == 0 and c % 8 == 0 and c0 + c <= self.c
+        return Act(self.t, self.n, self.h, self.w, c, self.c0 + c0)
+
+    def torch(self) -> torch.Tensor:
+        return self.t[..., self.c0:self.c0 + self.c]
+
+
+class Plan:
+    def __init__(self, lib, handle, keep, n_ops):
+        self.lib = lib
+        self._h = C.c_void_p(handle)
+        self._keep = keep
+        self.n_ops = n_ops
+
+    def _stream(self, stream):
+        if stream is not None:
+            return C.c_void_p(stream)
+        if torch.cuda.is_available() and not self.lib.is_simulator:
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(0)
+
+    def run(self, stream=None, graph: bool = False) -> None:
+        fn = self.lib.mtx_plan_run_graph if graph else self.lib.mtx_plan_run
+        self.lib.check(fn(self._h, self._stream(stream)), "mtx_plan_run")
+
+    def run_range(self, first: int, last: int, stream=None) -> None:
+        self.lib.check(self.lib.mtx_plan_run_range(self._h, first, last, self._stream(stream)), "mtx_plan_run_range")
+
+    def time(self, iters: int, graph: bool = False, stream=None) -> float:
+        ms = C.c_float(0.0)
+        self.lib.check(self.lib.mtx_plan_time(self._h, self._stream(stream), iters, int(graph), C.byref(ms)), "mtx_plan_time")
+        return float(ms.value)
+
+    def time_range(self, first: int, last: int, iters: int, stream=None) -> float:
+        ms = C.c_float(0.0)
+        self.lib.check(self.lib.mtx_plan_time_range(self._h, first, last, self._stream(stream), iters, C.byref(ms)), "mtx_plan_time_range")
+        return float(ms.value)
+
+    def close(self):
+        if self._h:
+            self.lib.mtx_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PlanBuilder:
+    def __init__(self, lib, device, dtype: int = abi.BF16):
+        self.lib = lib
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.tdtype = _TORCH_DT[dtype]
+        self.ops: List[abi.Op] = []
+        self.labels: List[str] = []
+        self.keep: list = []
+
+    # ---- memory ---------------------------------------------------------------------------
+    def hold(self, t):
+        self.keep.append(t)
+        return t
+
+    def act(self, n, h, w, c, ld=None, zero=False) -> Act:
+        ld = c if ld is None else ld
+        assert ld % 8 == 0, "pixel stride must be a multiple of 8 elements"
+        t = (torch.zeros if zero else torch.empty)((n, h, w, ld), dtype=self.tdtype, device=self.device)
+        self.keep.append(t)
+        return Act(t, n, h, w, c)
+
+    def buf(self, shape, dtype=torch.float32, zero=False):
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def const(self, t: torch.Tensor, dtype=None):
+        t = t.detach().to(device=self.device, dtype=dtype if dtype is not None else t.dtype).contiguous()
+        self.keep.append(t)
+        return t
+
+    # ---- op recording ---------------------------------------------------------------------
+    def _add(self, kind: int, args, label: str) -> int:
+        op = abi.Op()
+        op.kind = kind
+        setattr(op.u, abi.UNION_FIELD[kind], args)
+        self.ops.append(op)
+        self.labels.append(label)
+        return len(self.ops) - 1
+
+    def conv2d(self, x: Act, w_packed, bias, cout: int, ksize: int = 3, stride: int = 1,
+               act: int = abi.ACT_NONE, act_param: float = 0.0, res: Optional[Act] = None,
+               res_scale: float = 1.0, out: Optional[Act] = None, pixel_shuffle: int = 0,
+               chan_sum=None, label: str = "conv") -> Act:
+        pad = ksize // 2
+        ho = (x.h + 2 * pad - ksize) // stride + 1
+        wo = (x.w + 2 * pad - ksize) // stride + 1
+        if out is None:
+            if pixel_shuffle:
+                out = self.act(x.n, ho * pixel_shuffle, wo * pixel_shuffle, cout // (pixel_shuffle ** 2))
+            else:
+                out = self.act(x.n, ho, wo, cout)
+        a = abi.ConvArgs()
+        a.x, a.w, a.bias = x.ptr, _ptr(w_packed), _ptr(bias)
+        a.res = res.ptr if res is not None else None
+        a.y = out.ptr
+        a.chan_sum = _ptr(chan_sum)
+        a.n, a.h, a.w_in, a.cin, a.cout = x.n, x.h, x.w, x.c, cout
+        a.ksize, a.stride = ksize, stride
+        a.ldx, a.ldy, a.ldres = x.ld, out.ld, (res.ld if res is not None else 0)
+        a.act, a.act_param, a.res_scale = act, act_param, res_scale
+        a.pixel_shuffle, a.dtype = pixel_shuffle, self.dtype
+        self._add(abi.OP_CONV2D, a, label)
+        return out
+
+    def conv_tiles(self, x: Act, ksize=3, stride=1) -> int:
+        a = abi.ConvArgs()
+        a.n, a.h, a.w_in, a.cin, a.cout, a.ksize, a.stride = x.n, x.h, x.w, x.c, 8, ksize, stride
+        t = self.lib.mtx_conv2d_tiles(C.byref(a))
+        if t < 0:
+            raise ModelError(f"mtx_conv2d_tiles: {self.lib.last_error()}")
+        return t
+
+    def gemm(self, a_t, w_t, m, n, k, lda=None, ldw=None, out=None, ldc=None, bias=None, act=abi.ACT_NONE,
+             res=None, ldres=None, gate=None, ldgate=None, gate_rows_per=1, alpha=1.0, batch=1,
+             a_bs=0, w_bs=0, c_bs=0, out_f32=False, a_off=0, w_off=0, c_off=0, label="gemm"):
+        g = abi.GemmArgs()
+        if out is None:
+            out = self.buf((batch, m, n) if batch > 1 else (m, n), torch.float32 if out_f32 else self.tdtype)
+        g.a, g.w, g.c = _ptr(a_t, a_off), _ptr(w_t, w_off), _ptr(out, c_off)
+        g.bias, g.res, g.gate = _ptr(bias), _ptr(res), _ptr(gate)
+        g.m, g.n, g.k = m, n, k
+        g.lda, g.ldw, g.ldc = (lda or k), (ldw or k), (ldc or n)
+        g.ldres, g.ldgate = (ldres or n), (ldgate or n)
+        g.batch, g.a_bstride, g.w_bstride, g.c_bstride = batch, a_bs, w_bs, c_bs
+        g.gate_rows_per = gate_rows_per
+        g.act, g.act_param, g.alpha = act, 0.0, alpha
+        g.dtype, g.out_dtype = self.dtype, (abi.F32 if out_f32 else self.dtype)
+        self._add(abi.OP_GEMM, g, label)
+        return out
+
+    def attention(self, q, k, v, o, batch, heads, sq, sk, d, q_str, k_str, v_str, o_str, scale,
+                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn"):
+        a = abi.AttnArgs()
+        a.q, a.k, a.v, a.o = _ptr(q, q_off), _ptr(k, k_off), _ptr(v, v_off), _ptr(o, o_off)
+        a.batch, a.heads, a.sq, a.sk, a.d = batch, heads, sq, sk, d
+        a.q_bs, a.q_ss, a.q_hs = q_str
+        a.k_bs, a.k_ss, a.k_hs = k_str
+        a.v_bs, a.v_ss, a.v_hs = v_str
+        a.o_bs, a.o_ss, a.o_hs = o_str
+        a.scale, a.dtype = scale, self.dtype
+        self._add(abi.OP_ATTN, a, label)
+        return o
+
+    def norm(self, x, y, rows, c, ldx=None, ldy=None, gamma=None, beta=None, eps=1e-6, kind=0,
+             mod_scale=None, mod_shift=None, rows_per=0, ldmod=0, x_off=0, y_off=0, label="norm"):
+        a = abi.NormArgs()
+        a.x, a.y = _ptr(x, x_off), _ptr(y, y_off)
+        a.gamma, a.beta = _ptr(gamma), _ptr(beta)
+        a.mod_scale, a.mod_shift = _ptr(mod_scale), _ptr(mod_shift)
+        a.rows, a.c, a.ldx, a.ldy = rows, c, (ldx or c), (ldy or c)
+        a.rows_per, a.ldmod = rows_per, ldmod
+        a.eps, a.kind, a.dtype = eps, kind, self.dtype
+        self._add(abi.OP_NORM, a, label)
+        return y
+
+    def groupnorm(self, x: Act, gamma, beta, groups=32, eps=1e-6, act=abi.ACT_NONE, out=None, label="gn") -> Act:
+        assert x.c == x.ld and x.c0 == 0, "groupnorm needs a dense NHWC tensor"
+        if out is None:
+            out = self.act(x.n, x.h, x.w, x.c)
+        ws = self.buf((x.n * x.c * 2 + x.n * groups * 2,), torch.float32)
+        a = abi.GroupNormArgs()
+        a.x, a.y, a.gamma, a.beta, a.workspace = x.ptr, out.ptr, _ptr(gamma), _ptr(beta), _ptr(ws)
+        a.n, a.hw, a.c, a.groups = x.n, x.h * x.w, x.c, groups
+        a.eps, a.act, a.dtype = eps, act, self.dtype
+        self._add(abi.OP_GROUPNORM, a, label)
+        return out
+
+    def ew(self, kind, a_: Act, b: Optional[Act] = None, s=None, out: Optional[Act] = None, lds=0,
+           act=abi.ACT_NONE, act_param=0.0, i0=0, i1=0, label="ew") -> Act:
+        if out is None:
+            if kind == abi.EW_UPSAMPLE2X:
+                out = self.act(a_.n, a_.h * 2, a_.w * 2, a_.c)
+            elif kind == abi.EW_MAXPOOL:
+                pd = i0 // 2
+                out = self.act(a_.n, (a_.h + 2 * pd - i0) // i1 + 1, (a_.w + 2 * pd - i0) // i1 + 1, a_.c)
+            else:
+                out = self.act(a_.n, a_.h, a_.w, a_.c)
+        e = abi.EwArgs()
+        e.a, e.b, e.s, e.y = a_.ptr, (b.ptr if b is not None else None), _ptr(s), out.ptr
+        e.n, e.h, e.w, e.c = a_.n, a_.h, a_.w, a_.c
+        e.lda, e.ldb, e.ldy, e.lds = a_.ld, (b.ld if b is not None else 0), out.ld, lds
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = kind, act, act_param, i0, i1, self.dtype
+        self._add(abi.OP_EW, e, label)
+        return out
+
+    def channel_attention(self, chan_sum, w1, b1, w2, b2, s_out, n, tiles, c, cr, inv_hw, label="ca"):
+        a = abi.CaArgs()
+        a.chan_sum, a.w1, a.b1, a.w2, a.b2, a.s = (_ptr(chan_sum), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(s_out))
+        a.n, a.tiles, a.c, a.cr, a.inv_hw = n, tiles, c, cr, inv_hw
+        self._add(abi.OP_CA, a, label)
+        return s_out
+
+    def image_convert(self, kind, src, dst, n, h, w, c_pad, unshuffle=1, mul=1.0, add=(0.0, 0.0, 0.0), label="img"):
+        a = abi.ImgArgs()
+        a.src, a.dst = _ptr(src), _ptr(dst)
+        a.n, a.h, a.w, a.c_pad, a.unshuffle, a.mul = n, h, w, c_pad, unshuffle, mul
+        for i in range(3):
+            a.add[i] = float(add[i])
+        a.add[3] = 0.0
+        a.kind, a.dtype = kind, self.dtype
+        self._add(abi.OP_IMG, a, label)
+        return dst
+
+    def resize_threshold(self, src, dst, n, hs, ws, hd, wd, thresh=0.0, src_dtype=abi.F32, label="resize_thresh"):
+        a = abi.ResizeThreshArgs()
+        a.src, a.dst = _ptr(src), _ptr(dst)
+        a.n, a.hs, a.ws, a.hd, a.wd, a.thresh, a.dtype = n, hs, ws, hd, wd, thresh, src_dtype
+        self._add(abi.OP_RESIZE_THRESH, a, label)
+        return dst
+
+    def memset(self, t, value=0, label="memset"):
+        a = abi.MemsetArgs()
+        a.ptr, a.bytes, a.value = _ptr(t), t.numel() * t.element_size(), value
+        self._add(abi.OP_MEMSET, a, label)
+
+    # ---- finish ---------------------------------------------------------------------------
+    def build(self) -> Plan:
+        n = len(self.ops)
+        arr = (abi.Op * max(n, 1))(*self.ops)
+        handle = C.c_void_p()
+        self.lib.check(self.lib.mtx_plan_create(arr, n, C.byref(handle)), "mtx_plan_create")
+        plan = Plan(self.lib, handle.value, list(self.keep), n)
+        plan.labels = list(self.labels)
+        return plan

@@ -1,0 +1,210 @@
+// emu_hip.h — TEST INFRASTRUCTURE ONLY.
+//
+// A tiny SIMT simulator that lets the gfx950 kernel sources under mangatranslator_amd/csrc be
+// compiled for the host (clang++ -x c++ -DMTX_EMU) and executed on the CPU: every HIP thread is
+// a ucontext fiber, a workgroup is a round-robin scheduler over its fibers, __syncthreads() and
+// the wave-level primitives (MFMA, shuffles) are rendezvous points.  It exists so the index
+// arithmetic of the kernels (LDS swizzles, halo tiles, MFMA fragment maps, epilogues) can be
+// checked in the CPU-only test tier (`pytest -m "not gpu"`), where no MI355X is present.
+//
+// It is NOT a fallback: the product loader (mangatranslator_amd/hip/lib.py) only ever opens
+// libmtx_hip.so and raises ModelError when that is missing; the simulator library
+// (tests/emu/libmtx_emu.so) is opened by tests alone, through an explicit test-only entry point.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+#include <atomic>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipPeekAtLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+
+namespace emu {
+
+constexpr int kWave = 64;
+constexpr int kMaxThreads = 1024;
+constexpr size_t kStack = 96 * 1024;
+
+struct Fiber {
+  ucontext_t ctx;
+  dim3 tid;
+  int lin = 0;
+  bool done = false;
+  char* stack = nullptr;
+};
+
+struct WaveState {
+  int count = 0;
+  unsigned gen = 0;
+  alignas(16) unsigned char xa[kWave][64];   // per-lane exchange slot A (up to 64 bytes)
+  alignas(16) unsigned char xb[kWave][64];   // per-lane exchange slot B
+};
+
+struct Block {
+  dim3 bid, bdim, gdim;
+  int nthreads = 0;
+  int cur = 0;
+  int bar_count = 0;
+  unsigned bar_gen = 0;
+  ucontext_t main_ctx;
+  std::vector<Fiber> fibers;
+  std::vector<WaveState> waves;
+  char* dyn_smem = nullptr;
+  const std::function<void()>* body = nullptr;
+};
+
+extern thread_local Block* B;
+
+inline void yield() { swapcontext(&B->fibers[B->cur].ctx, &B->main_ctx); }
+
+inline void syncthreads() {
+  unsigned g = B->bar_gen;
+  if (++B->bar_count == B->nthreads) { B->bar_count = 0; B->bar_gen++; }
+  else while (B->bar_gen == g) yield();
+}
+
+inline int lane_id() { return B->fibers[B->cur].lin & (kWave - 1); }
+inline WaveState& wave() { return B->waves[B->fibers[B->cur].lin / kWave]; }
+inline int wave_width() {
+  int w = B->fibers[B->cur].lin / kWave;
+  int rem = B->nthreads - w * kWave;
+  return rem < kWave ? rem : kWave;
+}
+inline void wave_sync() {
+  WaveState& w = wave();
+  unsigned g = w.gen;
+  if (++w.count == wave_width()) { w.count = 0; w.gen++; }
+  else while (w.gen == g) yield();
+}
+
+void fiber_entry();
+void run_block(Block& blk);
+void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body);
+
+}  // namespace emu
+
+#define threadIdx (emu::B->fibers[emu::B->cur].tid)
+#define blockIdx (emu::B->bid)
+#define blockDim (emu::B->bdim)
+#define gridDim (emu::B->gdim)
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define __restrict__
+inline void __syncthreads() { emu::syncthreads(); }
+
+// ---- vector types (clang ext vectors work on the host too) --------------------------------
+typedef __attribute__((ext_vector_type(4))) float emu_f32x4;
+
+// ---- wave primitives -----------------------------------------------------------------------
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  (void)width;
+  emu::WaveState& w = emu::wave();
+  int l = emu::lane_id();
+  memcpy(w.xa[l], &v, sizeof(T));
+  emu::wave_sync();
+  T r;
+  memcpy(&r, w.xa[(l ^ mask) & 63], sizeof(T));
+  emu::wave_sync();
+  return r;
+}
+template <typename T>
+inline T __shfl_down(T v, int delta, int width = 64) {
+  (void)width;
+  emu::WaveState& w = emu::wave();
+  int l = emu::lane_id();
+  memcpy(w.xa[l], &v, sizeof(T));
+  emu::wave_sync();
+  T r;
+  int src = l + delta;
+  if (src > 63) src = l;
+  memcpy(&r, w.xa[src], sizeof(T));
+  emu::wave_sync();
+  return r;
+}
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+  (void)width;
+  emu::WaveState& w = emu::wave();
+  int l = emu::lane_id();
+  memcpy(w.xa[l], &v, sizeof(T));
+  emu::wave_sync();
+  T r;
+  memcpy(&r, w.xa[src & 63], sizeof(T));
+  emu::wave_sync();
+  return r;
+}
+
+// D = A(16x32) * B(32x16) + C ; lane l holds A[l&15][8*(l>>4)..+8], B[8*(l>>4)..+8][l&15],
+// C/D: col = l&15, row = 4*(l>>4) + r   (cdna_hip_programming.md §3 fragment layout)
+template <typename V8>
+inline emu_f32x4 emu_mfma_16x16x32(V8 a, V8 b, emu_f32x4 c) {
+  emu::WaveState& w = emu::wave();
+  int l = emu::lane_id();
+  float fa[8], fb[8];
+  for (int i = 0; i < 8; ++i) { fa[i] = (float)a[i]; fb[i] = (float)b[i]; }
+  memcpy(w.xa[l], fa, 32);
+  memcpy(w.xb[l], fb, 32);
+  emu::wave_sync();
+  emu_f32x4 d = c;
+  int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (l >> 4) + r;
+    float s = d[r];
+    for (int kb = 0; kb < 4; ++kb) {
+      const float* pa = reinterpret_cast<const float*>(w.xa[kb * 16 + row]);
+      const float* pb = reinterpret_cast<const float*>(w.xb[kb * 16 + col]);
+      for (int i = 0; i < 8; ++i) s += pa[i] * pb[i];
+    }
+    d[r] = s;
+  }
+  emu::wave_sync();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_16x16x32(a, b, c)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+
+inline float __expf(float x) { return expf(x); }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+
+// atomics (single OS thread per block; blocks of one launch may run on several OS threads)
+inline float atomicAdd(float* p, float v) {
+  auto* a = reinterpret_cast<std::atomic<float>*>(p);
+  float old = a->load();
+  while (!a->compare_exchange_weak(old, old + v)) {}
+  return old;
+}
+inline int atomicAdd(int* p, int v) { return reinterpret_cast<std::atomic<int>*>(p)->fetch_add(v); }
+
+#define MTX_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define MTX_DYN_SMEM(name) char* name = emu::B->dyn_smem
