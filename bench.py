@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — pages/sec of the vision hot path on N MI355X (one process per GPU).
+
+Metric (BASELINE.json): pages/sec (detect+segment+inpaint+upscale) 1024x1536 @1/2/4/8 MI355X.
+A "step" is one synthetic 1024x1536 page through every hot-path stage that is built so far;
+`config.stages` names exactly which stages ran inside the timed region (stages not listed there
+are NOT implemented yet and therefore NOT counted — see DESIGN.md "bench scope").
+Pages are resident in HBM before the timed region (decode/encode excluded).
+Pages are independent units: rank r processes its own pages, no data-path collective; the only
+collective is the start-up weight broadcast over RCCL (outside the timed region).
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1536)
+    ap.add_argument("--stages", default="all", help="comma list of: upscale (default: every built stage)")
+    ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def broadcast_state_dict(sd, rank, world, device):
+    """Rank 0 owns the checkpoint; one flat RCCL broadcast over xGMI hands it to every rank."""
+    import torch.distributed as dist
+    keys = sorted(sd.keys())
+    shapes = [tuple(sd[k].shape) for k in keys]
+    sizes = [int(torch.tensor(s).prod().item()) if len(s) else 1 for s in shapes]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    if rank == 0:
+        flat.copy_(torch.cat([sd[k].float().reshape(-1) for k in keys]).to(device))
+    dist.broadcast(flat, src=0)
+    out, off = {}, 0
+    flat = flat.cpu()
+    for k, s, n in zip(keys, shapes, sizes):
+        out[k] = flat[off:off + n].view(s).clone()
+        off += n
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from mangatranslator_amd.hip.lib import get_library
+    from mangatranslator_amd.core.ml.rcan import RCANUpscaler
+    from mangatranslator_amd.utils.synthetic_pages import make_page
+    from oracle.rcan_ref import make_state_dict   # synthetic checkpoint generator (no real weights offline)
+
+    lib = get_library()
+    lib.init(local_rank)
+
+    # ---- models: rank 0 "reads" the checkpoints, everyone else receives them over RCCL ----------
+    lite = args.upscale_model == "model_lite"
+    if lite:   # assumed Fast_RCAN_PU shape (pixel-unshuffle variant); real hyper-parameters come from the file
+        rcan_cfg = dict(n_feats=64, n_resgroups=4, n_resblocks=8, unshuffle=2)
+    else:      # canonical RCAN: 10 groups x 20 RCAB x 64 feats
+        rcan_cfg = dict(n_feats=64, n_resgroups=10, n_resblocks=20, unshuffle=1)
+    sd = make_state_dict(seed=7, **rcan_cfg) if (rank == 0 or world == 1) else None
+    if world > 1:
+        if rank != 0:
+            sd = {k: torch.empty_like(v) for k, v in make_state_dict(seed=0, **rcan_cfg).items()}
+        sd = broadcast_state_dict(sd, rank, world, device)
+    upscaler = RCANUpscaler(sd, device=device, lib=lib, graph=not args.no_graph)
+
+    # ---- synthetic pages, resident in HBM ----------------------------------------------------
+    W_, H_ = args.width, args.height
+    pool = 2
+    pages = []
+    for i in range(pool):
+        pg, boxes, regions = make_page(rank * 1000 + i, W_, H_)
+        pages.append(torch.from_numpy(pg).to(device))
+    torch.cuda.synchronize()
+
+    stages = ["upscale"]
+    outs = [None]
+
+    def step(i):
+        outs[0] = upscaler.upscale_u8(pages[i % pool])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pages_per_s = world * args.steps / dt
+
+    result = {
+        "metric": "pages/sec (detect+segment+inpaint+upscale) 1024x1536",
+        "value": pages_per_s, "unit": "pages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"{W_}x{H_} synthetic pages, one page per step per GPU, HBM-resident input",
+                   "stages": stages,
+                   "stages_not_built_yet": ["detect(YOLO)", "segment(SAM-2.1)", "inpaint(FLUX)"],
+                   "upscaler": {"arch": "RCAN", **rcan_cfg, "weights": "seeded random (no checkpoint offline)"},
+                   "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: 3x3 conv 64->64 at page resolution ---------------
+        u = upscaler.hp["unshuffle"]
+        plan = upscaler.plan_for(1, H_, W_)
+        idx = plan.labels.index("g0b0.conv1")
+        iters = 20
+        plan.time_range(idx, idx, 3)
+        ms = plan.time_range(idx, idx, iters)
+        work = upscaler.work(H_, W_)
+        gbs = work["conv64_bytes"] / (ms * 1e-3) / 1e9
+        tfs = work["conv64_flops"] / (ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": "conv2d_nhwc_kernel<f16,3,1> 64->64 @%dx%d" % (W_ // u, H_ // u),
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": None, "avg_launch_ms": ms, "launches_per_page": work["n_conv64"],
+            "algorithmic_bytes_per_launch": work["conv64_bytes"],
+            "mfma_tflops": tfs, "mfma_frac": tfs / MFMA_PEAK_TFLOPS,
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, W_, H_)
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, W_, H_):
+    """The oracle (CPU restatement, fp32 torch) timed on a bounded crop of the same page."""
+    from oracle.rcan_ref import load_ref
+    from mangatranslator_amd.utils.synthetic_pages import make_page
+    ref = load_ref(sd)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pg, _, _ = make_page(0, W_, H_)
+    ch, cw = 192, 128
+    x = torch.from_numpy(pg[:ch, :cw]).permute(2, 0, 1)[None].float() / 255.0
+    ref(x[:, :, :32, :32])
+    t0 = time.perf_counter()
+    ref(x)
+    dt = time.perf_counter() - t0
+    frac = (ch * cw) / float(W_ * H_)
+    return {"value": frac / dt, "unit": "pages/s", "cores": cores, "kind": "port",
+            "sample": f"oracle RCAN (torch fp32 CPU) on a {cw}x{ch} crop = {frac:.4f} page, {dt:.2f} s, upscale stage only"}
+
+
+if __name__ == "__main__":
+    main()

@@ -199,6 +199,9 @@ class RCANUpscaler:
         pb.image_convert(abi.IMG_NHWC_TO_NCHW_F32, y8.t, y_out, n, oh, ow, 8, mul=inv,
                          add=[v * inv for v in self.add_bias], label="to_nchw")
         y_u8 = pb.buf((n, oh, ow, 3), torch.uint8)
+        # tensor_to_image fused: clamp(0,1)*255 truncated to uint8 HWC (image_utils.py:361-366)
+        pb.image_convert(abi.IMG_NHWC_TO_HWC_U8, y8.t, y_u8, n, oh, ow, 8, mul=inv,
+                         add=[v * inv for v in self.add_bias], label="to_u8")
         plan = pb.build()
         plan.x_in, plan.y_out, plan.y8, plan.y_u8 = x_in, y_out, y8, y_u8
         plan.out_scale = (inv, [v * inv for v in self.add_bias])
@@ -222,6 +225,18 @@ class RCANUpscaler:
             plan.x_in.copy_(x.to(device=self.device, dtype=torch.float32))
             plan.run(graph=self._graph)
             return plan.y_out.clone()
+
+    @torch.no_grad()
+    def upscale_u8(self, page_u8: torch.Tensor) -> torch.Tensor:
+        """[H,W,3] uint8 page (device or host) -> [sH,sW,3] uint8 on the device: image_to_tensor,
+        model and tensor_to_image of the reference in one native plan run."""
+        h, w, _ = page_u8.shape
+        plan = self.plan_for(1, h, w)
+        with self._lock:
+            x = page_u8.to(self.device).permute(2, 0, 1).unsqueeze(0).to(torch.float32) / 255.0
+            plan.x_in.copy_(x)
+            plan.run(graph=self._graph)
+            return plan.y_u8[0].clone()
 
     def to(self, *a, **k):
         return self

@@ -1,0 +1,274 @@
+"""Op-level parity checks of libmtx_hip against plain torch fp32 references of the same op.
+
+Written once, run twice: on the CPU kernel simulator (tests/test_ops_sim.py, `-m "not gpu"`)
+to validate kernel index arithmetic, and on a real MI355X through the product library
+(tests/test_ops_gpu.py, `-m gpu`).  All calls go through the C ABI.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from mangatranslator_amd.hip import abi
+from mangatranslator_amd.hip.plan import Act, PlanBuilder
+
+TD = {abi.BF16: torch.bfloat16, abi.F16: torch.float16}
+TOL = {abi.BF16: 2.5e-2, abi.F16: 4e-3}   # relative to output scale; inputs are rounded to T first
+
+
+def _dev(lib):
+    return torch.device("cpu") if lib.is_simulator else torch.device("cuda:0")
+
+
+def _sync(lib):
+    if not lib.is_simulator:
+        torch.cuda.synchronize()
+
+
+def _relerr(y, ref):
+    return ((y.float() - ref.float()).abs().max() / ref.float().abs().max().clamp_min(1e-6)).item()
+
+
+def _run(pb):
+    plan = pb.build()
+    plan.run()
+    _sync(pb.lib)
+    return plan
+
+
+def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, with_res=False,
+               pixel_shuffle=0, with_sum=False, ldx_extra=0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = torch.randn(n, h, w, cin, generator=g)
+    wt = torch.randn(cout, cin, ksize, ksize, generator=g) / math.sqrt(cin * ksize * ksize)
+    b = torch.randn(cout, generator=g)
+    xq, wq = x.to(td).float(), wt.to(td).float()
+    ref = F.conv2d(xq.permute(0, 3, 1, 2), wq, b, stride=stride, padding=ksize // 2)
+    if act == abi.ACT_RELU:
+        ref = F.relu(ref)
+    elif act == abi.ACT_SILU:
+        ref = F.silu(ref)
+    elif act == abi.ACT_LEAKY:
+        ref = F.leaky_relu(ref, 0.1)
+    act_sum = ref.sum(dim=(2, 3)) if with_sum else None
+    if pixel_shuffle:
+        ref = F.pixel_shuffle(ref, pixel_shuffle)
+    res = None
+    if with_res:
+        res = torch.randn(ref.shape, generator=g).to(td).float()
+        ref = ref + 0.5 * res
+    ref = ref.permute(0, 2, 3, 1)
+
+    pb = PlanBuilder(lib, dev, dtype)
+    xb = pb.act(n, h, w, cin, ld=cin + ldx_extra)
+    xb.t[..., :cin] = xq.to(td)
+    if ldx_extra:
+        xb.t[..., cin:] = 7.0   # garbage in the unused channels must not leak
+    wp = wt
+    bp = b
+    if pixel_shuffle:
+        c = cout // 4
+        wp = wt.view(c, 4, cin, ksize, ksize).permute(1, 0, 2, 3, 4).reshape(cout, cin, ksize, ksize)
+        bp = b.view(c, 4).t().reshape(-1)
+    wpk = pb.const(wp.permute(0, 2, 3, 1).reshape(cout, ksize * ksize, cin), td)
+    bias = pb.const(bp, torch.float32)
+    rb = None
+    if with_res:
+        rb = pb.act(ref.shape[0], ref.shape[1], ref.shape[2], ref.shape[3])
+        rb.t.copy_(res.permute(0, 2, 3, 1).to(td))
+    cs = None
+    if with_sum:
+        tiles = pb.conv_tiles(xb, ksize, stride)
+        cs = pb.buf((n, tiles, cout), torch.float32, zero=True)
+    y = pb.conv2d(xb, wpk, bias, cout, ksize, stride, act=act, act_param=0.1, res=rb, res_scale=0.5,
+                  pixel_shuffle=pixel_shuffle, chan_sum=cs)
+    _run(pb)
+    err = _relerr(y.torch().cpu(), ref)
+    assert err < TOL[dtype], f"conv mismatch rel err {err}"
+    if with_sum:
+        s = cs.sum(dim=1).cpu()
+        e2 = ((s - act_sum).abs().max() / act_sum.abs().max()).item()
+        assert e2 < TOL[dtype], f"chan_sum mismatch {e2}"
+    return err
+
+
+def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=False, with_gate=False,
+               out_f32=False, batch=1, alpha=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    a = torch.randn(batch, m, k, generator=g).to(td)
+    w = (torch.randn(batch, n, k, generator=g) / math.sqrt(k)).to(td)
+    b = torch.randn(n, generator=g) if with_bias else None
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float()) * alpha
+    if b is not None:
+        ref = ref + b
+    if act == abi.ACT_GELU:
+        ref = F.gelu(ref)
+    elif act == abi.ACT_GELU_TANH:
+        ref = F.gelu(ref, approximate="tanh")
+    elif act == abi.ACT_SILU:
+        ref = F.silu(ref)
+    gate = res = None
+    rows_per = max(m // 2, 1)
+    if with_gate:
+        gate = torch.randn((m + rows_per - 1) // rows_per, n, generator=g).to(td)
+        ref = ref * gate.float().repeat_interleave(rows_per, dim=0)[:m]
+    if with_res:
+        res = torch.randn(batch, m, n, generator=g).to(td)
+        ref = ref + res.float()
+    pb = PlanBuilder(lib, dev, dtype)
+    at, wt = pb.const(a), pb.const(w)
+    out = pb.gemm(at, wt, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
+                  res=pb.const(res) if res is not None else None,
+                  gate=pb.const(gate) if gate is not None else None, gate_rows_per=rows_per,
+                  alpha=alpha, batch=batch, a_bs=m * k, w_bs=n * k, c_bs=m * n, out_f32=out_f32)
+    _run(pb)
+    err = _relerr(out.cpu().view(batch, m, n), ref)
+    assert err < TOL[dtype], f"gemm mismatch rel err {err}"
+    return err
+
+
+def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    q = torch.randn(batch, sq, heads, d, generator=g).to(td)
+    k = torch.randn(batch, sk, heads, d, generator=g).to(td)
+    v = torch.randn(batch, sk, heads, d, generator=g).to(td)
+    scale = 1.0 / math.sqrt(d)
+    ref = F.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2),
+                                         v.float().transpose(1, 2), scale=scale).transpose(1, 2)
+    pb = PlanBuilder(lib, dev, dtype)
+    qt, kt, vt = pb.const(q), pb.const(k), pb.const(v)
+    o = pb.buf((batch, sq, heads, d), td, zero=True)
+    pb.attention(qt, kt, vt, o, batch, heads, sq, sk, d,
+                 (sq * heads * d, heads * d, d), (sk * heads * d, heads * d, d),
+                 (sk * heads * d, heads * d, d), (sq * heads * d, heads * d, d), scale)
+    _run(pb)
+    err = _relerr(o.cpu(), ref)
+    assert err < TOL[dtype] * 1.5, f"attention mismatch rel err {err}"
+    return err
+
+
+def check_norm(lib, dtype, rows, c, kind=0, affine=True, modulate=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = (torch.randn(rows, c, generator=g) * 2 + 0.5).to(td)
+    gamma = torch.randn(c, generator=g) if affine else None
+    beta = torch.randn(c, generator=g) if (affine and kind == 0) else None
+    xf = x.float()
+    if kind == 0:
+        ref = F.layer_norm(xf, (c,), gamma, beta, 1e-6)
+    else:
+        ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+        if gamma is not None:
+            ref = ref * gamma
+    ms = mh = None
+    rows_per = max(rows // 2, 1)
+    if modulate:
+        nm = (rows + rows_per - 1) // rows_per
+        ms = torch.randn(nm, c, generator=g).to(td)
+        mh = torch.randn(nm, c, generator=g).to(td)
+        ref = ref * (1 + ms.float().repeat_interleave(rows_per, 0)[:rows]) + mh.float().repeat_interleave(rows_per, 0)[:rows]
+    pb = PlanBuilder(lib, dev, dtype)
+    xt = pb.const(x)
+    y = pb.buf((rows, c), td)
+    pb.norm(xt, y, rows, c, gamma=pb.const(gamma) if gamma is not None else None,
+            beta=pb.const(beta) if beta is not None else None, eps=1e-6, kind=kind,
+            mod_scale=pb.const(ms) if ms is not None else None, mod_shift=pb.const(mh) if mh is not None else None,
+            rows_per=rows_per if modulate else 0, ldmod=c if modulate else 0)
+    _run(pb)
+    err = _relerr(y.cpu(), ref)
+    assert err < TOL[dtype], f"norm mismatch rel err {err}"
+    return err
+
+
+def check_groupnorm(lib, dtype, n, h, w, c, groups, silu=True, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = (torch.randn(n, h, w, c, generator=g) * 1.5 + 0.3).to(td)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    ref = F.group_norm(x.float().permute(0, 3, 1, 2), groups, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    pb = PlanBuilder(lib, dev, dtype)
+    xa = pb.act(n, h, w, c)
+    xa.t.copy_(x)
+    y = pb.groupnorm(xa, pb.const(gamma), pb.const(beta), groups, 1e-6, abi.ACT_SILU if silu else abi.ACT_NONE)
+    _run(pb)
+    err = _relerr(y.torch().cpu(), ref)
+    assert err < TOL[dtype], f"groupnorm mismatch rel err {err}"
+    return err
+
+
+def check_ew(lib, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    n, h, w, c = 2, 5, 7, 24
+    a = torch.randn(n, h, w, c, generator=g).to(td)
+    b = torch.randn(n, h, w, c, generator=g).to(td)
+    s = torch.rand(n, c, generator=g)
+    pb = PlanBuilder(lib, dev, dtype)
+    A, B = pb.act(n, h, w, c), pb.act(n, h, w, c)
+    A.t.copy_(a); B.t.copy_(b)
+    y1 = pb.ew(abi.EW_SCALE_RES, A, b=B, s=pb.const(s), lds=c)
+    y2 = pb.ew(abi.EW_UPSAMPLE2X, A)
+    y3 = pb.ew(abi.EW_MAXPOOL, A, i0=5, i1=1)
+    y4 = pb.ew(abi.EW_MAXPOOL, A, i0=2, i1=2)
+    y5 = pb.ew(abi.EW_ADD, A, b=B, act=abi.ACT_SILU)
+    gs = torch.randn(n, c, generator=g).to(td)
+    y6 = pb.ew(abi.EW_GATE_RES, A, b=B, s=pb.const(gs), lds=c)
+    _run(pb)
+    af, bf = a.float(), b.float()
+    assert _relerr(y1.torch().cpu(), af * s[:, None, None, :] + bf) < TOL[dtype]
+    assert _relerr(y2.torch().cpu(), af.repeat_interleave(2, 1).repeat_interleave(2, 2)) < 1e-6
+    mp = F.max_pool2d(af.permute(0, 3, 1, 2), 5, 1, 2).permute(0, 2, 3, 1)
+    assert _relerr(y3.torch().cpu(), mp) < 1e-6
+    mp2 = F.max_pool2d(af.permute(0, 3, 1, 2), 2, 2, 1).permute(0, 2, 3, 1)
+    assert y4.torch().shape == mp2.shape and _relerr(y4.torch().cpu(), mp2) < 1e-6
+    assert _relerr(y5.torch().cpu(), F.silu(af + bf)) < TOL[dtype]
+    assert _relerr(y6.torch().cpu(), bf + af * gs.float()[:, None, None, :]) < TOL[dtype]
+
+
+def check_resize_threshold(lib, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev = _dev(lib)
+    src = torch.randn(3, 16, 16, generator=g)
+    hd, wd = 37, 29
+    ref = F.interpolate(src[None], (hd, wd), mode="bilinear", align_corners=False)[0] > 0.0
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    st = pb.const(src)
+    dst = pb.buf((3, hd, wd), torch.uint8, zero=True)
+    pb.resize_threshold(st, dst, 3, 16, 16, hd, wd, 0.0, abi.F32)
+    _run(pb)
+    mism = (dst.cpu().bool() != ref).float().mean().item()
+    # ties at exactly 0 are measure-zero; interpolation order differences may flip ~1e-7 logits
+    assert mism < 2e-3, f"mask mismatch fraction {mism}"
+    return mism
+
+
+def check_image_convert(lib, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = torch.rand(1, 3, 6, 8, generator=g)
+    pb = PlanBuilder(lib, dev, dtype)
+    xt = pb.const(x)
+    a = pb.act(1, 3, 4, 16)
+    pb.image_convert(abi.IMG_NCHW_F32_TO_NHWC, xt, a.t, 1, 6, 8, 16, unshuffle=2, mul=2.0, add=(0.1, 0.2, 0.3))
+    b = pb.act(1, 6, 8, 8)
+    pb.image_convert(abi.IMG_NCHW_F32_TO_NHWC, xt, b.t, 1, 6, 8, 8, unshuffle=1, mul=1.0, add=(0, 0, 0))
+    back = pb.buf((1, 3, 6, 8), torch.float32)
+    pb.image_convert(abi.IMG_NHWC_TO_NCHW_F32, b.t, back, 1, 6, 8, 8, mul=1.0, add=(0, 0, 0))
+    u8 = pb.buf((1, 6, 8, 3), torch.uint8)
+    pb.image_convert(abi.IMG_NHWC_TO_HWC_U8, b.t, u8, 1, 6, 8, 8, mul=1.0, add=(0, 0, 0))
+    _run(pb)
+    add = torch.tensor([0.1, 0.2, 0.3]).view(1, 3, 1, 1)
+    ref = F.pixel_unshuffle(x * 2.0 + add, 2).permute(0, 2, 3, 1)
+    assert _relerr(a.t.cpu()[..., :12], ref) < TOL[dtype]
+    assert a.t.cpu()[..., 12:].abs().max() == 0
+    assert _relerr(back.cpu(), x) < TOL[dtype]
+    xq = x.to(td).float()
+    ref8 = (xq.permute(0, 2, 3, 1).clamp(0, 1) * 255).to(torch.uint8)
+    assert (u8.cpu().int() - ref8.int()).abs().max() <= 0

@@ -1,0 +1,93 @@
+"""GPU tier: op-level parity of libmtx_hip.so (through the C ABI) against torch fp32 on MI355X."""
+import pytest
+
+import op_checks as oc
+from mangatranslator_amd.hip import abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])
+@pytest.mark.parametrize("cfg", [
+    dict(n=1, h=20, w=19, cin=64, cout=64, ksize=3, stride=1, act=abi.ACT_RELU),
+    dict(n=2, h=9, w=33, cin=16, cout=24, ksize=3, stride=1, with_res=True),
+    dict(n=1, h=17, w=18, cin=72, cout=136, ksize=3, stride=1, act=abi.ACT_SILU, ldx_extra=8),
+    dict(n=1, h=21, w=35, cin=48, cout=96, ksize=3, stride=2, act=abi.ACT_SILU),
+    dict(n=1, h=16, w=16, cin=128, cout=64, ksize=1, stride=1, act=abi.ACT_LEAKY),
+    dict(n=1, h=10, w=18, cin=32, cout=128, ksize=3, stride=1, pixel_shuffle=2, with_res=True),
+    dict(n=2, h=18, w=20, cin=64, cout=64, ksize=3, stride=1, with_sum=True, act=abi.ACT_RELU),
+    # page-scale shapes
+    dict(n=1, h=384, w=256, cin=64, cout=64, ksize=3, stride=1, with_res=True, with_sum=True),
+    dict(n=1, h=200, w=136, cin=192, cout=384, ksize=3, stride=2, act=abi.ACT_SILU),
+    dict(n=1, h=100, w=68, cin=576, cout=192, ksize=1, stride=1, act=abi.ACT_SILU),
+])
+def test_conv(hip_lib, dtype, cfg):
+    oc.check_conv(hip_lib, dtype, **cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(m=130, n=136, k=72, act=abi.ACT_GELU),
+    dict(m=64, n=20, k=144, with_res=True, with_gate=True),
+    dict(m=200, n=260, k=200, act=abi.ACT_GELU_TANH, out_f32=True),
+    dict(m=40, n=48, k=64, batch=3, alpha=0.5, with_bias=False),
+    dict(m=4096, n=1728, k=576, act=abi.ACT_GELU, with_res=True),
+    dict(m=8704, n=3072, k=3072, with_gate=True, with_res=True),
+    dict(m=65536, n=432, k=144),
+])
+def test_gemm(hip_lib, cfg):
+    oc.check_gemm(hip_lib, abi.BF16, **cfg)
+
+
+def test_gemm_f16(hip_lib):
+    oc.check_gemm(hip_lib, abi.F16, m=96, n=72, k=96, with_res=True)
+    oc.check_gemm(hip_lib, abi.F16, m=1000, n=512, k=1024)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(batch=1, heads=2, sq=70, sk=150, d=72),
+    dict(batch=2, heads=1, sq=16, sk=16, d=32),
+    dict(batch=1, heads=1, sq=130, sk=64, d=128),
+    dict(batch=1, heads=3, sq=9, sk=100, d=16),
+    dict(batch=1, heads=2, sq=64, sk=64, d=64),
+    dict(batch=16, heads=8, sq=256, sk=256, d=72),
+    dict(batch=1, heads=8, sq=4096, sk=4096, d=72),
+    dict(batch=1, heads=4, sq=2500, sk=2500, d=128),
+    dict(batch=64, heads=2, sq=64, sk=64, d=72),
+])
+def test_attention(hip_lib, cfg):
+    oc.check_attention(hip_lib, abi.BF16, **cfg)
+
+
+def test_attention_f16(hip_lib):
+    oc.check_attention(hip_lib, abi.F16, batch=1, heads=1, sq=33, sk=75, d=72)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(rows=7, c=144, kind=0),
+    dict(rows=5, c=3072, kind=0, affine=False, modulate=True),
+    dict(rows=9, c=128, kind=1),
+    dict(rows=3, c=1152, kind=0),
+    dict(rows=8704, c=3072, kind=0, affine=False, modulate=True),
+])
+def test_norm(hip_lib, cfg):
+    oc.check_norm(hip_lib, abi.BF16, **cfg)
+
+
+def test_groupnorm(hip_lib):
+    oc.check_groupnorm(hip_lib, abi.BF16, n=2, h=9, w=11, c=128, groups=32)
+    oc.check_groupnorm(hip_lib, abi.F16, n=1, h=40, w=30, c=256, groups=32, silu=False)
+    oc.check_groupnorm(hip_lib, abi.BF16, n=1, h=128, w=96, c=512, groups=32)
+
+
+def test_elementwise(hip_lib):
+    oc.check_ew(hip_lib, abi.BF16)
+    oc.check_ew(hip_lib, abi.F16)
+
+
+def test_resize_threshold(hip_lib):
+    oc.check_resize_threshold(hip_lib)
+
+
+def test_image_convert(hip_lib):
+    oc.check_image_convert(hip_lib, abi.F16)
+    oc.check_image_convert(hip_lib, abi.BF16)

@@ -1,0 +1,81 @@
+"""CPU tier: the gfx950 kernel sources, compiled for the host by tests/emu (SIMT simulator),
+checked op by op against torch fp32.  Validates indexing (halo tiles, swizzles, MFMA fragment
+maps, epilogues) where no GPU exists; the same checks run on hardware in test_ops_gpu.py."""
+import pytest
+
+import op_checks as oc
+from mangatranslator_amd.hip import abi
+
+
+@pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])
+@pytest.mark.parametrize("cfg", [
+    dict(n=1, h=20, w=19, cin=64, cout=64, ksize=3, stride=1, act=abi.ACT_RELU),
+    dict(n=2, h=9, w=33, cin=16, cout=24, ksize=3, stride=1, with_res=True),
+    dict(n=1, h=17, w=18, cin=72, cout=136, ksize=3, stride=1, act=abi.ACT_SILU, ldx_extra=8),
+    dict(n=1, h=21, w=35, cin=48, cout=96, ksize=3, stride=2, act=abi.ACT_SILU),
+    dict(n=1, h=16, w=16, cin=128, cout=64, ksize=1, stride=1, act=abi.ACT_LEAKY),
+    dict(n=1, h=10, w=18, cin=32, cout=128, ksize=3, stride=1, pixel_shuffle=2, with_res=True),
+    dict(n=2, h=18, w=20, cin=64, cout=64, ksize=3, stride=1, with_sum=True, act=abi.ACT_RELU),
+])
+def test_conv(emu_lib, dtype, cfg):
+    if dtype == abi.F16 and cfg.get("stride") == 2:
+        pytest.skip("one dtype is enough for the slow stride-2 case")
+    oc.check_conv(emu_lib, dtype, **cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(m=130, n=136, k=72, act=abi.ACT_GELU),
+    dict(m=64, n=20, k=144, with_res=True, with_gate=True),
+    dict(m=200, n=260, k=200, act=abi.ACT_GELU_TANH, out_f32=True),
+    dict(m=40, n=48, k=64, batch=3, alpha=0.5, with_bias=False),
+])
+def test_gemm(emu_lib, cfg):
+    oc.check_gemm(emu_lib, abi.BF16, **cfg)
+
+
+def test_gemm_f16(emu_lib):
+    oc.check_gemm(emu_lib, abi.F16, m=96, n=72, k=96, with_res=True)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(batch=1, heads=2, sq=70, sk=150, d=72),
+    dict(batch=2, heads=1, sq=16, sk=16, d=32),
+    dict(batch=1, heads=1, sq=130, sk=64, d=128),
+    dict(batch=1, heads=3, sq=9, sk=100, d=16),
+    dict(batch=1, heads=2, sq=64, sk=64, d=64),
+])
+def test_attention(emu_lib, cfg):
+    oc.check_attention(emu_lib, abi.BF16, **cfg)
+
+
+def test_attention_f16(emu_lib):
+    oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=33, sk=75, d=72)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(rows=7, c=144, kind=0),
+    dict(rows=5, c=3072, kind=0, affine=False, modulate=True),
+    dict(rows=9, c=128, kind=1),
+    dict(rows=3, c=1152, kind=0),
+])
+def test_norm(emu_lib, cfg):
+    oc.check_norm(emu_lib, abi.BF16, **cfg)
+
+
+def test_groupnorm(emu_lib):
+    oc.check_groupnorm(emu_lib, abi.BF16, n=2, h=9, w=11, c=128, groups=32)
+    oc.check_groupnorm(emu_lib, abi.F16, n=1, h=40, w=30, c=256, groups=32, silu=False)
+
+
+def test_elementwise(emu_lib):
+    oc.check_ew(emu_lib, abi.BF16)
+    oc.check_ew(emu_lib, abi.F16)
+
+
+def test_resize_threshold(emu_lib):
+    oc.check_resize_threshold(emu_lib)
+
+
+def test_image_convert(emu_lib):
+    oc.check_image_convert(emu_lib, abi.F16)
+    oc.check_image_convert(emu_lib, abi.BF16)
