@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1536)
-    ap.add_argument("--stages", default="all", help="comma list of: upscale (default: every built stage)")
+    ap.add_argument("--stages", default="all", help="comma list of: segment,upscale (default: every built stage)")
+    ap.add_argument("--boxes", type=int, default=8, help="detections per page (generator ground truth, SURVEY.md §8d)")
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -94,22 +95,47 @@ def main():
         if rank != 0:
             sd = {k: torch.empty_like(v) for k, v in make_state_dict(seed=0, **rcan_cfg).items()}
         sd = broadcast_state_dict(sd, rank, world, device)
-    upscaler = RCANUpscaler(sd, device=device, lib=lib, graph=not args.no_graph)
+    want = ["segment", "upscale"] if args.stages == "all" else [x.strip() for x in args.stages.split(",")]
+    upscaler = RCANUpscaler(sd, device=device, lib=lib, graph=not args.no_graph) if "upscale" in want else None
+    sam = None
+    if "segment" in want:
+        from mangatranslator_amd.core.ml.sam2 import Sam2Hip
+        from oracle.sam2_ref import make_config, make_model
+        if rank == 0 or world == 1:
+            m, sam_cfg = make_model("hiera_large", seed=11)     # facebook/sam2.1-hiera-large geometry, seeded weights
+            sam_sd = {k: v for k, v in m.state_dict().items()}
+            del m
+        else:
+            from transformers import Sam2Model
+            sam_cfg = make_config("hiera_large")
+            with torch.device("meta"):
+                shapes = {k: v.shape for k, v in Sam2Model(sam_cfg).state_dict().items()}
+            sam_sd = {k: torch.empty(s) for k, s in shapes.items()}
+        if world > 1:
+            sam_sd = broadcast_state_dict(sam_sd, rank, world, device)
+        sam = Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=not args.no_graph)
+        del sam_sd
 
     # ---- synthetic pages, resident in HBM ----------------------------------------------------
     W_, H_ = args.width, args.height
     pool = 2
-    pages = []
+    pages, page_boxes = [], []
     for i in range(pool):
-        pg, boxes, regions = make_page(rank * 1000 + i, W_, H_)
+        pg, boxes, regions = make_page(rank * 1000 + i, W_, H_, bubbles=args.boxes)
         pages.append(torch.from_numpy(pg).to(device))
+        page_boxes.append(boxes)
     torch.cuda.synchronize()
 
-    stages = ["upscale"]
-    outs = [None]
+    stages = [st for st in ("segment", "upscale") if st in want]
+    outs = [None, None]
+    stage_s = {st: 0.0 for st in stages}
 
-    def step(i):
-        outs[0] = upscaler.upscale_u8(pages[i % pool])
+    def step(i, timed=False):
+        pg = pages[i % pool]
+        if sam is not None:      # detect is not built yet: the generator's ground-truth boxes stand in
+            outs[0] = sam.segment(pg, page_boxes[i % pool])
+        if upscaler is not None:
+            outs[1] = upscaler.upscale_u8(pg)
 
     def barrier():
         torch.cuda.synchronize()
@@ -138,12 +164,23 @@ def main():
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{W_}x{H_} synthetic pages, one page per step per GPU, HBM-resident input",
                    "stages": stages,
-                   "stages_not_built_yet": ["detect(YOLO)", "segment(SAM-2.1)", "inpaint(FLUX)"],
-                   "upscaler": {"arch": "RCAN", **rcan_cfg, "weights": "seeded random (no checkpoint offline)"},
+                   "stages_not_built_yet": ["detect(YOLO)", "inpaint(FLUX)"],
+                   "boxes_per_page": args.boxes,
+                   "segmenter": {"arch": "SAM-2.1 Hiera-L (HF Sam2Model layout)", "weights": "seeded random"} if sam is not None else None,
+                   "upscaler": {"arch": "RCAN", **rcan_cfg, "weights": "seeded random (no checkpoint offline)"} if upscaler is not None else None,
                    "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL"},
     }
 
-    if rank == 0:
+    if rank == 0 and sam is not None:
+        # per-stage GPU time (HIP events on the launch stream), outside the timed region
+        pre, enc, dec, post = sam.plans(args.boxes, H_, W_)
+        result["config"]["segment_ms"] = {"preprocess": pre.time(5), "encoder": enc.time(5, graph=False),
+                                          "decoder": dec.time(5, graph=False), "upsample_threshold": post.time(5)}
+    if rank == 0 and upscaler is not None:
+        result["config"]["upscale_ms"] = upscaler.plan_for(1, H_, W_).time(3, graph=False)
+    if rank == 0 and upscaler is None:
+        print(json.dumps(result))
+    if rank == 0 and upscaler is not None:
         # ---- roofline of the dominant kernel: 3x3 conv 64->64 at page resolution ---------------
         u = upscaler.hp["unshuffle"]
         plan = upscaler.plan_for(1, H_, W_)
@@ -155,7 +192,7 @@ def main():
         gbs = work["conv64_bytes"] / (ms * 1e-3) / 1e9
         tfs = work["conv64_flops"] / (ms * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "conv2d_nhwc_kernel<f16,3,1> 64->64 @%dx%d" % (W_ // u, H_ // u),
+            "kernel": "conv3x3_c64_kernel<f16> 64->64 @%dx%d" % (W_ // u, H_ // u),
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": ms, "launches_per_page": work["n_conv64"],
             "algorithmic_bytes_per_launch": work["conv64_bytes"],
@@ -174,12 +211,12 @@ def cpu_baseline(sd, W_, H_):
     from oracle.rcan_ref import load_ref
     from mangatranslator_amd.utils.synthetic_pages import make_page
     ref = load_ref(sd)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # small convolutions stop scaling (and thrash) beyond this
     torch.set_num_threads(cores)
     pg, _, _ = make_page(0, W_, H_)
-    ch, cw = 192, 128
+    ch, cw = 96, 64
     x = torch.from_numpy(pg[:ch, :cw]).permute(2, 0, 1)[None].float() / 255.0
-    ref(x[:, :, :32, :32])
+    ref(x[:, :, :16, :16])
     t0 = time.perf_counter()
     ref(x)
     dt = time.perf_counter() - t0

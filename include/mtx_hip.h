@@ -71,6 +71,7 @@ typedef struct mtx_conv2d_args {
   int32_t act; float act_param; float res_scale;
   int32_t pixel_shuffle;
   int32_t dtype;
+  int32_t res_broadcast_n;       /* 1: res has batch 1 and is shared by all n images */
 } mtx_conv2d_args;
 
 /* C[M,N] = epilogue(A[M,K] * W[N,K]^T)   A row stride lda, C row stride ldc (elements).
@@ -83,6 +84,7 @@ typedef struct mtx_gemm_args {
   int64_t m, n, k;
   int64_t lda, ldw, ldc, ldres, ldgate;
   int64_t batch, a_bstride, w_bstride, c_bstride;
+  int64_t res_bstride;           /* batch stride of res (0 = the same res for every batch) */
   int32_t gate_rows_per;
   int32_t act; float act_param; float alpha;   /* acc *= alpha before bias */
   int32_t dtype; int32_t out_dtype;            /* out_dtype: MTX_BF16/F16 (=dtype) or MTX_F32 */
@@ -107,6 +109,7 @@ typedef struct mtx_norm_args {
   const void* mod_scale; const void* mod_shift;
   int64_t rows, c, ldx, ldy, rows_per, ldmod;
   float eps; int32_t kind; int32_t dtype;
+  int32_t act;                   /* activation applied last (Sam2 upscaler: LayerNorm -> GELU) */
 } mtx_norm_args;
 
 /* GroupNorm over NHWC [N, HW, C] with G groups, optional fused SiLU. */
@@ -122,9 +125,13 @@ typedef enum mtx_ew_kind {
   MTX_EW_MUL = 2,         /* y = a * b                                                        */
   MTX_EW_ACT = 3,         /* y = act(a)                                                       */
   MTX_EW_UPSAMPLE2X = 4,  /* nearest 2x: y[n, 2h+i, 2w+j, c] = a[n, h, w, c] (+ b if given)  */
-  MTX_EW_MAXPOOL = 5,     /* k x k, stride s, pad k/2 (i0 = k, i1 = s)                        */
+  MTX_EW_MAXPOOL = 5,     /* k x k, stride s (i0 = k, i1 = s), pad k/2 for odd k, 0 for even k */
   MTX_EW_COPY = 6,        /* strided channel-slice copy                                       */
-  MTX_EW_GATE_RES = 7     /* y = b + a * g[row / rows_per, c]   (DiT gated residual)         */
+  MTX_EW_GATE_RES = 7,    /* y = b + a * g[row / rows_per, c]   (DiT gated residual)         */
+  MTX_EW_ROW_GATHER = 8,  /* y[r, :] = a[idx[r], :], idx = (const int32_t*)s, r < n*h*w       */
+  MTX_EW_IM2COL = 9       /* y[r, tap*C + c] = a[n, oy*s-pad+ky, ox*s-pad+kx, c] (zero outside);
+                             i0 = k, i1 = stride, pad = k/2; optional s = int32 row map
+                             (output row r takes raster output pixel idx[r]); ldy >= k*k*C       */
 } mtx_ew_kind;
 
 typedef struct mtx_ew_args {
@@ -161,13 +168,32 @@ typedef struct mtx_img_args {
 /* bilinear resize of fp32/T logits to page size fused with the >0 threshold
  * (HF Sam2ImageProcessor.post_process_masks, called at core/image/detection.py:507-510). */
 typedef struct mtx_resize_thresh_args {
-  const void* src; uint8_t* dst;    /* src [N, hs, ws] ; dst [N, hd, wd] 0/1 */
+  const void* src; uint8_t* dst;    /* src [N, hs, ws, pix_stride] ; dst [N, hd, wd] 0/1 */
   int64_t n, hs, ws, hd, wd; float thresh; int32_t dtype;
+  int32_t pix_stride;               /* elements between source pixels (0 -> 1) */
+  const int32_t* sel;               /* optional [N]: channel picked per sample */
 } mtx_resize_thresh_args;
+
+/* SAM-2.1 single-mask selection (transformers Sam2MaskDecoder._dynamic_multimask_via_stability,
+ * modeling_sam2.py:1265-1311): per box, stability = |logit0 > +delta| / |logit0 > -delta|;
+ * sel = 0 if stability >= thresh else 1 + argmax(iou[1:4]).  logits fp32 [N, pix, 4].        */
+typedef struct mtx_mask_select_args {
+  const float* logits; const float* iou; int32_t* counts /* [N][2] scratch */; int32_t* sel /* [N] */;
+  int64_t n, pix; float delta, thresh;
+} mtx_mask_select_args;
+
+/* antialiased bilinear resize of a uint8 HWC page to (oh, ow), rounded to uint8 levels, then
+ * (x/255 - mean[c]) / std[c] into NHWC T with c_pad channels (Sam2ImageProcessor,
+ * image_processing_sam2.py:370-380; called at core/image/detection.py:494-495).             */
+typedef struct mtx_preproc_args {
+  const uint8_t* src; void* dst;
+  int64_t h, w, oh, ow; int32_t c_pad; float mean[3]; float std[3]; int32_t dtype;
+} mtx_preproc_args;
 
 typedef enum mtx_op_kind {
   MTX_OP_CONV2D = 1, MTX_OP_GEMM = 2, MTX_OP_ATTN = 3, MTX_OP_NORM = 4, MTX_OP_GROUPNORM = 5,
-  MTX_OP_EW = 6, MTX_OP_CA = 7, MTX_OP_IMG = 8, MTX_OP_RESIZE_THRESH = 9, MTX_OP_MEMSET = 10
+  MTX_OP_EW = 6, MTX_OP_CA = 7, MTX_OP_IMG = 8, MTX_OP_RESIZE_THRESH = 9, MTX_OP_MEMSET = 10,
+  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12
 } mtx_op_kind;
 
 typedef struct mtx_memset_args { void* ptr; int64_t bytes; int32_t value; } mtx_memset_args;
@@ -177,7 +203,7 @@ typedef struct mtx_op {
   union {
     mtx_conv2d_args conv; mtx_gemm_args gemm; mtx_attn_args attn; mtx_norm_args norm;
     mtx_groupnorm_args gn; mtx_ew_args ew; mtx_ca_args ca; mtx_img_args img;
-    mtx_resize_thresh_args rt; mtx_memset_args ms;
+    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre;
   } u;
 } mtx_op;
 
@@ -199,6 +225,8 @@ MTX_API int mtx_elementwise(const mtx_ew_args* a, void* stream);
 MTX_API int mtx_channel_attention(const mtx_ca_args* a, void* stream);
 MTX_API int mtx_image_convert(const mtx_img_args* a, void* stream);
 MTX_API int mtx_resize_threshold(const mtx_resize_thresh_args* a, void* stream);
+MTX_API int mtx_mask_select(const mtx_mask_select_args* a, void* stream);
+MTX_API int mtx_preprocess(const mtx_preproc_args* a, void* stream);
 
 /* ---- plans: a network forward as one native call ----------------------------------------- */
 MTX_API int mtx_plan_create(const mtx_op* ops, int n_ops, void** plan);

@@ -30,6 +30,7 @@ struct ConvParams {
   int ldx, ldy, ldres;
   int act; float act_param; float res_scale;
   int ps;           // pixel shuffle factor (0 or 2)
+  int res_bcast;
   int tiles_x, tiles_y, nblk;
 };
 
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
           for (int e = 0; e < 8; ++e) csum[e] += f[e];
         }
         if (p.res != nullptr) {
-          const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + (opix * (size_t)p.ldres + oc) * sizeof(T));
+          const size_t rpix = p.res_bcast ? opix - (size_t)img * (p.ps == 2 ? 4 : 1) * (size_t)p.ho * (size_t)p.wo : opix;
+          const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + (rpix * (size_t)p.ldres + oc) * sizeof(T));
           float g8[8];
           unpack8<T>(rr, g8);
 #pragma unroll
@@ -256,7 +258,12 @@ static bool conv_geometry(const mtx_conv2d_args* a, ConvParams& p, int& tiles) {
   return true;
 }
 
+int conv_c64_tiles(int n, int h, int w);
+bool conv_c64_applicable(const mtx_conv2d_args* a);
+int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err);
+
 int conv2d_tiles(const mtx_conv2d_args* a) {
+  if (conv_c64_applicable(a)) return conv_c64_tiles(a->n, a->h, a->w_in);
   ConvParams p; int tiles = 0;
   if (!conv_geometry(a, p, tiles)) return -1;
   return tiles;
@@ -272,11 +279,12 @@ int conv2d_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   }
   if (a->pixel_shuffle != 0 && (a->pixel_shuffle != 2 || (a->cout / 4) % 8)) { *err = "conv2d: pixel_shuffle must be 2 with Cout/4 % 8 == 0"; return MTX_ERR_INVALID; }
   if (a->n < 1 || a->h < 1 || a->w_in < 1) { *err = "conv2d: empty input"; return MTX_ERR_INVALID; }
+  if (conv_c64_applicable(a)) return conv_c64_launch(a, stream, err);
   p.x = (const unsigned char*)a->x; p.w = (const unsigned char*)a->w; p.bias = a->bias;
   p.res = (const unsigned char*)a->res; p.y = (unsigned char*)a->y; p.chan_sum = a->chan_sum;
   p.n = a->n; p.h = a->h; p.w_in = a->w_in; p.cin = a->cin; p.cout = a->cout;
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldres = a->ldres;
-  p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.ps = a->pixel_shuffle;
+  p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.ps = a->pixel_shuffle; p.res_bcast = a->res_broadcast_n;
   int rc;
   if (a->dtype == MTX_BF16) rc = launch_conv_t<__bf16>(a, p, stream, tiles);
   else if (a->dtype == MTX_F16) rc = launch_conv_t<_Float16>(a, p, stream, tiles);

@@ -18,9 +18,39 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
   const int kind = p.kind;
   long oh = p.h, ow = p.w;
   if (kind == MTX_EW_UPSAMPLE2X) { oh = 2 * p.h; ow = 2 * p.w; }
-  if (kind == MTX_EW_MAXPOOL) { const int k = p.i0, s = p.i1, pd = k / 2; oh = (p.h + 2 * pd - k) / s + 1; ow = (p.w + 2 * pd - k) / s + 1; }
-  const long total = p.n * oh * ow * C8;
+  if (kind == MTX_EW_MAXPOOL) { const int k = p.i0, s = p.i1, pd = (k & 1) ? k / 2 : 0; oh = (p.h + 2 * pd - k) / s + 1; ow = (p.w + 2 * pd - k) / s + 1; }
+  if (kind == MTX_EW_IM2COL) { const int k = p.i0, s = p.i1, pd = k / 2; oh = (p.h + 2 * pd - k) / s + 1; ow = (p.w + 2 * pd - k) / s + 1; }
   const T* A = reinterpret_cast<const T*>(p.a);
+  if (kind == MTX_EW_IM2COL) {
+    // one 16-byte chunk per (output row, tap, 8 channels)
+    const int k = p.i0, st = p.i1, pd = k / 2;
+    const long per_row = (long)k * k * C8;
+    const long rows = p.n * oh * ow;
+    const int32_t* map = reinterpret_cast<const int32_t*>(p.s);
+    T* Yo = reinterpret_cast<T*>(p.y);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < rows * per_row; idx += (long)gridDim.x * 256) {
+      const long r = idx / per_row, rem = idx % per_row;
+      const long tap = rem / C8, c = (rem % C8) * 8;
+      const long opix = map ? (long)map[r] : r;
+      const long ox = opix % ow, oy = (opix / ow) % oh, n = opix / (ow * oh);
+      const long iy = oy * st - pd + tap / k, ix = ox * st - pd + tap % k;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) v = *reinterpret_cast<const u32x4*>(A + ((n * p.h + iy) * p.w + ix) * p.lda + c);
+      *reinterpret_cast<u32x4*>(Yo + r * p.ldy + tap * p.c + c) = v;
+    }
+    return;
+  }
+  if (kind == MTX_EW_ROW_GATHER) {
+    const long rows = p.n * p.h * p.w;
+    const int32_t* map = reinterpret_cast<const int32_t*>(p.s);
+    T* Yo = reinterpret_cast<T*>(p.y);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < rows * C8; idx += (long)gridDim.x * 256) {
+      const long r = idx / C8, c = (idx % C8) * 8;
+      *reinterpret_cast<u32x4*>(Yo + r * p.ldy + c) = *reinterpret_cast<const u32x4*>(A + (long)map[r] * p.lda + c);
+    }
+    return;
+  }
+  const long total = p.n * oh * ow * C8;
   const T* Bp = reinterpret_cast<const T*>(p.b);
   const T* Sp = reinterpret_cast<const T*>(p.s);
   T* Y = reinterpret_cast<T*>(p.y);
@@ -36,7 +66,7 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] += g[e]; }
     } else if (kind == MTX_EW_MAXPOOL) {
-      const int k = p.i0, s = p.i1, pd = k / 2;
+      const int k = p.i0, s = p.i1, pd = (k & 1) ? k / 2 : 0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = -3.0e38f;
       for (int dy = 0; dy < k; ++dy) {
@@ -88,8 +118,14 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
   if (a->kind == MTX_EW_MAXPOOL && (a->i0 < 1 || a->i1 < 1)) { *err = "elementwise: maxpool needs kernel/stride"; return MTX_ERR_INVALID; }
   long oh = a->h, ow = a->w;
   if (a->kind == MTX_EW_UPSAMPLE2X) { oh *= 2; ow *= 2; }
-  if (a->kind == MTX_EW_MAXPOOL) { const int pd = a->i0 / 2; oh = (a->h + 2 * pd - a->i0) / a->i1 + 1; ow = (a->w + 2 * pd - a->i0) / a->i1 + 1; }
-  const long total = a->n * oh * ow * (a->c / 8);
+  if (a->kind == MTX_EW_MAXPOOL) { const int pd = (a->i0 & 1) ? a->i0 / 2 : 0; oh = (a->h + 2 * pd - a->i0) / a->i1 + 1; ow = (a->w + 2 * pd - a->i0) / a->i1 + 1; }
+  long total = a->n * oh * ow * (a->c / 8);
+  if (a->kind == MTX_EW_IM2COL) {
+    if (a->i0 < 1 || a->i1 < 1 || a->ldy < (long)a->i0 * a->i0 * a->c) { *err = "elementwise: im2col needs k, stride and ldy >= k*k*C"; return MTX_ERR_INVALID; }
+    const int pd = a->i0 / 2;
+    total = a->n * ((a->h + 2 * pd - a->i0) / a->i1 + 1) * ((a->w + 2 * pd - a->i0) / a->i1 + 1) * (long)a->i0 * a->i0 * (a->c / 8);
+  }
+  if (a->kind == MTX_EW_ROW_GATHER && !a->s) { *err = "elementwise: row_gather needs the index map in s"; return MTX_ERR_INVALID; }
   if (total <= 0) return MTX_OK;
   long blocks = (total + 255) / 256;
   if (blocks > 2048 * 4) blocks = 2048 * 4;
@@ -100,24 +136,36 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
 }
 
 // ---- RCAN channel attention squeeze/excite: one workgroup per image ---------------------------
-__global__ __launch_bounds__(256) void ca_kernel(mtx_ca_args p) {
+__global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
   __shared__ float mean[512];
   __shared__ float hid[128];
+  __shared__ float part[1024];
   const int n = blockIdx.x, tid = threadIdx.x;
-  for (int c = tid; c < p.c; c += 256) {
+  // partial-sum rows are reduced by all 1024 threads: thread -> (row subset, channel)
+  const int per = 1024 / p.c > 0 ? 1024 / p.c : 1;          // row subsets (C <= 512 -> >= 2)
+  {
+    const int c = tid % p.c, sub = tid / p.c;
     float s = 0.f;
-    const float* src = p.chan_sum + (size_t)n * p.tiles * p.c + c;
-    for (int t = 0; t < p.tiles; ++t) s += src[(size_t)t * p.c];
+    if (sub < per) {
+      const float* src = p.chan_sum + (size_t)n * p.tiles * p.c + c;
+      for (int t = sub; t < p.tiles; t += per) s += src[(size_t)t * p.c];
+    }
+    part[tid] = s;
+  }
+  __syncthreads();
+  for (int c = tid; c < p.c; c += 1024) {
+    float s = 0.f;
+    for (int k = 0; k < per; ++k) s += part[k * p.c + c];
     mean[c] = s * p.inv_hw;
   }
   __syncthreads();
-  for (int r = tid; r < p.cr; r += 256) {
+  for (int r = tid; r < p.cr; r += 1024) {
     float s = p.b1 ? p.b1[r] : 0.f;
     for (int c = 0; c < p.c; ++c) s += p.w1[r * p.c + c] * mean[c];
     hid[r] = s > 0.f ? s : 0.f;
   }
   __syncthreads();
-  for (int c = tid; c < p.c; c += 256) {
+  for (int c = tid; c < p.c; c += 1024) {
     float s = p.b2 ? p.b2[c] : 0.f;
     for (int r = 0; r < p.cr; ++r) s += p.w2[c * p.cr + r] * hid[r];
     p.s[(size_t)n * p.c + c] = 1.f / (1.f + __expf(-s));
@@ -127,7 +175,7 @@ __global__ __launch_bounds__(256) void ca_kernel(mtx_ca_args p) {
 int ca_launch(const mtx_ca_args* a, void* stream, const char** err) {
   if (!a->chan_sum || !a->w1 || !a->w2 || !a->s) { *err = "channel_attention: null operand"; return MTX_ERR_INVALID; }
   if (a->c > 512 || a->cr > 128 || a->c < 1 || a->cr < 1) { *err = "channel_attention: C <= 512 and C/r <= 128"; return MTX_ERR_INVALID; }
-  MTX_LAUNCH(ca_kernel, dim3((unsigned)a->n), dim3(256), 0, stream, *a);
+  MTX_LAUNCH(ca_kernel, dim3((unsigned)a->n), dim3(1024), 0, stream, *a);
   return MTX_OK;
 }
 
@@ -206,9 +254,10 @@ __global__ __launch_bounds__(256) void resize_thresh_kernel(mtx_resize_thresh_ar
     if (x0 > p.ws - 1) x0 = p.ws - 1;
     const long y1 = y0 + (y0 < p.hs - 1 ? 1 : 0), x1 = x0 + (x0 < p.ws - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0;
-    const T* base = S + n * p.hs * p.ws;
-    const float v00 = to_f32(base[y0 * p.ws + x0]), v01 = to_f32(base[y0 * p.ws + x1]);
-    const float v10 = to_f32(base[y1 * p.ws + x0]), v11 = to_f32(base[y1 * p.ws + x1]);
+    const long ps = p.pix_stride > 0 ? p.pix_stride : 1;
+    const T* base = S + n * p.hs * p.ws * ps + (p.sel ? p.sel[n] : 0);
+    const float v00 = to_f32(base[(y0 * p.ws + x0) * ps]), v01 = to_f32(base[(y0 * p.ws + x1) * ps]);
+    const float v10 = to_f32(base[(y1 * p.ws + x0) * ps]), v11 = to_f32(base[(y1 * p.ws + x1) * ps]);
     const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
     p.dst[idx] = v > p.thresh ? 1 : 0;
   }
@@ -223,6 +272,100 @@ int resize_thresh_launch(const mtx_resize_thresh_args* a, void* stream, const ch
   else if (a->dtype == MTX_BF16) MTX_LAUNCH((resize_thresh_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
   else if (a->dtype == MTX_F16) MTX_LAUNCH((resize_thresh_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
   else { *err = "resize_threshold: bad dtype"; return MTX_ERR_INVALID; }
+  return MTX_OK;
+}
+
+// ---- SAM-2.1 single-mask selection by stability ----------------------------------------------------
+__global__ __launch_bounds__(256) void mask_count_kernel(mtx_mask_select_args p) {
+  const long n = blockIdx.y;
+  const float* L = p.logits + n * p.pix * 4;
+  int hi = 0, lo = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.pix; i += (long)gridDim.x * 256) {
+    const float v = L[i * 4];
+    hi += v > p.delta ? 1 : 0;
+    lo += v > -p.delta ? 1 : 0;
+  }
+  float fh = wave_sum((float)hi), fl = wave_sum((float)lo);   // <= 2^24 per wave: exact in fp32
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(p.counts + n * 2, (int)fh);
+    atomicAdd(p.counts + n * 2 + 1, (int)fl);
+  }
+}
+__global__ __launch_bounds__(64) void mask_pick_kernel(mtx_mask_select_args p) {
+  const long n = (long)blockIdx.x * 64 + threadIdx.x;
+  if (n >= p.n) return;
+  const float ai = (float)p.counts[n * 2], au = (float)p.counts[n * 2 + 1];
+  const float stab = au > 0.f ? ai / au : 1.0f;
+  int sel = 0;
+  if (!(stab >= p.thresh)) {
+    const float* io = p.iou + n * 4;
+    sel = 1;
+    float best = io[1];
+    if (io[2] > best) { best = io[2]; sel = 2; }
+    if (io[3] > best) { best = io[3]; sel = 3; }
+  }
+  p.sel[n] = sel;
+}
+
+int mask_select_launch(const mtx_mask_select_args* a, void* stream, const char** err) {
+  if (!a->logits || !a->iou || !a->counts || !a->sel) { *err = "mask_select: null operand"; return MTX_ERR_INVALID; }
+  if (a->n < 1 || a->pix < 1) return MTX_OK;
+  if (hipMemsetAsync(a->counts, 0, (size_t)a->n * 2 * sizeof(int), (hipStream_t)stream) != hipSuccess) { *err = "mask_select: memset failed"; return MTX_ERR_HIP; }
+  long bx = (a->pix + 255) / 256; if (bx > 64) bx = 64;
+  MTX_LAUNCH(mask_count_kernel, dim3((unsigned)bx, (unsigned)a->n), dim3(256), 0, stream, *a);
+  MTX_LAUNCH(mask_pick_kernel, dim3((unsigned)((a->n + 63) / 64)), dim3(64), 0, stream, *a);
+  return MTX_OK;
+}
+
+// ---- SAM pre-processing: antialiased bilinear resize (uint8 levels) + normalise -> NHWC T ---------
+// separable triangle filter, torch upsample_bilinear2d_aa indexing (support = max(scale, 1))
+template <typename T>
+__global__ __launch_bounds__(256) void preproc_kernel(mtx_preproc_args p) {
+  const long total = p.oh * p.ow;
+  const float sy = (float)p.h / (float)p.oh, sx = (float)p.w / (float)p.ow;
+  const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
+  const float invy = sy >= 1.f ? 1.f / sy : 1.f, invx = sx >= 1.f ? 1.f / sx : 1.f;
+  T* D = reinterpret_cast<T*>(p.dst);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long ox = idx % p.ow, oy = idx / p.ow;
+    const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
+    long y0 = (long)(cy - supy + 0.5f); if (y0 < 0) y0 = 0;
+    long y1 = (long)(cy + supy + 0.5f); if (y1 > p.h) y1 = p.h;
+    long x0 = (long)(cx - supx + 0.5f); if (x0 < 0) x0 = 0;
+    long x1 = (long)(cx + supx + 0.5f); if (x1 > p.w) x1 = p.w;
+    float wys = 0.f, wxs = 0.f;
+    for (long y = y0; y < y1; ++y) { float t = fabsf(((float)y - cy + 0.5f) * invy); wys += t < 1.f ? 1.f - t : 0.f; }
+    for (long x = x0; x < x1; ++x) { float t = fabsf(((float)x - cx + 0.5f) * invx); wxs += t < 1.f ? 1.f - t : 0.f; }
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (long y = y0; y < y1; ++y) {
+      float ty = fabsf(((float)y - cy + 0.5f) * invy);
+      const float wy = (ty < 1.f ? 1.f - ty : 0.f) / wys;
+      float row[3] = {0.f, 0.f, 0.f};
+      for (long x = x0; x < x1; ++x) {
+        float tx = fabsf(((float)x - cx + 0.5f) * invx);
+        const float wx = (tx < 1.f ? 1.f - tx : 0.f) / wxs;
+        const uint8_t* px = p.src + (y * p.w + x) * 3;
+        row[0] += wx * (float)px[0]; row[1] += wx * (float)px[1]; row[2] += wx * (float)px[2];
+      }
+      acc[0] += wy * row[0]; acc[1] += wy * row[1]; acc[2] += wy * row[2];
+    }
+    T* o = D + idx * p.c_pad;
+    for (int c = 0; c < 3; ++c) {
+      float v = rintf(acc[c]);
+      v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+      o[c] = from_f32<T>((v * (1.0f / 255.0f) - p.mean[c]) / p.std[c]);
+    }
+    for (int c = 3; c < p.c_pad; ++c) o[c] = from_f32<T>(0.f);
+  }
+}
+
+int preproc_launch(const mtx_preproc_args* a, void* stream, const char** err) {
+  if (!a->src || !a->dst) { *err = "preprocess: null operand"; return MTX_ERR_INVALID; }
+  if (a->h < 1 || a->w < 1 || a->oh < 1 || a->ow < 1 || a->c_pad < 3) { *err = "preprocess: bad geometry"; return MTX_ERR_INVALID; }
+  long blocks = (a->oh * a->ow + 255) / 256; if (blocks > 8192) blocks = 8192;
+  if (a->dtype == MTX_BF16) MTX_LAUNCH((preproc_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
+  else if (a->dtype == MTX_F16) MTX_LAUNCH((preproc_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
+  else { *err = "preprocess: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
   return MTX_OK;
 }
 

@@ -17,7 +17,7 @@ namespace mtx {
 struct GemmParams {
   const unsigned char* a; const unsigned char* w; const float* bias; const unsigned char* res;
   const unsigned char* gate; unsigned char* c;
-  long m, n, k, lda, ldw, ldc, ldres, ldgate, a_bs, w_bs, c_bs;
+  long m, n, k, lda, ldw, ldc, ldres, ldgate, a_bs, w_bs, c_bs, res_bs;
   int gate_rows_per, act; float act_param, alpha;
   int out_f32;
   unsigned tiles_m, tiles_n;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             float v = acc[i][j][r] * p.alpha + (p.bias ? p.bias[n] : 0.f);
             v = apply_act(v, p.act, p.act_param);
             if (p.gate) v *= to_f32(reinterpret_cast<const T*>(p.gate)[(size_t)(m / p.gate_rows_per) * p.ldgate + n]);
-            if (p.res) v += to_f32(reinterpret_cast<const T*>(p.res)[(size_t)bz * p.c_bs + (size_t)m * p.ldres + n]);
+            if (p.res) v += to_f32(reinterpret_cast<const T*>(p.res)[(size_t)bz * p.res_bs + (size_t)m * p.ldres + n]);
             Cf[(size_t)m * p.ldc + n] = v;
           }
         }
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       const T* G = reinterpret_cast<const T*>(p.gate);
       const T* R = reinterpret_cast<const T*>(p.res);
       const size_t goff = (size_t)(m / (p.gate_rows_per > 0 ? p.gate_rows_per : 1)) * p.ldgate + n;
-      const size_t roff = (size_t)bz * p.c_bs + (size_t)m * p.ldres + n;
+      const size_t roff = (size_t)bz * p.res_bs + (size_t)m * p.ldres + n;
       if (full) {
         if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + goff), g8);
 #pragma unroll
@@ -188,14 +188,14 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (!a->a || !a->w || !a->c) { *err = "gemm: null operand"; return MTX_ERR_INVALID; }
   if (a->m < 1 || a->n < 1 || a->k < 1) { *err = "gemm: empty problem"; return MTX_ERR_INVALID; }
   if (a->k % 8 || a->lda % 8 || a->ldw % 8) { *err = "gemm: K, lda, ldw must be multiples of 8 (16-byte chunks)"; return MTX_ERR_INVALID; }
-  if (a->batch > 1 && (a->a_bstride % 8 || a->w_bstride % 8 || a->c_bstride % 8)) { *err = "gemm: batch strides must be multiples of 8"; return MTX_ERR_INVALID; }
+  if (a->batch > 1 && (a->a_bstride % 8 || a->w_bstride % 8 || a->c_bstride % 8 || a->res_bstride % 8)) { *err = "gemm: batch strides must be multiples of 8"; return MTX_ERR_INVALID; }
   if (a->out_dtype != a->dtype && a->out_dtype != MTX_F32) { *err = "gemm: out_dtype must equal dtype or be f32"; return MTX_ERR_INVALID; }
   GemmParams p;
   p.a = (const unsigned char*)a->a; p.w = (const unsigned char*)a->w; p.bias = a->bias;
   p.res = (const unsigned char*)a->res; p.gate = (const unsigned char*)a->gate; p.c = (unsigned char*)a->c;
   p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
   p.ldres = a->ldres; p.ldgate = a->ldgate;
-  p.a_bs = a->a_bstride; p.w_bs = a->w_bstride; p.c_bs = a->c_bstride;
+  p.a_bs = a->a_bstride; p.w_bs = a->w_bstride; p.c_bs = a->c_bstride; p.res_bs = a->res_bstride;
   p.gate_rows_per = a->gate_rows_per > 0 ? a->gate_rows_per : 1;
   p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;

@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
       if (MH) { float g[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(MH + mrow * p.ldmod + ch * 8), g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += g[e]; }
+      if (p.act != MTX_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = apply_act(o[e], p.act, 0.f);
+      }
       *reinterpret_cast<u32x4*>(Y + ch * 8) = pack8<T>(o);
     }
   }

@@ -7,10 +7,11 @@ ABI_VERSION = 1
 # enums
 BF16, F16, F32, U8, I32 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_SIGMOID, ACT_LEAKY = range(7)
-(EW_SCALE_RES, EW_ADD, EW_MUL, EW_ACT, EW_UPSAMPLE2X, EW_MAXPOOL, EW_COPY, EW_GATE_RES) = range(8)
+(EW_SCALE_RES, EW_ADD, EW_MUL, EW_ACT, EW_UPSAMPLE2X, EW_MAXPOOL, EW_COPY, EW_GATE_RES,
+ EW_ROW_GATHER, EW_IM2COL) = range(10)
 IMG_NCHW_F32_TO_NHWC, IMG_NHWC_TO_NCHW_F32, IMG_NHWC_TO_HWC_U8, IMG_HWC_U8_TO_NHWC = range(4)
 (OP_CONV2D, OP_GEMM, OP_ATTN, OP_NORM, OP_GROUPNORM, OP_EW, OP_CA, OP_IMG, OP_RESIZE_THRESH,
- OP_MEMSET) = range(1, 11)
+ OP_MEMSET, OP_MASK_SELECT, OP_PREPROC) = range(1, 13)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -21,7 +22,7 @@ class ConvArgs(C.Structure):
                 ("ksize", i32), ("stride", i32),
                 ("ldx", i32), ("ldy", i32), ("ldres", i32),
                 ("act", i32), ("act_param", f32), ("res_scale", f32),
-                ("pixel_shuffle", i32), ("dtype", i32)]
+                ("pixel_shuffle", i32), ("dtype", i32), ("res_broadcast_n", i32)]
 
 
 class GemmArgs(C.Structure):
@@ -29,6 +30,7 @@ class GemmArgs(C.Structure):
                 ("m", i64), ("n", i64), ("k", i64),
                 ("lda", i64), ("ldw", i64), ("ldc", i64), ("ldres", i64), ("ldgate", i64),
                 ("batch", i64), ("a_bstride", i64), ("w_bstride", i64), ("c_bstride", i64),
+                ("res_bstride", i64),
                 ("gate_rows_per", i32),
                 ("act", i32), ("act_param", f32), ("alpha", f32),
                 ("dtype", i32), ("out_dtype", i32)]
@@ -45,7 +47,7 @@ class AttnArgs(C.Structure):
 class NormArgs(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("mod_scale", vp), ("mod_shift", vp),
                 ("rows", i64), ("c", i64), ("ldx", i64), ("ldy", i64), ("rows_per", i64), ("ldmod", i64),
-                ("eps", f32), ("kind", i32), ("dtype", i32)]
+                ("eps", f32), ("kind", i32), ("dtype", i32), ("act", i32)]
 
 
 class GroupNormArgs(C.Structure):
@@ -77,7 +79,17 @@ class ImgArgs(C.Structure):
 class ResizeThreshArgs(C.Structure):
     _fields_ = [("src", vp), ("dst", vp),
                 ("n", i64), ("hs", i64), ("ws", i64), ("hd", i64), ("wd", i64),
-                ("thresh", f32), ("dtype", i32)]
+                ("thresh", f32), ("dtype", i32), ("pix_stride", i32), ("sel", vp)]
+
+
+class MaskSelectArgs(C.Structure):
+    _fields_ = [("logits", vp), ("iou", vp), ("counts", vp), ("sel", vp),
+                ("n", i64), ("pix", i64), ("delta", f32), ("thresh", f32)]
+
+
+class PreprocArgs(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("h", i64), ("w", i64), ("oh", i64), ("ow", i64),
+                ("c_pad", i32), ("mean", f32 * 3), ("std", f32 * 3), ("dtype", i32)]
 
 
 class MemsetArgs(C.Structure):
@@ -87,7 +99,7 @@ class MemsetArgs(C.Structure):
 class _OpUnion(C.Union):
     _fields_ = [("conv", ConvArgs), ("gemm", GemmArgs), ("attn", AttnArgs), ("norm", NormArgs),
                 ("gn", GroupNormArgs), ("ew", EwArgs), ("ca", CaArgs), ("img", ImgArgs),
-                ("rt", ResizeThreshArgs), ("ms", MemsetArgs)]
+                ("rt", ResizeThreshArgs), ("ms", MemsetArgs), ("sel", MaskSelectArgs), ("pre", PreprocArgs)]
 
 
 class Op(C.Structure):
@@ -96,16 +108,18 @@ class Op(C.Structure):
 
 ARG_TYPES = {OP_CONV2D: ConvArgs, OP_GEMM: GemmArgs, OP_ATTN: AttnArgs, OP_NORM: NormArgs,
              OP_GROUPNORM: GroupNormArgs, OP_EW: EwArgs, OP_CA: CaArgs, OP_IMG: ImgArgs,
-             OP_RESIZE_THRESH: ResizeThreshArgs, OP_MEMSET: MemsetArgs}
+             OP_RESIZE_THRESH: ResizeThreshArgs, OP_MEMSET: MemsetArgs,
+             OP_MASK_SELECT: MaskSelectArgs, OP_PREPROC: PreprocArgs}
 UNION_FIELD = {OP_CONV2D: "conv", OP_GEMM: "gemm", OP_ATTN: "attn", OP_NORM: "norm",
                OP_GROUPNORM: "gn", OP_EW: "ew", OP_CA: "ca", OP_IMG: "img",
-               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms"}
+               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms", OP_MASK_SELECT: "sel", OP_PREPROC: "pre"}
 
 # every symbol include/mtx_hip.h declares (tests check the built library exports all of them)
 EXPORTS = [
     "mtx_abi_version", "mtx_abi_sizeof", "mtx_last_error", "mtx_init", "mtx_device_info",
     "mtx_conv2d", "mtx_conv2d_tiles", "mtx_gemm", "mtx_attention", "mtx_norm", "mtx_groupnorm",
     "mtx_elementwise", "mtx_channel_attention", "mtx_image_convert", "mtx_resize_threshold",
+    "mtx_mask_select", "mtx_preprocess",
     "mtx_plan_create", "mtx_plan_run", "mtx_plan_run_graph", "mtx_plan_num_ops",
     "mtx_plan_run_range", "mtx_plan_destroy", "mtx_plan_time", "mtx_plan_time_range",
 ]

@@ -66,8 +66,20 @@ class Plan:
         return C.c_void_p(0)
 
     def run(self, stream=None, graph: bool = False) -> None:
-        fn = self.lib.mtx_plan_run_graph if graph else self.lib.mtx_plan_run
-        self.lib.check(fn(self._h, self._stream(stream)), "mtx_plan_run")
+        if not graph or self.lib.is_simulator:
+            self.lib.check(self.lib.mtx_plan_run(self._h, self._stream(stream)), "mtx_plan_run")
+            return
+        # hipGraph capture/replay needs a non-default stream: use a side stream owned by the
+        # plan, ordered after the caller's current stream and joined back into it.
+        if stream is not None:
+            self.lib.check(self.lib.mtx_plan_run_graph(self._h, C.c_void_p(stream)), "mtx_plan_run_graph")
+            return
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=cur.device)
+        self._side.wait_stream(cur)
+        self.lib.check(self.lib.mtx_plan_run_graph(self._h, C.c_void_p(self._side.cuda_stream)), "mtx_plan_run_graph")
+        cur.wait_stream(self._side)
 
     def run_range(self, first: int, last: int, stream=None) -> None:
         self.lib.check(self.lib.mtx_plan_run_range(self._h, first, last, self._stream(stream)), "mtx_plan_run_range")
@@ -138,7 +150,7 @@ class PlanBuilder:
     def conv2d(self, x: Act, w_packed, bias, cout: int, ksize: int = 3, stride: int = 1,
                act: int = abi.ACT_NONE, act_param: float = 0.0, res: Optional[Act] = None,
                res_scale: float = 1.0, out: Optional[Act] = None, pixel_shuffle: int = 0,
-               chan_sum=None, label: str = "conv") -> Act:
+               chan_sum=None, res_broadcast: bool = False, label: str = "conv") -> Act:
         pad = ksize // 2
         ho = (x.h + 2 * pad - ksize) // stride + 1
         wo = (x.w + 2 * pad - ksize) // stride + 1
@@ -157,6 +169,7 @@ class PlanBuilder:
         a.ldx, a.ldy, a.ldres = x.ld, out.ld, (res.ld if res is not None else 0)
         a.act, a.act_param, a.res_scale = act, act_param, res_scale
         a.pixel_shuffle, a.dtype = pixel_shuffle, self.dtype
+        a.res_broadcast_n = 1 if res_broadcast else 0
         self._add(abi.OP_CONV2D, a, label)
         return out
 
@@ -170,16 +183,18 @@ class PlanBuilder:
 
     def gemm(self, a_t, w_t, m, n, k, lda=None, ldw=None, out=None, ldc=None, bias=None, act=abi.ACT_NONE,
              res=None, ldres=None, gate=None, ldgate=None, gate_rows_per=1, alpha=1.0, batch=1,
-             a_bs=0, w_bs=0, c_bs=0, out_f32=False, a_off=0, w_off=0, c_off=0, label="gemm"):
+             a_bs=0, w_bs=0, c_bs=0, res_bs=0, out_f32=False, a_off=0, w_off=0, c_off=0, res_off=0,
+             label="gemm"):
         g = abi.GemmArgs()
         if out is None:
             out = self.buf((batch, m, n) if batch > 1 else (m, n), torch.float32 if out_f32 else self.tdtype)
         g.a, g.w, g.c = _ptr(a_t, a_off), _ptr(w_t, w_off), _ptr(out, c_off)
-        g.bias, g.res, g.gate = _ptr(bias), _ptr(res), _ptr(gate)
+        g.bias, g.res, g.gate = _ptr(bias), _ptr(res, res_off), _ptr(gate)
         g.m, g.n, g.k = m, n, k
         g.lda, g.ldw, g.ldc = (lda or k), (ldw or k), (ldc or n)
         g.ldres, g.ldgate = (ldres or n), (ldgate or n)
         g.batch, g.a_bstride, g.w_bstride, g.c_bstride = batch, a_bs, w_bs, c_bs
+        g.res_bstride = res_bs
         g.gate_rows_per = gate_rows_per
         g.act, g.act_param, g.alpha = act, 0.0, alpha
         g.dtype, g.out_dtype = self.dtype, (abi.F32 if out_f32 else self.dtype)
@@ -200,14 +215,15 @@ class PlanBuilder:
         return o
 
     def norm(self, x, y, rows, c, ldx=None, ldy=None, gamma=None, beta=None, eps=1e-6, kind=0,
-             mod_scale=None, mod_shift=None, rows_per=0, ldmod=0, x_off=0, y_off=0, label="norm"):
+             mod_scale=None, mod_shift=None, rows_per=0, ldmod=0, x_off=0, y_off=0, act=abi.ACT_NONE,
+             label="norm"):
         a = abi.NormArgs()
         a.x, a.y = _ptr(x, x_off), _ptr(y, y_off)
         a.gamma, a.beta = _ptr(gamma), _ptr(beta)
         a.mod_scale, a.mod_shift = _ptr(mod_scale), _ptr(mod_shift)
         a.rows, a.c, a.ldx, a.ldy = rows, c, (ldx or c), (ldy or c)
         a.rows_per, a.ldmod = rows_per, ldmod
-        a.eps, a.kind, a.dtype = eps, kind, self.dtype
+        a.eps, a.kind, a.dtype, a.act = eps, kind, self.dtype, act
         self._add(abi.OP_NORM, a, label)
         return y
 
@@ -229,7 +245,7 @@ class PlanBuilder:
             if kind == abi.EW_UPSAMPLE2X:
                 out = self.act(a_.n, a_.h * 2, a_.w * 2, a_.c)
             elif kind == abi.EW_MAXPOOL:
-                pd = i0 // 2
+                pd = i0 // 2 if i0 % 2 else 0
                 out = self.act(a_.n, (a_.h + 2 * pd - i0) // i1 + 1, (a_.w + 2 * pd - i0) // i1 + 1, a_.c)
             else:
                 out = self.act(a_.n, a_.h, a_.w, a_.c)
@@ -259,9 +275,46 @@ class PlanBuilder:
         self._add(abi.OP_IMG, a, label)
         return dst
 
-    def resize_threshold(self, src, dst, n, hs, ws, hd, wd, thresh=0.0, src_dtype=abi.F32, label="resize_thresh"):
+    def row_gather(self, src, dst, index_i32, rows, c, lda=None, ldy=None, label="row_gather"):
+        """dst[r, :c] = src[index[r], :c]  (token re-ordering between window layouts)"""
+        e = abi.EwArgs()
+        e.a, e.b, e.s, e.y = _ptr(src), None, _ptr(index_i32), _ptr(dst)
+        e.n, e.h, e.w, e.c = 1, 1, rows, c
+        e.lda, e.ldb, e.ldy, e.lds = (lda or c), 0, (ldy or c), 0
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_ROW_GATHER, 0, 0.0, 0, 0, self.dtype
+        self._add(abi.OP_EW, e, label)
+        return dst
+
+    def im2col(self, x: Act, dst, k, stride, ldy, row_map=None, label="im2col"):
+        e = abi.EwArgs()
+        e.a, e.b, e.s, e.y = x.ptr, None, _ptr(row_map), _ptr(dst)
+        e.n, e.h, e.w, e.c = x.n, x.h, x.w, x.c
+        e.lda, e.ldb, e.ldy, e.lds = x.ld, 0, ldy, 0
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_IM2COL, 0, 0.0, k, stride, self.dtype
+        self._add(abi.OP_EW, e, label)
+        return dst
+
+    def mask_select(self, logits, iou, counts, sel, n, pix, delta=0.05, thresh=0.98, label="mask_select"):
+        a = abi.MaskSelectArgs()
+        a.logits, a.iou, a.counts, a.sel = _ptr(logits), _ptr(iou), _ptr(counts), _ptr(sel)
+        a.n, a.pix, a.delta, a.thresh = n, pix, delta, thresh
+        self._add(abi.OP_MASK_SELECT, a, label)
+
+    def preprocess(self, src_u8, dst: "Act", h, w, mean, std, label="preprocess"):
+        a = abi.PreprocArgs()
+        a.src, a.dst = _ptr(src_u8), dst.ptr
+        a.h, a.w, a.oh, a.ow, a.c_pad = h, w, dst.h, dst.w, dst.ld
+        for i in range(3):
+            a.mean[i], a.std[i] = float(mean[i]), float(std[i])
+        a.dtype = self.dtype
+        self._add(abi.OP_PREPROC, a, label)
+        return dst
+
+    def resize_threshold(self, src, dst, n, hs, ws, hd, wd, thresh=0.0, src_dtype=abi.F32, pix_stride=1,
+                         sel=None, label="resize_thresh"):
         a = abi.ResizeThreshArgs()
         a.src, a.dst = _ptr(src), _ptr(dst)
+        a.pix_stride, a.sel = pix_stride, _ptr(sel)
         a.n, a.hs, a.ws, a.hd, a.wd, a.thresh, a.dtype = n, hs, ws, hd, wd, thresh, src_dtype
         self._add(abi.OP_RESIZE_THRESH, a, label)
         return dst

@@ -226,7 +226,7 @@ def check_ew(lib, dtype, seed=0):
     assert _relerr(y2.torch().cpu(), af.repeat_interleave(2, 1).repeat_interleave(2, 2)) < 1e-6
     mp = F.max_pool2d(af.permute(0, 3, 1, 2), 5, 1, 2).permute(0, 2, 3, 1)
     assert _relerr(y3.torch().cpu(), mp) < 1e-6
-    mp2 = F.max_pool2d(af.permute(0, 3, 1, 2), 2, 2, 1).permute(0, 2, 3, 1)
+    mp2 = F.max_pool2d(af.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
     assert y4.torch().shape == mp2.shape and _relerr(y4.torch().cpu(), mp2) < 1e-6
     assert _relerr(y5.torch().cpu(), F.silu(af + bf)) < TOL[dtype]
     assert _relerr(y6.torch().cpu(), bf + af * gs.float()[:, None, None, :]) < TOL[dtype]

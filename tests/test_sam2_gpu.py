@@ -1,0 +1,23 @@
+"""GPU tier: SAM-2.1 on MI355X through the C ABI vs HF Sam2Model on CPU fp32."""
+import pytest
+
+import sam2_checks as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sam2_tiny(hip_lib):
+    sc.check_sam2(hip_lib, "cuda:0", "tiny_test", h=300, w=200, n_boxes=3, seed=0)
+
+
+def test_sam2_small(hip_lib):
+    err, mism = sc.check_sam2(hip_lib, "cuda:0", "small_test", h=768, w=512, n_boxes=5, seed=1)
+    print(f"small_test: logits rel err {err:.4f}, mask mismatch {mism:.4%}")
+
+
+def test_sam2_hiera_large_page(hip_lib):
+    """Full Hiera-L geometry (48 blocks, 1024x1024 input, head_dim 72) with seeded weights on a
+    1024x1536 page with 8 boxes; the CPU oracle pass takes ~10 s."""
+    err, mism = sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=1536, w=1024, n_boxes=8, seed=2,
+                              logit_tol=0.15, mask_tol=0.02)
+    print(f"hiera_large: logits rel err {err:.4f}, mask mismatch {mism:.4%}")

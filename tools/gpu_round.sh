@@ -10,5 +10,5 @@ timeout 900 python bench.py --steps 6 --warmup 2 > gpurun_out/bench.log 2> gpuru
 tail -3 gpurun_out/bench.log; tail -5 gpurun_out/bench.err
 timeout 900 python tools/gpu_probe.py > gpurun_out/probe.log 2>&1
 tail -30 gpurun_out/probe.log
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
-find gpurun_out/prof -name "*stats*" | head; 
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/rocprof.log" 2>&1)
+find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -25 $f; done 
