@@ -2,17 +2,28 @@
 // (400 of the 404 convolutions of 2x-AnimeSharpV4_RCAN; spandrel model called at reference
 // core/image/image_utils.py:369-374) and the narrow YOLO stem layers.
 //
-// At 64 channels the whole filter bank is 9 x 64 x 64 x 2 B = 72 KiB: it fits in LDS next to one
-// input halo tile, so the kernel is PERSISTENT — one 8-wave workgroup per CU loads the filters
-// once and then walks 32x16-pixel output tiles (XCD-contiguous tile order, so neighbouring halos
-// hit the same L2):
-//     LDS:  filters [9][64 co][64 ci] 72 KiB  +  halo 18x34 px x 128 B = 76.5 KiB  (148.5 of 160 KiB)
-//     per tile:  prefetched halo registers -> LDS | issue next tile's halo loads (in flight behind
-//                the MFMAs) | 9 taps x 2 k-steps x 16 MFMA per wave | tile -> LDS -> 16-byte NHWC
-//                stores with bias / activation / residual / pixel-shuffle / channel sums fused.
-// Activations cross HBM once in (x1.20 halo overlap, L2-served) and once out; filters never again.
-// Same LDS swizzle, MFMA operand swap and epilogue as conv.hip.
+// At 64 channels the whole filter bank is 9 x 64 x 64 x 2 B = 72 KiB: it fits in LDS next to the
+// input halos, so the kernel is PERSISTENT — one 8-wave workgroup per CU loads the filters once and
+// walks 16x16-pixel output tiles in XCD-contiguous order (neighbouring halos hit the same L2).
+//
+// The 8 waves form TWO GROUPS of 4 that run half a period out of phase (LDS: filters 72 KiB +
+// one 18x18-pixel halo per group, 2 x 40.5 KiB):
+//
+//      slot 2k     : group 0  MFMA(tile k)          | group 1  memory phase of its tile k-1
+//      slot 2k + 1 : group 0  memory phase (tile k) | group 1  MFMA(tile k)
+//
+//   memory phase = { halo of the NEXT tile: prefetched registers -> LDS ; bias/act/residual epilogue
+//                    and NHWC stores of the finished tile ; issue the global loads of the tile after }
+//
+// so the matrix pipe always has one group's 288 MFMAs per wave to run while the other group's
+// loads, LDS writes and stores are in flight; one LDS-only barrier (s_waitcnt lgkmcnt(0); s_barrier
+// — never vmcnt, see MTX_LDS_BARRIER) separates the slots.  Inside the memory phase the order is
+// chosen for gfx950's in-order vmcnt: the halo registers are consumed BEFORE the tile's stores are
+// issued, and no global load that is needed soon is ever issued behind a store.
+// Activations cross HBM once in (x1.27 halo overlap, L2-served) and once out; filters never again.
+// Same LDS swizzle and MFMA operand swap as conv.hip.
 #include "mtx_device.h"
+#include <cstdlib>
 
 namespace mtx {
 
@@ -27,28 +38,35 @@ struct ConvC64Params {
   int tiles_x, tiles_y;
 };
 
-constexpr int C64_TW = 32, C64_TH = 16, C64_NPIX = C64_TW * C64_TH;
-constexpr int C64_HW = C64_TW + 2, C64_HH = C64_TH + 2, C64_HPIX = C64_HW * C64_HH;   // 34 x 18 = 612
+constexpr int C64_T = 16;                                  // tile edge (pixels)
+constexpr int C64_HW = C64_T + 2, C64_HPIX = C64_HW * C64_HW;   // 18 x 18 = 324 halo pixels
 constexpr int C64_W_BYTES = 9 * 64 * 128;
 constexpr int C64_HALO_BYTES = C64_HPIX * 128;
-constexpr int C64_SMEM = C64_W_BYTES + C64_HALO_BYTES;
-constexpr int C64_NLD = (C64_HPIX * 8 + 511) / 512;     // halo chunks per thread (10)
+constexpr int C64_BIAS_BYTES = 64 * 4;
+constexpr int C64_SMEM = C64_W_BYTES + 2 * C64_HALO_BYTES + C64_BIAS_BYTES;
 
-template <typename T>
+// ABL: timing-only ablations for profiling (tools/probe_conv.py); 0 = the real kernel
+template <typename T, int ABL, int ACT, bool SUM>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C64_SMEM];
   unsigned char* wts = smem;
-  unsigned char* halo = smem + C64_W_BYTES;
-  unsigned char* outs = halo;                                   // 64 KiB, aliases the halo
-  float* red = reinterpret_cast<float*>(halo + C64_NPIX * 128);  // [8 waves][64] after the tile
+  // bias lives in LDS: a global load inside the tile loop would sit behind earlier stores on the
+  // in-order vmcnt counter and expose their latency
+  float* bias_s = reinterpret_cast<float*>(smem + C64_W_BYTES + 2 * C64_HALO_BYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);           // wave-uniform group id
+  const int gt = tid & 255;                                            // thread within the group
+  const int wv = (tid >> 6) & 3;                                       // wave within the group
+  unsigned char* halo = smem + C64_W_BYTES + grp * C64_HALO_BYTES;
   const unsigned tiles_per_img = (unsigned)(p.tiles_x * p.tiles_y);
   const unsigned total = tiles_per_img * (unsigned)p.n;
+  const unsigned npairs = (total + 1) / 2;
 
-  // ---- filters: once per workgroup ---------------------------------------------------------------
+  // ---- filters + bias: once per workgroup ---------------------------------------------------------
   for (int idx = tid; idx < 9 * 64 * 8; idx += 512) {
     const int c = idx & 7, row = idx >> 3;            // row = tap*64 + co
     const int tap = row >> 6, co = row & 63;
@@ -58,179 +76,241 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       v = *reinterpret_cast<const u32x4*>(p.w + (((size_t)co * 9 + tap) * (size_t)p.cin + ch) * sizeof(T));
     *reinterpret_cast<u32x4*>(wts + row * 128 + ((c ^ (co & 7)) << 4)) = v;
   }
+  if (tid < 64) bias_s[tid] = (p.bias != nullptr && tid < p.cout) ? p.bias[tid] : 0.f;
   const int nks = p.cin > 32 ? 2 : 1;
 
-  u32x4 pre[C64_NLD];
-  auto issue_halo = [&](unsigned t) {
-    const unsigned lin = xcd_remap(t, total);
+  // tile owned by this group in pair-iteration k (or ~0u when past the end)
+  auto tile_of = [&](unsigned k) -> unsigned {
+    const unsigned pid = blockIdx.x + k * gridDim.x;
+    if (pid >= npairs) return ~0u;
+    const unsigned lin = 2u * xcd_remap(pid, npairs) + (unsigned)grp;
+    return lin < total ? lin : ~0u;
+  };
+
+  // halo staging by LDS-DMA (no staging registers): DMA instruction m of a group fills LDS rows
+  // 8m .. 8m+7 of the group's halo; lane l -> row 8m + l/8, 16-byte slot l%8, which must hold chunk
+  // (slot ^ (row & 7)) of that pixel — the swizzle is applied on the per-lane SOURCE address.
+  // Out-of-image pixels read the zero page.
+  constexpr int C64_NDMA = (C64_HPIX * 8 + 63) / 64;      // 41 wave-instructions per halo
+  auto dma_halo = [&](unsigned lin) {
     const int img = (int)(lin / tiles_per_img);
     const int tile = (int)(lin % tiles_per_img);
-    const int iy0 = (tile / p.tiles_x) * C64_TH - 1, ix0 = (tile % p.tiles_x) * C64_TW - 1;
+    const int iy0 = (tile / p.tiles_x) * C64_T - 1, ix0 = (tile % p.tiles_x) * C64_T - 1;
     const size_t img_off = (size_t)img * p.h * p.w_in;
 #pragma unroll
-    for (int it = 0; it < C64_NLD; ++it) {
-      const int idx = tid + it * 512;
-      const int c = idx & 7, hp = idx >> 3;
-      const int hy = hp / C64_HW, hx = hp - hy * C64_HW;
-      const int gy = iy0 + hy, gx = ix0 + hx, ch = c * 8;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (hp < C64_HPIX && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_in && ch < p.cin)
-        v = *reinterpret_cast<const u32x4*>(p.x + ((img_off + (size_t)gy * p.w_in + gx) * (size_t)p.ldx + ch) * sizeof(T));
-      pre[it] = v;
+    for (int it = 0; it < (C64_NDMA + 3) / 4; ++it) {
+      const int m = __builtin_amdgcn_readfirstlane(wv + it * 4);
+      if (m < C64_NDMA) {
+        const int slot = m * 64 + lane;
+        const int hp = slot >> 3, c = (slot & 7) ^ (hp & 7);
+        const int hy = hp / C64_HW, hx = hp - hy * C64_HW;
+        const int gy = iy0 + hy, gx = ix0 + hx, ch = c * 8;
+        const unsigned char* src = g_zero16;
+        if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_in && ch < p.cin)
+          src = p.x + ((img_off + (size_t)gy * p.w_in + gx) * (size_t)p.ldx + ch) * sizeof(T);
+        if (hp < C64_HPIX) glds16(src, halo + m * 1024);
+      }
     }
   };
 
-  // channel sums (fused global average pool): accumulated per workgroup across its tiles and
-  // flushed once per image -> chan_sum[img][blockIdx.x][C]  (rows = gridDim.x, zeroed by the launcher)
-  float csum[8];
+  // per-wave channel sums (fused global average pool): lane (l15, q) owns channels 16j + 4q + r;
+  // flushed per image as one partial row per WAVE: chan_sum[img][blockIdx.x * 8 + wave][C]
+  float csum[4][4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
   int sum_img = -1;
   auto flush_sums = [&](int img_) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = csum[e];
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      csum[e] = v;
-    }
-    __syncthreads();
-    if (lane < 8) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) red[wv * 64 + lane * 8 + e] = csum[e];
-    }
-    __syncthreads();
-    if (tid < 64 && tid < p.cout) {
-      float s_ = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s_ += red[k * 64 + tid];
-      p.chan_sum[((size_t)img_ * gridDim.x + blockIdx.x) * p.cout + tid] = s_;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
-  };
-
-  unsigned t = blockIdx.x;
-  if (t < total) issue_halo(t);
-  for (; t < total; t += gridDim.x) {
-    const unsigned lin = xcd_remap(t, total);
-    const int img = (int)(lin / tiles_per_img);
-    const int tile = (int)(lin % tiles_per_img);
-    if (p.chan_sum != nullptr && img != sum_img) {
-      if (sum_img >= 0) flush_sums(sum_img);
-      sum_img = img;
-    }
-    const int ty0 = (tile / p.tiles_x) * C64_TH, tx0 = (tile % p.tiles_x) * C64_TW;
-
-    // [A] prefetched halo -> LDS
-#pragma unroll
-    for (int it = 0; it < C64_NLD; ++it) {
-      const int idx = tid + it * 512;
-      const int c = idx & 7, hp = idx >> 3;
-      if (hp < C64_HPIX) *reinterpret_cast<u32x4*>(halo + hp * 128 + ((c ^ (hp & 7)) << 4)) = pre[it];
-    }
-    __syncthreads();
-    // [B] next tile's halo: global loads stay in flight behind the MFMAs
-    if (t + gridDim.x < total) issue_halo(t + gridDim.x);
-
-    // [C] 9 taps x nks k-steps; wave wv owns tile rows 2wv, 2wv+1 (4 fragments of 16 px)
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll 1
-      for (int ks = 0; ks < nks; ++ks) {
-        const int cch = ks * 4 + q;
-        v8 wf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = tap * 64 + j * 16 + l15;
-          wf[j] = *reinterpret_cast<const v8*>(wts + row * 128 + ((cch ^ (l15 & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = wv * 2 + (i >> 1), x0 = (i & 1) * 16;
-          const int lp = (r + ky) * C64_HW + x0 + l15 + kx;
-          const v8 xf = *reinterpret_cast<const v8*>(halo + lp * 128 + ((cch ^ (lp & 7)) << 4));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = Traits<T>::mfma(wf[j], xf, acc[i][j]);
-        }
-      }
-    }
-    __syncthreads();   // [D] every wave is done with the halo
-
-    // [E] bias + activation, 4 consecutive channels per lane -> LDS tile
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int chunk = j * 2 + (q >> 1);
-      float b4[4];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int bc = j * 16 + q * 4 + r;
-        b4[r] = (p.bias != nullptr && bc < p.cout) ? p.bias[bc] : 0.f;
+        float v = csum[j][r];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (l15 == 0 && j * 16 + q * 4 + r < p.cout)
+          p.chan_sum[((size_t)img_ * (gridDim.x * 8) + blockIdx.x * 8 + (tid >> 6)) * p.cout + j * 16 + q * 4 + r] = v;
+        csum[j][r] = 0.f;
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pt = (wv * 2 + (i >> 1)) * C64_TW + (i & 1) * 16 + l15;
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act(acc[i][j][r] + b4[r], p.act, p.act_param));
-        *reinterpret_cast<v4*>(outs + pt * 128 + ((chunk ^ (pt & 7)) << 4) + ((q & 1) << 3)) = o;
-      }
-    }
-    __syncthreads();   // [F]
+  };
 
-    // [G] 16-byte channel chunks out
-    const int c = tid & 7;
-    const int co = c * 8;
-#pragma unroll 2
-    for (int idx = tid; idx < C64_NPIX * 8; idx += 512) {
-      const int pt = idx >> 3;
-      const int oy = ty0 + (pt >> 5), ox = tx0 + (pt & 31);
-      if (oy < p.h && ox < p.w_in && co < p.cout) {
-        u32x4 raw = *reinterpret_cast<const u32x4*>(outs + pt * 128 + ((c ^ (pt & 7)) << 4));
-        size_t opix;
-        int oc = co;
-        if (p.ps == 2) {
-          const int cps = p.cout >> 2;
-          const int g = co / cps;
-          oc = co - g * cps;
-          opix = ((size_t)img * (2 * p.h) + (2 * oy + (g >> 1))) * (size_t)(2 * p.w_in) + (2 * ox + (g & 1));
-        } else {
-          opix = ((size_t)img * p.h + oy) * (size_t)p.w_in + ox;
-        }
-        if (p.chan_sum != nullptr || p.res != nullptr) {
-          float f[8];
-          unpack8<T>(raw, f);
-          if (p.chan_sum != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) csum[e] += f[e];
-          }
-          if (p.res != nullptr) {
-            const size_t rpix = p.res_bcast ? opix - (size_t)img * (p.ps == 2 ? 4 : 1) * (size_t)p.h * (size_t)p.w_in : opix;
-          const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + (rpix * (size_t)p.ldres + oc) * sizeof(T));
-            float g8[8];
-            unpack8<T>(rr, g8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += p.res_scale * g8[e];
-            raw = pack8<T>(f);
-          }
-        }
-        *reinterpret_cast<u32x4*>(p.y + (opix * (size_t)p.ldy + oc) * sizeof(T)) = raw;
-      }
-    }
-    __syncthreads();   // [H] tile buffer is free for the next halo
+  // ---- prologue: tile 0 -> LDS -------------------------------------------------
+  unsigned K = 0;                                   // pair-iterations of this workgroup
+  for (unsigned pid = blockIdx.x; pid < npairs; pid += gridDim.x) ++K;
+  {
+    const unsigned t0 = tile_of(0);
+    if (t0 != ~0u) dma_halo(t0);
   }
-  if (p.chan_sum != nullptr && sum_img >= 0) flush_sums(sum_img);
+  MTX_WAIT_VMEM();
+  MTX_LDS_BARRIER();
+
+  f32x4 acc[4][4];
+  u32x2_t rv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; rv[i][j] = u32x2_t{0u, 0u}; }
+
+  for (unsigned s = 0; s < 2 * K + 1; ++s) {
+    const bool mfma_slot = (int)(s & 1u) == grp;
+    if (mfma_slot) {
+      // ================= MFMA slot: tile k of this group ============================================
+      const unsigned k = (s - (unsigned)grp) >> 1;
+      const unsigned lin = k < K ? tile_of(k) : ~0u;
+      if (lin != ~0u) {
+        const int img = (int)(lin / tiles_per_img);
+        const int tile = (int)(lin % tiles_per_img);
+        const int ty0 = (tile / p.tiles_x) * C64_T, tx0 = (tile % p.tiles_x) * C64_T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // wave wv owns tile rows 4wv .. 4wv+3 (4 fragments of 16 px) x 64 couts (4 fragments)
+        auto load_frags = [&](int tap, int ks, v8 (&wf)[4], v8 (&xf)[4]) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const int cch = ks * 4 + q;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = tap * 64 + j * 16 + l15;
+            wf[j] = *reinterpret_cast<const v8*>(wts + row * 128 + ((cch ^ (l15 & 7)) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int lp = (wv * 4 + i + ky) * C64_HW + l15 + kx;
+            xf[i] = *reinterpret_cast<const v8*>(halo + lp * 128 + ((cch ^ (lp & 7)) << 4));
+          }
+        };
+        auto mfma16 = [&](v8 (&wf)[4], v8 (&xf)[4]) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = Traits<T>::mfma(wf[j], xf[i], acc[i][j]);
+        };
+        if (ABL != 1) {
+          // two fragment sets: the LDS reads of step n+1 are in flight behind the 16 MFMAs of step n
+          // (one wave per SIMD runs this loop, nothing else hides its LDS latency)
+          v8 wfA[4], xfA[4], wfB[4], xfB[4];
+          if (nks == 2) {
+            load_frags(0, 0, wfA, xfA);
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+              load_frags(tap, 1, wfB, xfB);
+              mfma16(wfA, xfA);
+              if (tap < 8) load_frags(tap + 1, 0, wfA, xfA);
+              mfma16(wfB, xfB);
+            }
+          } else {
+            load_frags(0, 0, wfA, xfA);
+#pragma unroll 1
+            for (int tap = 0; tap < 8; tap += 2) {
+              load_frags(tap + 1, 0, wfB, xfB);
+              mfma16(wfA, xfA);
+              load_frags(tap + 2, 0, wfA, xfA);
+              mfma16(wfB, xfB);
+            }
+            mfma16(wfA, xfA);
+          }
+        }
+        if (p.res != nullptr) {   // this tile's residual, issued after the MFMA loop (its registers are not live inside it);
+          // the latency hides behind the slot barrier and the next halo's LDS writes
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int oy = ty0 + wv * 4 + i, ox = tx0 + l15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int co = j * 16 + q * 4;
+              u32x2_t v = u32x2_t{0u, 0u};
+              if (oy < p.h && ox < p.w_in && co < p.cout) {
+                size_t opix; int oc = co;
+                const int rimg = p.res_bcast ? 0 : img;
+                if (p.ps == 2) {
+                  const int cps = p.cout >> 2; const int g = co / cps; oc = co - g * cps;
+                  opix = ((size_t)rimg * (2 * p.h) + (2 * oy + (g >> 1))) * (size_t)(2 * p.w_in) + (2 * ox + (g & 1));
+                } else {
+                  opix = ((size_t)rimg * p.h + oy) * (size_t)p.w_in + ox;
+                }
+                v = *reinterpret_cast<const u32x2_t*>(p.res + (opix * (size_t)p.ldres + oc) * sizeof(T));
+              }
+              rv[i][j] = v;
+            }
+          }
+        }
+      }
+    } else if (s > (unsigned)grp) {
+      // ================= memory slot: finish tile k, stage tile k+1, fetch tile k+2 ===================
+      const unsigned k = (s - (unsigned)grp - 1) >> 1;
+      const unsigned lin = k < K ? tile_of(k) : ~0u;
+      // (1) epilogue straight from the accumulators: bias, activation, residual, 8-byte NHWC stores
+      if (lin != ~0u) {
+        const int img = (int)(lin / tiles_per_img);
+        const int tile = (int)(lin % tiles_per_img);
+        const int ty0 = (tile / p.tiles_x) * C64_T, tx0 = (tile % p.tiles_x) * C64_T;
+        const bool want_sum = SUM;
+        if (want_sum && img != sum_img) {
+          if (sum_img >= 0) flush_sums(sum_img);
+          sum_img = img;
+        }
+        if (ABL == 4) {   // keep EVERY accumulator live (an ablation must not let the MFMAs be DCE'd)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+        } else {
+          size_t pix_off[4];
+          bool pix_ok[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int oy = ty0 + wv * 4 + i, ox = tx0 + l15;
+            pix_ok[i] = oy < p.h && ox < p.w_in;
+            pix_off[i] = p.ps == 2 ? ((size_t)img * (2 * p.h) + 2 * oy) * (size_t)(2 * p.w_in) + 2 * ox
+                                   : ((size_t)img * p.h + oy) * (size_t)p.w_in + ox;
+          }
+          const int cps = p.cout >> 2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int co = j * 16 + q * 4;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + co);
+            int oc = co;
+            size_t sub = 0;
+            if (p.ps == 2) { const int g = co / cps; oc = co - g * cps; sub = (size_t)(g >> 1) * (size_t)(2 * p.w_in) + (g & 1); }
+            const bool ch_ok = co < p.cout;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float f[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) f[r] = apply_act_t<ACT>(acc[i][j][r] + b4[r], p.act, p.act_param);
+              if (want_sum && pix_ok[i] && ch_ok) {   // pooled statistics of the values as stored (rounded to T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { f[r] = to_f32(from_f32<T>(f[r])); csum[j][r] += f[r]; }
+              }
+              if (p.res != nullptr) {
+                const v4 g4 = __builtin_bit_cast(v4, rv[i][j]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] += p.res_scale * to_f32(g4[r]);
+              }
+              v4 o;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(f[r]);
+              if (pix_ok[i] && ch_ok)
+                *reinterpret_cast<v4*>(p.y + ((pix_off[i] + sub) * (size_t)p.ldy + oc) * sizeof(T)) = o;
+            }
+          }
+        }
+      }
+      // (2) next tile's halo by LDS-DMA into this group's (now idle) halo buffer, then drain: the
+      //     DMA and this tile's stores must have landed before the barrier that opens our MFMA slot.
+      //     The drain overlaps the other group's MFMA slot.
+      const unsigned lin1 = k + 1 < K ? tile_of(k + 1) : ~0u;
+      if (ABL != 3 && lin1 != ~0u) dma_halo(lin1);
+      MTX_WAIT_VMEM();
+    }
+    MTX_LDS_BARRIER();
+  }
+  if (SUM && sum_img >= 0) flush_sums(sum_img);
 }
 
 static int g_num_cus = 0;
+static int abl_mode() { static int abl = -1; if (abl < 0) { const char* e = getenv("MTX_C64_ABL"); abl = e ? atoi(e) : 0; } return abl; }
 
 static int c64_num_cus(const char** err) {
   if (g_num_cus == 0) {
@@ -246,12 +326,17 @@ static int c64_num_cus(const char** err) {
   return g_num_cus;
 }
 
-// rows of the chan_sum buffer per image = workgroups of the persistent launch
-int conv_c64_tiles(int n, int h, int w) {
-  const long total = (long)((w + C64_TW - 1) / C64_TW) * ((h + C64_TH - 1) / C64_TH) * n;
+static unsigned c64_grid(int n, int h, int w) {
+  const long total = (long)((w + C64_T - 1) / C64_T) * ((h + C64_T - 1) / C64_T) * n;
+  const long npairs = (total + 1) / 2;
   const int cus = c64_num_cus(nullptr);
-  if (cus < 0) return -1;
-  return (int)(total < cus ? total : cus);
+  return (unsigned)(npairs < cus ? npairs : cus);
+}
+
+// rows of the chan_sum buffer per image = one partial per wave of the persistent launch
+int conv_c64_tiles(int n, int h, int w) {
+  if (c64_num_cus(nullptr) < 0) return -1;
+  return (int)c64_grid(n, h, w) * 8;
 }
 
 bool conv_c64_applicable(const mtx_conv2d_args* a) {
@@ -265,17 +350,27 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.n = a->n; p.h = a->h; p.w_in = a->w_in; p.cin = a->cin; p.cout = a->cout;
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldres = a->ldres;
   p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.ps = a->pixel_shuffle; p.res_bcast = a->res_broadcast_n;
-  p.tiles_x = (a->w_in + C64_TW - 1) / C64_TW;
-  p.tiles_y = (a->h + C64_TH - 1) / C64_TH;
+  p.tiles_x = (a->w_in + C64_T - 1) / C64_T;
+  p.tiles_y = (a->h + C64_T - 1) / C64_T;
   if (c64_num_cus(err) < 0) return MTX_ERR_HIP;
-  const long total = (long)p.tiles_x * p.tiles_y * p.n;
-  const unsigned grid = (unsigned)(total < g_num_cus ? total : g_num_cus);
+  const unsigned grid = c64_grid(a->n, a->h, a->w_in);
   if (a->chan_sum != nullptr &&
-      hipMemsetAsync(a->chan_sum, 0, (size_t)a->n * grid * a->cout * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+      hipMemsetAsync(a->chan_sum, 0, (size_t)a->n * grid * 8 * a->cout * sizeof(float), (hipStream_t)stream) != hipSuccess) {
     *err = "conv2d: chan_sum memset failed"; return MTX_ERR_HIP;
   }
-  if (a->dtype == MTX_BF16) MTX_LAUNCH((conv3x3_c64_kernel<__bf16>), dim3(grid), dim3(512), 0, stream, p);
-  else if (a->dtype == MTX_F16) MTX_LAUNCH((conv3x3_c64_kernel<_Float16>), dim3(grid), dim3(512), 0, stream, p);
+  const int abl = abl_mode();
+#define C64_GO(TT, AB, AC, SM) MTX_LAUNCH((conv3x3_c64_kernel<TT, AB, AC, SM>), dim3(grid), dim3(512), 0, stream, p)
+#define C64_ACT(TT, SM) do { if (a->act == MTX_ACT_NONE) C64_GO(TT, 0, MTX_ACT_NONE, SM); else if (a->act == MTX_ACT_RELU) C64_GO(TT, 0, MTX_ACT_RELU, SM); \
+                             else C64_GO(TT, 0, -1, SM); } while (0)
+  const bool sum = a->chan_sum != nullptr;
+  if (a->dtype == MTX_BF16) { if (sum) C64_ACT(__bf16, true); else C64_ACT(__bf16, false); }
+  else if (a->dtype == MTX_F16) {
+    if (abl == 1) C64_GO(_Float16, 1, MTX_ACT_RELU, false);
+    else if (abl == 3) C64_GO(_Float16, 3, MTX_ACT_RELU, false);
+    else if (abl == 4) C64_GO(_Float16, 4, MTX_ACT_RELU, false);
+    else if (sum) C64_ACT(_Float16, true);
+    else C64_ACT(_Float16, false);
+  }
   else { *err = "conv2d: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
   return MTX_OK;
 }

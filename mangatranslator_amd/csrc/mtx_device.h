@@ -19,7 +19,43 @@
 
 #include "../../include/mtx_hip.h"
 
+// Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() carries a workgroup
+// release fence, i.e. `s_waitcnt vmcnt(0)`: every outstanding global STORE (and LDS-DMA) must retire
+// before the barrier.  Inside a persistent tile loop that serialises each tile's store tail
+// (measured: 226 -> see profiles/ for the c64 conv).  Barriers that only guard LDS reuse wait on
+// lgkmcnt alone and let the stores drain behind the next tile's work.
+#ifdef MTX_EMU
+#define MTX_LDS_BARRIER() __syncthreads()
+#else
+#define MTX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 namespace mtx {
+
+// 16 zero bytes in device memory: the source of out-of-image halo chunks for LDS-DMA loads
+#ifdef MTX_EMU
+static unsigned char g_zero16[16] __attribute__((aligned(16))) = {0};
+#else
+__device__ __attribute__((aligned(16))) static unsigned char g_zero16[16];
+#endif
+
+// LDS-DMA: every ACTIVE lane copies 16 bytes from its own global address to
+// lds_wave_base + lane*16 (the LDS base must be wave-uniform; it is read with readfirstlane into M0).
+// Completion is tracked by vmcnt; nothing orders a later ds_read behind it except the issuing
+// wave's `s_waitcnt vmcnt` followed by a barrier.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+#ifdef MTX_EMU
+  memcpy(reinterpret_cast<unsigned char*>(lds_wave_base) + emu::lane_id() * 16, gsrc, 16);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+#ifdef MTX_EMU
+#define MTX_WAIT_VMEM() ((void)0)
+#else
+#define MTX_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -49,9 +85,17 @@ template <typename T> __device__ __forceinline__ float to_f32(T v) { return (flo
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 // _Float16 saturates instead of overflowing to inf (activations can spike on random weights)
 template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) {
+#ifdef MTX_EMU
   v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+#else
+  v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);      // one v_med3_f32
+#endif
   return (_Float16)v;
 }
+
+// compile-time activation (hot epilogues): ACT < 0 falls back to the runtime switch
+template <int ACT>
+__device__ __forceinline__ float apply_act_t(float v, int act, float p);
 
 __device__ __forceinline__ float apply_act(float v, int act, float p) {
   switch (act) {
@@ -66,6 +110,14 @@ __device__ __forceinline__ float apply_act(float v, int act, float p) {
     case MTX_ACT_LEAKY: return v > 0.f ? v : v * p;
     default: return v;
   }
+}
+
+template <int ACT>
+__device__ __forceinline__ float apply_act_t(float v, int act, float p) {
+  if (ACT == MTX_ACT_NONE) return v;
+  if (ACT == MTX_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (ACT == MTX_ACT_SILU) return v / (1.f + __expf(-v));
+  return apply_act(v, act, p);
 }
 
 // 16-byte chunk (8 x 16-bit) helpers
