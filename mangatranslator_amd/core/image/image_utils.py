@@ -1,0 +1,59 @@
+"""Final upscale operator: `upscale_image`, `upscale_image_to_dimension`,
+`image_to_tensor`, `tensor_to_image` with the reference's signatures (core/image/image_utils.py:351-548).
+The model call goes to the RCAN graph on libmtx_hip; PIL handles the final exact-size LANCZOS."""
+import numpy as np
+import torch
+from PIL import Image
+
+from ...utils.exceptions import ImageProcessingError
+from ...utils.logging import log_message
+from ..ml.model_manager import get_model_manager
+
+
+def image_to_tensor(image: Image.Image, device: torch.device) -> torch.Tensor:
+    if image.mode != "RGB":
+        image = image.convert("RGB")
+    arr = np.asarray(image).astype(np.float32) / 255.0
+    return torch.from_numpy(arr).permute(2, 0, 1).unsqueeze(0).to(device)
+
+
+def tensor_to_image(tensor: torch.Tensor) -> Image.Image:
+    arr = (tensor.squeeze(0).permute(1, 2, 0).clamp(0, 1).cpu().numpy() * 255).astype(np.uint8)
+    return Image.fromarray(arr)
+
+
+def _upscale_image(model, image: Image.Image, device: torch.device) -> Image.Image:
+    fast = getattr(model, "upscale_u8", None)
+    if fast is not None:      # uint8 page in, uint8 page out: both conversions fused into the plan
+        rgb = image if image.mode == "RGB" else image.convert("RGB")
+        return Image.fromarray(fast(torch.from_numpy(np.asarray(rgb))).cpu().numpy())
+    with torch.no_grad():
+        return tensor_to_image(model(image_to_tensor(image, device)))
+
+
+def upscale_image_to_dimension(model, image: Image.Image, target: int, device, mode: str = "max",
+                               model_type: str = "model", verbose: bool = False) -> Image.Image:
+    """Repeat model passes until max(w, h) (mode "max") or min(w, h) (mode "min") reaches `target`."""
+    if mode not in ("max", "min"):
+        raise ImageProcessingError(f"Invalid upscale mode: {mode}")
+    pick = max if mode == "max" else min
+    current = image
+    scale = getattr(model, "scale", 2)
+    for _ in range(8):
+        if pick(current.size) >= target:
+            break
+        current = _upscale_image(model, current, device)
+        if scale <= 1:
+            break
+    return current
+
+
+def upscale_image(image: Image.Image, factor: float, model_type: str = "model", verbose: bool = False) -> Image.Image:
+    if factor == 1.0:
+        return image
+    manager = get_model_manager()
+    model = manager.load_upscale_lite() if model_type == "model_lite" else manager.load_upscale()
+    log_message(f"Upscaling image by {factor}x...", verbose=verbose)
+    tw, th = int(image.width * factor), int(image.height * factor)
+    up = upscale_image_to_dimension(model, image, max(tw, th), manager.device, "max", model_type, verbose)
+    return up.resize((tw, th), Image.LANCZOS)

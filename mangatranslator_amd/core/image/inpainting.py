@@ -1,0 +1,262 @@
+"""FLUX.1-Kontext region inpainting — host side of SURVEY.md §8 rows a6/a7.
+
+Operator surface of the reference's `FluxKontextInpainter` (core/image/inpainting.py:91-102, 172, 209,
+636-645): same constructor arguments, `.inpaint_mask(image_pil, mask_np, seed, verbose, ocr_params,
+strict_mask_clipping, composite_clip_bbox) -> PIL.Image`, `.load_models()`, `.unload_models()`;
+returning the *same object* means "nothing was inpainted" (callers rely on that,
+reference core/outside_text_processor.py:902-905).
+
+The region math — mask bbox + context padding, EDT feather alpha, growth to the nearest of the 17
+preferred Kontext aspect ratios, 2-px quantisation, strict / clip-bbox masking, LANCZOS round trip and
+the fp32 alpha composite with uint8 truncation — is pinned against the reference by
+tests/golden/kontext_*.{json,npz}.  The diffusion itself is `self.pipeline`, an object with the
+diffusers call shape `pipeline(image=, width=, height=, num_inference_steps=, guidance_scale=,
+generator=, output_type="pt", max_area=, prompt_embeds=, pooled_prompt_embeds=).images[0]` — the
+MI355X FLUX graph from `ModelManager.load_flux_kontext_sdnq()` once that model is built; without it
+`load_models()` leaves `pipeline = None` and the page is returned untouched, as the reference does.
+"""
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+from scipy.ndimage import distance_transform_edt
+
+from ...utils.exceptions import ModelError
+from ...utils.logging import log_message
+
+BLUR_SCALE_FACTOR = 0.1
+MIN_BLUR_RADIUS = 1
+MAX_BLUR_RADIUS = 10
+FLUX_GUIDANCE_SCALE = 2.5
+CONTEXT_PADDING_RATIO = 0.5
+MAX_CONTEXT_PADDING = 80
+
+PREFERRED_KONTEXT_RESOLUTIONS = [
+    (672, 1568), (688, 1504), (720, 1456), (752, 1392), (800, 1328), (832, 1248), (880, 1184), (944, 1104),
+    (1024, 1024), (1104, 944), (1184, 880), (1248, 832), (1328, 800), (1392, 752), (1456, 720), (1504, 688),
+    (1568, 672),
+]
+
+
+def nearest_preferred_resolution(width: int, height: int, table=PREFERRED_KONTEXT_RESOLUTIONS) -> Tuple[int, int]:
+    """Entry whose aspect ratio is closest to width/height; ties go to the smaller (w, h) tuple
+    (the reference takes `min` over (|dAR|, w, h) triples)."""
+    ar = width / height
+    _, w, h = min((abs(ar - w / h), w, h) for (w, h) in table)
+    return w, h
+
+
+def feather_alpha(mask: np.ndarray, blur_radius: int) -> np.ndarray:
+    """1 inside the mask, linear ramp 1 -> 0 over `blur_radius` px of Euclidean distance outside it."""
+    m = mask.astype(bool)
+    if blur_radius <= 0:
+        return m.astype(np.float32)
+    d_out = distance_transform_edt(~m)
+    alpha = np.zeros(m.shape, np.float32)
+    alpha[m] = 1.0
+    ramp = np.clip(1.0 - d_out / blur_radius, 0.0, 1.0)
+    outside = d_out > 0
+    alpha[outside] = ramp[outside]
+    return alpha
+
+
+def _grow_axis(lo: int, hi: int, limit: int, target: int) -> Tuple[int, int]:
+    """Grow [lo, hi) to `target` long inside [0, limit): pinned to an edge it already touches,
+    otherwise centred (extra pixel to the far side) and shifted back inside."""
+    target = min(limit, target)
+    if hi == limit:
+        return limit - target, limit
+    if lo == 0:
+        return 0, target
+    new_lo = max(0, lo - (target - (hi - lo)) // 2)
+    new_hi = new_lo + target
+    if new_hi > limit:
+        new_lo, new_hi = limit - target, limit
+    return new_lo, new_hi
+
+
+def mask_region(mask: np.ndarray, padding: int, aspect: Optional[float], transpose: bool = False) -> Tuple[int, int, int, int]:
+    """(x, y, w, h) of the padded mask bbox grown towards `aspect` (= w/h) along one axis."""
+    H, W = mask.shape
+    rows, cols = np.flatnonzero(mask.any(axis=1)), np.flatnonzero(mask.any(axis=0))
+    x1, x2 = max(0, int(cols[0]) - padding), min(W, int(cols[-1]) + 1 + padding)
+    y1, y2 = max(0, int(rows[0]) - padding), min(H, int(rows[-1]) + 1 + padding)
+    w0, h0 = x2 - x1, y2 - y1
+    if aspect is None:
+        aspect = nearest_preferred_resolution(w0, h0)
+        aspect = aspect[0] / aspect[1]
+    req_w, req_h = math.ceil(h0 * aspect), math.floor(w0 / aspect)
+    nx1, nx2, ny1, ny2 = x1, x2, y1, y2
+    widen, heighten = req_w > w0, req_h > h0
+    if (not transpose and widen) or (transpose and not heighten and widen):
+        nx1, nx2 = _grow_axis(x1, x2, W, req_w)
+    elif heighten:
+        ny1, ny2 = _grow_axis(y1, y2, H, req_h)
+    return nx1, ny1, nx2 - nx1, ny2 - ny1
+
+
+def quantize_region(x: int, y: int, w: int, h: int, img_w: int, img_h: int, quant: int = 2) -> Tuple[int, int, int, int]:
+    """Snap the crop to multiples of `quant` (Python banker's rounding, as the reference's round())."""
+    qx1 = max(0, min(img_w, int(round(x / quant) * quant)))
+    qy1 = max(0, min(img_h, int(round(y / quant) * quant)))
+    qx2 = max(qx1 + 1, min(img_w, int(round((x + w) / quant) * quant)))
+    qy2 = max(qy1 + 1, min(img_h, int(round((y + h) / quant) * quant)))
+    return qx1, qy1, max(1, qx2 - qx1), max(1, qy2 - qy1)
+
+
+def composite_u8(page: np.ndarray, patch: np.ndarray, alpha: np.ndarray, x: int, y: int) -> np.ndarray:
+    """fp32 `patch*alpha + page*(1-alpha)` on the crop, truncated back to uint8 (reference :950-968).
+    A destination with more channels than the patch (RGBA page) gets an opaque source alpha."""
+    out = page.copy()
+    h, w = patch.shape[:2]
+    h, w = max(0, min(h, page.shape[0] - y)), max(0, min(w, page.shape[1] - x))
+    if h == 0 or w == 0:
+        return out
+    dst = page[y:y + h, x:x + w].astype(np.float32) / np.float32(255.0)
+    src = patch[:h, :w].astype(np.float32) / np.float32(255.0)
+    if dst.ndim == 2:
+        dst, src = dst[..., None], src[..., None] if src.ndim == 2 else src
+    if src.shape[-1] < dst.shape[-1]:
+        src = np.concatenate([src, np.ones(src.shape[:-1] + (dst.shape[-1] - src.shape[-1],), np.float32)], -1)
+    src = src[..., :dst.shape[-1]]
+    a = alpha[:h, :w].astype(np.float32)[..., None]
+    blended = src * a + dst * (np.float32(1.0) - a)
+    out[y:y + h, x:x + w] = (blended * np.float32(255.0)).astype(np.uint8).reshape(out[y:y + h, x:x + w].shape)
+    return out
+
+
+class FluxKontextInpainter:
+    def __init__(self, device: Optional[torch.device] = None, huggingface_token: str = "", num_inference_steps: int = 8,
+                 residual_diff_threshold: float = 0.15, backend: str = "nunchaku", low_vram: bool = False,
+                 sdcpp_cache_mode: str = "none", sdcpp_diffusion_quant: str = "", sdcpp_text_encoder_quant: str = ""):
+        from ..ml.model_manager import get_model_manager
+        self.manager = get_model_manager()
+        self.DEVICE = device if device is not None else self.manager.device
+        self.DTYPE = self.manager.dtype
+        self.huggingface_token = huggingface_token
+        self.num_inference_steps = num_inference_steps
+        self.residual_diff_threshold = residual_diff_threshold
+        self.backend = backend.lower()
+        if self.backend not in ("nunchaku", "sdnq", "sdcpp"):
+            raise ValueError(f"Invalid Kontext backend '{backend}'. Must be 'nunchaku', 'sdnq', or 'sdcpp'.")
+        self.low_vram = low_vram
+        self.sdcpp_cache_mode = sdcpp_cache_mode
+        self.sdcpp_diffusion_quant = sdcpp_diffusion_quant
+        self.sdcpp_text_encoder_quant = sdcpp_text_encoder_quant
+        self.PREFERED_KONTEXT_RESOLUTIONS = list(PREFERRED_KONTEXT_RESOLUTIONS)
+        self.pipeline = None
+        self.guidance_scale = FLUX_GUIDANCE_SCALE
+        self.prompt = "Remove all text."
+        self.context_padding_ratio = CONTEXT_PADDING_RATIO
+        self.max_context_padding = MAX_CONTEXT_PADDING
+        self._prompt_embeds = None
+
+    # ---- model lifecycle (delegated to the manager, as in the reference) ------------------------------
+    def load_models(self):
+        if self.pipeline is not None:
+            return
+        # every backend name maps onto the one MI355X-native FLUX graph
+        self.pipeline = self.manager.load_flux_kontext_sdnq(low_vram=self.low_vram, verbose=True)
+
+    def unload_models(self):
+        self.pipeline = None
+        self._prompt_embeds = None
+        self.manager.unload_flux_kontext_sdnq_models()
+
+    # ---- geometry -----------------------------------------------------------------------------------
+    def flux_kontext_image_scale(self, image_pil: Image.Image) -> Image.Image:
+        w_in, h_in = image_pil.size
+        if w_in == 0 or h_in == 0:
+            return image_pil
+        w_opt, h_opt = nearest_preferred_resolution(w_in, h_in, self.PREFERED_KONTEXT_RESOLUTIONS)
+        if (w_in, h_in) == (w_opt, h_opt):
+            return image_pil
+        return image_pil.resize((w_opt, h_opt), Image.Resampling.LANCZOS)
+
+    def compute_mask_bbox_aspect_ratio(self, mask_chw, padding, blur_radius, target_ar=None, transpose=False,
+                                       preferred_resolutions=None, verbose=False):
+        """-> (alpha[1,h,w] tensor, x, y, w, h) — same return shape as the reference (:327-495)."""
+        m = mask_chw[0, 0] if mask_chw.dim() == 4 else mask_chw[0]
+        mask = m.cpu().numpy() > 0
+        H, W = mask.shape
+        if not mask.any():
+            return torch.zeros((1, H, W), dtype=mask_chw.dtype), 0, 0, W, H
+        alpha = feather_alpha(mask, blur_radius)
+        x, y, w, h = mask_region(mask, padding, None if preferred_resolutions else target_ar, transpose)
+        return torch.from_numpy(alpha[y:y + h, x:x + w])[None].to(mask_chw.dtype), x, y, w, h
+
+    def region_for_mask(self, mask_np: np.ndarray, strict_mask_clipping: bool = False,
+                        composite_clip_bbox: Optional[Tuple[int, int, int, int]] = None):
+        """Crop rectangle and composite alpha for one mask: (alpha[h,w] f32, x, y, w, h, padding, blur)."""
+        mask = np.asarray(mask_np).astype(bool)
+        img_h, img_w = mask.shape
+        rows, cols = np.flatnonzero(mask.any(axis=1)), np.flatnonzero(mask.any(axis=0))
+        side = max(int(cols[-1]) - int(cols[0]), int(rows[-1]) - int(rows[0]))
+        padding = min(int(side * self.context_padding_ratio), self.max_context_padding)
+        blur = max(MIN_BLUR_RADIUS, min(int(side * BLUR_SCALE_FACTOR), MAX_BLUR_RADIUS))
+        alpha_full = feather_alpha(mask, blur)
+        x, y, w, h = mask_region(mask, padding, None)
+        qx, qy, qw, qh = quantize_region(x, y, w, h, img_w, img_h)
+        # alpha of the un-quantised crop, shifted into the quantised one (zero where the crop grew)
+        alpha = np.zeros((qh, qw), np.float32)
+        sx0, sy0 = max(x, qx), max(y, qy)
+        sx1, sy1 = min(x + w, qx + qw), min(y + h, qy + qh)
+        if sx1 > sx0 and sy1 > sy0:
+            alpha[sy0 - qy:sy1 - qy, sx0 - qx:sx1 - qx] = alpha_full[sy0:sy1, sx0:sx1]
+        if strict_mask_clipping:
+            alpha = alpha * mask[qy:qy + qh, qx:qx + qw].astype(np.float32)
+        if composite_clip_bbox is not None:
+            cx1, cy1, cx2, cy2 = composite_clip_bbox
+            cx1, cx2 = max(0, min(img_w, cx1)), max(0, min(img_w, cx2))
+            cy1, cy2 = max(0, min(img_h, cy1)), max(0, min(img_h, cy2))
+            keep = np.zeros_like(alpha)
+            ax0, ax1 = max(0, cx1 - qx), min(qw, cx2 - qx)
+            ay0, ay1 = max(0, cy1 - qy), min(qh, cy2 - qy)
+            if ax1 > ax0 and ay1 > ay0:
+                keep[ay0:ay1, ax0:ax1] = alpha[ay0:ay1, ax0:ax1]
+            alpha = keep
+        return alpha, qx, qy, qw, qh, padding, blur
+
+    # ---- the operator ---------------------------------------------------------------------------------
+    def inpaint_mask(self, image_pil: Image.Image, mask_np: np.ndarray, seed: int = 1, verbose: bool = False,
+                     ocr_params: Optional[Dict] = None, strict_mask_clipping: bool = False,
+                     composite_clip_bbox: Optional[Tuple[int, int, int, int]] = None) -> Image.Image:
+        mask = np.asarray(mask_np)
+        if mask.dtype != bool:
+            mask = mask.astype(bool)
+        if not mask.any():
+            return image_pil
+        alpha, x, y, w, h, padding, blur = self.region_for_mask(mask, strict_mask_clipping, composite_clip_bbox)
+        log_message(f"  - Optimized bbox found at ({x}, {y}) with size {w}x{h}", verbose=verbose)
+        crop = image_pil.crop((x, y, x + w, y + h))
+        scaled = self.flux_kontext_image_scale(crop)
+        inf_w, inf_h = scaled.size
+        if scaled.mode == "RGBA":
+            scaled = scaled.convert("RGB")
+        with self.manager.flux_inference_lock:
+            self.load_models()
+            if self.pipeline is None:
+                log_message("Warning: Flux Kontext pipeline not available. Skipping inpainting.", always_print=True)
+                return image_pil
+            with torch.inference_mode():
+                gen = torch.Generator(device="cpu").manual_seed(seed)
+                out = self.pipeline(image=scaled, width=inf_w, height=inf_h, num_inference_steps=self.num_inference_steps,
+                                    guidance_scale=self.guidance_scale, generator=gen, output_type="pt",
+                                    max_area=inf_w * inf_h, **self._prompt_kwargs())
+                img = out.images[0].float().cpu()
+                img = torch.nan_to_num(img, nan=0.0, posinf=1.0, neginf=0.0).clamp_(0, 1)
+                patch = Image.fromarray(img.mul(255).round().to(torch.uint8).permute(1, 2, 0).numpy())
+        patch = patch.resize((w, h), Image.Resampling.LANCZOS)
+        page = np.asarray(image_pil)
+        return Image.fromarray(composite_u8(page, np.asarray(patch), alpha, x, y))
+
+    def _prompt_kwargs(self) -> dict:
+        enc = getattr(self.pipeline, "encode_prompt", None)
+        if enc is None:
+            return {}
+        if self._prompt_embeds is None:
+            res = enc(prompt=self.prompt, prompt_2=None, device=self.DEVICE)
+            self._prompt_embeds = (res[0], res[1])
+        return {"prompt_embeds": self._prompt_embeds[0], "pooled_prompt_embeds": self._prompt_embeds[1]}

@@ -1,0 +1,240 @@
+"""Model lifecycle for the MI355X hot path (SURVEY.md §8 rows a10 / b).
+
+Same surface as the reference's `ModelManager` (core/ml/model_manager.py:57-1525) for the models on
+the vision path: a process-wide singleton with `.device`, `.dtype`, `.models`, `.model_paths`,
+`.flux_inference_lock`, `load_upscale()`, `load_upscale_lite()`, `load_sam2()`,
+`load_flux_kontext_sdnq()`, `unload_*()`, `clear_cache()`, `set_hf_token()` — but what the loaders
+return are libmtx_hip graph objects with the call shapes the operators use:
+
+    upscale model   model(tensor[1,3,H,W] f32) -> tensor            (image_utils.py:369-374)
+    SAM 2.1         (processor, model): processor(image, input_boxes=...), model(**inputs).pred_masks,
+                    processor.post_process_masks(...)               (detection.py:494-509)
+
+Checkpoints are read from `./models/...` exactly where the reference stores them; there is no
+network code here (downloads are the reference's job).  A missing file raises ModelError, which the
+reference's callers already catch and degrade on.  When several ranks are up, rank 0 reads the file
+and the tensors travel to the other GPUs in ONE flat RCCL broadcast over xGMI (`broadcast_state_dict`).
+"""
+import threading
+from enum import Enum
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+from ...utils.exceptions import ModelError
+from ...utils.logging import log_message
+from ..device import empty_cache, get_best_device, get_best_dtype
+
+
+class ModelType(Enum):
+    UPSCALE = "upscale"
+    UPSCALE_LITE = "upscale_lite"
+    YOLO_SPEECH_BUBBLE = "yolo_speech_bubble"
+    YOLO_SPEECH_BUBBLE_2 = "yolo_speech_bubble_2"
+    SAM2 = "sam2"
+    FLUX_KONTEXT_SDNQ_PIPELINE = "flux_kontext_sdnq_pipeline"
+
+
+def broadcast_state_dict(sd: Optional[dict], template: Optional[dict] = None, src: int = 0) -> dict:
+    """One flat collective for a whole checkpoint.  Rank `src` passes `sd`; the others pass a
+    `template` (name -> shape) or the same-shaped dict.  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sd
+    rank = dist.get_rank()
+    shapes = {k: tuple(v.shape) for k, v in (sd if rank == src else (template or sd)).items()}
+    keys = sorted(shapes)
+    sizes = [max(1, int(torch.tensor(shapes[k]).prod().item())) if len(shapes[k]) else 1 for k in keys]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    if rank == src:
+        flat.copy_(torch.cat([sd[k].detach().float().reshape(-1) for k in keys]))
+    dist.broadcast(flat, src=src)
+    flat = flat.cpu()
+    out, off = {}, 0
+    for k, n in zip(keys, sizes):
+        out[k] = flat[off:off + n].view(shapes[k]).clone()
+        off += n
+    return out
+
+
+class _Sam2ProcessorShim:
+    """The slice of `Sam2Processor` the operator uses; the heavy lifting is fused into the model."""
+
+    def __call__(self, image, input_boxes=None, return_tensors="pt"):
+        import numpy as np
+        arr = np.asarray(image.convert("RGB")) if hasattr(image, "convert") else np.asarray(image)
+        boxes = torch.as_tensor(input_boxes, dtype=torch.float32).reshape(1, -1, 4)
+        return _Sam2Inputs(page=arr, input_boxes=boxes, original_sizes=torch.tensor([[arr.shape[0], arr.shape[1]]]))
+
+    @staticmethod
+    def post_process_masks(pred_masks, original_sizes, **kw):
+        return pred_masks.resolved_masks()
+
+
+class _Sam2Inputs(dict):
+    def __init__(self, **kw):
+        super().__init__(**kw)
+
+    def to(self, device):
+        return self
+
+
+class _Sam2Outputs:
+    def __init__(self, masks_u8, low_res, iou):
+        self.pred_masks = _PredMasks(masks_u8, low_res)
+        self.iou_scores = iou
+
+
+class _PredMasks:
+    """Carries the page-resolution bitmasks produced on the device; `post_process_masks` returns them in
+    the reference's shape ([N,1,H,W] bool per image) without a second resize pass."""
+
+    def __init__(self, masks_u8, low_res):
+        self._m, self.low_res = masks_u8, low_res
+
+    def resolved_masks(self):
+        return [self._m.bool()[:, None]]
+
+
+class _Sam2ModelShim:
+    def __init__(self, hip_model, dtype):
+        self.hip, self.dtype = hip_model, dtype
+
+    def __call__(self, multimask_output=False, **inputs):
+        if multimask_output:
+            raise ModelError("SAM-2.1 on libmtx_hip implements multimask_output=False (the reference's call)")
+        masks, low, iou, _ = self.hip.segment(inputs["page"], inputs["input_boxes"][0].numpy(), return_logits=True)
+        return _Sam2Outputs(masks, low, iou)
+
+
+class ModelManager:
+    _instance = None
+    _lock = threading.RLock()
+
+    def __new__(cls):
+        with cls._lock:
+            if cls._instance is None:
+                cls._instance = super().__new__(cls)
+                cls._instance._initialized = False
+        return cls._instance
+
+    def __init__(self):
+        with self._lock:
+            if self._initialized:
+                return
+            self.device = get_best_device()
+            self.dtype = get_best_dtype(self.device)
+            self.models = {}
+            model_dir = Path("./models").resolve()
+            self.model_paths = {
+                ModelType.UPSCALE: model_dir / "upscale" / "2x-AnimeSharpV4_RCAN.safetensors",
+                ModelType.UPSCALE_LITE: model_dir / "upscale" / "2x-AnimeSharpV4_Fast_RCAN_PU.safetensors",
+                ModelType.SAM2: model_dir / "sam" / "sam2.1-hiera-large",
+                ModelType.FLUX_KONTEXT_SDNQ_PIPELINE: model_dir / "flux" / "kontext",
+            }
+            self.hf_token = None
+            self.flux_hf_token = None
+            self.flux_inference_lock = threading.Lock()
+            self._initialized = True
+            log_message(f"Model Manager initialized on device: {self.device}", always_print=True)
+
+    # ---- bookkeeping -------------------------------------------------------------------------------
+    def is_loaded(self, model_type: ModelType) -> bool:
+        with self._lock:
+            return self.models.get(model_type) is not None
+
+    def set_hf_token(self, token):
+        self.hf_token = token or None
+
+    def set_flux_hf_token(self, token):
+        self.flux_hf_token = token or None
+
+    def clear_cache(self):
+        empty_cache(self.device)
+
+    def unload_model(self, model_type: ModelType, force_gc: bool = True, verbose: bool = False):
+        with self._lock:
+            if not self.is_loaded(model_type):
+                return
+            log_message(f"Unloading {model_type.value}...", verbose=verbose)
+            self.models[model_type] = None
+            if force_gc:
+                empty_cache(self.device)
+
+    def unload_upscale_models(self, verbose: bool = False):
+        self.unload_model(ModelType.UPSCALE, force_gc=False, verbose=verbose)
+        self.unload_model(ModelType.UPSCALE_LITE, force_gc=False, verbose=verbose)
+        empty_cache(self.device)
+
+    def unload_flux_kontext_sdnq_models(self, verbose: bool = False):
+        self.unload_model(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE, verbose=verbose)
+
+    # ---- loaders -----------------------------------------------------------------------------------
+    def _read_safetensors(self, path: Path) -> dict:
+        import torch.distributed as dist
+        rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+        if rank0 and not path.exists():
+            raise ModelError(f"checkpoint not found: {path} (stage it under ./models; this build never downloads)")
+        sd = None
+        if rank0:
+            from safetensors import safe_open
+            with safe_open(str(path), framework="pt", device="cpu") as f:
+                sd = {k: f.get_tensor(k) for k in f.keys()}
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            meta = [{k: tuple(v.shape) for k, v in sd.items()}] if rank0 else [None]
+            dist.broadcast_object_list(meta, src=0)
+            sd = broadcast_state_dict(sd, template={k: torch.empty(s) for k, s in meta[0].items()})
+        return sd
+
+    def _load_rcan(self, model_type: ModelType, verbose: bool):
+        with self._lock:
+            if self.is_loaded(model_type):
+                return self.models[model_type]
+            from .rcan import RCANUpscaler
+            sd = self._read_safetensors(self.model_paths[model_type])
+            model = RCANUpscaler(sd, device=self.device)
+            self.models[model_type] = model
+            log_message(f"Upscale model loaded ({model_type.value}).", verbose=verbose)
+            return model
+
+    def load_upscale(self, verbose: bool = False):
+        return self._load_rcan(ModelType.UPSCALE, verbose)
+
+    def load_upscale_lite(self, verbose: bool = False):
+        return self._load_rcan(ModelType.UPSCALE_LITE, verbose)
+
+    def load_sam2(self, verbose: bool = False):
+        """-> (processor, model) like the reference (:982-1010), backed by the HIP graph."""
+        with self._lock:
+            if self.is_loaded(ModelType.SAM2):
+                return self.models[ModelType.SAM2]
+            from .sam2 import Sam2Hip
+            root = self.model_paths[ModelType.SAM2]
+            weights, cfg = root / "model.safetensors", root / "config.json"
+            if not cfg.exists():
+                raise ModelError(f"SAM-2.1 config not found: {cfg}")
+            from transformers import Sam2Config
+            config = Sam2Config.from_pretrained(str(root))
+            sd = self._read_safetensors(weights)
+            hip = Sam2Hip(sd, config, device=self.device)
+            self.models[ModelType.SAM2] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
+            log_message("SAM 2.1 model loaded.", verbose=verbose)
+            return self.models[ModelType.SAM2]
+
+    def load_flux_kontext_sdnq(self, low_vram: bool = False, verbose: bool = False):
+        """The MI355X FLUX graph; returns None while that model is not built or not staged, which the
+        inpainter treats like the reference's "pipeline not available"."""
+        with self._lock:
+            return self.models.get(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE)
+
+
+_model_manager = None
+
+
+def get_model_manager() -> ModelManager:
+    global _model_manager
+    if _model_manager is None:
+        _model_manager = ModelManager()
+    return _model_manager

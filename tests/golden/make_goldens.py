@@ -1,0 +1,238 @@
+"""Generates the golden vectors for the host-side integer logic of the hot path by IMPORTING THE
+REFERENCE (read-only, /root/reference) in this container — SURVEY.md Appendix C harness: heavy
+third-party deps are stubbed, only pure-Python reference functions are executed.  The reference
+cannot travel to the GPU box, so the vectors are committed as small fixtures next to this script:
+
+    python tests/golden/make_goldens.py        # rewrites tests/golden/*.json / *.npz
+
+Covered (reference file:line):
+  box hygiene      core/image/detection.py:219-254 (_deduplicate_primary_boxes), :257-295
+                   (_remove_contained_boxes), :345-400 (_categorize_detections), :403-472
+                   (_detect_overlapping_primaries)
+  wave scheduling  core/batch_coordinator.py:78-153 (bboxes_overlap, expanded_mask_bbox,
+                   partition_non_overlapping_waves)
+  FLUX host math   core/image/inpainting.py:327-495 (compute_mask_bbox_aspect_ratio), :636-977
+                   (inpaint_mask with a deterministic stand-in pipeline: crop geometry, bbox
+                   quantisation, preferred-resolution choice, LANCZOS round trip, alpha composite)
+  harness          core/pipeline.py:133-142 (_natural_path_sort_key), :2027-2064 (_resolve_output_path),
+                   core/scaling.py:64-96 (scale_kernel)
+"""
+import json
+import sys
+import types
+from pathlib import Path
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REF = "/root/reference"
+
+import importlib.machinery
+import importlib.util
+for name in ["cv2", "spandrel", "ultralytics", "oxipng", "diffusers", "sdnq", "skia", "uharfbuzz", "manga_ocr",
+             "pythainlp", "pythainlp.tokenize", "gradio", "torchvision"]:
+    try:
+        if importlib.util.find_spec(name) is not None:
+            continue
+    except (ImportError, ValueError):
+        pass
+    stub = MagicMock(name=name)
+    stub.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    sys.modules.setdefault(name, stub)
+for pkg in ["core", "core.image", "core.ml", "core.text", "core.services"]:
+    m = types.ModuleType(pkg)
+    m.__path__ = [REF + "/" + pkg.replace(".", "/")]
+    sys.modules[pkg] = m
+sys.path.insert(0, REF)
+# core.ml.model_manager imports HF processors that need torchvision (absent here); the functions under
+# test never touch it, so the module is replaced by a stub
+_mm = MagicMock(name="core.ml.model_manager")
+_mm.__spec__ = importlib.machinery.ModuleSpec("core.ml.model_manager", None)
+sys.modules["core.ml.model_manager"] = _mm
+
+from core import batch_coordinator, scaling  # noqa: E402
+from core.image import detection, inpainting  # noqa: E402
+from PIL import Image  # noqa: E402
+
+
+def rng_boxes(rng, n, w=1024, h=1536, nest=True):
+    b = []
+    for _ in range(n):
+        x0, y0 = rng.uniform(0, w * 0.8), rng.uniform(0, h * 0.8)
+        b.append([x0, y0, x0 + rng.uniform(30, 300), y0 + rng.uniform(30, 300)])
+    if nest and n >= 4:
+        b[1] = [b[0][0] + 5, b[0][1] + 5, b[0][2] - 5, b[0][3] - 5]          # nested
+        b[2] = [b[0][0] + 1, b[0][1] - 2, b[0][2] + 2, b[0][3] + 1]          # near-duplicate
+        b[3] = [b[0][0] + 0.4 * (b[0][2] - b[0][0]), b[0][1], b[0][2] + 80, b[0][3]]  # partial overlap
+    return np.asarray(b, dtype=np.float32)
+
+
+def gen_boxes():
+    rng = np.random.default_rng(7)
+    cases = []
+    for ci in range(24):
+        n = int(rng.integers(0, 14))
+        boxes = rng_boxes(rng, n, nest=(ci % 3 != 0))
+        conf = rng.uniform(0.3, 0.99, n).astype(np.float32)
+        if n >= 5 and ci % 4 == 0:
+            conf[4] = conf[0]                                                  # tie
+        tb, tc = torch.from_numpy(boxes).reshape(-1, 4), torch.from_numpy(conf)
+        _, keep = detection._deduplicate_primary_boxes(tb, tc, 0.7)
+        _, kept_idx = detection._remove_contained_boxes(tb, None, 0.9)
+        m = int(rng.integers(0, 10))
+        sec = rng_boxes(rng, m, nest=False)
+        if m >= 2 and n >= 1:   # two halves of primary 0 -> conjoined
+            x0, y0, x1, y1 = boxes[0]
+            sec[0] = [x0 + 2, y0 + 2, (x0 + x1) / 2, y1 - 2]
+            sec[1] = [(x0 + x1) / 2, y0 + 2, x1 - 2, y1 - 2]
+        conj, simple = ([], list(range(n)))
+        if n > 0 and m > 0:
+            conj, simple = detection._categorize_detections(tb, torch.from_numpy(sec).reshape(-1, 4))
+        groups, upd = detection._detect_overlapping_primaries(tb, list(simple)) if n > 0 else ([], [])
+        cases.append(dict(boxes=boxes.tolist(), conf=conf.tolist(), secondary=sec.tolist(),
+                          dedup_keep=[int(k) for k in keep], contained_keep=[int(i) for _, i in kept_idx],
+                          conjoined=[[int(p), [int(s) for s in ss]] for p, ss in conj], simple=[int(s) for s in simple],
+                          synthetic_groups=[[int(x) for x in g] for g in groups], simple_after=[int(s) for s in upd]))
+    return cases
+
+
+def rand_mask(rng, h, w, kind):
+    m = np.zeros((h, w), bool)
+    if kind == 0:
+        x0, y0 = int(rng.integers(0, w - 40)), int(rng.integers(0, h - 40))
+        m[y0:y0 + int(rng.integers(8, 120)), x0:x0 + int(rng.integers(8, 160))] = True
+    elif kind == 1:
+        yy, xx = np.mgrid[0:h, 0:w]
+        cx, cy = rng.uniform(0.2, 0.8) * w, rng.uniform(0.2, 0.8) * h
+        m = ((xx - cx) / rng.uniform(20, 90)) ** 2 + ((yy - cy) / rng.uniform(15, 70)) ** 2 <= 1
+    elif kind == 2:
+        m[0:int(rng.integers(5, 60)), 0:int(rng.integers(5, 80))] = True            # flush top-left
+    else:
+        m[h - int(rng.integers(5, 60)):, w - int(rng.integers(5, 80)):] = True      # flush bottom-right
+    return m
+
+
+COORD_MASKS = {}
+
+
+def gen_coordinator():
+    rng = np.random.default_rng(11)
+    out = []
+    for ci in range(16):
+        h, w = int(rng.integers(200, 500)), int(rng.integers(200, 500))
+        m = rand_mask(rng, h, w, ci % 4)
+        bbox = batch_coordinator.expanded_mask_bbox(m, (w, h))
+        out.append(dict(h=h, w=w, seed=int(ci), kind=ci % 4, bbox=list(bbox) if bbox else None))
+        COORD_MASKS[f"m{ci}"] = np.packbits(m)
+    waves_cases = []
+    for ci in range(12):
+        n = int(rng.integers(0, 9))
+        items = []
+        for _ in range(n):
+            if rng.uniform() < 0.15:
+                items.append(None)
+            else:
+                x0, y0 = int(rng.integers(0, 300)), int(rng.integers(0, 300))
+                items.append([x0, y0, x0 + int(rng.integers(10, 150)), y0 + int(rng.integers(10, 150))])
+        idx = list(range(n))
+        waves = batch_coordinator.partition_non_overlapping_waves(idx, lambda i: tuple(items[i]) if items[i] else None)
+        waves_cases.append(dict(bboxes=items, waves=waves))
+    return dict(expanded=out, waves=waves_cases)
+
+
+class _FakeOut:
+    def __init__(self, img):
+        self.images = [img]
+
+
+def fake_pipeline(**kw):
+    """Deterministic stand-in for FluxKontextPipeline: inverted, slightly blurred input at the requested size."""
+    img = kw["image"].convert("RGB").resize((kw["width"], kw["height"]), Image.BILINEAR)
+    t = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
+    return _FakeOut(1.0 - 0.9 * t)
+
+
+def gen_inpaint():
+    rng = np.random.default_rng(5)
+    inp = inpainting.FluxKontextInpainter.__new__(inpainting.FluxKontextInpainter)
+    # only the attributes inpaint_mask touches
+    inp.context_padding_ratio = inpainting.CONTEXT_PADDING_RATIO
+    inp.max_context_padding = inpainting.MAX_CONTEXT_PADDING
+    inp.PREFERED_KONTEXT_RESOLUTIONS = [(672, 1568), (688, 1504), (720, 1456), (752, 1392), (800, 1328), (832, 1248),
+                                        (880, 1184), (944, 1104), (1024, 1024), (1104, 944), (1184, 880), (1248, 832),
+                                        (1328, 800), (1392, 752), (1456, 720), (1504, 688), (1568, 672)]
+    inp.backend = "sdnq"
+    inp.low_vram = True
+    inp.DEVICE = torch.device("cpu")
+    inp.num_inference_steps = 4
+    inp.residual_diff_threshold = 0.12
+    inp.guidance_scale = 2.5
+    inp.prompt = "Remove all text."
+    inp.pipeline = fake_pipeline
+    inp.load_models = lambda *a, **k: None
+    inp._get_prompt_embeddings = lambda *a, **k: (None, None)
+    inp.manager = types.SimpleNamespace(flux_inference_lock=__import__("threading").Lock())
+    inp.cache = types.SimpleNamespace(should_use_inpaint_cache=lambda seed: False)
+    inpainting._flux_prompt_kwargs = lambda a, b: {}
+    inpainting._pipeline_execution_device = lambda p, d: d
+    geo, arrays = [], {}
+    for ci in range(8):
+        h, w = int(rng.integers(220, 420)), int(rng.integers(220, 420))
+        m = rand_mask(rng, h, w, ci % 4)
+        yy, xx = np.mgrid[0:h, 0:w]
+        page = np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (xx * yy // 7) % 256], -1).astype(np.uint8)
+        mt = torch.from_numpy(m.astype(np.float32))[None, None]
+        ys, xs = np.where(m)
+        bw, bh = int(xs.max()) - int(xs.min()), int(ys.max()) - int(ys.min())
+        padding = min(int(max(bw, bh) * inp.context_padding_ratio), inp.max_context_padding)
+        blur = max(inpainting.MIN_BLUR_RADIUS, min(int(max(bw, bh) * inpainting.BLUR_SCALE_FACTOR), inpainting.MAX_BLUR_RADIUS))
+        alpha, x, y, ww, hh = inp.compute_mask_bbox_aspect_ratio(mask_chw=mt, padding=padding, blur_radius=blur,
+                                                                 preferred_resolutions=inp.PREFERED_KONTEXT_RESOLUTIONS)
+        strict = bool(ci % 2)
+        clip = None if ci % 3 else [int(xs.min()) - 3, int(ys.min()) - 3, int(xs.max()) + 9, int(ys.max()) + 9]
+        out = inp.inpaint_mask(Image.fromarray(page), m, seed=1, strict_mask_clipping=strict, composite_clip_bbox=clip)
+        geo.append(dict(h=h, w=w, kind=ci % 4, padding=padding, blur=blur, bbox=[x, y, ww, hh], strict=strict, clip=clip))
+        arrays[f"mask{ci}"] = np.packbits(m)
+        arrays[f"alpha{ci}"] = alpha.numpy().astype(np.float32)
+        o = np.asarray(out)
+        assert np.array_equal(np.delete(o.reshape(-1, 3), [], 0).shape, page.reshape(-1, 3).shape)
+        outside = np.ones((h, w), bool); outside[y:y + hh, x:x + ww] = False
+        # the crop can shift by the 2-px quantisation; store a generous window and require the rest untouched
+        y0, y1, x0, x1 = max(0, y - 4), min(h, y + hh + 4), max(0, x - 4), min(w, x + ww + 4)
+        outside[y0:y1, x0:x1] = False
+        assert np.array_equal(o[outside], page[outside])
+        arrays[f"out{ci}"] = o[y0:y1, x0:x1]
+        geo[-1]["window"] = [y0, y1, x0, x1]
+    consts = dict(context_padding_ratio=inp.context_padding_ratio, max_context_padding=inp.max_context_padding,
+                  blur_scale=inpainting.BLUR_SCALE_FACTOR, min_blur=inpainting.MIN_BLUR_RADIUS, max_blur=inpainting.MAX_BLUR_RADIUS)
+    return geo, arrays, consts
+
+
+def gen_harness():
+    from core import pipeline
+    names = ["ch2/001.jpg", "ch2/010.jpg", "ch10/001.jpg", "P1.png", "p2.png", "p10.png", "a/b/3.webp", "a/b/12.webp",
+             "a/B/2.webp", "007.png", "7.png", "x1y20.png", "x1y3.png", "X1y3.PNG", "z.jpeg"]
+    order = sorted(names, key=lambda s: pipeline._natural_path_sort_key(Path(s)))
+    res = []
+    for fmt in ("png", "jpeg", "auto", "bogus"):
+        for preserve in (False, True):
+            cfg = types.SimpleNamespace(output=types.SimpleNamespace(output_format=fmt))
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                outp, disp, err = pipeline._resolve_output_path(Path("/in/ch1/p01.JPG"), Path("/in"), Path(td), cfg, preserve)
+                res.append(dict(fmt=fmt, preserve=preserve, out=str(outp.relative_to(td)), display=disp, error_key=err))
+    kernels = [[list(scaling.scale_kernel((a, b), s)) for s in (None, 0.5, 1.0, 1.254, 2.5, 6.3)] for a, b in ((7, 7), (5, 5), (3, 9))]
+    return dict(names=names, order=order, resolve=res, scale_kernel=kernels)
+
+
+if __name__ == "__main__":
+    json.dump(gen_boxes(), open(HERE / "box_hygiene.json", "w"))
+    json.dump(gen_coordinator(), open(HERE / "batch_coordinator.json", "w"))
+    np.savez_compressed(HERE / "batch_coordinator_masks.npz", **COORD_MASKS)
+    geo, arrays, consts = gen_inpaint()
+    json.dump(dict(cases=geo, consts=consts), open(HERE / "kontext_geometry.json", "w"))
+    np.savez_compressed(HERE / "kontext_arrays.npz", **arrays)
+    json.dump(gen_harness(), open(HERE / "harness.json", "w"))
+    print("golden vectors written to", HERE)
