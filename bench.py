@@ -95,7 +95,24 @@ def main():
         if rank != 0:
             sd = {k: torch.empty_like(v) for k, v in make_state_dict(seed=0, **rcan_cfg).items()}
         sd = broadcast_state_dict(sd, rank, world, device)
-    want = ["segment", "upscale"] if args.stages == "all" else [x.strip() for x in args.stages.split(",")]
+    want = ["detect", "segment", "upscale"] if args.stages == "all" else [x.strip() for x in args.stages.split(",")]
+    yolo = None
+    if "detect" in want:
+        from mangatranslator_amd.core.ml.yolo import YoloSegHip
+        from oracle.yolo_ref import make_model as make_yolo       # seeded YOLOv8m-seg (the reference's yolo_1 geometry)
+        ysd = None
+        if rank == 0 or world == 1:
+            ynet = make_yolo("m", 1, seed=3)
+            with torch.no_grad():
+                for l in range(3):
+                    ynet.model[22].cv3[l][2].weight.mul_(0.05); ynet.model[22].cv3[l][2].bias.fill_(-1.0)
+                    ynet.model[22].cv2[l][2].weight.mul_(0.1)
+            ysd = ynet.state_dict()
+        if world > 1:
+            if rank != 0:
+                ysd = {k: torch.empty_like(v) for k, v in make_yolo("m", 1, seed=0).state_dict().items()}
+            ysd = broadcast_state_dict(ysd, rank, world, device)
+        yolo = YoloSegHip(ysd, device=device, lib=lib, graph=not args.no_graph)
     upscaler = RCANUpscaler(sd, device=device, lib=lib, graph=not args.no_graph) if "upscale" in want else None
     sam = None
     if "segment" in want:
@@ -126,12 +143,20 @@ def main():
         page_boxes.append(boxes)
     torch.cuda.synchronize()
 
-    stages = [st for st in ("segment", "upscale") if st in want]
-    outs = [None, None]
-    stage_s = {st: 0.0 for st in stages}
+    stages = [st for st in ("detect", "segment", "upscale") if st in want]
+    outs = [None, None, None]
+    page_bgr = [pg.flip(-1).contiguous().cpu().numpy() for pg in pages]   # the detector's input is BGR (cv2 layout)
+    yolo_conf = 0.6
+    if yolo is not None:     # untimed calibration: seeded weights have arbitrary scores; let ~boxes anchors pass
+        r0 = yolo(page_bgr[0], conf=0.0, imgsz=1600, max_det=1)[0]
+        plan0, _ = yolo._plans[(H_, W_, 1600)]
+        sc = plan0.decoded[:, 4].float().sort(descending=True).values
+        yolo_conf = float(sc[min(3 * args.boxes, len(sc) - 1)])
 
     def step(i, timed=False):
         pg = pages[i % pool]
+        if yolo is not None:     # letterbox @1600 -> YOLOv8m-seg -> decode -> NMS -> retina masks
+            outs[2] = yolo(page_bgr[i % pool], conf=yolo_conf, imgsz=1600)[0]
         if sam is not None:      # detect is not built yet: the generator's ground-truth boxes stand in
             outs[0] = sam.segment(pg, page_boxes[i % pool])
         if upscaler is not None:
@@ -164,7 +189,9 @@ def main():
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{W_}x{H_} synthetic pages, one page per step per GPU, HBM-resident input",
                    "stages": stages,
-                   "stages_not_built_yet": ["detect(YOLO)", "inpaint(FLUX)"],
+                   "stages_not_built_yet": ["inpaint(FLUX)"],
+                   "detector": {"arch": "YOLOv8m-seg @imgsz 1600 (1088x1600 letterbox)", "weights": "seeded random",
+                                "note": "detections feed NMS + retina masks; SAM prompts are the generator's ground-truth boxes"} if yolo is not None else None,
                    "boxes_per_page": args.boxes,
                    "segmenter": {"arch": "SAM-2.1 Hiera-L (HF Sam2Model layout)", "weights": "seeded random"} if sam is not None else None,
                    "upscaler": {"arch": "RCAN", **rcan_cfg, "weights": "seeded random (no checkpoint offline)"} if upscaler is not None else None,
@@ -176,6 +203,9 @@ def main():
         pre, enc, dec, post = sam.plans(args.boxes, H_, W_)
         result["config"]["segment_ms"] = {"preprocess": pre.time(5), "encoder": enc.time(5, graph=False),
                                           "decoder": dec.time(5, graph=False), "upsample_threshold": post.time(5)}
+    if rank == 0 and yolo is not None:
+        yp, _ = yolo._plans[(H_, W_, 1600)]
+        result["config"]["detect_net_ms"] = yp.time(5, graph=False)
     if rank == 0 and upscaler is not None:
         result["config"]["upscale_ms"] = upscaler.plan_for(1, H_, W_).time(3, graph=False)
     if rank == 0 and upscaler is None:

@@ -172,6 +172,10 @@ typedef struct mtx_resize_thresh_args {
   int64_t n, hs, ws, hd, wd; float thresh; int32_t dtype;
   int32_t pix_stride;               /* elements between source pixels (0 -> 1) */
   const int32_t* sel;               /* optional [N]: channel picked per sample */
+  int64_t batch_stride;             /* elements between samples (-1 -> hs*ws*pix_stride; 0 = shared map) */
+  int32_t roi_y, roi_x, roi_h, roi_w;  /* source window that is resized (roi_h == 0 -> whole map) */
+  const float* crop_xyxy;           /* optional [N][4] page-space boxes: mask = 0 outside [x1,x2) x [y1,y2)
+                                       (ultralytics ops.crop_mask)                                   */
 } mtx_resize_thresh_args;
 
 /* SAM-2.1 single-mask selection (transformers Sam2MaskDecoder._dynamic_multimask_via_stability,
@@ -188,12 +192,26 @@ typedef struct mtx_mask_select_args {
 typedef struct mtx_preproc_args {
   const uint8_t* src; void* dst;
   int64_t h, w, oh, ow; int32_t c_pad; float mean[3]; float std[3]; int32_t dtype;
+  /* mode 1 = ultralytics LetterBox (called at core/image/detection.py:1337-1345): the page is resized
+   * with plain bilinear (no antialias) to new_h x new_w, placed at (pad_top, pad_left) of the oh x ow
+   * canvas filled with pad_value (114), channels flipped BGR -> RGB, scaled by 1/255.          */
+  int32_t mode; int32_t new_h, new_w, pad_top, pad_left; float pad_value;
 } mtx_preproc_args;
+
+/* YOLOv8 Detect/Segment head decode (ultralytics nn/modules/head.py Detect._inference + DFL):
+ * per anchor: box = dist2bbox(softmax-expectation over reg_max bins of the 4 sides) * stride (xyxy in
+ * letterboxed pixels), class scores = sigmoid, mask coefficients copied.  Level l holds NHWC rows of
+ * [4*reg_max | nc | nm] channels (ld elements per pixel).  out: fp32 [anchors][4 + nc + nm].      */
+typedef struct mtx_yolo_decode_args {
+  const void* level[4]; int32_t lh[4], lw[4], lld[4], lstride[4];
+  int32_t n_levels, nc, nm, reg_max; float* out; int32_t dtype;
+  int32_t cls_off, mc_off;       /* channel offsets of the class / mask-coefficient slices (0 -> packed) */
+} mtx_yolo_decode_args;
 
 typedef enum mtx_op_kind {
   MTX_OP_CONV2D = 1, MTX_OP_GEMM = 2, MTX_OP_ATTN = 3, MTX_OP_NORM = 4, MTX_OP_GROUPNORM = 5,
   MTX_OP_EW = 6, MTX_OP_CA = 7, MTX_OP_IMG = 8, MTX_OP_RESIZE_THRESH = 9, MTX_OP_MEMSET = 10,
-  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12
+  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12, MTX_OP_YOLO_DECODE = 13
 } mtx_op_kind;
 
 typedef struct mtx_memset_args { void* ptr; int64_t bytes; int32_t value; } mtx_memset_args;
@@ -203,7 +221,7 @@ typedef struct mtx_op {
   union {
     mtx_conv2d_args conv; mtx_gemm_args gemm; mtx_attn_args attn; mtx_norm_args norm;
     mtx_groupnorm_args gn; mtx_ew_args ew; mtx_ca_args ca; mtx_img_args img;
-    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre;
+    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre; mtx_yolo_decode_args yd;
   } u;
 } mtx_op;
 
@@ -227,6 +245,7 @@ MTX_API int mtx_image_convert(const mtx_img_args* a, void* stream);
 MTX_API int mtx_resize_threshold(const mtx_resize_thresh_args* a, void* stream);
 MTX_API int mtx_mask_select(const mtx_mask_select_args* a, void* stream);
 MTX_API int mtx_preprocess(const mtx_preproc_args* a, void* stream);
+MTX_API int mtx_yolo_decode(const mtx_yolo_decode_args* a, void* stream);
 
 /* ---- plans: a network forward as one native call ----------------------------------------- */
 MTX_API int mtx_plan_create(const mtx_op* ops, int n_ops, void** plan);

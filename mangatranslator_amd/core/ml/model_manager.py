@@ -131,6 +131,8 @@ class ModelManager:
             self.model_paths = {
                 ModelType.UPSCALE: model_dir / "upscale" / "2x-AnimeSharpV4_RCAN.safetensors",
                 ModelType.UPSCALE_LITE: model_dir / "upscale" / "2x-AnimeSharpV4_Fast_RCAN_PU.safetensors",
+                ModelType.YOLO_SPEECH_BUBBLE: model_dir / "yolo" / "yolov8m_seg-speech-bubble.safetensors",
+                ModelType.YOLO_SPEECH_BUBBLE_2: model_dir / "yolo" / "manga109-segmentation-bubble.safetensors",
                 ModelType.SAM2: model_dir / "sam" / "sam2.1-hiera-large",
                 ModelType.FLUX_KONTEXT_SDNQ_PIPELINE: model_dir / "flux" / "kontext",
             }
@@ -204,6 +206,21 @@ class ModelManager:
 
     def load_upscale_lite(self, verbose: bool = False):
         return self._load_rcan(ModelType.UPSCALE_LITE, verbose)
+
+    def load_yolo_speech_bubble(self, bubble_detector_model: str = "yolo_2", verbose: bool = False):
+        """YOLO-seg bubble detector as a libmtx_hip graph with the ultralytics call shape
+        (reference :711-743).  The checkpoint is the ultralytics state dict exported to safetensors
+        (tools/export_ultralytics_state_dict.py, run once where ultralytics is installed)."""
+        mt = ModelType.YOLO_SPEECH_BUBBLE_2 if bubble_detector_model == "yolo_2" else ModelType.YOLO_SPEECH_BUBBLE
+        with self._lock:
+            if self.is_loaded(mt):
+                return self.models[mt]
+            from .yolo import YoloSegHip
+            sd = self._read_safetensors(self.model_paths[mt])
+            model = YoloSegHip(sd, device=self.device, names={0: "speech_bubble"})
+            self.models[mt] = model
+            log_message(f"YOLO bubble detector loaded ({mt.value}).", verbose=verbose)
+            return model
 
     def load_sam2(self, verbose: bool = False):
         """-> (processor, model) like the reference (:982-1010), backed by the HIP graph."""

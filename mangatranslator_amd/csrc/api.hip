@@ -23,6 +23,7 @@ int img_launch(const mtx_img_args*, void*, const char**);
 int resize_thresh_launch(const mtx_resize_thresh_args*, void*, const char**);
 int mask_select_launch(const mtx_mask_select_args*, void*, const char**);
 int preproc_launch(const mtx_preproc_args*, void*, const char**);
+int yolo_decode_launch(const mtx_yolo_decode_args*, void*, const char**);
 
 static thread_local std::string g_err;
 
@@ -63,6 +64,7 @@ static int run_op(const mtx_op& op, void* stream) {
     case MTX_OP_RESIZE_THRESH: rc = resize_thresh_launch(&op.u.rt, stream, &err); break;
     case MTX_OP_MASK_SELECT: rc = mask_select_launch(&op.u.sel, stream, &err); break;
     case MTX_OP_PREPROC: rc = preproc_launch(&op.u.pre, stream, &err); break;
+    case MTX_OP_YOLO_DECODE: rc = yolo_decode_launch(&op.u.yd, stream, &err); break;
     case MTX_OP_MEMSET:
       if (hipMemsetAsync(op.u.ms.ptr, op.u.ms.value, (size_t)op.u.ms.bytes, (hipStream_t)stream) != hipSuccess) { rc = MTX_ERR_HIP; err = "memset failed"; }
       else rc = MTX_OK;
@@ -95,6 +97,7 @@ size_t mtx_abi_sizeof(int kind) {
     case MTX_OP_MEMSET: return sizeof(mtx_memset_args);
     case MTX_OP_MASK_SELECT: return sizeof(mtx_mask_select_args);
     case MTX_OP_PREPROC: return sizeof(mtx_preproc_args);
+    case MTX_OP_YOLO_DECODE: return sizeof(mtx_yolo_decode_args);
     default: return 0;
   }
 }
@@ -152,6 +155,7 @@ MTX_OP_ENTRY(mtx_image_convert, mtx_img_args, img_launch)
 MTX_OP_ENTRY(mtx_resize_threshold, mtx_resize_thresh_args, resize_thresh_launch)
 MTX_OP_ENTRY(mtx_mask_select, mtx_mask_select_args, mask_select_launch)
 MTX_OP_ENTRY(mtx_preprocess, mtx_preproc_args, preproc_launch)
+MTX_OP_ENTRY(mtx_yolo_decode, mtx_yolo_decode_args, yolo_decode_launch)
 
 int mtx_conv2d_tiles(const mtx_conv2d_args* a) {
   if (!a) return fail(MTX_ERR_INVALID, "mtx_conv2d_tiles: null args");

@@ -242,7 +242,9 @@ int img_launch(const mtx_img_args* a, void* stream, const char** err) {
 template <typename T>
 __global__ __launch_bounds__(256) void resize_thresh_kernel(mtx_resize_thresh_args p) {
   const long total = p.n * p.hd * p.wd;
-  const float sy = (float)p.hs / (float)p.hd, sx = (float)p.ws / (float)p.wd;
+  const long rh = p.roi_h > 0 ? p.roi_h : p.hs, rw = p.roi_h > 0 ? p.roi_w : p.ws;
+  const long ry = p.roi_h > 0 ? p.roi_y : 0, rx = p.roi_h > 0 ? p.roi_x : 0;
+  const float sy = (float)rh / (float)p.hd, sx = (float)rw / (float)p.wd;
   const T* S = reinterpret_cast<const T*>(p.src);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long x = idx % p.wd, y = (idx / p.wd) % p.hd, n = idx / (p.wd * p.hd);
@@ -250,12 +252,18 @@ __global__ __launch_bounds__(256) void resize_thresh_kernel(mtx_resize_thresh_ar
     float fy = ((float)y + 0.5f) * sy - 0.5f; if (fy < 0.f) fy = 0.f;
     float fx = ((float)x + 0.5f) * sx - 0.5f; if (fx < 0.f) fx = 0.f;
     long y0 = (long)fy, x0 = (long)fx;
-    if (y0 > p.hs - 1) y0 = p.hs - 1;
-    if (x0 > p.ws - 1) x0 = p.ws - 1;
-    const long y1 = y0 + (y0 < p.hs - 1 ? 1 : 0), x1 = x0 + (x0 < p.ws - 1 ? 1 : 0);
+    if (y0 > rh - 1) y0 = rh - 1;
+    if (x0 > rw - 1) x0 = rw - 1;
+    long y1 = y0 + (y0 < rh - 1 ? 1 : 0), x1 = x0 + (x0 < rw - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0;
+    y0 += ry; y1 += ry; x0 += rx; x1 += rx;
     const long ps = p.pix_stride > 0 ? p.pix_stride : 1;
-    const T* base = S + n * p.hs * p.ws * ps + (p.sel ? p.sel[n] : 0);
+    const long bs = p.batch_stride >= 0 ? p.batch_stride : p.hs * p.ws * ps;
+    if (p.crop_xyxy) {
+      const float* b = p.crop_xyxy + n * 4;
+      if (!((float)x >= b[0] && (float)x < b[2] && (float)y >= b[1] && (float)y < b[3])) { p.dst[idx] = 0; continue; }
+    }
+    const T* base = S + n * bs + (p.sel ? p.sel[n] : 0);
     const float v00 = to_f32(base[(y0 * p.ws + x0) * ps]), v01 = to_f32(base[(y0 * p.ws + x1) * ps]);
     const float v10 = to_f32(base[(y1 * p.ws + x0) * ps]), v11 = to_f32(base[(y1 * p.ws + x1) * ps]);
     const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
@@ -326,6 +334,33 @@ __global__ __launch_bounds__(256) void preproc_kernel(mtx_preproc_args p) {
   const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
   const float invy = sy >= 1.f ? 1.f / sy : 1.f, invx = sx >= 1.f ? 1.f / sx : 1.f;
   T* D = reinterpret_cast<T*>(p.dst);
+  if (p.mode == 1) {
+    const float ly = (float)p.h / (float)p.new_h, lx = (float)p.w / (float)p.new_w;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+      const long ox = idx % p.ow, oy = idx / p.ow;
+      const long ry = oy - p.pad_top, rx = ox - p.pad_left;
+      float v[3] = {p.pad_value, p.pad_value, p.pad_value};
+      if (ry >= 0 && ry < p.new_h && rx >= 0 && rx < p.new_w) {
+        float fy = ((float)ry + 0.5f) * ly - 0.5f, fx = ((float)rx + 0.5f) * lx - 0.5f;
+        if (fy < 0.f) fy = 0.f;
+        if (fx < 0.f) fx = 0.f;
+        long y0 = (long)fy, x0 = (long)fx;
+        if (y0 > p.h - 1) y0 = p.h - 1;
+        if (x0 > p.w - 1) x0 = p.w - 1;
+        const long y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+        const float wy = fy - (float)y0, wx = fx - (float)x0;
+        for (int c = 0; c < 3; ++c) {
+          const float a = (float)p.src[(y0 * p.w + x0) * 3 + c], b = (float)p.src[(y0 * p.w + x1) * 3 + c];
+          const float d = (float)p.src[(y1 * p.w + x0) * 3 + c], e = (float)p.src[(y1 * p.w + x1) * 3 + c];
+          v[2 - c] = rintf((1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * d + wx * e));   // BGR -> RGB
+        }
+      }
+      T* o = D + idx * p.c_pad;
+      for (int c = 0; c < 3; ++c) o[c] = from_f32<T>(v[c] * (1.0f / 255.0f));
+      for (int c = 3; c < p.c_pad; ++c) o[c] = from_f32<T>(0.f);
+    }
+    return;
+  }
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long ox = idx % p.ow, oy = idx / p.ow;
     const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
@@ -366,6 +401,44 @@ int preproc_launch(const mtx_preproc_args* a, void* stream, const char** err) {
   if (a->dtype == MTX_BF16) MTX_LAUNCH((preproc_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
   else if (a->dtype == MTX_F16) MTX_LAUNCH((preproc_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
   else { *err = "preprocess: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+  return MTX_OK;
+}
+
+// ---- YOLOv8 head decode --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void yolo_decode_kernel(mtx_yolo_decode_args p, int total) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= total) return;
+  int l = 0, off = a;
+  while (l < p.n_levels - 1 && off >= p.lh[l] * p.lw[l]) { off -= p.lh[l] * p.lw[l]; ++l; }
+  const int y = off / p.lw[l], x = off % p.lw[l];
+  const T* src = reinterpret_cast<const T*>(p.level[l]) + (size_t)off * p.lld[l];
+  float d4[4];
+  for (int s = 0; s < 4; ++s) {          // DFL: expectation of softmax over reg_max bins
+    float m = -1e30f;
+    for (int k = 0; k < p.reg_max; ++k) { const float v = to_f32(src[s * p.reg_max + k]); m = v > m ? v : m; }
+    float se = 0.f, sw = 0.f;
+    for (int k = 0; k < p.reg_max; ++k) { const float e = __expf(to_f32(src[s * p.reg_max + k]) - m); se += e; sw += e * (float)k; }
+    d4[s] = sw / se;
+  }
+  const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)p.lstride[l];
+  float* o = p.out + (size_t)a * (4 + p.nc + p.nm);
+  o[0] = (ax - d4[0]) * st; o[1] = (ay - d4[1]) * st; o[2] = (ax + d4[2]) * st; o[3] = (ay + d4[3]) * st;
+  const T* cls = src + (p.cls_off > 0 ? p.cls_off : 4 * p.reg_max);
+  for (int c = 0; c < p.nc; ++c) o[4 + c] = 1.f / (1.f + __expf(-to_f32(cls[c])));
+  const T* mc = p.mc_off > 0 ? src + p.mc_off : cls + p.nc;
+  for (int c = 0; c < p.nm; ++c) o[4 + p.nc + c] = to_f32(mc[c]);
+}
+
+int yolo_decode_launch(const mtx_yolo_decode_args* a, void* stream, const char** err) {
+  if (!a->out || a->n_levels < 1 || a->n_levels > 4 || a->reg_max < 1 || a->nc < 1) { *err = "yolo_decode: bad arguments"; return MTX_ERR_INVALID; }
+  int total = 0;
+  for (int l = 0; l < a->n_levels; ++l) { if (!a->level[l]) { *err = "yolo_decode: null level"; return MTX_ERR_INVALID; } total += a->lh[l] * a->lw[l]; }
+  if (total == 0) return MTX_OK;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (a->dtype == MTX_BF16) MTX_LAUNCH((yolo_decode_kernel<__bf16>), dim3(blocks), dim3(256), 0, stream, *a, total);
+  else if (a->dtype == MTX_F16) MTX_LAUNCH((yolo_decode_kernel<_Float16>), dim3(blocks), dim3(256), 0, stream, *a, total);
+  else { *err = "yolo_decode: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
   return MTX_OK;
 }
 

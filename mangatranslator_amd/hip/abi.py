@@ -11,7 +11,7 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_SIGMOID, ACT_LEAKY = 
  EW_ROW_GATHER, EW_IM2COL) = range(10)
 IMG_NCHW_F32_TO_NHWC, IMG_NHWC_TO_NCHW_F32, IMG_NHWC_TO_HWC_U8, IMG_HWC_U8_TO_NHWC = range(4)
 (OP_CONV2D, OP_GEMM, OP_ATTN, OP_NORM, OP_GROUPNORM, OP_EW, OP_CA, OP_IMG, OP_RESIZE_THRESH,
- OP_MEMSET, OP_MASK_SELECT, OP_PREPROC) = range(1, 13)
+ OP_MEMSET, OP_MASK_SELECT, OP_PREPROC, OP_YOLO_DECODE) = range(1, 14)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -79,7 +79,8 @@ class ImgArgs(C.Structure):
 class ResizeThreshArgs(C.Structure):
     _fields_ = [("src", vp), ("dst", vp),
                 ("n", i64), ("hs", i64), ("ws", i64), ("hd", i64), ("wd", i64),
-                ("thresh", f32), ("dtype", i32), ("pix_stride", i32), ("sel", vp)]
+                ("thresh", f32), ("dtype", i32), ("pix_stride", i32), ("sel", vp),
+                ("batch_stride", i64), ("roi_y", i32), ("roi_x", i32), ("roi_h", i32), ("roi_w", i32), ("crop_xyxy", vp)]
 
 
 class MaskSelectArgs(C.Structure):
@@ -89,7 +90,14 @@ class MaskSelectArgs(C.Structure):
 
 class PreprocArgs(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("h", i64), ("w", i64), ("oh", i64), ("ow", i64),
-                ("c_pad", i32), ("mean", f32 * 3), ("std", f32 * 3), ("dtype", i32)]
+                ("c_pad", i32), ("mean", f32 * 3), ("std", f32 * 3), ("dtype", i32),
+                ("mode", i32), ("new_h", i32), ("new_w", i32), ("pad_top", i32), ("pad_left", i32), ("pad_value", f32)]
+
+
+class YoloDecodeArgs(C.Structure):
+    _fields_ = [("level", vp * 4), ("lh", i32 * 4), ("lw", i32 * 4), ("lld", i32 * 4), ("lstride", i32 * 4),
+                ("n_levels", i32), ("nc", i32), ("nm", i32), ("reg_max", i32), ("out", vp), ("dtype", i32),
+                ("cls_off", i32), ("mc_off", i32)]
 
 
 class MemsetArgs(C.Structure):
@@ -99,7 +107,7 @@ class MemsetArgs(C.Structure):
 class _OpUnion(C.Union):
     _fields_ = [("conv", ConvArgs), ("gemm", GemmArgs), ("attn", AttnArgs), ("norm", NormArgs),
                 ("gn", GroupNormArgs), ("ew", EwArgs), ("ca", CaArgs), ("img", ImgArgs),
-                ("rt", ResizeThreshArgs), ("ms", MemsetArgs), ("sel", MaskSelectArgs), ("pre", PreprocArgs)]
+                ("rt", ResizeThreshArgs), ("ms", MemsetArgs), ("sel", MaskSelectArgs), ("pre", PreprocArgs), ("yd", YoloDecodeArgs)]
 
 
 class Op(C.Structure):
@@ -109,17 +117,17 @@ class Op(C.Structure):
 ARG_TYPES = {OP_CONV2D: ConvArgs, OP_GEMM: GemmArgs, OP_ATTN: AttnArgs, OP_NORM: NormArgs,
              OP_GROUPNORM: GroupNormArgs, OP_EW: EwArgs, OP_CA: CaArgs, OP_IMG: ImgArgs,
              OP_RESIZE_THRESH: ResizeThreshArgs, OP_MEMSET: MemsetArgs,
-             OP_MASK_SELECT: MaskSelectArgs, OP_PREPROC: PreprocArgs}
+             OP_MASK_SELECT: MaskSelectArgs, OP_PREPROC: PreprocArgs, OP_YOLO_DECODE: YoloDecodeArgs}
 UNION_FIELD = {OP_CONV2D: "conv", OP_GEMM: "gemm", OP_ATTN: "attn", OP_NORM: "norm",
                OP_GROUPNORM: "gn", OP_EW: "ew", OP_CA: "ca", OP_IMG: "img",
-               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms", OP_MASK_SELECT: "sel", OP_PREPROC: "pre"}
+               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms", OP_MASK_SELECT: "sel", OP_PREPROC: "pre", OP_YOLO_DECODE: "yd"}
 
 # every symbol include/mtx_hip.h declares (tests check the built library exports all of them)
 EXPORTS = [
     "mtx_abi_version", "mtx_abi_sizeof", "mtx_last_error", "mtx_init", "mtx_device_info",
     "mtx_conv2d", "mtx_conv2d_tiles", "mtx_gemm", "mtx_attention", "mtx_norm", "mtx_groupnorm",
     "mtx_elementwise", "mtx_channel_attention", "mtx_image_convert", "mtx_resize_threshold",
-    "mtx_mask_select", "mtx_preprocess",
+    "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode",
     "mtx_plan_create", "mtx_plan_run", "mtx_plan_run_graph", "mtx_plan_num_ops",
     "mtx_plan_run_range", "mtx_plan_destroy", "mtx_plan_time", "mtx_plan_time_range",
 ]

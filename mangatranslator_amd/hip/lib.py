@@ -45,7 +45,8 @@ class MtxLibrary:
                         ("mtx_groupnorm", abi.GroupNormArgs), ("mtx_elementwise", abi.EwArgs),
                         ("mtx_channel_attention", abi.CaArgs), ("mtx_image_convert", abi.ImgArgs),
                         ("mtx_resize_threshold", abi.ResizeThreshArgs),
-                        ("mtx_mask_select", abi.MaskSelectArgs), ("mtx_preprocess", abi.PreprocArgs)):
+                        ("mtx_mask_select", abi.MaskSelectArgs), ("mtx_preprocess", abi.PreprocArgs),
+                        ("mtx_yolo_decode", abi.YoloDecodeArgs)):
             getattr(d, name).argtypes = [C.POINTER(t), C.c_void_p]
         d.mtx_conv2d_tiles.argtypes = [C.POINTER(abi.ConvArgs)]
         d.mtx_plan_create.argtypes = [C.POINTER(abi.Op), C.c_int, C.POINTER(C.c_void_p)]

@@ -310,11 +310,35 @@ class PlanBuilder:
         self._add(abi.OP_PREPROC, a, label)
         return dst
 
+    def letterbox(self, src_u8, dst: "Act", h, w, new_h, new_w, pad_top, pad_left, pad_value=114.0, label="letterbox"):
+        a = abi.PreprocArgs()
+        a.src, a.dst = _ptr(src_u8), dst.ptr
+        a.h, a.w, a.oh, a.ow, a.c_pad = h, w, dst.h, dst.w, dst.ld
+        for i in range(3):
+            a.mean[i], a.std[i] = 0.0, 1.0
+        a.dtype, a.mode = self.dtype, 1
+        a.new_h, a.new_w, a.pad_top, a.pad_left, a.pad_value = new_h, new_w, pad_top, pad_left, pad_value
+        self._add(abi.OP_PREPROC, a, label)
+        return dst
+
+    def yolo_decode(self, levels, strides, nc, nm, reg_max, out, cls_off=0, mc_off=0, label="yolo_decode"):
+        a = abi.YoloDecodeArgs()
+        for i, (lv, st) in enumerate(zip(levels, strides)):
+            a.level[i], a.lh[i], a.lw[i], a.lld[i], a.lstride[i] = lv.ptr, lv.h, lv.w, lv.ld, st
+        a.n_levels, a.nc, a.nm, a.reg_max, a.out, a.dtype = len(levels), nc, nm, reg_max, _ptr(out), self.dtype
+        a.cls_off, a.mc_off = cls_off, mc_off
+        self._add(abi.OP_YOLO_DECODE, a, label)
+        return out
+
     def resize_threshold(self, src, dst, n, hs, ws, hd, wd, thresh=0.0, src_dtype=abi.F32, pix_stride=1,
-                         sel=None, label="resize_thresh"):
+                         sel=None, batch_stride=-1, roi=None, crop_xyxy=None, label="resize_thresh"):
         a = abi.ResizeThreshArgs()
         a.src, a.dst = _ptr(src), _ptr(dst)
         a.pix_stride, a.sel = pix_stride, _ptr(sel)
+        a.batch_stride = batch_stride
+        if roi is not None:
+            a.roi_y, a.roi_x, a.roi_h, a.roi_w = roi
+        a.crop_xyxy = _ptr(crop_xyxy)
         a.n, a.hs, a.ws, a.hd, a.wd, a.thresh, a.dtype = n, hs, ws, hd, wd, thresh, src_dtype
         self._add(abi.OP_RESIZE_THRESH, a, label)
         return dst

@@ -1,0 +1,53 @@
+"""YOLOv8-seg parity: libmtx_hip graph vs the torch fp32 oracle (oracle/yolo_ref.py)."""
+import numpy as np
+import torch
+
+from mangatranslator_amd.core.ml.yolo import YoloSegHip
+from mangatranslator_amd.utils.synthetic_pages import make_page
+from oracle import yolo_ref as yr
+
+
+def check_yolo(lib, device, scale="n", h=384, w=256, imgsz=256, seed=0, n_det=12, mask_tol=0.02):
+    net = yr.make_model(scale, 1, seed)
+    with torch.no_grad():      # spread the class scores so a handful of anchors pass the threshold
+        for l in range(3):
+            net.model[22].cv3[l][2].weight.mul_(0.05)
+            net.model[22].cv3[l][2].bias.fill_(-1.0)
+            net.model[22].cv2[l][2].weight.mul_(0.1)     # soft DFL distributions (a trained head is not saturated)
+    page, _, _ = make_page(seed, w, h, bubbles=3)
+    bgr = np.ascontiguousarray(page[..., ::-1])
+    x, lp = yr.letterbox(bgr, imgsz)
+    pred, proto = net(x)
+    scores = pred[0, 4].numpy()
+    conf = float(np.sort(scores)[-n_det])           # threshold that lets ~n_det anchors through
+    ref = yr.predict(net, bgr, imgsz, conf=conf)
+    hip = YoloSegHip(net.state_dict(), device=device, lib=lib)
+    out = hip(bgr, conf=conf, imgsz=imgsz)[0]
+    # raw head outputs
+    plan, _ = hip._plans[(h, w, imgsz)]
+    dec = plan.decoded.cpu()
+    box_err = (dec[:, :4] - pred[0, :4].t()).abs().max().item()
+    cls_err = (dec[:, 4] - pred[0, 4]).abs().max().item()
+    # f16 activations through a random-weight head: up to ~0.05 DFL bins (bin = stride px, max stride 32)
+    assert box_err < 2.0, f"decoded boxes differ by {box_err:.3f} px (letterboxed)"
+    assert (dec[:, :4] - pred[0, :4].t()).abs().median().item() < 0.05
+    assert cls_err < 0.02, f"class scores differ by {cls_err:.4f}"
+    if len(ref["boxes"]) == 0:
+        assert out.boxes is None
+        return box_err, 0.0
+    assert out.boxes is not None
+    got = out.boxes.xyxy.cpu().numpy()
+    # the detections are the same set (threshold ties aside): match by IoU
+    assert abs(len(got) - len(ref["boxes"])) <= 2, (len(got), len(ref["boxes"]))
+    matched, mism = 0, []
+    masks = out.masks.data.cpu().numpy().astype(bool)
+    for i, rb in enumerate(ref["boxes"]):
+        d = np.abs(got - rb[None]).max(1)
+        j = int(d.argmin())
+        if d[j] < 3.0:
+            matched += 1
+            mism.append(float((masks[j] != ref["masks"][i]).mean()))
+    assert matched >= len(ref["boxes"]) - 2
+    # box edges move by a pixel or two (see above), which moves the crop border of the mask with them
+    assert max(mism) < mask_tol, f"mask mismatch {max(mism):.4%}"
+    return box_err, max(mism)
