@@ -72,6 +72,8 @@ typedef struct mtx_conv2d_args {
   int32_t pixel_shuffle;
   int32_t dtype;
   int32_t res_broadcast_n;       /* 1: res has batch 1 and is shared by all n images */
+  int32_t pad_mode;              /* 0: pad k/2 on every side; 1: no pad top/left, 1 bottom/right
+                                    (diffusers Downsample2D: F.pad(0,1,0,1) + conv k3 s2 p0)     */
 } mtx_conv2d_args;
 
 /* C[M,N] = epilogue(A[M,K] * W[N,K]^T)   A row stride lda, C row stride ldc (elements).
@@ -129,9 +131,15 @@ typedef enum mtx_ew_kind {
   MTX_EW_COPY = 6,        /* strided channel-slice copy                                       */
   MTX_EW_GATE_RES = 7,    /* y = b + a * g[row / rows_per, c]   (DiT gated residual)         */
   MTX_EW_ROW_GATHER = 8,  /* y[r, :] = a[idx[r], :], idx = (const int32_t*)s, r < n*h*w       */
-  MTX_EW_IM2COL = 9       /* y[r, tap*C + c] = a[n, oy*s-pad+ky, ox*s-pad+kx, c] (zero outside);
+  MTX_EW_IM2COL = 9,      /* y[r, tap*C + c] = a[n, oy*s-pad+ky, ox*s-pad+kx, c] (zero outside);
                              i0 = k, i1 = stride, pad = k/2; optional s = int32 row map
                              (output row r takes raster output pixel idx[r]); ldy >= k*k*C       */
+  MTX_EW_SOFTMAX_ROWS = 10, /* y[r, :c] = softmax(act_param * a[r, :c]) over rows r < n*h*w (VAE attention) */
+  MTX_EW_TRANSPOSE = 11,  /* y[c, r] = a[r, c] for r < h*w rows, c columns (per n; ldy = row stride of y) */
+  MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
+                             i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then
+                             rotary on interleaved pairs with b = fp32 [rows][d] cos|sin table laid out as
+                             [rows][2][d/2]: (x0, x1) -> (x0*cos - x1*sin, x1*cos + x0*sin)            */
 } mtx_ew_kind;
 
 typedef struct mtx_ew_args {

@@ -203,6 +203,7 @@ class YoloSegHip:
         proto = self._conv(pb, t, "model.22.proto.cv3")
         plan = pb.build()
         plan.img, plan.decoded, plan.proto = img, decoded, proto
+        plan.dbg = dict(p2=p2, p3=p3, p4=p4, p5=p5, h4=h4, h3=h3, n4=n4, n5=n5, head0=heads[0], head1=heads[1], head2=heads[2])
         return plan
 
     def _mask_plan(self, nd, mh, mw, roi, h0, w0):

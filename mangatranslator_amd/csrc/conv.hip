@@ -31,6 +31,7 @@ struct ConvParams {
   int act; float act_param; float res_scale;
   int ps;           // pixel shuffle factor (0 or 2)
   int res_bcast;
+  int pad_lo;       // zero padding on the top/left side
   int tiles_x, tiles_y, nblk;
 };
 
@@ -84,9 +85,8 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
   const int ty0 = (tile / p.tiles_x) * C::TH;
   const int tx0 = (tile % p.tiles_x) * C::TW;
   const int n0 = nb * C::BN;
-  constexpr int PAD = KS / 2;
-  const int iy0 = ty0 * S - PAD;
-  const int ix0 = tx0 * S - PAD;
+  const int iy0 = ty0 * S - p.pad_lo;
+  const int ix0 = tx0 * S - p.pad_lo;
 
   f32x4 acc[C::FR][4];
 #pragma unroll
@@ -248,8 +248,10 @@ static int launch_conv_t(const mtx_conv2d_args* a, const ConvParams& p, void* st
 static bool conv_geometry(const mtx_conv2d_args* a, ConvParams& p, int& tiles) {
   if (!((a->ksize == 3 && (a->stride == 1 || a->stride == 2)) || (a->ksize == 1 && a->stride == 1))) return false;
   const int pad = a->ksize / 2;
-  p.ho = (a->h + 2 * pad - a->ksize) / a->stride + 1;
-  p.wo = (a->w_in + 2 * pad - a->ksize) / a->stride + 1;
+  const int pad_total = a->pad_mode == 1 ? 1 : 2 * pad;
+  p.pad_lo = a->pad_mode == 1 ? 0 : pad;
+  p.ho = (a->h + pad_total - a->ksize) / a->stride + 1;
+  p.wo = (a->w_in + pad_total - a->ksize) / a->stride + 1;
   const int th = a->stride == 1 ? 16 : 8;
   p.tiles_x = (p.wo + 15) / 16;
   p.tiles_y = (p.ho + th - 1) / th;
@@ -259,7 +261,7 @@ static bool conv_geometry(const mtx_conv2d_args* a, ConvParams& p, int& tiles) {
 }
 
 int conv_c64_tiles(int n, int h, int w);
-bool conv_c64_applicable(const mtx_conv2d_args* a);
+bool conv_c64_applicable(const mtx_conv2d_args* a);   // (never for pad_mode 1: stride 2)
 int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err);
 
 int conv2d_tiles(const mtx_conv2d_args* a) {

@@ -110,7 +110,132 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
   }
 }
 
+// ---- row softmax (one workgroup per row, any length; fp32 math) ---------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(mtx_ew_args p) {
+  __shared__ float red[8];
+  const long row = blockIdx.x;
+  const T* X = reinterpret_cast<const T*>(p.a) + row * p.lda;
+  T* Y = reinterpret_cast<T*>(p.y) + row * p.ldy;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long nch = p.c / 8;
+  const float sc = p.act_param * 1.4426950408889634f;
+  float m = -3.0e38f;
+  for (long ch = tid; ch < nch; ch += 256) {
+    float f[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = f[e] > m ? f[e] : m;
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (long ch = tid; ch < nch; ch += 256) {
+    float f[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += exp2f((f[e] - m) * sc);
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wv] = s;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (long ch = tid; ch < nch; ch += 256) {
+    float f[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = exp2f((f[e] - m) * sc) * inv;
+    *reinterpret_cast<u32x4*>(Y + ch * 8) = pack8<T>(f);
+  }
+}
+
+// ---- 2-D transpose through a padded LDS tile --------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(mtx_ew_args p) {
+  __shared__ T tile[64][66];
+  const long rows = p.h * p.w, cols = p.c;
+  const long n = blockIdx.z;
+  const T* X = reinterpret_cast<const T*>(p.a) + n * rows * p.lda;
+  T* Y = reinterpret_cast<T*>(p.y) + n * cols * p.ldy;
+  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? X[(r0 + r) * p.lda + c0 + c] : from_f32<T>(0.f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < rows && c0 + c < cols) Y[(c0 + c) * p.ldy + r0 + r] = tile[r][c];
+  }
+}
+
+// ---- FLUX q/k prep: per-head RMSNorm(d) * gamma, then rotary on interleaved pairs ----------------------
+template <typename T>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(mtx_ew_args p) {
+  const int d = p.i0, heads = (int)(p.c / d), lpr = d / 8;          // lanes per (token, head) row
+  const long rows = p.n * p.h * p.w;
+  const long total = rows * heads * lpr;
+  const float* gamma = reinterpret_cast<const float*>(p.s);
+  const float* cs = reinterpret_cast<const float*>(p.b);
+  const T* X = reinterpret_cast<const T*>(p.a);
+  T* Y = reinterpret_cast<T*>(p.y);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int part = (int)(idx % lpr);
+    const long hr = idx / lpr;
+    const int hd = (int)(hr % heads);
+    const long r = hr / heads;
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(X + r * p.lda + hd * d + part * 8), f);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+    for (int m = 1; m < lpr; m <<= 1) ss += __shfl_xor(ss, m, 64);      // lpr is a power of two (d = 64/128)
+    const float rs = 1.0f / sqrtf(ss / (float)d + p.act_param);
+    const float* c_ = cs + r * d + part * 4;                              // [rows][2][d/2]
+    const float* s_ = c_ + d / 2;
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // the reference rounds the normalised value to the model dtype before the rotary product
+      const float x0 = to_f32(from_f32<T>(f[2 * k] * rs * (gamma ? gamma[part * 8 + 2 * k] : 1.f)));
+      const float x1 = to_f32(from_f32<T>(f[2 * k + 1] * rs * (gamma ? gamma[part * 8 + 2 * k + 1] : 1.f)));
+      o[2 * k] = x0 * c_[k] - x1 * s_[k];
+      o[2 * k + 1] = x1 * c_[k] + x0 * s_[k];
+    }
+    *reinterpret_cast<u32x4*>(Y + r * p.ldy + hd * d + part * 8) = pack8<T>(o);
+  }
+}
+
 int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
+  if (a->kind == MTX_EW_SOFTMAX_ROWS) {
+    if (!a->a || !a->y || a->c % 8 || a->lda % 8 || a->ldy % 8) { *err = "softmax_rows: bad layout"; return MTX_ERR_INVALID; }
+    const long rows = a->n * a->h * a->w;
+    if (rows < 1) return MTX_OK;
+    if (a->dtype == MTX_BF16) MTX_LAUNCH((softmax_rows_kernel<__bf16>), dim3((unsigned)rows), dim3(256), 0, stream, *a);
+    else if (a->dtype == MTX_F16) MTX_LAUNCH((softmax_rows_kernel<_Float16>), dim3((unsigned)rows), dim3(256), 0, stream, *a);
+    else { *err = "softmax_rows: dtype"; return MTX_ERR_INVALID; }
+    return MTX_OK;
+  }
+  if (a->kind == MTX_EW_TRANSPOSE) {
+    if (!a->a || !a->y) { *err = "transpose: null operand"; return MTX_ERR_INVALID; }
+    const long rows = a->h * a->w;
+    dim3 grid((unsigned)((a->c + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)a->n);
+    if (a->dtype == MTX_BF16) MTX_LAUNCH((transpose_kernel<__bf16>), grid, dim3(256), 0, stream, *a);
+    else if (a->dtype == MTX_F16) MTX_LAUNCH((transpose_kernel<_Float16>), grid, dim3(256), 0, stream, *a);
+    else { *err = "transpose: dtype"; return MTX_ERR_INVALID; }
+    return MTX_OK;
+  }
+  if (a->kind == MTX_EW_QK_NORM_ROPE) {
+    const int d = a->i0;
+    if (!a->a || !a->y || !a->b || (d != 64 && d != 128) || a->c % d || a->lda % 8 || a->ldy % 8) { *err = "qk_norm_rope: head dim must be 64 or 128"; return MTX_ERR_INVALID; }
+    const long total = a->n * a->h * a->w * (a->c / d) * (d / 8);
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) return MTX_OK;
+    if (a->dtype == MTX_BF16) MTX_LAUNCH((qk_norm_rope_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
+    else if (a->dtype == MTX_F16) MTX_LAUNCH((qk_norm_rope_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
+    else { *err = "qk_norm_rope: dtype"; return MTX_ERR_INVALID; }
+    return MTX_OK;
+  }
   if (!a->a || !a->y) { *err = "elementwise: null operand"; return MTX_ERR_INVALID; }
   if (a->c % 8 || a->lda % 8 || a->ldy % 8 || (a->b && a->ldb % 8)) { *err = "elementwise: C and pixel strides must be multiples of 8"; return MTX_ERR_INVALID; }
   if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_ADD || a->kind == MTX_EW_MUL || a->kind == MTX_EW_GATE_RES) && !a->b) { *err = "elementwise: missing operand b"; return MTX_ERR_INVALID; }

@@ -150,10 +150,10 @@ class PlanBuilder:
     def conv2d(self, x: Act, w_packed, bias, cout: int, ksize: int = 3, stride: int = 1,
                act: int = abi.ACT_NONE, act_param: float = 0.0, res: Optional[Act] = None,
                res_scale: float = 1.0, out: Optional[Act] = None, pixel_shuffle: int = 0,
-               chan_sum=None, res_broadcast: bool = False, label: str = "conv") -> Act:
-        pad = ksize // 2
-        ho = (x.h + 2 * pad - ksize) // stride + 1
-        wo = (x.w + 2 * pad - ksize) // stride + 1
+               chan_sum=None, res_broadcast: bool = False, pad_mode: int = 0, label: str = "conv") -> Act:
+        pad_total = 1 if pad_mode == 1 else 2 * (ksize // 2)
+        ho = (x.h + pad_total - ksize) // stride + 1
+        wo = (x.w + pad_total - ksize) // stride + 1
         if out is None:
             if pixel_shuffle:
                 out = self.act(x.n, ho * pixel_shuffle, wo * pixel_shuffle, cout // (pixel_shuffle ** 2))
@@ -170,6 +170,7 @@ class PlanBuilder:
         a.act, a.act_param, a.res_scale = act, act_param, res_scale
         a.pixel_shuffle, a.dtype = pixel_shuffle, self.dtype
         a.res_broadcast_n = 1 if res_broadcast else 0
+        a.pad_mode = pad_mode
         self._add(abi.OP_CONV2D, a, label)
         return out
 

@@ -9,14 +9,25 @@ from oracle import yolo_ref as yr
 
 def check_yolo(lib, device, scale="n", h=384, w=256, imgsz=256, seed=0, n_det=12, mask_tol=0.02):
     net = yr.make_model(scale, 1, seed)
-    with torch.no_grad():      # spread the class scores so a handful of anchors pass the threshold
-        for l in range(3):
-            net.model[22].cv3[l][2].weight.mul_(0.05)
-            net.model[22].cv3[l][2].bias.fill_(-1.0)
-            net.model[22].cv2[l][2].weight.mul_(0.1)     # soft DFL distributions (a trained head is not saturated)
     page, _, _ = make_page(seed, w, h, bubbles=3)
     bgr = np.ascontiguousarray(page[..., ::-1])
     x, lp = yr.letterbox(bgr, imgsz)
+    # a random-weight head saturates (logits of +-50): rescale the last conv of the box / class branches
+    # so their logits have unit spread, as a trained head's do — otherwise the DFL expectation and the
+    # sigmoid amplify fp16 rounding into whole bins
+    seg = net.model[22]
+    grabbed = {}
+    hooks = [seg.cv2[l][1].register_forward_hook(lambda m, i, o, l=l: grabbed.__setitem__(("b", l), o)) for l in range(3)]
+    hooks += [seg.cv3[l][1].register_forward_hook(lambda m, i, o, l=l: grabbed.__setitem__(("c", l), o)) for l in range(3)]
+    net(x)
+    for hk in hooks:
+        hk.remove()
+    with torch.no_grad():
+        for l in range(3):
+            sb = seg.cv2[l][2](grabbed[("b", l)]).std().item()
+            seg.cv2[l][2].weight.div_(sb); seg.cv2[l][2].bias.div_(sb)
+            sc_ = seg.cv3[l][2](grabbed[("c", l)]).std().item()
+            seg.cv3[l][2].weight.div_(sc_); seg.cv3[l][2].bias.fill_(-1.0)
     pred, proto = net(x)
     scores = pred[0, 4].numpy()
     conf = float(np.sort(scores)[-n_det])           # threshold that lets ~n_det anchors through
