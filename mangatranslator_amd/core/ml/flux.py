@@ -1,0 +1,436 @@
+"""FLUX.1-Kontext (MMDiT + VAE + flow-match Euler) on libmtx_hip — SURVEY.md §8 row a7.
+
+The object `ModelManager.load_flux_kontext_sdnq()` hands to `FluxKontextInpainter`; called with the
+diffusers pipeline shape (reference core/image/inpainting.py:877-887):
+    pipeline(image=PIL, width=, height=, num_inference_steps=, guidance_scale=, generator=,
+             output_type="pt", max_area=, prompt_embeds=, pooled_prompt_embeds=).images[0]  -> CHW float 0..1
+Weights carry diffusers' names (FluxTransformer2DModel / AutoencoderKL state dicts); the architecture
+followed is restated in oracle/flux_ref.py.
+
+Graph design (MI355X-first):
+  * text and image tokens live in ONE [T, D] buffer (text rows first): the double-stream blocks work on
+    row ranges, the single-stream blocks on the whole buffer — the reference's torch.cat / split per block
+    do not exist.  q, k, v come from one fused [3D, D] GEMM per stream; per-head RMSNorm + 3-axis RoPE is
+    one in-place kernel over the q and k column slices; attention reads q/k/v through strides.
+  * every gated residual `x + gate * f(x)` is the GEMM epilogue (gate row broadcast + residual), GELU-tanh
+    and bias likewise; AdaLayerNorm = the row-norm kernel with the (1 + scale), shift vectors fused.
+  * single-stream blocks write attention output and MLP activations into column slices of one [T, 5D]
+    buffer, so `proj_out(cat(attn, mlp))` is a plain GEMM.
+  * the modulation vectors depend only on (timestep, guidance, pooled prompt): they are computed once per
+    step of a schedule (M = 1 GEMVs that stream 6.4 GB of weights at full size) and cached, instead of
+    every step of every region.
+  * VAE: NHWC 3x3 convs with fused bias / residual, GroupNorm+SiLU kernels, nearest-2x fused into a copy,
+    Downsample2D's asymmetric pad as a conv mode; the single-head mid-block attention (d = 512) runs as
+    GEMM -> row softmax -> GEMM.
+"""
+import math
+import threading
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from ...hip import abi
+from ...hip.lib import get_library
+from ...hip.plan import Act, PlanBuilder
+from ...utils.exceptions import ModelError
+
+
+def _rows(t2d, r0, r1, c0=0, c=None):
+    """Act view of rows [r0, r1) and columns [c0, c0+c) of a [R, LD] buffer."""
+    v = t2d[r0:r1]
+    return Act(v.view(1, 1, r1 - r0, t2d.shape[1]), 1, 1, r1 - r0, c if c is not None else t2d.shape[1] - c0, c0)
+
+
+def sinusoid(value: float, dim=256) -> np.ndarray:
+    half = dim // 2
+    freqs = np.exp(-math.log(10000.0) * np.arange(half, dtype=np.float32) / half).astype(np.float32)
+    a = np.float32(value) * freqs
+    return np.concatenate([np.cos(a), np.sin(a)]).astype(np.float32)
+
+
+def rope_table(ids: np.ndarray, axes_dim, theta=10000.0) -> np.ndarray:
+    """ids [S,3] -> fp32 [S, 2, D/2]: cos | sin of every rotary pair."""
+    cos, sin = [], []
+    for i, d in enumerate(axes_dim):
+        freqs = 1.0 / (theta ** (np.arange(0, d, 2, dtype=np.float64) / d))
+        ang = ids[:, i].astype(np.float64)[:, None] * freqs[None]
+        cos.append(np.cos(ang))
+        sin.append(np.sin(ang))
+    return np.stack([np.concatenate(cos, 1), np.concatenate(sin, 1)], 1).astype(np.float32)
+
+
+def flow_sigmas(steps: int, image_seq_len: int) -> np.ndarray:
+    """FlowMatchEulerDiscreteScheduler with dynamic exponential shifting (FluxKontextPipeline defaults)."""
+    s = np.linspace(1.0, 1.0 / steps, steps)
+    m = (1.15 - 0.5) / (4096 - 256)
+    mu = image_seq_len * m + (0.5 - m * 256)
+    s = math.exp(mu) / (math.exp(mu) + (1.0 / s - 1.0))
+    return np.append(s, 0.0).astype(np.float32)
+
+
+def image_ids(h2, w2, first) -> np.ndarray:
+    ids = np.zeros((h2, w2, 3), np.float32)
+    ids[..., 0] = first
+    ids[..., 1] = np.arange(h2)[:, None]
+    ids[..., 2] = np.arange(w2)[None, :]
+    return ids.reshape(-1, 3)
+
+
+class FluxDiTHip:
+    def __init__(self, provider, cfg: dict, device, lib=None):
+        """provider(name) -> tensor with diffusers' FluxTransformer2DModel parameter of that name."""
+        self.lib = lib if lib is not None else get_library()
+        self.device = torch.device(device)
+        self.dtype, self.tdt = abi.BF16, torch.bfloat16
+        self.cfg = cfg
+        D, H = cfg["d"], cfg["heads"]
+        self.hd = D // H
+        if self.hd not in (64, 128) or sum(cfg["axes_dim"]) != self.hd:
+            raise ModelError("FLUX DiT: head dim must be 64 or 128 and equal sum(axes_dims_rope)")
+        g = lambda n, dt=None: provider(n).detach().to(self.device, dt if dt is not None else self.tdt).contiguous()
+        f32 = torch.float32
+        W = {}
+        for nm in ("x_embedder", "context_embedder", "proj_out"):
+            W[nm] = (g(nm + ".weight"), g(nm + ".bias", f32))
+        for e in ("timestep_embedder", "guidance_embedder", "text_embedder"):
+            for l in ("linear_1", "linear_2"):
+                W[f"{e}.{l}"] = (g(f"time_text_embed.{e}.{l}.weight"), g(f"time_text_embed.{e}.{l}.bias", f32))
+        # all AdaLN projections stacked: one [n_vec * D, D] GEMV per step of a schedule
+        mods_w, mods_b = [], []
+        for i in range(cfg["layers"]):
+            for nm in ("norm1", "norm1_context"):
+                mods_w.append(g(f"transformer_blocks.{i}.{nm}.linear.weight")); mods_b.append(g(f"transformer_blocks.{i}.{nm}.linear.bias", f32))
+        for i in range(cfg["single_layers"]):
+            mods_w.append(g(f"single_transformer_blocks.{i}.norm.linear.weight")); mods_b.append(g(f"single_transformer_blocks.{i}.norm.linear.bias", f32))
+        mods_w.append(g("norm_out.linear.weight")); mods_b.append(g("norm_out.linear.bias", f32))
+        W["mods"] = (torch.cat(mods_w, 0).contiguous(), torch.cat(mods_b, 0).contiguous())
+        self.n_vec = W["mods"][0].shape[0] // D
+        self.blocks, self.singles = [], []
+        cat3 = lambda p, names: (torch.cat([g(f"{p}.{n}.weight") for n in names], 0).contiguous(),
+                                 torch.cat([g(f"{p}.{n}.bias", f32) for n in names], 0).contiguous())
+        for i in range(cfg["layers"]):
+            p = f"transformer_blocks.{i}"
+            self.blocks.append(dict(
+                qkv=cat3(p + ".attn", ("to_q", "to_k", "to_v")), cqkv=cat3(p + ".attn", ("add_q_proj", "add_k_proj", "add_v_proj")),
+                nq=g(p + ".attn.norm_q.weight", f32), nk=g(p + ".attn.norm_k.weight", f32),
+                cnq=g(p + ".attn.norm_added_q.weight", f32), cnk=g(p + ".attn.norm_added_k.weight", f32),
+                out=(g(p + ".attn.to_out.0.weight"), g(p + ".attn.to_out.0.bias", f32)),
+                cout=(g(p + ".attn.to_add_out.weight"), g(p + ".attn.to_add_out.bias", f32)),
+                ff1=(g(p + ".ff.net.0.proj.weight"), g(p + ".ff.net.0.proj.bias", f32)), ff2=(g(p + ".ff.net.2.weight"), g(p + ".ff.net.2.bias", f32)),
+                cff1=(g(p + ".ff_context.net.0.proj.weight"), g(p + ".ff_context.net.0.proj.bias", f32)),
+                cff2=(g(p + ".ff_context.net.2.weight"), g(p + ".ff_context.net.2.bias", f32))))
+        for i in range(cfg["single_layers"]):
+            p = f"single_transformer_blocks.{i}"
+            self.singles.append(dict(qkv=cat3(p + ".attn", ("to_q", "to_k", "to_v")), nq=g(p + ".attn.norm_q.weight", f32), nk=g(p + ".attn.norm_k.weight", f32),
+                                     mlp=(g(p + ".proj_mlp.weight"), g(p + ".proj_mlp.bias", f32)), out=(g(p + ".proj_out.weight"), g(p + ".proj_out.bias", f32))))
+        self.W = W
+        self._plans = {}
+        self._mod_plan = None
+        self._mod_cache = {}
+
+    # ---- modulation vectors of one (timestep, guidance, pooled) ------------------------------------------
+    def _build_mod_plan(self):
+        D, W = self.cfg["d"], self.W
+        pb = PlanBuilder(self.lib, self.device, self.dtype)
+        tin = pb.buf((2, 256), self.tdt)                     # sinusoids of timestep*1000 and guidance*1000
+        pooled = pb.buf((1, self.cfg["pooled_dim"]), self.tdt)
+        embs = []
+        for row, (e, src, k) in enumerate((("timestep_embedder", tin, 256), ("guidance_embedder", tin, 256), ("text_embedder", pooled, self.cfg["pooled_dim"]))):
+            off = row * 256 if src is tin and row < 2 else 0
+            h = pb.gemm(src, W[f"{e}.linear_1"][0], 1, D, k, bias=W[f"{e}.linear_1"][1], act=abi.ACT_SILU, a_off=off, label=f"temb.{e}.1")
+            embs.append(pb.gemm(h, W[f"{e}.linear_2"][0], 1, D, D, bias=W[f"{e}.linear_2"][1], label=f"temb.{e}.2"))
+        a = lambda t: Act(t.view(1, 1, 1, D), 1, 1, 1, D)
+        s1 = pb.ew(abi.EW_ADD, a(embs[0]), b=a(embs[1]), label="temb.sum1")
+        st = pb.ew(abi.EW_ADD, s1, b=a(embs[2]), act=abi.ACT_SILU, label="temb.sum2.silu")       # silu(temb) feeds every AdaLN
+        mods = pb.gemm(st.t.view(1, D), W["mods"][0], 1, self.n_vec * D, D, bias=W["mods"][1], label="adaln.all")
+        plan = pb.build()
+        plan.tin, plan.pooled, plan.mods = tin, pooled, mods
+        return plan
+
+    def modulation(self, timestep: float, guidance: float, pooled: torch.Tensor) -> torch.Tensor:
+        """[n_vec, D] bf16 modulation rows for one denoising step (cached per value triple)."""
+        key = (round(float(timestep), 7), round(float(guidance), 5), pooled.data_ptr())
+        if key not in self._mod_cache:
+            if self._mod_plan is None:
+                self._mod_plan = self._build_mod_plan()
+            mp = self._mod_plan
+            tin = np.stack([sinusoid(timestep * 1000.0), sinusoid(guidance * 1000.0)])
+            mp.tin.copy_(torch.from_numpy(tin).to(self.device, self.tdt))
+            mp.pooled.copy_(pooled.reshape(1, -1).to(self.device, self.tdt))
+            mp.run()
+            self._mod_cache[key] = mp.mods.view(self.n_vec, self.cfg["d"]).clone()
+        return self._mod_cache[key]
+
+    # ---- one denoising step as a plan ----------------------------------------------------------------------
+    def _build(self, t_txt, h2, w2, n_ref):
+        cfg, W = self.cfg, self.W
+        D, H, hd = cfg["d"], cfg["heads"], self.hd
+        t_noise = h2 * w2
+        t_img = t_noise * (1 + n_ref)
+        T = t_txt + t_img
+        pb = PlanBuilder(self.lib, self.device, self.dtype)
+        lat = pb.buf((t_img, cfg["in_channels"]), self.tdt)       # [noise tokens ; reference tokens]
+        ctx_in = pb.buf((t_txt, cfg["joint_dim"]), self.tdt)      # prompt embeddings
+        mod = pb.buf((self.n_vec, D), self.tdt)
+        ids = np.concatenate([np.zeros((t_txt, 3), np.float32)] + [image_ids(h2, w2, k) for k in range(1 + n_ref)])
+        cs = pb.hold(torch.from_numpy(rope_table(ids, cfg["axes_dim"])).to(self.device).contiguous())     # [T, 2, hd/2]
+        x = pb.buf((T, D), self.tdt)
+        nrm = pb.buf((T, D), self.tdt)
+        qkv = pb.buf((T, 3 * D), self.tdt)
+        o = pb.buf((T, D), self.tdt)
+        hid = pb.buf((T, 4 * D), self.tdt)
+        cat = pb.buf((T, 5 * D), self.tdt)
+        pb.gemm(ctx_in, W["context_embedder"][0], t_txt, D, cfg["joint_dim"], bias=W["context_embedder"][1], out=x, label="context_embedder")
+        pb.gemm(lat, W["x_embedder"][0], t_img, D, cfg["in_channels"], bias=W["x_embedder"][1], out=x, c_off=t_txt * D, label="x_embedder")
+        m_ = lambda idx: (mod, idx * D)       # (tensor, element offset) of one modulation row
+
+        def adaln(r0, r1, shift_i, scale_i, label):
+            pb.norm(x, nrm, r1 - r0, D, eps=1e-6, kind=0, mod_scale=mod[scale_i], mod_shift=mod[shift_i], rows_per=r1 - r0, ldmod=D,
+                    x_off=r0 * D, y_off=r0 * D, label=label)
+
+        def rope(buf, r0, r1, col, gamma, ld, label):
+            v = _rows(buf, r0, r1, col, D)
+            e = abi.EwArgs()
+            e.a, e.b, e.s, e.y = v.ptr, cs[r0:].data_ptr(), gamma.data_ptr(), v.ptr
+            e.n, e.h, e.w, e.c = 1, 1, r1 - r0, D
+            e.lda, e.ldb, e.ldy, e.lds = ld, 0, ld, 0
+            e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 0, 1e-6, hd, 0, self.dtype
+            pb._add(abi.OP_EW, e, label)
+
+        def attention(out_t, out_ld, label):
+            pb.attention(qkv, qkv, qkv, out_t, 1, H, T, T, hd, (0, 3 * D, hd), (0, 3 * D, hd), (0, 3 * D, hd), (0, out_ld, hd),
+                         1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label)
+
+        for i, B in enumerate(self.blocks):
+            b0 = i * 12
+            tag = f"dbl{i}"
+            adaln(t_txt, T, b0 + 0, b0 + 1, tag + ".norm1")
+            adaln(0, t_txt, b0 + 6, b0 + 7, tag + ".norm1_ctx")
+            pb.gemm(nrm, B["qkv"][0], t_img, 3 * D, D, bias=B["qkv"][1], out=qkv, a_off=t_txt * D, c_off=t_txt * 3 * D, label=tag + ".qkv")
+            pb.gemm(nrm, B["cqkv"][0], t_txt, 3 * D, D, bias=B["cqkv"][1], out=qkv, label=tag + ".qkv_ctx")
+            rope(qkv, t_txt, T, 0, B["nq"], 3 * D, tag + ".rope_q"); rope(qkv, t_txt, T, D, B["nk"], 3 * D, tag + ".rope_k")
+            rope(qkv, 0, t_txt, 0, B["cnq"], 3 * D, tag + ".rope_q_ctx"); rope(qkv, 0, t_txt, D, B["cnk"], 3 * D, tag + ".rope_k_ctx")
+            attention(o, D, tag + ".attn")
+            pb.gemm(o, B["out"][0], t_img, D, D, bias=B["out"][1], gate=mod[b0 + 2], gate_rows_per=t_img, res=x, out=x,
+                    a_off=t_txt * D, c_off=t_txt * D, res_off=t_txt * D, label=tag + ".to_out")
+            pb.gemm(o, B["cout"][0], t_txt, D, D, bias=B["cout"][1], gate=mod[b0 + 8], gate_rows_per=t_txt, res=x, out=x, label=tag + ".to_add_out")
+            adaln(t_txt, T, b0 + 3, b0 + 4, tag + ".norm2")
+            adaln(0, t_txt, b0 + 9, b0 + 10, tag + ".norm2_ctx")
+            pb.gemm(nrm, B["ff1"][0], t_img, 4 * D, D, bias=B["ff1"][1], act=abi.ACT_GELU_TANH, out=hid, a_off=t_txt * D, c_off=t_txt * 4 * D, label=tag + ".ff1")
+            pb.gemm(hid, B["ff2"][0], t_img, D, 4 * D, bias=B["ff2"][1], gate=mod[b0 + 5], gate_rows_per=t_img, res=x, out=x,
+                    a_off=t_txt * 4 * D, c_off=t_txt * D, res_off=t_txt * D, label=tag + ".ff2")
+            pb.gemm(nrm, B["cff1"][0], t_txt, 4 * D, D, bias=B["cff1"][1], act=abi.ACT_GELU_TANH, out=hid, label=tag + ".ff1_ctx")
+            pb.gemm(hid, B["cff2"][0], t_txt, D, 4 * D, bias=B["cff2"][1], gate=mod[b0 + 11], gate_rows_per=t_txt, res=x, out=x, label=tag + ".ff2_ctx")
+        s0 = cfg["layers"] * 12
+        for i, S in enumerate(self.singles):
+            b0 = s0 + i * 3
+            tag = f"sgl{i}"
+            adaln(0, T, b0 + 0, b0 + 1, tag + ".norm")
+            pb.gemm(nrm, S["qkv"][0], T, 3 * D, D, bias=S["qkv"][1], out=qkv, label=tag + ".qkv")
+            pb.gemm(nrm, S["mlp"][0], T, 4 * D, D, bias=S["mlp"][1], act=abi.ACT_GELU_TANH, out=cat, ldc=5 * D, c_off=D, label=tag + ".proj_mlp")
+            rope(qkv, 0, T, 0, S["nq"], 3 * D, tag + ".rope_q"); rope(qkv, 0, T, D, S["nk"], 3 * D, tag + ".rope_k")
+            attention(cat, 5 * D, tag + ".attn")
+            pb.gemm(cat, S["out"][0], T, D, 5 * D, bias=S["out"][1], gate=mod[b0 + 2], gate_rows_per=T, res=x, out=x, label=tag + ".proj_out")
+        f0 = s0 + cfg["single_layers"] * 3
+        pb.norm(x, nrm, t_noise, D, eps=1e-6, kind=0, mod_scale=mod[f0], mod_shift=mod[f0 + 1], rows_per=t_noise, ldmod=D,
+                x_off=t_txt * D, y_off=t_txt * D, label="norm_out")
+        vel = pb.gemm(nrm, W["proj_out"][0], t_noise, cfg["in_channels"], D, bias=W["proj_out"][1], a_off=t_txt * D, out_f32=True, label="proj_out")
+        plan = pb.build()
+        plan.lat, plan.ctx_in, plan.mod, plan.vel, plan.x = lat, ctx_in, mod, vel, x
+        plan.t_noise, plan.t_img, plan.T = t_noise, t_img, T
+        return plan
+
+    def plan_for(self, t_txt, h2, w2, n_ref=1):
+        key = (t_txt, h2, w2, n_ref)
+        if key not in self._plans:
+            self._plans[key] = self._build(t_txt, h2, w2, n_ref)
+        return self._plans[key]
+
+    def flops_per_step(self, t_txt, h2, w2, n_ref=1):
+        cfg = self.cfg
+        D = cfg["d"]
+        t_img = h2 * w2 * (1 + n_ref)
+        T = t_txt + t_img
+        dbl = cfg["layers"] * (2 * T * D * 3 * D + 2 * T * D * D + 2 * 2 * T * D * 4 * D)
+        sgl = cfg["single_layers"] * (2 * T * D * 3 * D + 2 * T * D * 4 * D + 2 * T * 5 * D * D)
+        attn = (cfg["layers"] + cfg["single_layers"]) * 4 * T * T * D
+        return dict(gemm=dbl + sgl, attention=attn, attention_per_layer=4 * T * T * D, tokens=T)
+
+
+class FluxVAEHip:
+    def __init__(self, provider, cfg: dict, device, lib=None):
+        self.lib = lib if lib is not None else get_library()
+        self.device = torch.device(device)
+        self.dtype, self.tdt = abi.BF16, torch.bfloat16
+        self.cfg = cfg
+        self.p = provider
+        self._w = {}
+        self._plans = {}
+
+    def _conv_w(self, name, cout_pad=0):
+        if name not in self._w:
+            w = self.p(name + ".weight").detach().float().cpu()
+            b = self.p(name + ".bias").detach().float().cpu()
+            co, ci, kh, kw = w.shape
+            ci_p, co_p = (ci + 7) // 8 * 8, max(co, cout_pad)
+            wt = torch.zeros(co_p, kh * kw, ci_p)
+            wt[:co, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+            bt = torch.zeros(co_p)
+            bt[:co] = b
+            self._w[name] = (wt.to(self.device, self.tdt).contiguous(), bt.to(self.device).contiguous(), co_p, kh)
+        return self._w[name]
+
+    def _vec(self, name):
+        if name not in self._w:
+            self._w[name] = self.p(name).detach().float().to(self.device).contiguous()
+        return self._w[name]
+
+    def _lin(self, name):
+        if name not in self._w:
+            self._w[name] = (self.p(name + ".weight").detach().to(self.device, self.tdt).contiguous(), self.p(name + ".bias").detach().float().to(self.device).contiguous())
+        return self._w[name]
+
+    def _conv(self, pb, x, name, stride=1, res=None, pad_mode=0, cout_pad=0):
+        w, b, co, k = self._conv_w(name, cout_pad)
+        return pb.conv2d(x, w, b, co, ksize=k, stride=stride, res=res, pad_mode=pad_mode, label=name)
+
+    def _gn(self, pb, x, name, silu=True):
+        return pb.groupnorm(x, self._vec(name + ".weight"), self._vec(name + ".bias"), self.cfg["groups"], 1e-6,
+                            abi.ACT_SILU if silu else abi.ACT_NONE, label=name)
+
+    def _res(self, pb, x, p, cout):
+        h = self._conv(pb, self._gn(pb, x, p + ".norm1"), p + ".conv1")
+        sc = self._conv(pb, x, p + ".conv_shortcut") if x.c != cout else x
+        return self._conv(pb, self._gn(pb, h, p + ".norm2"), p + ".conv2", res=sc)
+
+    def _attn(self, pb, x, p):
+        C, T = x.c, x.h * x.w
+        t = self._gn(pb, x, p + ".group_norm", silu=False)
+        q = pb.gemm(t.t, self._lin(p + ".to_q")[0], T, C, C, bias=self._lin(p + ".to_q")[1], label=p + ".q")
+        k = pb.gemm(t.t, self._lin(p + ".to_k")[0], T, C, C, bias=self._lin(p + ".to_k")[1], label=p + ".k")
+        v = pb.gemm(t.t, self._lin(p + ".to_v")[0], T, C, C, bias=self._lin(p + ".to_v")[1], label=p + ".v")
+        Tp = (T + 7) // 8 * 8
+        s = pb.buf((T, Tp), self.tdt, zero=True)
+        pb.gemm(q, k, T, T, C, out=s, ldc=Tp, label=p + ".qk")
+        sa = Act(s.view(1, 1, T, Tp), 1, 1, T, Tp)
+        if Tp != T:
+            raise ModelError("VAE attention: token count must be a multiple of 8")
+        pb.ew(abi.EW_SOFTMAX_ROWS, sa, out=sa, act_param=1.0 / math.sqrt(C), label=p + ".softmax")
+        vt = pb.buf((C, Tp), self.tdt, zero=True)
+        pb.ew(abi.EW_TRANSPOSE, Act(v.view(1, 1, T, C), 1, 1, T, C), out=Act(vt.view(1, 1, C, Tp), 1, 1, C, Tp), label=p + ".v_t")
+        o = pb.gemm(s, vt, T, C, Tp, label=p + ".pv")
+        out = pb.act(x.n, x.h, x.w, C)
+        pb.gemm(o, self._lin(p + ".to_out.0")[0], T, C, C, bias=self._lin(p + ".to_out.0")[1], res=x.t, out=out.t, label=p + ".out")
+        return out
+
+    def _mid(self, pb, x, p):
+        x = self._res(pb, x, p + ".resnets.0", x.c)
+        x = self._attn(pb, x, p + ".attentions.0")
+        return self._res(pb, x, p + ".resnets.1", x.c)
+
+    def encoder_plan(self, h, w):
+        key = ("enc", h, w)
+        if key not in self._plans:
+            ch = self.cfg["ch"]
+            pb = PlanBuilder(self.lib, self.device, self.dtype)
+            src = pb.buf((1, h, w, 3), torch.uint8)
+            x0 = pb.act(1, h, w, 8)
+            pb.image_convert(abi.IMG_HWC_U8_TO_NHWC, src, x0.t, 1, h, w, 8, mul=2.0, add=(-1.0, -1.0, -1.0), label="vae.in")
+            x = self._conv(pb, x0, "encoder.conv_in")
+            for i, c in enumerate(ch):
+                for j in range(2):
+                    x = self._res(pb, x, f"encoder.down_blocks.{i}.resnets.{j}", c)
+                if i < len(ch) - 1:
+                    x = self._conv(pb, x, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad_mode=1)
+            x = self._mid(pb, x, "encoder.mid_block")
+            x = self._conv(pb, self._gn(pb, x, "encoder.conv_norm_out"), "encoder.conv_out")
+            plan = pb.build()
+            plan.src, plan.moments = src, x
+            self._plans[key] = plan
+        return self._plans[key]
+
+    def decoder_plan(self, h8, w8):
+        key = ("dec", h8, w8)
+        if key not in self._plans:
+            rc = list(reversed(self.cfg["ch"]))
+            pb = PlanBuilder(self.lib, self.device, self.dtype)
+            z = pb.act(1, h8, w8, 16)
+            x = self._conv(pb, z, "decoder.conv_in")
+            x = self._mid(pb, x, "decoder.mid_block")
+            for i, c in enumerate(rc):
+                for j in range(3):
+                    x = self._res(pb, x, f"decoder.up_blocks.{i}.resnets.{j}", c)
+                if i < len(rc) - 1:
+                    x = self._conv(pb, pb.ew(abi.EW_UPSAMPLE2X, x, label=f"decoder.up{i}.nearest"), f"decoder.up_blocks.{i}.upsamplers.0.conv")
+            y = self._conv(pb, self._gn(pb, x, "decoder.conv_norm_out"), "decoder.conv_out", cout_pad=8)
+            out = pb.buf((1, 3, y.h, y.w), torch.float32)
+            pb.image_convert(abi.IMG_NHWC_TO_NCHW_F32, y.t, out, 1, y.h, y.w, 8, mul=0.5, add=(0.5, 0.5, 0.5), label="vae.out")
+            plan = pb.build()
+            plan.z, plan.out, plan.raw = z, out, y
+            self._plans[key] = plan
+        return self._plans[key]
+
+
+class FluxKontextHip:
+    """diffusers-pipeline-shaped callable built from the two graphs above."""
+
+    def __init__(self, dit: FluxDiTHip, vae: FluxVAEHip, graph: bool = True):
+        self.transformer, self.vae = dit, vae
+        self.device = dit.device
+        self._execution_device = dit.device
+        self._graph = graph and not dit.lib.is_simulator
+        self._lock = threading.Lock()
+        self._embeds = None
+
+    def set_prompt_embeds(self, prompt_embeds: torch.Tensor, pooled: torch.Tensor):
+        """T5 / CLIP embeddings of the (fixed) prompt — computed once per process by the caller."""
+        self._embeds = (prompt_embeds.reshape(-1, prompt_embeds.shape[-1]), pooled.reshape(-1))
+
+    def encode_prompt(self, prompt=None, prompt_2=None, device=None, **kw):
+        if self._embeds is None:
+            raise ModelError("FLUX text encoders are not part of the MI355X hot path: provide cached prompt embeddings with set_prompt_embeds()")
+        return self._embeds[0][None], self._embeds[1][None], None
+
+    @torch.no_grad()
+    def __call__(self, image=None, width=None, height=None, num_inference_steps=8, guidance_scale=2.5, generator=None,
+                 output_type="pt", max_area=None, prompt_embeds=None, pooled_prompt_embeds=None, latents=None, **kw):
+        if prompt_embeds is None:
+            prompt_embeds, pooled_prompt_embeds, _ = self.encode_prompt()
+        pe = prompt_embeds.reshape(-1, prompt_embeds.shape[-1])
+        pooled = pooled_prompt_embeds.reshape(-1)
+        img = np.asarray(image.convert("RGB").resize((width, height))) if hasattr(image, "convert") else np.asarray(image)
+        H, W = img.shape[:2]
+        if H % 16 or W % 16:
+            raise ModelError(f"FLUX Kontext needs H, W multiples of 16, got {W}x{H}")
+        h8, w8, h2, w2 = H // 8, W // 8, H // 16, W // 16
+        dit, vae = self.transformer, self.vae
+        vc = vae.cfg
+        with self._lock:
+            enc = vae.encoder_plan(H, W)
+            enc.src.copy_(torch.from_numpy(np.ascontiguousarray(img)).to(self.device).view(1, H, W, 3))
+            enc.run(graph=self._graph)
+            mean = enc.moments.t[0, :, :, :16].float().permute(2, 0, 1)[None]
+            ref = (mean - vc["shift_factor"]) * vc["scaling_factor"]
+            pack = lambda t: t.view(1, 16, h2, 2, w2, 2).permute(0, 2, 4, 1, 3, 5).reshape(h2 * w2, 64)
+            if latents is None:
+                latents = torch.randn((1, 16, h8, w8), generator=generator, dtype=torch.float32,
+                                      device=generator.device if generator is not None else "cpu")
+            lat = pack(latents.to(self.device, torch.float32))
+            plan = dit.plan_for(pe.shape[0], h2, w2, 1)
+            plan.ctx_in.copy_(pe.to(self.device, dit.tdt))
+            plan.lat[plan.t_noise:].copy_(pack(ref).to(dit.tdt))
+            sig = flow_sigmas(num_inference_steps, h2 * w2)
+            pooled_dev = pooled.to(self.device, dit.tdt)
+            for i in range(num_inference_steps):
+                plan.mod.copy_(dit.modulation(float(sig[i]), float(guidance_scale), pooled_dev))
+                plan.lat[: plan.t_noise].copy_(lat.to(dit.tdt))
+                plan.run(graph=self._graph)
+                lat = lat + (float(sig[i + 1]) - float(sig[i])) * plan.vel
+            z = lat.view(1, h2, w2, 16, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(1, 16, h8, w8) / vc["scaling_factor"] + vc["shift_factor"]
+            dec = vae.decoder_plan(h8, w8)
+            dec.z.t.copy_(z.permute(0, 2, 3, 1).to(dit.tdt))
+            dec.run(graph=self._graph)
+            out = dec.out[0].clamp(0, 1).clone()
+            self.last = dict(latents=lat, sigmas=sig)
+        return SimpleNamespace(images=[out])
