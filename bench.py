@@ -2,12 +2,16 @@
 """bench.py — pages/sec of the vision hot path on N MI355X (one process per GPU).
 
 Metric (BASELINE.json): pages/sec (detect+segment+inpaint+upscale) 1024x1536 @1/2/4/8 MI355X.
-A "step" is one synthetic 1024x1536 page through every hot-path stage that is built so far;
-`config.stages` names exactly which stages ran inside the timed region (stages not listed there
-are NOT implemented yet and therefore NOT counted — see DESIGN.md "bench scope").
-Pages are resident in HBM before the timed region (decode/encode excluded).
-Pages are independent units: rank r processes its own pages, no data-path collective; the only
-collective is the start-up weight broadcast over RCCL (outside the timed region).
+A "step" is one synthetic 1024x1536 page through every stage of the hot path:
+  detect   YOLOv8m-seg @imgsz 1600: letterbox -> network -> decode -> NMS -> retina masks
+  segment  SAM-2.1 Hiera-L: antialiased resize -> image encoder -> 8 box prompts -> mask decoder -> masks
+  inpaint  R=1 outside-text region: crop geometry + EDT feather (host) -> FLUX.1-Kontext, 20 Euler steps bf16
+           at the snapped ~1 MP resolution (VAE encode, 57-block MMDiT x steps, VAE decode) -> LANCZOS -> composite
+  upscale  2x RCAN (10 groups x 20 RCAB x 64 feats) on the whole page
+`config.stages` names the stages that ran inside the timed region.  Pages are resident in HBM before the
+timed region (image decode/encode excluded).  Pages are independent units: rank r processes
+its own pages, no data-path collective; the only collective is the start-up weight broadcast over RCCL
+(outside the timed region).  Weights are seeded random (no checkpoints offline) with the real architectures.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -19,24 +23,27 @@ import sys
 import time
 from pathlib import Path
 
+import numpy as np
 import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16 (no sparsity)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1536)
-    ap.add_argument("--stages", default="all", help="comma list of: segment,upscale (default: every built stage)")
-    ap.add_argument("--boxes", type=int, default=8, help="detections per page (generator ground truth, SURVEY.md §8d)")
+    ap.add_argument("--stages", default="all", help="comma list of: detect,segment,inpaint,upscale")
+    ap.add_argument("--boxes", type=int, default=8, help="bubbles per page (SAM prompts; generator ground truth, SURVEY.md §8d)")
+    ap.add_argument("--regions", type=int, default=1, help="FLUX-inpainted outside-text regions per page (R in SURVEY.md §8d)")
+    ap.add_argument("--inpaint-steps", type=int, default=20)
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -48,7 +55,7 @@ def broadcast_state_dict(sd, rank, world, device):
     import torch.distributed as dist
     keys = sorted(sd.keys())
     shapes = [tuple(sd[k].shape) for k in keys]
-    sizes = [int(torch.tensor(s).prod().item()) if len(s) else 1 for s in shapes]
+    sizes = [int(np.prod(s)) if len(s) else 1 for s in shapes]
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
     if rank == 0:
         flat.copy_(torch.cat([sd[k].float().reshape(-1) for k in keys]).to(device))
@@ -76,49 +83,48 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
+    from PIL import Image
     from mangatranslator_amd.hip.lib import get_library
-    from mangatranslator_amd.core.ml.rcan import RCANUpscaler
     from mangatranslator_amd.utils.synthetic_pages import make_page
-    from oracle.rcan_ref import make_state_dict   # synthetic checkpoint generator (no real weights offline)
 
     lib = get_library()
     lib.init(local_rank)
+    graph = not args.no_graph
+    want = ["detect", "segment", "inpaint", "upscale"] if args.stages == "all" else [x.strip() for x in args.stages.split(",")]
+    stages = [st for st in ("detect", "segment", "inpaint", "upscale") if st in want]
+    first = rank == 0 or world == 1
 
-    # ---- models: rank 0 "reads" the checkpoints, everyone else receives them over RCCL ----------
-    lite = args.upscale_model == "model_lite"
-    if lite:   # assumed Fast_RCAN_PU shape (pixel-unshuffle variant); real hyper-parameters come from the file
-        rcan_cfg = dict(n_feats=64, n_resgroups=4, n_resblocks=8, unshuffle=2)
-    else:      # canonical RCAN: 10 groups x 20 RCAB x 64 feats
-        rcan_cfg = dict(n_feats=64, n_resgroups=10, n_resblocks=20, unshuffle=1)
-    sd = make_state_dict(seed=7, **rcan_cfg) if (rank == 0 or world == 1) else None
-    if world > 1:
-        if rank != 0:
-            sd = {k: torch.empty_like(v) for k, v in make_state_dict(seed=0, **rcan_cfg).items()}
-        sd = broadcast_state_dict(sd, rank, world, device)
-    want = ["detect", "segment", "upscale"] if args.stages == "all" else [x.strip() for x in args.stages.split(",")]
+    # ---- models: rank 0 "reads" (seeds) the checkpoints, every other rank receives them over RCCL ---------
+    upscaler, rcan_sd, rcan_cfg = None, None, None
+    if "upscale" in want:
+        from mangatranslator_amd.core.ml.rcan import RCANUpscaler
+        from oracle.rcan_ref import make_state_dict   # synthetic checkpoint generator (no real weights offline)
+        if args.upscale_model == "model_lite":   # assumed Fast_RCAN_PU shape; real hyper-parameters come from the file
+            rcan_cfg = dict(n_feats=64, n_resgroups=4, n_resblocks=8, unshuffle=2)
+        else:                                    # canonical RCAN: 10 groups x 20 RCAB x 64 feats
+            rcan_cfg = dict(n_feats=64, n_resgroups=10, n_resblocks=20, unshuffle=1)
+        rcan_sd = make_state_dict(seed=7 if first else 0, **rcan_cfg)
+        if world > 1:
+            rcan_sd = broadcast_state_dict(rcan_sd, rank, world, device)
+        upscaler = RCANUpscaler(rcan_sd, device=device, lib=lib, graph=graph)
     yolo = None
     if "detect" in want:
         from mangatranslator_amd.core.ml.yolo import YoloSegHip
         from oracle.yolo_ref import make_model as make_yolo       # seeded YOLOv8m-seg (the reference's yolo_1 geometry)
-        ysd = None
-        if rank == 0 or world == 1:
-            ynet = make_yolo("m", 1, seed=3)
-            with torch.no_grad():
-                for l in range(3):
-                    ynet.model[22].cv3[l][2].weight.mul_(0.05); ynet.model[22].cv3[l][2].bias.fill_(-1.0)
-                    ynet.model[22].cv2[l][2].weight.mul_(0.1)
-            ysd = ynet.state_dict()
+        ynet = make_yolo("m", 1, seed=3 if first else 0)
+        with torch.no_grad():      # tame the random head so NMS sees a realistic number of candidates
+            for l in range(3):
+                ynet.model[22].cv3[l][2].weight.mul_(0.05); ynet.model[22].cv3[l][2].bias.fill_(-1.0)
+                ynet.model[22].cv2[l][2].weight.mul_(0.1)
+        ysd = ynet.state_dict()
         if world > 1:
-            if rank != 0:
-                ysd = {k: torch.empty_like(v) for k, v in make_yolo("m", 1, seed=0).state_dict().items()}
             ysd = broadcast_state_dict(ysd, rank, world, device)
-        yolo = YoloSegHip(ysd, device=device, lib=lib, graph=not args.no_graph)
-    upscaler = RCANUpscaler(sd, device=device, lib=lib, graph=not args.no_graph) if "upscale" in want else None
+        yolo = YoloSegHip(ysd, device=device, lib=lib, graph=graph)
     sam = None
     if "segment" in want:
         from mangatranslator_amd.core.ml.sam2 import Sam2Hip
         from oracle.sam2_ref import make_config, make_model
-        if rank == 0 or world == 1:
+        if first:
             m, sam_cfg = make_model("hiera_large", seed=11)     # facebook/sam2.1-hiera-large geometry, seeded weights
             sam_sd = {k: v for k, v in m.state_dict().items()}
             del m
@@ -130,37 +136,59 @@ def main():
             sam_sd = {k: torch.empty(s) for k, s in shapes.items()}
         if world > 1:
             sam_sd = broadcast_state_dict(sam_sd, rank, world, device)
-        sam = Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=not args.no_graph)
+        sam = Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph)
         del sam_sd
+    inpainter, flux = None, None
+    if "inpaint" in want:
+        from mangatranslator_amd.core.image.inpainting import FluxKontextInpainter
+        from mangatranslator_amd.core.ml import flux as fx
+        # 11.9 B-parameter MMDiT + 84 M-parameter VAE, bf16, seeded on rank 0's GPU and broadcast tensor by tensor
+        dit = fx.FluxDiTHip(fx.synthetic_provider(fx.dit_param_shapes(fx.KONTEXT_DIT_CFG), device, 21, broadcast=world > 1), fx.KONTEXT_DIT_CFG, device, lib=lib)
+        vae = fx.FluxVAEHip(fx.synthetic_provider(fx.vae_param_shapes(fx.KONTEXT_VAE_CFG), device, 22, broadcast=world > 1), fx.KONTEXT_VAE_CFG, device, lib=lib)
+        flux = fx.FluxKontextHip(dit, vae, graph=graph)
+        g = torch.Generator().manual_seed(23)     # cached T5 / CLIP embeddings of "Remove all text." (random stand-ins)
+        flux.set_prompt_embeds(torch.randn(512, 4096, generator=g), torch.randn(768, generator=g))
+        inpainter = FluxKontextInpainter(device=device, num_inference_steps=args.inpaint_steps, backend="sdnq")
+        inpainter.pipeline = flux
 
-    # ---- synthetic pages, resident in HBM ----------------------------------------------------
+    # ---- synthetic pages, resident in HBM -----------------------------------------------------------------
     W_, H_ = args.width, args.height
     pool = 2
-    pages, page_boxes = [], []
+    pages, page_boxes, page_pil, page_masks = [], [], [], []
     for i in range(pool):
-        pg, boxes, regions = make_page(rank * 1000 + i, W_, H_, bubbles=args.boxes)
+        pg, boxes, regions = make_page(rank * 1000 + i, W_, H_, bubbles=args.boxes, osb_regions=args.regions)
         pages.append(torch.from_numpy(pg).to(device))
         page_boxes.append(boxes)
+        page_pil.append(Image.fromarray(pg))
+        ms_ = []
+        for (x0, y0, x1, y1) in regions:
+            m_ = np.zeros((H_, W_), bool); m_[y0:y1, x0:x1] = True
+            ms_.append(m_)
+        page_masks.append(ms_)
     torch.cuda.synchronize()
 
-    stages = [st for st in ("detect", "segment", "upscale") if st in want]
-    outs = [None, None, None]
+    outs = {}
     page_bgr = [pg.flip(-1).contiguous().cpu().numpy() for pg in pages]   # the detector's input is BGR (cv2 layout)
     yolo_conf = 0.6
-    if yolo is not None:     # untimed calibration: seeded weights have arbitrary scores; let ~boxes anchors pass
-        r0 = yolo(page_bgr[0], conf=0.0, imgsz=1600, max_det=1)[0]
+    if yolo is not None:     # untimed calibration: seeded weights have arbitrary scores; let ~3x boxes anchors pass
+        yolo(page_bgr[0], conf=0.0, imgsz=1600, max_det=1)
         plan0, _ = yolo._plans[(H_, W_, 1600)]
         sc = plan0.decoded[:, 4].float().sort(descending=True).values
         yolo_conf = float(sc[min(3 * args.boxes, len(sc) - 1)])
 
-    def step(i, timed=False):
-        pg = pages[i % pool]
-        if yolo is not None:     # letterbox @1600 -> YOLOv8m-seg -> decode -> NMS -> retina masks
-            outs[2] = yolo(page_bgr[i % pool], conf=yolo_conf, imgsz=1600)[0]
-        if sam is not None:      # detect is not built yet: the generator's ground-truth boxes stand in
-            outs[0] = sam.segment(pg, page_boxes[i % pool])
+    def step(i):
+        k = i % pool
+        if yolo is not None:
+            outs["detect"] = yolo(page_bgr[k], conf=yolo_conf, imgsz=1600)[0]
+        if sam is not None:      # prompts: the generator's ground-truth boxes (fixed unit count)
+            outs["segment"] = sam.segment(pages[k], page_boxes[k])
+        if inpainter is not None:
+            img = page_pil[k]
+            for m_ in page_masks[k]:
+                img = inpainter.inpaint_mask(img, m_, seed=1)
+            outs["inpaint"] = img
         if upscaler is not None:
-            outs[1] = upscaler.upscale_u8(pg)
+            outs["upscale"] = upscaler.upscale_u8(pages[k])
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,73 +214,131 @@ def main():
         "metric": "pages/sec (detect+segment+inpaint+upscale) 1024x1536",
         "value": pages_per_s, "unit": "pages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"{W_}x{H_} synthetic pages, one page per step per GPU, HBM-resident input",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{W_}x{H_} synthetic pages, full pipeline (BASELINE.json configs[3] per GPU): one page per step per GPU, "
+                               f"{args.boxes} bubbles, {args.regions} FLUX region(s) x {args.inpaint_steps} steps, 2x upscale; HBM-resident input",
                    "stages": stages,
-                   "stages_not_built_yet": ["inpaint(FLUX)"],
-                   "detector": {"arch": "YOLOv8m-seg @imgsz 1600 (1088x1600 letterbox)", "weights": "seeded random",
-                                "note": "detections feed NMS + retina masks; SAM prompts are the generator's ground-truth boxes"} if yolo is not None else None,
-                   "boxes_per_page": args.boxes,
-                   "segmenter": {"arch": "SAM-2.1 Hiera-L (HF Sam2Model layout)", "weights": "seeded random"} if sam is not None else None,
-                   "upscaler": {"arch": "RCAN", **rcan_cfg, "weights": "seeded random (no checkpoint offline)"} if upscaler is not None else None,
+                   "dtypes": {"detect": "f16", "segment": "bf16", "inpaint": "bf16 (fp32 latents / Euler update)", "upscale": "f16"},
+                   "detector": "YOLOv8m-seg @imgsz 1600 (1088x1600 letterbox), seeded random weights" if yolo is not None else None,
+                   "segmenter": "SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights" if sam is not None else None,
+                   "inpainter": "FLUX.1-Kontext-dev geometry (19 double + 38 single blocks, d=3072, 24 heads), bf16, seeded random weights" if flux is not None else None,
+                   "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
                    "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL"},
     }
+    cfg = result["config"]
 
-    if rank == 0 and sam is not None:
-        # per-stage GPU time (HIP events on the launch stream), outside the timed region
-        pre, enc, dec, post = sam.plans(args.boxes, H_, W_)
-        result["config"]["segment_ms"] = {"preprocess": pre.time(5), "encoder": enc.time(5, graph=False),
-                                          "decoder": dec.time(5, graph=False), "upsample_threshold": post.time(5)}
-    if rank == 0 and yolo is not None:
-        yp, _ = yolo._plans[(H_, W_, 1600)]
-        result["config"]["detect_net_ms"] = yp.time(5, graph=False)
-    if rank == 0 and upscaler is not None:
-        result["config"]["upscale_ms"] = upscaler.plan_for(1, H_, W_).time(3, graph=False)
-    if rank == 0 and upscaler is None:
-        print(json.dumps(result))
-    if rank == 0 and upscaler is not None:
-        # ---- roofline of the dominant kernel: 3x3 conv 64->64 at page resolution ---------------
-        u = upscaler.hp["unshuffle"]
-        plan = upscaler.plan_for(1, H_, W_)
-        idx = plan.labels.index("g0b0.conv1")
-        iters = 20
-        plan.time_range(idx, idx, 3)
-        ms = plan.time_range(idx, idx, iters)
-        work = upscaler.work(H_, W_)
-        gbs = work["conv64_bytes"] / (ms * 1e-3) / 1e9
-        tfs = work["conv64_flops"] / (ms * 1e-3) / 1e12
-        result["roofline"] = {
-            "kernel": "conv3x3_c64_kernel<f16> 64->64 @%dx%d" % (W_ // u, H_ // u),
-            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": None, "avg_launch_ms": ms, "launches_per_page": work["n_conv64"],
-            "algorithmic_bytes_per_launch": work["conv64_bytes"],
-            "mfma_tflops": tfs, "mfma_frac": tfs / MFMA_PEAK_TFLOPS,
-        }
+    if rank == 0:
+        # ---- per-stage GPU time (HIP events on the launch stream), outside the timed region ---------------
+        if sam is not None:
+            pre, enc, dec, post = sam.plans(args.boxes, H_, W_)
+            cfg["segment_ms"] = {"preprocess": pre.time(5), "encoder": enc.time(5), "decoder": dec.time(5), "upsample_threshold": post.time(5)}
+        if yolo is not None:
+            cfg["detect_net_ms"] = yolo._plans[(H_, W_, 1600)][0].time(5)
+        if upscaler is not None:
+            cfg["upscale_ms"] = upscaler.plan_for(1, H_, W_).time(3)
+        if flux is not None:
+            key, plan = next(iter(flux.transformer._plans.items()))
+            t_txt, h2, w2, _ = key
+            fl = flux.transformer.flops_per_step(t_txt, h2, w2)
+            step_ms = plan.time(2)
+            cfg["inpaint"] = {"resolution": [w2 * 16, h2 * 16], "tokens": fl["tokens"], "dit_step_ms": step_ms,
+                              "dit_tflops": (fl["gemm"] + fl["attention"]) / step_ms / 1e9,
+                              "vae_encode_ms": flux.vae.encoder_plan(h2 * 16, w2 * 16).time(2), "vae_decode_ms": flux.vae.decoder_plan(h2 * 2, w2 * 2).time(2)}
+            # ---- roofline of the dominant kernel: flash attention of one MMDiT block (52 % of a step) ------
+            idx = plan.labels.index("sgl0.attn")
+            plan.time_range(idx, idx, 2)
+            ms = plan.time_range(idx, idx, 10)
+            tfs = fl["attention_per_layer"] / ms / 1e9
+            n_attn = len(flux.transformer.blocks) + len(flux.transformer.singles)
+            result["roofline"] = {
+                "kernel": f"attn_kernel<bf16, d=128> 24 heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)",
+                "bound": "mfma", "achieved": tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS,
+                "traffic": None, "avg_launch_ms": ms, "launches_per_page": n_attn * args.inpaint_steps * args.regions,
+                "algorithmic_flops_per_launch": fl["attention_per_layer"],
+            }
+        if upscaler is not None:
+            # ---- the HBM-bound kernel the north star names: RCAN 3x3 conv 64->64 at page resolution -------
+            u = upscaler.hp["unshuffle"]
+            plan = upscaler.plan_for(1, H_, W_)
+            idx = plan.labels.index("g0b0.conv1")
+            plan.time_range(idx, idx, 3)
+            ms = plan.time_range(idx, idx, 20)
+            work = upscaler.work(H_, W_)
+            gbs = work["conv64_bytes"] / (ms * 1e-3) / 1e9
+            tfs = work["conv64_flops"] / (ms * 1e-3) / 1e12
+            conv_roof = {
+                "kernel": "conv3x3_c64_kernel<f16> 64->64 @%dx%d" % (W_ // u, H_ // u),
+                "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": None, "avg_launch_ms": ms, "launches_per_page": work["n_conv64"],
+                "algorithmic_bytes_per_launch": work["conv64_bytes"], "mfma_tflops": tfs, "mfma_frac": tfs / MFMA_PEAK_TFLOPS,
+            }
+            if "roofline" in result:
+                result["roofline_upscale_conv"] = conv_roof
+            else:
+                result["roofline"] = conv_roof
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(sd, W_, H_)
+            result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"))
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(sd, W_, H_):
-    """The oracle (CPU restatement, fp32 torch) timed on a bounded crop of the same page."""
-    from oracle.rcan_ref import load_ref
+def cpu_baseline(stages, rcan_sd, W_, H_, args, inpaint_info):
+    """The oracle (CPU restatement, fp32 torch) timed on bounded samples of the same page; each stage's
+    sample is scaled to the full page by its unit count (stated in `sample`)."""
     from mangatranslator_amd.utils.synthetic_pages import make_page
-    ref = load_ref(sd)
-    cores = min(os.cpu_count() or 1, 32)     # small convolutions stop scaling (and thrash) beyond this
+    cores = min(os.cpu_count() or 1, 32)     # the oracle's small convolutions stop scaling (and thrash) beyond this
     torch.set_num_threads(cores)
-    pg, _, _ = make_page(0, W_, H_)
-    ch, cw = 96, 64
-    x = torch.from_numpy(pg[:ch, :cw]).permute(2, 0, 1)[None].float() / 255.0
-    ref(x[:, :, :16, :16])
-    t0 = time.perf_counter()
-    ref(x)
-    dt = time.perf_counter() - t0
-    frac = (ch * cw) / float(W_ * H_)
-    return {"value": frac / dt, "unit": "pages/s", "cores": cores, "kind": "port",
-            "sample": f"oracle RCAN (torch fp32 CPU) on a {cw}x{ch} crop = {frac:.4f} page, {dt:.2f} s, upscale stage only"}
+    pg, boxes, _ = make_page(0, W_, H_, bubbles=args.boxes)
+    parts, total, spent = [], 0.0, 0.0
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            fn()
+        return time.perf_counter() - t0
+
+    if "detect" in stages:
+        from oracle import yolo_ref
+        net = yolo_ref.make_model("m", 1, seed=3)
+        bgr = np.ascontiguousarray(pg[..., ::-1])
+        t = timed(lambda: yolo_ref.predict(net, bgr, imgsz=1600, conf=0.99))
+        parts.append(f"detect: oracle YOLOv8m-seg on the whole page {t:.2f} s"); total += t; spent += t
+    if "segment" in stages:
+        from oracle import sam2_ref
+        m, _ = sam2_ref.make_model("hiera_large", seed=11)
+        t = timed(lambda: sam2_ref.run(m, pg, boxes))
+        parts.append(f"segment: oracle SAM-2.1 Hiera-L on the whole page, {len(boxes)} boxes {t:.2f} s"); total += t; spent += t
+        del m
+    if "inpaint" in stages and inpaint_info is not None:
+        from oracle import flux_ref as fr
+        T = inpaint_info["tokens"]
+        t_txt = 512
+        w2, h2 = inpaint_info["resolution"][0] // 16, inpaint_info["resolution"][1] // 16
+        torch.manual_seed(0)
+        dbl, sgl = fr.DoubleBlock(3072, 24).eval(), fr.SingleBlock(3072, 24).eval()
+        ids = torch.cat([torch.zeros(t_txt, 3), fr.image_ids(h2, w2, 0), fr.image_ids(h2, w2, 1)])
+        cos, sin = fr.rope_tables(ids, (16, 56, 56))
+        x, temb = torch.randn(T, 3072), torch.randn(3072)
+        td = timed(lambda: dbl(x[t_txt:], x[:t_txt], temb, cos, sin))
+        ts = timed(lambda: sgl(x, temb, cos, sin))
+        t = args.regions * args.inpaint_steps * (19 * td + 38 * ts)
+        parts.append(f"inpaint: oracle MMDiT blocks at full width and T={T}: 1 double {td:.2f} s + 1 single {ts:.2f} s, "
+                     f"x(19, 38) blocks x {args.inpaint_steps} steps x {args.regions} region (VAE and host math not counted)")
+        total += t; spent += td + ts
+        del dbl, sgl
+    if "upscale" in stages:
+        from oracle.rcan_ref import load_ref
+        ref = load_ref(rcan_sd)
+        ch, cw = 256, 192
+        x = torch.from_numpy(pg[:ch, :cw].copy()).permute(2, 0, 1)[None].float() / 255.0
+        ref(x[:, :, :16, :16])
+        t = timed(lambda: ref(x))
+        frac = (ch * cw) / float(W_ * H_)
+        parts.append(f"upscale: oracle RCAN on a {cw}x{ch} crop = {frac:.4f} page {t:.2f} s"); total += t / frac; spent += t
+    return {"value": 1.0 / total, "unit": "pages/s", "cores": cores, "kind": "port",
+            "sample": f"{spent:.1f} s of CPU work, extrapolated to {total:.0f} s/page — " + "; ".join(parts)}
 
 
 if __name__ == "__main__":

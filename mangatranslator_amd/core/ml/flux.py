@@ -408,7 +408,7 @@ class FluxKontextHip:
         vc = vae.cfg
         with self._lock:
             enc = vae.encoder_plan(H, W)
-            enc.src.copy_(torch.from_numpy(np.ascontiguousarray(img)).to(self.device).view(1, H, W, 3))
+            enc.src.copy_(torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device).view(1, H, W, 3))
             enc.run(graph=self._graph)
             mean = enc.moments.t[0, :, :, :16].float().permute(2, 0, 1)[None]
             ref = (mean - vc["shift_factor"]) * vc["scaling_factor"]
@@ -434,3 +434,102 @@ class FluxKontextHip:
             out = dec.out[0].clamp(0, 1).clone()
             self.last = dict(latents=lat, sigmas=sig)
         return SimpleNamespace(images=[out])
+
+
+# ---- parameter inventories (diffusers names) ------------------------------------------------------------
+KONTEXT_DIT_CFG = dict(d=3072, heads=24, layers=19, single_layers=38, in_channels=64, joint_dim=4096, pooled_dim=768, axes_dim=(16, 56, 56))
+KONTEXT_VAE_CFG = dict(ch=(128, 256, 512, 512), groups=32, scaling_factor=0.3611, shift_factor=0.1159)
+
+
+def dit_param_shapes(cfg: dict) -> dict:
+    D, hd = cfg["d"], cfg["d"] // cfg["heads"]
+    s = {}
+
+    def lin(name, dout, din):
+        s[name + ".weight"], s[name + ".bias"] = (dout, din), (dout,)
+
+    lin("x_embedder", D, cfg["in_channels"]); lin("context_embedder", D, cfg["joint_dim"]); lin("proj_out", cfg["in_channels"], D)
+    for e, din in (("timestep_embedder", 256), ("guidance_embedder", 256), ("text_embedder", cfg["pooled_dim"])):
+        lin(f"time_text_embed.{e}.linear_1", D, din); lin(f"time_text_embed.{e}.linear_2", D, D)
+    for i in range(cfg["layers"]):
+        p = f"transformer_blocks.{i}"
+        lin(p + ".norm1.linear", 6 * D, D); lin(p + ".norm1_context.linear", 6 * D, D)
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+            lin(f"{p}.attn.{n}", D, D)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            s[f"{p}.attn.{n}.weight"] = (hd,)
+        for ff in ("ff", "ff_context"):
+            lin(f"{p}.{ff}.net.0.proj", 4 * D, D); lin(f"{p}.{ff}.net.2", D, 4 * D)
+    for i in range(cfg["single_layers"]):
+        p = f"single_transformer_blocks.{i}"
+        lin(p + ".norm.linear", 3 * D, D); lin(p + ".proj_mlp", 4 * D, D); lin(p + ".proj_out", D, 5 * D)
+        for n in ("to_q", "to_k", "to_v"):
+            lin(f"{p}.attn.{n}", D, D)
+        s[f"{p}.attn.norm_q.weight"] = s[f"{p}.attn.norm_k.weight"] = (hd,)
+    lin("norm_out.linear", 2 * D, D)
+    return s
+
+
+def vae_param_shapes(cfg: dict) -> dict:
+    ch = cfg["ch"]
+    s = {}
+
+    def conv(name, co, ci, k=3):
+        s[name + ".weight"], s[name + ".bias"] = (co, ci, k, k), (co,)
+
+    def gn(name, c):
+        s[name + ".weight"] = s[name + ".bias"] = (c,)
+
+    def res(p, ci, co):
+        gn(p + ".norm1", ci); conv(p + ".conv1", co, ci); gn(p + ".norm2", co); conv(p + ".conv2", co, co)
+        if ci != co:
+            conv(p + ".conv_shortcut", co, ci, 1)
+
+    def mid(p, c):
+        res(p + ".resnets.0", c, c); res(p + ".resnets.1", c, c)
+        gn(p + ".attentions.0.group_norm", c)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            s[f"{p}.attentions.0.{n}.weight"], s[f"{p}.attentions.0.{n}.bias"] = (c, c), (c,)
+
+    conv("encoder.conv_in", ch[0], 3)
+    c = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(2):
+            res(f"encoder.down_blocks.{i}.resnets.{j}", c, co); c = co
+        if i < len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", c, c)
+    mid("encoder.mid_block", c); gn("encoder.conv_norm_out", c); conv("encoder.conv_out", 32, c)
+    rc = list(reversed(ch))
+    conv("decoder.conv_in", rc[0], 16)
+    c = rc[0]
+    mid("decoder.mid_block", c)
+    for i, co in enumerate(rc):
+        for j in range(3):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", c, co); c = co
+        if i < len(rc) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", c, c)
+    gn("decoder.conv_norm_out", c); conv("decoder.conv_out", 3, c)
+    return s
+
+
+def synthetic_provider(shapes: dict, device, seed: int, broadcast: bool = False):
+    """Seeded random-init parameters generated on `device` one tensor at a time (benchmarks: there is no
+    checkpoint on the box).  With `broadcast`, rank 0's tensors are sent to every rank over RCCL — the
+    start-up weight broadcast of the page-sharded deployment."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+
+    def get(name):
+        shp = shapes[name]
+        if len(shp) >= 2:
+            fan = int(np.prod(shp[1:]))
+            t = torch.randn(shp, device=device, generator=gen, dtype=torch.float32).mul_(1.0 / math.sqrt(fan)).to(torch.bfloat16)
+        elif "norm" in name and name.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, device=device, generator=gen)
+        else:
+            t = 0.02 * torch.randn(shp, device=device, generator=gen)
+        if broadcast:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.broadcast(t, src=0)
+        return t
+    return get

@@ -241,10 +241,83 @@ class ModelManager:
             return self.models[ModelType.SAM2]
 
     def load_flux_kontext_sdnq(self, low_vram: bool = False, verbose: bool = False):
-        """The MI355X FLUX graph; returns None while that model is not built or not staged, which the
-        inpainter treats like the reference's "pipeline not available"."""
+        """FLUX.1-Kontext as libmtx_hip graphs behind the diffusers call shape (reference :1176-1252).
+
+        Expected under models/flux/kontext (diffusers layout, bf16 — 24 GB of transformer weights are
+        resident in the 288 GB of HBM, so the reference's SDNQ uint4 packing and cpu-offload shuffling are
+        not used):  transformer/*.safetensors, vae/*.safetensors, and prompt_embeds.safetensors holding
+        `prompt_embeds [512, 4096]` / `pooled_prompt_embeds [768]` of the fixed prompt "Remove all text."
+        (exported once with the T5 / CLIP encoders; the text encoders are not on the per-page path —
+        the reference caches the same two tensors, inpainting.py:846-873).
+        Returns None when nothing is staged: the inpainter then skips, like the reference's
+        "pipeline not available" branch."""
+        mt = ModelType.FLUX_KONTEXT_SDNQ_PIPELINE
         with self._lock:
-            return self.models.get(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE)
+            if self.is_loaded(mt):
+                return self.models[mt]
+            root = self.model_paths[mt]
+            if not (root / "transformer").is_dir():
+                return None
+            from .flux import (KONTEXT_DIT_CFG, KONTEXT_VAE_CFG, FluxDiTHip, FluxKontextHip, FluxVAEHip,
+                               dit_param_shapes, vae_param_shapes)
+            dcfg, vcfg = dict(KONTEXT_DIT_CFG), dict(KONTEXT_VAE_CFG)
+            import json
+            if (root / "transformer" / "config.json").exists():     # diffusers FluxTransformer2DModel config
+                c = json.loads((root / "transformer" / "config.json").read_text())
+                dcfg.update(d=c["num_attention_heads"] * c["attention_head_dim"], heads=c["num_attention_heads"], layers=c["num_layers"],
+                            single_layers=c["num_single_layers"], in_channels=c["in_channels"], joint_dim=c["joint_attention_dim"],
+                            pooled_dim=c["pooled_projection_dim"], axes_dim=tuple(c["axes_dims_rope"]))
+            if (root / "vae" / "config.json").exists():             # diffusers AutoencoderKL config
+                c = json.loads((root / "vae" / "config.json").read_text())
+                vcfg.update(ch=tuple(c["block_out_channels"]), groups=c["norm_num_groups"], scaling_factor=c["scaling_factor"], shift_factor=c["shift_factor"])
+            dit = FluxDiTHip(_ShardedProvider(root / "transformer", dit_param_shapes(dcfg), self.device), dcfg, self.device)
+            vae = FluxVAEHip(_ShardedProvider(root / "vae", vae_param_shapes(vcfg), self.device), vcfg, self.device)
+            pipe = FluxKontextHip(dit, vae)
+            emb = root / "prompt_embeds.safetensors"
+            if emb.exists():
+                e = self._read_safetensors(emb)
+                pipe.set_prompt_embeds(e["prompt_embeds"], e["pooled_prompt_embeds"])
+            self.models[mt] = pipe
+            log_message("Flux Kontext pipeline loaded (libmtx_hip graphs, bf16).", verbose=verbose)
+            return pipe
+
+
+class _ShardedProvider:
+    """name -> tensor over the *.safetensors shards of one diffusers sub-folder.  Rank 0 reads; with more
+    than one rank every tensor is handed to the others by an RCCL broadcast (start-up only)."""
+
+    def __init__(self, folder: Path, shapes: dict, device):
+        import torch.distributed as dist
+        self.shapes, self.device = shapes, device
+        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank0 = not self.multi or dist.get_rank() == 0
+        self.where = {}
+        if self.rank0:
+            from safetensors import safe_open
+            files = sorted(folder.glob("*.safetensors"))
+            if not files:
+                raise ModelError(f"no safetensors shards under {folder}")
+            self.handles = [safe_open(str(f), framework="pt", device="cpu") for f in files]
+            for h in self.handles:
+                for k in h.keys():
+                    self.where[k] = h
+            missing = [k for k in shapes if k not in self.where]
+            if missing:
+                raise ModelError(f"{folder}: {len(missing)} parameters missing (first: {missing[0]}); a bf16 diffusers "
+                                 "checkpoint is expected — SDNQ / nunchaku / GGUF packed weights are not read")
+
+    def __call__(self, name: str) -> torch.Tensor:
+        if self.rank0:
+            t = self.where[name].get_tensor(name)
+            if tuple(t.shape) != tuple(self.shapes[name]):
+                raise ModelError(f"{name}: shape {tuple(t.shape)} != expected {tuple(self.shapes[name])}")
+            t = t.to(self.device, torch.bfloat16)
+        else:
+            t = torch.empty(self.shapes[name], dtype=torch.bfloat16, device=self.device)
+        if self.multi:
+            import torch.distributed as dist
+            dist.broadcast(t, src=0)
+        return t
 
 
 _model_manager = None

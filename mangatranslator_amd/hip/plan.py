@@ -86,6 +86,11 @@ class Plan:
 
     def time(self, iters: int, graph: bool = False, stream=None) -> float:
         ms = C.c_float(0.0)
+        if graph and stream is None and not self.lib.is_simulator:
+            torch.cuda.synchronize()
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            stream = self._side.cuda_stream
         self.lib.check(self.lib.mtx_plan_time(self._h, self._stream(stream), iters, int(graph), C.byref(ms)), "mtx_plan_time")
         return float(ms.value)
 

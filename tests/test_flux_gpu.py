@@ -1,0 +1,25 @@
+"""GPU tier: FLUX.1-Kontext graphs through the C ABI on gfx950 vs the fp32 CPU oracle."""
+import pytest
+
+import flux_checks as fc
+
+pytestmark = pytest.mark.gpu
+
+MID = dict(d=256, heads=2, layers=2, single_layers=3, joint_dim=128, pooled_dim=64, axes_dim=(16, 56, 56), vae_ch=(32, 64, 128, 128), groups=8)
+
+
+def test_dit_step_hd64(hip_lib):
+    fc.check_dit_step(hip_lib, "cuda:0")
+
+
+def test_dit_step_hd128(hip_lib):
+    fc.check_dit_step(hip_lib, "cuda:0", h2=8, w2=12, t_txt=32, **MID)
+
+
+def test_vae(hip_lib):
+    fc.check_vae(hip_lib, "cuda:0", h=128, w=192, **MID)
+
+
+def test_kontext_loop(hip_lib):
+    e, p = fc.check_kontext(hip_lib, "cuda:0", h=128, w=192, t_txt=32, steps=4, **MID)
+    assert p >= fc.PSNR_MIN_DB

@@ -1,0 +1,87 @@
+"""CPU tier: ModelManager loaders (reference core/ml/model_manager.py surface) against staged tiny
+checkpoints, with the kernel simulator standing in for libmtx_hip (test-only substitution)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+from safetensors.torch import save_file
+
+import flux_checks as fc
+from oracle import flux_ref as fr
+from oracle.rcan_ref import load_ref, make_state_dict
+
+
+@pytest.fixture()
+def manager(emu_lib, tmp_path, monkeypatch):
+    import mangatranslator_amd.hip.lib as libmod
+    from mangatranslator_amd.core.ml import model_manager as mm
+    monkeypatch.setattr(libmod, "_lib", emu_lib)
+    monkeypatch.setattr(mm, "_model_manager", None)
+    monkeypatch.setattr(mm.ModelManager, "_instance", None)
+    m = mm.get_model_manager()
+    for k in list(m.model_paths):
+        rel = m.model_paths[k].relative_to(m.model_paths[k].parents[1])
+        m.model_paths[k] = tmp_path / rel
+    yield m
+    monkeypatch.setattr(mm.ModelManager, "_instance", None)
+
+
+def test_singleton_and_missing_checkpoint(manager):
+    from mangatranslator_amd.core.ml.model_manager import get_model_manager
+    from mangatranslator_amd.utils.exceptions import ModelError
+    assert get_model_manager() is manager
+    with pytest.raises(ModelError):
+        manager.load_upscale()
+    assert manager.load_flux_kontext_sdnq() is None      # nothing staged: inpainter skips, as the reference does
+
+
+def test_load_upscale_and_unload(manager):
+    sd = make_state_dict(n_feats=32, n_resgroups=1, n_resblocks=1, seed=3)
+    p = manager.model_paths[list(manager.model_paths)[0]]
+    p.parent.mkdir(parents=True)
+    save_file(sd, str(p))
+    model = manager.load_upscale()
+    assert manager.load_upscale() is model
+    x = torch.rand(1, 3, 12, 16, generator=torch.Generator().manual_seed(0))
+    assert (model(x).cpu() - load_ref(sd)(x)).abs().max() < 2e-2
+    manager.unload_upscale_models()
+    assert not manager.is_loaded(list(manager.model_paths)[0])
+
+
+def test_load_flux_kontext_and_inpaint(manager):
+    from mangatranslator_amd.core.image.inpainting import FluxKontextInpainter
+    from mangatranslator_amd.core.ml.model_manager import ModelType
+    t, v = fc.models(seed=4)
+    root = manager.model_paths[ModelType.FLUX_KONTEXT_SDNQ_PIPELINE]
+    (root / "transformer").mkdir(parents=True); (root / "vae").mkdir()
+    tsd = {k: x.to(torch.bfloat16).contiguous() for k, x in t.state_dict().items()}
+    keys = sorted(tsd)
+    save_file({k: tsd[k] for k in keys[::2]}, str(root / "transformer" / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: tsd[k] for k in keys[1::2]}, str(root / "transformer" / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    save_file({k: x.contiguous() for k, x in v.state_dict().items()}, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+    c = t.cfg
+    (root / "transformer" / "config.json").write_text(json.dumps(dict(
+        num_attention_heads=c["heads"], attention_head_dim=c["d"] // c["heads"], num_layers=c["layers"], num_single_layers=c["single_layers"],
+        in_channels=64, joint_attention_dim=c["joint_dim"], pooled_projection_dim=c["pooled_dim"], axes_dims_rope=list(c["axes_dim"]))))
+    (root / "vae" / "config.json").write_text(json.dumps(dict(block_out_channels=list(v.cfg["ch"]), norm_num_groups=v.cfg["groups"],
+                                                            scaling_factor=v.cfg["scaling_factor"], shift_factor=v.cfg["shift_factor"])))
+    g = torch.Generator().manual_seed(9)
+    save_file({"prompt_embeds": torch.randn(8, c["joint_dim"], generator=g), "pooled_prompt_embeds": torch.randn(c["pooled_dim"], generator=g)},
+              str(root / "prompt_embeds.safetensors"))
+    pipe = manager.load_flux_kontext_sdnq()
+    assert pipe is not None and manager.load_flux_kontext_sdnq() is pipe
+    # the inpainter drives it exactly as it drives the diffusers pipeline; shrink the preferred sizes so the
+    # simulator finishes quickly
+    inp = FluxKontextInpainter(num_inference_steps=1, backend="sdnq")
+    inp.PREFERED_KONTEXT_RESOLUTIONS = [(48, 32), (32, 48), (32, 32)]
+    page = Image.fromarray((np.random.default_rng(0).random((96, 128, 3)) * 255).astype(np.uint8))
+    mask = np.zeros((96, 128), bool); mask[30:50, 40:80] = True
+    out = inp.inpaint_mask(page, mask, seed=1)
+    a, b = np.asarray(page).astype(int), np.asarray(out).astype(int)
+    assert out.size == page.size and (a != b).any()
+    far = np.ones((96, 128), bool); far[10:70, 10:118] = False
+    assert (a[far] == b[far]).all()           # pixels far from the mask are untouched by the composite
+    manager.unload_flux_kontext_sdnq_models()
+    assert not manager.is_loaded(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE)
