@@ -8,7 +8,7 @@ dicts (`success_count`, `error_count`, `errors`, `failed_image_paths`, core/pipe
 import os
 import re
 from pathlib import Path
-from typing import Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Sequence, Tuple
 
 from ..utils.logging import log_message
 
@@ -54,3 +54,27 @@ def merge_batch_results(per_rank: Sequence[Dict]) -> Dict:
         merged["failed_image_paths"].extend(r.get("failed_image_paths", []))
     merged["failed_image_paths"].sort(key=lambda p: _natural_path_sort_key(Path(p)))
     return merged
+
+
+def process_pages_sharded(pages: Sequence, process_page: Callable[[Path], None]) -> Dict:
+    """The page-sharded batch loop: every rank of the initialised process group (one per
+    GPU) walks its own slice of the sorted page list with `process_page`, failures are collected per page
+    as the reference's batch loop does (core/pipeline.py:2233-2239), and the per-rank result dicts are
+    gathered host-side.  Every rank returns the merged dict.  Without a process group: plain loop."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    local = {"success_count": 0, "error_count": 0, "errors": {}, "failed_image_paths": []}
+    for page in shard_pages(pages, rank, world):
+        try:
+            process_page(Path(page))
+            local["success_count"] += 1
+        except Exception as e:      # noqa: BLE001 — a bad page must not stop the batch
+            local["error_count"] += 1
+            local["errors"][Path(page).name] = str(e)
+            local["failed_image_paths"].append(str(page))
+    if not multi:
+        return merge_batch_results([local])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    return merge_batch_results(gathered)
