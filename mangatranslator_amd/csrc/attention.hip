@@ -211,8 +211,212 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   }
 }
 
+// =====================================================================================================
+// Large-sequence kernel (FLUX MMDiT joint attention: d = 128, T ~ 8.6 k tokens, 24 heads).
+//
+// 8 waves x 32 query rows = 256 queries per workgroup, 64-key K/V tiles double-buffered in LDS (64 KB),
+// v_mfma_f32_32x32x16.  Both products are computed transposed (S^T = K Q^T, O^T = V^T P^T): lanes l and
+// l^32 together own one query row, so the softmax is register-local plus one v_permlane32_swap.
+//   * K rows (256 B) are XOR-swizzled by (row & 15) in 16-byte chunks -> conflict-free ds_read_b128.
+//   * V stays row-major [key][d]; the V^T operand comes from ds_read_b64_tr_b16 (hardware 4x16 transpose).
+//     Chunks are swizzled by 4*(row & 3) so the 32 lanes of a half hit 32 distinct bank pairs.
+//   * The PV k-slots are assigned to keys in the order the S^T accumulators hold them (lane half `hi` owns
+//     keys 8j + 4*hi + 0..3), so P goes from the accumulators into the B operand with a plain
+//     v_cvt_pk — no cross-lane exchange, no LDS round trip.
+//   * The running max is only refreshed when some row's tile max exceeds it by more than 2^8 (wave-uniform
+//     branch); otherwise the stale max is kept (P <= 256, exact in the final normalisation) and the
+//     64-register O^T rescale is skipped.
+//   * Next tile: global -> registers at the top of the iteration, registers -> LDS after PV (one barrier
+//     per tile, LDS-only: s_waitcnt lgkmcnt(0); s_barrier).
+constexpr int AB_KV = 64;
+constexpr int AB_QB = 256;
+
+template <typename T, int DP>
+__global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16;                  // k-steps of S^T
+  constexpr int DB = DP / 32;                  // 32-row blocks of O^T
+  constexpr int ROWB = DP * 2;                 // bytes per K / V row
+  constexpr int CPR = DP / 8;                  // 16-byte chunks per row
+  constexpr int TILE_B = AB_KV * ROWB;
+  constexpr int NLD = AB_KV * CPR / 512;       // chunks per thread per operand per tile
+  static_assert(DP == 128, "swizzles are written for 256-byte rows");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
+  const long b = bh / p.heads, h = bh % p.heads;
+  const long q0 = qb * AB_QB + wv * 32;
+  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
+
+  // Q^T fragments (B operand: column = query l31, k = d 16*ks + 8*hi + j)
+  v8 qf[KS];
+  {
+    const long qr = q0 + l31;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
+      qf[ks] = __builtin_bit_cast(v8, raw);
+    }
+  }
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_raw = -1.0e30f, lsum = 0.f;
+  const float c = p.scale_log2;
+  const float thr = 8.0f / c;                  // refresh the max when a row's tile max grows by > 2^8
+
+  u32x4 rk[NLD], rv[NLD];
+  auto load_tile = [&](long k0) {
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int idx = tid + it * 512;
+      const int ch = idx % CPR, row = idx / CPR;
+      u32x4 a = u32x4{0u, 0u, 0u, 0u}, e = u32x4{0u, 0u, 0u, 0u};
+      if (k0 + row < p.sk) {
+        a = *reinterpret_cast<const u32x4*>(K + (k0 + row) * p.k_ss + ch * 8);
+        e = *reinterpret_cast<const u32x4*>(V + (k0 + row) * p.v_ss + ch * 8);
+      }
+      rk[it] = a; rv[it] = e;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* Ks = smem + buf * 2 * TILE_B;
+    unsigned char* Vs = Ks + TILE_B;
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int idx = tid + it * 512;
+      const int ch = idx % CPR, row = idx / CPR;
+      *reinterpret_cast<u32x4*>(Ks + row * ROWB + ((ch ^ (row & 15)) << 4)) = rk[it];
+      *reinterpret_cast<u32x4*>(Vs + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4)) = rv[it];
+    }
+  };
+
+  // per-lane constant parts of the V^T transpose-read address: 16-lane group g1 covers d 16*g1..+15 of a
+  // 32-row block; lane i of the group addresses key (i>>2), d 4*(i&3)..+3
+  const int ti = lane & 15, g1 = (lane >> 4) & 1;
+  const int v_row = ti >> 2;                                   // + key base (a multiple of 4)
+  const int v_chunk = 2 * g1 + ((ti & 3) >> 1);                // + 4*db
+  const int v_byte = (ti & 1) * 8;
+
+  const long ntiles = (p.sk + AB_KV - 1) / AB_KV;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (long t = 0; t < ntiles; ++t) {
+    const long k0 = t * AB_KV;
+    const unsigned char* Ks = smem + (t & 1) * 2 * TILE_B;
+    const unsigned char* Vs = Ks + TILE_B;
+    if (t + 1 < ntiles) load_tile(k0 + AB_KV);
+
+    // ---- S^T = K Q^T: sacc[kb][r] = key 32*kb + (r&3) + 8*(r>>2) + 4*hi, query l31 -------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + l31;
+        const v8 kf = *reinterpret_cast<const v8*>(Ks + row * ROWB + (((2 * ks + hi) ^ (row & 15)) << 4));
+        sacc[kb] = Mma32<T>::mfma(kf, qf[ks], sacc[kb]);
+      }
+
+    // ---- softmax in registers ---------------------------------------------------------------------------
+    if (k0 + AB_KV > p.sk) {                   // ragged last tile: keys past sk do not exist
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.sk) sacc[kb][r] = -1.0e30f;
+    }
+    float tmax = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
+    tmax = half_max(tmax);
+    if (__any(tmax > m_raw + thr)) {
+      const float m_new = fmaxf(m_raw, tmax);
+      const float alpha = fast_exp2((m_raw - m_new) * c);
+      m_raw = m_new;
+      lsum *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+    const float mc = m_raw * c;
+    v8 pb[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(__builtin_fmaf(sacc[kb][r], c, -mc));
+        lsum += pv;
+        pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
+      }
+
+    // ---- O^T += V^T P^T: k-slot (hi, j) of step (kb, s2) is key 32*kb + 16*s2 + 8*(j>>2) + 4*hi + (j&3) ---
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int key_lo = kb * 32 + s2 * 16 + hi * 4 + v_row;
+        const int key_hi = key_lo + 8;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const int ch = 4 * d + v_chunk;
+          const v4 lo = lds_read_tr16<T>(Vs + key_lo * ROWB + ((ch ^ ((key_lo & 3) << 2)) << 4) + v_byte);
+          const v4 hv = lds_read_tr16<T>(Vs + key_hi * ROWB + ((ch ^ ((key_hi & 3) << 2)) << 4) + v_byte);
+          v8 vf;
+          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+          vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
+          oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
+        }
+      }
+
+    if (t + 1 < ntiles) store_tile((int)((t + 1) & 1));
+    MTX_LDS_BARRIER();
+  }
+
+  // ---- finish: the two lane halves of a row add their partial sums; 4 consecutive d per store -----------
+  const float l = half_sum(lsum);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const long qr = q0 + l31;
+  if (qr < p.sq) {
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[d][g * 4 + r] * inv);
+        *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
+      }
+  }
+}
+
 template <typename T>
-static int launch_attn_t(const AttnParams& p, void* stream) {
+static int launch_attn_t(const AttnParams& p0, void* stream) {
+  AttnParams p = p0;
+  if (p.d == 128 && p.sq >= 1024 && p.sk >= 256) {       // long sequences: the 8-wave 32x32x16 kernel
+    p.qblocks = (unsigned)((p.sq + AB_QB - 1) / AB_QB);
+    const unsigned g = (unsigned)(p.batch * p.heads) * p.qblocks;
+    MTX_LAUNCH((attn_mma32_kernel<T, 128>), dim3(g), dim3(512), 0, stream, p);
+    return MTX_OK;
+  }
   const unsigned grid = (unsigned)(p.batch * p.heads) * p.qblocks;
   if (p.d <= 32) MTX_LAUNCH((attn_kernel<T, 32>), dim3(grid), dim3(256), 0, stream, p);
   else if (p.d <= 64) MTX_LAUNCH((attn_kernel<T, 64>), dim3(grid), dim3(256), 0, stream, p);

@@ -81,6 +81,56 @@ template <> struct Traits<_Float16> {
   }
 };
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <typename T> struct Mma32;
+template <> struct Mma32<__bf16> {
+  static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma32<_Float16> {
+  static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// LDS transpose read (ds_read_b64_tr_b16): per 16-lane group a 4 x 16 block of 16-bit elements, lane i
+// addresses row i>>2, columns 4*(i&3)..+3 and receives column i (4 rows).
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::v4 lds_read_tr16(const void* lds_ptr) {
+#ifdef MTX_EMU
+  return emu_ds_read_tr16_b64<typename Traits<T>::v4>(lds_ptr);
+#else
+  typedef __attribute__((ext_vector_type(4))) short s4;
+  s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)lds_ptr);
+  return __builtin_bit_cast(typename Traits<T>::v4, r);
+#endif
+}
+
+// combine a value with the one held by lane ^ 32 (v_permlane32_swap: one VALU op, no LDS)
+__device__ __forceinline__ float half_max(float v) {
+#ifdef MTX_EMU
+  const float o = __shfl_xor(v, 32, 64); return o > v ? o : v;
+#else
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float a = __builtin_bit_cast(float, (unsigned)r[0]), b = __builtin_bit_cast(float, (unsigned)r[1]);
+  return a > b ? a : b;
+#endif
+}
+__device__ __forceinline__ float half_sum(float v) {
+#ifdef MTX_EMU
+  return v + __shfl_xor(v, 32, 64);
+#else
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+#endif
+}
+__device__ __forceinline__ float fast_exp2(float v) {
+#ifdef MTX_EMU
+  return exp2f(v);
+#else
+  return __builtin_amdgcn_exp2f(v);
+#endif
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 // _Float16 saturates instead of overflowing to inf (activations can spike on random weights)

@@ -187,11 +187,60 @@ inline emu_f32x4 emu_mfma_16x16x32(V8 a, V8 b, emu_f32x4 c) {
   emu::wave_sync();
   return d;
 }
+// D = A(32x16) * B(16x32) + C ; lane l holds A[l&31][8*(l>>5)..+8], B[8*(l>>5)..+8][l&31],
+// C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)   (checked on gfx950 with tools/probes/tr_probe.hip)
+typedef __attribute__((ext_vector_type(16))) float emu_f32x16;
+template <typename V8>
+inline emu_f32x16 emu_mfma_32x32x16(V8 a, V8 b, emu_f32x16 c) {
+  emu::WaveState& w = emu::wave();
+  int l = emu::lane_id();
+  float fa[8], fb[8];
+  for (int i = 0; i < 8; ++i) { fa[i] = (float)a[i]; fb[i] = (float)b[i]; }
+  memcpy(w.xa[l], fa, 32);
+  memcpy(w.xb[l], fb, 32);
+  emu::wave_sync();
+  emu_f32x16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float s = d[r];
+    for (int hb = 0; hb < 2; ++hb) {
+      const float* pa = reinterpret_cast<const float*>(w.xa[hb * 32 + row]);
+      const float* pb = reinterpret_cast<const float*>(w.xb[hb * 32 + col]);
+      for (int i = 0; i < 8; ++i) s += pa[i] * pb[i];
+    }
+    d[r] = s;
+  }
+  emu::wave_sync();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16(a, b, c)
+
+// ds_read_b64_tr_b16: within each 16-lane group the lanes' 4-element reads form a 4x16 matrix
+// (lane i supplies row i>>2, columns 4*(i&3)..+3); lane i receives column i (checked on gfx950).
+template <typename V4>
+inline V4 emu_ds_read_tr16_b64(const void* p) {
+  emu::WaveState& w = emu::wave();
+  int l = emu::lane_id();
+  memcpy(w.xa[l], p, 8);
+  emu::wave_sync();
+  V4 r;
+  const int g = l & ~15, i = l & 15;
+  for (int j = 0; j < 4; ++j) memcpy(reinterpret_cast<unsigned char*>(&r) + 2 * j, w.xa[g + 4 * j + (i >> 2)] + 2 * (i & 3), 2);
+  emu::wave_sync();
+  return r;
+}
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_16x16x32(a, b, c)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+inline int __any(int pred) {
+  int r = pred ? 1 : 0;
+  for (int m = 32; m >= 1; m >>= 1) r |= __shfl_xor(r, m, 64);
+  return r;
+}
 
 inline float __expf(float x) { return expf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }

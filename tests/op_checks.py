@@ -130,10 +130,10 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
     return err
 
 
-def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0):
+def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0):
     g = torch.Generator().manual_seed(seed)
     dev, td = _dev(lib), TD[dtype]
-    q = torch.randn(batch, sq, heads, d, generator=g).to(td)
+    q = (torch.randn(batch, sq, heads, d, generator=g) * qmul).to(td)     # qmul > 1: peaked rows, exercises max refreshes
     k = torch.randn(batch, sk, heads, d, generator=g).to(td)
     v = torch.randn(batch, sk, heads, d, generator=g).to(td)
     scale = 1.0 / math.sqrt(d)
