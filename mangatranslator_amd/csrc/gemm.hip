@@ -11,6 +11,7 @@
 // output columns; the tile is transposed through LDS and leaves as 16-byte row chunks with bias,
 // activation, per-sample gate (adaLN-Zero) and residual fused.
 #include "mtx_device.h"
+#include <cstdlib>
 
 namespace mtx {
 
@@ -184,6 +185,162 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
+// =====================================================================================================
+// Large-problem kernel: 256 x 256 x 64 tiles, 8 waves (2 per SIMD), v_mfma_f32_32x32x16, operands brought in
+// by LDS-DMA (global_load_lds, 16 B per lane) into two 64 KB stages — no staging registers, one barrier per
+// K tile, the next tile's DMA in flight behind the current tile's 32 MFMAs per wave.
+//   * LDS image of a stage: A rows then W rows, 128 B (64 k) per row, linear in DMA order; the XOR swizzle
+//     (chunk ^ ((row >> 1) & 7), conflict-free for the 32-row ds_read_b128 pattern of the 32x32 MFMA) is
+//     applied to the SOURCE address of each lane.
+//   * wave (wm, wn) of a 2 x 4 grid owns 128 rows (m) x 64 columns (n): 4 x 2 accumulator blocks of 32 x 32.
+//     Operands are swapped (A-operand = W rows), so a lane ends up with 4 consecutive n of one row m.
+//   * epilogue: bias / activation in registers -> the wave's own 16 KB LDS region (swizzled) -> 16-byte row
+//     chunks, gate (.) and residual (+) fused, 128-byte row segments to HBM.
+//   * workgroup -> tile map: XCD-contiguous, then groups of 4 tile rows x 8 tile columns so the 32 workgroups
+//     resident on one XCD share A and W panels through that XCD's L2.
+constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
+constexpr int G2_STAGE = (G2_BM + G2_BN) * 128;      // 64 KB
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wm = wv >> 2, wn = wv & 3;
+
+  const unsigned nwg = p.tiles_m * p.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  const unsigned GM = 4;
+  const unsigned per_group = GM * p.tiles_n;
+  const unsigned group = lin / per_group, first_m = group * GM;
+  const unsigned gsz = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+  const long m0 = (long)(first_m + (lin % per_group) % gsz) * G2_BM;
+  const long n0 = (long)((lin % per_group) / gsz) * G2_BN;
+  const long bz = blockIdx.y;
+  const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
+  const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
+  T* Cp = reinterpret_cast<T*>(p.c) + (size_t)bz * p.c_bs;
+
+  // ---- DMA plan: instruction i of wave wv fills LDS rows (i*8 + wv)*8 .. +7 of a stage (1 KB); rows 0..255
+  // are A, 256..511 are W.  This lane supplies slot (row = base + lane/8, position lane%8).
+  const T* src[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (i * 8 + wv) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    if (row < G2_BM) src[i] = (m0 + row < p.m) ? A + (size_t)(m0 + row) * p.lda + c * 8 : nullptr;
+    else src[i] = (n0 + row - G2_BM < p.n) ? W + (size_t)(n0 + row - G2_BM) * p.ldw + c * 8 : nullptr;
+  }
+  auto issue = [&](int stage, long k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const void* g = src[i] ? (const void*)(src[i] + k0) : (const void*)g_zero16;
+      glds16(g, smem + stage * G2_STAGE + (i * 8 + wv) * 1024);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment rows of this lane and their swizzle term
+  int arow[4], wrow[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) arow[i] = wm * 128 + i * 32 + l31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wrow[j] = G2_BM + wn * 64 + j * 32 + l31;
+
+  const long nk = p.k / G2_BK;
+  issue(0, 0);
+  for (long kt = 0; kt < nk; ++kt) {
+    MTX_WAIT_VMEM();
+    __syncthreads();
+    if (kt + 1 < nk) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
+    const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ch = 2 * ks + hi;
+      v8 af[4], wf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue.  acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
+  __syncthreads();
+  unsigned char* outs = smem + wv * 16384;          // [128 rows m][8 chunks of 16 B], chunk ^= (row & 7)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = j * 32 + g * 8 + hi * 4;         // local n of this lane's 4 values
+      float b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long n = n0 + wn * 64 + nl + r;
+        b[r] = (p.bias != nullptr && n < p.n) ? p.bias[n] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + l31;
+        v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act_t<ACT>(acc[i][j][g * 4 + r] * p.alpha + b[r], p.act, p.act_param));
+        *reinterpret_cast<v4*>(outs + row * 128 + ((((nl >> 3)) ^ (row & 7)) << 4) + ((nl & 4) << 1)) = o;
+      }
+    }
+  // a wave only re-reads its own region: no workgroup barrier needed, just its own LDS writes
+#ifdef MTX_EMU
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  const T* G = reinterpret_cast<const T*>(p.gate);
+  const T* R = reinterpret_cast<const T*>(p.res);
+  const int oc = lane & 7;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const long m = m0 + wm * 128 + row, n = n0 + wn * 64 + oc * 8;
+    if (m >= p.m || n >= p.n) continue;
+    u32x4 raw = *reinterpret_cast<const u32x4*>(outs + row * 128 + ((oc ^ (row & 7)) << 4));
+    if (G != nullptr || R != nullptr) {
+      float f[8];
+      unpack8<T>(raw, f);
+      if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + (size_t)(m / p.gate_rows_per) * p.ldgate + n), g8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
+      if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)bz * p.res_bs + (size_t)m * p.ldres + n), r8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += r8[e]; }
+      raw = pack8<T>(f);
+    }
+    *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = raw;
+  }
+}
+
+template <typename T>
+static void launch_gemm256(const GemmParams& p, dim3 grid, void* stream) {
+  switch (p.act) {
+    case MTX_ACT_NONE: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_NONE>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_SILU: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_SILU>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_GELU_TANH>), grid, dim3(512), 0, stream, p); break;
+    default: MTX_LAUNCH((gemm256_kernel<T, -1>), grid, dim3(512), 0, stream, p); break;
+  }
+}
+
 int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (!a->a || !a->w || !a->c) { *err = "gemm: null operand"; return MTX_ERR_INVALID; }
   if (a->m < 1 || a->n < 1 || a->k < 1) { *err = "gemm: empty problem"; return MTX_ERR_INVALID; }
@@ -202,6 +359,17 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;
+  // large, aligned problems: the 256 x 256 LDS-DMA kernel (needs whole K tiles and 16-byte rows everywhere)
+  const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;
+  const bool vec = a->n % 8 == 0 && a->ldc % 8 == 0 && (!a->res || a->ldres % 8 == 0) && (!a->gate || a->ldgate % 8 == 0) && a->c_bstride % 8 == 0;
+  const long min_tiles = getenv("MTX_GEMM256_MIN_TILES") ? atol(getenv("MTX_GEMM256_MIN_TILES")) : 160;   // tests lower it
+  if (!p.out_f32 && a->k % G2_BK == 0 && vec && t256 >= min_tiles && (a->dtype == MTX_BF16 || a->dtype == MTX_F16)) {
+    p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
+    p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
+    dim3 g2(p.tiles_m * p.tiles_n, (unsigned)batch);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16>(p, g2, stream); else launch_gemm256<_Float16>(p, g2, stream);
+    return MTX_OK;
+  }
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm_kernel<__bf16>), grid, dim3(256), 0, stream, p);
   else if (a->dtype == MTX_F16) MTX_LAUNCH((gemm_kernel<_Float16>), grid, dim3(256), 0, stream, p);

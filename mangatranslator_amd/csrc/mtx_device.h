@@ -167,6 +167,10 @@ __device__ __forceinline__ float apply_act_t(float v, int act, float p) {
   if (ACT == MTX_ACT_NONE) return v;
   if (ACT == MTX_ACT_RELU) return v > 0.f ? v : 0.f;
   if (ACT == MTX_ACT_SILU) return v / (1.f + __expf(-v));
+  if (ACT == MTX_ACT_GELU_TANH) {       // 0.5 v (1 + tanh u) == v * sigmoid(2u): one exp, one divide
+    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+    return v / (1.f + __expf(-2.f * u));
+  }
   return apply_act(v, act, p);
 }
 

@@ -98,3 +98,10 @@ def test_image_convert(hip_lib):
 def test_attention_long_sequence_kernel(hip_lib, cfg):
     oc.check_attention(hip_lib, abi.BF16, **cfg)
     oc.check_attention(hip_lib, abi.F16, **cfg)
+
+
+@pytest.mark.parametrize("cfg", [dict(m=8652, n=3072, k=3072, with_res=True, with_gate=True), dict(m=4100, n=9216, k=1024, act=abi.ACT_GELU_TANH),
+                                 dict(m=2048, n=5000 // 8 * 8, k=320, act=abi.ACT_SILU, with_bias=False, with_res=True)])
+def test_gemm_256_tile_kernel(hip_lib, cfg):
+    oc.check_gemm(hip_lib, abi.BF16, **cfg)
+    oc.check_gemm(hip_lib, abi.F16, **cfg)

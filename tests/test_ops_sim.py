@@ -85,3 +85,10 @@ def test_attention_long_sequence_kernel(emu_lib):
     """d = 128, sq >= 1024: the 8-wave 32x32x16 kernel (ragged q block and ragged last key tile)"""
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=2, sq=1030, sk=330, d=128)
     oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=256, d=128, qmul=5.0)
+
+
+def test_gemm_256_tile_kernel(emu_lib, monkeypatch):
+    """the 256 x 256 LDS-DMA kernel (normally reserved for >= 160 tiles) on ragged small problems"""
+    monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
+    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
+    oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False)
