@@ -231,6 +231,106 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 constexpr int AB_KV = 64;
 constexpr int AB_QB = 256;
 
+// One K/V tile of the main loop.  STAGE is a compile-time constant so every LDS address is
+// (loop-invariant VGPR) + (immediate offset).
+template <typename T, int DP, int STAGE, bool RAGGED>
+__device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
+                                                float& m_raw, float& lsum, const float c, const float thr,
+                                                const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
+  const unsigned char* Vs = Ks + TILE_B;
+
+  // ---- S^T = K Q^T: sacc[kb][r] = key 32*kb + (r&3) + 8*(r>>2) + 4*hi of this tile, query l31 ----------------
+  f32x16 sacc[2];
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
+      sacc[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : sacc[kb]);
+    }
+
+  if (RAGGED) {                                // last tile of a ragged sequence: keys >= kvalid do not exist
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) sacc[kb][r] = -1.0e30f;
+  }
+  float tmax = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+  for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
+  tmax = half_max(tmax);
+  if (__any(tmax > m_raw + thr)) {
+    const float m_new = fmaxf(m_raw, tmax);
+    const float alpha = fast_exp2((m_raw - m_new) * c);
+    m_raw = m_new;
+    lsum *= alpha;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+  }
+  const float mc = m_raw * c;
+  v8 pb[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = fast_exp2(__builtin_fmaf(sacc[kb][r], c, -mc));
+      lsum += pv;
+      pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
+    }
+
+  // ---- O^T += V^T P^T: k-slot (hi, j) of step (kb, s2) is key 32*kb + 16*s2 + 8*(j>>2) + 4*hi + (j&3) ------------
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
+        const v4 lo = lds_read_tr16<T>(a);
+        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+        v8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
+        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
+      }
+}
+
+// 16 bytes through a buffer descriptor: byte offset = voff (per lane) + soff (wave-uniform); reads past
+// `bytes` return zeros (the hardware range check), which is how rows >= sk become zero rows.
+struct BufView {
+#ifdef MTX_EMU
+  const unsigned char* base; unsigned bytes;
+#else
+  __amdgpu_buffer_rsrc_t rsrc;
+#endif
+};
+__device__ __forceinline__ BufView make_buf(const void* base, unsigned bytes) {
+  BufView b;
+#ifdef MTX_EMU
+  b.base = reinterpret_cast<const unsigned char*>(base); b.bytes = bytes;
+#else
+  b.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+#endif
+  return b;
+}
+__device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, unsigned soff) {
+#ifdef MTX_EMU
+  u32x4 r = u32x4{0u, 0u, 0u, 0u};
+  if ((unsigned long)voff + soff + 16 <= b.bytes) memcpy(&r, b.base + voff + soff, 16);
+  return r;
+#else
+  return __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)voff, (int)soff, 0);
+#endif
+}
+
 template <typename T, int DP>
 __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   typedef typename Traits<T>::v8 v8;
@@ -275,120 +375,81 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   const float c = p.scale_log2;
   const float thr = 8.0f / c;                  // refresh the max when a row's tile max grows by > 2^8
 
+  // ---- global -> register staging through buffer descriptors (no per-load predicates, no 64-bit VALU math)
+  const BufView kb_ = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
+  const BufView vb_ = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
+  unsigned kvoff[NLD], vvoff[NLD];
+  int ksw[NLD], vsw[NLD];
+#pragma unroll
+  for (int it = 0; it < NLD; ++it) {
+    const int idx = tid + it * 512;
+    const int ch = idx % CPR, row = idx / CPR;
+    kvoff[it] = (unsigned)((row * p.k_ss + ch * 8) * sizeof(T));
+    vvoff[it] = (unsigned)((row * p.v_ss + ch * 8) * sizeof(T));
+    ksw[it] = row * ROWB + ((ch ^ (row & 15)) << 4);
+    vsw[it] = TILE_B + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4);
+  }
+  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
   u32x4 rk[NLD], rv[NLD];
-  auto load_tile = [&](long k0) {
+  auto load_tile = [&](long t) {
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
-      const int idx = tid + it * 512;
-      const int ch = idx % CPR, row = idx / CPR;
-      u32x4 a = u32x4{0u, 0u, 0u, 0u}, e = u32x4{0u, 0u, 0u, 0u};
-      if (k0 + row < p.sk) {
-        a = *reinterpret_cast<const u32x4*>(K + (k0 + row) * p.k_ss + ch * 8);
-        e = *reinterpret_cast<const u32x4*>(V + (k0 + row) * p.v_ss + ch * 8);
-      }
-      rk[it] = a; rv[it] = e;
+      rk[it] = buf_load16(kb_, kvoff[it], (unsigned)t * k_step);
+      rv[it] = buf_load16(vb_, vvoff[it], (unsigned)t * v_step);
     }
   };
-  auto store_tile = [&](int buf) {
-    unsigned char* Ks = smem + buf * 2 * TILE_B;
-    unsigned char* Vs = Ks + TILE_B;
+  auto store_tile = [&](int stage) {
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
-      const int idx = tid + it * 512;
-      const int ch = idx % CPR, row = idx / CPR;
-      *reinterpret_cast<u32x4*>(Ks + row * ROWB + ((ch ^ (row & 15)) << 4)) = rk[it];
-      *reinterpret_cast<u32x4*>(Vs + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4)) = rv[it];
+      *reinterpret_cast<u32x4*>(smem + stage * 2 * TILE_B + ksw[it]) = rk[it];
+      *reinterpret_cast<u32x4*>(smem + stage * 2 * TILE_B + vsw[it]) = rv[it];
     }
   };
 
-  // per-lane constant parts of the V^T transpose-read address: 16-lane group g1 covers d 16*g1..+15 of a
-  // 32-row block; lane i of the group addresses key (i>>2), d 4*(i&3)..+3
-  const int ti = lane & 15, g1 = (lane >> 4) & 1;
-  const int v_row = ti >> 2;                                   // + key base (a multiple of 4)
-  const int v_chunk = 2 * g1 + ((ti & 3) >> 1);                // + 4*db
-  const int v_byte = (ti & 1) * 8;
+  // ---- loop-invariant LDS fragment addresses (byte offsets inside a stage) ---------------------------------
+  // K: row l31 (+32*kb), chunk (2*ks + hi) ^ (l31 & 15)
+  int kaddr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
+  // V^T by transpose reads: 16-lane group g1 covers d 16*g1..+15 of a 32-row block; lane i of the group
+  // addresses key 4*hi + (i>>2) (+ step base), d 4*(i&3)..+3; chunk swizzle 4*(key & 3) = 4*(i>>2)
+  int vaddr[DB];
+  {
+    const int ti = lane & 15, g1 = (lane >> 4) & 1;
+    const int vrow = hi * 4 + (ti >> 2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+      vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
+  }
 
   const long ntiles = (p.sk + AB_KV - 1) / AB_KV;
+  const long kv_last = p.sk - (ntiles - 1) * AB_KV;     // valid keys in the last tile (1..64)
   load_tile(0);
   store_tile(0);
   __syncthreads();
-  for (long t = 0; t < ntiles; ++t) {
-    const long k0 = t * AB_KV;
-    const unsigned char* Ks = smem + (t & 1) * 2 * TILE_B;
-    const unsigned char* Vs = Ks + TILE_B;
-    if (t + 1 < ntiles) load_tile(k0 + AB_KV);
-
-    // ---- S^T = K Q^T: sacc[kb][r] = key 32*kb + (r&3) + 8*(r>>2) + 4*hi, query l31 -------------------
-    f32x16 sacc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int row = kb * 32 + l31;
-        const v8 kf = *reinterpret_cast<const v8*>(Ks + row * ROWB + (((2 * ks + hi) ^ (row & 15)) << 4));
-        sacc[kb] = Mma32<T>::mfma(kf, qf[ks], sacc[kb]);
-      }
-
-    // ---- softmax in registers ---------------------------------------------------------------------------
-    if (k0 + AB_KV > p.sk) {                   // ragged last tile: keys past sk do not exist
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.sk) sacc[kb][r] = -1.0e30f;
-    }
-    float tmax = sacc[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
-    tmax = half_max(tmax);
-    if (__any(tmax > m_raw + thr)) {
-      const float m_new = fmaxf(m_raw, tmax);
-      const float alpha = fast_exp2((m_raw - m_new) * c);
-      m_raw = m_new;
-      lsum *= alpha;
-#pragma unroll
-      for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-    }
-    const float mc = m_raw * c;
-    v8 pb[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = fast_exp2(__builtin_fmaf(sacc[kb][r], c, -mc));
-        lsum += pv;
-        pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
-      }
-
-    // ---- O^T += V^T P^T: k-slot (hi, j) of step (kb, s2) is key 32*kb + 16*s2 + 8*(j>>2) + 4*hi + (j&3) ---
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int key_lo = kb * 32 + s2 * 16 + hi * 4 + v_row;
-        const int key_hi = key_lo + 8;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          const int ch = 4 * d + v_chunk;
-          const v4 lo = lds_read_tr16<T>(Vs + key_lo * ROWB + ((ch ^ ((key_lo & 3) << 2)) << 4) + v_byte);
-          const v4 hv = lds_read_tr16<T>(Vs + key_hi * ROWB + ((ch ^ ((key_hi & 3) << 2)) << 4) + v_byte);
-          v8 vf;
-          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-          vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
-          oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
-        }
-      }
-
-    if (t + 1 < ntiles) store_tile((int)((t + 1) & 1));
+  long t = 0;
+  // full tiles, two per iteration so the LDS stage is a compile-time constant
+  for (; t + 2 < ntiles; t += 2) {
+    load_tile(t + 1);
+    attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+    store_tile(1);
     MTX_LDS_BARRIER();
+    load_tile(t + 2);
+    attn_mma32_tile<T, DP, 1, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+    store_tile(0);
+    MTX_LDS_BARRIER();
+  }
+  // one or two tiles left; the very last one may be ragged
+  if (t + 2 == ntiles) {
+    load_tile(t + 1);
+    attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+    store_tile(1);
+    MTX_LDS_BARRIER();
+    if (kv_last < AB_KV) attn_mma32_tile<T, DP, 1, true>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
+    else attn_mma32_tile<T, DP, 1, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+  } else {
+    if (kv_last < AB_KV) attn_mma32_tile<T, DP, 0, true>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
+    else attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
   }
 
   // ---- finish: the two lane halves of a row add their partial sums; 4 consecutive d per store -----------

@@ -201,7 +201,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_STAGE = (G2_BM + G2_BN) * 128;      // 64 KB
 
-template <typename T, int ACT>
+#ifdef MTX_EMU
+#define G2_BAR() __syncthreads()
+#else
+#define G2_BAR() asm volatile("s_barrier" ::: "memory")
+#endif
+
+// PP = ping-pong schedule: the two waves of every SIMD (waves w and w+4) run one barrier apart, so while one
+// issues its fragment reads / DMA for a k-step the other owns the matrix pipe for its 8 MFMAs.
+template <typename T, int ACT, bool PP>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
@@ -257,25 +265,78 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   for (int j = 0; j < 2; ++j) wrow[j] = G2_BM + wn * 64 + j * 32 + l31;
 
   const long nk = p.k / G2_BK;
-  issue(0, 0);
-  for (long kt = 0; kt < nk; ++kt) {
+  if (!PP) {
+    issue(0, 0);
+    for (long kt = 0; kt < nk; ++kt) {
+      MTX_WAIT_VMEM();
+      __syncthreads();
+      if (kt + 1 < nk) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
+      const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ch = 2 * ks + hi;
+        v8 af[4], wf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+      }
+    }
+  } else {
+    // Barrier timeline B0, B1, ...: group 0 runs  L(k) B C(k) B  per k-step, group 1 the same one barrier later,
+    // so group 1's load segment L coincides with group 0's compute segment C and vice versa.
+    //  * tile kt+1 is DMA'd into the other stage from the load segments of k-steps 1 and 2 of tile kt: by then
+    //    both groups have finished (lgkmcnt(0)) their reads of tile kt-1, which used that stage;
+    //  * every wave drains its own DMA (vmcnt(0)) before the barrier that precedes group 0's first reads of
+    //    tile kt+1: group 0 at the end of C(kt,3), group 1 at the end of L(kt,3).
+    const int grp = wv >> 2;
+    issue(0, 0);
     MTX_WAIT_VMEM();
     __syncthreads();
-    if (kt + 1 < nk) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
-    const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+    if (grp == 1) G2_BAR();
+    for (long kt = 0; kt < nk; ++kt) {
+      const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+      const bool more = kt + 1 < nk;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int ch = 2 * ks + hi;
-      v8 af[4], wf[2];
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ch = 2 * ks + hi;
+        v8 af[4], wf[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
+        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+        if (more && (ks == 1 || ks == 2)) {
+          const int stage = (int)((kt + 1) & 1);
+          const long k0 = (kt + 1) * G2_BK;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i) {
+            const int pi = (ks - 1) * 4 + i;
+            const void* g = src[pi] ? (const void*)(src[pi] + k0) : (const void*)g_zero16;
+            glds16(g, smem + stage * G2_STAGE + (pi * 8 + wv) * 1024);
+          }
+        }
+        if (ks == 3 && grp == 1) MTX_WAIT_VMEM();
+        G2_BAR();
+#ifndef MTX_EMU
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+#ifndef MTX_EMU
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if (ks == 3 && grp == 0) MTX_WAIT_VMEM();
+        G2_BAR();
+      }
     }
+    if (grp == 0) G2_BAR();
   }
 
   // ---- epilogue.  acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
@@ -331,14 +392,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   }
 }
 
+template <typename T, bool PP>
+static void launch_gemm256_pp(const GemmParams& p, dim3 grid, void* stream) {
+  switch (p.act) {
+    case MTX_ACT_NONE: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_NONE, PP>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_SILU: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_SILU, PP>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_GELU_TANH, PP>), grid, dim3(512), 0, stream, p); break;
+    default: MTX_LAUNCH((gemm256_kernel<T, -1, PP>), grid, dim3(512), 0, stream, p); break;
+  }
+}
 template <typename T>
 static void launch_gemm256(const GemmParams& p, dim3 grid, void* stream) {
-  switch (p.act) {
-    case MTX_ACT_NONE: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_NONE>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_SILU: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_SILU>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_GELU_TANH>), grid, dim3(512), 0, stream, p); break;
-    default: MTX_LAUNCH((gemm256_kernel<T, -1>), grid, dim3(512), 0, stream, p); break;
-  }
+  const char* e = getenv("MTX_GEMM256_SCHED");          // A/B switch: "lockstep" selects the one-barrier-per-tile loop
+  if (e && e[0] == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
+  else launch_gemm256_pp<T, true>(p, grid, stream);
 }
 
 int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {

@@ -1,0 +1,63 @@
+"""GPU micro-benchmarks of the two MFMA-bound kernels at FLUX shapes (HIP-event timing via mtx_plan_time).
+usage: python tools/bench_kernels.py attn T [heads]   |   gemm M N K"""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mangatranslator_amd.hip import abi
+from mangatranslator_amd.hip.lib import get_library
+from mangatranslator_amd.hip.plan import PlanBuilder
+
+lib = get_library(); lib.init(0)
+dev = torch.device("cuda:0")
+
+
+def attn(T, heads=24, d=128, iters=10):
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    D = heads * d
+    qkv = pb.buf((T, 3 * D), torch.bfloat16); qkv.normal_()
+    o = pb.buf((T, D), torch.bfloat16)
+    pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D)
+    plan = pb.build(); plan.run(); torch.cuda.synchronize()
+    ms = plan.time(iters)
+    print(f"attn T={T} heads={heads}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s")
+
+
+def gemm(M, N, K, iters=10):
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    a = pb.buf((M, K), torch.bfloat16); a.normal_()
+    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
+    pb.gemm(a, w, M, N, K)
+    plan = pb.build(); plan.run(); torch.cuda.synchronize()
+    ms = plan.time(iters)
+    print(f"gemm M={M} N={N} K={K}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s")
+
+
+def gemm_ab(M, N, K, rounds=5, iters=20):
+    """interleaved A/B of the two 256-tile schedules in one process (run-to-run clock drift is ~10 %)"""
+    import os
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    a = pb.buf((M, K), torch.bfloat16); a.normal_()
+    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
+    pb.gemm(a, w, M, N, K)
+    plan = pb.build(); plan.run(); torch.cuda.synchronize()
+    res = {"pingpong": [], "lockstep": []}
+    for r in range(rounds):
+        for mode in res:
+            os.environ["MTX_GEMM256_SCHED"] = mode
+            plan.time(3)
+            res[mode].append(plan.time(iters))
+    for mode, v in res.items():
+        print(f"gemm {M}x{N}x{K} {mode}: best {min(v):.3f} ms ({2 * M * N * K / min(v) / 1e9:.0f} TF/s), median {sorted(v)[len(v) // 2]:.3f} ms")
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    while args:
+        if args[0] == "attn":
+            attn(int(args[1])); args = args[2:]
+        elif args[0] == "ab":
+            gemm_ab(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
+        else:
+            gemm(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
+

@@ -1,6 +1,7 @@
 """GPU probe: full-size FLUX.1-Kontext (random-init bf16) — per-step time and per-op breakdown."""
 import sys, time, json
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mangatranslator_amd.core.ml import flux as fx
 from mangatranslator_amd.hip.lib import get_library
