@@ -22,6 +22,7 @@ struct GemmParams {
   int gate_rows_per, act; float act_param, alpha;
   int out_f32;
   unsigned tiles_m, tiles_n;
+  int abl;          // MTX_GEMM_ABL: timing ablations of the 256-tile kernel (1 = no DMA after the first tile, 2 = no barrier wait)
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -201,6 +202,64 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_STAGE = (G2_BM + G2_BN) * 128;      // 64 KB
 
+// Epilogue of the 256-tile kernels, run by the 8 MFMA waves (wv = 0..7).
+// acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
+template <typename T, int ACT>
+__device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], unsigned char* smem, T* Cp,
+                                                 long m0, long n0, long bz, int wv, int lane) {
+  typedef typename Traits<T>::v4 v4;
+  const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 2, wn = wv & 3;
+  unsigned char* outs = smem + wv * 16384;          // [128 rows m][8 chunks of 16 B], chunk ^= (row & 7)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = j * 32 + g * 8 + hi * 4;         // local n of this lane's 4 values
+      float b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long n = n0 + wn * 64 + nl + r;
+        b[r] = (p.bias != nullptr && n < p.n) ? p.bias[n] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + l31;
+        v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act_t<ACT>(acc[i][j][g * 4 + r] * p.alpha + b[r], p.act, p.act_param));
+        *reinterpret_cast<v4*>(outs + row * 128 + ((((nl >> 3)) ^ (row & 7)) << 4) + ((nl & 4) << 1)) = o;
+      }
+    }
+  // a wave only re-reads its own region: no workgroup barrier needed, just its own LDS writes
+#ifdef MTX_EMU
+  emu::wave_sync();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  const T* G = reinterpret_cast<const T*>(p.gate);
+  const T* R = reinterpret_cast<const T*>(p.res);
+  const int oc = lane & 7;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const long m = m0 + wm * 128 + row, n = n0 + wn * 64 + oc * 8;
+    if (m >= p.m || n >= p.n) continue;
+    u32x4 raw = *reinterpret_cast<const u32x4*>(outs + row * 128 + ((oc ^ (row & 7)) << 4));
+    if (G != nullptr || R != nullptr) {
+      float f[8];
+      unpack8<T>(raw, f);
+      if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + (size_t)(m / p.gate_rows_per) * p.ldgate + n), g8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
+      if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)bz * p.res_bs + (size_t)m * p.ldres + n), r8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += r8[e]; }
+      raw = pack8<T>(f);
+    }
+    *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = raw;
+  }
+}
+
 #ifdef MTX_EMU
 #define G2_BAR() __syncthreads()
 #else
@@ -270,20 +329,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     for (long kt = 0; kt < nk; ++kt) {
       MTX_WAIT_VMEM();
       __syncthreads();
-      if (kt + 1 < nk) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
+      if (kt + 1 < nk && p.abl != 1) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
       const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+      // fragment reads run one k-step ahead of the MFMAs that consume them (two register sets)
+      v8 af[2][4], wf[2][2];
+      auto read_frags = [&](int ks, int set) {
+        const int ch = 2 * ks + hi;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+      };
+      read_frags(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int ch = 2 * ks + hi;
-        v8 af[4], wf[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+        if (ks < 3) read_frags(ks + 1, (ks + 1) & 1);
+#ifndef MTX_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+          for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
+#ifndef MTX_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
   } else {
@@ -339,56 +409,110 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     if (grp == 0) G2_BAR();
   }
 
-  // ---- epilogue.  acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
   __syncthreads();
-  unsigned char* outs = smem + wv * 16384;          // [128 rows m][8 chunks of 16 B], chunk ^= (row & 7)
+  gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
+}
+
+// Wave-specialised variant: 8 MFMA waves (never touch VMEM) + 4 DMA waves (one per SIMD) that stream the next
+// K tile into the other LDS stage while the MFMA waves work.  An LDS-DMA instruction costs its issuing wave
+// 60-180 cycles; in the kernel above that time is taken from the matrix pipe (both waves of a SIMD issue their
+// 8 pieces right after the barrier: no-DMA ablation 1460 vs 1150 TFLOP/s).  768 threads = 3 waves per SIMD,
+// so a wave has 168 registers: 128 accumulators + one fragment set.
+template <typename T, int ACT>
+__global__ __launch_bounds__(768) void gemm256ws_kernel(GemmParams p) {
+  typedef typename Traits<T>::v8 v8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+
+  const unsigned nwg = p.tiles_m * p.tiles_n;
+  const unsigned lin = xcd_remap(blockIdx.x, nwg);
+  const unsigned GM = 4;
+  const unsigned per_group = GM * p.tiles_n;
+  const unsigned group = lin / per_group, first_m = group * GM;
+  const unsigned gsz = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+  const long m0 = (long)(first_m + (lin % per_group) % gsz) * G2_BM;
+  const long n0 = (long)((lin % per_group) / gsz) * G2_BN;
+  const long bz = blockIdx.y;
+  const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
+  const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
+  T* Cp = reinterpret_cast<T*>(p.c) + (size_t)bz * p.c_bs;
+  const long nk = p.k / G2_BK;
+
+  if (wv >= 8) {
+    // ---- DMA wave L: LDS regions (1 KB = 8 rows of a stage) L*16 .. L*16+15; rows 0..255 are A, 256..511 W
+    const int L = wv - 8;
+    const T* src[16];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nl = j * 32 + g * 8 + hi * 4;         // local n of this lane's 4 values
-      float b[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long n = n0 + wn * 64 + nl + r;
-        b[r] = (p.bias != nullptr && n < p.n) ? p.bias[n] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = i * 32 + l31;
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act_t<ACT>(acc[i][j][g * 4 + r] * p.alpha + b[r], p.act, p.act_param));
-        *reinterpret_cast<v4*>(outs + row * 128 + ((((nl >> 3)) ^ (row & 7)) << 4) + ((nl & 4) << 1)) = o;
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int row = (L * 16 + i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      if (row < G2_BM) src[i] = (m0 + row < p.m) ? A + (size_t)(m0 + row) * p.lda + c * 8 : nullptr;
+      else src[i] = (n0 + row - G2_BM < p.n) ? W + (size_t)(n0 + row - G2_BM) * p.ldw + c * 8 : nullptr;
     }
-  // a wave only re-reads its own region: no workgroup barrier needed, just its own LDS writes
-#ifdef MTX_EMU
-  __syncthreads();
-#else
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto issue = [&](int stage, long k0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const void* g = src[i] ? (const void*)(src[i] + k0) : (const void*)g_zero16;
+        glds16(g, smem + stage * G2_STAGE + (L * 16 + i) * 1024);
+      }
+    };
+    issue(0, 0);
+    for (long kt = 0; kt < nk; ++kt) {
+      MTX_WAIT_VMEM();                         // tile kt has landed (this wave's part)
+      G2_BAR();                                // barrier kt: everyone's part landed; stage (kt+1)&1 is free again
+      if (kt + 1 < nk) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
+    }
+    __syncthreads();                           // matches the MFMA waves' barrier before the epilogue
+    return;
+  }
+
+  const int wm = wv >> 2, wn = wv & 3;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int aoff[4], woff[2];                        // byte offset of this lane's fragment row, k-step 0, hi-half folded in
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + l31; aoff[i] = r * 128 + ((hi ^ ((r >> 1) & 1)) << 4); }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int r = G2_BM + wn * 64 + j * 32 + l31; woff[j] = r * 128 + ((hi ^ ((r >> 1) & 1)) << 4); }
+  // chunk (2*ks + hi) ^ ((r>>1)&7) = ((ks ^ ((r>>2)&3)) << 1) | (hi ^ ((r>>1)&1)): the ks-dependent part is the same
+  // for all rows of a lane's fragments up to bits 2..3 of r, i.e. of l31 (row bases are multiples of 32)
+  const int kx = (l31 >> 2) & 3;
+  for (long kt = 0; kt < nk; ++kt) {
+    G2_BAR();                                  // barrier kt (the DMA waves waited for tile kt before arriving)
+    const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ko = (ks ^ kx) << 5;
+      v8 af[4], wf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + woff[j] + ko);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + aoff[i] + ko);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+    }
+#ifndef MTX_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-  const T* G = reinterpret_cast<const T*>(p.gate);
-  const T* R = reinterpret_cast<const T*>(p.res);
-  const int oc = lane & 7;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 8 + (lane >> 3);
-    const long m = m0 + wm * 128 + row, n = n0 + wn * 64 + oc * 8;
-    if (m >= p.m || n >= p.n) continue;
-    u32x4 raw = *reinterpret_cast<const u32x4*>(outs + row * 128 + ((oc ^ (row & 7)) << 4));
-    if (G != nullptr || R != nullptr) {
-      float f[8];
-      unpack8<T>(raw, f);
-      if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + (size_t)(m / p.gate_rows_per) * p.ldgate + n), g8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
-      if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)bz * p.res_bs + (size_t)m * p.ldres + n), r8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += r8[e]; }
-      raw = pack8<T>(f);
-    }
-    *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = raw;
+  }
+  __syncthreads();
+  gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
+}
+
+template <typename T>
+static void launch_gemm256ws(const GemmParams& p, dim3 grid, void* stream) {
+  switch (p.act) {
+    case MTX_ACT_NONE: MTX_LAUNCH((gemm256ws_kernel<T, MTX_ACT_NONE>), grid, dim3(768), 0, stream, p); break;
+    case MTX_ACT_SILU: MTX_LAUNCH((gemm256ws_kernel<T, MTX_ACT_SILU>), grid, dim3(768), 0, stream, p); break;
+    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256ws_kernel<T, MTX_ACT_GELU_TANH>), grid, dim3(768), 0, stream, p); break;
+    default: MTX_LAUNCH((gemm256ws_kernel<T, -1>), grid, dim3(768), 0, stream, p); break;
   }
 }
 
@@ -403,9 +527,13 @@ static void launch_gemm256_pp(const GemmParams& p, dim3 grid, void* stream) {
 }
 template <typename T>
 static void launch_gemm256(const GemmParams& p, dim3 grid, void* stream) {
-  const char* e = getenv("MTX_GEMM256_SCHED");          // A/B switch: "lockstep" selects the one-barrier-per-tile loop
-  if (e && e[0] == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
-  else launch_gemm256_pp<T, true>(p, grid, stream);
+  const char* e = getenv("MTX_GEMM256_SCHED");          // A/B switch: "lockstep" / "pingpong" select the 8-wave loops, "ws" the wave-specialised one; default by K
+  // measured on MI355X (tools/bench_kernels.py ab): ping-pong wins by 3-5 % up to K = 4096, the one-barrier loop by
+  // 5-8 % on long K; the wave-specialised variant is DMA-wave-bound (16 pieces per wave per tile) and 10-15 % behind
+  const char mode = e ? e[0] : (p.k <= 4096 ? 'p' : 'l');
+  if (mode == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
+  else if (mode == 'p') launch_gemm256_pp<T, true>(p, grid, stream);
+  else launch_gemm256ws<T>(p, grid, stream);
 }
 
 int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
@@ -423,6 +551,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.gate_rows_per = a->gate_rows_per > 0 ? a->gate_rows_per : 1;
   p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;
+  p.abl = getenv("MTX_GEMM_ABL") ? atoi(getenv("MTX_GEMM_ABL")) : 0;
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;

@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 ARGS="${@:-gemm 8192 8192 8192 attn 8652}"
-(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc" -o k -- python "$GRAFT_REPO_ROOT/tools/bench_kernels.py" $ARGS > "$GRAFT_REPO_ROOT/gpurun_out/pmc/log.txt" 2>&1)
+(cd /tmp && rocprofv3 --pmc ${PMC:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE} --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc" -o k -- python "$GRAFT_REPO_ROOT/tools/bench_kernels.py" $ARGS > "$GRAFT_REPO_ROOT/gpurun_out/pmc/log.txt" 2>&1)
 tail -3 gpurun_out/pmc/log.txt
 python - <<'PY'
 import csv, glob, collections
