@@ -251,10 +251,28 @@ def main():
             tfs = fl["attention_per_layer"] / ms / 1e9
             n_attn = len(flux.transformer.blocks) + len(flux.transformer.singles)
             result["roofline"] = {
-                "kernel": f"attn_kernel<bf16, d=128> 24 heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)",
+                "kernel": f"attn_mma32_kernel<bf16, 128> 24 heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)",
                 "bound": "mfma", "achieved": tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS,
                 "traffic": None, "avg_launch_ms": ms, "launches_per_page": n_attn * args.inpaint_steps * args.regions,
                 "algorithmic_flops_per_launch": fl["attention_per_layer"],
+            }
+            # the other MFMA-bound kernel: every 256-tile GEMM launch of one denoising step, timed one by one
+            D = flux.transformer.cfg["d"]
+            t_img = fl["tokens"] - t_txt
+            shapes = {"qkv": (3 * D, D), "proj_mlp": (4 * D, D), "proj_out": (D, 5 * D), "to_out": (D, D), "ff1": (4 * D, D), "ff2": (D, 4 * D)}
+            g_ms = g_fl = 0.0
+            g_n = 0
+            for i_, lab in enumerate(plan.labels):
+                blk, _, name = lab.partition(".")
+                if name in shapes and blk[:3] in ("sgl", "dbl"):
+                    rows = fl["tokens"] if blk.startswith("sgl") else t_img
+                    n_, k_ = shapes[name]
+                    g_ms += plan.time_range(i_, i_, 2); g_fl += 2.0 * rows * n_ * k_; g_n += 1
+            result["roofline_gemm"] = {
+                "kernel": "gemm256_kernel<bf16> (256x256x64 LDS-DMA tiles), image/joint-stream linears of one MMDiT step",
+                "bound": "mfma", "achieved": g_fl / g_ms / 1e9, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": g_fl / g_ms / 1e9 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": g_ms / g_n,
+                "launches_per_page": g_n * args.inpaint_steps * args.regions, "algorithmic_flops_per_launch": g_fl / g_n,
             }
         if upscaler is not None:
             # ---- the HBM-bound kernel the north star names: RCAN 3x3 conv 64->64 at page resolution -------
