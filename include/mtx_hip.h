@@ -216,6 +216,31 @@ typedef struct mtx_yolo_decode_args {
   int32_t cls_off, mc_off;       /* channel offsets of the class / mask-coefficient slices (0 -> packed) */
 } mtx_yolo_decode_args;
 
+/* ---- bubble cleaning, pixel half (replaces the cv2 chain of reference core/image/cleaning.py:296-337 ------
+ * `process_single_bubble`: dilate(ellipse) -> threshold [Otsu] -> distanceTransform(DIST_L2, 5) >= shrink ->
+ * erode(ellipse), and :155-207 `_build_adaptive_shrink_mask`) for all N bubbles of a page at once, each on
+ * its own crop rois[i] = (x0, y0, w, h) (the dilated mask's box + 2 px, clipped to the page).  Planes hold
+ * the crops back to back (bubble i starts at byte offsets[i]); values are 0 / 255 like the reference's
+ * masks.  stats[i] = { hist[256] of the thresholding image over the ROI, sum and count of grey under the
+ * base mask, is_black, threshold used }.  The chamfer distance is 16.16 fixed point (weights 65536, 91750,
+ * 143976) relaxed `sweeps` (>= ceil(shrink)) times: exact for every distance below the shrink radius.   */
+typedef struct mtx_clean_args {
+  const void* page_bgr;                 /* u8 [H][W][3] */
+  const void* masks;                    /* u8 [N][H][W], nonzero = inside the bubble */
+  const int32_t* rois;                  /* [N][4] */
+  const int64_t* offsets;               /* [N] */
+  void* base; void* roi; void* eroded; void* thresholded; void* shrunk;     /* u8 planes (out) */
+  int32_t* dist_a; int32_t* dist_b;     /* i32 planes (scratch) */
+  int32_t* stats;                       /* [N][260] (out; zeroed by the call) */
+  const int32_t* zones;                 /* [N][max_zones][4] junction zones x1,y1,x2,y2 (page coords), or NULL */
+  int32_t n, page_h, page_w, max_zones;
+  int32_t dil_r, ero_r;                 /* half heights of the two elliptical structuring elements */
+  int8_t dil_dx[64], ero_dx[64];        /* half widths of their rows dy = -r .. r (index dy + r) */
+  int32_t threshold, use_otsu;
+  int32_t shrink_fixed, junction_fixed; /* ceil(radius * 65536) */
+  int32_t sweeps, max_pixels;           /* max_pixels = largest crop area */
+} mtx_clean_args;
+
 typedef enum mtx_op_kind {
   MTX_OP_CONV2D = 1, MTX_OP_GEMM = 2, MTX_OP_ATTN = 3, MTX_OP_NORM = 4, MTX_OP_GROUPNORM = 5,
   MTX_OP_EW = 6, MTX_OP_CA = 7, MTX_OP_IMG = 8, MTX_OP_RESIZE_THRESH = 9, MTX_OP_MEMSET = 10,
@@ -254,6 +279,12 @@ MTX_API int mtx_resize_threshold(const mtx_resize_thresh_args* a, void* stream);
 MTX_API int mtx_mask_select(const mtx_mask_select_args* a, void* stream);
 MTX_API int mtx_preprocess(const mtx_preproc_args* a, void* stream);
 MTX_API int mtx_yolo_decode(const mtx_yolo_decode_args* a, void* stream);
+MTX_API int mtx_bubble_clean(const mtx_clean_args* a, void* stream);
+/* contour half of the same chain, host side on one crop (cleaning.py:340-386): external contours of the
+ * thresholded crop -> area / centroid filter -> filled union -> largest blob -> final mask + bounding box.
+ * Returns the number of accepted text fragments (0 = nothing to clean).                                */
+MTX_API int mtx_host_text_mask(const uint8_t* thr, const uint8_t* eroded, int w, int h, int ox, int oy, int page_w, int page_h,
+                               double min_area, uint8_t* final_mask, int* bbox);
 
 /* ---- plans: a network forward as one native call ----------------------------------------- */
 MTX_API int mtx_plan_create(const mtx_op* ops, int n_ops, void** plan);

@@ -34,3 +34,29 @@ def scale_kernel(kernel: Tuple[int, int], scale: Optional[float], *, minimum: in
         return max(minimum, d)
 
     return (one(kernel[0]), one(kernel[1]))
+
+
+def scale_scalar(value: float, scale: Optional[float], *, minimum: Optional[float] = None, maximum: Optional[float] = None) -> float:
+    """value * scale, clamped (reference core/scaling.py:18-31; a non-positive / missing scale counts as 1)."""
+    s = 1.0 if (scale is None or scale <= 0) else float(scale)
+    v = value * s
+    if minimum is not None:
+        v = max(minimum, v)
+    if maximum is not None:
+        v = min(maximum, v)
+    return v
+
+
+def scale_length(value: float, scale: Optional[float], *, minimum: Optional[float] = 1.0, maximum: Optional[float] = None) -> int:
+    return max(1, int(round(scale_scalar(value, scale, minimum=minimum, maximum=maximum))))
+
+
+def scale_area(value: float, scale: Optional[float], *, minimum: Optional[float] = 1.0, maximum: Optional[float] = None) -> int:
+    """area-like quantities scale with scale**2 (reference core/scaling.py:49-62)"""
+    s = 1.0 if (scale is None or scale <= 0) else float(scale)
+    v = value * (s * s)
+    if minimum is not None:
+        v = max(minimum, v)
+    if maximum is not None:
+        v = min(maximum, v)
+    return max(1, int(round(v)))

@@ -24,6 +24,7 @@ int resize_thresh_launch(const mtx_resize_thresh_args*, void*, const char**);
 int mask_select_launch(const mtx_mask_select_args*, void*, const char**);
 int preproc_launch(const mtx_preproc_args*, void*, const char**);
 int yolo_decode_launch(const mtx_yolo_decode_args*, void*, const char**);
+int clean_launch(const mtx_clean_args*, void*, const char**);
 
 static thread_local std::string g_err;
 
@@ -98,6 +99,7 @@ size_t mtx_abi_sizeof(int kind) {
     case MTX_OP_MASK_SELECT: return sizeof(mtx_mask_select_args);
     case MTX_OP_PREPROC: return sizeof(mtx_preproc_args);
     case MTX_OP_YOLO_DECODE: return sizeof(mtx_yolo_decode_args);
+    case 100: return sizeof(mtx_clean_args);       /* op-level only (not a plan op) */
     default: return 0;
   }
 }
@@ -156,6 +158,7 @@ MTX_OP_ENTRY(mtx_resize_threshold, mtx_resize_thresh_args, resize_thresh_launch)
 MTX_OP_ENTRY(mtx_mask_select, mtx_mask_select_args, mask_select_launch)
 MTX_OP_ENTRY(mtx_preprocess, mtx_preproc_args, preproc_launch)
 MTX_OP_ENTRY(mtx_yolo_decode, mtx_yolo_decode_args, yolo_decode_launch)
+MTX_OP_ENTRY(mtx_bubble_clean, mtx_clean_args, clean_launch)
 
 int mtx_conv2d_tiles(const mtx_conv2d_args* a) {
   if (!a) return fail(MTX_ERR_INVALID, "mtx_conv2d_tiles: null args");

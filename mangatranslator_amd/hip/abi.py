@@ -104,6 +104,19 @@ class MemsetArgs(C.Structure):
     _fields_ = [("ptr", vp), ("bytes", i64), ("value", i32)]
 
 
+class CleanArgs(C.Structure):
+    _fields_ = [("page_bgr", vp), ("masks", vp), ("rois", vp), ("offsets", vp),
+                ("base", vp), ("roi", vp), ("eroded", vp), ("thresholded", vp), ("shrunk", vp),
+                ("dist_a", vp), ("dist_b", vp), ("stats", vp), ("zones", vp),
+                ("n", i32), ("page_h", i32), ("page_w", i32), ("max_zones", i32),
+                ("dil_r", i32), ("ero_r", i32), ("dil_dx", C.c_int8 * 64), ("ero_dx", C.c_int8 * 64),
+                ("threshold", i32), ("use_otsu", i32), ("shrink_fixed", i32), ("junction_fixed", i32),
+                ("sweeps", i32), ("max_pixels", i32)]
+
+
+CLEAN_ARGS_KIND = 100      # mtx_abi_sizeof() key of the op-level-only struct
+
+
 class _OpUnion(C.Union):
     _fields_ = [("conv", ConvArgs), ("gemm", GemmArgs), ("attn", AttnArgs), ("norm", NormArgs),
                 ("gn", GroupNormArgs), ("ew", EwArgs), ("ca", CaArgs), ("img", ImgArgs),
@@ -127,7 +140,7 @@ EXPORTS = [
     "mtx_abi_version", "mtx_abi_sizeof", "mtx_last_error", "mtx_init", "mtx_device_info",
     "mtx_conv2d", "mtx_conv2d_tiles", "mtx_gemm", "mtx_attention", "mtx_norm", "mtx_groupnorm",
     "mtx_elementwise", "mtx_channel_attention", "mtx_image_convert", "mtx_resize_threshold",
-    "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode",
+    "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode", "mtx_bubble_clean", "mtx_host_text_mask",
     "mtx_plan_create", "mtx_plan_run", "mtx_plan_run_graph", "mtx_plan_num_ops",
     "mtx_plan_run_range", "mtx_plan_destroy", "mtx_plan_time", "mtx_plan_time_range",
 ]

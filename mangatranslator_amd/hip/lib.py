@@ -46,8 +46,10 @@ class MtxLibrary:
                         ("mtx_channel_attention", abi.CaArgs), ("mtx_image_convert", abi.ImgArgs),
                         ("mtx_resize_threshold", abi.ResizeThreshArgs),
                         ("mtx_mask_select", abi.MaskSelectArgs), ("mtx_preprocess", abi.PreprocArgs),
-                        ("mtx_yolo_decode", abi.YoloDecodeArgs)):
+                        ("mtx_yolo_decode", abi.YoloDecodeArgs), ("mtx_bubble_clean", abi.CleanArgs)):
             getattr(d, name).argtypes = [C.POINTER(t), C.c_void_p]
+        d.mtx_host_text_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_double, C.c_void_p, C.POINTER(C.c_int)]
         d.mtx_conv2d_tiles.argtypes = [C.POINTER(abi.ConvArgs)]
         d.mtx_plan_create.argtypes = [C.POINTER(abi.Op), C.c_int, C.POINTER(C.c_void_p)]
         d.mtx_plan_run.argtypes = [C.c_void_p, C.c_void_p]
@@ -61,6 +63,8 @@ class MtxLibrary:
             raise ModelError(f"{path}: ABI version {d.mtx_abi_version()} != {abi.ABI_VERSION}")
         if d.mtx_abi_sizeof(0) != C.sizeof(abi.Op):
             raise ModelError("mtx_op layout mismatch between include/mtx_hip.h and hip/abi.py")
+        if d.mtx_abi_sizeof(abi.CLEAN_ARGS_KIND) != C.sizeof(abi.CleanArgs):
+            raise ModelError("mtx_clean_args layout mismatch between include/mtx_hip.h and hip/abi.py")
         for kind, t in abi.ARG_TYPES.items():
             if d.mtx_abi_sizeof(kind) != C.sizeof(t):
                 raise ModelError(f"ABI struct mismatch for op kind {kind}: "
