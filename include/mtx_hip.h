@@ -101,7 +101,12 @@ typedef struct mtx_attn_args {
   int64_t q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
   float scale;
   int32_t dtype;
+  /* optional scratch for the long-sequence kernel: when the workgroup count leaves a partial last wave on the
+   * chip, the left-over query blocks are split over key ranges and merged from fp32 partials kept here
+   * (MTX_ATTN_WORKSPACE_BYTES is always enough); NULL = never split */
+  void* workspace; int64_t workspace_bytes;
 } mtx_attn_args;
+#define MTX_ATTN_WORKSPACE_BYTES (256 * (256 * 128 * 4 + 256 * 2 * 4))
 
 /* row-wise normalisation over the last dim C of [rows, C] (row stride ld):
  *  kind 0 LayerNorm (gamma,beta optional), 1 RMSNorm (gamma optional).

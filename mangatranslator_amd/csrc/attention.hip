@@ -12,6 +12,7 @@
 // (two xor-shuffles across the four 16-lane quads finish a row reduction), and P goes from the
 // S^T accumulators straight into the next MFMA's B operand without touching LDS.
 #include "mtx_device.h"
+#include <cstdlib>
 
 namespace mtx {
 
@@ -21,6 +22,10 @@ struct AttnParams {
   long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
   float scale_log2;
   unsigned qblocks;
+  // key-split tail of the long-sequence kernel: workgroups [0, n_full) cover whole key ranges; the remaining query
+  // blocks are cut into `split` key ranges each and merged from the partials (unnormalised O^T, running max, sum)
+  unsigned n_full, split;
+  float* part_o; float* part_ml;
 };
 
 constexpr int AT_KV = 64;      // keys per tile
@@ -345,7 +350,9 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+  unsigned vb, part = 0, nparts = 1;
+  if (blockIdx.x < p.n_full) vb = xcd_remap(blockIdx.x, p.n_full);
+  else { const unsigned i = blockIdx.x - p.n_full; vb = p.n_full + i / p.split; part = i % p.split; nparts = p.split; }
   const long bh = vb / p.qblocks, qb = vb % p.qblocks;
   const long b = bh / p.heads, h = bh % p.heads;
   const long q0 = qb * AB_QB + wv * 32;
@@ -422,12 +429,13 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
       vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
   }
 
-  const long ntiles = (p.sk + AB_KV - 1) / AB_KV;
-  const long kv_last = p.sk - (ntiles - 1) * AB_KV;     // valid keys in the last tile (1..64)
-  load_tile(0);
+  const long ntiles_all = (p.sk + AB_KV - 1) / AB_KV;
+  const long t_begin = part * ntiles_all / nparts, ntiles = (part + 1) * ntiles_all / nparts;    // this workgroup's key tiles
+  const long kv_last = ntiles == ntiles_all ? p.sk - (ntiles_all - 1) * AB_KV : AB_KV;     // valid keys in its last tile
+  load_tile(t_begin);
   store_tile(0);
   __syncthreads();
-  long t = 0;
+  long t = t_begin;
   // full tiles, two per iteration so the LDS stage is a compile-time constant
   for (; t + 2 < ntiles; t += 2) {
     load_tile(t + 1);
@@ -452,6 +460,23 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
     else attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
   }
 
+  if (nparts > 1) {
+    // ---- key-split tail: leave the unnormalised O^T (fp32), the row maximum and the row sum for the merge kernel
+    const unsigned slot = blockIdx.x - p.n_full;
+    const int row = wv * 32 + l31;
+    float* PO = p.part_o + ((size_t)slot * AB_QB + row) * DP;
+    const float lrow = half_sum(lsum);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {oacc[d][g * 4 + 0], oacc[d][g * 4 + 1], oacc[d][g * 4 + 2], oacc[d][g * 4 + 3]};
+        *reinterpret_cast<f32x4*>(PO + d * 32 + g * 8 + hi * 4) = o;
+      }
+    if (hi == 0) { p.part_ml[((size_t)slot * AB_QB + row) * 2] = m_raw; p.part_ml[((size_t)slot * AB_QB + row) * 2 + 1] = lrow; }
+    return;
+  }
+
   // ---- finish: the two lane halves of a row add their partial sums; 4 consecutive d per store -----------
   const float l = half_sum(lsum);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -469,13 +494,290 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   }
 }
 
+// =====================================================================================================
+// Software-pipelined variant of the long-sequence kernel: the S^T MFMAs of tile t+1 are issued together with
+// the softmax VALU work of tile t (two score accumulators), so inside ONE wave the matrix pipe works while the
+// exponentials are computed; K/V tiles arrive by LDS-DMA (buffer_load ... lds) into a three-stage ring, which
+// frees the 16 staging registers the second accumulator needs and removes the LDS store pass.
+// Per step:  DMA(t+2) -> [max(t), rare rescale] -> [S^T(t+1) MFMAs || exp/sum/convert(t)] -> PV(t) -> wait, barrier.
+__device__ __forceinline__ void buf_load16_lds(const BufView& b, unsigned voff, unsigned soff, void* lds_wave_base) {
+#ifdef MTX_EMU
+  unsigned char* d = reinterpret_cast<unsigned char*>(lds_wave_base) + emu::lane_id() * 16;
+  if ((unsigned long)voff + soff + 16 <= b.bytes) memcpy(d, b.base + voff + soff, 16); else memset(d, 0, 16);
+#else
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+#endif
+}
+
+template <typename T, int DP, int VS, bool HAS_NEXT, bool RAGGED>
+__device__ __forceinline__ void attn_pipe_step(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
+                                               f32x16 (&scur)[2], f32x16 (&snext)[2], float& m_raw, float& lsum, const float c, const float thr,
+                                               const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  const unsigned char* Kn = smem + ((VS + 1) % 3) * 2 * TILE_B;        // K of tile t+1
+  const unsigned char* Vs = smem + VS * 2 * TILE_B + TILE_B;           // V of tile t
+
+  if (RAGGED) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) scur[kb][r] = -1.0e30f;
+  }
+  float tmax = fmaxf(scur[0][0], scur[1][0]);
+#pragma unroll
+  for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, scur[0][r]), scur[1][r]);
+  tmax = half_max(tmax);
+  if (__any(tmax > m_raw + thr)) {
+    const float m_new = fmaxf(m_raw, tmax);
+    const float alpha = fast_exp2((m_raw - m_new) * c);
+    m_raw = m_new;
+    lsum *= alpha;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+  }
+
+  // ---- S^T(t+1) = K Q^T on the matrix pipe while the VALU turns scores(t) into probabilities ----------------
+  if (HAS_NEXT) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const v8 kf = *reinterpret_cast<const v8*>(Kn + kaddr[ks] + kb * 32 * ROWB);
+        snext[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : snext[kb]);
+      }
+  }
+  const float mc = m_raw * c;
+  v8 pb[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = fast_exp2(__builtin_fmaf(scur[kb][r], c, -mc));
+      lsum += pv;
+      pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
+    }
+
+  // ---- O^T += V^T P^T ----------------------------------------------------------------------------------------
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
+        const v4 lo = lds_read_tr16<T>(a);
+        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+        v8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
+        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
+      }
+  if (HAS_NEXT) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) scur[kb] = snext[kb];
+  }
+}
+
+template <typename T, int DP>
+__global__ __launch_bounds__(512) void attn_pipe_kernel(AttnParams p) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  static_assert(DP == 128, "swizzles are written for 256-byte rows");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 2 * TILE_B];      // 96 KB: three K|V stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
+  const long b = bh / p.heads, h = bh % p.heads;
+  const long q0 = qb * AB_QB + wv * 32;
+  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
+
+  v8 qf[KS];
+  {
+    const long qr = q0 + l31;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
+      qf[ks] = __builtin_bit_cast(v8, raw);
+    }
+  }
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_raw = -1.0e30f, lsum = 0.f;
+  const float c = p.scale_log2;
+  const float thr = 8.0f / c;
+
+  // ---- LDS-DMA plan: a wave instruction moves 1 KB = 4 rows of 256 B; wave wv owns rows 8*wv .. 8*wv+7 of K and of V.
+  // lane -> (row = base + lane/16, slot lane%16); the slot holds global chunk slot ^ swizzle(row)
+  const BufView kbv = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
+  const BufView vbv = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
+  unsigned kvoff[2], vvoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wv * 8 + i * 4 + (lane >> 4), slot = lane & 15;
+    kvoff[i] = (unsigned)((row * p.k_ss + ((slot ^ (row & 15)) << 3)) * sizeof(T));
+    vvoff[i] = (unsigned)((row * p.v_ss + ((slot ^ ((row & 3) << 2)) << 3)) * sizeof(T));
+  }
+  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
+  auto dma_tile = [&](long t, int stage) {
+    unsigned char* Ks = smem + stage * 2 * TILE_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      buf_load16_lds(kbv, kvoff[i], (unsigned)t * k_step, Ks + (wv * 8 + i * 4) * ROWB);
+      buf_load16_lds(vbv, vvoff[i], (unsigned)t * v_step, Ks + TILE_B + (wv * 8 + i * 4) * ROWB);
+    }
+  };
+
+  int kaddr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
+  int vaddr[DB];
+  {
+    const int ti = lane & 15, g1 = (lane >> 4) & 1;
+    const int vrow = hi * 4 + (ti >> 2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+      vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
+  }
+
+  const long ntiles = (p.sk + AB_KV - 1) / AB_KV;
+  const long kv_last = p.sk - (ntiles - 1) * AB_KV;
+  dma_tile(0, 0);
+  if (ntiles > 1) dma_tile(1, 1);
+  MTX_WAIT_VMEM();
+  __syncthreads();
+  f32x16 scur[2], snext[2];
+  {  // S^T(0)
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const v8 kf = *reinterpret_cast<const v8*>(smem + kaddr[ks] + kb * 32 * ROWB);
+        scur[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : scur[kb]);
+      }
+  }
+  // tile t lives in stage t % 3; a step needs K(t+1), V(t) resident and puts tile t+2 in flight
+#define ATTN_PIPE_STEP(VS, NEXT, RAG, KV)                                                                           \
+  attn_pipe_step<T, DP, VS, NEXT, RAG>(smem, qf, oacc, scur, snext, m_raw, lsum, c, thr, kaddr, vaddr, KV, hi)
+#define ATTN_PIPE_SYNC() { MTX_WAIT_VMEM(); MTX_LDS_BARRIER(); }
+  long t = 0;
+  for (; t + 3 < ntiles; t += 3) {           // three full steps, every one with a successor
+    dma_tile(t + 2, 2); ATTN_PIPE_STEP(0, true, false, AB_KV); ATTN_PIPE_SYNC();
+    dma_tile(t + 3, 0); ATTN_PIPE_STEP(1, true, false, AB_KV); ATTN_PIPE_SYNC();
+    if (t + 4 < ntiles) dma_tile(t + 4, 1);
+    ATTN_PIPE_STEP(2, true, false, AB_KV); ATTN_PIPE_SYNC();
+  }
+  // 1..3 tiles left (t is a multiple of 3, so tile t sits in stage 0); only the very last may be ragged
+  const long left = ntiles - t;
+  const bool rag = kv_last < AB_KV;
+  if (left == 1) {
+    if (rag) ATTN_PIPE_STEP(0, false, true, kv_last); else ATTN_PIPE_STEP(0, false, false, AB_KV);
+  } else if (left == 2) {
+    ATTN_PIPE_STEP(0, true, false, AB_KV); ATTN_PIPE_SYNC();
+    if (rag) ATTN_PIPE_STEP(1, false, true, kv_last); else ATTN_PIPE_STEP(1, false, false, AB_KV);
+  } else {
+    dma_tile(t + 2, 2); ATTN_PIPE_STEP(0, true, false, AB_KV); ATTN_PIPE_SYNC();
+    ATTN_PIPE_STEP(1, true, false, AB_KV); ATTN_PIPE_SYNC();
+    if (rag) ATTN_PIPE_STEP(2, false, true, kv_last); else ATTN_PIPE_STEP(2, false, false, AB_KV);
+  }
+#undef ATTN_PIPE_STEP
+#undef ATTN_PIPE_SYNC
+
+  const float l = half_sum(lsum);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const long qr = q0 + l31;
+  if (qr < p.sq) {
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[d][g * 4 + r] * inv);
+        *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
+      }
+  }
+}
+
+// merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
+  const unsigned tail = blockIdx.x;                          // tail query block index
+  const unsigned vb = p.n_full + tail;
+  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
+  const long b = bh / p.heads, h = bh % p.heads;
+  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
+  for (int idx = threadIdx.x; idx < AB_QB * (DP / 8); idx += 256) {
+    const int row = idx / (DP / 8), ch = idx % (DP / 8);
+    const long qr = qb * AB_QB + row;
+    if (qr >= p.sq) continue;
+    float M = -1.0e30f;
+    for (unsigned s = 0; s < p.split; ++s) { const float m = p.part_ml[((size_t)(tail * p.split + s) * AB_QB + row) * 2]; M = m > M ? m : M; }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
+    for (unsigned s = 0; s < p.split; ++s) {
+      const size_t base = (size_t)(tail * p.split + s) * AB_QB + row;
+      const float w = fast_exp2((p.part_ml[base * 2] - M) * p.scale_log2);
+      L += w * p.part_ml[base * 2 + 1];
+      const float* po = p.part_o + base * DP + ch * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += w * po[e];
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    *reinterpret_cast<u32x4*>(O + qr * p.o_ss + ch * 8) = pack8<T>(acc);
+  }
+}
+
+static int attn_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+#ifdef MTX_EMU
+    cus = 3;
+#else
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+#endif
+  }
+  return cus;
+}
+
 template <typename T>
 static int launch_attn_t(const AttnParams& p0, void* stream) {
   AttnParams p = p0;
   if (p.d == 128 && p.sq >= 1024 && p.sk >= 256) {       // long sequences: the 8-wave 32x32x16 kernel
     p.qblocks = (unsigned)((p.sq + AB_QB - 1) / AB_QB);
-    const unsigned g = (unsigned)(p.batch * p.heads) * p.qblocks;
+    const unsigned total = (unsigned)(p.batch * p.heads) * p.qblocks;
+    const char* e = getenv("MTX_ATTN_KERNEL");           // A/B switch: "pipe" = the S^T-pipelined LDS-DMA variant (no tail split)
+    if (e && e[0] == 'p') { MTX_LAUNCH((attn_pipe_kernel<T, 128>), dim3(total), dim3(512), 0, stream, p); return MTX_OK; }
+    // one workgroup per CU at a time: a partial last wave of `rem` query blocks leaves most of the chip idle for a
+    // whole block time, so cut those blocks into `split` key ranges (fp32 partials in the caller's scratch) + merge
+    const unsigned cus = (unsigned)attn_num_cus(), rem = total % cus;
+    const unsigned ntiles = (unsigned)((p.sk + AB_KV - 1) / AB_KV);
+    unsigned split = (rem > 0 && total > cus) ? cus / rem : 1;
+    if (split > 8) split = 8;
+    if (split > ntiles / 2) split = ntiles / 2;          // at least two key tiles per part
+    const char* ns = getenv("MTX_ATTN_NOSPLIT");
+    if (split < 2 || p.part_o == nullptr || (ns && ns[0] == '1')) { p.n_full = total; p.split = 1; }
+    else { p.n_full = total - rem; p.split = split; }
+    const unsigned g = p.n_full + (total - p.n_full) * p.split;
     MTX_LAUNCH((attn_mma32_kernel<T, 128>), dim3(g), dim3(512), 0, stream, p);
+    if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3(total - p.n_full), dim3(256), 0, stream, p);
     return MTX_OK;
   }
   const unsigned grid = (unsigned)(p.batch * p.heads) * p.qblocks;
@@ -499,6 +801,11 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   p.v_bs = a->v_bs; p.v_ss = a->v_ss; p.v_hs = a->v_hs; p.o_bs = a->o_bs; p.o_ss = a->o_ss; p.o_hs = a->o_hs;
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
+  p.n_full = 0; p.split = 1; p.part_o = nullptr; p.part_ml = nullptr;
+  if (a->workspace && a->workspace_bytes >= (int64_t)MTX_ATTN_WORKSPACE_BYTES) {      // 256 slots of [256][128] fp32 + [256][2] fp32
+    p.part_o = reinterpret_cast<float*>(a->workspace);
+    p.part_ml = p.part_o + (size_t)256 * AB_QB * 128;
+  }
   if (a->dtype == MTX_BF16) return launch_attn_t<__bf16>(p, stream);
   if (a->dtype == MTX_F16) return launch_attn_t<_Float16>(p, stream);
   *err = "attention: dtype must be bf16 or f16";

@@ -217,6 +217,9 @@ class PlanBuilder:
         a.v_bs, a.v_ss, a.v_hs = v_str
         a.o_bs, a.o_ss, a.o_hs = o_str
         a.scale, a.dtype = scale, self.dtype
+        if d == 128 and sq >= 1024 and sk >= 256:      # long sequences: scratch for the key-split tail (include/mtx_hip.h)
+            ws = self.buf((abi.ATTN_WORKSPACE_BYTES,), torch.uint8)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), abi.ATTN_WORKSPACE_BYTES
         self._add(abi.OP_ATTN, a, label)
         return o
 

@@ -94,7 +94,8 @@ def test_image_convert(hip_lib):
 
 
 @pytest.mark.parametrize("cfg", [dict(batch=1, heads=2, sq=1030, sk=330, d=128), dict(batch=2, heads=3, sq=2048, sk=2048, d=128),
-                                 dict(batch=1, heads=4, sq=4100, sk=4100, d=128, qmul=6.0)])
+                                 dict(batch=1, heads=4, sq=4100, sk=4100, d=128, qmul=6.0), dict(batch=1, heads=2, sq=1500, sk=8652, d=128),
+                                 dict(batch=1, heads=2, sq=1100, sk=320, d=128), dict(batch=1, heads=2, sq=1100, sk=449, d=128)])
 def test_attention_long_sequence_kernel(hip_lib, cfg):
     oc.check_attention(hip_lib, abi.BF16, **cfg)
     oc.check_attention(hip_lib, abi.F16, **cfg)

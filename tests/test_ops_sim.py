@@ -85,6 +85,8 @@ def test_attention_long_sequence_kernel(emu_lib):
     """d = 128, sq >= 1024: the 8-wave 32x32x16 kernel (ragged q block and ragged last key tile)"""
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=2, sq=1030, sk=330, d=128)
     oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=256, d=128, qmul=5.0)
+    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1024, sk=320, d=128)      # 5 tiles: two left after the 3-step loop
+    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1024, sk=448, d=128, qmul=3.0)      # 7 tiles: one left
 
 
 def test_gemm_256_tile_kernel(emu_lib, monkeypatch):

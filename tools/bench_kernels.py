@@ -33,6 +33,24 @@ def gemm(M, N, K, iters=10):
     print(f"gemm M={M} N={N} K={K}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s")
 
 
+def attn_ab(T, heads=24, d=128, rounds=5, iters=20):
+    import os
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    D = heads * d
+    qkv = pb.buf((T, 3 * D), torch.bfloat16); qkv.normal_()
+    o = pb.buf((T, D), torch.bfloat16)
+    pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D)
+    plan = pb.build(); plan.run(); torch.cuda.synchronize()
+    res = {"pipe": [], "mma32": []}
+    for r in range(rounds):
+        for mode in res:
+            os.environ["MTX_ATTN_KERNEL"] = mode
+            plan.time(3)
+            res[mode].append(plan.time(iters))
+    for mode, v in res.items():
+        print(f"attn T={T} {mode}: best {min(v):.3f} ms ({4 * T * T * D / min(v) / 1e9:.0f} TF/s), median {sorted(v)[len(v) // 2]:.3f} ms")
+
+
 def gemm_ab(M, N, K, rounds=5, iters=20):
     """interleaved A/B of the two 256-tile schedules in one process (run-to-run clock drift is ~10 %)"""
     import os
@@ -56,6 +74,8 @@ if __name__ == "__main__":
     while args:
         if args[0] == "attn":
             attn(int(args[1])); args = args[2:]
+        elif args[0] == "attn_ab":
+            attn_ab(int(args[1])); args = args[2:]
         elif args[0] == "ab":
             gemm_ab(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
         else:
