@@ -113,8 +113,8 @@ class FluxDiTHip:
             p = f"transformer_blocks.{i}"
             self.blocks.append(dict(
                 qkv=cat3(p + ".attn", ("to_q", "to_k", "to_v")), cqkv=cat3(p + ".attn", ("add_q_proj", "add_k_proj", "add_v_proj")),
-                nq=g(p + ".attn.norm_q.weight", f32), nk=g(p + ".attn.norm_k.weight", f32),
-                cnq=g(p + ".attn.norm_added_q.weight", f32), cnk=g(p + ".attn.norm_added_k.weight", f32),
+                nqk=torch.cat([g(p + ".attn.norm_q.weight", f32), g(p + ".attn.norm_k.weight", f32)]).contiguous(),
+                cnqk=torch.cat([g(p + ".attn.norm_added_q.weight", f32), g(p + ".attn.norm_added_k.weight", f32)]).contiguous(),
                 out=(g(p + ".attn.to_out.0.weight"), g(p + ".attn.to_out.0.bias", f32)),
                 cout=(g(p + ".attn.to_add_out.weight"), g(p + ".attn.to_add_out.bias", f32)),
                 ff1=(g(p + ".ff.net.0.proj.weight"), g(p + ".ff.net.0.proj.bias", f32)), ff2=(g(p + ".ff.net.2.weight"), g(p + ".ff.net.2.bias", f32)),
@@ -122,7 +122,8 @@ class FluxDiTHip:
                 cff2=(g(p + ".ff_context.net.2.weight"), g(p + ".ff_context.net.2.bias", f32))))
         for i in range(cfg["single_layers"]):
             p = f"single_transformer_blocks.{i}"
-            self.singles.append(dict(qkv=cat3(p + ".attn", ("to_q", "to_k", "to_v")), nq=g(p + ".attn.norm_q.weight", f32), nk=g(p + ".attn.norm_k.weight", f32),
+            self.singles.append(dict(qkv=cat3(p + ".attn", ("to_q", "to_k", "to_v")),
+                                     nqk=torch.cat([g(p + ".attn.norm_q.weight", f32), g(p + ".attn.norm_k.weight", f32)]).contiguous(),
                                      mlp=(g(p + ".proj_mlp.weight"), g(p + ".proj_mlp.bias", f32)), out=(g(p + ".proj_out.weight"), g(p + ".proj_out.bias", f32))))
         self.W = W
         self._plans = {}
@@ -189,13 +190,14 @@ class FluxDiTHip:
             pb.norm(x, nrm, r1 - r0, D, eps=1e-6, kind=0, mod_scale=mod[scale_i], mod_shift=mod[shift_i], rows_per=r1 - r0, ldmod=D,
                     x_off=r0 * D, y_off=r0 * D, label=label)
 
-        def rope(buf, r0, r1, col, gamma, ld, label):
-            v = _rows(buf, r0, r1, col, D)
+        def rope(buf, r0, r1, gamma_qk, ld, label):
+            """per-head RMSNorm + RoPE over the q AND k column slices (2D columns) of rows [r0, r1) in one launch"""
+            v = _rows(buf, r0, r1, 0, 2 * D)
             e = abi.EwArgs()
-            e.a, e.b, e.s, e.y = v.ptr, cs[r0:].data_ptr(), gamma.data_ptr(), v.ptr
-            e.n, e.h, e.w, e.c = 1, 1, r1 - r0, D
+            e.a, e.b, e.s, e.y = v.ptr, cs[r0:].data_ptr(), gamma_qk.data_ptr(), v.ptr
+            e.n, e.h, e.w, e.c = 1, 1, r1 - r0, 2 * D
             e.lda, e.ldb, e.ldy, e.lds = ld, 0, ld, 0
-            e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 0, 1e-6, hd, 0, self.dtype
+            e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 0, 1e-6, hd, H, self.dtype
             pb._add(abi.OP_EW, e, label)
 
         def attention(out_t, out_ld, label):
@@ -209,8 +211,8 @@ class FluxDiTHip:
             adaln(0, t_txt, b0 + 6, b0 + 7, tag + ".norm1_ctx")
             pb.gemm(nrm, B["qkv"][0], t_img, 3 * D, D, bias=B["qkv"][1], out=qkv, a_off=t_txt * D, c_off=t_txt * 3 * D, label=tag + ".qkv")
             pb.gemm(nrm, B["cqkv"][0], t_txt, 3 * D, D, bias=B["cqkv"][1], out=qkv, label=tag + ".qkv_ctx")
-            rope(qkv, t_txt, T, 0, B["nq"], 3 * D, tag + ".rope_q"); rope(qkv, t_txt, T, D, B["nk"], 3 * D, tag + ".rope_k")
-            rope(qkv, 0, t_txt, 0, B["cnq"], 3 * D, tag + ".rope_q_ctx"); rope(qkv, 0, t_txt, D, B["cnk"], 3 * D, tag + ".rope_k_ctx")
+            rope(qkv, t_txt, T, B["nqk"], 3 * D, tag + ".rope_qk")
+            rope(qkv, 0, t_txt, B["cnqk"], 3 * D, tag + ".rope_qk_ctx")
             attention(o, D, tag + ".attn")
             pb.gemm(o, B["out"][0], t_img, D, D, bias=B["out"][1], gate=mod[b0 + 2], gate_rows_per=t_img, res=x, out=x,
                     a_off=t_txt * D, c_off=t_txt * D, res_off=t_txt * D, label=tag + ".to_out")
@@ -229,7 +231,7 @@ class FluxDiTHip:
             adaln(0, T, b0 + 0, b0 + 1, tag + ".norm")
             pb.gemm(nrm, S["qkv"][0], T, 3 * D, D, bias=S["qkv"][1], out=qkv, label=tag + ".qkv")
             pb.gemm(nrm, S["mlp"][0], T, 4 * D, D, bias=S["mlp"][1], act=abi.ACT_GELU_TANH, out=cat, ldc=5 * D, c_off=D, label=tag + ".proj_mlp")
-            rope(qkv, 0, T, 0, S["nq"], 3 * D, tag + ".rope_q"); rope(qkv, 0, T, D, S["nk"], 3 * D, tag + ".rope_k")
+            rope(qkv, 0, T, S["nqk"], 3 * D, tag + ".rope_qk")
             attention(cat, 5 * D, tag + ".attn")
             pb.gemm(cat, S["out"][0], T, D, 5 * D, bias=S["out"][1], gate=mod[b0 + 2], gate_rows_per=T, res=x, out=x, label=tag + ".proj_out")
         f0 = s0 + cfg["single_layers"] * 3

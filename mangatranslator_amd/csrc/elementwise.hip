@@ -175,15 +175,21 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(mtx_ew_args p) {
   const int d = p.i0, heads = (int)(p.c / d), lpr = d / 8;          // lanes per (token, head) row
   const long rows = p.n * p.h * p.w;
   const long total = rows * heads * lpr;
-  const float* gamma = reinterpret_cast<const float*>(p.s);
+  const float* gamma0 = reinterpret_cast<const float*>(p.s);
+  const int split_at = p.i1;          // > 0: heads >= split_at use the second gamma vector (fused q|k slices)
   const float* cs = reinterpret_cast<const float*>(p.b);
   const T* X = reinterpret_cast<const T*>(p.a);
   T* Y = reinterpret_cast<T*>(p.y);
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+  // every lane of a wave runs the same number of iterations (the row reduction is a cross-lane shuffle); lanes past
+  // the end recompute the last element and skip the store
+  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+    const bool live = base + threadIdx.x < total;
+    const long idx = live ? base + threadIdx.x : total - lpr + (threadIdx.x % lpr);
     const int part = (int)(idx % lpr);
     const long hr = idx / lpr;
     const int hd = (int)(hr % heads);
     const long r = hr / heads;
+    const float* gamma = (gamma0 != nullptr && split_at > 0 && hd >= split_at) ? gamma0 + d : gamma0;
     float f[8];
     unpack8<T>(*reinterpret_cast<const u32x4*>(X + r * p.lda + hd * d + part * 8), f);
     float ss = 0.f;
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(mtx_ew_args p) {
       o[2 * k] = x0 * c_[k] - x1 * s_[k];
       o[2 * k + 1] = x1 * c_[k] + x0 * s_[k];
     }
-    *reinterpret_cast<u32x4*>(Y + r * p.ldy + hd * d + part * 8) = pack8<T>(o);
+    if (live) *reinterpret_cast<u32x4*>(Y + r * p.ldy + hd * d + part * 8) = pack8<T>(o);
   }
 }
 

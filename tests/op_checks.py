@@ -272,3 +272,62 @@ def check_image_convert(lib, dtype, seed=0):
     xq = x.to(td).float()
     ref8 = (xq.permute(0, 2, 3, 1).clamp(0, 1) * 255).to(torch.uint8)
     assert (u8.cpu().int() - ref8.int()).abs().max() <= 0
+
+
+def check_qk_norm_rope(lib, dtype, rows, heads, d, fused=True, seed=0):
+    """per-head RMSNorm * gamma then rotary on interleaved pairs, in place on the q|k column slices of a [rows, 3*H*d] buffer"""
+    from mangatranslator_amd.hip.plan import Act
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    D = heads * d
+    qkv = torch.randn(rows, 3 * D, generator=g).to(td)
+    gam = 1.0 + 0.2 * torch.randn(2, d, generator=g)
+    ang = torch.rand(rows, d // 2, generator=g) * 6.28
+    cs = torch.stack([ang.cos(), ang.sin()], 1).contiguous()            # [rows, 2, d/2]
+    ref = qkv.float().clone()
+    for part in range(2):
+        x = ref[:, part * D:(part + 1) * D].reshape(rows, heads, d)
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * gam[part]
+        x = x.to(td).float()                                             # the model rounds before the rotary product
+        x0, x1 = x[..., 0::2], x[..., 1::2]
+        c, s_ = ang.cos()[:, None], ang.sin()[:, None]
+        ref[:, part * D:(part + 1) * D] = torch.stack([x0 * c - x1 * s_, x1 * c + x0 * s_], -1).reshape(rows, D)
+    pb = PlanBuilder(lib, dev, dtype)
+    buf, cst, gm = pb.const(qkv), pb.const(cs), pb.const(gam.reshape(-1).contiguous())
+    def add(col, ncols, gamma_off, split):
+        e = abi.EwArgs()
+        e.a = e.y = buf.data_ptr() + col * buf.element_size()
+        e.b, e.s = cst.data_ptr(), gm.data_ptr() + gamma_off * 4
+        e.n, e.h, e.w, e.c = 1, 1, rows, ncols
+        e.lda = e.ldy = 3 * D
+        e.kind, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 1e-6, d, split, dtype
+        pb._add(abi.OP_EW, e, "rope")
+    if fused:
+        add(0, 2 * D, 0, heads)
+    else:
+        add(0, D, 0, 0); add(D, D, d, 0)
+    _run(pb)
+    err = _relerr(buf.cpu()[:, :2 * D], ref[:, :2 * D])
+    assert err < TOL[dtype], f"qk_norm_rope mismatch rel err {err}"
+    assert torch.equal(buf.cpu()[:, 2 * D:], qkv[:, 2 * D:]), "v slice must stay untouched"
+    return err
+
+
+def check_softmax_transpose(lib, dtype, rows, cols, seed=0):
+    from mangatranslator_amd.hip.plan import Act
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = (torch.randn(rows, cols, generator=g) * 3).to(td)
+    pb = PlanBuilder(lib, dev, dtype)
+    xt = pb.const(x)
+    a = Act(xt.view(1, 1, rows, cols), 1, 1, rows, cols)
+    sm = pb.ew(abi.EW_SOFTMAX_ROWS, a, act_param=0.37)
+    rp = (rows + 7) // 8 * 8
+    tr = pb.buf((cols, rp), td, zero=True)
+    pb.ew(abi.EW_TRANSPOSE, a, out=Act(tr.view(1, 1, cols, rp), 1, 1, cols, rp))
+    _run(pb)
+    ref = torch.softmax(x.float() * 0.37, -1)
+    err = _relerr(sm.t.cpu().view(rows, cols), ref)
+    assert err < TOL[dtype], f"softmax_rows mismatch rel err {err}"
+    assert torch.equal(tr.cpu()[:, :rows], x.t()), "transpose must be exact"
+    return err

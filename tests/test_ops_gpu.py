@@ -106,3 +106,10 @@ def test_attention_long_sequence_kernel(hip_lib, cfg):
 def test_gemm_256_tile_kernel(hip_lib, cfg):
     oc.check_gemm(hip_lib, abi.BF16, **cfg)
     oc.check_gemm(hip_lib, abi.F16, **cfg)
+
+
+def test_flux_prep_kernels(hip_lib):
+    oc.check_qk_norm_rope(hip_lib, abi.BF16, rows=1000, heads=24, d=128)
+    oc.check_qk_norm_rope(hip_lib, abi.F16, rows=333, heads=2, d=64, fused=False)
+    oc.check_softmax_transpose(hip_lib, abi.BF16, rows=1024, cols=1024)
+    oc.check_softmax_transpose(hip_lib, abi.F16, rows=70, cols=136)

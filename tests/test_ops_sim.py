@@ -94,3 +94,10 @@ def test_gemm_256_tile_kernel(emu_lib, monkeypatch):
     monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
     oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
     oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False)
+
+
+def test_flux_prep_kernels(emu_lib):
+    oc.check_qk_norm_rope(emu_lib, abi.BF16, rows=70, heads=3, d=64)
+    oc.check_qk_norm_rope(emu_lib, abi.F16, rows=33, heads=2, d=128, fused=False)
+    oc.check_softmax_transpose(emu_lib, abi.BF16, rows=24, cols=40)
+    oc.check_softmax_transpose(emu_lib, abi.F16, rows=70, cols=136)
