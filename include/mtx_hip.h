@@ -90,7 +90,11 @@ typedef struct mtx_gemm_args {
   int32_t gate_rows_per;
   int32_t act; float act_param; float alpha;   /* acc *= alpha before bias */
   int32_t dtype; int32_t out_dtype;            /* out_dtype: MTX_BF16/F16 (=dtype) or MTX_F32 */
+  /* optional scratch for the 256-tile kernel's stream-K tail (fp32 partial tiles); NULL = never split.
+   * MTX_GEMM_WORKSPACE_BYTES is always enough (2 pieces per CU, up to 320 CUs). */
+  void* workspace; int64_t workspace_bytes;
 } mtx_gemm_args;
+#define MTX_GEMM_WORKSPACE_BYTES (2 * 320 * 256 * 256 * 4)
 
 /* softmax(scale * Q K^T) V, non-causal, one launch for [batch, heads].
  * q: [batch, sq, heads, d] with strides; k,v: [batch, sk, heads, d]; o like q.

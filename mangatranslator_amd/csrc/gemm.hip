@@ -22,6 +22,8 @@ struct GemmParams {
   int gate_rows_per, act; float act_param, alpha;
   int out_f32;
   unsigned tiles_m, tiles_n;
+  // stream-K tail: tiles [n_full, tiles) are cut into `units` equal runs of K iterations; fp32 partials in `part`
+  unsigned n_full, units; float* part;
   int abl;          // MTX_GEMM_ABL: timing ablations of the 256-tile kernel (1 = no DMA after the first tile, 2 = no barrier wait)
 };
 
@@ -260,6 +262,16 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&a
   }
 }
 
+// tile `lin` of the grouped order -> its origin: groups of 4 tile rows x all tile columns, column-major inside a group
+__device__ __forceinline__ void gemm256_tile_origin(const GemmParams& p, unsigned lin, long& m0, long& n0) {
+  const unsigned GM = 4;
+  const unsigned per_group = GM * p.tiles_n;
+  const unsigned group = lin / per_group, first_m = group * GM;
+  const unsigned gsz = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+  m0 = (long)(first_m + (lin % per_group) % gsz) * G2_BM;
+  n0 = (long)((lin % per_group) / gsz) * G2_BN;
+}
+
 #ifdef MTX_EMU
 #define G2_BAR() __syncthreads()
 #else
@@ -277,14 +289,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wm = wv >> 2, wn = wv & 3;
 
-  const unsigned nwg = p.tiles_m * p.tiles_n;
-  const unsigned lin = xcd_remap(blockIdx.x, nwg);
-  const unsigned GM = 4;
-  const unsigned per_group = GM * p.tiles_n;
-  const unsigned group = lin / per_group, first_m = group * GM;
-  const unsigned gsz = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
-  const long m0 = (long)(first_m + (lin % per_group) % gsz) * G2_BM;
-  const long n0 = (long)((lin % per_group) / gsz) * G2_BN;
+  // the launch covers tiles [0, gridDim.x) of the grouped order (all of them, or the whole waves when the rest goes
+  // to the stream-K tail kernel)
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  long m0, n0;
+  gemm256_tile_origin(p, lin, m0, n0);
   const long bz = blockIdx.y;
   const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
   const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
@@ -516,6 +525,152 @@ static void launch_gemm256ws(const GemmParams& p, dim3 grid, void* stream) {
   }
 }
 
+// ---- stream-K tail ------------------------------------------------------------------------------------------
+// With one 256 x 256 tile per CU at a time, `rem = tiles % CUs` left-over tiles keep rem CUs busy for a whole tile
+// time while the others idle (FLUX proj_out: 408 tiles on 256 CUs = 1.59 waves billed as 2).  The left-over tiles'
+// K iterations are instead dealt out evenly: unit u takes iterations [u*I/units, (u+1)*I/units) of the rem * nk
+// iterations, i.e. the end of one tile and possibly the start of the next, and leaves an fp32 partial per piece
+// (slot 2u, 2u+1); the merge kernel adds a tile's pieces in K order and applies the usual epilogue.
+template <typename T>
+__global__ __launch_bounds__(512) void gemm256_tail_kernel(GemmParams p) {
+  typedef typename Traits<T>::v8 v8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wm = wv >> 2, wn = wv & 3;
+  const long nk = p.k / G2_BK;
+  const unsigned tiles = p.tiles_m * p.tiles_n, rem = tiles - p.n_full;
+  const long I = (long)rem * nk;
+  const unsigned u = blockIdx.x;
+  const long it0 = u * I / p.units, it1 = (u + 1) * I / p.units;
+  const T* A = reinterpret_cast<const T*>(p.a);
+  const T* W = reinterpret_cast<const T*>(p.w);
+  int arow[4], wrow[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) arow[i] = wm * 128 + i * 32 + l31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wrow[j] = G2_BM + wn * 64 + j * 32 + l31;
+
+  for (int seg = 0; seg < 2; ++seg) {
+    const long t0 = it0 / nk;                                   // tail tile of the first piece
+    const long kbeg = seg == 0 ? it0 - t0 * nk : 0;
+    const long kend = seg == 0 ? (it1 < (t0 + 1) * nk ? it1 - t0 * nk : nk) : it1 - (t0 + 1) * nk;
+    if (kend <= kbeg) continue;                                 // (wave-uniform)
+    long m0, n0;
+    gemm256_tile_origin(p, (unsigned)(p.n_full + t0 + seg), m0, n0);
+    const T* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (i * 8 + wv) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      if (row < G2_BM) src[i] = (m0 + row < p.m) ? A + (size_t)(m0 + row) * p.lda + c * 8 : nullptr;
+      else src[i] = (n0 + row - G2_BM < p.n) ? W + (size_t)(n0 + row - G2_BM) * p.ldw + c * 8 : nullptr;
+    }
+    auto issue = [&](int stage, long k0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const void* g = src[i] ? (const void*)(src[i] + k0) : (const void*)g_zero16;
+        glds16(g, smem + stage * G2_STAGE + (i * 8 + wv) * 1024);
+      }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();                                            // the previous piece is done with the LDS stages
+    issue((int)(kbeg & 1), kbeg * G2_BK);
+    for (long kt = kbeg; kt < kend; ++kt) {
+      MTX_WAIT_VMEM();
+      __syncthreads();
+      if (kt + 1 < kend) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
+      const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ch = 2 * ks + hi;
+        v8 af[4], wf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+      }
+    }
+    // fp32 partial of this piece: [256 m][256 n], a lane stores 4 consecutive n
+    float* P = p.part + (size_t)(2 * u + seg) * G2_BM * G2_BN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int m = wm * 128 + i * 32 + l31, n = wn * 64 + j * 32 + g * 8 + hi * 4;
+          f32x4 v = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+          *reinterpret_cast<f32x4*>(P + (size_t)m * G2_BN + n) = v;
+        }
+  }
+}
+
+// one workgroup per (tail tile, 32-row band): sum the pieces in K order, epilogue, 16-byte stores
+template <typename T>
+__global__ __launch_bounds__(256) void gemm256_merge_kernel(GemmParams p) {
+  const long nk = p.k / G2_BK;
+  const unsigned tiles = p.tiles_m * p.tiles_n, rem = tiles - p.n_full;
+  const long I = (long)rem * nk;
+  const unsigned ti = blockIdx.x / 8, band = blockIdx.x % 8;
+  long m0, n0;
+  gemm256_tile_origin(p, p.n_full + ti, m0, n0);
+  // units whose run intersects iterations [ti*nk, (ti+1)*nk)
+  long u_lo = (long)ti * nk * p.units / I; if (u_lo > 0) --u_lo;
+  long u_hi = ((long)(ti + 1) * nk * p.units + I - 1) / I + 1; if (u_hi > p.units) u_hi = p.units;
+  T* Cp = reinterpret_cast<T*>(p.c);
+  const T* G = reinterpret_cast<const T*>(p.gate);
+  const T* R = reinterpret_cast<const T*>(p.res);
+  for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+    const int row = band * 32 + idx / 32, ch = idx % 32;
+    const long m = m0 + row, n = n0 + ch * 8;
+    if (m >= p.m || n >= p.n) continue;
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long u = u_lo; u < u_hi; ++u) {
+      const long it0 = u * I / p.units, it1 = (u + 1) * I / p.units;
+      const long t0 = it0 / nk;
+      int seg = -1;
+      if (t0 == ti && it1 > it0) seg = 0;
+      else if (t0 + 1 == ti && it1 > (t0 + 1) * nk) seg = 1;
+      if (seg < 0) continue;
+      const float* P = p.part + ((size_t)(2 * u + seg) * G2_BM + row) * G2_BN + ch * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += P[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = apply_act(f[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f), p.act, p.act_param);
+    if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + (size_t)(m / p.gate_rows_per) * p.ldgate + n), g8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
+    if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)m * p.ldres + n), r8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += r8[e]; }
+    *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = pack8<T>(f);
+  }
+}
+
+static int gemm_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+#ifdef MTX_EMU
+    cus = 3;
+#else
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+#endif
+  }
+  return cus;
+}
+
 template <typename T, bool PP>
 static void launch_gemm256_pp(const GemmParams& p, dim3 grid, void* stream) {
   switch (p.act) {
@@ -526,14 +681,24 @@ static void launch_gemm256_pp(const GemmParams& p, dim3 grid, void* stream) {
   }
 }
 template <typename T>
-static void launch_gemm256(const GemmParams& p, dim3 grid, void* stream) {
+static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream) {
+  GemmParams p = p0;
   const char* e = getenv("MTX_GEMM256_SCHED");          // A/B switch: "lockstep" / "pingpong" select the 8-wave loops, "ws" the wave-specialised one; default by K
   // measured on MI355X (tools/bench_kernels.py ab): ping-pong wins by 3-5 % up to K = 4096, the one-barrier loop by
   // 5-8 % on long K; the wave-specialised variant is DMA-wave-bound (16 pieces per wave per tile) and 10-15 % behind
   const char mode = e ? e[0] : (p.k <= 4096 ? 'p' : 'l');
+  // stream-K tail when the last wave of tiles would fill less than ~70 % of the chip
+  const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
+  const char* ns = getenv("MTX_GEMM_NOSPLIT");
+  const bool tail = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles > cus && rem > 0 && rem * 10 < cus * 7 && p.k / G2_BK >= (getenv("MTX_GEMM256_MIN_TILES") ? 8 : 64) && !(ns && ns[0] == '1');
+  if (tail) { p.n_full = tiles - rem; p.units = cus; grid.x = p.n_full; }
   if (mode == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
   else if (mode == 'p') launch_gemm256_pp<T, true>(p, grid, stream);
   else launch_gemm256ws<T>(p, grid, stream);
+  if (tail) {
+    MTX_LAUNCH((gemm256_tail_kernel<T>), dim3(p.units), dim3(512), 0, stream, p);
+    MTX_LAUNCH((gemm256_merge_kernel<T>), dim3(rem * 8), dim3(256), 0, stream, p);
+  }
 }
 
 int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
@@ -552,6 +717,8 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;
   p.abl = getenv("MTX_GEMM_ABL") ? atoi(getenv("MTX_GEMM_ABL")) : 0;
+  p.n_full = 0; p.units = 0;
+  p.part = (a->workspace && a->workspace_bytes >= (int64_t)MTX_GEMM_WORKSPACE_BYTES) ? reinterpret_cast<float*>(a->workspace) : nullptr;
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;

@@ -33,7 +33,10 @@ class GemmArgs(C.Structure):
                 ("res_bstride", i64),
                 ("gate_rows_per", i32),
                 ("act", i32), ("act_param", f32), ("alpha", f32),
-                ("dtype", i32), ("out_dtype", i32)]
+                ("dtype", i32), ("out_dtype", i32), ("workspace", vp), ("workspace_bytes", i64)]
+
+
+GEMM_WORKSPACE_BYTES = 2 * 320 * 256 * 256 * 4
 
 
 class AttnArgs(C.Structure):

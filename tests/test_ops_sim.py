@@ -101,3 +101,11 @@ def test_flux_prep_kernels(emu_lib):
     oc.check_qk_norm_rope(emu_lib, abi.F16, rows=33, heads=2, d=128, fused=False)
     oc.check_softmax_transpose(emu_lib, abi.BF16, rows=24, cols=40)
     oc.check_softmax_transpose(emu_lib, abi.F16, rows=70, cols=136)
+
+
+def test_gemm_stream_k_tail(emu_lib, monkeypatch):
+    """tiles % CUs != 0 (the simulator reports 3 CUs): the left-over tiles go through the stream-K tail + merge kernels"""
+    monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
+    # 2048 x 1024 -> 8 x 4 = 32 tiles, 32 % 3 = 2 left over, K = 512 -> 8 iterations per tile dealt to 3 units
+    oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
+    oc.check_gemm(emu_lib, abi.F16, m=2048, n=1032, k=576, with_bias=False)       # 40 tiles: one left over, ragged N
