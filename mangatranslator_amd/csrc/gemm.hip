@@ -691,13 +691,18 @@ static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream) {
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
   const char* ns = getenv("MTX_GEMM_NOSPLIT");
   const bool tail = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles > cus && rem > 0 && rem * 10 < cus * 7 && p.k / G2_BK >= (getenv("MTX_GEMM256_MIN_TILES") ? 8 : 64) && !(ns && ns[0] == '1');
-  if (tail) { p.n_full = tiles - rem; p.units = cus; grid.x = p.n_full; }
-  if (mode == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
-  else if (mode == 'p') launch_gemm256_pp<T, true>(p, grid, stream);
-  else launch_gemm256ws<T>(p, grid, stream);
-  if (tail) {
+  // few tiles but a long K (FLUX text-stream ff2: 24 tiles x 192 iterations): stream-K over the whole problem
+  const bool allk = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles * 2 <= cus && p.k / G2_BK >= 128 && !(ns && ns[0] == '1');
+  if (allk) { p.n_full = 0; p.units = cus; }
+  else if (tail) { p.n_full = tiles - rem; p.units = cus; grid.x = p.n_full; }
+  if (!allk) {
+    if (mode == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
+    else if (mode == 'p') launch_gemm256_pp<T, true>(p, grid, stream);
+    else launch_gemm256ws<T>(p, grid, stream);
+  }
+  if (tail || allk) {
     MTX_LAUNCH((gemm256_tail_kernel<T>), dim3(p.units), dim3(512), 0, stream, p);
-    MTX_LAUNCH((gemm256_merge_kernel<T>), dim3(rem * 8), dim3(256), 0, stream, p);
+    MTX_LAUNCH((gemm256_merge_kernel<T>), dim3((tiles - p.n_full) * 8), dim3(256), 0, stream, p);
   }
 }
 
@@ -726,7 +731,8 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;
   const bool vec = a->n % 8 == 0 && a->ldc % 8 == 0 && (!a->res || a->ldres % 8 == 0) && (!a->gate || a->ldgate % 8 == 0) && a->c_bstride % 8 == 0;
   const long min_tiles = getenv("MTX_GEMM256_MIN_TILES") ? atol(getenv("MTX_GEMM256_MIN_TILES")) : 160;   // tests lower it
-  if (!p.out_f32 && a->k % G2_BK == 0 && vec && t256 >= min_tiles && (a->dtype == MTX_BF16 || a->dtype == MTX_F16)) {
+  const bool few_long = a->workspace != nullptr && batch == 1 && t256 * 2 <= gemm_num_cus() && a->k / G2_BK >= 128 && a->m >= 256;
+  if (!p.out_f32 && a->k % G2_BK == 0 && vec && (t256 >= min_tiles || few_long) && (a->dtype == MTX_BF16 || a->dtype == MTX_F16)) {
     p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
     p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
     dim3 g2(p.tiles_m * p.tiles_n, (unsigned)batch);

@@ -204,7 +204,7 @@ class PlanBuilder:
         g.gate_rows_per = gate_rows_per
         g.act, g.act_param, g.alpha = act, 0.0, alpha
         g.dtype, g.out_dtype = self.dtype, (abi.F32 if out_f32 else self.dtype)
-        if m >= 2048 and n >= 1024 and k >= 512 and batch == 1 and not out_f32:
+        if ((m >= 2048 and n >= 1024 and k >= 512) or (m >= 256 and k >= 8192)) and batch == 1 and not out_f32:
             # large problems: one shared scratch per plan for the stream-K tail of the 256-tile kernel (ops of a plan run in order)
             if getattr(self, "_gemm_ws", None) is None:
                 self._gemm_ws = self.buf((abi.GEMM_WORKSPACE_BYTES,), torch.uint8)

@@ -113,3 +113,9 @@ def test_flux_prep_kernels(hip_lib):
     oc.check_qk_norm_rope(hip_lib, abi.F16, rows=333, heads=2, d=64, fused=False)
     oc.check_softmax_transpose(hip_lib, abi.BF16, rows=1024, cols=1024)
     oc.check_softmax_transpose(hip_lib, abi.F16, rows=70, cols=136)
+
+
+def test_gemm_stream_k(hip_lib):
+    oc.check_gemm(hip_lib, abi.BF16, m=512, n=3072, k=12288, with_res=True, with_gate=True)        # whole problem dealt over K
+    oc.check_gemm(hip_lib, abi.BF16, m=8624, n=3072, k=15360, act=abi.ACT_NONE, with_res=True, with_gate=True)   # left-over tiles only
+    oc.check_gemm(hip_lib, abi.F16, m=8112, n=3072, k=12288)
