@@ -717,13 +717,13 @@ __global__ __launch_bounds__(512) void attn_pipe_kernel(AttnParams p) {
 // merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
 template <typename T, int DP>
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
-  const unsigned tail = blockIdx.x;                          // tail query block index
+  const unsigned tail = blockIdx.x / 8, band = blockIdx.x % 8;      // tail query block, 32-row band
   const unsigned vb = p.n_full + tail;
   const long bh = vb / p.qblocks, qb = vb % p.qblocks;
   const long b = bh / p.heads, h = bh % p.heads;
   T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
-  for (int idx = threadIdx.x; idx < AB_QB * (DP / 8); idx += 256) {
-    const int row = idx / (DP / 8), ch = idx % (DP / 8);
+  for (int idx = threadIdx.x; idx < 32 * (DP / 8); idx += 256) {
+    const int row = band * 32 + idx / (DP / 8), ch = idx % (DP / 8);
     const long qr = qb * AB_QB + row;
     if (qr >= p.sq) continue;
     float M = -1.0e30f;
@@ -777,7 +777,7 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     else { p.n_full = total - rem; p.split = split; }
     const unsigned g = p.n_full + (total - p.n_full) * p.split;
     MTX_LAUNCH((attn_mma32_kernel<T, 128>), dim3(g), dim3(512), 0, stream, p);
-    if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3(total - p.n_full), dim3(256), 0, stream, p);
+    if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
     return MTX_OK;
   }
   const unsigned grid = (unsigned)(p.batch * p.heads) * p.qblocks;
