@@ -24,7 +24,7 @@ struct GemmParams {
   unsigned tiles_m, tiles_n;
   // stream-K tail: tiles [n_full, tiles) are cut into `units` equal runs of K iterations; fp32 partials in `part`
   unsigned n_full, units; float* part;
-  int abl;          // MTX_GEMM_ABL: timing ablations of the 256-tile kernel (1 = no DMA after the first tile, 2 = no barrier wait)
+  int abl;          // MTX_GEMM_ABL: timing ablations of the 256-tile kernel (1 = no DMA after the first tile, 2 = DMA burst after the barrier, 3 = two pieces per k-step)
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -338,7 +338,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     for (long kt = 0; kt < nk; ++kt) {
       MTX_WAIT_VMEM();
       __syncthreads();
-      if (kt + 1 < nk && p.abl != 1) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
+      const bool more = kt + 1 < nk;
+      if (more && p.abl == 2) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);      // ablation: all eight pieces right after the barrier
+      const int nst = (int)((kt + 1) & 1);
+      const long nk0 = (kt + 1) * G2_BK;
+      auto piece = [&](int i) {                 // one DMA instruction (1 KB) of the next tile
+        const void* g = src[i] ? (const void*)(src[i] + nk0) : (const void*)g_zero16;
+        glds16(g, smem + nst * G2_STAGE + (i * 8 + wv) * 1024);
+      };
       const unsigned char* st = smem + (kt & 1) * G2_STAGE;
       // fragment reads run one k-step ahead of the MFMAs that consume them (two register sets)
       v8 af[2][4], wf[2][2];
@@ -356,10 +363,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #ifndef MTX_EMU
         __builtin_amdgcn_sched_barrier(0);
 #endif
+        if (p.abl == 3 && more) {               // two pieces ahead of each k-step's MFMAs
+          piece(2 * ks); piece(2 * ks + 1);
+#ifndef MTX_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = Mma32<T>::mfma(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
+            if (p.abl == 0 && more) {           // the next tile's 8 DMA pieces threaded between the MFMAs: 3, 3, 2, 0 per k-step (+3 % vs a burst)
+              const int m = i * 2 + j;
+              const int first = ks == 0 ? 0 : (ks == 1 ? 3 : 6), cnt = ks < 2 ? 3 : (ks == 2 ? 2 : 0);
+              if (m == 1 && cnt > 0) piece(first);
+              if (m == 3 && cnt > 1) piece(first + 1);
+              if (m == 5 && cnt > 2) piece(first + 2);
+#ifndef MTX_EMU
+              __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+          }
 #ifndef MTX_EMU
         __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -52,6 +52,26 @@ def attn_ab(T, heads=24, d=128, rounds=5, iters=20):
         print(f"attn T={T} {mode}: best {min(v):.3f} ms ({4 * T * T * D / min(v) / 1e9:.0f} TF/s), median {sorted(v)[len(v) // 2]:.3f} ms")
 
 
+def gemm_abl(M, N, K, rounds=4, iters=20):
+    """DMA placement variants of the one-barrier loop (MTX_GEMM_ABL), interleaved in one process"""
+    import os
+    os.environ["MTX_GEMM256_SCHED"] = "lockstep"
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    a = pb.buf((M, K), torch.bfloat16); a.normal_()
+    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
+    pb.gemm(a, w, M, N, K)
+    plan = pb.build(); plan.run(); torch.cuda.synchronize()
+    res = {"0": [], "3": [], "4": []}
+    for r in range(rounds):
+        for mode in res:
+            os.environ["MTX_GEMM_ABL"] = mode
+            plan.time(3)
+            res[mode].append(plan.time(iters))
+    os.environ["MTX_GEMM_ABL"] = "0"
+    for mode, v in res.items():
+        print(f"gemm {M}x{N}x{K} abl={mode}: best {min(v):.3f} ms ({2 * M * N * K / min(v) / 1e9:.0f} TF/s)")
+
+
 def gemm_ab(M, N, K, rounds=5, iters=20):
     """interleaved A/B of the two 256-tile schedules in one process (run-to-run clock drift is ~10 %)"""
     import os
@@ -77,6 +97,8 @@ if __name__ == "__main__":
             attn(int(args[1])); args = args[2:]
         elif args[0] == "attn_ab":
             attn_ab(int(args[1])); args = args[2:]
+        elif args[0] == "abl":
+            gemm_abl(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
         elif args[0] == "ab":
             gemm_ab(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
         else:
