@@ -94,6 +94,7 @@ def test_gemm_256_tile_kernel(emu_lib, monkeypatch):
     monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
     oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
     oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False)
+    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=4160, with_res=True)          # K > 4096: the one-barrier loop with threaded DMA
 
 
 def test_flux_prep_kernels(emu_lib):
