@@ -714,6 +714,228 @@ __global__ __launch_bounds__(512) void attn_pipe_kernel(AttnParams p) {
   }
 }
 
+// =====================================================================================================
+// One-wave-per-SIMD variant: 4 waves x 64 query rows (two 32-row blocks A, B per wave), up to 512 registers per lane.
+// Every K / V fragment read from LDS feeds two MFMAs (halves the LDS traffic per FLOP) and the straight-line step
+//   S^T(t+1) for A and B  ||  softmax A(t) -> PV A(t)  ||  softmax B(t) -> PV B(t)
+// gives the in-order wave independent matrix and VALU work to interleave without a partner wave.
+template <typename T, int DP, int VS, bool HAS_NEXT, bool RAGGED>
+__device__ __forceinline__ void attn_w64_step(unsigned char* smem, const typename Traits<T>::v8 (&qf)[2][DP / 16], f32x16 (&oacc)[2][DP / 32],
+                                              f32x16 (&scur)[2][2], f32x16 (&snext)[2][2], float (&m_raw)[2], float (&lsum)[2], const float c, const float thr,
+                                              const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  const unsigned char* Kn = smem + ((VS + 1) % 3) * 2 * TILE_B;
+  const unsigned char* Vs = smem + VS * 2 * TILE_B + TILE_B;
+
+  float mc[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    if (RAGGED) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) scur[f][kb][r] = -1.0e30f;
+    }
+    float tmax = fmaxf(scur[f][0][0], scur[f][1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, scur[f][0][r]), scur[f][1][r]);
+    tmax = half_max(tmax);
+    if (__any(tmax > m_raw[f] + thr)) {
+      const float m_new = fmaxf(m_raw[f], tmax);
+      const float alpha = fast_exp2((m_raw[f] - m_new) * c);
+      m_raw[f] = m_new;
+      lsum[f] *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[f][d][r] *= alpha;
+    }
+    mc[f] = m_raw[f] * c;
+  }
+
+  if (HAS_NEXT) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const v8 kf = *reinterpret_cast<const v8*>(Kn + kaddr[ks] + kb * 32 * ROWB);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          if (ks == 0) Mma32Pinned<T>::set_vgpr(snext[f][kb], kf, qf[f][ks]); else Mma32Pinned<T>::acc_vgpr(snext[f][kb], kf, qf[f][ks]);
+        }
+      }
+  }
+  v8 pb[2][2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(__builtin_fmaf(scur[f][kb][r], c, -mc[f]));
+        lsum[f] += pv;
+        pb[f][kb][r >> 3][r & 7] = from_f32<T>(pv);
+      }
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
+        const v4 lo = lds_read_tr16<T>(a);
+        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+        v8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) Mma32Pinned<T>::acc_agpr(oacc[f][d], vf, pb[f][kb][s2]);
+      }
+  if (HAS_NEXT) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) scur[f][kb] = snext[f][kb];
+  }
+}
+
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_w64_kernel(AttnParams p) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  static_assert(DP == 128, "swizzles are written for 256-byte rows");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 2 * TILE_B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
+  const long b = bh / p.heads, h = bh % p.heads;
+  const long q0 = qb * AB_QB + wv * 64;
+  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
+
+  v8 qf[2][KS];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const long qr = q0 + f * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
+      qf[f][ks] = __builtin_bit_cast(v8, raw);
+    }
+  }
+  f32x16 oacc[2][DB];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[f][d][r] = 0.f;
+  float m_raw[2] = {-1.0e30f, -1.0e30f}, lsum[2] = {0.f, 0.f};
+  const float c = p.scale_log2;
+  const float thr = 8.0f / c;
+
+  // LDS-DMA: wave wv owns rows 16*wv .. 16*wv+15 of K and of V (4 pieces of 4 rows each)
+  const BufView kbv = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
+  const BufView vbv = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
+  unsigned kvoff[4], vvoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wv * 16 + i * 4 + (lane >> 4), slot = lane & 15;
+    kvoff[i] = (unsigned)((row * p.k_ss + ((slot ^ (row & 15)) << 3)) * sizeof(T));
+    vvoff[i] = (unsigned)((row * p.v_ss + ((slot ^ ((row & 3) << 2)) << 3)) * sizeof(T));
+  }
+  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
+  auto dma_tile = [&](long t, int stage) {
+    unsigned char* Ks = smem + stage * 2 * TILE_B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      buf_load16_lds(kbv, kvoff[i], (unsigned)t * k_step, Ks + (wv * 16 + i * 4) * ROWB);
+      buf_load16_lds(vbv, vvoff[i], (unsigned)t * v_step, Ks + TILE_B + (wv * 16 + i * 4) * ROWB);
+    }
+  };
+  int kaddr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
+  int vaddr[DB];
+  {
+    const int ti = lane & 15, g1 = (lane >> 4) & 1;
+    const int vrow = hi * 4 + (ti >> 2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+      vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
+  }
+
+  const long ntiles = (p.sk + AB_KV - 1) / AB_KV;
+  const long kv_last = p.sk - (ntiles - 1) * AB_KV;
+  dma_tile(0, 0);
+  if (ntiles > 1) dma_tile(1, 1);
+  MTX_WAIT_VMEM();
+  __syncthreads();
+  f32x16 scur[2][2], snext[2][2];
+  {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const v8 kf = *reinterpret_cast<const v8*>(smem + kaddr[ks] + kb * 32 * ROWB);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          if (ks == 0) Mma32Pinned<T>::set_vgpr(scur[f][kb], kf, qf[f][ks]); else Mma32Pinned<T>::acc_vgpr(scur[f][kb], kf, qf[f][ks]);
+        }
+      }
+  }
+#define ATTN_W64_STEP(VS, NEXT, RAG, KV)                                                                           \
+  attn_w64_step<T, DP, VS, NEXT, RAG>(smem, qf, oacc, scur, snext, m_raw, lsum, c, thr, kaddr, vaddr, KV, hi)
+#define ATTN_W64_SYNC() { MTX_WAIT_VMEM(); MTX_LDS_BARRIER(); }
+  long t = 0;
+  for (; t + 3 < ntiles; t += 3) {
+    dma_tile(t + 2, 2); ATTN_W64_STEP(0, true, false, AB_KV); ATTN_W64_SYNC();
+    dma_tile(t + 3, 0); ATTN_W64_STEP(1, true, false, AB_KV); ATTN_W64_SYNC();
+    if (t + 4 < ntiles) dma_tile(t + 4, 1);
+    ATTN_W64_STEP(2, true, false, AB_KV); ATTN_W64_SYNC();
+  }
+  const long left = ntiles - t;
+  const bool rag = kv_last < AB_KV;
+  if (left == 1) {
+    if (rag) ATTN_W64_STEP(0, false, true, kv_last); else ATTN_W64_STEP(0, false, false, AB_KV);
+  } else if (left == 2) {
+    ATTN_W64_STEP(0, true, false, AB_KV); ATTN_W64_SYNC();
+    if (rag) ATTN_W64_STEP(1, false, true, kv_last); else ATTN_W64_STEP(1, false, false, AB_KV);
+  } else {
+    dma_tile(t + 2, 2); ATTN_W64_STEP(0, true, false, AB_KV); ATTN_W64_SYNC();
+    ATTN_W64_STEP(1, true, false, AB_KV); ATTN_W64_SYNC();
+    if (rag) ATTN_W64_STEP(2, false, true, kv_last); else ATTN_W64_STEP(2, false, false, AB_KV);
+  }
+#undef ATTN_W64_STEP
+#undef ATTN_W64_SYNC
+
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const float l = half_sum(lsum[f]);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const long qr = q0 + f * 32 + l31;
+    if (qr < p.sq) {
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[f][d][g * 4 + r] * inv);
+          *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
+        }
+    }
+  }
+}
+
 // merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
 template <typename T, int DP>
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
@@ -765,6 +987,7 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     const unsigned total = (unsigned)(p.batch * p.heads) * p.qblocks;
     const char* e = getenv("MTX_ATTN_KERNEL");           // A/B switch: "pipe" = the S^T-pipelined LDS-DMA variant (no tail split)
     if (e && e[0] == 'p') { MTX_LAUNCH((attn_pipe_kernel<T, 128>), dim3(total), dim3(512), 0, stream, p); return MTX_OK; }
+    if (e && e[0] == 'w') { MTX_LAUNCH((attn_w64_kernel<T, 128>), dim3(total), dim3(256), 0, stream, p); return MTX_OK; }
     // one workgroup per CU at a time: a partial last wave of `rem` query blocks leaves most of the chip idle for a
     // whole block time, so cut those blocks into `split` key ranges (fp32 partials in the caller's scratch) + merge
     const unsigned cus = (unsigned)attn_num_cus(), rem = total % cus;

@@ -90,6 +90,30 @@ template <> struct Mma32<_Float16> {
   static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
+// 32x32x16 MFMA with the accumulator pinned to a register class: AGPRs for accumulators only the matrix pipe touches
+// (attention O^T), VGPRs for accumulators the VALU reads next (attention S^T) — with 512 registers per lane the
+// compiler otherwise parks S^T in AGPRs and pays a v_accvgpr_read per element.
+template <typename T> struct Mma32Pinned;
+#ifdef MTX_EMU
+template <typename T> struct Mma32Pinned {
+  typedef typename Traits<T>::v8 v8;
+  static __device__ __forceinline__ void acc_agpr(f32x16& c, v8 a, v8 b) { c = Mma32<T>::mfma(a, b, c); }
+  static __device__ __forceinline__ void acc_vgpr(f32x16& c, v8 a, v8 b) { c = Mma32<T>::mfma(a, b, c); }
+  static __device__ __forceinline__ void set_vgpr(f32x16& c, v8 a, v8 b) { const f32x16 z = {0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f}; c = Mma32<T>::mfma(a, b, z); }
+};
+#else
+template <> struct Mma32Pinned<__bf16> {
+  static __device__ __forceinline__ void acc_agpr(f32x16& c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc_vgpr(f32x16& c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void set_vgpr(f32x16& c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b)); }
+};
+template <> struct Mma32Pinned<_Float16> {
+  static __device__ __forceinline__ void acc_agpr(f32x16& c, f16x8 a, f16x8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc_vgpr(f32x16& c, f16x8 a, f16x8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void set_vgpr(f32x16& c, f16x8 a, f16x8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b)); }
+};
+#endif
+
 // LDS transpose read (ds_read_b64_tr_b16): per 16-lane group a 4 x 16 block of 16-bit elements, lane i
 // addresses row i>>2, columns 4*(i&3)..+3 and receives column i (4 rows).
 template <typename T>
