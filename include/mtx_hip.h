@@ -292,6 +292,9 @@ MTX_API int mtx_bubble_clean(const mtx_clean_args* a, void* stream);
 /* contour half of the same chain, host side on one crop (cleaning.py:340-386): external contours of the
  * thresholded crop -> area / centroid filter -> filled union -> largest blob -> final mask + bounding box.
  * Returns the number of accepted text fragments (0 = nothing to clean).                                */
+/* host side: cv2.distanceTransform(src, DIST_L2, 5) on a crop (two-pass 16.16 fixed-point chamfer), used by the
+ * conjoined-bubble partition (reference core/image/detection.py:932-968) */
+MTX_API int mtx_host_chamfer_l2_5x5(const uint8_t* src, int w, int h, float* dist);
 MTX_API int mtx_host_text_mask(const uint8_t* thr, const uint8_t* eroded, int w, int h, int ox, int oy, int page_w, int page_h,
                                double min_area, uint8_t* final_mask, int* bbox);
 

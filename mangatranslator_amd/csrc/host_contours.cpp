@@ -132,6 +132,47 @@ void external_contours(const uint8_t* img, int w, int h, std::vector<Blob>& blob
 
 extern "C" {
 
+// float32 distance to the nearest zero pixel under the 5x5 chamfer metric cv2.distanceTransform(src, DIST_L2, 5)
+// uses: two raster passes over a 16.16 fixed-point image (weights 1, 1.4, 2.1969; outside the image = far).
+// Used on mask crops by the conjoined-bubble partition (reference core/image/detection.py:932-968).
+MTX_API int mtx_host_chamfer_l2_5x5(const uint8_t* src, int w, int h, float* dist) {
+  if (!src || !dist || w < 1 || h < 1) return MTX_ERR_INVALID;
+  const int HV = 65536, DG = 91750, LG = 143976, INIT = 0x1fffffff, B = 2;
+  const int W = w + 2 * B;
+  std::vector<int> t((size_t)W * (h + 2 * B), INIT);
+  auto at = [&](int x, int y) -> int& { return t[(size_t)(y + B) * W + x + B]; };
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      if (src[(size_t)y * w + x] == 0) { at(x, y) = 0; continue; }
+      int m = at(x - 1, y - 2) + LG, v;
+      v = at(x + 1, y - 2) + LG; m = v < m ? v : m;
+      v = at(x - 2, y - 1) + LG; m = v < m ? v : m;
+      v = at(x - 1, y - 1) + DG; m = v < m ? v : m;
+      v = at(x, y - 1) + HV; m = v < m ? v : m;
+      v = at(x + 1, y - 1) + DG; m = v < m ? v : m;
+      v = at(x + 2, y - 1) + LG; m = v < m ? v : m;
+      v = at(x - 1, y) + HV; m = v < m ? v : m;
+      at(x, y) = m;
+    }
+  for (int y = h - 1; y >= 0; --y)
+    for (int x = w - 1; x >= 0; --x) {
+      int m = at(x, y), v;
+      if (m > HV) {
+        v = at(x + 1, y + 2) + LG; m = v < m ? v : m;
+        v = at(x - 1, y + 2) + LG; m = v < m ? v : m;
+        v = at(x + 2, y + 1) + LG; m = v < m ? v : m;
+        v = at(x + 1, y + 1) + DG; m = v < m ? v : m;
+        v = at(x, y + 1) + HV; m = v < m ? v : m;
+        v = at(x - 1, y + 1) + DG; m = v < m ? v : m;
+        v = at(x - 2, y + 1) + LG; m = v < m ? v : m;
+        v = at(x + 1, y) + HV; m = v < m ? v : m;
+        at(x, y) = m;
+      }
+      dist[(size_t)y * w + x] = (float)m * (1.0f / 65536.0f);
+    }
+  return MTX_OK;
+}
+
 // thr / eroded: [h][w] crops (0 / 255) at page offset (ox, oy) of a page_w x page_h page.
 // final_mask: [h][w] out (0 / 255).  bbox: x, y, w, h of the kept text blob in PAGE coordinates.
 // returns the number of text fragments that passed the area + centroid test (0 = nothing to clean), < 0 on error

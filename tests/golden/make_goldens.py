@@ -227,7 +227,75 @@ def gen_harness():
     return dict(names=names, order=order, resolve=res, scale_kernel=kernels)
 
 
+def gen_conjoined():
+    """conjoined-bubble mask partition: core/image/detection.py:971-1035 (_split_conjoined_mask) with everything it calls
+    (:568-579, :582-665, :668-929, :932-968, :317-342, :793-827) and :1075-1260 (_build_segmentation_detections).
+    cv2 is absent here: the ONE cv2 call on this path, cv2.distanceTransform(inv_seed, DIST_L2, 5) at :954, is served by
+    the oracle's restatement (oracle/cleaning_ref.distance_transform_l2_5x5); every other line executed is the reference's."""
+    sys.path.insert(0, str(HERE.parent.parent))
+    from oracle.cleaning_ref import distance_transform_l2_5x5
+    detection.cv2 = types.SimpleNamespace(distanceTransform=lambda img, dt, ms: distance_transform_l2_5x5(np.asarray(img)), DIST_L2=2)
+    H, W = 120, 168
+    yy, xx = np.mgrid[0:H, 0:W]
+    ell = lambda cx, cy, a, b: ((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 <= 1.0
+    scen = []
+    # (parent mask, child boxes, text boxes or None)
+    scen.append((ell(50, 60, 40, 35) | ell(110, 60, 42, 36), [[10.2, 24.7, 92.5, 96.1], [66.4, 22.0, 153.3, 97.9]], None))                      # side by side
+    scen.append((ell(80, 35, 50, 28) | ell(84, 82, 52, 30), [[28.0, 6.0, 132.0, 66.0], [30.5, 48.2, 137.0, 113.0]], None))                       # stacked
+    scen.append((ell(55, 45, 42, 34) | ell(112, 78, 44, 33), [[12.0, 10.0, 99.0, 80.0], [66.0, 44.0, 158.0, 112.0]], None))                      # diagonal, same-sign offsets
+    scen.append((ell(112, 42, 42, 32) | ell(56, 80, 44, 32), [[68.0, 9.0, 156.0, 76.0], [10.0, 46.0, 102.0, 113.0]], None))                      # diagonal, opposite signs
+    scen.append((ell(50, 60, 40, 35) | ell(110, 60, 42, 36), [[10.2, 24.7, 92.5, 96.1], [66.4, 22.0, 153.3, 97.9]],
+                 [[20, 45, 70, 75, 0.9], [22, 47, 60, 70, 0.8], [96, 40, 140, 80, 0.9]]))                                                          # text-safe, nested text box
+    scen.append((ell(50, 60, 40, 35) | ell(110, 60, 42, 36), [[10.2, 24.7, 92.5, 96.1], [66.4, 22.0, 153.3, 97.9]],
+                 [[30, 45, 84, 75, 0.9], [74, 40, 140, 80, 0.9]]))                                                                                  # texts overlap the cut: no feasible offset
+    scen.append((ell(50, 60, 40, 35) | ell(110, 60, 42, 36), [[10.2, 24.7, 92.5, 96.1], [66.4, 22.0, 153.3, 97.9]],
+                 [[60, 50, 100, 70, 0.9], [20, 40, 50, 60, 0.7], [110, 45, 140, 75, 0.7]]))                                                        # one ambiguous text box
+    scen.append((ell(40, 60, 32, 40) | ell(84, 60, 30, 42) | ell(128, 60, 32, 40), [[6.0, 18.0, 70.0, 102.0], [52.0, 16.0, 116.0, 104.0], [96.0, 18.0, 162.0, 102.0]], None))   # three in a row
+    scen.append((ell(50, 60, 40, 35), [[10.0, 24.0, 60.0, 96.0], [120.0, 10.0, 160.0, 40.0]], None))                                             # second child outside the parent: nearest-pixel seed
+    scen.append((np.zeros((H, W), bool), [[10.0, 24.0, 60.0, 96.0], [50.0, 20.0, 120.0, 90.0]], None))                                            # empty parent
+    scen.append((ell(80, 60, 60, 45), [[20.0, 15.0, 140.0, 105.0]], None))                                                                        # single child
+    scen.append((ell(60, 60, 45, 40) | ell(100, 62, 45, 40), [[14.5, 19.5, 105.5, 100.5], [54.5, 21.5, 146.0, 102.5]],
+                 [[25, 50, 55, 70, 0.9], [105, 50, 135, 72, 0.9]]))                                                                                  # text-safe offset far from the midline
+    arrays, meta = {}, []
+    for k, (pm, boxes, texts) in enumerate(scen):
+        tb = [torch.tensor(b, dtype=torch.float32) for b in boxes]
+        tx = np.asarray(texts, np.float32) if texts is not None else None
+        grp = detection._get_group_osb_text_boxes(tx, torch.tensor([0.0, 0.0, float(W), float(H)])) if tx is not None else None
+        out = detection._split_conjoined_mask(pm.astype(np.uint8) * 255, tb, osb_text_boxes=grp)
+        arrays[f"parent_{k}"] = np.packbits(pm)
+        arrays[f"out_{k}"] = np.packbits(np.stack([np.asarray(o) > 0 for o in out]) if out else np.zeros((0, H, W), bool))
+        meta.append(dict(boxes=boxes, texts=texts, n_out=len(out), arrangement=detection._detect_group_arrangement(tb),
+                         group_texts=(np.asarray(grp).tolist() if grp is not None else None),
+                         match=({str(i): np.asarray(v).tolist() for i, v in detection._match_text_boxes_to_bubbles(grp, tb).items()} if grp is not None else None),
+                         rects=[[int(v) for v in np.nonzero(detection._build_rect_mask_from_box(t, H, W).any(0))[0][[0, -1]]] +
+                                [int(v) for v in np.nonzero(detection._build_rect_mask_from_box(t, H, W).any(1))[0][[0, -1]]] for t in tb]))
+    # assembly: one simple bubble with a SAM mask, one simple without (rect fallback), one conjoined pair, one synthetic group
+    pm = ell(50, 60, 40, 35) | ell(110, 60, 42, 36)
+    primary = torch.tensor([[8.0, 20.0, 156.0, 100.0], [20.3, 5.2, 60.8, 30.9], [100.0, 100.0, 150.0, 118.0], [10.0, 100.0, 60.0, 119.0], [40.0, 98.0, 95.0, 119.0]], dtype=torch.float32)
+    secondary = torch.tensor([[10.2, 24.7, 92.5, 96.1], [66.4, 22.0, 153.3, 97.9]], dtype=torch.float32)
+    ns = types.SimpleNamespace
+    pres = ns(boxes=ns(conf=torch.tensor([0.9, 0.8, 0.7, 0.65, 0.6]), cls=torch.tensor([0.0, 0.0, 0.0, 0.0, 0.0]), __len__=None), masks=None)
+    pres.boxes = type("B", (), {"conf": torch.tensor([0.9, 0.8, 0.7, 0.65, 0.6]), "cls": torch.zeros(5), "__len__": lambda self: 5})()
+    sres = ns(names={0: "bubble"})
+    sres.boxes = type("B", (), {"conf": torch.tensor([0.55, 0.45]), "cls": torch.zeros(2), "__len__": lambda self: 2})()
+    model = ns(names={0: "speech_bubble"})
+    sam = [pm.astype(np.uint8) * 255, ell(40, 18, 18, 11).astype(np.uint8) * 255, None, None, None]
+    synth = [dict(parent_mask=(ell(35, 110, 24, 8) | ell(68, 109, 26, 9)).astype(np.uint8) * 255, parent_box=[10.0, 98.0, 95.0, 119.0], member_indices=[3, 4])]
+    dets = detection._build_segmentation_detections(primary, primary, [("primary", i) for i in range(5)], pres, model, secondary,
+                                                    [("secondary", 0), ("secondary", 1)], sres, [1, 2], [(0, [0, 1])], H, W, 0.35,
+                                                    osb_text_boxes_np=None, sam_masks=sam, synthetic_conjoined_groups=synth)
+    arrays["assembly_masks"] = np.packbits(np.stack([np.asarray(d["sam_mask"]) > 0 for d in dets]))
+    arrays["assembly_sam0"], arrays["assembly_sam1"], arrays["assembly_synth"] = np.packbits(sam[0] > 0), np.packbits(sam[1] > 0), np.packbits(synth[0]["parent_mask"] > 0)
+    assembly = dict(primary=primary.tolist(), secondary=secondary.tolist(),
+                    dets=[dict(bbox=list(d["bbox"]), confidence=float(d["confidence"]), cls=d["class"],
+                               neighbors=[list(b) for b in d.get("conjoined_neighbor_bboxes", [])] if "conjoined_neighbor_bboxes" in d else None) for d in dets])
+    return dict(H=H, W=W, scenarios=meta, assembly=assembly), arrays
+
+
 if __name__ == "__main__":
+    cj_meta, cj_arrays = gen_conjoined()
+    json.dump(cj_meta, open(HERE / "conjoined.json", "w"))
+    np.savez_compressed(HERE / "conjoined.npz", **cj_arrays)
     json.dump(gen_boxes(), open(HERE / "box_hygiene.json", "w"))
     json.dump(gen_coordinator(), open(HERE / "batch_coordinator.json", "w"))
     np.savez_compressed(HERE / "batch_coordinator_masks.npz", **COORD_MASKS)
