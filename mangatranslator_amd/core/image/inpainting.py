@@ -53,12 +53,23 @@ def feather_alpha(mask: np.ndarray, blur_radius: int) -> np.ndarray:
     m = mask.astype(bool)
     if blur_radius <= 0:
         return m.astype(np.float32)
-    d_out = distance_transform_edt(~m)
     alpha = np.zeros(m.shape, np.float32)
-    alpha[m] = 1.0
+    rows, cols = np.flatnonzero(m.any(axis=1)), np.flatnonzero(m.any(axis=0))
+    if rows.size == 0:
+        return alpha
+    # the ramp is zero beyond blur_radius of the mask, and every mask pixel lies inside this window, so the
+    # Euclidean transform of the window equals the full-page transform wherever alpha is non-zero
+    g = int(blur_radius) + 2
+    y0, y1 = max(0, int(rows[0]) - g), min(m.shape[0], int(rows[-1]) + 1 + g)
+    x0, x1 = max(0, int(cols[0]) - g), min(m.shape[1], int(cols[-1]) + 1 + g)
+    mw = m[y0:y1, x0:x1]
+    d_out = distance_transform_edt(~mw)
+    aw = np.zeros(mw.shape, np.float32)
+    aw[mw] = 1.0
     ramp = np.clip(1.0 - d_out / blur_radius, 0.0, 1.0)
     outside = d_out > 0
-    alpha[outside] = ramp[outside]
+    aw[outside] = ramp[outside]
+    alpha[y0:y1, x0:x1] = aw
     return alpha
 
 

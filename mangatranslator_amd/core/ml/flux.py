@@ -149,9 +149,14 @@ class FluxDiTHip:
         plan.tin, plan.pooled, plan.mods = tin, pooled, mods
         return plan
 
-    def modulation(self, timestep: float, guidance: float, pooled: torch.Tensor) -> torch.Tensor:
-        """[n_vec, D] bf16 modulation rows for one denoising step (cached per value triple)."""
-        key = (round(float(timestep), 7), round(float(guidance), 5), pooled.data_ptr())
+    def modulation(self, timestep: float, guidance: float, pooled: torch.Tensor, pooled_key=None) -> torch.Tensor:
+        """[n_vec, D] bf16 modulation rows for one denoising step, cached per (timestep, guidance, pooled prompt).
+        `pooled_key` identifies the pooled-prompt CONTENT (callers hash it once per image, not once per step)."""
+        if pooled_key is None:
+            pooled_key = hash(pooled.detach().float().cpu().numpy().tobytes())
+        key = (round(float(timestep), 7), round(float(guidance), 5), pooled_key)
+        if len(self._mod_cache) > 256:          # a few schedules x prompts at most; never grow without bound
+            self._mod_cache.clear()
         if key not in self._mod_cache:
             if self._mod_plan is None:
                 self._mod_plan = self._build_mod_plan()
@@ -424,8 +429,9 @@ class FluxKontextHip:
             plan.lat[plan.t_noise:].copy_(pack(ref).to(dit.tdt))
             sig = flow_sigmas(num_inference_steps, h2 * w2)
             pooled_dev = pooled.to(self.device, dit.tdt)
+            pooled_key = hash(pooled_dev.float().cpu().numpy().tobytes())
             for i in range(num_inference_steps):
-                plan.mod.copy_(dit.modulation(float(sig[i]), float(guidance_scale), pooled_dev))
+                plan.mod.copy_(dit.modulation(float(sig[i]), float(guidance_scale), pooled_dev, pooled_key))
                 plan.lat[: plan.t_noise].copy_(lat.to(dit.tdt))
                 plan.run(graph=self._graph)
                 lat = lat + (float(sig[i + 1]) - float(sig[i])) * plan.vel
