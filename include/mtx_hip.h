@@ -74,6 +74,7 @@ typedef struct mtx_conv2d_args {
   int32_t res_broadcast_n;       /* 1: res has batch 1 and is shared by all n images */
   int32_t pad_mode;              /* 0: pad k/2 on every side; 1: no pad top/left, 1 bottom/right
                                     (diffusers Downsample2D: F.pad(0,1,0,1) + conv k3 s2 p0)     */
+  int32_t act_after_res;     /* 1: y = act(conv(x) + bias + res_scale * res)  (ResNet bottleneck), 0: act before the residual */
 } mtx_conv2d_args;
 
 /* C[M,N] = epilogue(A[M,K] * W[N,K]^T)   A row stride lda, C row stride ldc (elements).
@@ -145,6 +146,7 @@ typedef enum mtx_ew_kind {
                              (output row r takes raster output pixel idx[r]); ldy >= k*k*C       */
   MTX_EW_SOFTMAX_ROWS = 10, /* y[r, :c] = softmax(act_param * a[r, :c]) over rows r < n*h*w (VAE attention) */
   MTX_EW_TRANSPOSE = 11,  /* y[c, r] = a[r, c] for r < h*w rows, c columns (per n; ldy = row stride of y) */
+  MTX_EW_AVGPOOL2 = 13,   /* 2x2 stride-2 average pool, ceil mode, divisor = in-bounds taps (ResNet-vd shortcut) */
   MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
                              i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then
                              rotary on interleaved pairs with b = fp32 [rows][d] cos|sin table laid out as
@@ -250,10 +252,26 @@ typedef struct mtx_clean_args {
   int32_t sweeps, max_pixels;           /* max_pixels = largest crop area */
 } mtx_clean_args;
 
+/* ---- RT-DETR decoder pieces (HF RTDetrV2, reference core/ml/rtdetr_adapter.py:61-113) -------------------------
+ * kind 0  multi-scale deformable attention ("default" method): for query r, head h, the heads*d channels of
+ *         out[r] = sum_p softmax_p(aw[r, h, :])[p] * bilinear(value_level(p)[h], ref[r].xy + off[r, h, p] * ref[r].wh * scale / n_points)
+ *         (grid_sample align_corners = False, zero padding).  value: [sum(H_l*W_l)][heads*d] T; off: [rows][heads*L*P*2] T;
+ *         aw: [rows][heads*L*P] T; ref: fp32 [rows][8] (cx, cy, w, h, ...).
+ * kind 1  reference refinement: ref_out = sigmoid(delta[r, :4] + logit(clamp(ref[r]))) (fp32) and its T copy (8 columns, zero padded)
+ * kind 2  ref_out = sigmoid(x[r, :4]) from fp32 logits x, plus the T copy                                              */
+typedef struct mtx_detr_args {
+  const void* value; const void* off; const void* aw; const float* ref; void* out;     /* kind 0 */
+  const void* delta; float* ref_out; void* ref_t;                                       /* kinds 1, 2 (ref = input) */
+  int32_t kind, rows, heads, d, levels, points;
+  int32_t lh[4], lw[4], lstart[4];
+  int32_t ld_value, ld_off, ld_aw, ld_out, ld_delta;
+  float offset_scale; int32_t dtype;
+} mtx_detr_args;
+
 typedef enum mtx_op_kind {
   MTX_OP_CONV2D = 1, MTX_OP_GEMM = 2, MTX_OP_ATTN = 3, MTX_OP_NORM = 4, MTX_OP_GROUPNORM = 5,
   MTX_OP_EW = 6, MTX_OP_CA = 7, MTX_OP_IMG = 8, MTX_OP_RESIZE_THRESH = 9, MTX_OP_MEMSET = 10,
-  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12, MTX_OP_YOLO_DECODE = 13
+  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12, MTX_OP_YOLO_DECODE = 13, MTX_OP_DETR = 14
 } mtx_op_kind;
 
 typedef struct mtx_memset_args { void* ptr; int64_t bytes; int32_t value; } mtx_memset_args;
@@ -263,7 +281,7 @@ typedef struct mtx_op {
   union {
     mtx_conv2d_args conv; mtx_gemm_args gemm; mtx_attn_args attn; mtx_norm_args norm;
     mtx_groupnorm_args gn; mtx_ew_args ew; mtx_ca_args ca; mtx_img_args img;
-    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre; mtx_yolo_decode_args yd;
+    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre; mtx_yolo_decode_args yd; mtx_detr_args detr;
   } u;
 } mtx_op;
 
@@ -289,6 +307,7 @@ MTX_API int mtx_mask_select(const mtx_mask_select_args* a, void* stream);
 MTX_API int mtx_preprocess(const mtx_preproc_args* a, void* stream);
 MTX_API int mtx_yolo_decode(const mtx_yolo_decode_args* a, void* stream);
 MTX_API int mtx_bubble_clean(const mtx_clean_args* a, void* stream);
+MTX_API int mtx_detr(const mtx_detr_args* a, void* stream);
 /* contour half of the same chain, host side on one crop (cleaning.py:340-386): external contours of the
  * thresholded crop -> area / centroid filter -> filled union -> largest blob -> final mask + bounding box.
  * Returns the number of accepted text fragments (0 = nothing to clean).                                */

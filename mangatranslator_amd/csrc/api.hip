@@ -25,6 +25,7 @@ int mask_select_launch(const mtx_mask_select_args*, void*, const char**);
 int preproc_launch(const mtx_preproc_args*, void*, const char**);
 int yolo_decode_launch(const mtx_yolo_decode_args*, void*, const char**);
 int clean_launch(const mtx_clean_args*, void*, const char**);
+int detr_launch(const mtx_detr_args*, void*, const char**);
 
 static thread_local std::string g_err;
 
@@ -66,6 +67,7 @@ static int run_op(const mtx_op& op, void* stream) {
     case MTX_OP_MASK_SELECT: rc = mask_select_launch(&op.u.sel, stream, &err); break;
     case MTX_OP_PREPROC: rc = preproc_launch(&op.u.pre, stream, &err); break;
     case MTX_OP_YOLO_DECODE: rc = yolo_decode_launch(&op.u.yd, stream, &err); break;
+    case MTX_OP_DETR: rc = detr_launch(&op.u.detr, stream, &err); break;
     case MTX_OP_MEMSET:
       if (hipMemsetAsync(op.u.ms.ptr, op.u.ms.value, (size_t)op.u.ms.bytes, (hipStream_t)stream) != hipSuccess) { rc = MTX_ERR_HIP; err = "memset failed"; }
       else rc = MTX_OK;
@@ -99,6 +101,7 @@ size_t mtx_abi_sizeof(int kind) {
     case MTX_OP_MASK_SELECT: return sizeof(mtx_mask_select_args);
     case MTX_OP_PREPROC: return sizeof(mtx_preproc_args);
     case MTX_OP_YOLO_DECODE: return sizeof(mtx_yolo_decode_args);
+    case MTX_OP_DETR: return sizeof(mtx_detr_args);
     case 100: return sizeof(mtx_clean_args);       /* op-level only (not a plan op) */
     default: return 0;
   }
@@ -159,6 +162,7 @@ MTX_OP_ENTRY(mtx_mask_select, mtx_mask_select_args, mask_select_launch)
 MTX_OP_ENTRY(mtx_preprocess, mtx_preproc_args, preproc_launch)
 MTX_OP_ENTRY(mtx_yolo_decode, mtx_yolo_decode_args, yolo_decode_launch)
 MTX_OP_ENTRY(mtx_bubble_clean, mtx_clean_args, clean_launch)
+MTX_OP_ENTRY(mtx_detr, mtx_detr_args, detr_launch)
 
 int mtx_conv2d_tiles(const mtx_conv2d_args* a) {
   if (!a) return fail(MTX_ERR_INVALID, "mtx_conv2d_tiles: null args");

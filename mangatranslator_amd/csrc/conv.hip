@@ -28,7 +28,7 @@ struct ConvParams {
   unsigned char* y; float* chan_sum;
   int n, h, w_in, cin, cout, ho, wo;
   int ldx, ldy, ldres;
-  int act; float act_param; float res_scale;
+  int act; float act_param; float res_scale; int act_after;
   int ps;           // pixel shuffle factor (0 or 2)
   int res_bcast;
   int pad_lo;       // zero padding on the top/left side
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
       const int pt = (wv * C::FR + i) * 16 + l15;
       v4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act(acc[i][j][r] + b[r], p.act, p.act_param));
+      for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(p.act_after ? acc[i][j][r] + b[r] : apply_act(acc[i][j][r] + b[r], p.act, p.act_param));
       *reinterpret_cast<v4*>(outs + pt * 128 + ((chunk ^ (pt & 7)) << 4) + ((q & 1) << 3)) = o;
     }
   }
@@ -214,6 +214,10 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
           unpack8<T>(rr, g8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] += p.res_scale * g8[e];
+          if (p.act_after) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = apply_act(f[e], p.act, p.act_param);
+          }
           raw = pack8<T>(f);
         }
       }
@@ -286,7 +290,7 @@ int conv2d_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.res = (const unsigned char*)a->res; p.y = (unsigned char*)a->y; p.chan_sum = a->chan_sum;
   p.n = a->n; p.h = a->h; p.w_in = a->w_in; p.cin = a->cin; p.cout = a->cout;
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldres = a->ldres;
-  p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.ps = a->pixel_shuffle; p.res_bcast = a->res_broadcast_n;
+  p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.act_after = (a->act_after_res && a->res != nullptr) ? 1 : 0; p.ps = a->pixel_shuffle; p.res_bcast = a->res_broadcast_n;
   int rc;
   if (a->dtype == MTX_BF16) rc = launch_conv_t<__bf16>(a, p, stream, tiles);
   else if (a->dtype == MTX_F16) rc = launch_conv_t<_Float16>(a, p, stream, tiles);

@@ -340,6 +340,7 @@ int conv_c64_tiles(int n, int h, int w) {
 }
 
 bool conv_c64_applicable(const mtx_conv2d_args* a) {
+  if (a->act_after_res) return false;
   return a->ksize == 3 && a->stride == 1 && a->cin <= 64 && a->cout <= 64;
 }
 

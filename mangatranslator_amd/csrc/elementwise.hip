@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
   long oh = p.h, ow = p.w;
   if (kind == MTX_EW_UPSAMPLE2X) { oh = 2 * p.h; ow = 2 * p.w; }
   if (kind == MTX_EW_MAXPOOL) { const int k = p.i0, s = p.i1, pd = (k & 1) ? k / 2 : 0; oh = (p.h + 2 * pd - k) / s + 1; ow = (p.w + 2 * pd - k) / s + 1; }
+  if (kind == MTX_EW_AVGPOOL2) { oh = (p.h + 1) / 2; ow = (p.w + 1) / 2; }
   if (kind == MTX_EW_IM2COL) { const int k = p.i0, s = p.i1, pd = k / 2; oh = (p.h + 2 * pd - k) / s + 1; ow = (p.w + 2 * pd - k) / s + 1; }
   const T* A = reinterpret_cast<const T*>(p.a);
   if (kind == MTX_EW_IM2COL) {
@@ -65,6 +66,23 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
       if (Bp) { float g[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] += g[e]; }
+    } else if (kind == MTX_EW_AVGPOOL2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      int taps = 0;
+      for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+          const long iy = y * 2 + dy, ix = x * 2 + dx;
+          if (iy >= p.h || ix >= p.w) continue;
+          float g[8];
+          unpack8<T>(*reinterpret_cast<const u32x4*>(A + ((n * p.h + iy) * p.w + ix) * p.lda + c), g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += g[e];
+          ++taps;
+        }
+      const float inv = 1.0f / (float)taps;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= inv;
     } else if (kind == MTX_EW_MAXPOOL) {
       const int k = p.i0, s = p.i1, pd = (k & 1) ? k / 2 : 0;
 #pragma unroll
@@ -267,6 +285,7 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
   long oh = a->h, ow = a->w;
   if (a->kind == MTX_EW_UPSAMPLE2X) { oh *= 2; ow *= 2; }
   if (a->kind == MTX_EW_MAXPOOL) { const int pd = (a->i0 & 1) ? a->i0 / 2 : 0; oh = (a->h + 2 * pd - a->i0) / a->i1 + 1; ow = (a->w + 2 * pd - a->i0) / a->i1 + 1; }
+  if (a->kind == MTX_EW_AVGPOOL2) { oh = (a->h + 1) / 2; ow = (a->w + 1) / 2; }
   long total = a->n * oh * ow * (a->c / 8);
   if (a->kind == MTX_EW_IM2COL) {
     if (a->i0 < 1 || a->i1 < 1 || a->ldy < (long)a->i0 * a->i0 * a->c) { *err = "elementwise: im2col needs k, stride and ldy >= k*k*C"; return MTX_ERR_INVALID; }

@@ -155,7 +155,8 @@ class PlanBuilder:
     def conv2d(self, x: Act, w_packed, bias, cout: int, ksize: int = 3, stride: int = 1,
                act: int = abi.ACT_NONE, act_param: float = 0.0, res: Optional[Act] = None,
                res_scale: float = 1.0, out: Optional[Act] = None, pixel_shuffle: int = 0,
-               chan_sum=None, res_broadcast: bool = False, pad_mode: int = 0, label: str = "conv") -> Act:
+               chan_sum=None, res_broadcast: bool = False, pad_mode: int = 0, act_after_res: bool = False,
+               label: str = "conv") -> Act:
         pad_total = 1 if pad_mode == 1 else 2 * (ksize // 2)
         ho = (x.h + pad_total - ksize) // stride + 1
         wo = (x.w + pad_total - ksize) // stride + 1
@@ -176,6 +177,7 @@ class PlanBuilder:
         a.pixel_shuffle, a.dtype = pixel_shuffle, self.dtype
         a.res_broadcast_n = 1 if res_broadcast else 0
         a.pad_mode = pad_mode
+        a.act_after_res = 1 if act_after_res else 0
         self._add(abi.OP_CONV2D, a, label)
         return out
 
@@ -258,6 +260,8 @@ class PlanBuilder:
         if out is None:
             if kind == abi.EW_UPSAMPLE2X:
                 out = self.act(a_.n, a_.h * 2, a_.w * 2, a_.c)
+            elif kind == abi.EW_AVGPOOL2:
+                out = self.act(a_.n, (a_.h + 1) // 2, (a_.w + 1) // 2, a_.c)
             elif kind == abi.EW_MAXPOOL:
                 pd = i0 // 2 if i0 % 2 else 0
                 out = self.act(a_.n, (a_.h + 2 * pd - i0) // i1 + 1, (a_.w + 2 * pd - i0) // i1 + 1, a_.c)
@@ -356,6 +360,30 @@ class PlanBuilder:
         a.n, a.hs, a.ws, a.hd, a.wd, a.thresh, a.dtype = n, hs, ws, hd, wd, thresh, src_dtype
         self._add(abi.OP_RESIZE_THRESH, a, label)
         return dst
+
+    def deform_attention(self, value, off, aw, ref_f32, out, rows, heads, d, level_shapes, points, offset_scale,
+                         ld_value=None, ld_off=None, ld_aw=None, ld_out=None, label="deform_attn"):
+        """RT-DETR multi-scale deformable attention (include/mtx_hip.h mtx_detr_args kind 0)"""
+        a = abi.DetrArgs()
+        a.value, a.off, a.aw, a.ref, a.out = _ptr(value), _ptr(off), _ptr(aw), _ptr(ref_f32), _ptr(out)
+        a.kind, a.rows, a.heads, a.d, a.levels, a.points = 0, rows, heads, d, len(level_shapes), points
+        start = 0
+        for i, (h, w) in enumerate(level_shapes):
+            a.lh[i], a.lw[i], a.lstart[i] = h, w, start
+            start += h * w
+        lp = len(level_shapes) * points
+        a.ld_value, a.ld_out = ld_value or heads * d, ld_out or heads * d
+        a.ld_off, a.ld_aw = ld_off or heads * lp * 2, ld_aw or heads * lp
+        a.offset_scale, a.dtype = offset_scale, self.dtype
+        self._add(abi.OP_DETR, a, label)
+        return out
+
+    def box_refine(self, ref_in_f32, ref_out_f32, ref_t, rows, delta=None, ld_delta=8, label="box_refine"):
+        """ref_out = sigmoid(delta + logit(ref_in)) (delta given) or sigmoid(ref_in) (logits in); ref_t = T copy [rows, 8]"""
+        a = abi.DetrArgs()
+        a.ref, a.ref_out, a.ref_t, a.delta = _ptr(ref_in_f32), _ptr(ref_out_f32), _ptr(ref_t), _ptr(delta)
+        a.kind, a.rows, a.ld_delta, a.dtype = (1 if delta is not None else 2), rows, ld_delta, self.dtype
+        self._add(abi.OP_DETR, a, label)
 
     def memset(self, t, value=0, label="memset"):
         a = abi.MemsetArgs()

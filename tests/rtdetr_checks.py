@@ -1,0 +1,78 @@
+"""RT-DETR-v2 parity: libmtx_hip graphs vs HF RTDetrV2ForObjectDetection (oracle/rtdetr_ref.py).
+
+With seeded random weights the 8400 (here: a few hundred) encoder scores are nearly tied, so WHICH tokens become queries is
+an argsort of f16 noise.  The checks therefore pin (1) everything up to the scores, (2) the selection wherever the fp32 score
+gap is larger than the f16 error, and (3) the decoder on the oracle's own selection, where rows line up one to one."""
+import numpy as np
+import torch
+
+from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
+from oracle import rtdetr_ref as rr
+
+
+def rel(x, y):
+    x, y = x.float().cpu().reshape(-1), y.float().cpu().reshape(-1)
+    return ((x - y).norm() / (y.norm() + 1e-9)).item()
+
+
+def check_raw(lib, device, size="tiny_test", hw=(128, 160), seed=0, tol=2e-2):
+    m, cfg = rr.make_model(size, seed)
+    model = RTDetrHip(m.state_dict(), cfg, device, lib=lib, graph=False)
+    g = np.random.default_rng(seed + 5)
+    H, W = hw
+    img = (g.random((H, W, 3)) * 255).astype(np.uint8)
+    img[H // 4:H // 2, W // 4:W // 2] = 240
+    caps = {}
+    hook = lambda name: (lambda mod, inp, out: caps.__setitem__(name, out))
+    mm = m.model
+    for i in range(3):
+        mm.decoder_input_proj[i].register_forward_hook(hook(f"decproj{i}"))
+    mm.enc_output.register_forward_hook(hook("enc_output"))
+    mm.enc_score_head.register_forward_hook(hook("enc_score"))
+    mm.enc_bbox_head.register_forward_hook(hook("enc_bbox"))
+    logits_ref, boxes_ref = rr.run(m, img)
+    a, b = model.plans(H, W)
+    a.src.copy_(torch.from_numpy(img).to(device).view(1, H, W, 3))
+    a.run()
+    nc, Q = cfg.num_labels, cfg.num_queries
+    ref_mem = torch.cat([caps[f"decproj{i}"][0].flatten(1).t() for i in range(3)], 0)
+    e = dict(memory=rel(a.mem, ref_mem), enc_output=rel(a.om, caps["enc_output"][0]), enc_score=rel(a.scores[:, :nc], caps["enc_score"][0]),
+             enc_bbox=rel(a.boxes[:, :4], caps["enc_bbox"][0]))
+    # selection: every token whose fp32 score clears the Q-th score by more than the observed score error must be chosen
+    s_ref = caps["enc_score"][0].max(-1).values
+    s_hip = a.scores[:, :nc].max(-1).values.cpu()
+    err = (s_hip - s_ref).abs().max().item()
+    kth = s_ref.topk(Q).values[-1].item()
+    sure = set(torch.nonzero(s_ref > kth + 2 * err).flatten().tolist())
+    chosen = set(s_hip.topk(Q).indices.tolist())
+    assert sure <= chosen, f"{len(sure - chosen)} clearly-top tokens were not selected"
+    # decoder on the oracle's selection
+    top = s_ref.topk(Q).indices.to(device)
+    b.mem.copy_(a.mem)
+    b.h0.copy_(a.om.index_select(0, top))
+    b.ref_logit.copy_((a.boxes + a.anchors).index_select(0, top))
+    b.run()
+    e["logits"], e["boxes"] = rel(b.logits[:, :nc], logits_ref), rel(b.boxes[:, :4], boxes_ref)
+    print(f"RT-DETR {size} {hw}: " + ", ".join(f"{k} {v:.2e}" for k, v in e.items()) + f"; {len(sure)} of {Q} selections unambiguous")
+    assert max(e.values()) < tol, e
+    # the public path end to end (its own selection): finite, right shapes, boxes inside the unit square
+    lg, bx = model.forward_raw(img)
+    assert lg.shape == (Q, nc) and bx.shape == (Q, 4) and torch.isfinite(lg).all() and (bx >= 0).all() and (bx <= 1).all()
+    return e
+
+
+def check_call_shape(lib, device, size="tiny_test", seed=1):
+    """the ultralytics-shaped call of reference core/ml/rtdetr_adapter.py:61-113"""
+    from PIL import Image
+    m, cfg = rr.make_model(size, seed)
+    model = RTDetrHip(m.state_dict(), cfg, device, lib=lib, graph=False, names={0: "a", 1: "b", 2: "c"})
+    rng = np.random.default_rng(3)
+    bgr = (rng.random((100, 140, 3)) * 255).astype(np.uint8)
+    res = model(bgr, conf=0.0, imgsz=96)[0]
+    n = len(res.boxes)
+    assert n > 0 and res.boxes.xyxy.shape == (n, 4) and res.boxes.conf.shape == (n,) and res.boxes.cls.shape == (n,)
+    assert (res.boxes.conf[:-1] >= res.boxes.conf[1:]).all() and res.names == {0: "a", 1: "b", 2: "c"}
+    want = rr.predict(m, Image.fromarray(bgr[..., ::-1].copy()), conf=0.0, imgsz=96)
+    assert abs(float(res.boxes.conf[0]) - float(want[1][0])) < 2e-2          # best score agrees
+    assert len(model(bgr, conf=1.1, imgsz=96)[0].boxes) == 0
+    return n
