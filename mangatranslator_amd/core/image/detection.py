@@ -4,16 +4,19 @@ Signature and result shape of the reference operator (core/image/detection.py:12
 `(detections, primary_boxes)` where each detection is
 `{"bbox": (x0, y0, x1, y1) ints via round(), "confidence", "class", "sam_mask": uint8 0/255 [H, W]}`.
 
-Built so far (the simple-bubble path the reference takes when no conjoined groups are found):
-    primary YOLO-seg @ imgsz (1600 for yolo_2, 640 for yolo_1)        detection.py:1337-1351
- -> IoU-0.7 confidence-ordered dedup, IoA-0.9 contained-box removal     :1358-1378
- -> seg_model "sam2": all boxes of the page through SAM-2.1 in one call  :1641-1750 (`_process_simple_bubbles`)
-    with each mask ANDed with its floor/ceil-clipped prompt box          :1732-1750
-    seg_model "yolo": the detector's own retina masks                    :514-565
- -> any SAM failure falls back to the YOLO masks, as the reference does  :1783-1813
-Secondary RT-DETR conjoined grouping / mask splitting (rows a2 tail, a4) are not built yet: with
-`conjoined_detection=True` the synthetic-overlap grouping (`_detect_overlapping_primaries`) is computed
-and reported, but group members are still emitted as simple bubbles.
+Flow (reference line numbers):
+    primary YOLO-seg @ imgsz (1600 for yolo_2, 640 for yolo_1)                        detection.py:1337-1351
+ -> IoU-0.7 confidence-ordered dedup, IoA-0.9 contained-box removal                     :1358-1378
+ -> secondary RT-DETR-v2 @640 (conjoined_detection): contained removal, class routing (bubble / text_free /
+    text_bubble), bubbles the primary missed are appended, primaries marked text_free are dropped      :1392-1546
+ -> simple vs conjoined (>= 2 secondaries inside a primary), synthetic groups of mutually overlapping
+    primaries                                                                                             :1571-1620
+ -> seg_model "sam2": simple boxes + conjoined parents + synthetic parents through SAM-2.1 in ONE call, each
+    mask ANDed with its floor/ceil-clipped prompt box                                                     :1660-1750
+ -> detection dicts; conjoined parents partitioned per child (core/image/conjoined.py)                    :1075-1260
+ -> any SAM failure falls back to the detector's own masks                                                :1783-1813
+Not built: OSB text verification (`osb_text_verification`, needs the OSB text detector, §8 f3) and the
+disk cache of detections (out of scope).  Returns `(detections, text_free_boxes)` like the reference.
 """
 from typing import List, Optional, Tuple
 
@@ -24,7 +27,7 @@ from PIL import Image
 from ...utils.exceptions import ImageProcessingError, ModelError
 from ...utils.logging import log_message
 from ..ml.model_manager import get_model_manager
-from . import box_ops
+from . import box_ops, conjoined
 
 IOU_DUPLICATE_THRESHOLD = 0.7
 SAM_MASK_THRESHOLD = 0.5
@@ -50,55 +53,149 @@ def rect_mask_from_box(box, img_h: int, img_w: int) -> np.ndarray:
     return m
 
 
+def _ioa(a, b) -> float:
+    area = max(0.0, a[2] - a[0]) * max(0.0, a[3] - a[1])
+    if area <= 0:
+        return 0.0
+    return max(0.0, min(a[2], b[2]) - max(a[0], b[0])) * max(0.0, min(a[3], b[3]) - max(a[1], b[1])) / area
+
+
+IOA_THRESHOLD = 0.50
+IOA_OVERLAP_THRESHOLD = 0.5
+
+
 def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, verbose: bool = False, device=None,
                           seg_model: str = "sam2", conjoined_detection: bool = True, conjoined_confidence: float = 0.35,
                           image_override: Optional[Image.Image] = None, osb_enabled: bool = False,
                           osb_text_verification: bool = False, osb_text_hf_token: str = "",
                           bubble_detector_model: str = "yolo_2") -> Tuple[List[dict], List[List[float]]]:
+    detections: List[dict] = []
+    text_free_boxes: List[List[float]] = []
     try:
         image_pil = image_override if image_override is not None else Image.open(image_path)
         rgb = np.asarray(image_pil.convert("RGB"))
     except Exception as e:
-        raise ImageProcessingError(f"Failed to load image: {e}") from e
+        raise ImageProcessingError(f"Error loading image: {e}") from e
     img_h, img_w = rgb.shape[:2]
     bgr = np.ascontiguousarray(rgb[..., ::-1])
     manager = get_model_manager()
-    model = manager.load_yolo_speech_bubble(bubble_detector_model)
+    try:
+        primary_model = manager.load_yolo_speech_bubble(bubble_detector_model)
+    except Exception as e:
+        raise ModelError(f"Error loading primary model: {e}") from e
     imgsz = 1600 if bubble_detector_model == "yolo_2" else 640
-    res = model(bgr, conf=confidence, device=device, verbose=False, imgsz=imgsz, retina_masks=True)[0]
-    if res.boxes is None or len(res.boxes.xyxy) == 0:
-        return [], []
-    boxes, confs, classes = res.boxes.xyxy, res.boxes.conf, res.boxes.cls
-    keep = box_ops.deduplicate_primary_boxes(boxes, confs, IOU_DUPLICATE_THRESHOLD)
-    boxes_k = boxes[keep]
-    keep2 = box_ops.remove_contained_boxes(boxes_k)
-    order = [keep[i] for i in keep2]
-    boxes_f = boxes[order]
+    primary_results = primary_model(bgr, conf=confidence, device=device, verbose=False, imgsz=imgsz, retina_masks=True)[0]
+    primary_boxes = primary_results.boxes.xyxy if primary_results.boxes is not None else torch.zeros((0, 4))
+    primary_sources = [("primary", i) for i in range(len(primary_boxes))]
+    if len(primary_boxes) > 1:
+        keep = box_ops.deduplicate_primary_boxes(primary_boxes, primary_results.boxes.conf, IOU_DUPLICATE_THRESHOLD)
+        primary_boxes, primary_sources = primary_boxes[keep], [primary_sources[i] for i in keep]
+    if len(primary_boxes) > 1:
+        keep = box_ops.remove_contained_boxes(primary_boxes)
+        primary_boxes, primary_sources = primary_boxes[keep], [primary_sources[i] for i in keep]
+    if len(primary_boxes) == 0:
+        log_message("No detections found", verbose=verbose)
+        return detections, text_free_boxes
+    log_message(f"Detected {len(primary_boxes)} speech bubbles with YOLO", always_print=True)
+
+    secondary_boxes, secondary_sources, secondary_results = torch.zeros((0, 4)), [], None
     if conjoined_detection:
-        groups, _ = box_ops.detect_overlapping_primaries(boxes_f, list(range(len(order))))
-        if groups:
-            log_message(f"Detected {len(groups)} synthetic conjoined group(s)", verbose=verbose)
-    masks: List[Optional[np.ndarray]] = [None] * len(order)
-    if seg_model == "sam2":
         try:
-            processor, sam = manager.load_sam2()
-            inputs = processor(Image.fromarray(rgb), input_boxes=boxes_f.unsqueeze(0).cpu(), return_tensors="pt")
+            secondary_model = manager.load_rtdetr_conjoined_bubble()
+            secondary_results = secondary_model(bgr, conf=conjoined_confidence, device=device, verbose=False, imgsz=640)[0]
+            secondary_boxes = secondary_results.boxes.xyxy if secondary_results.boxes is not None else torch.zeros((0, 4))
+            secondary_sources = [("secondary", i) for i in range(len(secondary_boxes))]
+            if len(secondary_boxes) > 1:
+                keep = box_ops.remove_contained_boxes(secondary_boxes)
+                secondary_boxes, secondary_sources = secondary_boxes[keep], [secondary_sources[i] for i in keep]
+            if len(secondary_boxes) > 0 and hasattr(secondary_model, "names"):
+                ids = {name: cid for cid, name in secondary_model.names.items()}
+                bubble_id, text_free_id = ids.get("bubble"), ids.get("text_free")
+                kept_b, kept_s = [], []
+                for i, sb in enumerate(secondary_boxes):
+                    cid = int(secondary_results.boxes.cls[secondary_sources[i][1]])
+                    if text_free_id is not None and cid == text_free_id:
+                        text_free_boxes.append(sb.tolist())
+                    elif bubble_id is None or cid == bubble_id:
+                        kept_b.append(sb); kept_s.append(secondary_sources[i])
+                secondary_boxes = torch.stack(kept_b) if kept_b else secondary_boxes[:0]
+                secondary_sources = kept_s
+                if len(secondary_boxes) > 0:           # bubbles the primary model missed
+                    plist = primary_boxes.tolist()
+                    new_b, new_s = [], []
+                    for i, sb in enumerate(secondary_boxes):
+                        sl = sb.tolist()
+                        if not any(_ioa(sl, pl) > IOA_OVERLAP_THRESHOLD or _ioa(pl, sl) > IOA_OVERLAP_THRESHOLD for pl in plist):
+                            new_b.append(sb); new_s.append(secondary_sources[i])
+                    if new_b:
+                        log_message(f"Found {len(new_b)} missed bubbles from secondary model", always_print=True)
+                        primary_boxes = torch.cat((primary_boxes, torch.stack(new_b).to(primary_boxes)), dim=0)
+                        primary_sources.extend(new_s)
+            if text_free_boxes and len(primary_boxes) > 0:
+                drop = [i for i, pb_ in enumerate(primary_boxes.tolist())
+                        if any(_ioa(pb_, tf) > IOA_OVERLAP_THRESHOLD or _ioa(tf, pb_) > IOA_OVERLAP_THRESHOLD for tf in text_free_boxes)]
+                if drop:
+                    action = "routing to OSB pipeline" if osb_enabled else "discarding (OSB disabled)"
+                    log_message(f"Removing {len(drop)} bubbles marked text_free ({action})", always_print=True)
+                    keep = [i for i in range(len(primary_boxes)) if i not in drop]
+                    primary_boxes = primary_boxes[keep] if keep else primary_boxes[:0]
+                    primary_sources = [primary_sources[i] for i in keep]
+        except Exception as e:
+            log_message(f"Warning: Could not load/run secondary RT-DETR model: {e}. Proceeding without conjoined/fallback detection.", verbose=verbose)
+            secondary_boxes, secondary_sources = torch.zeros((0, 4)), []
+    if len(primary_boxes) == 0:
+        return detections, text_free_boxes
+
+    grouping_primary_boxes = primary_boxes.clone()
+    conjoined_indices, simple_indices = [], list(range(len(primary_boxes)))
+    if len(secondary_boxes) > 0 and conjoined_detection:
+        conjoined_indices, simple_indices = box_ops.categorize_detections(grouping_primary_boxes, secondary_boxes, ioa_threshold=IOA_THRESHOLD)
+        if conjoined_indices:
+            log_message(f"Detected {len(conjoined_indices)} conjoined speech bubbles with RT-DETR", always_print=True)
+    synthetic_groups: List[dict] = []
+    if len(simple_indices) > 1:
+        groups, simple_indices = box_ops.detect_overlapping_primaries(grouping_primary_boxes, simple_indices)
+        for members in groups:
+            st = grouping_primary_boxes[members]
+            synthetic_groups.append({"member_indices": members, "parent_mask": None,
+                                     "parent_box": torch.cat([st[:, :2].min(dim=0).values, st[:, 2:].max(dim=0).values])})
+
+    def assemble(sam_masks):
+        return conjoined.build_segmentation_detections(primary_boxes, grouping_primary_boxes, primary_sources, primary_results, primary_model,
+                                                       secondary_boxes, secondary_sources, secondary_results, simple_indices, conjoined_indices,
+                                                       img_h, img_w, conjoined_confidence, osb_text_boxes_np=None, verbose=verbose,
+                                                       sam_masks=sam_masks, synthetic_conjoined_groups=synthetic_groups)
+
+    if seg_model not in ("sam2", "sam3"):
+        log_message("SAM disabled, using YOLO segmentation masks", verbose=verbose)
+        return assemble(None), text_free_boxes
+    try:
+        processor, sam = manager.load_sam2(verbose=verbose)
+        prompts, owners = [], []
+        for idx in simple_indices:
+            prompts.append(primary_boxes[idx]); owners.append(idx)
+        for p_idx, s_indices in conjoined_indices:           # the prompt must cover every child
+            st = torch.cat([primary_boxes[p_idx].unsqueeze(0)] + [secondary_boxes[s].unsqueeze(0).to(primary_boxes) for s in s_indices], dim=0)
+            prompts.append(torch.cat([st[:, :2].min(dim=0).values, st[:, 2:].max(dim=0).values])); owners.append(p_idx)
+        synth_start = len(prompts)
+        prompts += [sg["parent_box"] for sg in synthetic_groups]
+        sam_masks = [None] * len(primary_boxes)
+        if prompts:
+            all_boxes = torch.stack(prompts)
+            inputs = processor(Image.fromarray(rgb), input_boxes=all_boxes.unsqueeze(0).cpu(), return_tensors="pt")
             out = sam(multimask_output=False, **inputs)
             m = processor.post_process_masks(out.pred_masks, inputs["original_sizes"])[0][:, 0]
             m = (m > SAM_MASK_THRESHOLD).cpu().numpy()
-            for i in range(len(order)):
-                masks[i] = clip_mask_to_box(m[i], boxes_f[i].tolist(), img_h, img_w)
-        except (ModelError, RuntimeError) as e:
-            log_message(f"SAM segmentation failed ({e}); falling back to YOLO masks", always_print=True)
-    yolo_masks = res.masks.data.cpu().numpy() if res.masks is not None else None
-    detections = []
-    for i, src in enumerate(order):
-        m = masks[i]
-        if m is None and yolo_masks is not None:
-            m = (yolo_masks[src] > 0).astype(np.uint8) * 255
-        if m is None:
-            m = rect_mask_from_box(boxes_f[i].tolist(), img_h, img_w)
-        x0, y0, x1, y1 = boxes_f[i].tolist()
-        detections.append({"bbox": (int(round(x0)), int(round(y0)), int(round(x1)), int(round(y1))),
-                           "confidence": float(confs[src]), "class": model.names[int(classes[src])], "sam_mask": m})
-    return detections, boxes_f.tolist()
+            for i, box in enumerate(prompts):
+                clipped = clip_mask_to_box(m[i], box.tolist(), img_h, img_w)
+                if i < synth_start:
+                    sam_masks[owners[i]] = clipped
+                else:
+                    synthetic_groups[i - synth_start]["parent_mask"] = clipped
+            log_message(f"Generated {len(prompts)} primary masks with SAM 2.1", always_print=True)
+        return assemble(sam_masks), text_free_boxes
+    except Exception as e:
+        log_message(f"SAM 2.1 segmentation failed: {e}. Falling back to YOLO segmentation masks.", always_print=True)
+        for sg in synthetic_groups:
+            sg["parent_mask"] = None
+        return assemble(None), text_free_boxes

@@ -33,6 +33,7 @@ class ModelType(Enum):
     YOLO_SPEECH_BUBBLE = "yolo_speech_bubble"
     YOLO_SPEECH_BUBBLE_2 = "yolo_speech_bubble_2"
     SAM2 = "sam2"
+    RTDETR_CONJOINED_BUBBLE = "rtdetr_conjoined_bubble"
     FLUX_KONTEXT_SDNQ_PIPELINE = "flux_kontext_sdnq_pipeline"
 
 
@@ -134,6 +135,7 @@ class ModelManager:
                 ModelType.YOLO_SPEECH_BUBBLE: model_dir / "yolo" / "yolov8m_seg-speech-bubble.safetensors",
                 ModelType.YOLO_SPEECH_BUBBLE_2: model_dir / "yolo" / "manga109-segmentation-bubble.safetensors",
                 ModelType.SAM2: model_dir / "sam" / "sam2.1-hiera-large",
+                ModelType.RTDETR_CONJOINED_BUBBLE: model_dir / "rtdetr" / "comic-text-and-bubble-detector",
                 ModelType.FLUX_KONTEXT_SDNQ_PIPELINE: model_dir / "flux" / "kontext",
             }
             self.hf_token = None
@@ -220,6 +222,30 @@ class ModelManager:
             model = YoloSegHip(sd, device=self.device, names={0: "speech_bubble"})
             self.models[mt] = model
             log_message(f"YOLO bubble detector loaded ({mt.value}).", verbose=verbose)
+            return model
+
+    def load_rtdetr_conjoined_bubble(self, verbose: bool = False):
+        """RT-DETR-v2 secondary detector as libmtx_hip graphs with the YOLO-shaped call of the reference's adapter
+        (reference :745-778; core/ml/rtdetr_adapter.py).  Expects the HF repo layout (config.json + model.safetensors)."""
+        mt = ModelType.RTDETR_CONJOINED_BUBBLE
+        with self._lock:
+            if self.is_loaded(mt):
+                return self.models[mt]
+            from .rtdetr import RTDetrHip
+            root = self.model_paths[mt]
+            if not (root / "config.json").exists():
+                raise ModelError(f"RT-DETR config not found: {root / 'config.json'} (stage it under ./models; this build never downloads)")
+            try:
+                from transformers import RTDetrV2Config
+                config = RTDetrV2Config.from_pretrained(str(root))
+                sd = self._read_safetensors(root / "model.safetensors")
+                model = RTDetrHip(sd, config, device=self.device, names=getattr(config, "id2label", None))
+            except ModelError:
+                raise
+            except Exception as e:
+                raise ModelError(f"Failed to load RT-DETR conjoined model: {e}") from e
+            self.models[mt] = model
+            log_message("RT-DETR conjoined bubble model loaded.", verbose=verbose)
             return model
 
     def load_sam2(self, verbose: bool = False):

@@ -292,7 +292,110 @@ def gen_conjoined():
     return dict(H=H, W=W, scenarios=meta, assembly=assembly), arrays
 
 
+def detection_flow_inputs():
+    """canned detector outputs for the operator-flow golden (shared with tests/test_detection_flow.py through the json)"""
+    primary = [[20.0, 30.0, 190.0, 120.0],      # P0: one box over two touching bubbles (conjoined parent)
+               [210.0, 20.0, 290.0, 90.0],      # P1: simple
+               [30.0, 150.0, 120.0, 230.0],     # P2, P3: mutually overlapping primaries -> synthetic group
+               [95.0, 155.0, 185.0, 232.0],
+               [220.0, 150.0, 300.0, 220.0],    # P4: marked text_free by the secondary model
+               [212.0, 22.0, 288.0, 88.0]]      # P5: duplicate of P1 (lower confidence)
+    pconf = [0.9, 0.85, 0.8, 0.75, 0.7, 0.65]
+    secondary = [[22.0, 32.0, 108.0, 118.0], [100.0, 34.0, 188.0, 119.0],          # S0, S1: the two halves of P0 (bubble)
+                 [222.0, 152.0, 298.0, 218.0],                                          # S2: text_free over P4
+                 [130.0, 250.0, 200.0, 300.0],                                          # S3: a bubble the primary missed
+                 [40.0, 50.0, 90.0, 100.0],                                             # S4: text_bubble (ignored)
+                 [30.0, 40.0, 100.0, 110.0]]                                            # S5: bubble nested in S0 (contained removal)
+    sconf = [0.8, 0.78, 0.6, 0.5, 0.9, 0.4]
+    scls = [0, 0, 2, 0, 1, 0]
+    return dict(H=320, W=320, primary=primary, pconf=pconf, secondary=secondary, sconf=sconf, scls=scls,
+                names={"0": "bubble", "1": "text_bubble", "2": "text_free"})
+
+
+def gen_detection_flow():
+    """the whole operator: core/image/detection.py:1263-1816 `detect_speech_bubbles` driven by canned detector / SAM outputs
+    (the models themselves have their own parity tests).  cv2 here: cvtColor at image load (a channel flip) and the
+    distanceTransform of the conjoined partition (the oracle's restatement, as in gen_conjoined)."""
+    sys.path.insert(0, str(HERE.parent.parent))
+    from oracle.cleaning_ref import distance_transform_l2_5x5
+    inp = detection_flow_inputs()
+    H, W = inp["H"], inp["W"]
+    detection.cv2 = types.SimpleNamespace(distanceTransform=lambda img, dt, ms: distance_transform_l2_5x5(np.asarray(img)), DIST_L2=2,
+                                          cvtColor=lambda a, code: np.ascontiguousarray(a[..., ::-1]), COLOR_RGB2BGR=4, COLOR_BGR2RGB=4)
+
+    class Boxes:
+        def __init__(self, xyxy, conf, cls):
+            self.xyxy, self.conf, self.cls = torch.tensor(xyxy, dtype=torch.float32), torch.tensor(conf, dtype=torch.float32), torch.tensor(cls, dtype=torch.float32)
+
+        def __len__(self):
+            return len(self.xyxy)
+
+    primary_model = lambda *a, **k: [types.SimpleNamespace(boxes=Boxes(inp["primary"], inp["pconf"], [0] * 6), masks=None, orig_shape=(H, W))]
+    primary_model_obj = types.SimpleNamespace(names={0: "speech_bubble"}, __call__=None)
+
+    class Callable_:
+        def __init__(self, fn, names):
+            self.fn, self.names = fn, names
+
+        def __call__(self, *a, **k):
+            return self.fn(*a, **k)
+
+    pm = Callable_(primary_model, {0: "speech_bubble"})
+    sm = Callable_(lambda *a, **k: [types.SimpleNamespace(boxes=Boxes(inp["secondary"], inp["sconf"], inp["scls"]), names={int(k_): v for k_, v in inp["names"].items()})],
+                   {int(k_): v for k_, v in inp["names"].items()})
+    prompts_seen = []
+
+    class Inputs(dict):
+        def to(self, *a, **k):
+            return self
+
+    class Proc:
+        def __call__(self, image, input_boxes=None, return_tensors="pt"):
+            return Inputs(boxes=torch.as_tensor(input_boxes, dtype=torch.float32).reshape(-1, 4), original_sizes=torch.tensor([[H, W]]))
+
+        def post_process_masks(self, pred, sizes, **kw):
+            return [pred]
+
+    class Sam:
+        dtype = torch.float32
+
+        def __call__(self, multimask_output=False, **inputs):
+            bx = inputs["boxes"]
+            prompts_seen.append(bx.tolist())
+            yy, xx = np.mgrid[0:H, 0:W]
+            ms = []
+            for x0, y0, x1, y1 in bx.tolist():   # an ellipse around the prompt box, slightly larger than it (so the box clip matters)
+                cx, cy, a, b = (x0 + x1) / 2, (y0 + y1) / 2, (x1 - x0) / 2 * 1.08, (y1 - y0) / 2 * 1.08
+                ms.append(((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 <= 1.0)
+            return types.SimpleNamespace(pred_masks=torch.from_numpy(np.stack(ms))[:, None].float())
+
+    sam = Sam()
+    mgr = types.SimpleNamespace(load_yolo_speech_bubble=lambda *a, **k: pm, load_rtdetr_conjoined_bubble=lambda *a, **k: sm,
+                                load_sam2=lambda *a, **k: (Proc(), sam), device="cpu")
+    detection.get_model_manager = lambda: mgr
+    none = lambda *a, **k: None
+    detection.get_cache = lambda: types.SimpleNamespace(get_yolo_cache_key=none, get_yolo_detection=none, set_yolo_detection=none,
+                                                        get_sam_cache_key=none, get_sam_masks=none, set_sam_masks=none)
+    rng = np.random.default_rng(3)
+    img = Image.fromarray((rng.random((H, W, 3)) * 255).astype(np.uint8))
+    out = {}
+    for seg in ("sam2", "yolo"):
+        dets, text_free = detection.detect_speech_bubbles(Path("page.png"), "yolo_2", confidence=0.6, device="cpu", seg_model=seg,
+                                                          conjoined_detection=True, image_override=img)
+        out[seg] = dict(text_free=[[float(v) for v in b] for b in text_free],
+                        dets=[dict(bbox=list(d["bbox"]), confidence=float(d["confidence"]), cls=d["class"],
+                                   neighbors=[list(b) for b in d["conjoined_neighbor_bboxes"]] if "conjoined_neighbor_bboxes" in d else None) for d in dets])
+        DET_MASKS[seg] = np.packbits(np.stack([np.asarray(d["sam_mask"]) > 0 for d in dets]))
+    out["prompts"] = prompts_seen[0]
+    return dict(inputs=inp, results=out)
+
+
+DET_MASKS = {}
+
+
 if __name__ == "__main__":
+    json.dump(gen_detection_flow(), open(HERE / "detection_flow.json", "w"))
+    np.savez_compressed(HERE / "detection_flow_masks.npz", **DET_MASKS)
     cj_meta, cj_arrays = gen_conjoined()
     json.dump(cj_meta, open(HERE / "conjoined.json", "w"))
     np.savez_compressed(HERE / "conjoined.npz", **cj_arrays)
