@@ -107,7 +107,7 @@ def main():
         if world > 1:
             rcan_sd = broadcast_state_dict(rcan_sd, rank, world, device)
         upscaler = RCANUpscaler(rcan_sd, device=device, lib=lib, graph=graph)
-    yolo = None
+    yolo = rtdetr = None
     if "detect" in want:
         from mangatranslator_amd.core.ml.yolo import YoloSegHip
         from oracle.yolo_ref import make_model as make_yolo       # seeded YOLOv8m-seg (the reference's yolo_1 geometry)
@@ -120,6 +120,15 @@ def main():
         if world > 1:
             ysd = broadcast_state_dict(ysd, rank, world, device)
         yolo = YoloSegHip(ysd, device=device, lib=lib, graph=graph)
+        # secondary detector of the same stage: RT-DETR-v2 R50 @640 (reference detection.py:1401-1407, on by default)
+        from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
+        from oracle.rtdetr_ref import make_model as make_rtdetr
+        rnet, rcfg = make_rtdetr("r50", seed=5 if first else 0)
+        rsd = rnet.state_dict()
+        if world > 1:
+            rsd = broadcast_state_dict({k: v for k, v in rsd.items() if v.is_floating_point()}, rank, world, device)
+        rtdetr = RTDetrHip(rsd, rcfg, device=device, lib=lib, graph=graph, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
+        del rnet
     sam = None
     if "segment" in want:
         from mangatranslator_amd.core.ml.sam2 import Sam2Hip
@@ -180,6 +189,7 @@ def main():
         k = i % pool
         if yolo is not None:
             outs["detect"] = yolo(page_bgr[k], conf=yolo_conf, imgsz=1600)[0]
+            outs["detect2"] = rtdetr(page_bgr[k], conf=0.35, imgsz=640)[0]
         if sam is not None:      # prompts: the generator's ground-truth boxes (fixed unit count)
             outs["segment"] = sam.segment(pages[k], page_boxes[k])
         if inpainter is not None:
@@ -219,7 +229,7 @@ def main():
                                f"{args.boxes} bubbles, {args.regions} FLUX region(s) x {args.inpaint_steps} steps, 2x upscale; HBM-resident input",
                    "stages": stages,
                    "dtypes": {"detect": "f16", "segment": "bf16", "inpaint": "bf16 (fp32 latents / Euler update)", "upscale": "f16"},
-                   "detector": "YOLOv8m-seg @imgsz 1600 (1088x1600 letterbox), seeded random weights" if yolo is not None else None,
+                   "detector": "YOLOv8m-seg @imgsz 1600 (1088x1600 letterbox) + RT-DETR-v2 R50 @640 (secondary), seeded random weights" if yolo is not None else None,
                    "segmenter": "SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights" if sam is not None else None,
                    "inpainter": "FLUX.1-Kontext-dev geometry (19 double + 38 single blocks, d=3072, 24 heads), bf16, seeded random weights" if flux is not None else None,
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
@@ -234,6 +244,30 @@ def main():
             cfg["segment_ms"] = {"preprocess": pre.time(5), "encoder": enc.time(5), "decoder": dec.time(5), "upsample_threshold": post.time(5)}
         if yolo is not None:
             cfg["detect_net_ms"] = yolo._plans[(H_, W_, 1600)][0].time(5)
+            ra, rb = rtdetr.plans(640, 640)
+            cfg["detect_rtdetr_ms"] = {"backbone_encoder": ra.time(5), "decoder": rb.time(5)}
+        # not part of the metric, reported for reference: the OpenCV-style cleaning chain on the page's 8 bubbles
+        try:
+            from mangatranslator_amd.core.image import cleaning as cl
+            yy, xx = np.mgrid[0:H_, 0:W_]
+            bm = []
+            for x0, y0, x1, y1 in page_boxes[0]:
+                cx, cy, a_, b_ = (x0 + x1) / 2, (y0 + y1) / 2, (x1 - x0) / 2 - 4, (y1 - y0) / 2 - 4
+                bm.append((((xx - cx) / a_) ** 2 + ((yy - cy) / b_) ** 2 <= 1.0).astype(np.uint8) * 255)
+            dm = torch.from_numpy(np.stack(bm)).to(device)
+            sc = (W_ * H_ / 1e6) ** 0.5
+            kw = dict(dilation_kernel=cl.structuring_element(cl.scale_kernel(cl.DILATION_KERNEL_SIZE, sc)),
+                      constraint_erosion_kernel=cl.structuring_element(cl.scale_kernel(cl.EROSION_KERNEL_SIZE, sc)),
+                      min_contour_area=cl.scale_area(50, sc, minimum=50, maximum=5000), processing_scale=sc, device=device, lib=lib)
+            bbs = [tuple(int(v) for v in b_) for b_ in page_boxes[0]]
+            cl.process_bubbles(page_bgr[0], dm, bbs, 200, False, float(cl.scale_scalar(5, sc, minimum=0.0, maximum=64.0)), **kw)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3):
+                cl.process_bubbles(page_bgr[0], dm, bbs, 200, False, float(cl.scale_scalar(5, sc, minimum=0.0, maximum=64.0)), **kw)
+            torch.cuda.synchronize()
+            cfg["clean_ms_not_in_metric"] = (time.perf_counter() - t0) / 3 * 1e3
+        except Exception as e:      # informational only
+            cfg["clean_ms_not_in_metric"] = f"failed: {e}"
         if upscaler is not None:
             cfg["upscale_ms"] = upscaler.plan_for(1, H_, W_).time(3)
         if flux is not None:
