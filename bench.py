@@ -237,6 +237,17 @@ def main():
     }
     cfg = result["config"]
 
+    def pmc_traffic(key_prefix):
+        """HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs; see the file's _how)"""
+        try:
+            tr = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+            for k_, v_ in tr.items():
+                if k_.startswith(key_prefix):
+                    return v_["bytes_per_launch"]
+        except Exception:
+            pass
+        return None
+
     if rank == 0:
         # ---- per-stage GPU time (HIP events on the launch stream), outside the timed region ---------------
         if sam is not None:
@@ -287,7 +298,8 @@ def main():
             result["roofline"] = {
                 "kernel": f"attn_mma32_kernel<bf16, 128> 24 heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)",
                 "bound": "mfma", "achieved": tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS,
-                "traffic": None, "avg_launch_ms": ms, "launches_per_page": n_attn * args.inpaint_steps * args.regions,
+                "traffic": pmc_traffic("attn_mma32_kernel") if fl["tokens"] == 8652 else None,
+                "avg_launch_ms": ms, "launches_per_page": n_attn * args.inpaint_steps * args.regions,
                 "algorithmic_flops_per_launch": fl["attention_per_layer"],
             }
             # the other MFMA-bound kernel: every 256-tile GEMM launch of one denoising step, timed one by one
@@ -321,7 +333,8 @@ def main():
             conv_roof = {
                 "kernel": "conv3x3_c64_kernel<f16> 64->64 @%dx%d" % (W_ // u, H_ // u),
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": None, "avg_launch_ms": ms, "launches_per_page": work["n_conv64"],
+                "traffic": pmc_traffic("conv3x3_c64_kernel") if (W_, H_, u) == (1024, 1536, 1) else None,
+                "avg_launch_ms": ms, "launches_per_page": work["n_conv64"],
                 "algorithmic_bytes_per_launch": work["conv64_bytes"], "mfma_tflops": tfs, "mfma_frac": tfs / MFMA_PEAK_TFLOPS,
             }
             if "roofline" in result:
