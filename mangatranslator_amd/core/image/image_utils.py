@@ -31,20 +31,25 @@ def _upscale_image(model, image: Image.Image, device: torch.device) -> Image.Ima
         return tensor_to_image(model(image_to_tensor(image, device)))
 
 
-def upscale_image_to_dimension(model, image: Image.Image, target: int, device, mode: str = "max",
-                               model_type: str = "model", verbose: bool = False) -> Image.Image:
-    """Repeat model passes until max(w, h) (mode "max") or min(w, h) (mode "min") reaches `target`."""
-    if mode not in ("max", "min"):
-        raise ImageProcessingError(f"Invalid upscale mode: {mode}")
-    pick = max if mode == "max" else min
+def upscale_image_to_dimension(model, image: Image.Image, target: int, device, mode: str, model_type: str = "model",
+                               verbose: bool = False) -> Image.Image:
+    """Model passes until max(w, h) (mode "max") or min(w, h) (mode "min") reaches `target` (reference :377-500; the
+    reference's PNG round trips between passes only free host memory and are not reproduced)."""
+    if mode not in {"max", "min"}:
+        raise ImageProcessingError("mode must be 'max' or 'min'")
+    if image.width <= 0 or image.height <= 0:
+        msg = f"Invalid image dimensions: {image.width}x{image.height}. Cannot upscale 0x0 images."
+        log_message(msg, always_print=True)
+        raise ImageProcessingError(msg)
+    met = (lambda w, h: max(w, h) >= target) if mode == "max" else (lambda w, h: min(w, h) >= target)
     current = image
-    scale = getattr(model, "scale", 2)
-    for _ in range(8):
-        if pick(current.size) >= target:
-            break
-        current = _upscale_image(model, current, device)
-        if scale <= 1:
-            break
+    while not met(current.width, current.height):
+        log_message(f"Upscaling from {current.width}x{current.height}...", verbose=verbose)
+        nxt = _upscale_image(model, current, device)
+        if nxt.width <= current.width and nxt.height <= current.height:
+            raise ImageProcessingError("upscale model did not enlarge the image")          # a 1x model would loop forever
+        current = nxt
+        log_message(f"...to {current.width}x{current.height}", verbose=verbose)
     return current
 
 
