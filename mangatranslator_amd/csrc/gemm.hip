@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       const bool more = kt + 1 < nk;
       if (more && p.abl == 2) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);      // ablation: all eight pieces right after the barrier
       const int nst = (int)((kt + 1) & 1);
-      const long nk0 = (kt + 1) * G2_BK;
+      const long nk0 = p.abl == 5 ? 0 : (kt + 1) * G2_BK;            // ablation 5: always re-read the first K tile (L2-resident source)
       auto piece = [&](int i) {                 // one DMA instruction (1 KB) of the next tile
         const void* g = src[i] ? (const void*)(src[i] + nk0) : (const void*)g_zero16;
         glds16(g, smem + nst * G2_STAGE + (i * 8 + wv) * 1024);
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             acc[i][j] = Mma32<T>::mfma(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
-            if (p.abl == 0 && more) {           // the next tile's 8 DMA pieces threaded between the MFMAs: 3, 3, 2, 0 per k-step (+3 % vs a burst)
+            if ((p.abl == 0 || p.abl == 5) && more) {           // the next tile's 8 DMA pieces threaded between the MFMAs: 3, 3, 2, 0 per k-step (+3 % vs a burst)
               const int m = i * 2 + j;
               const int first = ks == 0 ? 0 : (ks == 1 ? 3 : 6), cnt = ks < 2 ? 3 : (ks == 2 ? 2 : 0);
               if (m == 1 && cnt > 0) piece(first);

@@ -61,7 +61,7 @@ def gemm_abl(M, N, K, rounds=4, iters=20):
     w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
     pb.gemm(a, w, M, N, K)
     plan = pb.build(); plan.run(); torch.cuda.synchronize()
-    res = {"0": [], "3": [], "4": []}
+    res = {"0": [], "5": [], "1": []}
     for r in range(rounds):
         for mode in res:
             os.environ["MTX_GEMM_ABL"] = mode
