@@ -259,6 +259,42 @@ int mtx_plan_time_range(void* plan, int first, int last, void* stream, int iters
 #endif
 }
 
+// In-context op timing: the whole plan runs eagerly `iters` times with a HIP-event pair around every selected op, so an
+// op is measured with the caches, clocks and neighbours it has in the real sequence (isolated back-to-back replays of one
+// attention launch measured 13 % faster than the same launch inside a denoising step).  ms_total = sum over ops and iters.
+int mtx_plan_time_ops(void* plan, void* stream, const int* op_idx, int n_idx, int iters, float* ms_total) {
+  if (!plan || !op_idx || !ms_total || n_idx < 1 || iters < 1) return fail(MTX_ERR_INVALID, "mtx_plan_time_ops: bad arguments");
+  Plan* p = static_cast<Plan*>(plan);
+  *ms_total = 0.f;
+#ifdef MTX_EMU
+  for (int i = 0; i < iters; ++i) { int rc = mtx_plan_run(plan, stream); if (rc) return rc; }
+  return MTX_OK;
+#else
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<char> sel(p->ops.size(), 0);
+  for (int i = 0; i < n_idx; ++i) { if (op_idx[i] < 0 || op_idx[i] >= (int)p->ops.size()) return fail(MTX_ERR_INVALID, "mtx_plan_time_ops: op index out of range"); sel[(size_t)op_idx[i]] = 1; }
+  std::vector<hipEvent_t> ev((size_t)n_idx * 2);
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return fail(MTX_ERR_HIP, "hipEventCreate failed");
+  int rc = MTX_OK;
+  double total = 0.0;
+  for (int it = 0; it < iters && rc == MTX_OK; ++it) {
+    size_t k = 0;
+    for (size_t i = 0; i < p->ops.size() && rc == MTX_OK; ++i) {
+      if (sel[i]) hipEventRecord(ev[k * 2], s);
+      rc = run_op(p->ops[i], stream);
+      if (rc != MTX_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; break; }
+      if (sel[i]) { hipEventRecord(ev[k * 2 + 1], s); ++k; }
+    }
+    if (rc != MTX_OK) break;
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(MTX_ERR_HIP, "hipStreamSynchronize failed"); break; }
+    for (size_t j = 0; j < k; ++j) { float t = 0.f; hipEventElapsedTime(&t, ev[j * 2], ev[j * 2 + 1]); total += t; }
+  }
+  for (auto& e : ev) hipEventDestroy(e);
+  *ms_total = (float)total;
+  return rc;
+#endif
+}
+
 int mtx_plan_time(void* plan, void* stream, int iters, int use_graph, float* ms_per_iter) {
   if (!plan || !ms_per_iter || iters < 1) return fail(MTX_ERR_INVALID, "mtx_plan_time: bad arguments");
 #ifdef MTX_EMU

@@ -156,5 +156,5 @@ EXPORTS = [
     "mtx_elementwise", "mtx_channel_attention", "mtx_image_convert", "mtx_resize_threshold",
     "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode", "mtx_detr", "mtx_bubble_clean", "mtx_host_text_mask", "mtx_host_chamfer_l2_5x5",
     "mtx_plan_create", "mtx_plan_run", "mtx_plan_run_graph", "mtx_plan_num_ops",
-    "mtx_plan_run_range", "mtx_plan_destroy", "mtx_plan_time", "mtx_plan_time_range",
+    "mtx_plan_run_range", "mtx_plan_destroy", "mtx_plan_time", "mtx_plan_time_range", "mtx_plan_time_ops",
 ]

@@ -59,6 +59,7 @@ class MtxLibrary:
         d.mtx_plan_run_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         d.mtx_plan_time.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
         d.mtx_plan_time_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        d.mtx_plan_time_ops.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float)]
         d.mtx_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
         if d.mtx_abi_version() != abi.ABI_VERSION:
             raise ModelError(f"{path}: ABI version {d.mtx_abi_version()} != {abi.ABI_VERSION}")

@@ -99,6 +99,13 @@ class Plan:
         self.lib.check(self.lib.mtx_plan_time_range(self._h, first, last, self._stream(stream), iters, C.byref(ms)), "mtx_plan_time_range")
         return float(ms.value)
 
+    def time_ops(self, op_indices, iters: int = 1, stream=None) -> float:
+        """summed in-context duration (ms) of the listed ops over `iters` eager runs of the whole plan"""
+        idx = (C.c_int * len(op_indices))(*[int(i) for i in op_indices])
+        ms = C.c_float(0.0)
+        self.lib.check(self.lib.mtx_plan_time_ops(self._h, self._stream(stream), idx, len(op_indices), iters, C.byref(ms)), "mtx_plan_time_ops")
+        return float(ms.value)
+
     def close(self):
         if self._h:
             self.lib.mtx_plan_destroy(self._h)
