@@ -15,8 +15,10 @@ Flow (reference line numbers):
     mask ANDed with its floor/ceil-clipped prompt box                                                     :1660-1750
  -> detection dicts; conjoined parents partitioned per child (core/image/conjoined.py)                    :1075-1260
  -> any SAM failure falls back to the detector's own masks                                                :1783-1813
-Not built: OSB text verification (`osb_text_verification`, needs the OSB text detector, §8 f3) and the
-disk cache of detections (out of scope).  Returns `(detections, text_free_boxes)` like the reference.
+ -> osb_text_verification: primary boxes grown to cover the OSB text boxes that belong to them, the same text boxes
+    steer the conjoined partition (text-safe cuts)                                                      :120-201, 1555-1571
+Not built: the disk cache of detections (out of scope; the OSB text model runs once per call).  Returns
+`(detections, text_free_boxes)` like the reference.
 """
 from typing import List, Optional, Tuple
 
@@ -62,6 +64,38 @@ def _ioa(a, b) -> float:
 
 IOA_THRESHOLD = 0.50
 IOA_OVERLAP_THRESHOLD = 0.5
+
+
+def expand_boxes_with_osb_text(image_cv, primary_boxes: torch.Tensor, model_manager, device, confidence: float, hf_token: str,
+                               verbose: bool):
+    """Grow each speech-bubble box to fully contain the OSB text boxes that meaningfully belong to it (reference
+    `_expand_boxes_with_osb_text`, :120-198).  Returns `(boxes, osb_text_boxes_np or None)`; any failure (model unavailable)
+    leaves the boxes untouched, as in the reference."""
+    if primary_boxes is None or len(primary_boxes) == 0:
+        return primary_boxes, None
+    try:
+        osb_model = model_manager.load_yolo_osbtext(token=hf_token)
+        res = osb_model(image_cv, conf=confidence, device=device, verbose=False, imgsz=640)[0]
+        osb_boxes = res.boxes.xyxy if res.boxes is not None else torch.tensor([])
+        if osb_boxes is None or len(osb_boxes) == 0:
+            return primary_boxes, None
+        pb_np, osb_np = primary_boxes.detach().cpu().numpy(), osb_boxes.detach().cpu().numpy()
+        for t_box in osb_np:
+            best_idx, best_inter = None, 0.0
+            for i, b_box in enumerate(pb_np):
+                inter = conjoined.box_intersection_area(t_box, b_box)
+                if inter > best_inter:
+                    best_inter, best_idx = inter, i
+            if best_idx is None or best_inter <= 0.0:
+                continue
+            b = pb_np[best_idx]
+            if not conjoined.text_box_belongs_to(t_box, b) or (t_box[0] >= b[0] and t_box[1] >= b[1] and t_box[2] <= b[2] and t_box[3] <= b[3]):
+                continue
+            pb_np[best_idx] = [min(b[0], t_box[0]), min(b[1], t_box[1]), max(b[2], t_box[2]), max(b[3], t_box[3])]
+        return torch.tensor(pb_np, device=primary_boxes.device, dtype=primary_boxes.dtype), osb_np
+    except Exception as e:
+        log_message(f"OSB text verification skipped: {e}", verbose=verbose)
+        return primary_boxes, None
 
 
 def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, verbose: bool = False, device=None,
@@ -147,6 +181,9 @@ def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, 
         return detections, text_free_boxes
 
     grouping_primary_boxes = primary_boxes.clone()
+    osb_text_boxes_np = None
+    if osb_text_verification and len(primary_boxes) > 0:
+        primary_boxes, osb_text_boxes_np = expand_boxes_with_osb_text(bgr, primary_boxes, manager, device, confidence, osb_text_hf_token, verbose)
     conjoined_indices, simple_indices = [], list(range(len(primary_boxes)))
     if len(secondary_boxes) > 0 and conjoined_detection:
         conjoined_indices, simple_indices = box_ops.categorize_detections(grouping_primary_boxes, secondary_boxes, ioa_threshold=IOA_THRESHOLD)
@@ -163,7 +200,7 @@ def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, 
     def assemble(sam_masks):
         return conjoined.build_segmentation_detections(primary_boxes, grouping_primary_boxes, primary_sources, primary_results, primary_model,
                                                        secondary_boxes, secondary_sources, secondary_results, simple_indices, conjoined_indices,
-                                                       img_h, img_w, conjoined_confidence, osb_text_boxes_np=None, verbose=verbose,
+                                                       img_h, img_w, conjoined_confidence, osb_text_boxes_np=osb_text_boxes_np, verbose=verbose,
                                                        sam_masks=sam_masks, synthetic_conjoined_groups=synthetic_groups)
 
     if seg_model not in ("sam2", "sam3"):

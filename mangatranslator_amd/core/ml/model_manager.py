@@ -34,6 +34,7 @@ class ModelType(Enum):
     YOLO_SPEECH_BUBBLE_2 = "yolo_speech_bubble_2"
     SAM2 = "sam2"
     RTDETR_CONJOINED_BUBBLE = "rtdetr_conjoined_bubble"
+    YOLO_OSBTEXT = "yolo_osbtext"
     FLUX_KONTEXT_SDNQ_PIPELINE = "flux_kontext_sdnq_pipeline"
 
 
@@ -136,6 +137,7 @@ class ModelManager:
                 ModelType.YOLO_SPEECH_BUBBLE_2: model_dir / "yolo" / "manga109-segmentation-bubble.safetensors",
                 ModelType.SAM2: model_dir / "sam" / "sam2.1-hiera-large",
                 ModelType.RTDETR_CONJOINED_BUBBLE: model_dir / "rtdetr" / "comic-text-and-bubble-detector",
+                ModelType.YOLO_OSBTEXT: model_dir / "yolo" / "animetext_yolov12x.safetensors",
                 ModelType.FLUX_KONTEXT_SDNQ_PIPELINE: model_dir / "flux" / "kontext",
             }
             self.hf_token = None
@@ -171,6 +173,10 @@ class ModelManager:
         self.unload_model(ModelType.UPSCALE, force_gc=False, verbose=verbose)
         self.unload_model(ModelType.UPSCALE_LITE, force_gc=False, verbose=verbose)
         empty_cache(self.device)
+
+    def unload_ocr_models(self, verbose: bool = False):
+        """reference :1391-1396 (the OCR recognisers themselves are outside the hot path; only the OSB text detector slot lives here)"""
+        self.unload_model(ModelType.YOLO_OSBTEXT, verbose=verbose)
 
     def unload_flux_kontext_sdnq_models(self, verbose: bool = False):
         self.unload_model(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE, verbose=verbose)
@@ -223,6 +229,16 @@ class ModelManager:
             self.models[mt] = model
             log_message(f"YOLO bubble detector loaded ({mt.value}).", verbose=verbose)
             return model
+
+    def load_yolo_osbtext(self, token: Optional[str] = None, verbose: bool = False):
+        """OSB text detector (YOLO12x "AnimeText", reference :780-808).  The YOLO12 graph (A2C2f area attention) is not built in
+        this round: the loader raises ModelError, and the callers degrade exactly as the reference does when the
+        gated checkpoint cannot be fetched — `detect_outside_text` falls back to the secondary detector's text_free boxes
+        (ocr_detection.py:447-468) and `detect_speech_bubbles` skips OSB text verification (detection.py:196-198)."""
+        with self._lock:
+            if self.is_loaded(ModelType.YOLO_OSBTEXT):
+                return self.models[ModelType.YOLO_OSBTEXT]
+            raise ModelError("OSB text detector (YOLO12x) is not available in this build; using the text_free fallback")
 
     def load_rtdetr_conjoined_bubble(self, verbose: bool = False):
         """RT-DETR-v2 secondary detector as libmtx_hip graphs with the YOLO-shaped call of the reference's adapter

@@ -234,11 +234,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 //   * Next tile: global -> registers at the top of the iteration, registers -> LDS after PV (one barrier
 //     per tile, LDS-only: s_waitcnt lgkmcnt(0); s_barrier).
 constexpr int AB_KV = 64;
+// scheduling fence for LDS reads and MFMAs only: VALU / SALU / VMEM may still move across it
+#ifdef MTX_EMU
+#define MTX_SCHED_FENCE() ((void)0)
+#else
+#define MTX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x0476)
+#endif
 constexpr int AB_QB = 256;
 
 // One K/V tile of the main loop.  STAGE is a compile-time constant so every LDS address is
 // (loop-invariant VGPR) + (immediate offset).
-template <typename T, int DP, int STAGE, bool RAGGED>
+// PF > 0 pins the order of the fragment reads: the K fragments of S^T run PF k-steps ahead of the MFMAs that consume them
+// and the V^T fragments of PV 2*PF steps ahead (left alone, the compiler issues each pair of reads right in front of its two
+// MFMAs, so every pair pays the LDS round trip).
+template <typename T, int DP, int STAGE, bool RAGGED, int PF = 0>
 __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
                                                 float& m_raw, float& lsum, const float c, const float thr,
                                                 const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
@@ -251,13 +260,32 @@ __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typen
   // ---- S^T = K Q^T: sacc[kb][r] = key 32*kb + (r&3) + 8*(r>>2) + 4*hi of this tile, query l31 ----------------
   f32x16 sacc[2];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (PF == 0) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
-      sacc[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : sacc[kb]);
+      for (int kb = 0; kb < 2; ++kb) {
+        const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
+        sacc[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : sacc[kb]);
+      }
+  } else {
+    v8 kf[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < PF && ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) kf[ks][kb] = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
+    MTX_SCHED_FENCE();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + PF < KS) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) kf[ks + PF][kb] = *reinterpret_cast<const v8*>(Ks + kaddr[ks + PF] + kb * 32 * ROWB);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sacc[kb] = Mma32<T>::mfma(kf[ks][kb], qf[ks], ks == 0 ? zero : sacc[kb]);
+      MTX_SCHED_FENCE();
     }
+  }
 
   if (RAGGED) {                                // last tile of a ragged sequence: keys >= kvalid do not exist
 #pragma unroll
@@ -292,20 +320,42 @@ __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typen
     }
 
   // ---- O^T += V^T P^T: k-slot (hi, j) of step (kb, s2) is key 32*kb + 16*s2 + 8*(j>>2) + 4*hi + (j&3) ------------
+  if (PF == 0) {
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
-        const v4 lo = lds_read_tr16<T>(a);
-        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-        v8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
-        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
-      }
+        for (int d = 0; d < DB; ++d) {
+          const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
+          const v4 lo = lds_read_tr16<T>(a);
+          const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+          v8 vf;
+          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+          vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
+          oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
+        }
+  } else {
+    constexpr int NS = 4 * DB, PV = 2 * PF;      // step = (kb, s2, d)
+    v8 vf[NS];
+    auto vread = [&](int st) {
+      const int d = st % DB, ks2 = st / DB;      // ks2 = kb*2 + s2: 16-key step of the tile
+      const unsigned char* a = Vs + vaddr[d] + ks2 * 16 * ROWB;
+      const v4 lo = lds_read_tr16<T>(a);
+      const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+      vf[st][0] = lo[0]; vf[st][1] = lo[1]; vf[st][2] = lo[2]; vf[st][3] = lo[3];
+      vf[st][4] = hv[0]; vf[st][5] = hv[1]; vf[st][6] = hv[2]; vf[st][7] = hv[3];
+    };
+#pragma unroll
+    for (int st = 0; st < PV && st < NS; ++st) vread(st);
+    MTX_SCHED_FENCE();
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      if (st + PV < NS) vread(st + PV);
+      oacc[st % DB] = Mma32<T>::mfma(vf[st], pb[st / DB / 2][(st / DB) & 1], oacc[st % DB]);
+      MTX_SCHED_FENCE();
+    }
+  }
 }
 
 // The two halves of a tile step, for the staggered schedule: the score phase (S^T MFMAs + row maximum + rare rescale)
@@ -413,8 +463,10 @@ __device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, uns
 // S^T MFMAs of its tile, the other turns its scores into probabilities and runs the PV MFMAs — separated by a workgroup
 // barrier per half tile.  Tile t+1 is written to LDS at the start of the (global) segment in which group 0 runs its
 // value phase of tile t and group 1 its score phase of tile t: by then both have finished with that buffer's tile t-1.
-template <typename T, int DP, bool STAG>
+template <typename T, int DP, int MODE>
 __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
+  constexpr bool STAG = MODE == 1;
+  constexpr int PF = MODE >= 2 ? MODE : 0;          // MODE 2, 3, 4: lockstep loop with fragment reads pinned PF k-steps ahead
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
   constexpr int KS = DP / 16;                  // k-steps of S^T
@@ -517,25 +569,25 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
     // full tiles, two per iteration so the LDS stage is a compile-time constant
     for (; t + 2 < ntiles; t += 2) {
       load_tile(t + 1);
-      attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      attn_mma32_tile<T, DP, 0, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
       store_tile(1);
       MTX_LDS_BARRIER();
       load_tile(t + 2);
-      attn_mma32_tile<T, DP, 1, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      attn_mma32_tile<T, DP, 1, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
       store_tile(0);
       MTX_LDS_BARRIER();
     }
     // one or two tiles left; the very last one may be ragged
     if (t + 2 == ntiles) {
       load_tile(t + 1);
-      attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      attn_mma32_tile<T, DP, 0, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
       store_tile(1);
       MTX_LDS_BARRIER();
-      if (kv_last < AB_KV) attn_mma32_tile<T, DP, 1, true>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
-      else attn_mma32_tile<T, DP, 1, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      if (kv_last < AB_KV) attn_mma32_tile<T, DP, 1, true, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
+      else attn_mma32_tile<T, DP, 1, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
     } else {
-      if (kv_last < AB_KV) attn_mma32_tile<T, DP, 0, true>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
-      else attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      if (kv_last < AB_KV) attn_mma32_tile<T, DP, 0, true, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
+      else attn_mma32_tile<T, DP, 0, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
     }
   } else {
     // group 0 (waves 0-3) runs  [score(t)] B [feed, value(t)] B ;  group 1 the same shifted by one barrier:
@@ -1132,8 +1184,11 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     const unsigned g = p.n_full + (total - p.n_full) * p.split;
     // one barrier per tile is the default; "stag" = the half-tile staggered schedule (measured equal: 1092 vs 1091 TFLOP/s —
     // the two waves of a SIMD already drift into complementary phases between barriers)
-    if (e && e[0] == 's') MTX_LAUNCH((attn_mma32_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
-    else MTX_LAUNCH((attn_mma32_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
+    if (e && e[0] == 's') MTX_LAUNCH((attn_mma32_kernel<T, 128, 1>), dim3(g), dim3(512), 0, stream, p);
+    else if (e && e[0] == '2') MTX_LAUNCH((attn_mma32_kernel<T, 128, 2>), dim3(g), dim3(512), 0, stream, p);
+    else if (e && e[0] == '3') MTX_LAUNCH((attn_mma32_kernel<T, 128, 3>), dim3(g), dim3(512), 0, stream, p);
+    else if (e && e[0] == '4') MTX_LAUNCH((attn_mma32_kernel<T, 128, 4>), dim3(g), dim3(512), 0, stream, p);
+    else MTX_LAUNCH((attn_mma32_kernel<T, 128, 0>), dim3(g), dim3(512), 0, stream, p);
     if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
     return MTX_OK;
   }

@@ -447,6 +447,123 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
 }
 
+// Ring schedule: the same 8-wave ping-pong, but the 128 KB of LDS is a ring of four K = 32 slices (64-byte rows,
+// chunk ^ ((row >> 2) & 3): 16 consecutive rows of one logical chunk cover a 256-byte bank row exactly once) instead
+// of two K = 64 stages.  A slice's slot is released after its two k-steps, so slice s+3 is DMA'd while slice s is
+// consumed and the wait before the barrier that publishes slice s+1 is a COUNTED vmcnt(8): the two youngest slices
+// stay in flight and every piece has two slice-times (~2k cycles) to land instead of the ~0.5-1k of the two-stage
+// loops, whose vmcnt(0) per K tile exposes HBM latency (ablation: no DMA 1460-1567 vs 1141 TFLOP/s).
+//   WAR: slot (s+3)&3 held slice s-1; both groups finished those reads (lgkmcnt(0) at the start of their C(s-1, 1))
+//        at least one barrier before anyone's L(s, 1), where the refill is issued.
+//   RAW: every wave counts its own pieces of slice s+1 down before the barrier that precedes group 0's L(s+1, 0):
+//        group 0 at the end of C(s, 1), group 1 at the end of L(s, 1) (the same physical barrier).
+constexpr int G2R_SLOT = (G2_BM + G2_BN) * 64;      // 32 KB
+#ifdef MTX_EMU
+#define MTX_WAIT_VMEM_N(n) ((void)0)
+#else
+#define MTX_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
+template <typename T, int ACT>
+__global__ __launch_bounds__(512) void gemm256r_kernel(GemmParams p) {
+  typedef typename Traits<T>::v8 v8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * G2R_SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wm = wv >> 2, wn = wv & 3, grp = wv >> 2;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  long m0, n0;
+  gemm256_tile_origin(p, lin, m0, n0);
+  const long bz = blockIdx.y;
+  const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
+  const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
+  T* Cp = reinterpret_cast<T*>(p.c) + (size_t)bz * p.c_bs;
+
+  // DMA plan: piece i (0..3) of wave wv fills slot rows (i*8 + wv)*16 .. +15 (1 KB); lane -> row base + lane/4, position lane%4
+  const T* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 8 + wv) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    // rows past M / N are clamped to the last valid row: they only feed outputs the epilogue never stores
+    if (row < G2_BM) { const long m = m0 + row < p.m ? m0 + row : p.m - 1; src[i] = A + (size_t)m * p.lda + c * 8; }
+    else { const long n = n0 + row - G2_BM < p.n ? n0 + row - G2_BM : p.n - 1; src[i] = W + (size_t)n * p.ldw + c * 8; }
+  }
+  auto issue = [&](long s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(src[i] + s * 32, smem + (int)(s & 3) * G2R_SLOT + (i * 8 + wv) * 1024);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // byte offsets of this lane's fragment rows inside a slot, for chunk 0; the chunk term is XORed in per k-step
+  int aoff[4], woff[2], asw[4], wsw[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + l31; aoff[i] = r * 64; asw[i] = (r >> 2) & 3; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int r = G2_BM + wn * 64 + j * 32 + l31; woff[j] = r * 64; wsw[j] = (r >> 2) & 3; }
+
+  const long ns = p.k / 32;
+  // the wait that makes slice `nxt` visible: everything but the pieces of the slices after it (at most two) has landed
+  auto wait_slice = [&](long nxt) {
+    if (nxt + 2 < ns) MTX_WAIT_VMEM_N(8);
+    else if (nxt + 1 < ns) MTX_WAIT_VMEM_N(4);
+    else MTX_WAIT_VMEM();
+  };
+  issue(0);
+  if (ns > 1) issue(1);
+  if (ns > 2) issue(2);
+  wait_slice(0);
+  __syncthreads();
+  if (grp == 1) G2_BAR();
+  for (long s = 0; s < ns; ++s) {
+    const unsigned char* st = smem + (int)(s & 3) * G2R_SLOT;
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) {
+      const int ch = 2 * ksl + hi;
+      v8 af[4], wf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + woff[j] + ((ch ^ wsw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + aoff[i] + ((ch ^ asw[i]) << 4));
+      if (ksl == 1 && s + 3 < ns) issue(s + 3);
+      if (ksl == 1 && grp == 1) wait_slice(s + 1);
+      G2_BAR();
+#ifndef MTX_EMU
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+#ifndef MTX_EMU
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      if (ksl == 1 && grp == 0) wait_slice(s + 1);
+      G2_BAR();
+    }
+  }
+  if (grp == 0) G2_BAR();
+
+  __syncthreads();
+  gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
+}
+template <typename T>
+static void launch_gemm256r(const GemmParams& p, dim3 grid, void* stream) {
+  switch (p.act) {
+    case MTX_ACT_NONE: MTX_LAUNCH((gemm256r_kernel<T, MTX_ACT_NONE>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_SILU: MTX_LAUNCH((gemm256r_kernel<T, MTX_ACT_SILU>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256r_kernel<T, MTX_ACT_GELU_TANH>), grid, dim3(512), 0, stream, p); break;
+    default: MTX_LAUNCH((gemm256r_kernel<T, -1>), grid, dim3(512), 0, stream, p); break;
+  }
+}
+
 // Wave-specialised variant: 8 MFMA waves (never touch VMEM) + 4 DMA waves (one per SIMD) that stream the next
 // K tile into the other LDS stage while the MFMA waves work.  An LDS-DMA instruction costs its issuing wave
 // 60-180 cycles; in the kernel above that time is taken from the matrix pipe (both waves of a SIMD issue their
@@ -723,6 +840,7 @@ static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream) {
   if (!allk) {
     if (mode == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
     else if (mode == 'p') launch_gemm256_pp<T, true>(p, grid, stream);
+    else if (mode == 'r') launch_gemm256r<T>(p, grid, stream);
     else launch_gemm256ws<T>(p, grid, stream);
   }
   if (tail || allk) {

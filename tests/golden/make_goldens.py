@@ -308,8 +308,12 @@ def detection_flow_inputs():
                  [30.0, 40.0, 100.0, 110.0]]                                            # S5: bubble nested in S0 (contained removal)
     sconf = [0.8, 0.78, 0.6, 0.5, 0.9, 0.4]
     scls = [0, 0, 2, 0, 1, 0]
+    osb_text = [[35.0, 45.0, 95.0, 105.0], [112.0, 50.0, 180.0, 100.0],          # one text block in each half of the conjoined P0
+                [250.0, 60.0, 300.0, 100.0],                                          # sticks out of P1 -> P1 grows
+                [60.0, 170.0, 110.0, 210.0], [125.0, 175.0, 175.0, 215.0],            # P2 / P3 texts (the first reaches into the overlap)
+                [5.0, 280.0, 60.0, 310.0]]                                            # belongs to no bubble
     return dict(H=320, W=320, primary=primary, pconf=pconf, secondary=secondary, sconf=sconf, scls=scls,
-                names={"0": "bubble", "1": "text_bubble", "2": "text_free"})
+                names={"0": "bubble", "1": "text_bubble", "2": "text_free"}, osb_text=osb_text, osb_conf=[0.9, 0.88, 0.8, 0.7, 0.75, 0.6])
 
 
 def gen_detection_flow():
@@ -387,13 +391,146 @@ def gen_detection_flow():
                                    neighbors=[list(b) for b in d["conjoined_neighbor_bboxes"]] if "conjoined_neighbor_bboxes" in d else None) for d in dets])
         DET_MASKS[seg] = np.packbits(np.stack([np.asarray(d["sam_mask"]) > 0 for d in dets]))
     out["prompts"] = prompts_seen[0]
+    # osb_text_verification: the OSB text model's boxes grow the bubble boxes (:120-198) and steer the conjoined cuts; the reference
+    # reads them back from its detection cache (:298-314), so the stub cache really stores here
+    store = {}
+    om = Callable_(lambda *a, **k: [types.SimpleNamespace(boxes=Boxes(inp["osb_text"], inp["osb_conf"], [0] * len(inp["osb_text"])))], {0: "text"})
+
+    class Paths(dict):
+        def __missing__(self, k):
+            return "osb.pt"
+
+    mgr.load_yolo_osbtext = lambda *a, **k: om
+    mgr.model_paths = Paths()
+    detection.get_cache = lambda: types.SimpleNamespace(get_yolo_cache_key=lambda im, path, conf: (str(path), conf), get_yolo_detection=store.get,
+                                                        set_yolo_detection=store.__setitem__, get_sam_cache_key=none, get_sam_masks=none, set_sam_masks=none)
+    n_before = len(prompts_seen)
+    dets, text_free = detection.detect_speech_bubbles(Path("page.png"), "yolo_2", confidence=0.6, device="cpu", seg_model="sam2",
+                                                      conjoined_detection=True, image_override=img, osb_text_verification=True)
+    out["sam2_osb_verify"] = dict(text_free=[[float(v) for v in b] for b in text_free], prompts=prompts_seen[n_before],
+                                  dets=[dict(bbox=list(d["bbox"]), confidence=float(d["confidence"]), cls=d["class"],
+                                             neighbors=[list(b) for b in d["conjoined_neighbor_bboxes"]] if "conjoined_neighbor_bboxes" in d else None) for d in dets])
+    DET_MASKS["sam2_osb_verify"] = np.packbits(np.stack([np.asarray(d["sam_mask"]) > 0 for d in dets]))
     return dict(inputs=inp, results=out)
 
 
 DET_MASKS = {}
 
 
+def osb_inputs():
+    """canned detector outputs for the OSB region golden (shared with tests/test_osb_regions.py through the json)"""
+    return dict(
+        W=400, H=300,
+        bubbles=[[20.3, 20.1, 140.2, 110.6], [200.4, 30.2, 330.1, 120.7]], bconf=[0.9, 0.8],
+        secondary=[[40.2, 200.4, 120.6, 270.1],        # S0 bubble the primary missed
+                   [250.5, 180.2, 380.3, 260.8],       # S1 text_free (a narration box)
+                   [205.1, 32.3, 328.2, 118.4],        # S2 text_free that is the bubble B1
+                   [50.0, 40.0, 90.0, 70.0]],          # S3 text_bubble (ignored)
+        sconf=[0.7, 0.6, 0.55, 0.9], scls=[0, 2, 2, 1],
+        names={"0": "bubble", "1": "text_bubble", "2": "text_free"},
+        osb=[[30.4, 30.6, 100.2, 80.3],                # T0 inside B0 -> belongs to a bubble
+             [210.7, 40.2, 300.9, 100.4],              # T1 inside B1, but B1 is a text_free region -> kept
+             [150.2, 130.6, 190.8, 150.3],             # T2 free-standing
+             [152.1, 132.2, 188.3, 148.9],             # T3 nested in T2 -> removed
+             [130.5, 60.1, 160.2, 90.7],               # T4 a third of it inside B0 -> belongs to B0
+             [135.3, 95.2, 185.6, 125.4],              # T5 5 % inside B0, centre outside -> kept
+             [160.9, 140.2, 200.1, 160.8],             # T6 close to T2
+             [45.6, 205.3, 110.2, 260.9],              # T7 inside the missed bubble S0
+             [300.2, 10.5, 300.9, 25.0]],              # T8 zero width after int() -> dropped by get_text_masks, shifting the pairing
+        oconf=[0.91, 0.82, 0.73, 0.64, 0.55, 0.86, 0.77, 0.68, 0.95])
+
+
+OSB_MASKS = {}
+
+
+def gen_osb():
+    """core/image/ocr_detection.py:189-808 — `detect_outside_text`, `get_text_masks`, `_group_text_boxes_spatially` driven by
+    canned detector outputs.  cv2 there is only the RGB<->BGR flip at image load."""
+    from core.image import ocr_detection as ref
+    inp = osb_inputs()
+    W, H = inp["W"], inp["H"]
+    ref.cv2 = types.SimpleNamespace(cvtColor=lambda a, code: np.ascontiguousarray(a[..., ::-1]), COLOR_RGB2BGR=4, COLOR_BGR2RGB=4)
+
+    class Boxes:
+        def __init__(self, xyxy, conf, cls):
+            self.xyxy, self.conf, self.cls = torch.tensor(xyxy, dtype=torch.float32).reshape(-1, 4), torch.tensor(conf, dtype=torch.float32), torch.tensor(cls, dtype=torch.float32)
+
+        def __len__(self):
+            return len(self.xyxy)
+
+    class Model:
+        def __init__(self, boxes, names):
+            self.boxes, self.names, self.calls = boxes, names, 0
+
+        def __call__(self, *a, **k):
+            self.calls += 1
+            return [types.SimpleNamespace(boxes=self.boxes)]
+
+    names = {int(k): v for k, v in inp["names"].items()}
+    bub = Model(Boxes(inp["bubbles"], inp["bconf"], [0, 0]), {0: "speech_bubble"})
+    sec = Model(Boxes(inp["secondary"], inp["sconf"], inp["scls"]), names)
+    osb = Model(Boxes(inp["osb"], inp["oconf"], [0] * len(inp["osb"])), {0: "text"})
+    state = dict(osb_ok=True)
+
+    def load_osb(token=None):
+        if not state["osb_ok"]:
+            raise RuntimeError("gated repo")
+        return osb
+
+    class Paths(dict):
+        def __missing__(self, k):
+            return "model.pt"
+
+    mgr = types.SimpleNamespace(load_yolo_speech_bubble=lambda *a, **k: bub, load_rtdetr_conjoined_bubble=lambda *a, **k: sec,
+                                load_yolo_osbtext=load_osb, model_paths=Paths(), device="cpu")
+    none = lambda *a, **k: None
+    ref.get_model_manager = lambda: mgr
+    ref.get_cache = lambda: types.SimpleNamespace(get_yolo_cache_key=none, get_yolo_detection=none, set_yolo_detection=none)
+    ref.get_best_device = lambda: "cpu"
+    det = ref.OutsideTextDetector(device="cpu")
+    img = Image.fromarray((np.random.default_rng(5).random((H, W, 3)) * 255).astype(np.uint8))
+    ser = lambda res: [dict(bbox=[float(v) for v in b], conf=float(c)) for b, c in res]
+    out = {}
+    res_a = det.detect_outside_text("page.png", image_override=img)
+    out["detect_all_models"] = ser(res_a)
+    provided = [dict(bbox=inp["bubbles"][0]), inp["bubbles"][1], dict(bbox=None), [1, 2, 3]]
+    out["detect_provided_bubbles"] = ser(det.detect_outside_text("page.png", image_override=img, existing_bubbles=provided, text_free_boxes=[inp["secondary"][1]]))
+    out["detect_text_free_only"] = ser(det.detect_outside_text("page.png", image_override=img, existing_bubbles=provided, text_free_only=True))
+    state["osb_ok"] = False
+    out["detect_osb_model_unavailable"] = ser(det.detect_outside_text("page.png", image_override=img, min_area_ignore_ratio=0.01))
+    state["osb_ok"] = True
+    out["detect_no_bubbles_given_empty_list"] = ser(det.detect_outside_text("page.png", image_override=img, existing_bubbles=[]))
+
+    def ser_groups(tag, groups):
+        rows = []
+        for gi, g in enumerate(groups or []):
+            OSB_MASKS[f"{tag}_{gi}_combined"] = np.packbits(g["combined_mask"])
+            OSB_MASKS[f"{tag}_{gi}_individual"] = np.packbits(np.stack(g["individual_masks"]))
+            rows.append(dict(bbox=g["bbox"], original_bbox=g["original_bbox"], mask_indices=[int(i) for i in g["mask_indices"]],
+                             confidence=float(g["confidence"]), n_individual=len(g["individual_masks"])))
+        return rows
+
+    # the un-filtered list keeps the degenerate box T8, so the pairing shift of get_text_masks is exercised too
+    order = [0, 1, 2, 8, 3, 4, 5, 6, 7]          # the degenerate box in the middle
+    raw = [(np.asarray(inp["osb"][i], np.float32), float(inp["oconf"][i])) for i in order]
+    masks = {}
+    for tag, (ew, eh, ratio, results) in dict(plain=(0.0, 0.0, 0.02, res_a), grown=(0.1, 0.2, 0.06, res_a), wide=(0.5, 0.5, 0.3, res_a),
+                                              raw_shift=(0.05, 0.05, 0.08, raw)).items():
+        groups, _ = det.get_text_masks("page.png", ew, eh, ratio, image_override=img, existing_results=results)
+        masks[tag] = dict(args=[ew, eh, ratio], source="raw" if results is raw else "detect_all_models", raw_order=order, groups=ser_groups(tag, groups))
+    big = Image.new("RGB", (2000, 1800), "white")
+    far = [(np.asarray([10.5, 20.5, 110.2, 90.9], np.float32), 0.9), (np.asarray([1700.1, 1650.2, 1900.7, 1760.3], np.float32), 0.7),
+           (np.asarray([60.0, 60.0, 200.0, 130.0], np.float32), 0.5)]
+    groups, _ = det.get_text_masks("page.png", 0.0, 0.0, 2.0, image_override=big, existing_results=far)
+    masks["too_large"] = dict(args=[0.0, 0.0, 2.0], size=[2000, 1800], results=[dict(bbox=[float(v) for v in b], conf=c) for b, c in far],
+                              groups=ser_groups("too_large", groups))
+    out["empty"] = det.get_text_masks("page.png", image_override=img, existing_results=[])[0]
+    return dict(inputs=inp, provided=[p if not isinstance(p, dict) else p for p in provided], detect=out, masks=masks)
+
+
 if __name__ == "__main__":
+    json.dump(gen_osb(), open(HERE / "osb_regions.json", "w"))
+    np.savez_compressed(HERE / "osb_regions_masks.npz", **OSB_MASKS)
     json.dump(gen_detection_flow(), open(HERE / "detection_flow.json", "w"))
     np.savez_compressed(HERE / "detection_flow_masks.npz", **DET_MASKS)
     cj_meta, cj_arrays = gen_conjoined()

@@ -33,7 +33,7 @@ class _Model:
         return [self.result]
 
 
-@pytest.mark.parametrize("seg", ["sam2", "yolo"])
+@pytest.mark.parametrize("seg", ["sam2", "yolo", "sam2_osb_verify"])
 def test_flow_matches_reference(emu_lib, monkeypatch, seg):
     inp = GOLD["inputs"]
     H, W = inp["H"], inp["W"]
@@ -63,14 +63,17 @@ def test_flow_matches_reference(emu_lib, monkeypatch, seg):
             ms.append(((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 <= 1.0)
         return types.SimpleNamespace(pred_masks=torch.from_numpy(np.stack(ms))[:, None].float())
 
+    om = _Model(types.SimpleNamespace(boxes=_Boxes(inp["osb_text"], inp["osb_conf"], [0] * len(inp["osb_text"]))), {0: "text"})
     mgr = types.SimpleNamespace(load_yolo_speech_bubble=lambda *a, **k: pm, load_rtdetr_conjoined_bubble=lambda *a, **k: sm,
-                                load_sam2=lambda *a, **k: (Proc(), sam), device="cpu")
+                                load_sam2=lambda *a, **k: (Proc(), sam), load_yolo_osbtext=lambda *a, **k: om, device="cpu")
     monkeypatch.setattr(detection, "get_model_manager", lambda: mgr)
+    verify = seg == "sam2_osb_verify"
+    seg_arg = "sam2" if verify else seg
     import mangatranslator_amd.hip.lib as libmod
     monkeypatch.setattr(libmod, "_lib", emu_lib)          # the conjoined partition's native chamfer transform
     img = Image.fromarray((np.random.default_rng(3).random((H, W, 3)) * 255).astype(np.uint8))
-    dets, text_free = detection.detect_speech_bubbles(Path("page.png"), "yolo_2", confidence=0.6, device="cpu", seg_model=seg,
-                                                      conjoined_detection=True, image_override=img)
+    dets, text_free = detection.detect_speech_bubbles(Path("page.png"), "yolo_2", confidence=0.6, device="cpu", seg_model=seg_arg,
+                                                      conjoined_detection=True, image_override=img, osb_text_verification=verify)
     want = GOLD["results"][seg]
     assert [[float(v) for v in b] for b in text_free] == want["text_free"]
     assert len(dets) == len(want["dets"])
@@ -81,6 +84,23 @@ def test_flow_matches_reference(emu_lib, monkeypatch, seg):
         assert np.array_equal(np.asarray(d["sam_mask"]) > 0, m)
     if seg == "sam2":
         assert prompts[0] == GOLD["results"]["prompts"]
+    if verify:
+        assert prompts[0] == want["prompts"]             # P1 was grown to cover the text block sticking out of it
+
+
+def test_osb_verification_skipped_without_model(monkeypatch, emu_lib):
+    """no OSB text model (this build's loader raises): boxes stay as detected, like the reference's `OSB text verification skipped`"""
+    inp = GOLD["inputs"]
+    H, W = inp["H"], inp["W"]
+    pm = _Model(types.SimpleNamespace(boxes=_Boxes(inp["primary"][:2], inp["pconf"][:2], [0, 0]), masks=None, orig_shape=(H, W)), {0: "speech_bubble"})
+
+    def boom(*a, **k):
+        raise RuntimeError("not staged")
+    mgr = types.SimpleNamespace(load_yolo_speech_bubble=lambda *a, **k: pm, load_rtdetr_conjoined_bubble=boom, load_sam2=boom, load_yolo_osbtext=boom, device="cpu")
+    monkeypatch.setattr(detection, "get_model_manager", lambda: mgr)
+    img = Image.fromarray(np.zeros((H, W, 3), np.uint8))
+    dets, _ = detection.detect_speech_bubbles(Path("p.png"), image_override=img, osb_text_verification=True)
+    assert [list(d["bbox"]) for d in dets] == [[20, 30, 190, 120], [210, 20, 290, 90]]
 
 
 def test_no_secondary_model_falls_back(monkeypatch, emu_lib):

@@ -89,12 +89,27 @@ def test_attention_long_sequence_kernel(emu_lib):
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1024, sk=448, d=128, qmul=3.0)      # 7 tiles: one left
 
 
+def test_attention_long_sequence_prefetch_variant(emu_lib, monkeypatch):
+    """MTX_ATTN_KERNEL=2: the same loop with the K / V^T fragment reads pinned ahead of their MFMAs"""
+    monkeypatch.setenv("MTX_ATTN_KERNEL", "2")
+    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0)
+
+
 def test_gemm_256_tile_kernel(emu_lib, monkeypatch):
     """the 256 x 256 LDS-DMA kernel (normally reserved for >= 160 tiles) on ragged small problems"""
     monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
     oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
     oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False)
     oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=4160, with_res=True)          # K > 4096: the one-barrier loop with threaded DMA
+
+
+def test_gemm_256_ring_schedule(emu_lib, monkeypatch):
+    """the four-slot K = 32 ring (counted vmcnt) schedule: 1, 2, 3 and many slices, ragged M / N"""
+    monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
+    monkeypatch.setenv("MTX_GEMM256_SCHED", "ring")
+    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=64, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
+    oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=192, batch=2, alpha=0.5, with_bias=False)
+    oc.check_gemm(emu_lib, abi.BF16, m=260, n=250 // 8 * 8, k=448, with_res=True)
 
 
 def test_flux_prep_kernels(emu_lib):

@@ -42,7 +42,7 @@ def attn_ab(T, heads=24, d=128, rounds=5, iters=20):
     o = pb.buf((T, D), torch.bfloat16)
     pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D)
     plan = pb.build(); plan.run(); torch.cuda.synchronize()
-    res = {"mma32": [], "stag": [], "pipe": [], "w64": []}
+    res = {"mma32": [], "2": [], "3": [], "4": []}
     for r in range(rounds):
         for mode in res:
             os.environ["MTX_ATTN_KERNEL"] = mode
@@ -80,7 +80,7 @@ def gemm_ab(M, N, K, rounds=5, iters=20):
     w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
     pb.gemm(a, w, M, N, K)
     plan = pb.build(); plan.run(); torch.cuda.synchronize()
-    res = {"ws": [], "pingpong": [], "lockstep": []}
+    res = {"ring": [], "pingpong": [], "lockstep": []}
     for r in range(rounds):
         for mode in res:
             os.environ["MTX_GEMM256_SCHED"] = mode
