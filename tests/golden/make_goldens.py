@@ -528,7 +528,75 @@ def gen_osb():
     return dict(inputs=inp, provided=[p if not isinstance(p, dict) else p for p in provided], detect=out, masks=masks)
 
 
+def gen_osb_stage():
+    """core/outside_text_processor.py:217-1691 — `prepare_outside_text_work` + `finish_outside_text_work` on the synthetic page of
+    tests/golden/osb_page.py.  Stand-ins: the inpainter (deterministic), cv2.dilate (a zero-padded maximum filter == cv2's default
+    constant border), and the cv2 calls of the rendered-text colour probe (:1096-1165: identity / no contours — that probe only feeds
+    the text renderer); `_build_outside_text_data` / `_apply_inpaint_render_metadata` (translation payload) are replaced by no-ops."""
+    from scipy import ndimage
+    sys.path.insert(0, str(HERE))
+    import osb_page
+    from core import outside_text_processor as ref
+    from core.image import ocr_detection as refdet
+
+    refdet.cv2 = types.SimpleNamespace(cvtColor=lambda a, code: np.ascontiguousarray(a[..., ::-1]), COLOR_RGB2BGR=4, COLOR_BGR2RGB=4)
+    ref.cv2 = types.SimpleNamespace(
+        dilate=lambda img, k, iterations=1: ndimage.maximum_filter(np.asarray(img), size=k.shape[0], mode="constant", cval=0),
+        cvtColor=lambda a, code: np.asarray(a), morphologyEx=lambda a, op, k: a, erode=lambda a, k, iterations=1: a,
+        findContours=lambda a, m, c: ([], None), contourArea=lambda c: 0.0, drawContours=lambda *a, **k: None,
+        COLOR_RGB2LAB=0, COLOR_RGB2HSV=1, MORPH_CLOSE=3, RETR_EXTERNAL=0, CHAIN_APPROX_SIMPLE=2, FILLED=-1)
+    ref._build_outside_text_data = lambda **kw: []
+    ref._apply_inpaint_render_metadata = lambda *a, **k: None
+    ref.FluxKontextInpainter = osb_page.StandInInpainter
+
+    class Boxes:
+        def __init__(self, xyxy, conf):
+            self.xyxy, self.conf, self.cls = torch.tensor(xyxy, dtype=torch.float32).reshape(-1, 4), torch.tensor(conf, dtype=torch.float32), torch.zeros(len(conf))
+
+    osb_model = lambda *a, **k: [types.SimpleNamespace(boxes=Boxes(osb_page.OSB, osb_page.OSB_CONF))]
+
+    def boom(*a, **k):
+        raise RuntimeError("bubbles are provided: no bubble detector may run")
+
+    class Paths(dict):
+        def __missing__(self, k):
+            return "model.pt"
+
+    mgr = types.SimpleNamespace(load_yolo_speech_bubble=boom, load_rtdetr_conjoined_bubble=boom, load_yolo_osbtext=lambda token=None: osb_model,
+                                model_paths=Paths(), device="cpu")
+    none = lambda *a, **k: None
+    refdet.get_model_manager = lambda: mgr
+    refdet.get_cache = lambda: types.SimpleNamespace(get_yolo_cache_key=none, get_yolo_detection=none, set_yolo_detection=none)
+    refdet.get_best_device = lambda: "cpu"
+    page = osb_page.make_page()
+    out = {}
+    for tag, method, over in [("flux", "flux_kontext", {}), ("opencv", "opencv", {}), ("none", "none", {}),
+                              ("flux_no_coordinator", "flux_kontext", dict(_no_coord=True)),
+                              ("min_area", "flux_kontext", dict(min_area_ignore_ratio=0.012, osb_render_expansion_narrow_multiplier=1.0))]:
+        over = dict(over)
+        coord = None if over.pop("_no_coord", False) else batch_coordinator.BatchRequestCoordinator(2)
+        cfg = osb_page.make_config(coord, method, **over)
+        osb_page.StandInInpainter.calls = []
+        work = ref.prepare_outside_text_work(page, cfg, "page.png", "PNG", bubble_data=osb_page.bubble_data(), text_free_boxes=osb_page.TEXT_FREE,
+                                             panels=osb_page.PANELS)
+        prep = dict(results=[[[int(v) for v in b], float(c)] for b, c in work.outside_text_results],
+                    raw=[[[float(v) for v in b], float(c)] for b, c in work.raw_outside_text_results],
+                    colors={",".join(map(str, k)): bool(v) for k, v in work.original_text_colors.items()},
+                    groups=[dict(bbox=g["bbox"], original_bbox=g["original_bbox"], mask_indices=[int(i) for i in g["mask_indices"]]) for g in work.mask_groups],
+                    bubble_mask_sum=int(work.total_bubble_mask.sum()))
+        STAGE_ARRAYS[f"{tag}_bubble_mask"] = np.packbits(work.total_bubble_mask)
+        final, _ = ref.finish_outside_text_work(work)
+        STAGE_ARRAYS[f"{tag}_final"] = np.asarray(final.convert("RGB"))
+        out[tag] = dict(method=method, over=over, prepare=prep, calls=sorted(osb_page.StandInInpainter.calls, key=lambda c: c["seed"]))
+    return out
+
+
+STAGE_ARRAYS = {}
+
+
 if __name__ == "__main__":
+    json.dump(gen_osb_stage(), open(HERE / "osb_stage.json", "w"))
+    np.savez_compressed(HERE / "osb_stage_arrays.npz", **STAGE_ARRAYS)
     json.dump(gen_osb(), open(HERE / "osb_regions.json", "w"))
     np.savez_compressed(HERE / "osb_regions_masks.npz", **OSB_MASKS)
     json.dump(gen_detection_flow(), open(HERE / "detection_flow.json", "w"))

@@ -1,0 +1,80 @@
+"""The OSB stage of a page (second half): `prepare_outside_text_work` + `finish_outside_text_work` vs goldens
+produced by running the REFERENCE functions (core/outside_text_processor.py:217-1691) on the synthetic page of
+tests/golden/osb_page.py with the same deterministic stand-in inpainter — render-expanded boxes, background-brightness probes,
+region groups, the dilated bubble guard mask, which regions go to FLUX (with which seed / clip box / mask) and which are
+flat-filled with which colour, wave scheduling, failure fallbacks, and the final page — bit-exact."""
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+G = Path(__file__).resolve().parent / "golden"
+sys.path.insert(0, str(G))
+import osb_page  # noqa: E402
+
+from mangatranslator_amd.core import outside_text_processor as otp  # noqa: E402
+from mangatranslator_amd.core.batch_coordinator import BatchRequestCoordinator  # noqa: E402
+from mangatranslator_amd.core.image import ocr_detection  # noqa: E402
+from mangatranslator_amd.utils.exceptions import ValidationError  # noqa: E402
+
+GOLD = json.loads((G / "osb_stage.json").read_text())
+ARR = np.load(G / "osb_stage_arrays.npz")
+
+
+class _Boxes:
+    def __init__(self, xyxy, conf):
+        self.xyxy, self.conf, self.cls = torch.tensor(xyxy, dtype=torch.float32).reshape(-1, 4), torch.tensor(conf, dtype=torch.float32), torch.zeros(len(conf))
+
+
+@pytest.fixture
+def rig(monkeypatch):
+    def boom(*a, **k):
+        raise RuntimeError("bubbles are provided: no bubble detector may run")
+    osb_model = lambda *a, **k: [types.SimpleNamespace(boxes=_Boxes(osb_page.OSB, osb_page.OSB_CONF))]
+    mgr = types.SimpleNamespace(load_yolo_speech_bubble=boom, load_rtdetr_conjoined_bubble=boom, load_yolo_osbtext=lambda token=None: osb_model, device="cpu")
+    monkeypatch.setattr(ocr_detection, "get_model_manager", lambda: mgr)
+    monkeypatch.setattr(otp, "FluxKontextInpainter", osb_page.StandInInpainter)
+    return osb_page.make_page()
+
+
+@pytest.mark.parametrize("tag", list(GOLD))
+def test_stage_matches_reference(rig, tag):
+    gold = GOLD[tag]
+    over = dict(gold["over"])
+    coord = None if tag == "flux_no_coordinator" else BatchRequestCoordinator(2)
+    cfg = osb_page.make_config(coord, gold["method"], **over)
+    osb_page.StandInInpainter.calls = []
+    work = otp.prepare_outside_text_work(rig, cfg, "page.png", "PNG", bubble_data=osb_page.bubble_data(), text_free_boxes=osb_page.TEXT_FREE,
+                                         panels=osb_page.PANELS)
+    p = gold["prepare"]
+    assert [[[int(v) for v in b], float(c)] for b, c in work.outside_text_results] == p["results"]
+    assert [[[float(v) for v in b], float(c)] for b, c in work.raw_outside_text_results] == p["raw"]
+    assert {",".join(map(str, k)): bool(v) for k, v in work.original_text_colors.items()} == p["colors"]
+    assert [dict(bbox=g["bbox"], original_bbox=g["original_bbox"], mask_indices=[int(i) for i in g["mask_indices"]]) for g in work.mask_groups] == p["groups"]
+    assert np.array_equal(np.packbits(work.total_bubble_mask), ARR[f"{tag}_bubble_mask"])
+    final, data = otp.finish_outside_text_work(work)
+    assert data == []
+    assert sorted(osb_page.StandInInpainter.calls, key=lambda c: c["seed"]) == gold["calls"]
+    assert np.array_equal(np.asarray(final.convert("RGB")), ARR[f"{tag}_final"])
+
+
+def test_disabled_and_refused_options(rig):
+    cfg = osb_page.make_config(None, enabled=False)
+    assert otp.prepare_outside_text_work(rig, cfg, "p.png", "PNG") is None
+    assert otp.process_outside_text(rig, cfg, "p.png", "PNG") == (rig, [])
+    with pytest.raises(ValidationError):
+        otp.prepare_outside_text_work(rig, osb_page.make_config(None, enable_page_number_filtering=True), "p.png", "PNG")
+
+
+def test_ring_statistics():
+    ring = np.full((100, 3), 250, np.uint8)
+    ring[:4] = 0                                         # 4 % outliers: still solid, snapped to white
+    assert otp.ring_statistics(ring) == (True, (255, 255, 255))
+    ring[:6] = 0                                         # 6 %: not solid
+    assert otp.ring_statistics(ring)[0] is False
+    assert otp.ring_statistics(np.full((30, 3), 9, np.uint8)) == (True, (0, 0, 0))
+    assert otp.ring_statistics(np.tile(np.array([[120, 130, 140]], np.uint8), (30, 1))) == (True, (120, 130, 140))
