@@ -159,11 +159,27 @@ def main():
         flux.set_prompt_embeds(torch.randn(512, 4096, generator=g), torch.randn(768, generator=g))
         inpainter = FluxKontextInpainter(device=device, num_inference_steps=args.inpaint_steps, backend="sdnq")
         inpainter.pipeline = flux
+        # the OSB stage (core/outside_text_processor.py) builds its own inpainter and asks the manager for the pipeline
+        from mangatranslator_amd.core.ml.model_manager import ModelType, get_model_manager
+        from mangatranslator_amd.core.batch_coordinator import BatchRequestCoordinator
+        from mangatranslator_amd.core import outside_text_processor as otp
+        import types as _types
+        get_model_manager().models[ModelType.FLUX_KONTEXT_SDNQ_PIPELINE] = flux
+        osb_cfg = _types.SimpleNamespace(
+            device=device, yolo_model_path=None, request_coordinator=BatchRequestCoordinator(1),
+            detection=_types.SimpleNamespace(conjoined_confidence=0.35, bubble_detector_model="yolo_2"),
+            outside_text=_types.SimpleNamespace(      # the reference's OutsideTextConfig defaults (core/config.py:126-173), Kontext selected
+                enabled=True, enable_page_number_filtering=False, min_area_ignore_ratio=0.0, seed=1, huggingface_token="",
+                inpainting_method="flux_kontext", flux_backend="sdnq", flux_low_vram=False, flux_num_inference_steps=args.inpaint_steps,
+                flux_group_regions=False, flux_residual_diff_threshold=0.15, osb_confidence=0.5, osb_text_free_only=False,
+                bbox_expansion_percent_width=0.1, bbox_expansion_percent_height=0.1, osb_render_expansion_narrow_multiplier=1.0,
+                osb_render_expansion_tiny_multiplier=1.0, osb_render_expansion_aspect_ratio_threshold=0.4,
+                osb_render_expansion_area_ratio_threshold=0.005, text_box_proximity_ratio=0.02))
 
     # ---- synthetic pages, resident in HBM -----------------------------------------------------------------
     W_, H_ = args.width, args.height
     pool = 2
-    pages, page_boxes, page_pil, page_masks = [], [], [], []
+    pages, page_boxes, page_pil, page_masks, page_text_boxes = [], [], [], [], []
     for i in range(pool):
         pg, boxes, regions = make_page(rank * 1000 + i, W_, H_, bubbles=args.boxes, osb_regions=args.regions)
         pages.append(torch.from_numpy(pg).to(device))
@@ -174,6 +190,9 @@ def main():
             m_ = np.zeros((H_, W_), bool); m_[y0:y1, x0:x1] = True
             ms_.append(m_)
         page_masks.append(ms_)
+        # the outside-text detections of the page: the text inside each gradient block (block inset by 10 px, so the 2 px ring the
+        # solid-border test samples lies on the gradient and the region goes to FLUX)
+        page_text_boxes.append([[x0 + 10.0, y0 + 10.0, x1 - 10.0, y1 - 10.0] for (x0, y0, x1, y1) in regions])
     torch.cuda.synchronize()
 
     outs = {}
@@ -193,10 +212,16 @@ def main():
         if sam is not None:      # prompts: the generator's ground-truth boxes (fixed unit count)
             outs["segment"] = sam.segment(pages[k], page_boxes[k])
         if inpainter is not None:
-            img = page_pil[k]
-            for m_ in page_masks[k]:
-                img = inpainter.inpaint_mask(img, m_, seed=1)
-            outs["inpaint"] = img
+            # the reference's OSB stage end to end (prepare + finish): bubbles from the segment stage guard the fills, the text boxes
+            # arrive as text_free detections (the OSB text model's stand-in: ground truth, like the SAM prompts), each region is
+            # classified by its border ring and the non-solid ones run through FLUX in waves
+            bubbles_ = [{"bbox": tuple(float(v) for v in b)} for b in page_boxes[k]]
+            if "segment" in outs and outs["segment"] is not None:
+                host_masks = outs["segment"].cpu().numpy()
+                for b_, m_ in zip(bubbles_, host_masks):
+                    b_["sam_mask"] = m_
+            outs["inpaint"], _ = otp.process_outside_text(page_pil[k], osb_cfg, "page.png", "PNG", bubble_data=bubbles_,
+                                                          text_free_boxes=page_text_boxes[k])
         if upscaler is not None:
             outs["upscale"] = upscaler.upscale_u8(pages[k])
 
@@ -208,6 +233,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if flux is not None and args.warmup > 0:      # every page must have sent its R regions through FLUX (none classified as solid / dropped)
+        assert flux.calls == args.warmup * args.regions, f"expected {args.warmup * args.regions} FLUX calls in warm-up, saw {flux.calls}"
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -389,6 +389,7 @@ class FluxKontextHip:
         self._graph = graph and not dit.lib.is_simulator
         self._lock = threading.Lock()
         self._embeds = None
+        self.calls = 0                # pipeline invocations (benchmarks assert the expected number of FLUX regions ran)
 
     def set_prompt_embeds(self, prompt_embeds: torch.Tensor, pooled: torch.Tensor):
         """T5 / CLIP embeddings of the (fixed) prompt — computed once per process by the caller."""
@@ -402,6 +403,7 @@ class FluxKontextHip:
     @torch.no_grad()
     def __call__(self, image=None, width=None, height=None, num_inference_steps=8, guidance_scale=2.5, generator=None,
                  output_type="pt", max_area=None, prompt_embeds=None, pooled_prompt_embeds=None, latents=None, **kw):
+        self.calls += 1
         if prompt_embeds is None:
             prompt_embeds, pooled_prompt_embeds, _ = self.encode_prompt()
         pe = prompt_embeds.reshape(-1, prompt_embeds.shape[-1])

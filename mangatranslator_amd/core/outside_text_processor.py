@@ -66,8 +66,10 @@ def background_is_dark(pixels: np.ndarray) -> bool:
     """2-means over the box's pixels; the larger cluster is the background; BT.601 luma < 128 (reference :558-582, same
     scikit-learn call so the clustering is the reference's own)"""
     from sklearn.cluster import KMeans
+    from threadpoolctl import threadpool_limits
     kmeans = KMeans(n_clusters=2, random_state=42, n_init=10)
-    kmeans.fit(pixels)
+    with threadpool_limits(limits=1):        # ~20 k points: one thread takes ~40 ms, the default pool spins for > 1 s on a many-core host
+        kmeans.fit(pixels)
     unique, counts = np.unique(kmeans.labels_, return_counts=True)
     bg = kmeans.cluster_centers_[unique[np.argmax(counts)]]
     return bool(0.299 * bg[0] + 0.587 * bg[1] + 0.114 * bg[2] < 128)

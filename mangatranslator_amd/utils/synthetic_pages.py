@@ -1,6 +1,6 @@
 """Synthetic manga pages for benchmarks and tests: seed = 1234 + page_index,
 RGB uint8, near-white paper, 6 screentone rectangles, B elliptical speech bubbles with dark
-strokes inside, R outside-text blocks on a non-solid gradient background.  Returns the page and
+strokes inside, R outside-text blocks on a non-solid gradient background (placed clear of the bubbles).  Returns the page and
 the generator's ground-truth bubble boxes (used in place of detector output when checkpoints are
 absent, so every stage processes a fixed unit count)."""
 import numpy as np
@@ -33,7 +33,10 @@ def make_page(index: int, width: int = 1024, height: int = 1536, bubbles: int = 
     regions = []
     for _ in range(osb_regions):
         rw, rh = 200 * width // 1024, 120 * width // 1024
-        x0, y0 = int(rng.integers(0, width - rw)), int(rng.integers(0, height - rh))
+        for _try in range(64):     # clear of the bubbles and earlier blocks (a text box inside a bubble is dialogue, not outside text)
+            x0, y0 = int(rng.integers(0, width - rw)), int(rng.integers(0, height - rh))
+            if not any(x0 < b[2] + 16 and b[0] - 16 < x0 + rw and y0 < b[3] + 16 and b[1] - 16 < y0 + rh for b in boxes + regions):
+                break
         grad = np.linspace(90, 230, rw)[None, :, None] + np.linspace(-25, 25, rh)[:, None, None]
         page[y0:y0 + rh, x0:x0 + rw] = grad
         for _ in range(14):

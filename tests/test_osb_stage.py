@@ -78,3 +78,40 @@ def test_ring_statistics():
     assert otp.ring_statistics(ring)[0] is False
     assert otp.ring_statistics(np.full((30, 3), 9, np.uint8)) == (True, (0, 0, 0))
     assert otp.ring_statistics(np.tile(np.array([[120, 130, 140]], np.uint8), (30, 1))) == (True, (120, 130, 140))
+
+
+def test_synthetic_bench_page_sends_its_block_to_flux(monkeypatch):
+    """the benchmark's page generator: the text box inside the gradient block fails the solid-border test and is
+    inpainted through the manager's Kontext pipeline; pixels outside the text box's clip rectangle are untouched"""
+    from PIL import Image
+    from mangatranslator_amd.core.ml.model_manager import ModelType, get_model_manager
+    from mangatranslator_amd.utils.synthetic_pages import make_page
+    W_, H_ = 512, 768
+    pg, boxes, regions = make_page(3, W_, H_, bubbles=8, osb_regions=1)
+    x0, y0, x1, y1 = regions[0]
+    assert not any(x0 < b[2] and b[0] < x1 and y0 < b[3] and b[1] < y1 for b in boxes)        # blocks are placed clear of the bubbles
+    text_boxes = [[x0 + 5.0, y0 + 5.0, x1 - 5.0, y1 - 5.0]]
+
+    class Pipe:
+        calls = 0
+
+        def encode_prompt(self, **kw):
+            return torch.zeros(512, 8), torch.zeros(8), None
+
+        def __call__(self, image=None, width=None, height=None, **kw):
+            Pipe.calls += 1
+            return types.SimpleNamespace(images=[torch.full((3, height, width), 0.5)])
+
+    mgr = get_model_manager()
+    monkeypatch.setitem(mgr.models, ModelType.FLUX_KONTEXT_SDNQ_PIPELINE, Pipe())
+    cfg = osb_page.make_config(BatchRequestCoordinator(1), osb_render_expansion_narrow_multiplier=1.0, text_box_proximity_ratio=0.02, seed=1)
+    cfg.device = torch.device("cpu")
+    page = Image.fromarray(pg)
+    out, _ = otp.process_outside_text(page, cfg, "page.png", "PNG", bubble_data=[{"bbox": tuple(float(v) for v in b)} for b in boxes],
+                                      text_free_boxes=text_boxes)
+    assert Pipe.calls == 1
+    a, b = np.asarray(page), np.asarray(out)
+    changed = np.argwhere((a != b).any(-1))
+    assert len(changed) > 0
+    cx0, cy0, cx1, cy1 = [int(v) for v in text_boxes[0]]
+    assert changed[:, 1].min() >= cx0 and changed[:, 1].max() < cx1 and changed[:, 0].min() >= cy0 and changed[:, 0].max() < cy1
