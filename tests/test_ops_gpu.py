@@ -98,6 +98,7 @@ def test_image_convert(hip_lib):
                                  dict(batch=1, heads=2, sq=1100, sk=320, d=128), dict(batch=1, heads=2, sq=1100, sk=449, d=128)])
 def test_attention_long_sequence_kernel(hip_lib, cfg):
     oc.check_attention(hip_lib, abi.BF16, **cfg)
+    oc.check_attention(hip_lib, abi.F16, **cfg)
 
 
 @pytest.mark.parametrize("kernel", ["2", "3", "stag", "pipe"])
@@ -106,7 +107,6 @@ def test_attention_long_sequence_variants(hip_lib, monkeypatch, kernel):
     monkeypatch.setenv("MTX_ATTN_KERNEL", kernel)
     oc.check_attention(hip_lib, abi.BF16, batch=1, heads=3, sq=2100, sk=2100, d=128, qmul=4.0)
     oc.check_attention(hip_lib, abi.F16, batch=1, heads=2, sq=1100, sk=449, d=128)
-    oc.check_attention(hip_lib, abi.F16, **cfg)
 
 
 @pytest.mark.parametrize("cfg", [dict(m=8652, n=3072, k=3072, with_res=True, with_gate=True), dict(m=4100, n=9216, k=1024, act=abi.ACT_GELU_TANH),
