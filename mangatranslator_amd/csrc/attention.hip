@@ -1119,23 +1119,166 @@ __global__ __launch_bounds__(256) void attn_w64_kernel(AttnParams p) {
   }
 }
 
-// merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
+// =====================================================================================================
+// Two-workgroups-per-CU variant of the long-sequence kernel: 4 waves x 32 query rows = 128 queries per workgroup, 64 KB of LDS
+// (two K|V stages), at most 256 registers, so TWO workgroups share a CU and every SIMD hosts one wave of each.  The per-tile
+// barrier of the 8-wave kernel re-aligns the two waves of a SIMD at every tile, so their MFMA phases (2 x 1024 cycles per tile
+// pair) and their VALU softmax phases (2 x ~900) add up instead of overlapping (measured: MFMA busy 53 %, tile time = the sum).
+// Two independent workgroups have no common barrier: they start at different times and drift, and one's matrix phase runs under
+// the other's softmax.  Price: every K/V tile is staged twice per CU (once per workgroup).
+//   * K/V tiles arrive by LDS-DMA (buffer_load ... lds, swizzles applied on the source address): no staging registers, no ds_write;
+//     tile t+1 is put in flight right after the barrier that ends tile t-1 and waited for (vmcnt(0)) before the barrier that ends t.
+//   * compute of a tile = attn_mma32_tile (same fragment layouts, same deferred-max softmax).
+constexpr int AD_QB = 128;
 template <typename T, int DP>
+__global__ __launch_bounds__(256, 2) void attn_duo_kernel(AttnParams p) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  static_assert(DP == 128, "swizzles are written for 256-byte rows");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B];          // 64 KB: two K|V stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  unsigned vb, part = 0, nparts = 1;
+  if (blockIdx.x < p.n_full) vb = xcd_remap(blockIdx.x, p.n_full);
+  else { const unsigned i = blockIdx.x - p.n_full; vb = p.n_full + i / p.split; part = i % p.split; nparts = p.split; }
+  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
+  const long b = bh / p.heads, h = bh % p.heads;
+  const long q0 = qb * AD_QB + wv * 32;
+  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
+
+  v8 qf[KS];
+  {
+    const long qr = q0 + l31;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
+      qf[ks] = __builtin_bit_cast(v8, raw);
+    }
+  }
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_raw = -1.0e30f, lsum = 0.f;
+  const float c = p.scale_log2;
+  const float thr = 8.0f / c;
+
+  // LDS-DMA plan: one wave instruction moves 1 KB = 4 rows of 256 B; wave wv owns rows 16*wv .. 16*wv+15 of K and of V.
+  // lane -> (row = base + lane/16, slot lane%16); the slot holds global chunk slot ^ swizzle(row)
+  const BufView kbv = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
+  const BufView vbv = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
+  unsigned kvoff[4], vvoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wv * 16 + i * 4 + (lane >> 4), slot = lane & 15;
+    kvoff[i] = (unsigned)((row * p.k_ss + ((slot ^ (row & 15)) << 3)) * sizeof(T));
+    vvoff[i] = (unsigned)((row * p.v_ss + ((slot ^ ((row & 3) << 2)) << 3)) * sizeof(T));
+  }
+  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
+  auto dma_tile = [&](long t, int stage) {
+    unsigned char* Ks = smem + stage * 2 * TILE_B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      buf_load16_lds(kbv, kvoff[i], (unsigned)t * k_step, Ks + (wv * 16 + i * 4) * ROWB);
+      buf_load16_lds(vbv, vvoff[i], (unsigned)t * v_step, Ks + TILE_B + (wv * 16 + i * 4) * ROWB);
+    }
+  };
+
+  int kaddr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
+  int vaddr[DB];
+  {
+    const int ti = lane & 15, g1 = (lane >> 4) & 1;
+    const int vrow = hi * 4 + (ti >> 2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+      vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
+  }
+
+  const long ntiles_all = (p.sk + AB_KV - 1) / AB_KV;
+  const long t_begin = part * ntiles_all / nparts, ntiles = (part + 1) * ntiles_all / nparts;
+  const long kv_last = ntiles == ntiles_all ? p.sk - (ntiles_all - 1) * AB_KV : AB_KV;
+  dma_tile(t_begin, 0);
+  MTX_WAIT_VMEM();
+  __syncthreads();
+#define ATTN_DUO_SYNC() { MTX_WAIT_VMEM(); MTX_LDS_BARRIER(); }
+  long t = t_begin;
+  for (; t + 2 < ntiles; t += 2) {             // two full tiles per iteration: the stage is a compile-time constant
+    dma_tile(t + 1, 1);
+    attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+    ATTN_DUO_SYNC();
+    dma_tile(t + 2, 0);
+    attn_mma32_tile<T, DP, 1, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+    ATTN_DUO_SYNC();
+  }
+  if (t + 2 == ntiles) {                       // two tiles left, the second possibly ragged
+    dma_tile(t + 1, 1);
+    attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+    ATTN_DUO_SYNC();
+    if (kv_last < AB_KV) attn_mma32_tile<T, DP, 1, true>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
+    else attn_mma32_tile<T, DP, 1, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+  } else {
+    if (kv_last < AB_KV) attn_mma32_tile<T, DP, 0, true>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
+    else attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+  }
+#undef ATTN_DUO_SYNC
+
+  if (nparts > 1) {                            // key-split tail: unnormalised O^T (fp32), row maximum and row sum for the merge kernel
+    const unsigned slot = blockIdx.x - p.n_full;
+    const int row = wv * 32 + l31;
+    float* PO = p.part_o + ((size_t)slot * AD_QB + row) * DP;
+    const float lrow = half_sum(lsum);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {oacc[d][g * 4 + 0], oacc[d][g * 4 + 1], oacc[d][g * 4 + 2], oacc[d][g * 4 + 3]};
+        *reinterpret_cast<f32x4*>(PO + d * 32 + g * 8 + hi * 4) = o;
+      }
+    if (hi == 0) { p.part_ml[((size_t)slot * AD_QB + row) * 2] = m_raw; p.part_ml[((size_t)slot * AD_QB + row) * 2 + 1] = lrow; }
+    return;
+  }
+  const float l = half_sum(lsum);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const long qr = q0 + l31;
+  if (qr < p.sq) {
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[d][g * 4 + r] * inv);
+        *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
+      }
+  }
+}
+
+// merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
+template <typename T, int DP, int QB = AB_QB>
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
-  const unsigned tail = blockIdx.x / 8, band = blockIdx.x % 8;      // tail query block, 32-row band
+  constexpr unsigned BANDS = QB / 32;
+  const unsigned tail = blockIdx.x / BANDS, band = blockIdx.x % BANDS;      // tail query block, 32-row band
   const unsigned vb = p.n_full + tail;
   const long bh = vb / p.qblocks, qb = vb % p.qblocks;
   const long b = bh / p.heads, h = bh % p.heads;
   T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
   for (int idx = threadIdx.x; idx < 32 * (DP / 8); idx += 256) {
     const int row = band * 32 + idx / (DP / 8), ch = idx % (DP / 8);
-    const long qr = qb * AB_QB + row;
+    const long qr = qb * QB + row;
     if (qr >= p.sq) continue;
     float M = -1.0e30f;
-    for (unsigned s = 0; s < p.split; ++s) { const float m = p.part_ml[((size_t)(tail * p.split + s) * AB_QB + row) * 2]; M = m > M ? m : M; }
+    for (unsigned s = 0; s < p.split; ++s) { const float m = p.part_ml[((size_t)(tail * p.split + s) * QB + row) * 2]; M = m > M ? m : M; }
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
     for (unsigned s = 0; s < p.split; ++s) {
-      const size_t base = (size_t)(tail * p.split + s) * AB_QB + row;
+      const size_t base = (size_t)(tail * p.split + s) * QB + row;
       const float w = fast_exp2((p.part_ml[base * 2] - M) * p.scale_log2);
       L += w * p.part_ml[base * 2 + 1];
       const float* po = p.part_o + base * DP + ch * 8;
@@ -1169,6 +1312,20 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     p.qblocks = (unsigned)((p.sq + AB_QB - 1) / AB_QB);
     const unsigned total = (unsigned)(p.batch * p.heads) * p.qblocks;
     const char* e = getenv("MTX_ATTN_KERNEL");           // A/B switch: "pipe" = the S^T-pipelined LDS-DMA variant (no tail split)
+    if (e && e[0] == 'd') {                              // "duo": 128-query workgroups, two per CU
+      p.qblocks = (unsigned)((p.sq + AD_QB - 1) / AD_QB);
+      const unsigned total2 = (unsigned)(p.batch * p.heads) * p.qblocks, slots = 2u * (unsigned)attn_num_cus(), rem2 = total2 % slots;
+      const unsigned nt = (unsigned)((p.sk + AB_KV - 1) / AB_KV);
+      unsigned split2 = (rem2 > 0 && total2 > slots) ? slots / rem2 : 1;
+      if (split2 > 8) split2 = 8;
+      if (split2 > nt / 2) split2 = nt / 2;
+      const char* ns2 = getenv("MTX_ATTN_NOSPLIT");
+      if (split2 < 2 || p.part_o == nullptr || (ns2 && ns2[0] == '1')) { p.n_full = total2; p.split = 1; }
+      else { p.n_full = total2 - rem2; p.split = split2; }
+      MTX_LAUNCH((attn_duo_kernel<T, 128>), dim3(p.n_full + (total2 - p.n_full) * p.split), dim3(256), 0, stream, p);
+      if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128, AD_QB>), dim3((total2 - p.n_full) * (AD_QB / 32)), dim3(256), 0, stream, p);
+      return MTX_OK;
+    }
     if (e && e[0] == 'p') { MTX_LAUNCH((attn_pipe_kernel<T, 128>), dim3(total), dim3(512), 0, stream, p); return MTX_OK; }
     if (e && e[0] == 'w') { MTX_LAUNCH((attn_w64_kernel<T, 128>), dim3(total), dim3(256), 0, stream, p); return MTX_OK; }
     // one workgroup per CU at a time: a partial last wave of `rem` query blocks leaves most of the chip idle for a

@@ -101,7 +101,7 @@ def test_attention_long_sequence_kernel(hip_lib, cfg):
     oc.check_attention(hip_lib, abi.F16, **cfg)
 
 
-@pytest.mark.parametrize("kernel", ["2", "3", "stag", "pipe"])
+@pytest.mark.parametrize("kernel", ["2", "3", "stag", "pipe", "duo"])
 def test_attention_long_sequence_variants(hip_lib, monkeypatch, kernel):
     """the A/B schedules of the long-sequence kernel (MTX_ATTN_KERNEL) compute the same attention"""
     monkeypatch.setenv("MTX_ATTN_KERNEL", kernel)

@@ -95,6 +95,13 @@ def test_attention_long_sequence_prefetch_variant(emu_lib, monkeypatch):
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0)
 
 
+def test_attention_long_sequence_duo_variant(emu_lib, monkeypatch):
+    """MTX_ATTN_KERNEL=duo: 128-query workgroups (two per CU), K/V by LDS-DMA; ragged last tile, key-split tail (3 simulated CUs)"""
+    monkeypatch.setenv("MTX_ATTN_KERNEL", "duo")
+    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0)
+    oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=320, d=128)
+
+
 def test_gemm_256_tile_kernel(emu_lib, monkeypatch):
     """the 256 x 256 LDS-DMA kernel (normally reserved for >= 160 tiles) on ragged small problems"""
     monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
