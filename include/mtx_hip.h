@@ -110,7 +110,12 @@ typedef struct mtx_attn_args {
    * chip, the left-over query blocks are split over key ranges and merged from fp32 partials kept here
    * (MTX_ATTN_WORKSPACE_BYTES is always enough); NULL = never split */
   void* workspace; int64_t workspace_bytes;
+  int32_t flags;                 /* MTX_ATTN_* bits */
 } mtx_attn_args;
+/* q already carries scale * log2(e) (folded into the producer, e.g. the pre-scaled rotary table of MTX_EW_QK_NORM_ROPE): `scale`
+ * is ignored, scores are used as base-2 logits as they come out of the matrix pipe.  The long-sequence kernel then seeds its score
+ * accumulators with minus the running maximum and needs no per-score multiply-add. */
+#define MTX_ATTN_Q_PRESCALED 1
 #define MTX_ATTN_WORKSPACE_BYTES (256 * (256 * 128 * 4 + 256 * 2 * 4))
 
 /* row-wise normalisation over the last dim C of [rows, C] (row stride ld):
@@ -150,7 +155,10 @@ typedef enum mtx_ew_kind {
   MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
                              i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then
                              rotary on interleaved pairs with b = fp32 [rows][d] cos|sin table laid out as
-                             [rows][2][d/2]: (x0, x1) -> (x0*cos - x1*sin, x1*cos + x0*sin)            */
+                             [rows][2][d/2]: (x0, x1) -> (x0*cos - x1*sin, x1*cos + x0*sin).
+                             i1 > 0: heads >= i1 use the second gamma vector (fused q|k slices); with ldb > 0 the heads
+                             < i1 (the q slice) read their table at b + ldb floats instead — a copy pre-multiplied by
+                             the attention scale * log2(e), see MTX_ATTN_Q_PRESCALED                    */
 } mtx_ew_kind;
 
 typedef struct mtx_ew_args {

@@ -180,7 +180,12 @@ class FluxDiTHip:
         ctx_in = pb.buf((t_txt, cfg["joint_dim"]), self.tdt)      # prompt embeddings
         mod = pb.buf((self.n_vec, D), self.tdt)
         ids = np.concatenate([np.zeros((t_txt, 3), np.float32)] + [image_ids(h2, w2, k) for k in range(1 + n_ref)])
-        cs = pb.hold(torch.from_numpy(rope_table(ids, cfg["axes_dim"])).to(self.device).contiguous())     # [T, 2, hd/2]
+        # rotary tables [2][T, 2, hd/2]: plain (k heads) and pre-multiplied by softmax scale * log2(e) (q heads), so q leaves the
+        # norm+rope kernel as base-2 logit factors after its ONE rounding and the attention kernel spends no VALU slot on scaling
+        tab = torch.from_numpy(rope_table(ids, cfg["axes_dim"]))
+        q_fold = (1.0 / math.sqrt(hd)) * 1.4426950408889634
+        cs2 = pb.hold(torch.stack([tab, tab * q_fold]).to(self.device).contiguous())
+        cs = cs2[0]
         x = pb.buf((T, D), self.tdt)
         nrm = pb.buf((T, D), self.tdt)
         qkv = pb.buf((T, 3 * D), self.tdt)
@@ -201,13 +206,13 @@ class FluxDiTHip:
             e = abi.EwArgs()
             e.a, e.b, e.s, e.y = v.ptr, cs[r0:].data_ptr(), gamma_qk.data_ptr(), v.ptr
             e.n, e.h, e.w, e.c = 1, 1, r1 - r0, 2 * D
-            e.lda, e.ldb, e.ldy, e.lds = ld, 0, ld, 0
+            e.lda, e.ldb, e.ldy, e.lds = ld, T * hd, ld, 0
             e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 0, 1e-6, hd, H, self.dtype
             pb._add(abi.OP_EW, e, label)
 
         def attention(out_t, out_ld, label):
             pb.attention(qkv, qkv, qkv, out_t, 1, H, T, T, hd, (0, 3 * D, hd), (0, 3 * D, hd), (0, 3 * D, hd), (0, out_ld, hd),
-                         1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label)
+                         1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True)
 
         for i, B in enumerate(self.blocks):
             b0 = i * 12

@@ -26,6 +26,7 @@ struct AttnParams {
   // blocks are cut into `split` key ranges each and merged from the partials (unnormalised O^T, running max, sum)
   unsigned n_full, split;
   float* part_o; float* part_ml;
+  int prescaled;                 // q carries scale * log2(e): scale_log2 == 1
 };
 
 constexpr int AT_KV = 64;      // keys per tile
@@ -358,6 +359,125 @@ __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typen
   }
 }
 
+// Bias variant of the tile step: Q arrives pre-multiplied by scale * log2(e) and the S^T accumulators START at minus the running
+// maximum (`minit`, a persistent 16-register tuple that only changes when the maximum is refreshed), so the matrix pipe delivers
+// s*c - M directly and the softmax needs no per-score fused multiply-add: exp2 straight from the accumulator (32 VALU issue slots
+// per wave and tile saved out of ~135).  `M` is in log2 units; the first tile always refreshes (M starts at 0, not -inf, so the
+// accumulation keeps its precision).
+// NOMAX: the row maximum is not computed on the hot path at all.  With M folded into the accumulator the only thing a stale M can
+// do is let exp2 grow large, and fp32 / bf16 keep their relative precision while it does; the tile's partial row sums (which are
+// needed anyway) flag the danger zone (> 2^40, inf or nan), and only then — and on the first tile — the exact maximum is taken and
+// the tile's probabilities are recomputed.
+template <typename T, int DP, int STAGE, bool RAGGED, bool NOMAX = false>
+__device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
+                                               float& M, float& lsum, f32x16& minit, bool& first,
+                                               const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
+  const unsigned char* Vs = Ks + TILE_B;
+  f32x16 sacc[2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
+      if (ks == 0) Mma32Pinned<T>::set_from(sacc[kb], kf, qf[ks], minit);
+      else sacc[kb] = Mma32<T>::mfma(kf, qf[ks], sacc[kb]);
+    }
+  if (RAGGED) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) sacc[kb][r] = -1.0e30f;
+  }
+  v8 pb[2][2];
+  if (!NOMAX) {
+    float tmax = fmaxf(sacc[0][0], sacc[1][0]);       // relative to M
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
+    tmax = half_max(tmax);
+    if (first || __any(tmax > 8.0f)) {
+      const float delta = first ? tmax : fmaxf(tmax, 0.f);     // the first tile sets M to its own maximum (may be negative)
+      const float alpha = fast_exp2(-delta);
+      M += delta;
+      lsum *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) minit[r] = -M;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
+      first = false;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(sacc[kb][r]);
+        lsum += pv;
+        pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
+      }
+  } else {
+    float tsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(sacc[kb][r]);
+        tsum += pv;
+        pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
+      }
+    if (first || __any(!(tsum < 1.0e12f))) {          // 2^40: far from fp32 overflow, catches inf / nan as well
+      float tmax = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
+      tmax = half_max(tmax);
+      const float delta = first ? tmax : fmaxf(tmax, 0.f);
+      const float alpha = fast_exp2(-delta);
+      M += delta;
+      lsum *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) minit[r] = -M;
+      tsum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(sacc[kb][r] - delta);
+          tsum += pv;
+          pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
+        }
+      first = false;
+    }
+    lsum += tsum;
+  }
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
+        const v4 lo = lds_read_tr16<T>(a);
+        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+        v8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
+        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
+      }
+}
+
 // The two halves of a tile step, for the staggered schedule: the score phase (S^T MFMAs + row maximum + rare rescale)
 // and the value phase (exponentials -> P, PV MFMAs).  The scores stay in registers across the barrier between them.
 template <typename T, int DP, int STAGE, bool RAGGED>
@@ -466,7 +586,8 @@ __device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, uns
 template <typename T, int DP, int MODE>
 __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   constexpr bool STAG = MODE == 1;
-  constexpr int PF = MODE >= 2 ? MODE : 0;          // MODE 2, 3, 4: lockstep loop with fragment reads pinned PF k-steps ahead
+  constexpr int PF = (MODE >= 2 && MODE <= 4) ? MODE : 0;          // MODE 2, 3, 4: lockstep loop with fragment reads pinned PF k-steps ahead
+  constexpr bool BIAS = MODE == 5 || MODE == 6;     // MODE 5: Q pre-scaled, S^T accumulators start at -max (attn_bias_tile); 6: and no max on the hot path
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
   constexpr int KS = DP / 16;                  // k-steps of S^T
@@ -499,6 +620,10 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
       u32x4 raw = u32x4{0u, 0u, 0u, 0u};
       if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
       qf[ks] = __builtin_bit_cast(v8, raw);
+      if (BIAS) {                              // Q <- Q * scale * log2(e), rounded back to the storage type
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(to_f32(qf[ks][e]) * p.scale_log2);
+      }
     }
   }
 
@@ -507,9 +632,13 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-  float m_raw = -1.0e30f, lsum = 0.f;
+  float m_raw = BIAS ? 0.f : -1.0e30f, lsum = 0.f;     // BIAS: m_raw holds M in log2 units
   const float c = p.scale_log2;
   const float thr = 8.0f / c;                  // refresh the max when a row's tile max grows by > 2^8
+  f32x16 minit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
+  bool first = true;
 
   // ---- global -> register staging through buffer descriptors (no per-load predicates, no 64-bit VALU math)
   const BufView kb_ = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
@@ -562,6 +691,8 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   const long t_begin = part * ntiles_all / nparts, ntiles = (part + 1) * ntiles_all / nparts;    // this workgroup's key tiles
   const long kv_last = ntiles == ntiles_all ? p.sk - (ntiles_all - 1) * AB_KV : AB_KV;     // valid keys in its last tile
   if (!STAG) {
+#define ATTN_TILE(ST, RAG, KV) do { if constexpr (BIAS) attn_bias_tile<T, DP, ST, RAG, MODE == 6>(smem, qf, oacc, m_raw, lsum, minit, first, kaddr, vaddr, KV, hi); \
+                                    else attn_mma32_tile<T, DP, ST, RAG, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, KV, hi); } while (0)
     load_tile(t_begin);
     store_tile(0);
     __syncthreads();
@@ -569,26 +700,27 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
     // full tiles, two per iteration so the LDS stage is a compile-time constant
     for (; t + 2 < ntiles; t += 2) {
       load_tile(t + 1);
-      attn_mma32_tile<T, DP, 0, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      ATTN_TILE(0, false, AB_KV);
       store_tile(1);
       MTX_LDS_BARRIER();
       load_tile(t + 2);
-      attn_mma32_tile<T, DP, 1, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      ATTN_TILE(1, false, AB_KV);
       store_tile(0);
       MTX_LDS_BARRIER();
     }
     // one or two tiles left; the very last one may be ragged
     if (t + 2 == ntiles) {
       load_tile(t + 1);
-      attn_mma32_tile<T, DP, 0, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      ATTN_TILE(0, false, AB_KV);
       store_tile(1);
       MTX_LDS_BARRIER();
-      if (kv_last < AB_KV) attn_mma32_tile<T, DP, 1, true, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
-      else attn_mma32_tile<T, DP, 1, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      if (kv_last < AB_KV) ATTN_TILE(1, true, kv_last);
+      else ATTN_TILE(1, false, AB_KV);
     } else {
-      if (kv_last < AB_KV) attn_mma32_tile<T, DP, 0, true, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
-      else attn_mma32_tile<T, DP, 0, false, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
+      if (kv_last < AB_KV) ATTN_TILE(0, true, kv_last);
+      else ATTN_TILE(0, false, AB_KV);
     }
+#undef ATTN_TILE
   } else {
     // group 0 (waves 0-3) runs  [score(t)] B [feed, value(t)] B ;  group 1 the same shifted by one barrier:
     // B [feed, score(t)] B [value(t)] ...  `feed` = tile t+1 registers -> LDS, tile t+2 -> registers; both groups feed in the
@@ -656,7 +788,7 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
         f32x4 o = {oacc[d][g * 4 + 0], oacc[d][g * 4 + 1], oacc[d][g * 4 + 2], oacc[d][g * 4 + 3]};
         *reinterpret_cast<f32x4*>(PO + d * 32 + g * 8 + hi * 4) = o;
       }
-    if (hi == 0) { p.part_ml[((size_t)slot * AB_QB + row) * 2] = m_raw; p.part_ml[((size_t)slot * AB_QB + row) * 2 + 1] = lrow; }
+    if (hi == 0) { p.part_ml[((size_t)slot * AB_QB + row) * 2] = BIAS ? m_raw / c : m_raw; p.part_ml[((size_t)slot * AB_QB + row) * 2 + 1] = lrow; }
     return;
   }
 
@@ -1345,6 +1477,9 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     else if (e && e[0] == '2') MTX_LAUNCH((attn_mma32_kernel<T, 128, 2>), dim3(g), dim3(512), 0, stream, p);
     else if (e && e[0] == '3') MTX_LAUNCH((attn_mma32_kernel<T, 128, 3>), dim3(g), dim3(512), 0, stream, p);
     else if (e && e[0] == '4') MTX_LAUNCH((attn_mma32_kernel<T, 128, 4>), dim3(g), dim3(512), 0, stream, p);
+    else if (e && e[0] == 'b') MTX_LAUNCH((attn_mma32_kernel<T, 128, 5>), dim3(g), dim3(512), 0, stream, p);
+    else if (e && e[0] == 'n') MTX_LAUNCH((attn_mma32_kernel<T, 128, 6>), dim3(g), dim3(512), 0, stream, p);
+    else if (p.prescaled && !e) MTX_LAUNCH((attn_mma32_kernel<T, 128, 6>), dim3(g), dim3(512), 0, stream, p);      // exact: no rounding added by the x 1.0
     else MTX_LAUNCH((attn_mma32_kernel<T, 128, 0>), dim3(g), dim3(512), 0, stream, p);
     if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
     return MTX_OK;
@@ -1368,7 +1503,8 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   p.batch = a->batch; p.heads = a->heads; p.sq = a->sq; p.sk = a->sk; p.d = a->d;
   p.q_bs = a->q_bs; p.q_ss = a->q_ss; p.q_hs = a->q_hs; p.k_bs = a->k_bs; p.k_ss = a->k_ss; p.k_hs = a->k_hs;
   p.v_bs = a->v_bs; p.v_ss = a->v_ss; p.v_hs = a->v_hs; p.o_bs = a->o_bs; p.o_ss = a->o_ss; p.o_hs = a->o_hs;
-  p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.prescaled = (a->flags & MTX_ATTN_Q_PRESCALED) ? 1 : 0;
+  p.scale_log2 = p.prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
   p.n_full = 0; p.split = 1; p.part_o = nullptr; p.part_ml = nullptr;
   if (a->workspace && a->workspace_bytes >= (int64_t)MTX_ATTN_WORKSPACE_BYTES) {      // 256 slots of [256][128] fp32 + [256][2] fp32

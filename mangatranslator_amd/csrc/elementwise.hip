@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(mtx_ew_args p) {
   const int part = (int)(chc & (unsigned)(lpr - 1));
   const int hd = (int)(chc / (unsigned)lpr);
   const float* gamma = (gamma0 != nullptr && split_at > 0 && hd >= split_at) ? gamma0 + d : gamma0;
+  if (split_at > 0 && p.ldb > 0 && hd < split_at) cs += p.ldb;       // q heads: the pre-scaled copy of the rotary table
   float gm[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) gm[e] = gamma ? gamma[part * 8 + e] : 1.f;

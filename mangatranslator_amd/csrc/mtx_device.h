@@ -100,17 +100,21 @@ template <typename T> struct Mma32Pinned {
   static __device__ __forceinline__ void acc_agpr(f32x16& c, v8 a, v8 b) { c = Mma32<T>::mfma(a, b, c); }
   static __device__ __forceinline__ void acc_vgpr(f32x16& c, v8 a, v8 b) { c = Mma32<T>::mfma(a, b, c); }
   static __device__ __forceinline__ void set_vgpr(f32x16& c, v8 a, v8 b) { const f32x16 z = {0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f,0.f}; c = Mma32<T>::mfma(a, b, z); }
+  static __device__ __forceinline__ void set_from(f32x16& d, v8 a, v8 b, const f32x16& c) { d = Mma32<T>::mfma(a, b, c); }
 };
 #else
 template <> struct Mma32Pinned<__bf16> {
   static __device__ __forceinline__ void acc_agpr(f32x16& c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc_vgpr(f32x16& c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void set_vgpr(f32x16& c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b)); }
+  // D = A B + C with C in a DIFFERENT register tuple than D (the compiler's VGPR form ties them and copies C first)
+  static __device__ __forceinline__ void set_from(f32x16& d, bf16x8 a, bf16x8 b, const f32x16& c) { asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
 };
 template <> struct Mma32Pinned<_Float16> {
   static __device__ __forceinline__ void acc_agpr(f32x16& c, f16x8 a, f16x8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc_vgpr(f32x16& c, f16x8 a, f16x8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void set_vgpr(f32x16& c, f16x8 a, f16x8 b) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void set_from(f32x16& d, f16x8 a, f16x8 b, const f32x16& c) { asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
 };
 #endif
 

@@ -222,8 +222,9 @@ class PlanBuilder:
         return out
 
     def attention(self, q, k, v, o, batch, heads, sq, sk, d, q_str, k_str, v_str, o_str, scale,
-                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn"):
+                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False):
         a = abi.AttnArgs()
+        a.flags = abi.ATTN_Q_PRESCALED if q_prescaled else 0
         a.q, a.k, a.v, a.o = _ptr(q, q_off), _ptr(k, k_off), _ptr(v, v_off), _ptr(o, o_off)
         a.batch, a.heads, a.sq, a.sk, a.d = batch, heads, sq, sk, d
         a.q_bs, a.q_ss, a.q_hs = q_str

@@ -130,21 +130,24 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
     return err
 
 
-def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0):
+def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, prescaled=False):
+    """prescaled: q carries scale * log2(e) before its rounding to the storage type (MTX_ATTN_Q_PRESCALED): the reference is the
+    base-2 softmax of q k^T, i.e. SDPA with scale = ln 2 on the very same rounded q"""
     g = torch.Generator().manual_seed(seed)
     dev, td = _dev(lib), TD[dtype]
-    q = (torch.randn(batch, sq, heads, d, generator=g) * qmul).to(td)     # qmul > 1: peaked rows, exercises max refreshes
+    scale = 1.0 / math.sqrt(d)
+    q = torch.randn(batch, sq, heads, d, generator=g) * qmul              # qmul > 1: peaked rows, exercises max refreshes
+    q = (q * (scale * 1.4426950408889634)).to(td) if prescaled else q.to(td)
     k = torch.randn(batch, sk, heads, d, generator=g).to(td)
     v = torch.randn(batch, sk, heads, d, generator=g).to(td)
-    scale = 1.0 / math.sqrt(d)
     ref = F.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2),
-                                         v.float().transpose(1, 2), scale=scale).transpose(1, 2)
+                                         v.float().transpose(1, 2), scale=math.log(2.0) if prescaled else scale).transpose(1, 2)
     pb = PlanBuilder(lib, dev, dtype)
     qt, kt, vt = pb.const(q), pb.const(k), pb.const(v)
     o = pb.buf((batch, sq, heads, d), td, zero=True)
     pb.attention(qt, kt, vt, o, batch, heads, sq, sk, d,
                  (sq * heads * d, heads * d, d), (sk * heads * d, heads * d, d),
-                 (sk * heads * d, heads * d, d), (sq * heads * d, heads * d, d), scale)
+                 (sk * heads * d, heads * d, d), (sq * heads * d, heads * d, d), scale, q_prescaled=prescaled)
     _run(pb)
     err = _relerr(o.cpu(), ref)
     assert err < TOL[dtype] * 1.5, f"attention mismatch rel err {err}"
@@ -274,7 +277,7 @@ def check_image_convert(lib, dtype, seed=0):
     assert (u8.cpu().int() - ref8.int()).abs().max() <= 0
 
 
-def check_qk_norm_rope(lib, dtype, rows, heads, d, fused=True, seed=0):
+def check_qk_norm_rope(lib, dtype, rows, heads, d, fused=True, seed=0, q_fold=None):
     """per-head RMSNorm * gamma then rotary on interleaved pairs, in place on the q|k column slices of a [rows, 3*H*d] buffer"""
     from mangatranslator_amd.hip.plan import Act
     g = torch.Generator().manual_seed(seed)
@@ -291,8 +294,13 @@ def check_qk_norm_rope(lib, dtype, rows, heads, d, fused=True, seed=0):
         x = x.to(td).float()                                             # the model rounds before the rotary product
         x0, x1 = x[..., 0::2], x[..., 1::2]
         c, s_ = ang.cos()[:, None], ang.sin()[:, None]
+        if q_fold is not None and part == 0:                                # q heads rotate with the pre-scaled table copy
+            c, s_ = c * q_fold, s_ * q_fold
         ref[:, part * D:(part + 1) * D] = torch.stack([x0 * c - x1 * s_, x1 * c + x0 * s_], -1).reshape(rows, D)
     pb = PlanBuilder(lib, dev, dtype)
+    if q_fold is not None:
+        assert fused
+        cs = torch.stack([cs, cs * q_fold]).contiguous()
     buf, cst, gm = pb.const(qkv), pb.const(cs), pb.const(gam.reshape(-1).contiguous())
     def add(col, ncols, gamma_off, split):
         e = abi.EwArgs()
@@ -300,6 +308,7 @@ def check_qk_norm_rope(lib, dtype, rows, heads, d, fused=True, seed=0):
         e.b, e.s = cst.data_ptr(), gm.data_ptr() + gamma_off * 4
         e.n, e.h, e.w, e.c = 1, 1, rows, ncols
         e.lda = e.ldy = 3 * D
+        e.ldb = rows * d if q_fold is not None else 0
         e.kind, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 1e-6, d, split, dtype
         pb._add(abi.OP_EW, e, "rope")
     if fused:

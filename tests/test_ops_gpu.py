@@ -101,7 +101,7 @@ def test_attention_long_sequence_kernel(hip_lib, cfg):
     oc.check_attention(hip_lib, abi.F16, **cfg)
 
 
-@pytest.mark.parametrize("kernel", ["2", "3", "stag", "pipe", "duo"])
+@pytest.mark.parametrize("kernel", ["2", "3", "stag", "pipe", "duo", "bias"])
 def test_attention_long_sequence_variants(hip_lib, monkeypatch, kernel):
     """the A/B schedules of the long-sequence kernel (MTX_ATTN_KERNEL) compute the same attention"""
     monkeypatch.setenv("MTX_ATTN_KERNEL", kernel)
@@ -124,8 +124,16 @@ def test_gemm_256_schedules(hip_lib, monkeypatch, sched):
     oc.check_gemm(hip_lib, abi.BF16, m=4100, n=3072, k=64)
 
 
+def test_attention_prescaled_q(hip_lib):
+    oc.check_attention(hip_lib, abi.BF16, batch=1, heads=3, sq=2100, sk=2100, d=128, qmul=4.0, prescaled=True)
+    oc.check_attention(hip_lib, abi.BF16, batch=1, heads=24, sq=8652, sk=8652, d=128, prescaled=True)          # FLUX shape, key-split tail
+    oc.check_attention(hip_lib, abi.F16, batch=1, heads=2, sq=1100, sk=449, d=128, qmul=40.0, prescaled=True)    # refresh path
+    oc.check_attention(hip_lib, abi.BF16, batch=2, heads=2, sq=300, sk=200, d=64, prescaled=True)
+
+
 def test_flux_prep_kernels(hip_lib):
     oc.check_qk_norm_rope(hip_lib, abi.BF16, rows=1000, heads=24, d=128)
+    oc.check_qk_norm_rope(hip_lib, abi.BF16, rows=1000, heads=24, d=128, q_fold=0.1275)
     oc.check_qk_norm_rope(hip_lib, abi.F16, rows=333, heads=2, d=64, fused=False)
     oc.check_softmax_transpose(hip_lib, abi.BF16, rows=1024, cols=1024)
     oc.check_softmax_transpose(hip_lib, abi.F16, rows=70, cols=136)

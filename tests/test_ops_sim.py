@@ -95,6 +95,22 @@ def test_attention_long_sequence_prefetch_variant(emu_lib, monkeypatch):
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0)
 
 
+def test_attention_long_sequence_bias_variant(emu_lib, monkeypatch):
+    """MTX_ATTN_KERNEL=bias: pre-scaled Q, S^T accumulators seeded with minus the running maximum (peaked rows force refreshes)"""
+    monkeypatch.setenv("MTX_ATTN_KERNEL", "bias")
+    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0)
+    oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=448, d=128, qmul=6.0)
+
+
+def test_attention_prescaled_q(emu_lib):
+    """MTX_ATTN_Q_PRESCALED (what the FLUX graph passes): the long-sequence kernel runs without a per-score multiply-add and takes
+    the row maximum only on the first tile or when a partial row sum explodes; short sequences go through the generic kernel"""
+    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0, prescaled=True)
+    oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=320, d=128, prescaled=True)
+    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1024, sk=448, d=128, qmul=40.0, prescaled=True)      # logits of +-500: refresh path
+    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=2, sq=100, sk=130, d=64, prescaled=True)
+
+
 def test_attention_long_sequence_duo_variant(emu_lib, monkeypatch):
     """MTX_ATTN_KERNEL=duo: 128-query workgroups (two per CU), K/V by LDS-DMA; ragged last tile, key-split tail (3 simulated CUs)"""
     monkeypatch.setenv("MTX_ATTN_KERNEL", "duo")
@@ -121,6 +137,7 @@ def test_gemm_256_ring_schedule(emu_lib, monkeypatch):
 
 def test_flux_prep_kernels(emu_lib):
     oc.check_qk_norm_rope(emu_lib, abi.BF16, rows=70, heads=3, d=64)
+    oc.check_qk_norm_rope(emu_lib, abi.BF16, rows=37, heads=2, d=128, q_fold=0.1275)
     oc.check_qk_norm_rope(emu_lib, abi.F16, rows=33, heads=2, d=128, fused=False)
     oc.check_softmax_transpose(emu_lib, abi.BF16, rows=24, cols=40)
     oc.check_softmax_transpose(emu_lib, abi.F16, rows=70, cols=136)

@@ -42,7 +42,7 @@ def attn_ab(T, heads=24, d=128, rounds=5, iters=20):
     o = pb.buf((T, D), torch.bfloat16)
     pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D)
     plan = pb.build(); plan.run(); torch.cuda.synchronize()
-    res = {"mma32": [], "duo": []}
+    res = {"mma32": [], "bias": [], "nomax": []}
     for r in range(rounds):
         for mode in res:
             os.environ["MTX_ATTN_KERNEL"] = mode
