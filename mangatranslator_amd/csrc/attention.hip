@@ -368,6 +368,9 @@ __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typen
 // do is let exp2 grow large, and fp32 / bf16 keep their relative precision while it does; the tile's partial row sums (which are
 // needed anyway) flag the danger zone (> 2^40, inf or nan), and only then — and on the first tile — the exact maximum is taken and
 // the tile's probabilities are recomputed.
+// largest partial row sum a stale maximum may produce before the exact path is taken: the probabilities must stay finite in T
+template <typename T> struct AttnSumLimit { static constexpr float v = 1.0e12f; };       // bf16: fp32 exponent range, 2^40
+template <> struct AttnSumLimit<_Float16> { static constexpr float v = 3.0e4f; };        // f16: max 65504
 template <typename T, int DP, int STAGE, bool RAGGED, bool NOMAX = false>
 __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
                                                float& M, float& lsum, f32x16& minit, bool& first,
@@ -434,7 +437,7 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
         tsum += pv;
         pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
       }
-    if (first || __any(!(tsum < 1.0e12f))) {          // 2^40: far from fp32 overflow, catches inf / nan as well
+    if (first || __any(!(tsum < AttnSumLimit<T>::v))) {          // far from overflow of T / fp32, catches inf / nan as well
       float tmax = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
       for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);

@@ -108,6 +108,7 @@ def test_attention_prescaled_q(emu_lib):
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0, prescaled=True)
     oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=320, d=128, prescaled=True)
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1024, sk=448, d=128, qmul=40.0, prescaled=True)      # logits of +-500: refresh path
+    oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=449, d=128, qmul=40.0, prescaled=True)       # f16 probabilities: limit 3e4
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=2, sq=100, sk=130, d=64, prescaled=True)
 
 

@@ -1,2 +1,2 @@
 set -x
-timeout 900 python tools/bench_kernels.py attn_ab 8192 attn_ab 8704 2>&1 | tail -7
+timeout 600 python -m pytest tests/test_ops_gpu.py -x -q --tb=short -k "prescaled or variants or long_sequence" 2>&1 | tail -5
