@@ -280,7 +280,10 @@ __device__ __forceinline__ void gemm256_tile_origin(const GemmParams& p, unsigne
 
 // PP = ping-pong schedule: the two waves of every SIMD (waves w and w+4) run one barrier apart, so while one
 // issues its fragment reads / DMA for a k-step the other owns the matrix pipe for its 8 MFMAs.
-template <typename T, int ACT, bool PP>
+// CLAMP: rows past M / N are read from the last valid row instead of a zero block — they only feed outputs the epilogue never
+// stores — so the loop carries no per-piece select and no scalar load of the zero block's address (whose s_waitcnt lgkmcnt(0)
+// also drained the fragment reads in front of every DMA burst).
+template <typename T, int ACT, bool PP, bool CLAMP = true>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
@@ -306,15 +309,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   for (int i = 0; i < 8; ++i) {
     const int row = (i * 8 + wv) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    if (row < G2_BM) src[i] = (m0 + row < p.m) ? A + (size_t)(m0 + row) * p.lda + c * 8 : nullptr;
-    else src[i] = (n0 + row - G2_BM < p.n) ? W + (size_t)(n0 + row - G2_BM) * p.ldw + c * 8 : nullptr;
+    if (row < G2_BM) src[i] = (m0 + row < p.m) ? A + (size_t)(m0 + row) * p.lda + c * 8 : (CLAMP ? A + (size_t)(p.m - 1) * p.lda + c * 8 : nullptr);
+    else src[i] = (n0 + row - G2_BM < p.n) ? W + (size_t)(n0 + row - G2_BM) * p.ldw + c * 8 : (CLAMP ? W + (size_t)(p.n - 1) * p.ldw + c * 8 : nullptr);
   }
+  auto srcp = [&](int i, long k0) -> const void* {
+    if (CLAMP) return (const void*)(src[i] + k0);
+    return src[i] ? (const void*)(src[i] + k0) : (const void*)g_zero16;
+  };
   auto issue = [&](int stage, long k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const void* g = src[i] ? (const void*)(src[i] + k0) : (const void*)g_zero16;
-      glds16(g, smem + stage * G2_STAGE + (i * 8 + wv) * 1024);
-    }
+    for (int i = 0; i < 8; ++i) glds16(srcp(i, k0), smem + stage * G2_STAGE + (i * 8 + wv) * 1024);
   };
 
   f32x16 acc[4][2];
@@ -343,8 +347,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       const int nst = (int)((kt + 1) & 1);
       const long nk0 = p.abl == 5 ? 0 : (kt + 1) * G2_BK;            // ablation 5: always re-read the first K tile (L2-resident source)
       auto piece = [&](int i) {                 // one DMA instruction (1 KB) of the next tile
-        const void* g = src[i] ? (const void*)(src[i] + nk0) : (const void*)g_zero16;
-        glds16(g, smem + nst * G2_STAGE + (i * 8 + wv) * 1024);
+        glds16(srcp(i, nk0), smem + nst * G2_STAGE + (i * 8 + wv) * 1024);
       };
       const unsigned char* st = smem + (kt & 1) * G2_STAGE;
       // fragment reads run one k-step ahead of the MFMAs that consume them (two register sets)
@@ -419,8 +422,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int pi = (ks - 1) * 4 + i;
-            const void* g = src[pi] ? (const void*)(src[pi] + k0) : (const void*)g_zero16;
-            glds16(g, smem + stage * G2_STAGE + (pi * 8 + wv) * 1024);
+            glds16(srcp(pi, k0), smem + stage * G2_STAGE + (pi * 8 + wv) * 1024);
           }
         }
         if (ks == 3 && grp == 1) MTX_WAIT_VMEM();
@@ -704,15 +706,13 @@ __global__ __launch_bounds__(512) void gemm256_tail_kernel(GemmParams p) {
     for (int i = 0; i < 8; ++i) {
       const int row = (i * 8 + wv) * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
-      if (row < G2_BM) src[i] = (m0 + row < p.m) ? A + (size_t)(m0 + row) * p.lda + c * 8 : nullptr;
-      else src[i] = (n0 + row - G2_BM < p.n) ? W + (size_t)(n0 + row - G2_BM) * p.ldw + c * 8 : nullptr;
+      // rows past M / N: the last valid row (their partial sums are never merged into a stored output)
+      if (row < G2_BM) src[i] = A + (size_t)(m0 + row < p.m ? m0 + row : p.m - 1) * p.lda + c * 8;
+      else src[i] = W + (size_t)(n0 + row - G2_BM < p.n ? n0 + row - G2_BM : p.n - 1) * p.ldw + c * 8;
     }
     auto issue = [&](int stage, long k0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const void* g = src[i] ? (const void*)(src[i] + k0) : (const void*)g_zero16;
-        glds16(g, smem + stage * G2_STAGE + (i * 8 + wv) * 1024);
-      }
+      for (int i = 0; i < 8; ++i) glds16(src[i] + k0, smem + stage * G2_STAGE + (i * 8 + wv) * 1024);
     };
     f32x16 acc[4][2];
 #pragma unroll
@@ -813,14 +813,20 @@ static int gemm_num_cus() {
   return cus;
 }
 
+template <typename T, bool PP, bool CLAMP>
+static void launch_gemm256_ppc(const GemmParams& p, dim3 grid, void* stream) {
+  switch (p.act) {
+    case MTX_ACT_NONE: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_NONE, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_SILU: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_SILU, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_GELU_TANH, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
+    default: MTX_LAUNCH((gemm256_kernel<T, -1, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
+  }
+}
 template <typename T, bool PP>
 static void launch_gemm256_pp(const GemmParams& p, dim3 grid, void* stream) {
-  switch (p.act) {
-    case MTX_ACT_NONE: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_NONE, PP>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_SILU: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_SILU, PP>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_GELU_TANH, PP>), grid, dim3(512), 0, stream, p); break;
-    default: MTX_LAUNCH((gemm256_kernel<T, -1, PP>), grid, dim3(512), 0, stream, p); break;
-  }
+  const char* e = getenv("MTX_GEMM_CLAMP");              // A/B switch: "0" = the zero-block select of the first version
+  if (e && e[0] == '0') launch_gemm256_ppc<T, PP, false>(p, grid, stream);
+  else launch_gemm256_ppc<T, PP, true>(p, grid, stream);
 }
 template <typename T>
 static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream) {

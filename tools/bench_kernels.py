@@ -90,6 +90,23 @@ def gemm_ab(M, N, K, rounds=5, iters=20):
         print(f"gemm {M}x{N}x{K} {mode}: best {min(v):.3f} ms ({2 * M * N * K / min(v) / 1e9:.0f} TF/s), median {sorted(v)[len(v) // 2]:.3f} ms")
 
 
+def gemm_clamp(M, N, K, rounds=5, iters=20):
+    """interleaved A/B of the zero-block select (MTX_GEMM_CLAMP=0) vs clamped rows in the 256-tile loops"""
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    a = pb.buf((M, K), torch.bfloat16); a.normal_()
+    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
+    pb.gemm(a, w, M, N, K)
+    plan = pb.build(); plan.run(); torch.cuda.synchronize()
+    res = {"1": [], "0": []}
+    for r in range(rounds):
+        for mode in res:
+            os.environ["MTX_GEMM_CLAMP"] = mode
+            plan.time(3)
+            res[mode].append(plan.time(iters))
+    for mode, v in res.items():
+        print(f"gemm {M}x{N}x{K} clamp={mode}: best {min(v):.3f} ms ({2 * M * N * K / min(v) / 1e9:.0f} TF/s), median {sorted(v)[len(v) // 2]:.3f} ms")
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     while args:
@@ -99,6 +116,8 @@ if __name__ == "__main__":
             attn_ab(int(args[1])); args = args[2:]
         elif args[0] == "abl":
             gemm_abl(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
+        elif args[0] == "clamp":
+            gemm_clamp(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
         elif args[0] == "ab":
             gemm_ab(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
         else:
