@@ -554,34 +554,6 @@ __device__ __forceinline__ void attn_value_phase(unsigned char* smem, f32x16 (&o
       }
 }
 
-// 16 bytes through a buffer descriptor: byte offset = voff (per lane) + soff (wave-uniform); reads past
-// `bytes` return zeros (the hardware range check), which is how rows >= sk become zero rows.
-struct BufView {
-#ifdef MTX_EMU
-  const unsigned char* base; unsigned bytes;
-#else
-  __amdgpu_buffer_rsrc_t rsrc;
-#endif
-};
-__device__ __forceinline__ BufView make_buf(const void* base, unsigned bytes) {
-  BufView b;
-#ifdef MTX_EMU
-  b.base = reinterpret_cast<const unsigned char*>(base); b.bytes = bytes;
-#else
-  b.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-#endif
-  return b;
-}
-__device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, unsigned soff) {
-#ifdef MTX_EMU
-  u32x4 r = u32x4{0u, 0u, 0u, 0u};
-  if ((unsigned long)voff + soff + 16 <= b.bytes) memcpy(&r, b.base + voff + soff, 16);
-  return r;
-#else
-  return __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)voff, (int)soff, 0);
-#endif
-}
-
 // STAG = staggered schedule: the two waves of every SIMD (w and w+4) run half a tile apart — while one group issues the
 // S^T MFMAs of its tile, the other turns its scores into probabilities and runs the PV MFMAs — separated by a workgroup
 // barrier per half tile.  Tile t+1 is written to LDS at the start of the (global) segment in which group 0 runs its
@@ -818,15 +790,6 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
 // exponentials are computed; K/V tiles arrive by LDS-DMA (buffer_load ... lds) into a three-stage ring, which
 // frees the 16 staging registers the second accumulator needs and removes the LDS store pass.
 // Per step:  DMA(t+2) -> [max(t), rare rescale] -> [S^T(t+1) MFMAs || exp/sum/convert(t)] -> PV(t) -> wait, barrier.
-__device__ __forceinline__ void buf_load16_lds(const BufView& b, unsigned voff, unsigned soff, void* lds_wave_base) {
-#ifdef MTX_EMU
-  unsigned char* d = reinterpret_cast<unsigned char*>(lds_wave_base) + emu::lane_id() * 16;
-  if ((unsigned long)voff + soff + 16 <= b.bytes) memcpy(d, b.base + voff + soff, 16); else memset(d, 0, 16);
-#else
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
-#endif
-}
-
 template <typename T, int DP, int VS, bool HAS_NEXT, bool RAGGED>
 __device__ __forceinline__ void attn_pipe_step(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
                                                f32x16 (&scur)[2], f32x16 (&snext)[2], float& m_raw, float& lsum, const float c, const float thr,

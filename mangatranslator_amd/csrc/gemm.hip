@@ -278,12 +278,97 @@ __device__ __forceinline__ void gemm256_tile_origin(const GemmParams& p, unsigne
 #define G2_BAR() asm volatile("s_barrier" ::: "memory")
 #endif
 
+// The ping-pong K loop with descriptor DMA over iterations [kbeg, kend) of one 256 x 256 tile (used by the full-tile kernel and by
+// the stream-K tail): barrier timeline B0, B1, ...: group 0 (waves 0-3) runs  L(k) B C(k) B  per k-step, group 1 the same one
+// barrier later, so one group's load segment (fragment reads + DMA issue) coincides with the other's 8 MFMAs.
+//   * DMA: per piece a loop-invariant 32-bit lane offset into a buffer descriptor over the valid bytes of A / W (rows past M / N
+//     are zero-filled by the range check), the K position as the wave-uniform soffset, the LDS base (M0) from scalar arithmetic:
+//     no VALU instruction per piece.
+//   * the eight pieces of tile kt+1 are issued 3 / 3 / 2 / 0 over the load segments of tile kt; a wave waits for its own fragment
+//     reads BEFORE it joins the barrier that ends a load segment, so the stage tile kt-1 occupied is free from L(kt, 0) on;
+//   * every wave drains its DMA (vmcnt(0)) before the barrier that precedes group 0's first reads of tile kt+1: group 0 at the end
+//     of C(kt, 3), group 1 at the end of L(kt, 3).
+// The caller provides a workgroup barrier between two calls (the stages are reused).
+template <typename T>
+__device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigned char* smem, const T* A, const T* W, long m0, long n0,
+                                                    long kbeg, long kend, f32x16 (&acc)[4][2]) {
+  typedef typename Traits<T>::v8 v8;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wm = wv >> 2, wn = wv & 3, grp = wv >> 2;
+  int wvs = wv;
+#ifndef MTX_EMU
+  wvs = __builtin_amdgcn_readfirstlane(wv);
+#endif
+  const BufView abuf = make_buf(A, (unsigned)((((size_t)p.m - 1) * p.lda + p.k) * sizeof(T)));
+  const BufView wbuf = make_buf(W, (unsigned)((((size_t)p.n - 1) * p.ldw + p.k) * sizeof(T)));
+  unsigned voff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {           // piece i of wave wv fills LDS rows (i*8 + wv)*8 .. +7 of a stage; rows 0..255 are A, 256..511 W
+    const int row = (i * 8 + wv) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voff[i] = i < 4 ? (unsigned)(((size_t)(m0 + row) * p.lda + c * 8) * sizeof(T)) : (unsigned)(((size_t)(n0 + row - G2_BM) * p.ldw + c * 8) * sizeof(T));
+  }
+  auto piece = [&](int i, int stage, long k0) {
+    buf_load16_lds(i < 4 ? abuf : wbuf, voff[i], (unsigned)(k0 * sizeof(T)), smem + stage * G2_STAGE + (i * 8 + wvs) * 1024);
+  };
+  int arow[4], wrow[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) arow[i] = wm * 128 + i * 32 + l31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wrow[j] = G2_BM + wn * 64 + j * 32 + l31;
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) piece(i, (int)(kbeg & 1), kbeg * G2_BK);
+  MTX_WAIT_VMEM();
+  __syncthreads();
+  if (grp == 1) G2_BAR();
+  for (long kt = kbeg; kt < kend; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+    const bool more = kt + 1 < kend;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ch = 2 * ks + hi;
+      v8 af[4], wf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+      if (more && ks < 3) {
+        const int stage = (int)((kt + 1) & 1);
+        const long k0 = (kt + 1) * G2_BK;
+        const int first = ks * 3, cnt = ks < 2 ? 3 : 2;
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) piece(first + i, stage, k0);
+      }
+#ifndef MTX_EMU
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads done before the barrier: frees the stage for DMA
+#endif
+      if (ks == 3 && grp == 1) MTX_WAIT_VMEM();
+      G2_BAR();
+#ifndef MTX_EMU
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+#ifndef MTX_EMU
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      if (ks == 3 && grp == 0) MTX_WAIT_VMEM();
+      G2_BAR();
+    }
+  }
+  if (grp == 0) G2_BAR();
+}
+
 // PP = ping-pong schedule: the two waves of every SIMD (waves w and w+4) run one barrier apart, so while one
 // issues its fragment reads / DMA for a k-step the other owns the matrix pipe for its 8 MFMAs.
 // CLAMP: rows past M / N are read from the last valid row instead of a zero block — they only feed outputs the epilogue never
 // stores — so the loop carries no per-piece select and no scalar load of the zero block's address (whose s_waitcnt lgkmcnt(0)
 // also drained the fragment reads in front of every DMA burst).
-template <typename T, int ACT, bool PP, bool CLAMP = true>
+// BUF: the K loop is gemm256_pp_buf_loop (descriptor DMA, 3/3/2/0 piece spread) — the default; PP / !PP are the earlier loops.
+template <typename T, int ACT, bool PP, bool CLAMP = true, bool BUF = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
@@ -337,7 +422,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   for (int j = 0; j < 2; ++j) wrow[j] = G2_BM + wn * 64 + j * 32 + l31;
 
   const long nk = p.k / G2_BK;
-  if (!PP) {
+  if (BUF) {
+    gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, 0, nk, acc);
+  } else if (!PP) {
     issue(0, 0);
     for (long kt = 0; kt < nk; ++kt) {
       MTX_WAIT_VMEM();
@@ -701,19 +788,6 @@ __global__ __launch_bounds__(512) void gemm256_tail_kernel(GemmParams p) {
     if (kend <= kbeg) continue;                                 // (wave-uniform)
     long m0, n0;
     gemm256_tile_origin(p, (unsigned)(p.n_full + t0 + seg), m0, n0);
-    const T* src[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = (i * 8 + wv) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      // rows past M / N: the last valid row (their partial sums are never merged into a stored output)
-      if (row < G2_BM) src[i] = A + (size_t)(m0 + row < p.m ? m0 + row : p.m - 1) * p.lda + c * 8;
-      else src[i] = W + (size_t)(n0 + row - G2_BM < p.n ? n0 + row - G2_BM : p.n - 1) * p.ldw + c * 8;
-    }
-    auto issue = [&](int stage, long k0) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) glds16(src[i] + k0, smem + stage * G2_STAGE + (i * 8 + wv) * 1024);
-    };
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -722,26 +796,7 @@ __global__ __launch_bounds__(512) void gemm256_tail_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     __syncthreads();                                            // the previous piece is done with the LDS stages
-    issue((int)(kbeg & 1), kbeg * G2_BK);
-    for (long kt = kbeg; kt < kend; ++kt) {
-      MTX_WAIT_VMEM();
-      __syncthreads();
-      if (kt + 1 < kend) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
-      const unsigned char* st = smem + (kt & 1) * G2_STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int ch = 2 * ks + hi;
-        v8 af[4], wf[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
-      }
-    }
+    gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, kbeg, kend, acc);
     // fp32 partial of this piece: [256 m][256 n], a lane stores 4 consecutive n
     float* P = p.part + (size_t)(2 * u + seg) * G2_BM * G2_BN;
 #pragma unroll
@@ -822,6 +877,15 @@ static void launch_gemm256_ppc(const GemmParams& p, dim3 grid, void* stream) {
     default: MTX_LAUNCH((gemm256_kernel<T, -1, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
   }
 }
+template <typename T>
+static void launch_gemm256_buf(const GemmParams& p, dim3 grid, void* stream) {
+  switch (p.act) {
+    case MTX_ACT_NONE: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_NONE, true, true, true>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_SILU: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_SILU, true, true, true>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_GELU_TANH, true, true, true>), grid, dim3(512), 0, stream, p); break;
+    default: MTX_LAUNCH((gemm256_kernel<T, -1, true, true, true>), grid, dim3(512), 0, stream, p); break;
+  }
+}
 template <typename T, bool PP>
 static void launch_gemm256_pp(const GemmParams& p, dim3 grid, void* stream) {
   const char* e = getenv("MTX_GEMM_CLAMP");              // A/B switch: "0" = the zero-block select of the first version
@@ -831,22 +895,26 @@ static void launch_gemm256_pp(const GemmParams& p, dim3 grid, void* stream) {
 template <typename T>
 static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream) {
   GemmParams p = p0;
-  const char* e = getenv("MTX_GEMM256_SCHED");          // A/B switch: "lockstep" / "pingpong" select the 8-wave loops, "ws" the wave-specialised one; default by K
-  // measured on MI355X (tools/bench_kernels.py ab): ping-pong wins by 3-5 % up to K = 4096, the one-barrier loop by
-  // 5-8 % on long K; the wave-specialised variant is DMA-wave-bound (16 pieces per wave per tile) and 10-15 % behind
-  const char mode = e ? e[0] : (p.k <= 4096 ? 'p' : 'l');
+  const char* e = getenv("MTX_GEMM256_SCHED");          // A/B switch: "buf" (default), "pingpong", "lockstep", "ring", "ws"
+  // measured on MI355X (tools/bench_kernels.py ab, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the
+  // 3/3/2/0 piece spread runs 1119-1341 TFLOP/s, 12-15 % ahead of the flat-address ping-pong (wins up to K = 4096) and one-barrier
+  // (wins above) loops it replaces; the ring is 2-5 % and the wave-specialised variant 10-15 % behind those
+  const bool fits32 = ((size_t)p.m * p.lda + p.k) * sizeof(T) < (1ull << 32) && ((size_t)p.n * p.ldw + p.k) * sizeof(T) < (1ull << 32);
+  const char mode = e ? e[0] : (fits32 ? 'b' : (p.k <= 4096 ? 'p' : 'l'));
   // stream-K tail when the last wave of tiles would fill less than ~70 % of the chip
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
   const char* ns = getenv("MTX_GEMM_NOSPLIT");
-  const bool tail = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles > cus && rem > 0 && rem * 10 < cus * 7 && p.k / G2_BK >= (getenv("MTX_GEMM256_MIN_TILES") ? 8 : 64) && !(ns && ns[0] == '1');
+  const bool tail = fits32 && p.part != nullptr && cus <= 320 && grid.y == 1 && tiles > cus && rem > 0 && rem * 10 < cus * 7 && p.k / G2_BK >= (getenv("MTX_GEMM256_MIN_TILES") ? 8 : 64) && !(ns && ns[0] == '1');
   // few tiles but a long K (FLUX text-stream ff2: 24 tiles x 192 iterations): stream-K over the whole problem
-  const bool allk = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles * 2 <= cus && p.k / G2_BK >= 128 && !(ns && ns[0] == '1');
+  const bool allk = fits32 && p.part != nullptr && cus <= 320 && grid.y == 1 && tiles * 2 <= cus && p.k / G2_BK >= 128 && !(ns && ns[0] == '1');
   if (allk) { p.n_full = 0; p.units = cus; }
   else if (tail) { p.n_full = tiles - rem; p.units = cus; grid.x = p.n_full; }
   if (!allk) {
     if (mode == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
     else if (mode == 'p') launch_gemm256_pp<T, true>(p, grid, stream);
     else if (mode == 'r') launch_gemm256r<T>(p, grid, stream);
+    else if (mode == 'b' && fits32) launch_gemm256_buf<T>(p, grid, stream);
+    else if (mode == 'b') launch_gemm256_pp<T, true>(p, grid, stream);          // a descriptor addresses 4 GB
     else launch_gemm256ws<T>(p, grid, stream);
   }
   if (tail || allk) {

@@ -238,4 +238,42 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + idx;
 }
 
+// 16 bytes through a buffer descriptor: byte offset = voff (per lane) + soff (wave-uniform); reads past
+// `bytes` return zeros (the hardware range check), which is how rows >= sk become zero rows.
+struct BufView {
+#ifdef MTX_EMU
+  const unsigned char* base; unsigned bytes;
+#else
+  __amdgpu_buffer_rsrc_t rsrc;
+#endif
+};
+__device__ __forceinline__ BufView make_buf(const void* base, unsigned bytes) {
+  BufView b;
+#ifdef MTX_EMU
+  b.base = reinterpret_cast<const unsigned char*>(base); b.bytes = bytes;
+#else
+  b.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+#endif
+  return b;
+}
+__device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, unsigned soff) {
+#ifdef MTX_EMU
+  u32x4 r = u32x4{0u, 0u, 0u, 0u};
+  if ((unsigned long)voff + soff + 16 <= b.bytes) memcpy(&r, b.base + voff + soff, 16);
+  return r;
+#else
+  return __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)voff, (int)soff, 0);
+#endif
+}
+
+// the same, straight into LDS (LDS-DMA): lane l's 16 bytes land at lds_wave_base + 16 l
+__device__ __forceinline__ void buf_load16_lds(const BufView& b, unsigned voff, unsigned soff, void* lds_wave_base) {
+#ifdef MTX_EMU
+  unsigned char* d = reinterpret_cast<unsigned char*>(lds_wave_base) + emu::lane_id() * 16;
+  if ((unsigned long)voff + soff + 16 <= b.bytes) memcpy(d, b.base + voff + soff, 16); else memset(d, 0, 16);
+#else
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+#endif
+}
+
 }  // namespace mtx

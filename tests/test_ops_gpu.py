@@ -116,7 +116,7 @@ def test_gemm_256_tile_kernel(hip_lib, cfg):
     oc.check_gemm(hip_lib, abi.F16, **cfg)
 
 
-@pytest.mark.parametrize("sched", ["ring", "pingpong", "lockstep"])
+@pytest.mark.parametrize("sched", ["ring", "pingpong", "lockstep", "buf"])
 def test_gemm_256_schedules(hip_lib, monkeypatch, sched):
     monkeypatch.setenv("MTX_GEMM256_SCHED", sched)
     oc.check_gemm(hip_lib, abi.BF16, m=8652, n=3072, k=3072, with_res=True, with_gate=True)

@@ -127,6 +127,15 @@ def test_gemm_256_tile_kernel(emu_lib, monkeypatch):
     oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=4160, with_res=True)          # K > 4096: the one-barrier loop with threaded DMA
 
 
+def test_gemm_256_buffer_dma_schedule(emu_lib, monkeypatch):
+    """MTX_GEMM256_SCHED=buf: ping-pong loop with descriptor-based LDS-DMA (range-checked zero fill), pieces spread 3/3/2/0"""
+    monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
+    monkeypatch.setenv("MTX_GEMM256_SCHED", "buf")
+    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
+    oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False)
+    oc.check_gemm(emu_lib, abi.BF16, m=260, n=250 // 8 * 8, k=448, with_res=True)
+
+
 def test_gemm_256_ring_schedule(emu_lib, monkeypatch):
     """the four-slot K = 32 ring (counted vmcnt) schedule: 1, 2, 3 and many slices, ragged M / N"""
     monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")

@@ -80,7 +80,7 @@ def gemm_ab(M, N, K, rounds=5, iters=20):
     w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
     pb.gemm(a, w, M, N, K)
     plan = pb.build(); plan.run(); torch.cuda.synchronize()
-    res = {"ring": [], "pingpong": [], "lockstep": []}
+    res = {"buf": [], "pingpong": [], "lockstep": []}
     for r in range(rounds):
         for mode in res:
             os.environ["MTX_GEMM256_SCHED"] = mode
