@@ -336,16 +336,26 @@ __device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigne
       if (more && ks < 3) {
         const int stage = (int)((kt + 1) & 1);
         const long k0 = (kt + 1) * G2_BK;
-        const int first = ks * 3, cnt = ks < 2 ? 3 : 2;
+        if (p.abl == 9 || p.abl == 10) {                       // ablations: 4/4/0/0 and 2/3/3/0 piece spreads
+          const int lo = p.abl == 9 ? ks * 4 : (ks == 0 ? 0 : (ks == 1 ? 2 : 5));
+          const int hi_ = p.abl == 9 ? (ks < 2 ? ks * 4 + 4 : 8) : (ks == 0 ? 2 : (ks == 1 ? 5 : 8));
 #pragma unroll
-        for (int i = 0; i < cnt; ++i) piece(first + i, stage, k0);
+          for (int i = 0; i < 8; ++i) if (i >= lo && i < hi_) piece(i, stage, k0);
+        } else {
+          const int first = ks * 3, cnt = ks < 2 ? 3 : 2;
+#pragma unroll
+          for (int i = 0; i < cnt; ++i) piece(first + i, stage, k0);
+        }
       }
 #ifndef MTX_EMU
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads done before the barrier: frees the stage for DMA
+      // the tile's LAST fragment reads finish before the barrier (from the next segment on the other group's DMA overwrites this
+      // stage); the others are waited for after it, where the wait no longer delays the other group's load segment
+      if (ks == 3 || p.abl == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
       if (ks == 3 && grp == 1) MTX_WAIT_VMEM();
       G2_BAR();
 #ifndef MTX_EMU
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll

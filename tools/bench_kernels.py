@@ -17,7 +17,10 @@ def attn(T, heads=24, d=128, iters=10):
     D = heads * d
     qkv = pb.buf((T, 3 * D), torch.bfloat16); qkv.normal_()
     o = pb.buf((T, D), torch.bfloat16)
-    pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D)
+    # the FLUX graph's form: q pre-multiplied by scale * log2(e) (MTX_ATTN_Q_PRESCALED)
+    qkv[:, :D] *= d ** -0.5 * 1.4426950408889634
+    pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D,
+                 q_prescaled=True)
     plan = pb.build(); plan.run(); torch.cuda.synchronize()
     ms = plan.time(iters)
     print(f"attn T={T} heads={heads}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s")
@@ -97,14 +100,14 @@ def gemm_clamp(M, N, K, rounds=5, iters=20):
     w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
     pb.gemm(a, w, M, N, K)
     plan = pb.build(); plan.run(); torch.cuda.synchronize()
-    res = {"1": [], "0": []}
+    res = {"0": [], "9": [], "10": []}
     for r in range(rounds):
         for mode in res:
-            os.environ["MTX_GEMM_CLAMP"] = mode
+            os.environ["MTX_GEMM_ABL"] = mode
             plan.time(3)
             res[mode].append(plan.time(iters))
     for mode, v in res.items():
-        print(f"gemm {M}x{N}x{K} clamp={mode}: best {min(v):.3f} ms ({2 * M * N * K / min(v) / 1e9:.0f} TF/s), median {sorted(v)[len(v) // 2]:.3f} ms")
+        print(f"gemm {M}x{N}x{K} abl={mode}: best {min(v):.3f} ms ({2 * M * N * K / min(v) / 1e9:.0f} TF/s), median {sorted(v)[len(v) // 2]:.3f} ms")
 
 
 if __name__ == "__main__":
