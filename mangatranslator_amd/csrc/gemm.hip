@@ -11,6 +11,7 @@
 // output columns; the tile is transposed through LDS and leaves as 16-byte row chunks with bias,
 // activation, per-sample gate (adaLN-Zero) and residual fused.
 #include "mtx_device.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace mtx {
@@ -311,46 +312,44 @@ __device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigne
   auto piece = [&](int i, int stage, long k0) {
     buf_load16_lds(i < 4 ? abuf : wbuf, voff[i], (unsigned)(k0 * sizeof(T)), smem + stage * G2_STAGE + (i * 8 + wvs) * 1024);
   };
-  int arow[4], wrow[2];
+  // fragment addresses: one VGPR per (stage, k-step, operand) — rows i*32 / j*32 further down share the swizzle term, so they are
+  // immediate offsets (4096 per 32 rows) and the loop carries no address arithmetic (every VALU instruction of a load segment
+  // takes an issue slot from the other group's MFMAs)
+  const int ar0 = wm * 128 + l31, wr0 = G2_BM + wn * 64 + l31;
+  int aaddr[2][4], waddr[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) arow[i] = wm * 128 + i * 32 + l31;
+  for (int st_ = 0; st_ < 2; ++st_)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) wrow[j] = G2_BM + wn * 64 + j * 32 + l31;
+    for (int ks = 0; ks < 4; ++ks) {
+      aaddr[st_][ks] = st_ * G2_STAGE + ar0 * 128 + (((2 * ks + hi) ^ ((ar0 >> 1) & 7)) << 4);
+      waddr[st_][ks] = st_ * G2_STAGE + wr0 * 128 + (((2 * ks + hi) ^ ((wr0 >> 1) & 7)) << 4);
+    }
 
 #pragma unroll
   for (int i = 0; i < 8; ++i) piece(i, (int)(kbeg & 1), kbeg * G2_BK);
   MTX_WAIT_VMEM();
   __syncthreads();
   if (grp == 1) G2_BAR();
-  for (long kt = kbeg; kt < kend; ++kt) {
-    const unsigned char* st = smem + (kt & 1) * G2_STAGE;
+  auto tile = [&](auto stage_c, long kt) {
+    constexpr int S = decltype(stage_c)::value;
     const bool more = kt + 1 < kend;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int ch = 2 * ks + hi;
       v8 af[4], wf[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(smem + waddr[S][ks] + j * 4096);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(smem + aaddr[S][ks] + i * 4096);
       if (more && ks < 3) {
-        const int stage = (int)((kt + 1) & 1);
         const long k0 = (kt + 1) * G2_BK;
-        if (p.abl == 9 || p.abl == 10) {                       // ablations: 4/4/0/0 and 2/3/3/0 piece spreads
-          const int lo = p.abl == 9 ? ks * 4 : (ks == 0 ? 0 : (ks == 1 ? 2 : 5));
-          const int hi_ = p.abl == 9 ? (ks < 2 ? ks * 4 + 4 : 8) : (ks == 0 ? 2 : (ks == 1 ? 5 : 8));
+        const int first = ks * 3, cnt = ks < 2 ? 3 : 2;       // 3/3/2/0 (4/4/0/0 measured equal, 2/3/3/0 2-6 % slower)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) if (i >= lo && i < hi_) piece(i, stage, k0);
-        } else {
-          const int first = ks * 3, cnt = ks < 2 ? 3 : 2;
-#pragma unroll
-          for (int i = 0; i < cnt; ++i) piece(first + i, stage, k0);
-        }
+        for (int i = 0; i < cnt; ++i) piece(first + i, 1 - S, k0);
       }
 #ifndef MTX_EMU
       // the tile's LAST fragment reads finish before the barrier (from the next segment on the other group's DMA overwrites this
-      // stage); the others are waited for after it, where the wait no longer delays the other group's load segment
-      if (ks == 3 || p.abl == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // stage); the others are waited for after it, where the wait does not delay the other group's load segment (measured equal)
+      if (ks == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
       if (ks == 3 && grp == 1) MTX_WAIT_VMEM();
       G2_BAR();
@@ -368,7 +367,13 @@ __device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigne
       if (ks == 3 && grp == 0) MTX_WAIT_VMEM();
       G2_BAR();
     }
-  }
+  };
+  typedef std::integral_constant<int, 0> St0;
+  typedef std::integral_constant<int, 1> St1;
+  long kt = kbeg;
+  if (kt & 1) { tile(St1(), kt); ++kt; }                      // tile kt lives in stage kt & 1
+  for (; kt + 1 < kend; kt += 2) { tile(St0(), kt); tile(St1(), kt + 1); }
+  if (kt < kend) tile(St0(), kt);
   if (grp == 0) G2_BAR();
 }
 
