@@ -120,7 +120,7 @@ def test_attention_long_sequence_duo_variant(emu_lib, monkeypatch):
 
 
 def test_gemm_256_tile_kernel(emu_lib, monkeypatch):
-    """the 256 x 256 LDS-DMA kernel (normally reserved for >= 160 tiles) on ragged small problems"""
+    """the 256 x 256 LDS-DMA kernel (normally used from 24 tiles up) on ragged small problems"""
     monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
     oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
     oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False)

@@ -110,6 +110,24 @@ def gemm_clamp(M, N, K, rounds=5, iters=20):
         print(f"gemm {M}x{N}x{K} abl={mode}: best {min(v):.3f} ms ({2 * M * N * K / min(v) / 1e9:.0f} TF/s), median {sorted(v)[len(v) // 2]:.3f} ms")
 
 
+def gemm_mintiles(M, N, K, rounds=5, iters=20):
+    """128-tile kernel (default below 160 tiles) vs the 256-tile descriptor-DMA kernel on few-tile problems"""
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    a = pb.buf((M, K), torch.bfloat16); a.normal_()
+    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
+    pb.gemm(a, w, M, N, K)
+    plan = pb.build(); plan.run(); torch.cuda.synchronize()
+    res = {"160": [], "1": []}
+    for r in range(rounds):
+        for mode in res:
+            os.environ["MTX_GEMM256_MIN_TILES"] = mode
+            plan.time(3)
+            res[mode].append(plan.time(iters))
+    os.environ.pop("MTX_GEMM256_MIN_TILES")
+    for mode, v in res.items():
+        print(f"gemm {M}x{N}x{K} min_tiles={mode}: best {min(v):.4f} ms ({2 * M * N * K / min(v) / 1e9:.0f} TF/s)")
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     while args:
@@ -121,6 +139,8 @@ if __name__ == "__main__":
             gemm_abl(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
         elif args[0] == "clamp":
             gemm_clamp(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
+        elif args[0] == "mintiles":
+            gemm_mintiles(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
         elif args[0] == "ab":
             gemm_ab(int(args[1]), int(args[2]), int(args[3])); args = args[4:]
         else:
