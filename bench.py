@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--boxes", type=int, default=8, help="bubbles per page (SAM prompts; generator ground truth, SURVEY.md §8d)")
     ap.add_argument("--regions", type=int, default=1, help="FLUX-inpainted outside-text regions per page (R in SURVEY.md §8d)")
     ap.add_argument("--inpaint-steps", type=int, default=20)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -76,12 +77,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if os.environ.get("MTX_BENCH_ONE_DEVICE") == "1":     # dry run of the N > 1 code path on a one-GPU box (with --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from PIL import Image
     from mangatranslator_amd.hip.lib import get_library
