@@ -256,9 +256,10 @@ class FluxKontextInpainter:
                 out = self.pipeline(image=scaled, width=inf_w, height=inf_h, num_inference_steps=self.num_inference_steps,
                                     guidance_scale=self.guidance_scale, generator=gen, output_type="pt",
                                     max_area=inf_w * inf_h, **self._prompt_kwargs())
-                img = out.images[0].float().cpu()
-                img = torch.nan_to_num(img, nan=0.0, posinf=1.0, neginf=0.0).clamp_(0, 1)
-                patch = Image.fromarray(img.mul(255).round().to(torch.uint8).permute(1, 2, 0).numpy())
+                # sanitise / quantise where the tensor lives (on the GPU these are microseconds; on the host 100 ms of fp32 passes
+                # over 3 MP) and download the uint8 HWC image — the same IEEE operations in the same order, so the bytes are identical
+                img = torch.nan_to_num(out.images[0].float(), nan=0.0, posinf=1.0, neginf=0.0).clamp_(0, 1)
+                patch = Image.fromarray(img.mul(255).round().to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy())
         patch = patch.resize((w, h), Image.Resampling.LANCZOS)
         page = np.asarray(image_pil)
         return Image.fromarray(composite_u8(page, np.asarray(patch), alpha, x, y))
