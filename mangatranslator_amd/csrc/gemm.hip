@@ -965,7 +965,10 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   // with the descriptor-DMA loop the 256-tile kernel wins from ~24 tiles up even though most CUs idle (512x9216x3072: 55 vs 68 us,
   // 1024x4608x1152: 24.5 vs 32.7 us); below that the 128-tile kernel's extra parallelism pays.  Tests lower it.
   // (short K — SAM's 576-wide stage — keeps the old threshold: the tile prologue / epilogue dominates there, encoder 12.5 vs 11.8 ms)
-  const long min_tiles = getenv("MTX_GEMM256_MIN_TILES") ? atol(getenv("MTX_GEMM256_MIN_TILES")) : (a->k >= 1024 ? 24 : 160);
+  // and so do shapes that would pad a 256-tile row or column by more than 10 % (SAM's N = 576: 3 columns for 2.25)
+  const long t256m = (a->m + G2_BM - 1) / G2_BM, t256n = (a->n + G2_BN - 1) / G2_BN;
+  const bool snug = a->m * 10 >= t256m * G2_BM * 9 && a->n * 10 >= t256n * G2_BN * 9;
+  const long min_tiles = getenv("MTX_GEMM256_MIN_TILES") ? atol(getenv("MTX_GEMM256_MIN_TILES")) : ((a->k >= 1024 && snug) ? 24 : 160);
   const bool few_long = a->workspace != nullptr && batch == 1 && t256 * 2 <= gemm_num_cus() && a->k / G2_BK >= 128 && a->m >= 256;
   if (!p.out_f32 && a->k % G2_BK == 0 && vec && (t256 >= min_tiles || few_long) && (a->dtype == MTX_BF16 || a->dtype == MTX_F16)) {
     p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
