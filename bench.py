@@ -210,23 +210,40 @@ def main():
         sc = plan0.decoded[:, 4].float().sort(descending=True).values
         yolo_conf = float(sc[min(3 * args.boxes, len(sc) - 1)])
 
+    stage_wall = {}
+
+    def lap(name, t_prev):      # only when a stage-by-stage wall-clock breakdown is being taken (one extra page after the timed region)
+        if stage_wall is not None and stage_wall.get("_on"):
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            stage_wall[name] = stage_wall.get(name, 0.0) + 1e3 * (now - t_prev)
+            return now
+        return t_prev
+
     def step(i):
         k = i % pool
+        tl = time.perf_counter()
         if yolo is not None:
             outs["detect"] = yolo(page_bgr[k], conf=yolo_conf, imgsz=1600)[0]
             outs["detect2"] = rtdetr(page_bgr[k], conf=0.35, imgsz=640)[0]
+            tl = lap("detect", tl)
         if sam is not None:      # prompts: the generator's ground-truth boxes (fixed unit count)
             outs["segment"] = sam.segment(pages[k], page_boxes[k])
+            tl = lap("segment", tl)
         if inpainter is not None:
             # the reference's OSB stage end to end (prepare + finish): the bubbles guard the fills, the text boxes arrive as text_free
             # detections, each region is classified by its border ring and the non-solid ones run through FLUX in waves.  Bubbles
             # and text boxes are the generator's ground truth, like the SAM prompts (seeded-random SAM weights give arbitrary
             # masks that may swallow the text block, so the masks of the segment stage are not fed forward here)
             bubbles_ = [{"bbox": tuple(float(v) for v in b)} for b in page_boxes[k]]
-            outs["inpaint"], _ = otp.process_outside_text(page_pil[k], osb_cfg, "page.png", "PNG", bubble_data=bubbles_,
-                                                          text_free_boxes=page_text_boxes[k])
+            work_ = otp.prepare_outside_text_work(page_pil[k], osb_cfg, "page.png", "PNG", bubble_data=bubbles_,      # == process_outside_text
+                                                  text_free_boxes=page_text_boxes[k])
+            tl = lap("inpaint_prepare", tl)
+            outs["inpaint"], _ = otp.finish_outside_text_work(work_) if work_ is not None else (page_pil[k], [])
+            tl = lap("inpaint_finish", tl)
         if upscaler is not None:
             outs["upscale"] = upscaler.upscale_u8(pages[k])
+            tl = lap("upscale", tl)
 
     def barrier():
         torch.cuda.synchronize()
@@ -247,6 +264,10 @@ def main():
     if flux is not None:          # every page sent its R regions through FLUX (none classified as solid, none dropped)
         want_calls = (pool + args.warmup + args.steps) * args.regions
         assert flux.calls == want_calls, f"expected {want_calls} FLUX calls, saw {flux.calls}"
+    if rank == 0:               # informational: wall clock of each stage of one more page, synchronised stage by stage
+        stage_wall["_on"] = True
+        step(0)
+        stage_wall.pop("_on")
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -266,6 +287,7 @@ def main():
                    "segmenter": "SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights" if sam is not None else None,
                    "inpainter": "FLUX.1-Kontext-dev geometry (19 double + 38 single blocks, d=3072, 24 heads), bf16, seeded random weights" if flux is not None else None,
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
+                   "stage_wall_ms_one_page": {k_: round(v_, 2) for k_, v_ in stage_wall.items()},
                    "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL"},
     }
     cfg = result["config"]

@@ -1,4 +1,6 @@
 set -x
-export MTX_BENCH_ONE_DEVICE=1
-timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 1 --warmup 1 --inpaint-steps 2 --backend gloo > gpurun_out/bench2.log 2> gpurun_out/bench2.err
-echo "exit $?"; tail -c 700 gpurun_out/bench2.log; echo; grep -v "amdgpu.ids\|RuntimeWarning\|alive &=\|iou = " gpurun_out/bench2.err | tail -15
+timeout 900 python bench.py --no-cpu-baseline > gpurun_out/bench_sw.log 2> gpurun_out/bench_sw.err; tail -c 300 gpurun_out/bench_sw.log; python - <<'PY'
+import json
+d = json.loads(open('gpurun_out/bench_sw.log').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['config']['stage_wall_ms_one_page'], d['config']['inpaint'], d['config']['segment_ms'], d['config']['upscale_ms'], d['config']['detect_net_ms'], d['config']['detect_rtdetr_ms'])
+PY
