@@ -300,14 +300,17 @@ __device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigne
 #ifndef MTX_EMU
   wvs = __builtin_amdgcn_readfirstlane(wv);
 #endif
-  const BufView abuf = make_buf(A, (unsigned)((((size_t)p.m - 1) * p.lda + p.k) * sizeof(T)));
-  const BufView wbuf = make_buf(W, (unsigned)((((size_t)p.n - 1) * p.ldw + p.k) * sizeof(T)));
+  // descriptors are TILE-relative (base = first row of the tile, records = the tile's valid rows): lane offsets stay far below
+  // 4 GB whatever the matrix size, and rows past M / N fall outside the records (zero fill)
+  const long mrows = p.m - m0 < G2_BM ? p.m - m0 : G2_BM, nrows = p.n - n0 < G2_BN ? p.n - n0 : G2_BN;
+  const BufView abuf = make_buf(A + (size_t)m0 * p.lda, (unsigned)((((size_t)mrows - 1) * p.lda + p.k) * sizeof(T)));
+  const BufView wbuf = make_buf(W + (size_t)n0 * p.ldw, (unsigned)((((size_t)nrows - 1) * p.ldw + p.k) * sizeof(T)));
   unsigned voff[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {           // piece i of wave wv fills LDS rows (i*8 + wv)*8 .. +7 of a stage; rows 0..255 are A, 256..511 W
     const int row = (i * 8 + wv) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    voff[i] = i < 4 ? (unsigned)(((size_t)(m0 + row) * p.lda + c * 8) * sizeof(T)) : (unsigned)(((size_t)(n0 + row - G2_BM) * p.ldw + c * 8) * sizeof(T));
+    voff[i] = i < 4 ? (unsigned)(((size_t)row * p.lda + c * 8) * sizeof(T)) : (unsigned)(((size_t)(row - G2_BM) * p.ldw + c * 8) * sizeof(T));
   }
   auto piece = [&](int i, int stage, long k0) {
     buf_load16_lds(i < 4 ? abuf : wbuf, voff[i], (unsigned)(k0 * sizeof(T)), smem + stage * G2_STAGE + (i * 8 + wvs) * 1024);
@@ -914,7 +917,7 @@ static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream) {
   // measured on MI355X (tools/bench_kernels.py ab, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the
   // 3/3/2/0 piece spread runs 1119-1341 TFLOP/s, 12-15 % ahead of the flat-address ping-pong (wins up to K = 4096) and one-barrier
   // (wins above) loops it replaces; the ring is 2-5 % and the wave-specialised variant 10-15 % behind those
-  const bool fits32 = ((size_t)p.m * p.lda + p.k) * sizeof(T) < (1ull << 32) && ((size_t)p.n * p.ldw + p.k) * sizeof(T) < (1ull << 32);
+  const bool fits32 = ((size_t)G2_BM * p.lda + p.k) * sizeof(T) < (1ull << 32) && ((size_t)G2_BN * p.ldw + p.k) * sizeof(T) < (1ull << 32);      // one tile's rows under a descriptor
   const char mode = e ? e[0] : (fits32 ? 'b' : (p.k <= 4096 ? 'p' : 'l'));
   // stream-K tail when the last wave of tiles would fill less than ~70 % of the chip
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;

@@ -130,6 +130,28 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
     return err
 
 
+def check_gemm_huge_rows(lib, dtype, m, n, k, seed=0):
+    """A matrix larger than 4 GB (a descriptor's reach): the rows are generated on the device and row blocks at the start, at the end
+    and around the 4 GB byte offset are compared with a torch fp32 product of those rows"""
+    dev, td = _dev(lib), TD[dtype]
+    g = torch.Generator(device=dev).manual_seed(seed)
+    pb = PlanBuilder(lib, dev, dtype)
+    at = pb.buf((m, k), td)
+    step = 1 << 16
+    for r0 in range(0, m, step):                       # filled in slices: a 4.5 GB fp32 temporary per call otherwise
+        at[r0:r0 + step] = torch.randn((min(step, m - r0), k), device=dev, generator=g).to(td)
+    w = (torch.randn(n, k, generator=torch.Generator().manual_seed(seed + 1)) / math.sqrt(k)).to(td)
+    wt = pb.const(w)
+    out = pb.gemm(at, wt, m, n, k)
+    _run(pb)
+    edge = (1 << 32) // (k * at.element_size())        # first row whose bytes start beyond 4 GB
+    for r0 in (0, edge - 300, m - 517):
+        rows = slice(max(r0, 0), min(max(r0, 0) + 517, m))
+        ref = at[rows].float() @ wt.float().t()
+        err = _relerr(out[rows].float().cpu(), ref.cpu())
+        assert err < TOL[dtype], f"gemm rows {rows} mismatch rel err {err}"
+
+
 def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, prescaled=False):
     """prescaled: q carries scale * log2(e) before its rounding to the storage type (MTX_ATTN_Q_PRESCALED): the reference is the
     base-2 softmax of q k^T, i.e. SDPA with scale = ln 2 on the very same rounded q"""

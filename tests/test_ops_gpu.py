@@ -139,6 +139,11 @@ def test_flux_prep_kernels(hip_lib):
     oc.check_softmax_transpose(hip_lib, abi.F16, rows=70, cols=136)
 
 
+def test_gemm_matrix_beyond_4gb(hip_lib):
+    """VAE im2col shape class: 1.05 M rows x 2304 columns of bf16 = 4.8 GB; tile-relative descriptors keep the 256-tile kernel"""
+    oc.check_gemm_huge_rows(hip_lib, abi.BF16, m=1050000, n=256, k=2304)
+
+
 def test_gemm_stream_k(hip_lib):
     oc.check_gemm(hip_lib, abi.BF16, m=512, n=3072, k=12288, with_res=True, with_gate=True)        # whole problem dealt over K
     oc.check_gemm(hip_lib, abi.BF16, m=8624, n=3072, k=15360, act=abi.ACT_NONE, with_res=True, with_gate=True)   # left-over tiles only
