@@ -1,6 +1,11 @@
 """Final upscale operator: `upscale_image`, `upscale_image_to_dimension`,
 `image_to_tensor`, `tensor_to_image` with the reference's signatures (core/image/image_utils.py:351-548).
-The model call goes to the RCAN graph on libmtx_hip; PIL handles the final exact-size LANCZOS."""
+The model call goes to the RCAN graph on libmtx_hip; PIL handles the final exact-size LANCZOS.
+Plus the page writer of row f2, `save_image_with_compression` (reference :59-170)."""
+import io
+import os
+from pathlib import Path
+
 import numpy as np
 import torch
 from PIL import Image
@@ -8,6 +13,56 @@ from PIL import Image
 from ...utils.exceptions import ImageProcessingError
 from ...utils.logging import log_message
 from ..ml.model_manager import get_model_manager
+
+
+def save_image_with_compression(image: Image.Image, output_path, jpeg_quality: int = 95, png_compression: int = 2, verbose: bool = False) -> bool:
+    """JPEG (alpha composited on white, quality clamped to 1..100), PNG (oxipng level 0..6 when the optimiser is installed, else
+    the reference's own Pillow fallback: compress_level + optimize), lossless WEBP; unknown extensions become .png (reference :59-170)."""
+    output_path = Path(output_path)
+    ext = output_path.suffix.lower()
+    fmt, opts = None, {}
+    if ext in (".jpg", ".jpeg"):
+        fmt = "JPEG"
+        if image.mode in ("RGBA", "LA"):
+            background = Image.new("RGB", image.size, (255, 255, 255))
+            background.paste(image, mask=image.split()[-1])
+            image = background
+        elif image.mode != "RGB":
+            image = image.convert("RGB")
+        opts["quality"] = max(1, min(jpeg_quality, 100))
+    elif ext == ".png":
+        fmt = "PNG"
+    elif ext == ".webp":
+        fmt, opts = "WEBP", {"lossless": True}
+    else:
+        log_message(f"Warning: Unknown output extension '{ext}'. Saving as PNG.", always_print=True)
+        fmt, output_path = "PNG", output_path.with_suffix(".png")
+    level = min(6, max(0, int(png_compression)))
+    log_message(f"Saving {fmt} image to {output_path}", verbose=verbose)
+    try:
+        os.makedirs(output_path.parent, exist_ok=True)
+        if fmt == "PNG":
+            data = None
+            try:
+                import oxipng                                        # optional Rust optimiser, as in the reference
+                buffer = io.BytesIO()
+                image.save(buffer, format="PNG")
+                data = oxipng.optimize_from_memory(buffer.getvalue(), level=level, optimize_alpha=True)
+            except ImportError:
+                pass
+            except Exception as e:                                   # oxipng.PngError
+                log_message(f"oxipng optimization failed: {e}. Falling back to Pillow save.", always_print=True)
+            if data is not None:
+                with open(output_path, "wb") as f:
+                    f.write(data)
+            else:
+                image.save(str(output_path), format="PNG", compress_level=level, optimize=True)
+        else:
+            image.save(str(output_path), format=fmt, **opts)
+        return True
+    except Exception as e:
+        log_message(f"Error saving image to {output_path}: {e}", always_print=True)
+        raise ImageProcessingError(f"Failed to save image to {output_path}") from e
 
 
 def image_to_tensor(image: Image.Image, device: torch.device) -> torch.Tensor:

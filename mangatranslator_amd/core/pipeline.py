@@ -7,10 +7,13 @@ dicts (`success_count`, `error_count`, `errors`, `failed_image_paths`, core/pipe
 """
 import os
 import re
+import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 from ..utils.logging import log_message
+from ..utils.path_list import IMAGE_EXTENSIONS, write_failed_paths
 
 NATURAL_SORT_TOKEN_RE = re.compile(r"(\d+)")
 
@@ -78,3 +81,111 @@ def process_pages_sharded(pages: Sequence, process_page: Callable[[Path], None])
     gathered = [None] * world
     dist.all_gather_object(gathered, local)
     return merge_batch_results(gathered)
+
+
+# ---- the batch harness's image I/O around the GPU work ------------------------------------------------
+def collect_image_files(input_dir: Path, preserve_structure: bool = False) -> List[Path]:
+    """the page list of a batch in the reference's order (core/pipeline.py:2532-2560): .jpg/.jpeg/.png/.webp files of the directory
+    (recursively with preserve_structure), naturally sorted on the path relative to the input directory"""
+    input_dir = Path(input_dir)
+    if preserve_structure:
+        files = [Path(root) / f for root, _dirs, names in os.walk(input_dir) for f in names if Path(f).suffix.lower() in IMAGE_EXTENSIONS]
+    else:
+        files = [f for f in input_dir.iterdir() if f.is_file() and f.suffix.lower() in IMAGE_EXTENSIONS]
+
+    def key(path: Path):
+        try:
+            rel = path.relative_to(input_dir) if preserve_structure else Path(path.name)
+        except ValueError:
+            rel = path
+        return _natural_path_sort_key(rel)
+    files.sort(key=key)
+    return files
+
+
+def load_page(img_path: Path, output_format: str):
+    """decode + the reference's mode rule (core/pipeline.py:707-717): RGBA unless the output is JPEG"""
+    from PIL import Image
+    with Image.open(img_path) as im:
+        im.load()
+        page = im.copy()
+    jpeg_out = output_format == "jpeg" or (output_format == "auto" and Path(img_path).suffix.lower() in (".jpg", ".jpeg"))
+    target = "RGB" if jpeg_out else "RGBA"
+    return page if page.mode == target else page.convert(target)
+
+
+def batch_process_images(input_dir, config, output_dir=None, preserve_structure: bool = False,
+                         process_image: Optional[Callable] = None, io_threads: int = 2) -> Dict:
+    """The vision half of `batch_translate_images` (core/pipeline.py:2481-2733) on one GPU or page-sharded over the ranks of the
+    initialised process group: same page list and order, same output naming (`_resolve_output_path`), same results dict
+    (`success_count`, `error_count`, `errors` keyed by the display path, `failed_image_paths` absolute, `failed_paths_file`), a bad
+    page never stops the batch.  `process_image(page: PIL.Image, path: Path) -> PIL.Image` is the per-page vision stack.
+    Host codec work is kept off the GPU's critical path: a pool of `io_threads` workers decodes the next pages while the current
+    one is on the GPU and encodes / writes finished pages behind it (PIL releases the GIL in its codecs)."""
+    from .image.image_utils import save_image_with_compression
+    import torch.distributed as dist
+    empty = {"success_count": 0, "error_count": 0, "errors": {}, "failed_image_paths": []}
+    input_dir = Path(input_dir)
+    if not input_dir.is_dir():
+        log_message(f"Input path '{input_dir}' is not a directory", always_print=True)
+        return empty
+    output_dir = Path(output_dir) if output_dir else Path("./output") / time.strftime("%Y%m%d_%H%M%S")
+    os.makedirs(output_dir, exist_ok=True)
+    files = collect_image_files(input_dir, preserve_structure)
+    if not files:
+        log_message(f"No image files found in '{input_dir}'", always_print=True)
+        return empty
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    mine = files[rank::world]                      # already in batch order: rank r takes pages r, r + G, ...
+    fmt = config.output.output_format
+    local = {"success_count": 0, "error_count": 0, "errors": {}, "failed_image_paths": []}
+    t0 = time.time()
+
+    def fail(img_path, error_key, e):
+        log_message(f"Error processing {error_key}: {e}", always_print=True)
+        local["error_count"] += 1
+        local["errors"][error_key] = str(e)
+        try:
+            local["failed_image_paths"].append(str(Path(img_path).resolve()))
+        except OSError:
+            local["failed_image_paths"].append(str(img_path))
+
+    with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool:
+        ahead = max(1, io_threads)
+        decodes = {i: pool.submit(load_page, mine[i], fmt) for i in range(min(ahead, len(mine)))}
+        saves = []
+        for i, img_path in enumerate(mine):
+            if i + ahead < len(mine):
+                decodes[i + ahead] = pool.submit(load_page, mine[i + ahead], fmt)
+            error_key = img_path.name
+            try:
+                out_path, display, error_key = _resolve_output_path(img_path, input_dir, output_dir, config, preserve_structure)
+                log_message(f"Processing {rank + i * world + 1}/{len(files)}: {display}", always_print=True)
+                page = decodes.pop(i).result()
+                result = process_image(page, img_path) if process_image is not None else page
+                saves.append((pool.submit(save_image_with_compression, result, out_path, config.output.jpeg_quality,
+                                          config.output.png_compression), img_path, error_key))
+            except Exception as e:      # noqa: BLE001 — a bad page must not stop the batch
+                decodes.pop(i, None)
+                fail(img_path, error_key, e)
+        for fut, img_path, error_key in saves:
+            try:
+                fut.result()
+                local["success_count"] += 1
+            except Exception as e:      # noqa: BLE001
+                fail(img_path, error_key, e)
+
+    if multi:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        results = merge_batch_results(gathered)
+    else:
+        results = merge_batch_results([local])
+    dt = time.time() - t0
+    log_message(f"Batch complete: {results['success_count']}/{len(files)} images in {dt:.2f}s ({dt / len(files):.2f}s/image)", always_print=True)
+    if results["failed_image_paths"] and rank == 0:
+        failed_file = write_failed_paths(output_dir, results["failed_image_paths"])
+        if failed_file:
+            results["failed_paths_file"] = str(failed_file)
+    return results

@@ -593,8 +593,50 @@ def gen_osb_stage():
 
 STAGE_ARRAYS = {}
 
+BATCH_TREE = ["P1.png", "p2.png", "p10.png", "ch2/001.jpg", "ch2/010.jpg", "ch10/001.jpg", "ch10/notes.txt", "x.webp", "cover.JPEG", "thumbs.db"]
+BATCH_FAIL = ["p2.png", "010.jpg"]
+
+
+def gen_batch():
+    """core/pipeline.py:2481-2733 `batch_translate_images` (sequential branch) with `translate_and_render` replaced by a recorder that
+    fails for two files: page list and order, output paths, results dict, failed_paths.txt — for the three output formats and both
+    directory modes."""
+    import tempfile
+    from core import pipeline as refp
+    refp._build_previous_context_images = lambda *a, **k: None
+    refp._build_previous_context_texts = lambda *a, **k: None
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        root = Path(tmp) / "in"
+        for rel in BATCH_TREE:
+            f = root / rel
+            f.parent.mkdir(parents=True, exist_ok=True)
+            if f.suffix.lower() in (".png", ".jpg", ".jpeg", ".webp"):
+                Image.new("RGB", (8, 8), (200, 10, 10)).save(f)
+            else:
+                f.write_text("x")
+        for tag, preserve, fmt in [("flat_png", False, "png"), ("tree_auto", True, "auto"), ("flat_jpeg", False, "jpeg"), ("tree_png", True, "png")]:
+            seen = []
+            odir = Path(tmp) / f"out_{tag}"
+
+            def fake(img_path, config, output_path, **kw):
+                seen.append([str(Path(img_path).relative_to(root)), str(Path(output_path).relative_to(odir))])
+                if Path(img_path).name in BATCH_FAIL:
+                    raise RuntimeError(f"boom: {Path(img_path).name}")
+            refp.translate_and_render = fake
+            cfg = types.SimpleNamespace(parallel_requests=1, verbose=False, retry_failed_once=False,
+                                        output=types.SimpleNamespace(output_format=fmt, jpeg_quality=95, png_compression=2))
+            res = refp.batch_translate_images(root, cfg, odir, preserve_structure=preserve)
+            ff = res.get("failed_paths_file")
+            out[tag] = dict(preserve=preserve, fmt=fmt, seen=seen, success_count=res["success_count"], error_count=res["error_count"],
+                            errors=res["errors"], failed=[str(Path(p_).relative_to(root.resolve())) for p_ in res["failed_image_paths"]],
+                            failed_file_lines=[str(Path(l).relative_to(root.resolve())) for l in Path(ff).read_text().split()] if ff else None,
+                            failed_file_name=Path(ff).name if ff else None)
+    return dict(tree=BATCH_TREE, fail=BATCH_FAIL, runs=out)
+
 
 if __name__ == "__main__":
+    json.dump(gen_batch(), open(HERE / "batch_harness.json", "w"))
     json.dump(gen_osb_stage(), open(HERE / "osb_stage.json", "w"))
     np.savez_compressed(HERE / "osb_stage_arrays.npz", **STAGE_ARRAYS)
     json.dump(gen_osb(), open(HERE / "osb_regions.json", "w"))

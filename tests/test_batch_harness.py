@@ -1,0 +1,124 @@
+"""The batch harness's page I/O vs goldens produced by running the REFERENCE `batch_translate_images`
+(core/pipeline.py:2481-2733, sequential branch, `translate_and_render` replaced by a recorder): page list and order, output naming,
+results dict, failed_paths.txt — for three output formats and both directory modes; plus the page writer and a 2-rank gloo run."""
+import json
+import os
+import socket
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from PIL import Image
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = json.loads((Path(__file__).resolve().parent / "golden" / "batch_harness.json").read_text())
+
+
+def _make_tree(root: Path):
+    for rel in GOLD["tree"]:
+        f = root / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        if f.suffix.lower() in (".png", ".jpg", ".jpeg", ".webp"):
+            Image.new("RGB", (8, 8), (200, 10, 10)).save(f)
+        else:
+            f.write_text("x")
+
+
+def _cfg(fmt):
+    return types.SimpleNamespace(verbose=False, output=types.SimpleNamespace(output_format=fmt, jpeg_quality=95, png_compression=2))
+
+
+@pytest.mark.parametrize("tag", list(GOLD["runs"]))
+def test_batch_matches_reference(tmp_path, tag):
+    from mangatranslator_amd.core.pipeline import batch_process_images
+    g = GOLD["runs"][tag]
+    root, odir = tmp_path / "in", tmp_path / "out"
+    _make_tree(root)
+    seen = []
+
+    def process(page, path):
+        seen.append(str(Path(path).relative_to(root)))
+        assert page.mode == ("RGB" if g["fmt"] == "jpeg" or (g["fmt"] == "auto" and path.suffix.lower() in (".jpg", ".jpeg")) else "RGBA")
+        if path.name in GOLD["fail"]:
+            raise RuntimeError(f"boom: {path.name}")
+        return page
+
+    res = batch_process_images(root, _cfg(g["fmt"]), odir, preserve_structure=g["preserve"], process_image=process)
+    assert seen == [s[0] for s in g["seen"]]
+    assert res["success_count"] == g["success_count"] and res["error_count"] == g["error_count"] and res["errors"] == g["errors"]
+    assert [str(Path(p).relative_to(root.resolve())) for p in res["failed_image_paths"]] == g["failed"]
+    ff = Path(res["failed_paths_file"])
+    assert ff.name == g["failed_file_name"] and ff.parent == odir
+    assert [str(Path(l).relative_to(root.resolve())) for l in ff.read_text().split()] == g["failed_file_lines"]
+    for rel_in, rel_out in g["seen"]:
+        ok = Path(rel_in).name not in GOLD["fail"]
+        assert (odir / rel_out).exists() == ok
+        if ok:
+            with Image.open(odir / rel_out) as im:
+                assert im.size == (8, 8)
+
+
+def test_save_image_with_compression(tmp_path):
+    from mangatranslator_amd.core.image.image_utils import save_image_with_compression
+    rgba = Image.fromarray(np.dstack([np.full((6, 5, 3), 40, np.uint8), np.zeros((6, 5, 1), np.uint8)]), "RGBA")
+    save_image_with_compression(rgba, tmp_path / "a" / "x.jpg", jpeg_quality=500)
+    with Image.open(tmp_path / "a" / "x.jpg") as im:          # transparent pixels are composited on white
+        assert im.mode == "RGB" and min(im.getpixel((2, 2))) > 245
+    save_image_with_compression(rgba, tmp_path / "x.png", png_compression=9)
+    with Image.open(tmp_path / "x.png") as im:                # lossless
+        assert im.mode == "RGBA" and np.array_equal(np.asarray(im), np.asarray(rgba))
+    save_image_with_compression(rgba, tmp_path / "x.webp")
+    save_image_with_compression(rgba.convert("RGB"), tmp_path / "x.tiff")
+    assert (tmp_path / "x.webp").exists() and (tmp_path / "x.png").exists() and not (tmp_path / "x.tiff").exists()
+
+
+def test_empty_and_missing_dirs(tmp_path):
+    from mangatranslator_amd.core.pipeline import batch_process_images, collect_image_files
+    empty = {"success_count": 0, "error_count": 0, "errors": {}, "failed_image_paths": []}
+    assert batch_process_images(tmp_path / "nope", _cfg("png"), tmp_path / "o") == empty
+    (tmp_path / "e").mkdir()
+    assert batch_process_images(tmp_path / "e", _cfg("png"), tmp_path / "o") == empty
+    assert collect_image_files(tmp_path / "e") == []
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mangatranslator_amd.core.pipeline import batch_process_images
+    root, odir = Path(tmp) / "in", Path(tmp) / "out"
+    g = GOLD["runs"]["tree_png"]
+    mine = []
+
+    def process(page, path):
+        mine.append(str(Path(path).relative_to(root)))
+        if path.name in GOLD["fail"]:
+            raise RuntimeError(f"boom: {path.name}")
+        return page
+
+    res = batch_process_images(root, _cfg("png"), odir, preserve_structure=True, process_image=process)
+    order = [s[0] for s in g["seen"]]
+    assert mine == order[rank::world]                                          # rank r takes pages r, r + G, ... of the batch order
+    assert res["success_count"] == g["success_count"] and res["error_count"] == g["error_count"] and res["errors"] == g["errors"]
+    assert [str(Path(p).relative_to(root.resolve())) for p in res["failed_image_paths"]] == g["failed"]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_batch(tmp_path):
+    _make_tree(tmp_path / "in")
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g = GOLD["runs"]["tree_png"]
+    written = sorted(str(p.relative_to(tmp_path / "out")) for p in (tmp_path / "out").rglob("*_translated.png"))
+    assert written == sorted(s[1] for s in g["seen"] if Path(s[0]).name not in GOLD["fail"])
+    assert (tmp_path / "out" / "failed_paths.txt").exists()
