@@ -189,3 +189,66 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
         if failed_file:
             results["failed_paths_file"] = str(failed_file)
     return results
+
+
+# ---- the vision half of `translate_and_render` (reference core/pipeline.py:638-1000, cleaning-only flow) ----------------------------
+def process_page_vision(page, config, image_path="page.png", image_format: Optional[str] = None, verbose: bool = False):
+    """One page through the hot path in the reference's stage order: detect speech bubbles (+ SAM masks) -> OSB text stage (regions
+    to FLUX or flat fill) -> bubble cleaning -> optional final upscale -> target mode.  `page` is the decoded PIL page already in its
+    target mode (`load_page`); the result is what the reference hands to `save_image_with_compression` in `cleaning_only` mode.
+    Stage failures degrade exactly as there: detection errors -> no bubbles (:804-807), cleaning errors -> the uncleaned page
+    (:94-123), OSB errors -> the page as it was.  Panel detection (`use_panel_sorting`) is not built: panels = None.
+    Returns `(page_out, info)` with the detections, the per-bubble cleaning records and the processing scale."""
+    import math
+    import numpy as np
+    from PIL import Image
+    from .image.cleaning import clean_speech_bubbles
+    from .image.detection import detect_speech_bubbles
+    from .image.image_utils import upscale_image
+    from .outside_text_processor import process_outside_text
+    from ..utils.exceptions import CleaningError
+    target_mode = page.mode if page.mode in ("RGB", "RGBA") else "RGBA"
+    if page.mode != target_mode:
+        page = page.convert(target_mode)
+    info = {"bubbles": [], "text_free_boxes": [], "cleaned": [], "processing_scale": 1.0}
+    if getattr(config, "upscaling_only", False):
+        out = page
+        if config.output.upscale_final_image:
+            out = upscale_image(out, config.output.image_upscale_factor, model_type=config.output.image_upscale_model, verbose=verbose)
+        return (out if out.mode == target_mode else out.convert(target_mode)), info
+    scale = math.sqrt(page.width * page.height / 1_000_000) if config.preprocessing.auto_scale else 1.0          # :765-771
+    info["processing_scale"] = scale
+    det = config.detection
+    try:
+        bubbles, text_free = detect_speech_bubbles(image_path, getattr(config, "yolo_model_path", None), det.confidence, verbose=verbose,
+                                                   device=config.device, seg_model=det.seg_model, conjoined_detection=det.conjoined_detection,
+                                                   conjoined_confidence=det.conjoined_confidence, image_override=page,
+                                                   osb_enabled=config.outside_text.enabled,
+                                                   osb_text_verification=det.use_osb_text_verification,
+                                                   osb_text_hf_token=config.outside_text.huggingface_token,
+                                                   bubble_detector_model=det.bubble_detector_model)
+    except Exception as e:      # noqa: BLE001
+        log_message(f"Error during detection: {e}", always_print=True)
+        bubbles, text_free = [], []
+    info["bubbles"], info["text_free_boxes"] = bubbles, text_free
+    page, _osb = process_outside_text(page, config, image_path, image_format, verbose, bubble_data=bubbles, text_free_boxes=text_free, panels=None)
+    if bubbles:
+        cl = config.cleaning
+        try:
+            cleaned_cv, info["cleaned"] = clean_speech_bubbles(
+                page, getattr(config, "yolo_model_path", None), det.confidence, pre_computed_detections=bubbles, device=config.device,
+                thresholding_value=cl.thresholding_value, use_otsu_threshold=cl.use_otsu_threshold, roi_shrink_px=cl.roi_shrink_px,
+                verbose=verbose, processing_scale=scale, conjoined_confidence=det.conjoined_confidence,
+                inpaint_colored_bubbles=cl.inpaint_colored_bubbles, bubble_detector_model=det.bubble_detector_model,
+                request_coordinator=getattr(config, "request_coordinator", None))
+            arr = np.asarray(cleaned_cv)
+            page = Image.fromarray(np.ascontiguousarray(arr[..., [2, 1, 0] + ([3] if arr.shape[2] == 4 else [])]))     # cv2_to_pil
+        except (CleaningError, Exception) as e:      # noqa: BLE001
+            log_message(f"Error during cleaning: {e}", always_print=True)
+    if page.mode != target_mode:
+        page = page.convert(target_mode)
+    if config.output.upscale_final_image:
+        page = upscale_image(page, config.output.image_upscale_factor, model_type=config.output.image_upscale_model, verbose=verbose)
+        if page.mode != target_mode:
+            page = page.convert(target_mode)
+    return page, info

@@ -1,0 +1,96 @@
+"""`process_page_vision` — the vision half of the reference's `translate_and_render` (core/pipeline.py:638-1000, cleaning-only flow):
+stage order, argument plumbing, mode handling and the degrade paths, with the four operators replaced by recorders."""
+import math
+import types
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from mangatranslator_amd.core import pipeline
+from mangatranslator_amd.core.image import cleaning, detection, image_utils
+from mangatranslator_amd.core import outside_text_processor as otp
+
+
+def _config(**over):
+    c = types.SimpleNamespace(
+        device="cpu", yolo_model_path=None, upscaling_only=False, request_coordinator=None,
+        preprocessing=types.SimpleNamespace(auto_scale=True),
+        detection=types.SimpleNamespace(confidence=0.6, seg_model="sam2", conjoined_detection=True, conjoined_confidence=0.35,
+                                        use_osb_text_verification=False, bubble_detector_model="yolo_2"),
+        cleaning=types.SimpleNamespace(thresholding_value=200, use_otsu_threshold=False, roi_shrink_px=5, inpaint_colored_bubbles=False),
+        outside_text=types.SimpleNamespace(enabled=True, huggingface_token=""),
+        output=types.SimpleNamespace(upscale_final_image=True, image_upscale_factor=2.0, image_upscale_model="model_lite"))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+@pytest.fixture
+def calls(monkeypatch):
+    log = []
+    bubbles = [{"bbox": (1, 2, 30, 40), "confidence": 0.9, "class": "bubble", "sam_mask": np.zeros((60, 50), np.uint8)}]
+
+    def detect(image_path, model_path, confidence, **kw):
+        log.append(("detect", kw["image_override"].mode, kw["seg_model"], kw["osb_enabled"], kw["bubble_detector_model"]))
+        return bubbles, [[5.0, 5.0, 9.0, 9.0]]
+
+    def osb(page, config, image_path, image_format, verbose, bubble_data=None, text_free_boxes=None, panels=None):
+        log.append(("osb", len(bubble_data), text_free_boxes, panels))
+        out = page.copy(); out.putpixel((0, 0), (1, 2, 3, 255) if page.mode == "RGBA" else (1, 2, 3))
+        return out, []
+
+    def clean(page, model_path, confidence, pre_computed_detections=None, processing_scale=1.0, **kw):
+        log.append(("clean", page.getpixel((0, 0))[:3], len(pre_computed_detections), round(processing_scale, 6), kw["thresholding_value"]))
+        arr = np.asarray(page)
+        bgr = np.ascontiguousarray(arr[..., [2, 1, 0] + ([3] if arr.shape[2] == 4 else [])]).copy()
+        bgr[1, 1, :3] = (10, 20, 30)                                   # B, G, R
+        return bgr, [{"bbox": (1, 2, 30, 40)}]
+
+    def upscale(image, factor, model_type="model", verbose=False):
+        log.append(("upscale", image.size, image.getpixel((1, 1))[:3], factor, model_type))
+        return image.resize((int(image.width * factor), int(image.height * factor))).convert("RGB")
+
+    monkeypatch.setattr(detection, "detect_speech_bubbles", detect)
+    monkeypatch.setattr(otp, "process_outside_text", osb)
+    monkeypatch.setattr(cleaning, "clean_speech_bubbles", clean)
+    monkeypatch.setattr(image_utils, "upscale_image", upscale)
+    return log
+
+
+def test_stage_order_and_plumbing(calls):
+    page = Image.new("RGBA", (50, 60), (250, 250, 250, 255))
+    out, info = pipeline.process_page_vision(page, _config())
+    assert [c[0] for c in calls] == ["detect", "osb", "clean", "upscale"]
+    assert calls[0] == ("detect", "RGBA", "sam2", True, "yolo_2")
+    assert calls[1] == ("osb", 1, [[5.0, 5.0, 9.0, 9.0]], None)
+    assert calls[2] == ("clean", (1, 2, 3), 1, round(math.sqrt(50 * 60 / 1e6), 6), 200)      # cleaning sees the OSB stage's output
+    assert calls[3] == ("upscale", (50, 60), (30, 20, 10), 2.0, "model_lite")                 # BGR -> RGB on the way back
+    assert out.mode == "RGBA" and out.size == (100, 120)                                      # the upscaler's RGB is brought back to the target mode
+    assert info["processing_scale"] == pytest.approx(math.sqrt(0.003)) and len(info["bubbles"]) == 1 and len(info["cleaned"]) == 1
+
+
+def test_degrade_paths_and_modes(calls, monkeypatch):
+    def boom(*a, **k):
+        raise RuntimeError("no model")
+    monkeypatch.setattr(detection, "detect_speech_bubbles", boom)
+    page = Image.new("RGB", (40, 40), (9, 9, 9))
+    cfg = _config(); cfg.output.upscale_final_image = False; cfg.preprocessing.auto_scale = False
+    out, info = pipeline.process_page_vision(page, cfg)
+    assert [c[0] for c in calls] == ["osb"] and calls[0][1] == 0           # no bubbles: OSB still runs, cleaning is skipped
+    assert out.mode == "RGB" and info["bubbles"] == [] and info["processing_scale"] == 1.0
+    calls.clear()
+    up = _config(upscaling_only=True)
+    out, _ = pipeline.process_page_vision(Image.new("RGBA", (10, 12)), up)
+    assert [c[0] for c in calls] == ["upscale"] and out.size == (20, 24) and out.mode == "RGBA"
+
+
+def test_cleaning_failure_keeps_the_page(calls, monkeypatch):
+    from mangatranslator_amd.utils.exceptions import CleaningError
+
+    def bad_clean(*a, **k):
+        raise CleaningError("contours")
+    monkeypatch.setattr(cleaning, "clean_speech_bubbles", bad_clean)
+    cfg = _config(); cfg.output.upscale_final_image = False
+    out, info = pipeline.process_page_vision(Image.new("RGBA", (50, 60), (250, 250, 250, 255)), cfg)
+    assert out.getpixel((0, 0))[:3] == (1, 2, 3) and info["cleaned"] == []
