@@ -92,20 +92,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   // (slot ^ (row & 7)) of that pixel — the swizzle is applied on the per-lane SOURCE address.
   // Out-of-image pixels read the zero page.
   constexpr int C64_NDMA = (C64_HPIX * 8 + 63) / 64;      // 41 wave-instructions per halo
-  // Interior tiles (the whole 18 x 18 halo inside the image; 95 % of a page) take the descriptor path: a halo pixel's offset from
-  // the tile origin does not depend on the tile, so each lane keeps one 32-bit offset per DMA instruction and the tile origin is
-  // the wave-uniform soffset — no address arithmetic, no bounds tests in the loop (they cost 18 of 146 us: every VALU instruction of
-  // a memory slot takes an issue slot from the other group's MFMAs).  Border tiles keep the per-pixel path below.
-  const bool fast_ok = ABL != 7 && p.cin == 64 && (size_t)p.n * p.h * p.w_in * (size_t)p.ldx * sizeof(T) < (1ull << 32);
-  const BufView xbuf = make_buf(p.x, (unsigned)((size_t)p.n * p.h * p.w_in * (size_t)p.ldx * sizeof(T)));
-  unsigned hvoff[(C64_NDMA + 3) / 4];
-#pragma unroll
-  for (int it = 0; it < (C64_NDMA + 3) / 4; ++it) {
-    const int slot = (wv + it * 4) * 64 + lane;
-    const int hp = slot >> 3, c = (slot & 7) ^ (hp & 7);
-    const int hy = hp / C64_HW, hx = hp - hy * C64_HW;
-    hvoff[it] = (unsigned)((((size_t)hy * p.w_in + hx) * (size_t)p.ldx + c * 8) * sizeof(T));
-  }
   auto dma_halo = [&](unsigned lin_in) {
 #ifdef MTX_EMU
     const unsigned lin = lin_in;
@@ -116,16 +102,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
     const int tile = (int)(lin % tiles_per_img);
     const int iy0 = (tile / p.tiles_x) * C64_T - 1, ix0 = (tile % p.tiles_x) * C64_T - 1;
     const size_t img_off = (size_t)img * p.h * p.w_in;
-    if (fast_ok && iy0 >= 0 && ix0 >= 0 && iy0 + C64_HW <= p.h && ix0 + C64_HW <= p.w_in) {
-      const unsigned soff = (unsigned)(((img_off + (size_t)iy0 * p.w_in + ix0) * (size_t)p.ldx) * sizeof(T));
-#pragma unroll
-      for (int it = 0; it < (C64_NDMA + 3) / 4; ++it) {
-        const int m = __builtin_amdgcn_readfirstlane(wv + it * 4);
-        if (m < C64_NDMA - 1) buf_load16_lds(xbuf, hvoff[it], soff, halo + m * 1024);
-        else if (m == C64_NDMA - 1 && lane < (C64_HPIX * 8 - (C64_NDMA - 1) * 64)) buf_load16_lds(xbuf, hvoff[it], soff, halo + m * 1024);
-      }
-      return;
-    }
 #pragma unroll
     for (int it = 0; it < (C64_NDMA + 3) / 4; ++it) {
       const int m = __builtin_amdgcn_readfirstlane(wv + it * 4);
@@ -271,7 +247,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       const unsigned lin = k < K ? tile_of(k) : ~0u;
       const unsigned lin1 = k + 1 < K ? tile_of(k + 1) : ~0u;
       // the next tile's halo goes in flight FIRST (this group's halo buffer is idle from the slot barrier on), so its latency runs
-      // behind the epilogue below (-3 % vs issuing it after the stores; ABL 5 = that older order)
+      // behind the epilogue below (whole RCAN graph 92.4 vs 96.5 ms with it issued after the stores; ABL 5 = that older order)
       if (ABL != 3 && ABL != 5 && lin1 != ~0u) dma_halo(lin1);
       // (1) epilogue straight from the accumulators: bias, activation, residual, 8-byte NHWC stores
       if (lin != ~0u) {
@@ -401,7 +377,6 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
     if (abl == 1) C64_GO(_Float16, 1, MTX_ACT_RELU, false);
     else if (abl == 3) C64_GO(_Float16, 3, MTX_ACT_RELU, false);
     else if (abl == 4) C64_GO(_Float16, 4, MTX_ACT_RELU, false);
-    else if (abl == 7) C64_GO(_Float16, 7, MTX_ACT_RELU, false);
     else if (abl == 5 && !sum && a->act == MTX_ACT_RELU) C64_GO(_Float16, 5, MTX_ACT_RELU, false);
     else if (abl == 5 && !sum && a->act == MTX_ACT_NONE) C64_GO(_Float16, 5, MTX_ACT_NONE, false);
     else if (sum) C64_ACT(_Float16, true);
