@@ -23,7 +23,6 @@ import torch
 from PIL import Image
 from scipy.ndimage import distance_transform_edt
 
-from ...utils.exceptions import ModelError
 from ...utils.logging import log_message
 
 BLUR_SCALE_FACTOR = 0.1

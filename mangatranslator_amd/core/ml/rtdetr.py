@@ -15,7 +15,6 @@ Graph (two plans, both replayable as hipGraphs):
   B  6 decoder layers: self-attention, multi-scale deformable attention (`mtx_detr` kernel), FFN, iterative box refinement.
 Post-processing (sigmoid, top-k over queries x classes, box scaling) follows HF `post_process_object_detection`.
 """
-import math
 import threading
 from types import SimpleNamespace
 

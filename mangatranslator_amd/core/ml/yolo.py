@@ -18,7 +18,6 @@ kernel; retina masks = one GEMM (prototypes x coefficients) + fused padding-crop
 / threshold writing page-resolution bitmasks.  NMS runs on the few surviving candidates on the host in
 the reference's exact order.
 """
-import math
 import threading
 from types import SimpleNamespace
 
@@ -27,7 +26,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder
+from ...hip.plan import PlanBuilder
 from ...utils.exceptions import ModelError
 
 
