@@ -358,10 +358,10 @@ def main():
                               "dit_tflops": (fl["gemm"] + fl["attention"]) / step_ms / 1e9,
                               "vae_encode_ms": flux.vae.encoder_plan(h2 * 16, w2 * 16).time(2), "vae_decode_ms": flux.vae.decoder_plan(h2 * 2, w2 * 2).time(2)}
             # ---- roofline of the dominant kernel: flash attention of one MMDiT block (52 % of a step) ------
-            # in-context timing: two eager runs of the whole step with an event pair around each of its 57 attention ops
+            # in-context timing: the whole step replayed as a hipGraph minus the same graph without its 57 attention ops
             attn_idx = [i_ for i_, lab in enumerate(plan.labels) if lab.endswith(".attn")]
-            plan.time_ops(attn_idx, 2)
-            ms = plan.time_ops(attn_idx, 3) / (3 * len(attn_idx))
+            plan.time_ops(attn_idx, 1)
+            ms = plan.time_ops(attn_idx, 4) / (4 * len(attn_idx))
             tfs = fl["attention_per_layer"] / ms / 1e9
             n_attn = len(flux.transformer.blocks) + len(flux.transformer.singles)
             result["roofline"] = {
@@ -384,7 +384,7 @@ def main():
                     n_, k_ = shapes[name]
                     g_fl += 2.0 * rows * n_ * k_; g_idx.append(i_)
             g_n = len(g_idx)
-            g_ms = plan.time_ops(g_idx, 3) / 3
+            g_ms = plan.time_ops(g_idx, 4) / 4
             result["roofline_gemm"] = {
                 "kernel": "gemm256_kernel<bf16> (256x256x64 LDS-DMA tiles), image/joint-stream linears of one MMDiT step",
                 "bound": "mfma", "achieved": g_fl / g_ms / 1e9, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -270,26 +270,49 @@ int mtx_plan_time_ops(void* plan, void* stream, const int* op_idx, int n_idx, in
   for (int i = 0; i < iters; ++i) { int rc = mtx_plan_run(plan, stream); if (rc) return rc; }
   return MTX_OK;
 #else
-  hipStream_t s = (hipStream_t)stream;
+  (void)stream;
   std::vector<char> sel(p->ops.size(), 0);
   for (int i = 0; i < n_idx; ++i) { if (op_idx[i] < 0 || op_idx[i] >= (int)p->ops.size()) return fail(MTX_ERR_INVALID, "mtx_plan_time_ops: op index out of range"); sel[(size_t)op_idx[i]] = 1; }
-  std::vector<hipEvent_t> ev((size_t)n_idx * 2);
-  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return fail(MTX_ERR_HIP, "hipEventCreate failed");
+  // In-context time of the selected ops = replay of the WHOLE plan as a hipGraph minus replay of the same graph without them, on a
+  // stream of its own.  (Event pairs around single eager launches read 0.15 ms too long on some boxes — the pair's own cost and the
+  // submission gap land inside the interval — while the production path is a graph replay anyway.)
+  hipStream_t s = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess || hipStreamCreate(&s) != hipSuccess) return fail(MTX_ERR_HIP, "mtx_plan_time_ops: stream setup failed");
+  hipGraphExec_t exec[2] = {nullptr, nullptr};
+  hipGraph_t graph[2] = {nullptr, nullptr};
   int rc = MTX_OK;
-  double total = 0.0;
-  for (int it = 0; it < iters && rc == MTX_OK; ++it) {
-    size_t k = 0;
+  for (int g = 0; g < 2 && rc == MTX_OK; ++g) {
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: begin capture failed"); break; }
     for (size_t i = 0; i < p->ops.size() && rc == MTX_OK; ++i) {
-      if (sel[i]) hipEventRecord(ev[k * 2], s);
-      rc = run_op(p->ops[i], stream);
-      if (rc != MTX_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; break; }
-      if (sel[i]) { hipEventRecord(ev[k * 2 + 1], s); ++k; }
+      if (g == 1 && sel[i]) continue;
+      rc = run_op(p->ops[i], (void*)s);
+      if (rc != MTX_OK) g_err = "op " + std::to_string(i) + ": " + g_err;
     }
-    if (rc != MTX_OK) break;
-    if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(MTX_ERR_HIP, "hipStreamSynchronize failed"); break; }
-    for (size_t j = 0; j < k; ++j) { float t = 0.f; hipEventElapsedTime(&t, ev[j * 2], ev[j * 2 + 1]); total += t; }
+    hipError_t e = hipStreamEndCapture(s, &graph[g]);
+    if (rc == MTX_OK && e != hipSuccess) rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: end capture failed");
+    if (rc == MTX_OK && hipGraphInstantiate(&exec[g], graph[g], nullptr, nullptr, 0) != hipSuccess) rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: instantiate failed");
   }
-  for (auto& e : ev) hipEventDestroy(e);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (rc == MTX_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail(MTX_ERR_HIP, "hipEventCreate failed");
+  double total = 0.0;
+  if (rc == MTX_OK) {
+    hipGraphLaunch(exec[0], s); hipGraphLaunch(exec[1], s);          // untimed first replays
+    for (int it = 0; it < iters && rc == MTX_OK; ++it)
+      for (int g = 0; g < 2; ++g) {
+        hipEventRecord(e0, s);
+        if (hipGraphLaunch(exec[g], s) != hipSuccess) { rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: graph launch failed"); break; }
+        hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(MTX_ERR_HIP, "hipEventSynchronize failed"); break; }
+        float t = 0.f;
+        hipEventElapsedTime(&t, e0, e1);
+        total += g == 0 ? t : -t;
+      }
+  }
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  for (int g = 0; g < 2; ++g) { if (exec[g]) hipGraphExecDestroy(exec[g]); if (graph[g]) hipGraphDestroy(graph[g]); }
+  hipStreamSynchronize(s);
+  hipStreamDestroy(s);
   *ms_total = (float)total;
   return rc;
 #endif

@@ -100,7 +100,8 @@ class Plan:
         return float(ms.value)
 
     def time_ops(self, op_indices, iters: int = 1, stream=None) -> float:
-        """summed in-context duration (ms) of the listed ops over `iters` eager runs of the whole plan"""
+        """in-context duration (ms) of the listed ops summed over `iters` measurements: graph replay of the whole plan minus graph
+        replay without them (include/mtx_hip.h)"""
         idx = (C.c_int * len(op_indices))(*[int(i) for i in op_indices])
         ms = C.c_float(0.0)
         self.lib.check(self.lib.mtx_plan_time_ops(self._h, self._stream(stream), idx, len(op_indices), iters, C.byref(ms)), "mtx_plan_time_ops")
