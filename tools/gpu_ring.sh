@@ -1,7 +1,4 @@
 set -x
-timeout 900 python bench.py --no-cpu-baseline > gpurun_out/bench_t.log 2> gpurun_out/bench_t.err; python - <<'PY'
-import json
-d = json.loads(open('gpurun_out/bench_t.log').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['config']['inpaint']['dit_step_ms'], {k: d['roofline'][k] for k in ('achieved','frac','avg_launch_ms')}, {k: d['roofline_gemm'][k] for k in ('achieved','frac','avg_launch_ms')})
-PY
-tail -3 gpurun_out/bench_t.err
+PMC="FETCH_SIZE" timeout 600 bash tools/pmc_kernels.sh attn 8652 gemm 8624 9216 3072 > gpurun_out/pmc_f.log 2>&1; cp gpurun_out/pmc/k_counter_collection.csv gpurun_out/pmc_fetch.csv
+PMC="WRITE_SIZE" timeout 600 bash tools/pmc_kernels.sh attn 8652 gemm 8624 9216 3072 > gpurun_out/pmc_w.log 2>&1; cp gpurun_out/pmc/k_counter_collection.csv gpurun_out/pmc_write.csv
+tail -3 gpurun_out/pmc_w.log
