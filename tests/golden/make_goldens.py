@@ -593,6 +593,51 @@ def gen_osb_stage():
 
 STAGE_ARRAYS = {}
 
+CLEAN_CASES = {      # name -> (page kwargs, operator kwargs, neighbours?, RGBA page?)
+    "light": (dict(seed=0), dict(), False, False),
+    "dark": (dict(seed=1, dark=True), dict(), False, False),
+    "otsu": (dict(seed=2), dict(use_otsu_threshold=True), False, False),
+    "scaled": (dict(seed=3), dict(processing_scale=1.5, roi_shrink_px=4), False, False),
+    "colored": (dict(seed=4), dict(inpaint_colored_bubbles=True, inpaint_method="none"), False, False),
+    "neighbors": (dict(seed=5), dict(), True, False),
+    "border_rgba": (dict(seed=6, touch_border=True), dict(thresholding_value=180), False, True),
+    "retry": (dict(seed=7, dark=True), dict(thresholding_value=250), False, False),       # nothing passes 250 on a dark bubble -> Otsu retry
+}
+CLEAN_ARRAYS = {}
+
+
+def gen_cleaning():
+    """core/image/cleaning.py:210-1140 — `clean_speech_bubbles` (incl. `process_single_bubble`, `_build_adaptive_shrink_mask`, the Otsu
+    retry and the grouped flat fill) run on the synthetic bubble pages of tests/cleaning_checks.py with every cv2 primitive served by
+    the restatement in oracle/cleaning_ref.py (tests/golden/cv2_shim.py): pins the reference's control flow around the primitives."""
+    sys.path.insert(0, str(HERE.parent.parent)); sys.path.insert(0, str(HERE.parent)); sys.path.insert(0, str(HERE))
+    import cv2_shim
+    import cleaning_checks
+    from core.image import cleaning as refc
+    from core.image import image_utils as refu
+    refc.cv2 = cv2_shim.namespace
+    refu.cv2 = cv2_shim.namespace
+    out = {}
+    for name, (pkw, okw, neigh, rgba) in CLEAN_CASES.items():
+        page, masks, bboxes = cleaning_checks.make_page(**pkw)
+        dets = []
+        for i, (m, bb) in enumerate(zip(masks, bboxes)):
+            d = {"bbox": tuple(int(v) for v in bb), "confidence": 0.9, "class": "bubble", "sam_mask": m}
+            if neigh:
+                d["conjoined_neighbor_bboxes"] = [tuple(int(v) for v in bboxes[1 - i])]
+            dets.append(d)
+        rgb = page[..., ::-1]
+        pil = Image.fromarray(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]) if rgba else np.ascontiguousarray(rgb))
+        cleaned, info = refc.clean_speech_bubbles(pil, None, pre_computed_detections=dets, **okw)
+        CLEAN_ARRAYS[f"{name}_cleaned"] = np.asarray(cleaned)
+        CLEAN_ARRAYS[f"{name}_masks"] = np.packbits(np.stack([b["mask"] > 0 for b in info])) if info else np.zeros(0, np.uint8)
+        out[name] = dict(page=pkw, op={k: v for k, v in okw.items()}, neighbors=neigh, rgba=rgba,
+                         bubbles=[dict(bbox=[int(v) for v in b["bbox"]], color=[int(v) for v in b["color"]], is_colored=bool(b["is_colored"]),
+                                       text_bbox=[int(v) for v in b["text_bbox"]] if b.get("text_bbox") is not None else None,
+                                       is_sam=bool(b["is_sam"])) for b in info])
+    return out
+
+
 BATCH_TREE = ["P1.png", "p2.png", "p10.png", "ch2/001.jpg", "ch2/010.jpg", "ch10/001.jpg", "ch10/notes.txt", "x.webp", "cover.JPEG", "thumbs.db"]
 BATCH_FAIL = ["p2.png", "010.jpg"]
 
@@ -636,6 +681,8 @@ def gen_batch():
 
 
 if __name__ == "__main__":
+    json.dump(gen_cleaning(), open(HERE / "cleaning_flow.json", "w"))
+    np.savez_compressed(HERE / "cleaning_flow_arrays.npz", **CLEAN_ARRAYS)
     json.dump(gen_batch(), open(HERE / "batch_harness.json", "w"))
     json.dump(gen_osb_stage(), open(HERE / "osb_stage.json", "w"))
     np.savez_compressed(HERE / "osb_stage_arrays.npz", **STAGE_ARRAYS)
