@@ -20,6 +20,16 @@ ARR = np.load(G / "cleaning_flow_arrays.npz")
 
 @pytest.mark.parametrize("name", list(GOLD))
 def test_clean_speech_bubbles_matches_reference_flow(emu_lib, name):
+    _check(emu_lib, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(GOLD))
+def test_clean_speech_bubbles_matches_reference_flow_gpu(hip_lib, name):
+    _check(hip_lib, name)
+
+
+def _check(emu_lib, name):
     g = GOLD[name]
     page, masks, bboxes = cleaning_checks.make_page(**g["page"])
     dets = []
