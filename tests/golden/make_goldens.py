@@ -638,6 +638,39 @@ def gen_cleaning():
     return out
 
 
+UPSCALE_ARRAYS = {}
+
+
+def fake_upscaler(t):
+    """deterministic stand-in for the RCAN model: nearest-neighbour 2x plus a position-dependent tint (float32 in, float32 out)"""
+    up = t.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    yy = torch.arange(up.shape[2], dtype=torch.float32).view(1, 1, -1, 1)
+    xx = torch.arange(up.shape[3], dtype=torch.float32).view(1, 1, 1, -1)
+    return up * 0.9 + ((yy * 3 + xx * 5) % 17) / 255.0
+
+
+def gen_upscale():
+    """core/image/image_utils.py:351-548 — `upscale_image` / `upscale_image_to_dimension` / tensor conversions with a stand-in 2x
+    model: pass count, u8 truncation between passes, the final exact-size LANCZOS resize, RGBA / L inputs."""
+    from core.image import image_utils as refu
+    none = lambda *a, **k: None
+    refu.get_cache = lambda: types.SimpleNamespace(get_upscale_cache_key=none, get_upscale_dimension_cache_key=none, get_upscaled_image=none, set_upscaled_image=none)
+    mgr = types.SimpleNamespace(load_upscale=lambda *a, **k: fake_upscaler, load_upscale_lite=lambda *a, **k: fake_upscaler, device=torch.device("cpu"))
+    refu.get_model_manager = lambda: mgr
+    rng = np.random.default_rng(11)
+    out = {}
+    for name, (mode, size, factor, mtype) in dict(x2=("RGB", (23, 17), 2.0, "model"), x1_5=("RGB", (23, 17), 1.5, "model_lite"),
+                                                  x3=("RGB", (9, 14), 3.0, "model"), x1=("RGB", (8, 8), 1.0, "model"),
+                                                  rgba=("RGBA", (12, 10), 2.5, "model"), gray=("L", (10, 12), 2.0, "model")).items():
+        arr = (rng.random((size[1], size[0], {"RGB": 3, "RGBA": 4, "L": 1}[mode])) * 255).astype(np.uint8)
+        img = Image.fromarray(arr[..., 0] if mode == "L" else arr, mode)
+        res = refu.upscale_image(img, factor, model_type=mtype)
+        UPSCALE_ARRAYS[f"{name}_in"] = arr
+        UPSCALE_ARRAYS[f"{name}_out"] = np.asarray(res)
+        out[name] = dict(mode=mode, size=list(size), factor=factor, model_type=mtype, out_mode=res.mode, out_size=list(res.size))
+    return out
+
+
 BATCH_TREE = ["P1.png", "p2.png", "p10.png", "ch2/001.jpg", "ch2/010.jpg", "ch10/001.jpg", "ch10/notes.txt", "x.webp", "cover.JPEG", "thumbs.db"]
 BATCH_FAIL = ["p2.png", "010.jpg"]
 
@@ -681,6 +714,8 @@ def gen_batch():
 
 
 if __name__ == "__main__":
+    json.dump(gen_upscale(), open(HERE / "upscale_flow.json", "w"))
+    np.savez_compressed(HERE / "upscale_flow_arrays.npz", **UPSCALE_ARRAYS)
     json.dump(gen_cleaning(), open(HERE / "cleaning_flow.json", "w"))
     np.savez_compressed(HERE / "cleaning_flow_arrays.npz", **CLEAN_ARRAYS)
     json.dump(gen_batch(), open(HERE / "batch_harness.json", "w"))
