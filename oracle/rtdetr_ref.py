@@ -39,6 +39,16 @@ def make_model(size="tiny_test", seed=0):
 
 
 @torch.no_grad()
+def spread_class_scores(model, seed=77, std=0.6):
+    """seeded class heads are nearly constant over the queries (every score 0.954...): widen them so thresholds and top-k order matter"""
+    g = torch.Generator().manual_seed(seed)
+    for name, p in model.named_parameters():
+        if "class_embed" in name or "enc_score_head" in name:
+            p.copy_(torch.randn(p.shape, generator=g) * std)
+    return model
+
+
+@torch.no_grad()
 def run(model, img_u8_resized: np.ndarray):
     """resized RGB uint8 [H, W, 3] -> (logits [Q, C], boxes cxcywh [Q, 4])"""
     x = torch.from_numpy(img_u8_resized).permute(2, 0, 1)[None].float() / 255.0
