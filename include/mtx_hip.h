@@ -324,6 +324,10 @@ MTX_API int mtx_detr(const mtx_detr_args* a, void* stream);
 MTX_API int mtx_host_chamfer_l2_5x5(const uint8_t* src, int w, int h, float* dist);
 MTX_API int mtx_host_text_mask(const uint8_t* thr, const uint8_t* eroded, int w, int h, int ox, int oy, int page_w, int page_h,
                                double min_area, uint8_t* final_mask, int* bbox);
+/* outline polygon of the largest 8-connected blob of a [h][w] mask (nonzero = set), outer border walked pixel centre to pixel
+ * centre — what ultralytics exposes as `results.masks[i].xy[0]` (reference core/image/detection.py:525-556 reads it when SAM gave no
+ * mask).  Writes up to `cap` (x, y) pairs, returns the outline's point count (call again if it exceeds cap), 0 for an empty mask. */
+MTX_API int mtx_host_mask_outline(const uint8_t* mask, int w, int h, int* xy, int cap);
 
 /* ---- plans: a network forward as one native call ----------------------------------------- */
 MTX_API int mtx_plan_create(const mtx_op* ops, int n_ops, void** plan);

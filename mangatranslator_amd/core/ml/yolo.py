@@ -258,7 +258,7 @@ class YoloSegHip:
             pb_[:, [0, 2]] = ((pb_[:, [0, 2]] - padw) / gain).clip(0, w0)
             pb_[:, [1, 3]] = ((pb_[:, [1, 3]] - padh) / gain).clip(0, h0)
             boxes_t = torch.from_numpy(pb_).to(self.device)
-            res.boxes = SimpleNamespace(xyxy=boxes_t, conf=torch.from_numpy(sc).to(self.device), cls=torch.from_numpy(cl.astype(np.float32)).to(self.device))
+            res.boxes = _Boxes(boxes_t, torch.from_numpy(sc).to(self.device), torch.from_numpy(cl.astype(np.float32)).to(self.device))
             # retina masks
             mh, mw = plan.proto.h, plan.proto.w
             gm = min(mh / h0, mw / w0)
@@ -270,5 +270,42 @@ class YoloSegHip:
             mp.protoflat.copy_(plan.proto.t.view(mh * mw, nm))
             mp.boxes.copy_(boxes_t)
             mp.run()
-            res.masks = SimpleNamespace(data=mp.masks.clone())
+            res.masks = _Masks(mp.masks.clone(), self.lib)
             return [res]
+
+
+class _Boxes:
+    """the slice of ultralytics `Boxes` the operators read: `.xyxy / .conf / .cls` tensors on the device, `len()`"""
+
+    def __init__(self, xyxy, conf, cls):
+        self.xyxy, self.conf, self.cls = xyxy, conf, cls
+
+    def __len__(self):
+        return int(self.xyxy.shape[0])
+
+
+class _Masks:
+    """the slice of ultralytics `Masks` the operators read (reference core/image/detection.py:525-556): `.data [N, H, W]` on the
+    device, `len()`, and `masks[i].xy[0]` — the instance's outline polygon (largest external contour, float32 (x, y) pixel
+    coordinates), traced natively on the host (`mtx_host_mask_outline`) only when somebody asks for it"""
+
+    def __init__(self, data, lib):
+        self.data, self._lib = data, lib
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    def __getitem__(self, i):
+        if not -len(self) <= i < len(self):
+            raise IndexError(i)
+        m = np.ascontiguousarray((self.data[i] > 0).to(torch.uint8).cpu().numpy())
+        h, w = m.shape
+        cap = 4 * (h + w)
+        buf = np.empty((cap, 2), np.int32)
+        n = self._lib.mtx_host_mask_outline(m.ctypes.data, w, h, buf.ctypes.data, cap)
+        if n > cap:
+            buf = np.empty((n, 2), np.int32)
+            n = self._lib.mtx_host_mask_outline(m.ctypes.data, w, h, buf.ctypes.data, n)
+        if n < 0:
+            raise RuntimeError("mtx_host_mask_outline failed")
+        return SimpleNamespace(xy=[buf[:n].astype(np.float32)], data=self.data[i:i + 1])

@@ -216,4 +216,20 @@ MTX_API int mtx_host_text_mask(const uint8_t* thr, const uint8_t* eroded, int w,
   return valid;
 }
 
+// Outline of the largest blob of a mask (ultralytics `Masks.xy`: the polygon of one instance = its largest external contour):
+// up to `cap` points (x, y) of the outer border walk, pixel centres.  Returns the number of points of the outline (which may exceed
+// `cap`: call again with a larger buffer), 0 for an empty mask.
+MTX_API int mtx_host_mask_outline(const uint8_t* mask, int w, int h, int* xy, int cap) {
+  if (!mask || w < 1 || h < 1 || (cap > 0 && !xy)) return MTX_ERR_INVALID;
+  std::vector<Blob> blobs;
+  external_contours(mask, w, h, blobs);
+  if (blobs.empty()) return 0;
+  size_t best = 0;
+  for (size_t i = 1; i < blobs.size(); ++i) if (blobs[i].poly.size() > blobs[best].poly.size()) best = i;      // "largest" = most points, as masks2segments
+  const std::vector<Pt>& c = blobs[best].poly;
+  const int n = (int)c.size();
+  for (int i = 0; i < n && i < cap; ++i) { xy[2 * i] = c[i].x; xy[2 * i + 1] = c[i].y; }
+  return n;
+}
+
 }  // extern "C"

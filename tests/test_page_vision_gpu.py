@@ -1,0 +1,98 @@
+"""GPU tier: one synthetic page through `process_page_vision` with every stage on the real HIP path (libmtx_hip through the C ABI) —
+YOLO-seg detector, RT-DETR-v2 secondary detector, SAM-2.1 (processor / model shims of the manager), the OSB stage with the FLUX
+Kontext pipeline, bubble cleaning kernels, RCAN final upscale — small seeded geometries of each network, loaded through the
+ModelManager slots the operators ask for.  Checks that the operators and the model objects fit together end to end (call shapes,
+result objects, devices, modes) and that the page leaves every stage changed the way that stage changes it."""
+import types
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(yolo_conf, coordinator):
+    return types.SimpleNamespace(
+        device=torch.device("cuda:0"), yolo_model_path=None, upscaling_only=False, request_coordinator=coordinator,
+        preprocessing=types.SimpleNamespace(auto_scale=True),
+        detection=types.SimpleNamespace(confidence=yolo_conf, seg_model="sam2", conjoined_detection=True, conjoined_confidence=0.35,
+                                        use_osb_text_verification=False, bubble_detector_model="yolo_1"),
+        cleaning=types.SimpleNamespace(thresholding_value=200, use_otsu_threshold=False, roi_shrink_px=5, inpaint_colored_bubbles=False),
+        outside_text=types.SimpleNamespace(
+            enabled=True, enable_page_number_filtering=False, min_area_ignore_ratio=0.0, seed=1, huggingface_token="",
+            inpainting_method="flux_kontext", flux_backend="sdnq", flux_low_vram=False, flux_num_inference_steps=2,
+            flux_group_regions=False, flux_residual_diff_threshold=0.15, osb_confidence=0.5, osb_text_free_only=False,
+            bbox_expansion_percent_width=0.1, bbox_expansion_percent_height=0.1, osb_render_expansion_narrow_multiplier=1.0,
+            osb_render_expansion_tiny_multiplier=1.0, text_box_proximity_ratio=0.02),
+        output=types.SimpleNamespace(upscale_final_image=True, image_upscale_factor=2.0, image_upscale_model="model_lite"))
+
+
+def test_page_through_all_stages(hip_lib, monkeypatch):
+    import flux_checks
+    from oracle import rcan_ref, rtdetr_ref, sam2_ref, yolo_ref
+    from mangatranslator_amd.core import pipeline
+    from mangatranslator_amd.core.batch_coordinator import BatchRequestCoordinator
+    from mangatranslator_amd.core.ml import flux as fx
+    from mangatranslator_amd.core.ml import model_manager as mm
+    from mangatranslator_amd.core.ml.rcan import RCANUpscaler
+    from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
+    from mangatranslator_amd.core.ml.sam2 import Sam2Hip
+    from mangatranslator_amd.core.ml.yolo import YoloSegHip
+    from mangatranslator_amd.utils.synthetic_pages import make_page
+    dev = torch.device("cuda:0")
+    mgr = mm.get_model_manager()
+    monkeypatch.setattr(mgr, "device", dev)
+
+    ynet = yolo_ref.make_model("n", 1, seed=3)
+    with torch.no_grad():
+        for l in range(3):
+            ynet.model[22].cv3[l][2].weight.mul_(0.05); ynet.model[22].cv3[l][2].bias.fill_(-1.0)
+            ynet.model[22].cv2[l][2].weight.mul_(0.1)
+    yolo = YoloSegHip(ynet.state_dict(), device=dev, lib=hip_lib, names={0: "speech_bubble"})
+    rmodel, rcfg = rtdetr_ref.make_model("tiny_test", seed=5)
+    rtdetr = RTDetrHip(rmodel.state_dict(), rcfg, device=dev, lib=hip_lib, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
+    smodel, scfg = sam2_ref.make_model("tiny_test", seed=2)
+    sam = Sam2Hip(smodel.state_dict(), scfg, device=dev, lib=hip_lib)
+    t, v = flux_checks.models(seed=4)
+    dit, vae = flux_checks.hip_models(t, v, hip_lib, dev)
+    flux = fx.FluxKontextHip(dit, vae)
+    g = torch.Generator().manual_seed(9)
+    flux.set_prompt_embeds(torch.randn(16, t.cfg["joint_dim"], generator=g), torch.randn(t.cfg["pooled_dim"], generator=g))
+    rcan = RCANUpscaler(rcan_ref.make_state_dict(n_feats=64, n_resgroups=2, n_resblocks=2, unshuffle=1, seed=7), device=dev, lib=hip_lib)
+    for slot, obj in [(mm.ModelType.YOLO_SPEECH_BUBBLE, yolo), (mm.ModelType.RTDETR_CONJOINED_BUBBLE, rtdetr),
+                      (mm.ModelType.SAM2, (mm._Sam2ProcessorShim(), mm._Sam2ModelShim(sam, torch.bfloat16))),
+                      (mm.ModelType.FLUX_KONTEXT_SDNQ_PIPELINE, flux), (mm.ModelType.UPSCALE_LITE, rcan)]:
+        monkeypatch.setitem(mgr.models, slot, obj)
+
+    W, H = 512, 768
+    pg, boxes, regions = make_page(3, W, H, bubbles=8, osb_regions=1)
+    page = Image.fromarray(pg).convert("RGBA")
+    # seeded weights have arbitrary scores: a threshold that lets about a dozen anchors through (as bench.py does)
+    yolo(np.ascontiguousarray(pg[..., ::-1]), conf=0.0, imgsz=640, max_det=1)
+    plan0, _ = next(iter(yolo._plans.values()))
+    sc = plan0.decoded[:, 4].float().sort(descending=True).values
+    conf = float(sc[min(12, len(sc) - 1)])
+    cfg = _config(conf, BatchRequestCoordinator(1))
+    x0, y0, x1, y1 = regions[0]
+    calls0 = flux.calls
+
+    # the OSB text boxes come from the generator (the OSB text network is not built: the manager's loader raises and the
+    # detector falls back to text_free boxes, which here are appended to what the secondary detector reports)
+    from mangatranslator_amd.core import outside_text_processor as otp
+    real = otp.process_outside_text
+
+    def osb_with_ground_truth(p, c, path, fmt, verbose, bubble_data=None, text_free_boxes=None, panels=None):
+        return real(p, c, path, fmt, verbose, bubble_data=bubble_data, text_free_boxes=list(text_free_boxes or []) + [[x0 + 5.0, y0 + 5.0, x1 - 5.0, y1 - 5.0]], panels=panels)
+    monkeypatch.setattr(otp, "process_outside_text", osb_with_ground_truth)
+
+    out, info = pipeline.process_page_vision(page, cfg)
+    assert out.mode == "RGBA" and out.size == (2 * W, 2 * H)
+    assert len(info["bubbles"]) >= 1, "the calibrated threshold lets detections through"
+    for b in info["bubbles"]:
+        assert b["sam_mask"].shape == (H, W) and b["sam_mask"].dtype == np.uint8 and len(b["bbox"]) == 4
+    assert flux.calls >= calls0 + 1, "the text block on the gradient went through the Kontext pipeline"
+    assert info["processing_scale"] == pytest.approx((W * H / 1e6) ** 0.5)
+    a = np.asarray(out.convert("RGB"))
+    assert a.std() > 5 and np.isfinite(a).all()

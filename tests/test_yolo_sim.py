@@ -22,3 +22,28 @@ def test_nms_order_and_ties():
 
 def test_yolo_n_small(emu_lib):
     yc.check_yolo(emu_lib, "cpu", "n", 160, 96, 128, mask_tol=0.05)
+
+
+def test_result_objects_have_the_ultralytics_surface(emu_lib):
+    """what the operators call on a detector result (reference core/image/detection.py:525-556, conjoined assembly): len(boxes),
+    len(masks), masks[i].xy[0] (outline polygon of the largest blob), masks.data"""
+    import numpy as np
+    import torch
+    from mangatranslator_amd.core.image.cleaning import _polygon_mask
+    from mangatranslator_amd.core.image.conjoined import fallback_to_yolo_mask
+    from mangatranslator_amd.core.ml.yolo import _Boxes, _Masks
+    import types
+    yy, xx = np.mgrid[0:40, 0:50]
+    blob = ((xx - 20) / 12.0) ** 2 + ((yy - 18) / 9.0) ** 2 <= 1
+    m = blob.astype(np.uint8)
+    m[30:33, 40:44] = 1                                   # a smaller second blob: the outline is the largest one's
+    masks = _Masks(torch.from_numpy(np.stack([m, np.zeros_like(m)])), emu_lib)
+    boxes = _Boxes(torch.zeros(2, 4), torch.ones(2), torch.zeros(2))
+    assert len(masks) == 2 and len(boxes) == 2
+    pts = masks[0].xy[0]
+    assert pts.dtype == np.float32 and pts.shape[1] == 2 and np.array_equal(_polygon_mask(pts, 40, 50) > 0, blob)
+    assert masks[1].xy[0].shape == (0, 2)
+    res = types.SimpleNamespace(masks=masks, boxes=boxes, orig_shape=(40, 50))
+    assert fallback_to_yolo_mask(res, 0, "points") == pts.tolist()
+    assert np.array_equal(fallback_to_yolo_mask(res, 0, "binary") > 0, m > 0)
+    assert fallback_to_yolo_mask(res, 5, "points") is None
