@@ -96,3 +96,12 @@ def test_page_through_all_stages(hip_lib, monkeypatch):
     assert info["processing_scale"] == pytest.approx((W * H / 1e6) ** 0.5)
     a = np.asarray(out.convert("RGB"))
     assert a.std() > 5 and np.isfinite(a).all()
+
+    # the same page with SAM switched off: masks come from the detector's own instance masks (`results.masks`), and the cleaning
+    # chain accepts those detections
+    from mangatranslator_amd.core.image import cleaning, detection
+    dets, _tf = detection.detect_speech_bubbles("page.png", None, conf, device=dev, seg_model="none", conjoined_detection=True,
+                                                image_override=page, bubble_detector_model="yolo_1")
+    assert len(dets) >= 1 and all(d["sam_mask"].shape == (H, W) for d in dets)
+    cleaned, cinfo = cleaning.clean_speech_bubbles(page, None, pre_computed_detections=dets, device=dev, processing_scale=info["processing_scale"])
+    assert cleaned.shape == (H, W, 4) and isinstance(cinfo, list)
