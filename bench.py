@@ -413,7 +413,7 @@ def main():
                 result["roofline_upscale_conv"] = conv_roof
             else:
                 result["roofline"] = conv_roof
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is a single-GPU-run item (rank 0 at N = 1 only)
             result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"))
         print(json.dumps(result))
     if dist is not None:
