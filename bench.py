@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--time-ops", default="auto", choices=["auto", "difference", "stamp"],
+                    help="in-context kernel timing of the roofline objects: hipGraph with minus hipGraph without the ops (HIP events), "
+                         "or device wall-clock stamps around the ops inside one graph (mtx_plan_time_ops, MTX_TIME_OPS=stamp); auto = "
+                         "both, stamps reported when they pass a sanity band around the difference figure")
     return ap.parse_args()
 
 
@@ -360,15 +364,15 @@ def main():
             # ---- roofline of the dominant kernel: flash attention of one MMDiT block (52 % of a step) ------
             # in-context timing: the whole step replayed as a hipGraph minus the same graph without its 57 attention ops
             attn_idx = [i_ for i_, lab in enumerate(plan.labels) if lab.endswith(".attn")]
-            plan.time_ops(attn_idx, 1)
-            ms = plan.time_ops(attn_idx, 4) / (4 * len(attn_idx))
+            a_ms, a_how, a_info = in_context_ms(plan, attn_idx, 4, args.time_ops)
+            ms = a_ms / len(attn_idx)
             tfs = fl["attention_per_layer"] / ms / 1e9
             n_attn = len(flux.transformer.blocks) + len(flux.transformer.singles)
             result["roofline"] = {
                 "kernel": f"attn_mma32_kernel<bf16, 128> 24 heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)",
                 "bound": "mfma", "achieved": tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS,
                 "traffic": pmc_traffic("attn_mma32_kernel") if fl["tokens"] == 8652 else None,
-                "avg_launch_ms": ms, "launches_per_page": n_attn * args.inpaint_steps * args.regions,
+                "avg_launch_ms": ms, "timing": a_how, "timing_detail": a_info, "launches_per_page": n_attn * args.inpaint_steps * args.regions,
                 "algorithmic_flops_per_launch": fl["attention_per_layer"], "pmc": pmc_mfma_util("attn_mma32_kernel"),
             }
             # the other MFMA-bound kernel: every 256-tile GEMM launch of one denoising step, timed one by one
@@ -384,11 +388,11 @@ def main():
                     n_, k_ = shapes[name]
                     g_fl += 2.0 * rows * n_ * k_; g_idx.append(i_)
             g_n = len(g_idx)
-            g_ms = plan.time_ops(g_idx, 4) / 4
+            g_ms, g_how, g_info = in_context_ms(plan, g_idx, 4, args.time_ops)
             result["roofline_gemm"] = {
                 "kernel": "gemm256_kernel<bf16> (256x256x64 LDS-DMA tiles), image/joint-stream linears of one MMDiT step",
                 "bound": "mfma", "achieved": g_fl / g_ms / 1e9, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": g_fl / g_ms / 1e9 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": g_ms / g_n,
+                "frac": g_fl / g_ms / 1e9 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": g_ms / g_n, "timing": g_how, "timing_detail": g_info,
                 "launches_per_page": g_n * args.inpaint_steps * args.regions, "algorithmic_flops_per_launch": g_fl / g_n,
                 "pmc": pmc_mfma_util("gemm256_kernelIDF16bLi0ELb1"),
             }
@@ -406,7 +410,7 @@ def main():
                 "kernel": "conv3x3_c64_kernel<f16> 64->64 @%dx%d" % (W_ // u, H_ // u),
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("conv3x3_c64_kernel") if (W_, H_, u) == (1024, 1536, 1) else None,
-                "avg_launch_ms": ms, "launches_per_page": work["n_conv64"],
+                "avg_launch_ms": ms, "timing": "event pair around 20 eager launches", "launches_per_page": work["n_conv64"],
                 "algorithmic_bytes_per_launch": work["conv64_bytes"], "mfma_tflops": tfs, "mfma_frac": tfs / MFMA_PEAK_TFLOPS,
             }
             if "roofline" in result:
@@ -419,6 +423,32 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def in_context_ms(plan, idx, iters, mode):
+    """Duration (ms per plan replay) of the ops `idx` inside the replayed plan.  "difference": hipGraph with minus hipGraph without the
+    ops, HIP events around each replay — an upper bound on a power-limited chip, where the graph without the ops also clocks higher
+    (run 20).  "stamp": device wall-clock stamps before and after each op inside ONE replay graph.  "auto": both; the
+    stamps are reported when they land in a sanity band around the difference figure (0.6x .. 1.05x), else the difference is."""
+    os.environ.pop("MTX_TIME_OPS", None)
+    plan.time_ops(idx, 1)
+    diff = plan.time_ops(idx, iters) / iters
+    info = {"difference_ms_per_launch": diff / len(idx)}
+    if mode == "difference":
+        return diff, "difference", info
+    stamped = None
+    try:
+        os.environ["MTX_TIME_OPS"] = "stamp"
+        plan.time_ops(idx, 1)
+        stamped = plan.time_ops(idx, iters) / iters
+        info["stamp_ms_per_launch"] = stamped / len(idx)
+    except Exception as e:                                    # a HIP error in the stamped replay: keep the difference figure
+        info["stamp_error"] = str(e)[:160]
+    finally:
+        os.environ.pop("MTX_TIME_OPS", None)
+    if stamped is not None and (mode == "stamp" or 0.6 * diff <= stamped <= 1.05 * diff):
+        return stamped, "stamp", info
+    return diff, "difference", info
 
 
 def cpu_baseline(stages, rcan_sd, W_, H_, args, inpaint_info):

@@ -342,7 +342,9 @@ MTX_API void mtx_plan_destroy(void* plan);
 MTX_API int mtx_plan_time(void* plan, void* stream, int iters, int use_graph, float* ms_per_iter);
 /* in-context time of the ops listed in op_idx: the whole plan replayed as a hipGraph minus the same graph without those ops, HIP
  * events around each replay on a stream of the function's own; *ms_total = that difference summed over `iters` pairs of replays
- * (caches, clocks and launch mode as in the production path).  The skipped ops leave their outputs stale: timing only. */
+ * (caches, clocks and launch mode as in the production path).  The skipped ops leave their outputs stale: timing only.
+ * With MTX_TIME_OPS=stamp in the environment the figure comes instead from one replay graph that stores the device wall clock
+ * before and after each listed op (no second graph, so the power mix of the replay is the production one). */
 MTX_API int mtx_plan_time_ops(void* plan, void* stream, const int* op_idx, int n_idx, int iters, float* ms_total);
 /* time only ops [first,last] of a plan: avg ms over iters (events on `stream`)              */
 MTX_API int mtx_plan_time_range(void* plan, int first, int last, void* stream, int iters, float* ms);

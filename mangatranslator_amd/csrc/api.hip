@@ -7,6 +7,7 @@
 #include "mtx_device.h"
 #include <string>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include <new>
 
@@ -76,6 +77,56 @@ static int run_op(const mtx_op& op, void* stream) {
   }
   return check_launch(rc, err);
 }
+
+#ifndef MTX_EMU
+// Opt-in alternative to the graph-difference timing below (MTX_TIME_OPS=stamp): ONE replay graph of the whole plan with a one-lane
+// kernel before and after every selected op that stores the device's constant-rate wall clock; the op's time is the stamp
+// difference (plus two launch gaps of a few microseconds).  Unlike "graph with minus graph without" it does not change the power
+// mix of the replay, so the clocks the other kernels run at do not leak into the figure.
+__global__ void stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
+
+static int time_ops_stamped(Plan* p, const std::vector<char>& sel, int iters, float* ms_total) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+    return fail(MTX_ERR_HIP, "mtx_plan_time_ops: wall clock rate unavailable");
+  size_t n_sel = 0;
+  for (char c : sel) n_sel += c != 0;
+  hipStream_t s = nullptr;
+  unsigned long long* d_t = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess || hipStreamCreate(&s) != hipSuccess) return fail(MTX_ERR_HIP, "mtx_plan_time_ops: stream setup failed");
+  if (hipMalloc((void**)&d_t, 2 * n_sel * sizeof(unsigned long long)) != hipSuccess) { hipStreamDestroy(s); return fail(MTX_ERR_HIP, "mtx_plan_time_ops: hipMalloc failed"); }
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int rc = MTX_OK;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: begin capture failed");
+  if (rc == MTX_OK) {
+    size_t k = 0;
+    for (size_t i = 0; i < p->ops.size() && rc == MTX_OK; ++i) {
+      if (sel[i]) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, d_t + 2 * k);
+      rc = run_op(p->ops[i], (void*)s);
+      if (rc != MTX_OK) g_err = "op " + std::to_string(i) + ": " + g_err;
+      if (sel[i]) { hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, d_t + 2 * k + 1); ++k; }
+    }
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc == MTX_OK && e != hipSuccess) rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: end capture failed");
+    if (rc == MTX_OK && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: instantiate failed");
+  }
+  std::vector<unsigned long long> h_t(2 * n_sel);
+  double ticks = 0.0;
+  for (int it = -1; it < iters && rc == MTX_OK; ++it) {                // replay -1 is untimed
+    if (hipGraphLaunch(exec, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: graph launch failed"); break; }
+    if (it < 0) continue;
+    if (hipMemcpy(h_t.data(), d_t, h_t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: stamp readback failed"); break; }
+    for (size_t k = 0; k < n_sel; ++k) ticks += (double)(h_t[2 * k + 1] - h_t[2 * k]);
+  }
+  if (exec) hipGraphExecDestroy(exec);
+  if (graph) hipGraphDestroy(graph);
+  hipFree(d_t);
+  hipStreamDestroy(s);
+  *ms_total = (float)(ticks / (double)khz);
+  return rc;
+}
+#endif
 
 }  // namespace mtx
 
@@ -273,6 +324,8 @@ int mtx_plan_time_ops(void* plan, void* stream, const int* op_idx, int n_idx, in
   (void)stream;
   std::vector<char> sel(p->ops.size(), 0);
   for (int i = 0; i < n_idx; ++i) { if (op_idx[i] < 0 || op_idx[i] >= (int)p->ops.size()) return fail(MTX_ERR_INVALID, "mtx_plan_time_ops: op index out of range"); sel[(size_t)op_idx[i]] = 1; }
+  const char* how = getenv("MTX_TIME_OPS");
+  if (how && !strcmp(how, "stamp")) return time_ops_stamped(p, sel, iters, ms_total);
   // In-context time of the selected ops = replay of the WHOLE plan as a hipGraph minus replay of the same graph without them, on a
   // stream of its own.  (Event pairs around single eager launches read 0.15 ms too long on some boxes — the pair's own cost and the
   // submission gap land inside the interval — while the production path is a graph replay anyway.)

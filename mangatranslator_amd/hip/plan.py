@@ -101,7 +101,7 @@ class Plan:
 
     def time_ops(self, op_indices, iters: int = 1, stream=None) -> float:
         """in-context duration (ms) of the listed ops summed over `iters` measurements: graph replay of the whole plan minus graph
-        replay without them (include/mtx_hip.h)"""
+        replay without them, or (MTX_TIME_OPS=stamp) device wall-clock stamps around them inside one replay (include/mtx_hip.h)"""
         idx = (C.c_int * len(op_indices))(*[int(i) for i in op_indices])
         ms = C.c_float(0.0)
         self.lib.check(self.lib.mtx_plan_time_ops(self._h, self._stream(stream), idx, len(op_indices), iters, C.byref(ms)), "mtx_plan_time_ops")
