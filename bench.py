@@ -224,8 +224,12 @@ def main():
             return now
         return t_prev
 
+    from mangatranslator_amd.core.caching import get_cache
+    stage_memo = get_cache()
+
     def step(i):
         k = i % pool
+        stage_memo.reset()        # the operators remember results per (pixels, settings); the pool repeats pages, and no step may be served from memory
         tl = time.perf_counter()
         if yolo is not None:
             outs["detect"] = yolo(page_bgr[k], conf=yolo_conf, imgsz=1600)[0]
@@ -285,7 +289,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{W_}x{H_} synthetic pages, full pipeline (BASELINE.json configs[3] per GPU): one page per step per GPU, "
                                f"{args.boxes} bubbles, {args.regions} FLUX region(s) x {args.inpaint_steps} steps, 2x upscale; HBM-resident input",
-                   "stages": stages,
+                   "stages": stages, "stage_memo": "cleared before every page (no cached outputs in the timed region)",
                    "dtypes": {"detect": "f16", "segment": "bf16", "inpaint": "bf16 (fp32 latents / Euler update)", "upscale": "f16"},
                    "detector": "YOLOv8m-seg @imgsz 1600 (1088x1600 letterbox) + RT-DETR-v2 R50 @640 (secondary), seeded random weights" if yolo is not None else None,
                    "segmenter": "SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights" if sam is not None else None,

@@ -17,8 +17,10 @@ Flow (reference line numbers):
  -> any SAM failure falls back to the detector's own masks                                                :1783-1813
  -> osb_text_verification: primary boxes grown to cover the OSB text boxes that belong to them, the same text boxes
     steer the conjoined partition (text-safe cuts)                                                      :120-201, 1555-1571
-Not built: the disk cache of detections (out of scope; the OSB text model runs once per call).  Returns
-`(detections, text_free_boxes)` like the reference.
+Stage memo (core/caching.py; reference :1330-1351, 1646-1656, 1781): the primary detector's result is remembered under (pixels,
+model path, confidence), the finished SAM detections under (pixels, prompt boxes, seg model, conjoined settings); a SAM hit returns
+the remembered list itself, as the reference does.  The OSB text model runs once per call.  Returns `(detections, text_free_boxes)`
+like the reference.
 """
 from typing import List, Optional, Tuple
 
@@ -28,6 +30,7 @@ from PIL import Image
 
 from ...utils.exceptions import ImageProcessingError, ModelError
 from ...utils.logging import log_message
+from ..caching import get_cache
 from ..ml.model_manager import get_model_manager
 from . import box_ops, conjoined
 
@@ -103,11 +106,20 @@ def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, 
                           image_override: Optional[Image.Image] = None, osb_enabled: bool = False,
                           osb_text_verification: bool = False, osb_text_hf_token: str = "",
                           bubble_detector_model: str = "yolo_2") -> Tuple[List[dict], List[List[float]]]:
+    with get_cache().pixels_scope():          # the detector key and the SAM key digest the same page: once per call
+        return _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, seg_model, conjoined_detection, conjoined_confidence,
+                                      image_override, osb_enabled, osb_text_verification, osb_text_hf_token, bubble_detector_model)
+
+
+def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, seg_model, conjoined_detection, conjoined_confidence,
+                           image_override, osb_enabled, osb_text_verification, osb_text_hf_token, bubble_detector_model):
     detections: List[dict] = []
     text_free_boxes: List[List[float]] = []
     try:
         image_pil = image_override if image_override is not None else Image.open(image_path)
-        rgb = np.asarray(image_pil.convert("RGB"))
+        if image_pil.mode != "RGB":
+            image_pil = image_pil.convert("RGB")
+        rgb = np.asarray(image_pil)
     except Exception as e:
         raise ImageProcessingError(f"Error loading image: {e}") from e
     img_h, img_w = rgb.shape[:2]
@@ -117,9 +129,17 @@ def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, 
         primary_model = manager.load_yolo_speech_bubble(bubble_detector_model)
     except Exception as e:
         raise ModelError(f"Error loading primary model: {e}") from e
-    imgsz = 1600 if bubble_detector_model == "yolo_2" else 640
-    primary_results = primary_model(bgr, conf=confidence, device=device, verbose=False, imgsz=imgsz, retina_masks=True)[0]
-    primary_boxes = primary_results.boxes.xyxy if primary_results.boxes is not None else torch.zeros((0, 4))
+    cache = get_cache()
+    yolo_key = cache.get_yolo_cache_key(image_pil, str(model_path), confidence)
+    remembered = cache.get_yolo_detection(yolo_key)
+    if remembered is not None:
+        log_message("Using cached YOLO detections", verbose=verbose)
+        primary_results, primary_boxes = remembered
+    else:
+        imgsz = 1600 if bubble_detector_model == "yolo_2" else 640
+        primary_results = primary_model(bgr, conf=confidence, device=device, verbose=False, imgsz=imgsz, retina_masks=True)[0]
+        primary_boxes = primary_results.boxes.xyxy if primary_results.boxes is not None else torch.zeros((0, 4))
+        cache.set_yolo_detection(yolo_key, (primary_results, primary_boxes))
     primary_sources = [("primary", i) for i in range(len(primary_boxes))]
     if len(primary_boxes) > 1:
         keep = box_ops.deduplicate_primary_boxes(primary_boxes, primary_results.boxes.conf, IOU_DUPLICATE_THRESHOLD)
@@ -207,6 +227,11 @@ def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, 
         log_message("SAM disabled, using YOLO segmentation masks", verbose=verbose)
         return assemble(None), text_free_boxes
     try:
+        sam_key = cache.get_sam_cache_key(image_pil, primary_boxes, seg_model, conjoined_detection, conjoined_confidence)
+        remembered = cache.get_sam_masks(sam_key)
+        if remembered is not None:
+            log_message("Using cached SAM masks", verbose=verbose)
+            return remembered, text_free_boxes
         processor, sam = manager.load_sam2(verbose=verbose)
         prompts, owners = [], []
         for idx in simple_indices:
@@ -219,7 +244,7 @@ def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, 
         sam_masks = [None] * len(primary_boxes)
         if prompts:
             all_boxes = torch.stack(prompts)
-            inputs = processor(Image.fromarray(rgb), input_boxes=all_boxes.unsqueeze(0).cpu(), return_tensors="pt")
+            inputs = processor(image_pil, input_boxes=all_boxes.unsqueeze(0).cpu(), return_tensors="pt")
             out = sam(multimask_output=False, **inputs)
             m = processor.post_process_masks(out.pred_masks, inputs["original_sizes"])[0][:, 0]
             m = (m > SAM_MASK_THRESHOLD).cpu().numpy()
@@ -230,7 +255,9 @@ def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, 
                 else:
                     synthetic_groups[i - synth_start]["parent_mask"] = clipped
             log_message(f"Generated {len(prompts)} primary masks with SAM 2.1", always_print=True)
-        return assemble(sam_masks), text_free_boxes
+        detections = assemble(sam_masks)
+        cache.set_sam_masks(sam_key, detections)
+        return detections, text_free_boxes
     except Exception as e:
         log_message(f"SAM 2.1 segmentation failed: {e}. Falling back to YOLO segmentation masks.", always_print=True)
         for sg in synthetic_groups:

@@ -12,6 +12,7 @@ from PIL import Image
 
 from ...utils.exceptions import ImageProcessingError
 from ...utils.logging import log_message
+from ..caching import get_cache
 from ..ml.model_manager import get_model_manager
 
 
@@ -89,13 +90,20 @@ def _upscale_image(model, image: Image.Image, device: torch.device) -> Image.Ima
 def upscale_image_to_dimension(model, image: Image.Image, target: int, device, mode: str, model_type: str = "model",
                                verbose: bool = False) -> Image.Image:
     """Model passes until max(w, h) (mode "max") or min(w, h) (mode "min") reaches `target` (reference :377-500; the
-    reference's PNG round trips between passes only free host memory and are not reproduced)."""
+    reference's PNG round trips between passes only free host memory and are not reproduced).  Results are remembered by the stage
+    memo (core/caching.py) under (pixels, target, mode, model type), like the reference :406-419, 499."""
     if mode not in {"max", "min"}:
         raise ImageProcessingError("mode must be 'max' or 'min'")
     if image.width <= 0 or image.height <= 0:
         msg = f"Invalid image dimensions: {image.width}x{image.height}. Cannot upscale 0x0 images."
         log_message(msg, always_print=True)
         raise ImageProcessingError(msg)
+    cache = get_cache()
+    key = cache.get_upscale_dimension_cache_key(image, target, mode, model_type)
+    remembered = cache.get_upscaled_image(key)
+    if remembered is not None:
+        log_message("  - Using cached upscaled image", verbose=verbose)
+        return remembered
     met = (lambda w, h: max(w, h) >= target) if mode == "max" else (lambda w, h: min(w, h) >= target)
     current = image
     while not met(current.width, current.height):
@@ -105,15 +113,25 @@ def upscale_image_to_dimension(model, image: Image.Image, target: int, device, m
             raise ImageProcessingError("upscale model did not enlarge the image")          # a 1x model would loop forever
         current = nxt
         log_message(f"...to {current.width}x{current.height}", verbose=verbose)
+    cache.set_upscaled_image(key, current, verbose)
     return current
 
 
 def upscale_image(image: Image.Image, factor: float, model_type: str = "model", verbose: bool = False) -> Image.Image:
     if factor == 1.0:
         return image
-    manager = get_model_manager()
-    model = manager.load_upscale_lite() if model_type == "model_lite" else manager.load_upscale()
-    log_message(f"Upscaling image by {factor}x...", verbose=verbose)
-    tw, th = int(image.width * factor), int(image.height * factor)
-    up = upscale_image_to_dimension(model, image, max(tw, th), manager.device, "max", model_type, verbose)
-    return up.resize((tw, th), Image.LANCZOS)
+    cache = get_cache()
+    with cache.pixels_scope():            # the page is digested once for this key and the one upscale_image_to_dimension builds
+        key = cache.get_upscale_cache_key(image, factor, model_type)
+        remembered = cache.get_upscaled_image(key)
+        if remembered is not None:
+            log_message("  - Using cached upscaled image", verbose=verbose)
+            return remembered
+        manager = get_model_manager()
+        model = manager.load_upscale_lite() if model_type == "model_lite" else manager.load_upscale()
+        log_message(f"Upscaling image by {factor}x...", verbose=verbose)
+        tw, th = int(image.width * factor), int(image.height * factor)
+        up = upscale_image_to_dimension(model, image, max(tw, th), manager.device, "max", model_type, verbose)
+    result = up.resize((tw, th), Image.LANCZOS)
+    cache.set_upscaled_image(key, result)
+    return result

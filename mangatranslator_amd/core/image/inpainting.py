@@ -24,6 +24,7 @@ from PIL import Image
 from scipy.ndimage import distance_transform_edt
 
 from ...utils.logging import log_message
+from ..caching import get_cache
 
 BLUR_SCALE_FACTOR = 0.1
 MIN_BLUR_RADIUS = 1
@@ -162,6 +163,7 @@ class FluxKontextInpainter:
         self.context_padding_ratio = CONTEXT_PADDING_RATIO
         self.max_context_padding = MAX_CONTEXT_PADDING
         self._prompt_embeds = None
+        self.cache = get_cache()
 
     # ---- model lifecycle (delegated to the manager, as in the reference) ------------------------------
     def load_models(self):
@@ -241,6 +243,11 @@ class FluxKontextInpainter:
         alpha, x, y, w, h, padding, blur = self.region_for_mask(mask, strict_mask_clipping, composite_clip_bbox)
         log_message(f"  - Optimized bbox found at ({x}, {y}) with size {w}x{h}", verbose=verbose)
         crop = image_pil.crop((x, y, x + w, y + h))
+        key = self._memo_key(crop, mask[y:y + h, x:x + w], seed, (x, y, w, h), padding, blur, ocr_params, strict_mask_clipping, composite_clip_bbox)
+        patch = self.cache.get_inpainted_image(key) if key is not None else None
+        if patch is not None:
+            log_message("  - Using cached inpainting patch", verbose=verbose)
+            return Image.fromarray(composite_u8(np.asarray(image_pil), np.asarray(patch), alpha, x, y))
         scaled = self.flux_kontext_image_scale(crop)
         inf_w, inf_h = scaled.size
         if scaled.mode == "RGBA":
@@ -260,8 +267,33 @@ class FluxKontextInpainter:
                 img = torch.nan_to_num(out.images[0].float(), nan=0.0, posinf=1.0, neginf=0.0).clamp_(0, 1)
                 patch = Image.fromarray(img.mul(255).round().to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy())
         patch = patch.resize((w, h), Image.Resampling.LANCZOS)
+        if key is not None:
+            self.cache.set_inpainted_image(key, patch)
         page = np.asarray(image_pil)
         return Image.fromarray(composite_u8(page, np.asarray(patch), alpha, x, y))
+
+    def _memo_key(self, crop, mask_crop, seed, bbox, padding, blur, ocr_params, strict_mask_clipping, composite_clip_bbox):
+        """Key of the crop-sized patch in the stage memo (reference :781-827): crop pixels, a <= 64x64 bilinear signature of the mask
+        (robust to one-pixel jitter of the detections), sampler settings and crop geometry.  None when seed == -1 (fresh noise)."""
+        if not self.cache.should_use_inpaint_cache(seed):
+            return None
+        params = {"bbox": tuple(int(v) for v in bbox), "padding": int(padding), "blur": int(blur), "backend": self.backend}
+        if self.backend == "sdcpp":
+            params.update(sdcpp_cache=self.sdcpp_cache_mode, sdcpp_diffusion_quant=self.sdcpp_diffusion_quant,
+                          sdcpp_text_encoder_quant=self.sdcpp_text_encoder_quant)
+        if strict_mask_clipping:
+            params["strict_clip"] = True
+        if composite_clip_bbox is not None:
+            params["clip_bbox"] = tuple(composite_clip_bbox)
+        if ocr_params:
+            params.update(ocr_params)
+        signature = mask_crop
+        if mask_crop.size > 0:
+            size = (min(64, max(4, mask_crop.shape[0])), min(64, max(4, mask_crop.shape[1])))
+            small = torch.nn.functional.interpolate(torch.from_numpy(mask_crop.astype(np.float32))[None, None], size=size, mode="bilinear", align_corners=False)
+            signature = (small > 0.5).numpy().astype(np.uint8)[0, 0]
+        return self.cache.get_inpaint_cache_key(crop, signature, seed, self.num_inference_steps, self.residual_diff_threshold,
+                                                self.guidance_scale, self.prompt, params)
 
     def _prompt_kwargs(self) -> dict:
         enc = getattr(self.pipeline, "encode_prompt", None)

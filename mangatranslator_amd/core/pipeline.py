@@ -202,6 +202,7 @@ def process_page_vision(page, config, image_path="page.png", image_format: Optio
     import math
     import numpy as np
     from PIL import Image
+    from .caching import get_cache
     from .image.cleaning import clean_speech_bubbles
     from .image.detection import detect_speech_bubbles
     from .image.image_utils import upscale_image
@@ -218,6 +219,7 @@ def process_page_vision(page, config, image_path="page.png", image_format: Optio
         return (out if out.mode == target_mode else out.convert(target_mode)), info
     scale = math.sqrt(page.width * page.height / 1_000_000) if config.preprocessing.auto_scale else 1.0          # :765-771
     info["processing_scale"] = scale
+    get_cache().set_current_image(page, verbose)       # :774 — a new page drops what the stage memo holds for the previous one
     det = config.detection
     try:
         bubbles, text_free = detect_speech_bubbles(image_path, getattr(config, "yolo_model_path", None), det.confidence, verbose=verbose,

@@ -36,3 +36,11 @@ def hip_lib():
     lib = get_library()
     lib.init(0)
     return lib
+
+
+@pytest.fixture(autouse=True)
+def fresh_stage_memo():
+    """every test starts with an empty stage memo (core/caching.py is process-global, like the reference's)"""
+    from mangatranslator_amd.core import caching
+    caching.get_cache().reset()
+    yield

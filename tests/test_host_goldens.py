@@ -75,6 +75,9 @@ def _inpainter():
     inp.context_padding_ratio, inp.max_context_padding = inpainting.CONTEXT_PADDING_RATIO, inpainting.MAX_CONTEXT_PADDING
     inp.PREFERED_KONTEXT_RESOLUTIONS = list(inpainting.PREFERRED_KONTEXT_RESOLUTIONS)
     inp.num_inference_steps, inp.guidance_scale, inp.prompt = 4, 2.5, "Remove all text."
+    inp.backend, inp.residual_diff_threshold = "sdnq", 0.12
+    from mangatranslator_amd.core import caching
+    inp.cache = caching.UnifiedCache()
     inp._prompt_embeds = None
     inp.manager = types.SimpleNamespace(flux_inference_lock=__import__("threading").Lock())
     inp.load_models = lambda: None
