@@ -81,7 +81,7 @@ static int run_op(const mtx_op& op, void* stream) {
 #ifndef MTX_EMU
 // Opt-in alternative to the graph-difference timing below (MTX_TIME_OPS=stamp): ONE replay graph of the whole plan with a one-lane
 // kernel before and after every selected op that stores the device's constant-rate wall clock; the op's time is the stamp
-// difference (plus two launch gaps of a few microseconds).  Unlike "graph with minus graph without" it does not change the power
+// difference minus two dispatch gaps, the gap taken from a back-to-back stamp pair in the same graph.  Unlike "graph with minus graph without" it does not change the power
 // mix of the replay, so the clocks the other kernels run at do not leak into the figure.
 __global__ void stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
 
@@ -94,7 +94,7 @@ static int time_ops_stamped(Plan* p, const std::vector<char>& sel, int iters, fl
   hipStream_t s = nullptr;
   unsigned long long* d_t = nullptr;
   if (hipDeviceSynchronize() != hipSuccess || hipStreamCreate(&s) != hipSuccess) return fail(MTX_ERR_HIP, "mtx_plan_time_ops: stream setup failed");
-  if (hipMalloc((void**)&d_t, 2 * n_sel * sizeof(unsigned long long)) != hipSuccess) { hipStreamDestroy(s); return fail(MTX_ERR_HIP, "mtx_plan_time_ops: hipMalloc failed"); }
+  if (hipMalloc((void**)&d_t, (2 * n_sel + 2) * sizeof(unsigned long long)) != hipSuccess) { hipStreamDestroy(s); return fail(MTX_ERR_HIP, "mtx_plan_time_ops: hipMalloc failed"); }
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   int rc = MTX_OK;
@@ -102,6 +102,10 @@ static int time_ops_stamped(Plan* p, const std::vector<char>& sel, int iters, fl
   if (rc == MTX_OK) {
     size_t k = 0;
     for (size_t i = 0; i < p->ops.size() && rc == MTX_OK; ++i) {
+      if (sel[i] && k == 0) {      // calibration pair: two stamps back to back = one dispatch gap + one stamp kernel
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, d_t + 2 * n_sel);
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, d_t + 2 * n_sel + 1);
+      }
       if (sel[i]) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, d_t + 2 * k);
       rc = run_op(p->ops[i], (void*)s);
       if (rc != MTX_OK) g_err = "op " + std::to_string(i) + ": " + g_err;
@@ -111,13 +115,18 @@ static int time_ops_stamped(Plan* p, const std::vector<char>& sel, int iters, fl
     if (rc == MTX_OK && e != hipSuccess) rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: end capture failed");
     if (rc == MTX_OK && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: instantiate failed");
   }
-  std::vector<unsigned long long> h_t(2 * n_sel);
+  std::vector<unsigned long long> h_t(2 * n_sel + 2);
   double ticks = 0.0;
   for (int it = -1; it < iters && rc == MTX_OK; ++it) {                // replay -1 is untimed
     if (hipGraphLaunch(exec, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: graph launch failed"); break; }
     if (it < 0) continue;
     if (hipMemcpy(h_t.data(), d_t, h_t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MTX_ERR_HIP, "mtx_plan_time_ops: stamp readback failed"); break; }
-    for (size_t k = 0; k < n_sel; ++k) ticks += (double)(h_t[2 * k + 1] - h_t[2 * k]);
+    // a bracket holds the op plus two dispatch gaps (stamp -> op, op -> stamp); the calibration pair measures one such gap
+    const double gap = (double)(h_t[2 * n_sel + 1] - h_t[2 * n_sel]);
+    for (size_t k = 0; k < n_sel; ++k) {
+      const double d = (double)(h_t[2 * k + 1] - h_t[2 * k]) - 2.0 * gap;
+      ticks += d > 0.0 ? d : 0.0;
+    }
   }
   if (exec) hipGraphExecDestroy(exec);
   if (graph) hipGraphDestroy(graph);
