@@ -130,7 +130,9 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
     except Exception as e:
         raise ModelError(f"Error loading primary model: {e}") from e
     cache = get_cache()
-    yolo_key = cache.get_yolo_cache_key(image_pil, str(model_path), confidence)
+    # the reference keys on the checkpoint path its caller passes; here the manager picks the checkpoint from `bubble_detector_model`,
+    # so that name stands in when no path is given (two detectors must never share an entry)
+    yolo_key = cache.get_yolo_cache_key(image_pil, str(model_path) if model_path is not None else str(bubble_detector_model), confidence)
     remembered = cache.get_yolo_detection(yolo_key)
     if remembered is not None:
         log_message("Using cached YOLO detections", verbose=verbose)
