@@ -1,7 +1,8 @@
 """Final upscale operator: `upscale_image`, `upscale_image_to_dimension`,
 `image_to_tensor`, `tensor_to_image` with the reference's signatures (core/image/image_utils.py:351-548).
 The model call goes to the RCAN graph on libmtx_hip; PIL handles the final exact-size LANCZOS.
-Plus the page writer of row f2, `save_image_with_compression` (reference :59-170)."""
+Plus the page writer of row f2, `save_image_with_compression` (reference :59-170), and the bubble-crop half of row f4:
+`process_bubble_image_cached`, `resize_to_min_side`, `pil_to_cv2` / `cv2_to_pil` (reference :678-728, :569-595, :20-55)."""
 import io
 import os
 from pathlib import Path
@@ -64,6 +65,40 @@ def save_image_with_compression(image: Image.Image, output_path, jpeg_quality: i
     except Exception as e:
         log_message(f"Error saving image to {output_path}: {e}", always_print=True)
         raise ImageProcessingError(f"Failed to save image to {output_path}") from e
+
+
+def pil_to_cv2(pil_image: Image.Image) -> np.ndarray:
+    """RGB(A) PIL image -> BGR(A) ndarray, other modes as they are (reference :20-36; the channel flip is all cv2 did there)"""
+    a = np.array(pil_image)
+    if a.ndim == 3 and a.shape[2] == 3:
+        return np.ascontiguousarray(a[..., ::-1])
+    if a.ndim == 3 and a.shape[2] == 4:
+        return np.ascontiguousarray(a[..., [2, 1, 0, 3]])
+    return a
+
+
+def cv2_to_pil(cv2_image: np.ndarray) -> Image.Image:
+    """BGR(A) ndarray -> RGB(A) PIL image (reference :39-55)"""
+    if cv2_image.ndim == 3 and cv2_image.shape[2] == 3:
+        return Image.fromarray(np.ascontiguousarray(cv2_image[..., ::-1]))
+    if cv2_image.ndim == 3 and cv2_image.shape[2] == 4:
+        return Image.fromarray(np.ascontiguousarray(cv2_image[..., [2, 1, 0, 3]]))
+    return Image.fromarray(cv2_image)
+
+
+def resize_to_min_side(image: Image.Image, min_side: int, verbose: bool = False) -> Image.Image:
+    """LANCZOS resize so that the shorter side is exactly `min_side` (reference :569-595)"""
+    w, h = image.size
+    if w <= 0 or h <= 0:
+        msg = f"Invalid image dimensions: {w}x{h}. Cannot resize 0x0 images."
+        log_message(msg, always_print=True)
+        raise ImageProcessingError(msg)
+    if min(w, h) == min_side:
+        return image
+    scale = min_side / min(w, h)
+    size = (max(1, int(round(w * scale))), max(1, int(round(h * scale))))
+    log_message(f"Resizing to min-side {min_side}: {w}x{h} -> {size[0]}x{size[1]}", verbose=verbose)
+    return image.resize(size, Image.LANCZOS)
 
 
 def image_to_tensor(image: Image.Image, device: torch.device) -> torch.Tensor:
@@ -135,3 +170,20 @@ def upscale_image(image: Image.Image, factor: float, model_type: str = "model", 
     result = up.resize((tw, th), Image.LANCZOS)
     cache.set_upscaled_image(key, result)
     return result
+
+
+def process_bubble_image_cached(bubble_image_pil: Image.Image, upscale_model, device, target_min_side: int = 200, mode: str = "min",
+                                model_type: str = "model", verbose: bool = False) -> Image.Image:
+    """One bubble crop for the OCR / translation request: model passes until the shorter side reaches `target_min_side`, then the exact
+    LANCZOS fit; the finished crop is remembered in the stage memo (reference :678-728)."""
+    cache = get_cache()
+    with cache.pixels_scope():
+        key = cache.get_bubble_processing_cache_key(bubble_image_pil, target_min_side, mode, model_type)
+        remembered = cache.get_upscaled_image(key)
+        if remembered is not None:
+            log_message("  - Using cached bubble processing result", verbose=verbose)
+            return remembered
+        up = upscale_image_to_dimension(upscale_model, bubble_image_pil, target_min_side, device, mode, model_type, verbose)
+    fitted = resize_to_min_side(up, target_min_side, verbose)
+    cache.set_upscaled_image(key, fitted, verbose)
+    return fitted
