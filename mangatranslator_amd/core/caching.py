@@ -223,3 +223,24 @@ def get_cache() -> UnifiedCache:
         if _global_cache is None:
             _global_cache = UnifiedCache()
         return _global_cache
+
+
+def detector_memo_path(manager, model_path, bubble_detector_model: str) -> str:
+    """What stands for "which bubble detector" in a detector memo key.  The reference keys on the checkpoint path its callers pass
+    (`detect_speech_bubbles` :1330, `OutsideTextDetector` :285-292); this build's manager picks the checkpoint from
+    `bubble_detector_model`, so without an explicit path the manager's path for that detector is used — the same string from both
+    operators, so the OSB stage reuses the page's detection like the reference does."""
+    if model_path is not None:
+        return str(model_path)
+    paths = getattr(manager, "model_paths", None)
+    if paths:
+        for model_type, path in paths.items():
+            if getattr(model_type, "name", "") == ("YOLO_SPEECH_BUBBLE_2" if bubble_detector_model == "yolo_2" else "YOLO_SPEECH_BUBBLE"):
+                return str(path)
+    return str(bubble_detector_model)
+
+
+def osb_text_memo_path(manager) -> str:
+    """the OSB text model's stand-in in a detector memo key: the manager's checkpoint path (reference detection.py:135, ocr_detection.py:411)"""
+    paths = getattr(manager, "model_paths", None) or {}
+    return next((str(p) for t, p in paths.items() if getattr(t, "name", "") == "YOLO_OSBTEXT"), "yolo_osbtext")

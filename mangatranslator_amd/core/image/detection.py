@@ -30,7 +30,7 @@ from PIL import Image
 
 from ...utils.exceptions import ImageProcessingError, ModelError
 from ...utils.logging import log_message
-from ..caching import get_cache
+from ..caching import detector_memo_path, get_cache, osb_text_memo_path
 from ..ml.model_manager import get_model_manager
 from . import box_ops, conjoined
 
@@ -70,16 +70,24 @@ IOA_OVERLAP_THRESHOLD = 0.5
 
 
 def expand_boxes_with_osb_text(image_cv, primary_boxes: torch.Tensor, model_manager, device, confidence: float, hf_token: str,
-                               verbose: bool):
+                               verbose: bool, image_pil=None, cache=None):
     """Grow each speech-bubble box to fully contain the OSB text boxes that meaningfully belong to it (reference
     `_expand_boxes_with_osb_text`, :120-198).  Returns `(boxes, osb_text_boxes_np or None)`; any failure (model unavailable)
-    leaves the boxes untouched, as in the reference."""
+    leaves the boxes untouched, as in the reference.  With `image_pil` + `cache` the OSB text model's result is read from / stored in
+    the stage memo under the key the OSB stage uses (:135-161), so the page runs that model once."""
     if primary_boxes is None or len(primary_boxes) == 0:
         return primary_boxes, None
     try:
-        osb_model = model_manager.load_yolo_osbtext(token=hf_token)
-        res = osb_model(image_cv, conf=confidence, device=device, verbose=False, imgsz=640)[0]
-        osb_boxes = res.boxes.xyxy if res.boxes is not None else torch.tensor([])
+        key = cache.get_yolo_cache_key(image_pil, osb_text_memo_path(model_manager), confidence) if cache is not None and image_pil is not None else None
+        remembered = cache.get_yolo_detection(key) if key is not None else None
+        if remembered is not None:
+            _, osb_boxes, _ = remembered
+        else:
+            osb_model = model_manager.load_yolo_osbtext(token=hf_token)
+            res = osb_model(image_cv, conf=confidence, device=device, verbose=False, imgsz=640)[0]
+            osb_boxes = res.boxes.xyxy if res.boxes is not None else torch.tensor([])
+            if key is not None:
+                cache.set_yolo_detection(key, (res, osb_boxes, res.boxes.conf if res.boxes is not None else torch.tensor([])))
         if osb_boxes is None or len(osb_boxes) == 0:
             return primary_boxes, None
         pb_np, osb_np = primary_boxes.detach().cpu().numpy(), osb_boxes.detach().cpu().numpy()
@@ -130,9 +138,7 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
     except Exception as e:
         raise ModelError(f"Error loading primary model: {e}") from e
     cache = get_cache()
-    # the reference keys on the checkpoint path its caller passes; here the manager picks the checkpoint from `bubble_detector_model`,
-    # so that name stands in when no path is given (two detectors must never share an entry)
-    yolo_key = cache.get_yolo_cache_key(image_pil, str(model_path) if model_path is not None else str(bubble_detector_model), confidence)
+    yolo_key = cache.get_yolo_cache_key(image_pil, detector_memo_path(manager, model_path, bubble_detector_model), confidence)
     remembered = cache.get_yolo_detection(yolo_key)
     if remembered is not None:
         log_message("Using cached YOLO detections", verbose=verbose)
@@ -205,7 +211,8 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
     grouping_primary_boxes = primary_boxes.clone()
     osb_text_boxes_np = None
     if osb_text_verification and len(primary_boxes) > 0:
-        primary_boxes, osb_text_boxes_np = expand_boxes_with_osb_text(bgr, primary_boxes, manager, device, confidence, osb_text_hf_token, verbose)
+        primary_boxes, osb_text_boxes_np = expand_boxes_with_osb_text(bgr, primary_boxes, manager, device, confidence, osb_text_hf_token, verbose,
+                                                                          image_pil=image_pil, cache=cache)
     conjoined_indices, simple_indices = [], list(range(len(primary_boxes)))
     if len(secondary_boxes) > 0 and conjoined_detection:
         conjoined_indices, simple_indices = box_ops.categorize_detections(grouping_primary_boxes, secondary_boxes, ioa_threshold=IOA_THRESHOLD)

@@ -9,8 +9,8 @@ FLUX regions a page has.  Mirrors `OutsideTextDetector` of the reference (core/i
 
 All of it is integer / float64 host arithmetic on a handful of boxes (outputs are indices and rectangles ⇒ bit-exact
 target, pinned by tests/golden/osb_regions.json); the detectors it calls are the libmtx_hip graphs returned by the
-model manager.  The reference's detection cache (core/caching.py) is a disk/LRU memo of detector outputs and is not
-part of this build: every call runs its detectors.
+model manager.  Detector outputs go through the stage memo (core/caching.py) under the reference's keys: the bubble
+detection of the page is the entry `detect_speech_bubbles` stored, the OSB text model's result has its own.
 """
 import os
 from typing import List, Optional, Tuple
@@ -21,6 +21,7 @@ from PIL import Image
 
 from ...utils.exceptions import ImageProcessingError
 from ...utils.logging import log_message
+from ..caching import detector_memo_path, get_cache, osb_text_memo_path
 from ..device import get_best_device
 from ..ml.model_manager import get_model_manager
 
@@ -34,6 +35,7 @@ class OutsideTextDetector:
         self.device = device if device is not None else get_best_device()
         self.hf_token = hf_token
         self.manager = get_model_manager()
+        self.cache = get_cache()
 
     # ---- box predicates (reference :43-147) ---------------------------------------------------------------------
     def boxes_overlap(self, box1, box2) -> bool:
@@ -129,10 +131,17 @@ class OutsideTextDetector:
             yolo_boxes = torch.tensor(provided, device=self.device, dtype=torch.float32)
             log_message(f"Skipping YOLO; using provided bubbles ({len(yolo_boxes)})", verbose=verbose)
         else:
-            model = self.manager.load_yolo_speech_bubble(bubble_detector_model)
-            res = model(image_cv, conf=confidence, device=self.device, verbose=False,
-                        imgsz=1600 if bubble_detector_model == "yolo_2" else 640, retina_masks=True)[0]
-            yolo_boxes = res.boxes.xyxy if res.boxes is not None else torch.tensor([])
+            key = self.cache.get_yolo_cache_key(image_pil, detector_memo_path(self.manager, yolo_model_path, bubble_detector_model), confidence)
+            remembered = self.cache.get_yolo_detection(key)          # the page's detection from `detect_speech_bubbles`, same key (:285-313)
+            if remembered is not None:
+                log_message("Using cached Speech Bubble detections", verbose=verbose)
+                res, yolo_boxes = remembered
+            else:
+                model = self.manager.load_yolo_speech_bubble(bubble_detector_model)
+                res = model(image_cv, conf=confidence, device=self.device, verbose=False,
+                            imgsz=1600 if bubble_detector_model == "yolo_2" else 640, retina_masks=True)[0]
+                yolo_boxes = res.boxes.xyxy if res.boxes is not None else torch.tensor([])
+                self.cache.set_yolo_detection(key, (res, yolo_boxes))
             log_message(f"YOLO detected {len(yolo_boxes) if yolo_boxes.nelement() > 0 else 0} speech bubbles", verbose=verbose)
 
         # secondary detector: when text_free_only still lacks text_free boxes, or when the bubbles were detected here
@@ -175,10 +184,17 @@ class OutsideTextDetector:
                 log_message("No text_free detections available; skipping OSB text detections", always_print=True)
         else:
             try:
-                osb_model = self.manager.load_yolo_osbtext(token=self.hf_token)
-                res = osb_model(image_cv, conf=confidence, device=self.device, verbose=False, imgsz=640)[0]
-                osb_boxes = res.boxes.xyxy if res.boxes is not None else None
-                osb_confs = res.boxes.conf if res.boxes is not None else None
+                key = self.cache.get_yolo_cache_key(image_pil, osb_text_memo_path(self.manager), confidence)
+                remembered = self.cache.get_yolo_detection(key)      # :414-446
+                if remembered is not None:
+                    log_message("Using cached OSBText detections", verbose=verbose)
+                    res, osb_boxes, osb_confs = remembered
+                else:
+                    osb_model = self.manager.load_yolo_osbtext(token=self.hf_token)
+                    res = osb_model(image_cv, conf=confidence, device=self.device, verbose=False, imgsz=640)[0]
+                    osb_boxes = res.boxes.xyxy if res.boxes is not None else None
+                    osb_confs = res.boxes.conf if res.boxes is not None else None
+                    self.cache.set_yolo_detection(key, (res, osb_boxes, osb_confs))
             except Exception as e:
                 log_message(f"OSB text model unavailable: {e}. Using text_free fallback if available.", always_print=True)
                 if text_free_boxes:

@@ -106,6 +106,7 @@ def main():
     out["inpaint_flow"] = inpaint_flow()
     out["detection_memo"] = detection_memo()
     out["upscale_memo"] = upscale_memo()
+    out["osb_memo"] = osb_memo()
     json.dump(out, open(HERE / "cache_keys.json", "w"), indent=0)
     np.savez_compressed(HERE / "cache_inpaint_masks.npz", **MASKS)
     print("wrote cache_keys.json", len(json.dumps(out)))
@@ -146,6 +147,48 @@ def detection_memo():
         same_as = next((i for i, r in enumerate(results) if r is dets), None)
         results.append(dets)
         rows.append(dict(call=[page, seg, conf, cconf], counts=dict(counts), same_list_as_call=same_as, n=len(dets), stats=cache.get_cache_stats()))
+    return rows
+
+
+def osb_memo():
+    """reference `OutsideTextDetector.detect_outside_text` (core/image/ocr_detection.py:189-540) with the REAL memo on the canned rig of
+    make_goldens.gen_osb, over the script of tests/test_osb_regions.py: how often each detector runs"""
+    mg.gen_osb()
+    from core.image import ocr_detection as ref
+    mgr = ref.get_model_manager()
+    bub, sec, osb = mgr.load_yolo_speech_bubble(), mgr.load_rtdetr_conjoined_bubble(), mgr.load_yolo_osbtext()
+    bub.calls = sec.calls = osb.calls = 0
+    state = dict(ok=True)
+
+    def load_osb(token=None):
+        if not state["ok"]:
+            raise RuntimeError("gated repo")
+        return osb
+
+    class Paths(dict):
+        def __missing__(self, k):
+            return repr(k)                                       # one distinct path per model type
+    mgr.load_yolo_osbtext, mgr.model_paths = load_osb, Paths()
+    cache = UnifiedCache()
+    ref.get_cache = lambda: cache
+    det = ref.OutsideTextDetector(device="cpu")
+    inp = mg.osb_inputs()
+    img = Image.fromarray((np.random.default_rng(5).random((inp["H"], inp["W"], 3)) * 255).astype(np.uint8))
+    provided = [dict(bbox=inp["bubbles"][0]), inp["bubbles"][1], dict(bbox=None), [1, 2, 3]]
+    rows = []
+
+    def run(tag, **kw):
+        res = det.detect_outside_text("page.png", image_override=img, **kw)
+        rows.append(dict(tag=tag, calls=[bub.calls, sec.calls, osb.calls], n=len(res), yolo_slot=cache.get_cache_stats()["yolo"]))
+    run("all_models")
+    run("all_models_again")
+    run("provided", existing_bubbles=provided, text_free_boxes=[inp["secondary"][1]])
+    run("text_free_only", existing_bubbles=provided, text_free_only=True)
+    state["ok"] = False
+    run("osb_unavailable", min_area_ignore_ratio=0.01)
+    state["ok"] = True
+    run("empty_list", existing_bubbles=[])
+    run("other_confidence", confidence=0.5)
     return rows
 
 

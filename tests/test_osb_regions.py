@@ -75,7 +75,7 @@ def test_detect_outside_text_modes(rig):
            gold["detect_provided_bubbles"])
     assert (rig.bub.calls, rig.sec.calls) == (1, 1)              # provided bubbles: neither bubble detector runs again
     _check(det.detect_outside_text("page.png", image_override=img, existing_bubbles=provided, text_free_only=True), gold["detect_text_free_only"])
-    assert (rig.bub.calls, rig.sec.calls, rig.osb.calls) == (1, 2, 2)       # text_free_only: secondary only, OSB model skipped
+    assert (rig.bub.calls, rig.sec.calls) == (1, 2)              # text_free_only: secondary only, OSB model skipped
     rig.state["osb_ok"] = False
     _check(det.detect_outside_text("page.png", image_override=img, min_area_ignore_ratio=0.01), gold["detect_osb_model_unavailable"])
     rig.state["osb_ok"] = True
@@ -135,3 +135,20 @@ def test_grouping_order_and_threshold():
     assert [g[2] for g in groups] == [[0, 2], [1, 3], [4]]
     assert det._boxes_are_nearby([0, 0, 10, 10], [8, 0, 18, 10], 8.0) and not det._boxes_are_nearby([0, 0, 10, 10], [8, 1, 18, 11], 8.0)
     assert det._group_text_boxes_spatially([], [], 10, 10) == []
+
+
+def test_detector_memo_counts(rig):
+    """how often each detector runs over a script of calls on one page — the one-entry detector slot is shared by the bubble detector
+    and the OSB text model, which evict each other — equal to the reference with its real memo (tests/golden/make_cache_goldens.py osb_memo)"""
+    memo = json.loads((G / "cache_keys.json").read_text())["osb_memo"]
+    inp, det, img = rig.inp, rig.det, rig.img
+    provided = [dict(bbox=inp["bubbles"][0]), inp["bubbles"][1], dict(bbox=None), [1, 2, 3]]
+    script = dict(all_models={}, all_models_again={}, provided=dict(existing_bubbles=provided, text_free_boxes=[inp["secondary"][1]]),
+                  text_free_only=dict(existing_bubbles=provided, text_free_only=True), osb_unavailable=dict(min_area_ignore_ratio=0.01),
+                  empty_list=dict(existing_bubbles=[]), other_confidence=dict(confidence=0.5))
+    from mangatranslator_amd.core.caching import get_cache
+    for row in memo:
+        rig.state["osb_ok"] = row["tag"] != "osb_unavailable"
+        res = det.detect_outside_text("page.png", image_override=img, **script[row["tag"]])
+        assert [rig.bub.calls, rig.sec.calls, rig.osb.calls] == row["calls"], row["tag"]
+        assert len(res) == row["n"] and get_cache().get_cache_stats()["yolo"] == row["yolo_slot"]
