@@ -272,3 +272,38 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
         for sg in synthetic_groups:
             sg["parent_mask"] = None
         return assemble(None), text_free_boxes
+
+
+def detect_panels(image_path, confidence: float = 0.25, device=None, verbose: bool = False, image_override: Optional[Image.Image] = None):
+    """Panel rectangles `(x1, y1, x2, y2)` (ints via round()) of the detections whose class is "frame" — every detection when the
+    model names no such class (reference `detect_panels`, :1817-1915).  Image and loader failures raise ImageProcessingError / ModelError;
+    a failure while running the model degrades to `[]`, as there."""
+    try:
+        image_pil = image_override if image_override is not None else Image.open(image_path)
+        if image_pil.mode != "RGB":
+            image_pil = image_pil.convert("RGB")
+        bgr = np.ascontiguousarray(np.asarray(image_pil)[..., ::-1])
+        log_message(f"Processing image for panel detection: {getattr(image_path, 'name', image_path) if image_path else 'override'} "
+                    f"({bgr.shape[1]}x{bgr.shape[0]})", verbose=verbose)
+    except Exception as e:
+        raise ImageProcessingError(f"Error loading image: {e}") from e
+    try:
+        model = get_model_manager().load_yolo_panel(verbose=verbose)
+    except Exception as e:
+        raise ModelError(f"Error loading panel model: {e}") from e
+    try:
+        res = model(bgr, conf=confidence, device=device, verbose=False, imgsz=640)[0]
+        boxes = res.boxes.xyxy if res.boxes is not None else torch.zeros((0, 4))
+        classes = res.boxes.cls if res.boxes is not None else torch.zeros((0,))
+        if len(boxes) == 0:
+            log_message("No panels detected", verbose=verbose)
+            return []
+        frame_id = next((cid for cid, name in getattr(model, "names", {}).items() if name.lower() == "frame"), None)
+        panels = []
+        for box, cid in zip(boxes.tolist(), classes.tolist()):
+            if frame_id is None or int(cid) == frame_id:
+                panels.append(tuple(int(round(v)) for v in box))
+        return panels
+    except Exception as e:
+        log_message(f"Panel detection failed: {e}. Proceeding without panel information.", always_print=True)
+        return []

@@ -35,6 +35,7 @@ class ModelType(Enum):
     SAM2 = "sam2"
     RTDETR_CONJOINED_BUBBLE = "rtdetr_conjoined_bubble"
     YOLO_OSBTEXT = "yolo_osbtext"
+    YOLO_PANEL = "yolo_panel"
     FLUX_KONTEXT_SDNQ_PIPELINE = "flux_kontext_sdnq_pipeline"
 
 
@@ -138,6 +139,7 @@ class ModelManager:
                 ModelType.SAM2: model_dir / "sam" / "sam2.1-hiera-large",
                 ModelType.RTDETR_CONJOINED_BUBBLE: model_dir / "rtdetr" / "comic-text-and-bubble-detector",
                 ModelType.YOLO_OSBTEXT: model_dir / "yolo" / "animetext_yolov12x.safetensors",
+                ModelType.YOLO_PANEL: model_dir / "yolo" / "manga109_panel_yolo11l.safetensors",
                 ModelType.FLUX_KONTEXT_SDNQ_PIPELINE: model_dir / "flux" / "kontext",
             }
             self.hf_token = None
@@ -239,6 +241,15 @@ class ModelManager:
             if self.is_loaded(ModelType.YOLO_OSBTEXT):
                 return self.models[ModelType.YOLO_OSBTEXT]
             raise ModelError("OSB text detector (YOLO12x) is not available in this build; using the text_free fallback")
+
+    def load_yolo_panel(self, verbose: bool = False):
+        """Panel detector (YOLO11-L, reference :810-838).  The YOLO11 graph (C3k2 / C2PSA blocks, depthwise head) is not built in this
+        round: the loader hands out whatever object a deployment put in the slot and otherwise raises ModelError, which
+        `detect_panels` turns into the reference's ModelError and the page flow into "Panel detection failed ... Using global sorting"."""
+        with self._lock:
+            if self.is_loaded(ModelType.YOLO_PANEL):
+                return self.models[ModelType.YOLO_PANEL]
+            raise ModelError("panel detector (YOLO11-L) is not available in this build")
 
     def load_rtdetr_conjoined_bubble(self, verbose: bool = False):
         """RT-DETR-v2 secondary detector as libmtx_hip graphs with the YOLO-shaped call of the reference's adapter

@@ -197,14 +197,15 @@ def process_page_vision(page, config, image_path="page.png", image_format: Optio
     to FLUX or flat fill) -> bubble cleaning -> optional final upscale -> target mode.  `page` is the decoded PIL page already in its
     target mode (`load_page`); the result is what the reference hands to `save_image_with_compression` in `cleaning_only` mode.
     Stage failures degrade exactly as there: detection errors -> no bubbles (:804-807), cleaning errors -> the uncleaned page
-    (:94-123), OSB errors -> the page as it was.  Panel detection (`use_panel_sorting`) is not built: panels = None.
+    (:94-123), OSB errors -> the page as it was.  Panel detection (`use_panel_sorting`): the operator is here, the YOLO11-L graph is not — without a
+    model in the manager's slot the page proceeds with panels = None, the reference's own failure path.
     Returns `(page_out, info)` with the detections, the per-bubble cleaning records and the processing scale."""
     import math
     import numpy as np
     from PIL import Image
     from .caching import get_cache
     from .image.cleaning import clean_speech_bubbles
-    from .image.detection import detect_speech_bubbles
+    from .image.detection import detect_panels, detect_speech_bubbles
     from .image.image_utils import upscale_image
     from .outside_text_processor import process_outside_text
     from ..utils.exceptions import CleaningError
@@ -233,7 +234,16 @@ def process_page_vision(page, config, image_path="page.png", image_format: Optio
         log_message(f"Error during detection: {e}", always_print=True)
         bubbles, text_free = [], []
     info["bubbles"], info["text_free_boxes"] = bubbles, text_free
-    page, _osb = process_outside_text(page, config, image_path, image_format, verbose, bubble_data=bubbles, text_free_boxes=text_free, panels=None)
+    panels = None
+    if getattr(det, "use_panel_sorting", False):                  # :804-831 — the OSB stage keeps its render boxes inside the panel
+        try:
+            panels = detect_panels(image_path, confidence=det.panel_confidence, device=config.device, verbose=verbose, image_override=page)
+            log_message(f"Detected {len(panels)} panels" if panels else "No panels detected", always_print=bool(panels), verbose=verbose)
+        except Exception as e:      # noqa: BLE001
+            log_message(f"Panel detection failed: {e}. Using global sorting.", always_print=True)
+            panels = None
+    info["panels"] = panels
+    page, _osb = process_outside_text(page, config, image_path, image_format, verbose, bubble_data=bubbles, text_free_boxes=text_free, panels=panels)
     if bubbles:
         cl = config.cleaning
         try:

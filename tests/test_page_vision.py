@@ -94,3 +94,27 @@ def test_cleaning_failure_keeps_the_page(calls, monkeypatch):
     cfg = _config(); cfg.output.upscale_final_image = False
     out, info = pipeline.process_page_vision(Image.new("RGBA", (50, 60), (250, 250, 250, 255)), cfg)
     assert out.getpixel((0, 0))[:3] == (1, 2, 3) and info["cleaned"] == []
+
+
+def test_panels_reach_the_osb_stage(calls, monkeypatch):
+    """use_panel_sorting: panels from `detect_panels` are handed to the OSB stage (reference pipeline.py:804-831, :1733); a failing panel
+    detector leaves panels = None and the page goes on."""
+    cfg = _config()
+    cfg.detection.use_panel_sorting, cfg.detection.panel_confidence = True, 0.25
+    seen = []
+
+    def panels(image_path, confidence=0.25, device=None, verbose=False, image_override=None):
+        seen.append((confidence, image_override.size))
+        return [(0, 0, 25, 60), (25, 0, 50, 60)]
+    monkeypatch.setattr(detection, "detect_panels", panels)
+    page = Image.new("RGB", (50, 60), (250, 250, 250))
+    _, info = pipeline.process_page_vision(page, cfg)
+    assert seen == [(0.25, (50, 60))] and calls[1] == ("osb", 1, [[5.0, 5.0, 9.0, 9.0]], [(0, 0, 25, 60), (25, 0, 50, 60)])
+    assert info["panels"] == [(0, 0, 25, 60), (25, 0, 50, 60)]
+    calls.clear()
+    monkeypatch.undo()                                   # the product operator: no panel model in this build -> ModelError -> None
+    monkeypatch.setattr(detection, "detect_speech_bubbles", lambda *a, **k: ([], []))
+    monkeypatch.setattr(otp, "process_outside_text", lambda page, *a, panels="unset", **k: (calls.append(("osb", panels)), (page, []))[1])
+    monkeypatch.setattr(image_utils, "upscale_image", lambda image, *a, **k: image)
+    _, info = pipeline.process_page_vision(page, cfg)
+    assert calls == [("osb", None)] and info["panels"] is None
