@@ -137,6 +137,12 @@ class UnifiedCache:
             n = len(self._slots[slot].cache)
         log_message(f"  - Cached {what} (cache size: {n})", verbose=verbose)
 
+    def holds_any(self, slot: str) -> bool:
+        """False when a lookup in `slot` cannot hit — lets a caller postpone the page digest its key needs (10 ms per 4.7 MB page on a
+        host core) until there is something to look up or to store.  Not in the reference."""
+        with self._lock:
+            return bool(self._slots[slot].cache)
+
     def get_yolo_detection(self, cache_key):
         return self._get("yolo", cache_key)
 

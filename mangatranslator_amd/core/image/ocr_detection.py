@@ -104,6 +104,12 @@ class OutsideTextDetector:
                             existing_bubbles: Optional[List] = None, text_free_boxes: Optional[List] = None,
                             bubble_detector_model: str = "yolo_2", min_area_ignore_ratio: float = 0.0, text_free_only: bool = False):
         """-> [(bbox float32[4], confidence)] of text regions outside speech bubbles."""
+        with self.cache.pixels_scope():       # the bubble key and the OSB text key digest the same page: once per call
+            return self._detect_outside_text(image_path, yolo_model_path, confidence, conjoined_confidence, verbose, image_override,
+                                             existing_bubbles, text_free_boxes, bubble_detector_model, min_area_ignore_ratio, text_free_only)
+
+    def _detect_outside_text(self, image_path, yolo_model_path, confidence, conjoined_confidence, verbose, image_override, existing_bubbles,
+                             text_free_boxes, bubble_detector_model, min_area_ignore_ratio, text_free_only):
         if image_override is None and not os.path.exists(image_path):
             raise FileNotFoundError(f"Error: The file '{image_path}' was not found.")
         try:
@@ -184,8 +190,12 @@ class OutsideTextDetector:
                 log_message("No text_free detections available; skipping OSB text detections", always_print=True)
         else:
             try:
-                key = self.cache.get_yolo_cache_key(image_pil, osb_text_memo_path(self.manager), confidence)
-                remembered = self.cache.get_yolo_detection(key)      # :414-446
+                def osb_key():
+                    return self.cache.get_yolo_cache_key(image_pil, osb_text_memo_path(self.manager), confidence)
+                # :414-446; the key (a digest of the page) is only built when the one-entry detector slot holds something to compare
+                # it with, or when there is a result to store — not for a model that turns out to be unavailable
+                key = osb_key() if self.cache.holds_any("yolo") else None
+                remembered = self.cache.get_yolo_detection(key) if key is not None else None
                 if remembered is not None:
                     log_message("Using cached OSBText detections", verbose=verbose)
                     res, osb_boxes, osb_confs = remembered
@@ -194,7 +204,7 @@ class OutsideTextDetector:
                     res = osb_model(image_cv, conf=confidence, device=self.device, verbose=False, imgsz=640)[0]
                     osb_boxes = res.boxes.xyxy if res.boxes is not None else None
                     osb_confs = res.boxes.conf if res.boxes is not None else None
-                    self.cache.set_yolo_detection(key, (res, osb_boxes, osb_confs))
+                    self.cache.set_yolo_detection(key if key is not None else osb_key(), (res, osb_boxes, osb_confs))
             except Exception as e:
                 log_message(f"OSB text model unavailable: {e}. Using text_free fallback if available.", always_print=True)
                 if text_free_boxes:
