@@ -433,7 +433,8 @@ def in_context_ms(plan, idx, iters, mode):
     """Duration (ms per plan replay) of the ops `idx` inside the replayed plan.  "difference": hipGraph with minus hipGraph without the
     ops, HIP events around each replay — an upper bound on a power-limited chip, where the graph without the ops also clocks higher
     (run 20).  "stamp": device wall-clock stamps before and after each op inside ONE replay graph.  "auto": both; the
-    stamps are reported when they land in a sanity band around the difference figure (0.6x .. 1.05x), else the difference is."""
+    stamps are reported when they land in a sanity band around the difference figure (0.6x .. 1.25x: a wrong clock rate would be far
+    outside it), else the difference is."""
     os.environ.pop("MTX_TIME_OPS", None)
     plan.time_ops(idx, 1)
     diff = plan.time_ops(idx, iters) / iters
@@ -450,7 +451,7 @@ def in_context_ms(plan, idx, iters, mode):
         info["stamp_error"] = str(e)[:160]
     finally:
         os.environ.pop("MTX_TIME_OPS", None)
-    if stamped is not None and (mode == "stamp" or 0.6 * diff <= stamped <= 1.05 * diff):
+    if stamped is not None and (mode == "stamp" or 0.6 * diff <= stamped <= 1.25 * diff):
         return stamped, "stamp", info
     return diff, "difference", info
 

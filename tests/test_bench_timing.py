@@ -29,7 +29,8 @@ class _Plan:
     ("auto", 0.94, 0.80, False, 0.80, "stamp"),
     ("auto", 0.80, 0.81, False, 0.81, "stamp"),
     ("auto", 0.80, 0.30, False, 0.80, "difference"),          # implausible stamps (wrong clock rate): keep the event figure
-    ("auto", 0.80, 1.20, False, 0.80, "difference"),
+    ("auto", 0.80, 0.95, False, 0.95, "stamp"),
+    ("auto", 0.80, 1.40, False, 0.80, "difference"),
     ("auto", 0.80, 0.0, True, 0.80, "difference"),
     ("stamp", 0.80, 0.30, False, 0.30, "stamp"),
 ])
