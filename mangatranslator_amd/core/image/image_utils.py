@@ -86,6 +86,47 @@ def cv2_to_pil(cv2_image: np.ndarray) -> Image.Image:
     return Image.fromarray(cv2_image)
 
 
+def convert_image_to_target_mode(pil_image: Image.Image, target_mode: str, verbose: bool = False) -> Image.Image:
+    """Page into its working mode (reference :598-676).  To RGB: anything carrying transparency (RGBA, LA, palette with a transparency
+    entry) is flattened onto white through its alpha, not stripped of it; everything else is a plain convert.  To RGBA: plain convert."""
+    if pil_image.mode == target_mode:
+        return pil_image
+    if target_mode == "RGBA":
+        log_message(f"Converting {pil_image.mode} to RGBA", verbose=verbose)
+        return pil_image.convert("RGBA")
+    if target_mode != "RGB":
+        return pil_image
+    transparent = pil_image.mode in ("RGBA", "LA") or (pil_image.mode == "P" and "transparency" in pil_image.info)
+    if not transparent:
+        log_message(f"Converting {pil_image.mode} to RGB", verbose=verbose)
+        return pil_image.convert("RGB")
+    log_message(f"Converting {pil_image.mode} to RGB (flattening transparency)", verbose=verbose)
+    try:
+        alpha = (pil_image if pil_image.mode != "P" else pil_image.convert("RGBA")).getchannel("A")
+        flat = Image.new("RGB", pil_image.size, (255, 255, 255))
+        flat.paste(pil_image, mask=alpha)
+        return flat
+    except Exception as e:      # noqa: BLE001 — the reference's second and third attempts
+        log_message(f"Warning: Paste failed, trying alpha_composite: {e}", verbose=verbose)
+        try:
+            white = Image.new("RGBA", pil_image.size, (255, 255, 255, 255))
+            return Image.alpha_composite(white, pil_image if pil_image.mode == "RGBA" else pil_image.convert("RGBA")).convert("RGB")
+        except Exception as e2:      # noqa: BLE001
+            log_message(f"Warning: Alpha composite failed, using simple convert: {e2}", verbose=verbose)
+            return pil_image.convert("RGB")
+
+
+def resize_to_max_side(image: Image.Image, max_side: int, verbose: bool = False) -> Image.Image:
+    """LANCZOS resize so that the longer side is exactly `max_side` (reference :551-566)"""
+    w, h = image.size
+    if max(w, h) == max_side:
+        return image
+    scale = max_side / max(w, h)
+    size = (max(1, int(round(w * scale))), max(1, int(round(h * scale))))
+    log_message(f"Resizing to max-side {max_side}: {w}x{h} -> {size[0]}x{size[1]}", verbose=verbose)
+    return image.resize(size, Image.LANCZOS)
+
+
 def resize_to_min_side(image: Image.Image, min_side: int, verbose: bool = False) -> Image.Image:
     """LANCZOS resize so that the shorter side is exactly `min_side` (reference :569-595)"""
     w, h = image.size

@@ -104,14 +104,16 @@ def collect_image_files(input_dir: Path, preserve_structure: bool = False) -> Li
 
 
 def load_page(img_path: Path, output_format: str):
-    """decode + the reference's mode rule (core/pipeline.py:707-717): RGBA unless the output is JPEG"""
+    """decode + the reference's mode rule (core/pipeline.py:707-717): RGBA unless the output is JPEG; transparency is flattened onto
+    white on the way to RGB (`convert_image_to_target_mode`, :715-717)"""
     from PIL import Image
+    from .image.image_utils import convert_image_to_target_mode
     with Image.open(img_path) as im:
         im.load()
         page = im.copy()
     jpeg_out = output_format == "jpeg" or (output_format == "auto" and Path(img_path).suffix.lower() in (".jpg", ".jpeg"))
     target = "RGB" if jpeg_out else "RGBA"
-    return page if page.mode == target else page.convert(target)
+    return convert_image_to_target_mode(page, target)
 
 
 def batch_process_images(input_dir, config, output_dir=None, preserve_structure: bool = False,
