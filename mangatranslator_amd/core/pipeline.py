@@ -194,6 +194,29 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
 
 
 # ---- the vision half of `translate_and_render` (reference core/pipeline.py:638-1000, cleaning-only flow) ----------------------------
+def resolve_pre_upscale_factor(pre_cfg, verbose: bool = False) -> float:
+    """initial upscaling factor of the page (reference `_resolve_pre_upscale_factor`, :602-614): off unless `preprocessing.enabled`,
+    clamped to 1..8, anything up to 1.01 counts as off"""
+    if pre_cfg is None or not getattr(pre_cfg, "enabled", False):
+        return 1.0
+    factor = max(1.0, min(float(getattr(pre_cfg, "factor", None) or 1.0), 8.0))
+    if factor <= 1.01:
+        return 1.0
+    log_message(f"Initial upscaling enabled: {factor:.2f}x", verbose=verbose)
+    return factor
+
+
+def apply_pre_upscale_if_needed(image, config, verbose: bool = False):
+    """(page, factor): the page through the RCAN upscaler (the output stage's model choice) before detection when initial upscaling is
+    on (reference `_apply_pre_upscale_if_needed`, :617-635)"""
+    factor = resolve_pre_upscale_factor(getattr(config, "preprocessing", None), verbose)
+    if factor == 1.0:
+        return image, 1.0
+    from .image.image_utils import upscale_image
+    model_type = getattr(config.output, "image_upscale_model", "model_lite") if hasattr(config, "output") else "model_lite"
+    return upscale_image(image, factor, model_type=model_type, verbose=verbose), factor
+
+
 def process_page_vision(page, config, image_path="page.png", image_format: Optional[str] = None, verbose: bool = False):
     """One page through the hot path in the reference's stage order: detect speech bubbles (+ SAM masks) -> OSB text stage (regions
     to FLUX or flat fill) -> bubble cleaning -> optional final upscale -> target mode.  `page` is the decoded PIL page already in its
@@ -215,6 +238,7 @@ def process_page_vision(page, config, image_path="page.png", image_format: Optio
     if page.mode != target_mode:
         page = page.convert(target_mode)
     info = {"bubbles": [], "text_free_boxes": [], "cleaned": [], "processing_scale": 1.0}
+    page, info["pre_upscale_factor"] = apply_pre_upscale_if_needed(page, config, verbose)      # :718-720, before anything looks at the page
     if getattr(config, "upscaling_only", False):
         out = page
         if config.output.upscale_final_image:

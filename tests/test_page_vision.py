@@ -118,3 +118,33 @@ def test_panels_reach_the_osb_stage(calls, monkeypatch):
     monkeypatch.setattr(image_utils, "upscale_image", lambda image, *a, **k: image)
     _, info = pipeline.process_page_vision(page, cfg)
     assert calls == [("osb", None)] and info["panels"] is None
+
+
+def test_initial_upscale_rule(calls, monkeypatch):
+    """`preprocessing.enabled` + `factor`: the page goes through the upscaler before detection (reference pipeline.py:602-635, :718-720) —
+    factor rule and model choice against the reference's two functions (tests/golden/make_pre_upscale_golden.py)"""
+    import json
+    from pathlib import Path
+    gold = json.loads((Path(__file__).resolve().parent / "golden" / "pre_upscale.json").read_text())
+    T = types.SimpleNamespace
+    for row in gold["resolve"]:
+        cfg = None if row["cfg"] is None else T(**row["cfg"])
+        assert pipeline.resolve_pre_upscale_factor(cfg) == row["factor"], row
+    seen = []
+    monkeypatch.setattr(image_utils, "upscale_image", lambda image, factor, model_type="model", verbose=False: (seen.append([factor, model_type]), "up")[1])
+    r = [pipeline.apply_pre_upscale_if_needed("img", T(preprocessing=T(enabled=True, factor=2.0), output=T(image_upscale_model="model"))),
+         pipeline.apply_pre_upscale_if_needed("img", T(preprocessing=T(enabled=True, factor=3.0))),
+         pipeline.apply_pre_upscale_if_needed("img", T(preprocessing=T(enabled=False, factor=3.0), output=T(image_upscale_model="model")))]
+    assert [list(x) for x in r] == gold["apply"] and seen == gold["calls"]
+    # in the page flow: detection sees the enlarged page, the processing scale follows it
+    monkeypatch.undo()
+    log = []
+    monkeypatch.setattr(image_utils, "upscale_image", lambda image, factor, model_type="model", verbose=False: (log.append(("up", factor, model_type)), image.resize((int(image.width * factor), int(image.height * factor))))[1])
+    monkeypatch.setattr(detection, "detect_speech_bubbles", lambda *a, **k: (log.append(("detect", k["image_override"].size)), ([], []))[1])
+    monkeypatch.setattr(otp, "process_outside_text", lambda page, *a, **k: (page, []))
+    cfg = _config()
+    cfg.preprocessing = T(auto_scale=True, enabled=True, factor=2.0)
+    cfg.output.upscale_final_image = False
+    out, info = pipeline.process_page_vision(Image.new("RGB", (50, 60)), cfg)
+    assert log == [("up", 2.0, "model_lite"), ("detect", (100, 120))] and out.size == (100, 120)
+    assert info["pre_upscale_factor"] == 2.0 and info["processing_scale"] == pytest.approx(math.sqrt(100 * 120 / 1e6))
