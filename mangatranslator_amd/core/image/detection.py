@@ -134,7 +134,8 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
     bgr = np.ascontiguousarray(rgb[..., ::-1])
     manager = get_model_manager()
     try:
-        primary_model = manager.load_yolo_speech_bubble(bubble_detector_model)
+        # the reference names the detector by its checkpoint path (:1325); with no path the detector's short name stands in
+        primary_model = manager.load_yolo_speech_bubble(model_path if model_path is not None else bubble_detector_model)
     except Exception as e:
         raise ModelError(f"Error loading primary model: {e}") from e
     cache = get_cache()

@@ -143,7 +143,7 @@ class OutsideTextDetector:
                 log_message("Using cached Speech Bubble detections", verbose=verbose)
                 res, yolo_boxes = remembered
             else:
-                model = self.manager.load_yolo_speech_bubble(bubble_detector_model)
+                model = self.manager.load_yolo_speech_bubble(yolo_model_path if yolo_model_path is not None else bubble_detector_model)
                 res = model(image_cv, conf=confidence, device=self.device, verbose=False,
                             imgsz=1600 if bubble_detector_model == "yolo_2" else 640, retina_masks=True)[0]
                 yolo_boxes = res.boxes.xyxy if res.boxes is not None else torch.tensor([])

@@ -217,20 +217,42 @@ class ModelManager:
     def load_upscale_lite(self, verbose: bool = False):
         return self._load_rcan(ModelType.UPSCALE_LITE, verbose)
 
-    def load_yolo_speech_bubble(self, bubble_detector_model: str = "yolo_2", verbose: bool = False):
+    def _resolve_speech_bubble_model(self, model_path):
+        """(slot, checkpoint path) for what the caller names.  The reference names the detector by checkpoint path (None = the first
+        model, the second model's own path = the second, any other path = a custom checkpoint in the first slot; :702-709); this
+        build's operators may also pass the detector's short name, "yolo_1" / "yolo_2"."""
+        if model_path in ("yolo_1", "yolo_2"):
+            mt = ModelType.YOLO_SPEECH_BUBBLE_2 if model_path == "yolo_2" else ModelType.YOLO_SPEECH_BUBBLE
+            return mt, self.model_paths[mt]
+        if model_path is None:
+            return ModelType.YOLO_SPEECH_BUBBLE, self.model_paths[ModelType.YOLO_SPEECH_BUBBLE]
+        if Path(model_path) == self.model_paths[ModelType.YOLO_SPEECH_BUBBLE_2]:
+            return ModelType.YOLO_SPEECH_BUBBLE_2, self.model_paths[ModelType.YOLO_SPEECH_BUBBLE_2]
+        return ModelType.YOLO_SPEECH_BUBBLE, Path(model_path)
+
+    def load_yolo_speech_bubble(self, model_path: Optional[str] = None, verbose: bool = False):
         """YOLO-seg bubble detector as a libmtx_hip graph with the ultralytics call shape
-        (reference :711-743).  The checkpoint is the ultralytics state dict exported to safetensors
-        (tools/export_ultralytics_state_dict.py, run once where ultralytics is installed)."""
-        mt = ModelType.YOLO_SPEECH_BUBBLE_2 if bubble_detector_model == "yolo_2" else ModelType.YOLO_SPEECH_BUBBLE
+        (reference :711-743; same `model_path` meaning, see `_resolve_speech_bubble_model`).  The checkpoint is the ultralytics state
+        dict exported to safetensors (tools/export_ultralytics_state_dict.py, run once where ultralytics is installed)."""
         with self._lock:
+            mt, path = self._resolve_speech_bubble_model(model_path)
             if self.is_loaded(mt):
                 return self.models[mt]
             from .yolo import YoloSegHip
-            sd = self._read_safetensors(self.model_paths[mt])
+            sd = self._read_safetensors(path)
             model = YoloSegHip(sd, device=self.device, names={0: "speech_bubble"})
             self.models[mt] = model
             log_message(f"YOLO bubble detector loaded ({mt.value}).", verbose=verbose)
             return model
+
+    def unload_all(self, verbose: bool = False):
+        """every slot emptied, device cache released (reference :1482-1493)"""
+        log_message("Unloading all models...", verbose=verbose)
+        with self._lock:
+            for model_type in list(self.models):
+                self.models[model_type] = None
+        self.clear_cache()
+        log_message("All models unloaded.", verbose=verbose)
 
     def load_yolo_osbtext(self, token: Optional[str] = None, verbose: bool = False):
         """OSB text detector (YOLO12x "AnimeText", reference :780-808).  The YOLO12 graph (A2C2f area attention) is not built in

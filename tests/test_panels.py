@@ -64,3 +64,24 @@ def test_product_loader_raises_until_the_graph_exists():
         assert mgr.load_yolo_panel() is sentinel
     finally:
         mgr.models.pop(ModelType.YOLO_PANEL, None)
+
+
+def test_speech_bubble_loader_path_rule():
+    """`load_yolo_speech_bubble(model_path)`: the reference's rule (model_manager.py:702-709) plus this build's short names"""
+    from mangatranslator_amd.core.ml.model_manager import ModelType, get_model_manager
+    mgr = get_model_manager()
+    first, second = mgr.model_paths[ModelType.YOLO_SPEECH_BUBBLE], mgr.model_paths[ModelType.YOLO_SPEECH_BUBBLE_2]
+    assert mgr._resolve_speech_bubble_model(None) == (ModelType.YOLO_SPEECH_BUBBLE, first)
+    assert mgr._resolve_speech_bubble_model(str(second)) == (ModelType.YOLO_SPEECH_BUBBLE_2, second)
+    assert mgr._resolve_speech_bubble_model(str(first)) == (ModelType.YOLO_SPEECH_BUBBLE, first)
+    assert mgr._resolve_speech_bubble_model("/data/custom.safetensors") == (ModelType.YOLO_SPEECH_BUBBLE, Path("/data/custom.safetensors"))
+    assert mgr._resolve_speech_bubble_model("yolo_2") == (ModelType.YOLO_SPEECH_BUBBLE_2, second)
+    assert mgr._resolve_speech_bubble_model("yolo_1") == (ModelType.YOLO_SPEECH_BUBBLE, first)
+    sentinel = object()
+    mgr.models[ModelType.YOLO_SPEECH_BUBBLE_2] = sentinel
+    try:
+        assert mgr.load_yolo_speech_bubble(str(second)) is sentinel and mgr.load_yolo_speech_bubble("yolo_2") is sentinel
+        mgr.unload_all()
+        assert not mgr.is_loaded(ModelType.YOLO_SPEECH_BUBBLE_2)
+    finally:
+        mgr.models.pop(ModelType.YOLO_SPEECH_BUBBLE_2, None)
