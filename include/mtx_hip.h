@@ -36,7 +36,7 @@ extern "C" {
 #define MTX_API
 #endif
 
-#define MTX_ABI_VERSION 1
+#define MTX_ABI_VERSION 2
 
 typedef enum mtx_status {
   MTX_OK = 0,
@@ -46,7 +46,8 @@ typedef enum mtx_status {
   MTX_ERR_STATE = -4
 } mtx_status;
 
-typedef enum mtx_dtype { MTX_BF16 = 0, MTX_F16 = 1, MTX_F32 = 2, MTX_U8 = 3, MTX_I32 = 4 } mtx_dtype;
+typedef enum mtx_dtype { MTX_BF16 = 0, MTX_F16 = 1, MTX_F32 = 2, MTX_U8 = 3, MTX_I32 = 4,
+                         MTX_F8 = 5 /* OCP e4m3fn bytes with MX block scales, see mtx_quant_args */ } mtx_dtype;
 
 typedef enum mtx_act {
   MTX_ACT_NONE = 0, MTX_ACT_RELU = 1, MTX_ACT_SILU = 2, MTX_ACT_GELU = 3 /* erf */,
@@ -94,7 +95,15 @@ typedef struct mtx_gemm_args {
   /* optional scratch for the 256-tile kernel's stream-K tail (fp32 partial tiles); NULL = never split.
    * MTX_GEMM_WORKSPACE_BYTES is always enough (2 pieces per CU, up to 320 CUs). */
   void* workspace; int64_t workspace_bytes;
+  /* in_dtype == MTX_F8 (the CDNA4 fp8 path, BASELINE.json config 5): a and w are e4m3 bytes ([M, K] / [N, K], lda / ldw in
+   * elements = bytes) with MX scale planes as written by mtx_quantize_mx: a_scale[(k / 128) * lds_a + m], w_scale[(k / 128) *
+   * lds_w + n].  `dtype` stays the 16-bit type of bias-free epilogue operands (gate, res) and of c.  K % 128 == 0, lda / ldw % 16 == 0.
+   * in_dtype == 0 (or == dtype): the 16-bit path above. */
+  const void* a_scale; const void* w_scale; int64_t lds_a, lds_w; int32_t in_dtype;
+  int32_t flags;                 /* MTX_GEMM_* bits (tests / kernel benches; 0 in production graphs) */
 } mtx_gemm_args;
+#define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
+#define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the stream-K tail */
 #define MTX_GEMM_WORKSPACE_BYTES (2 * 320 * 256 * 256 * 4)
 
 /* softmax(scale * Q K^T) V, non-causal, one launch for [batch, heads].
@@ -152,6 +161,7 @@ typedef enum mtx_ew_kind {
   MTX_EW_SOFTMAX_ROWS = 10, /* y[r, :c] = softmax(act_param * a[r, :c]) over rows r < n*h*w (VAE attention) */
   MTX_EW_TRANSPOSE = 11,  /* y[c, r] = a[r, c] for r < h*w rows, c columns (per n; ldy = row stride of y) */
   MTX_EW_AVGPOOL2 = 13,   /* 2x2 stride-2 average pool, ceil mode, divisor = in-bounds taps (ResNet-vd shortcut) */
+  MTX_EW_SWIGLU = 14,     /* y = silu(a) * b   (FLUX.2 feed-forward: a, b = the two column halves of linear_in's output) */
   MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
                              i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then
                              rotary on interleaved pairs with b = fp32 [rows][d] cos|sin table laid out as
@@ -276,10 +286,21 @@ typedef struct mtx_detr_args {
   float offset_scale; int32_t dtype;
 } mtx_detr_args;
 
+/* MX block quantisation of a 16-bit [rows, K] matrix (row stride ldx) to OCP fp8 e4m3 for the scaled matrix instructions
+ * (v_mfma_scale_f32_32x32x64_f8f6f4): every 32 consecutive k of a row share one E8M0 scale 2^(e - 127), e chosen so that
+ * the block's largest magnitude lands in (224, 448] (never saturates); q = RNE(x * 2^-(e - 127)).  q: [rows][ldq] bytes.
+ * scale: one uint32 per (row, 128 k): byte b = e of block 4 * (k / 128) + b, laid out scale[(k / 128) * lds + row] so the
+ * 32 rows a GEMM wave reads are contiguous.  K % 128 == 0. */
+typedef struct mtx_quant_args {
+  const void* x; void* q; void* scale;
+  int64_t rows, k, ldx, ldq, lds;
+  int32_t dtype;                 /* MTX_BF16 / MTX_F16: type of x */
+} mtx_quant_args;
+
 typedef enum mtx_op_kind {
   MTX_OP_CONV2D = 1, MTX_OP_GEMM = 2, MTX_OP_ATTN = 3, MTX_OP_NORM = 4, MTX_OP_GROUPNORM = 5,
   MTX_OP_EW = 6, MTX_OP_CA = 7, MTX_OP_IMG = 8, MTX_OP_RESIZE_THRESH = 9, MTX_OP_MEMSET = 10,
-  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12, MTX_OP_YOLO_DECODE = 13, MTX_OP_DETR = 14
+  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12, MTX_OP_YOLO_DECODE = 13, MTX_OP_DETR = 14, MTX_OP_QUANT = 15
 } mtx_op_kind;
 
 typedef struct mtx_memset_args { void* ptr; int64_t bytes; int32_t value; } mtx_memset_args;
@@ -289,7 +310,7 @@ typedef struct mtx_op {
   union {
     mtx_conv2d_args conv; mtx_gemm_args gemm; mtx_attn_args attn; mtx_norm_args norm;
     mtx_groupnorm_args gn; mtx_ew_args ew; mtx_ca_args ca; mtx_img_args img;
-    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre; mtx_yolo_decode_args yd; mtx_detr_args detr;
+    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre; mtx_yolo_decode_args yd; mtx_detr_args detr; mtx_quant_args quant;
   } u;
 } mtx_op;
 
@@ -316,6 +337,7 @@ MTX_API int mtx_preprocess(const mtx_preproc_args* a, void* stream);
 MTX_API int mtx_yolo_decode(const mtx_yolo_decode_args* a, void* stream);
 MTX_API int mtx_bubble_clean(const mtx_clean_args* a, void* stream);
 MTX_API int mtx_detr(const mtx_detr_args* a, void* stream);
+MTX_API int mtx_quantize_mx(const mtx_quant_args* a, void* stream);
 /* contour half of the same chain, host side on one crop (cleaning.py:340-386): external contours of the
  * thresholded crop -> area / centroid filter -> filled union -> largest blob -> final mask + bounding box.
  * Returns the number of accepted text fragments (0 = nothing to clean).                                */

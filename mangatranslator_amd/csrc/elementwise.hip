@@ -107,6 +107,11 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
         unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = f[e] * S32[n * p.lds + c + e] + g[e];
+      } else if (kind == MTX_EW_SWIGLU) {
+        float g[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] / (1.f + __expf(-f[e])) * g[e];
       } else if (kind == MTX_EW_ADD || kind == MTX_EW_MUL) {
         float g[8];
         unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), g);
@@ -280,7 +285,7 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
   }
   if (!a->a || !a->y) { *err = "elementwise: null operand"; return MTX_ERR_INVALID; }
   if (a->c % 8 || a->lda % 8 || a->ldy % 8 || (a->b && a->ldb % 8)) { *err = "elementwise: C and pixel strides must be multiples of 8"; return MTX_ERR_INVALID; }
-  if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_ADD || a->kind == MTX_EW_MUL || a->kind == MTX_EW_GATE_RES) && !a->b) { *err = "elementwise: missing operand b"; return MTX_ERR_INVALID; }
+  if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_ADD || a->kind == MTX_EW_MUL || a->kind == MTX_EW_GATE_RES || a->kind == MTX_EW_SWIGLU) && !a->b) { *err = "elementwise: missing operand b"; return MTX_ERR_INVALID; }
   if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_GATE_RES) && !a->s) { *err = "elementwise: missing operand s"; return MTX_ERR_INVALID; }
   if (a->kind == MTX_EW_MAXPOOL && (a->i0 < 1 || a->i1 < 1)) { *err = "elementwise: maxpool needs kernel/stride"; return MTX_ERR_INVALID; }
   long oh = a->h, ow = a->w;

@@ -25,7 +25,9 @@ struct GemmParams {
   unsigned tiles_m, tiles_n;
   // stream-K tail: tiles [n_full, tiles) are cut into `units` equal runs of K iterations; fp32 partials in `part`
   unsigned n_full, units; float* part;
-  int abl;          // MTX_GEMM_ABL: timing ablations of the 256-tile kernel (1 = no DMA after the first tile, 2 = DMA burst after the barrier, 3 = two pieces per k-step)
+  // fp8 path (in_dtype == MTX_F8): MX scale planes, one uint32 (4 E8M0 bytes) per row and 128 k
+  const unsigned* a_scale; const unsigned* w_scale; long lds_a, lds_w;
+  int bk;           // K elements per LDS stage row: 64 (16-bit operands) or 128 (fp8); a row is 128 bytes either way
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -380,21 +382,11 @@ __device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigne
   if (grp == 0) G2_BAR();
 }
 
-// PP = ping-pong schedule: the two waves of every SIMD (waves w and w+4) run one barrier apart, so while one
-// issues its fragment reads / DMA for a k-step the other owns the matrix pipe for its 8 MFMAs.
-// CLAMP: rows past M / N are read from the last valid row instead of a zero block — they only feed outputs the epilogue never
-// stores — so the loop carries no per-piece select and no scalar load of the zero block's address (whose s_waitcnt lgkmcnt(0)
-// also drained the fragment reads in front of every DMA burst).
-// BUF: the K loop is gemm256_pp_buf_loop (descriptor DMA, 3/3/2/0 piece spread) — the default; PP / !PP are the earlier loops.
-template <typename T, int ACT, bool PP, bool CLAMP = true, bool BUF = false>
+// 256-tile kernel over whole tiles: the K loop above, then the epilogue.
+template <typename T, int ACT>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int wm = wv >> 2, wn = wv & 3;
-
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // the launch covers tiles [0, gridDim.x) of the grouped order (all of them, or the whole waves when the rest goes
   // to the stream-K tail kernel)
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -404,327 +396,185 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
   const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
   T* Cp = reinterpret_cast<T*>(p.c) + (size_t)bz * p.c_bs;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, 0, p.k / G2_BK, acc);
+  __syncthreads();
+  gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
+}
 
-  // ---- DMA plan: instruction i of wave wv fills LDS rows (i*8 + wv)*8 .. +7 of a stage (1 KB); rows 0..255
-  // are A, 256..511 are W.  This lane supplies slot (row = base + lane/8, position lane%8).
-  const T* src[8];
+// =====================================================================================================
+// fp8 path (BASELINE.json config 5, "CDNA4 fp8 MFMA path"): the same 256 x 256 tile, LDS image, DMA plan, ping-pong barrier
+// timeline and epilogue, with OCP e4m3 operands and MX block scales on v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 per
+// instruction, twice the bf16 rate).  A 128-byte LDS row now holds 128 k, so a stage is one K = 128 tile = two k-steps; each
+// k-step is split into two segments of 4 MFMAs (64 cycles each) so a segment still occupies the matrix pipe for 256 cycles and
+// the bytes the DMA and the fragment reads move per pipe cycle are those of the 16-bit kernel.
+//   * lane (row l31, half hi) of k-step ks feeds the instruction the 32 bytes of logical chunks 4 ks + 2 hi, +1 — one MX block,
+//     index 2 ks + hi of the K tile — for both operands, so the pairing of k indices between A and W is by construction and
+//     one scale byte per lane applies: byte 2 ks of (scale word >> 8 hi).
+//   * the scale words of tile kt+1 (4 A rows + 2 W rows per lane) are fetched with plain global loads in the first load segment
+//     of tile kt and first touched after the vmcnt(0) that ends the tile.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// in place (acc += A B), as `asm volatile`: the builtin form is free to move, and the optimiser sinks the MFMAs of several segments
+// past the barriers and load segments (all their fragments stay live: 150-300 spilled registers).  Every operand is in registers long
+// before the instruction (fragments behind an lgkmcnt(0), scales shifted at the top of the tile); consecutive MFMAs use different
+// accumulators, and a tile's second k-step re-enters an accumulator 3 x 64 cycles after the first wrote it.
+template <int OPSEL>
+__device__ __forceinline__ void mfma_mx_f8(f32x16& c, i32x8 a, i32x8 b, unsigned sa, unsigned sb) {
+#ifdef MTX_EMU
+  c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, OPSEL, (int)sa, OPSEL, (int)sb);
+#else
+  if (OPSEL == 0) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+  else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[1,1,0]" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+#endif
+}
+
+__device__ __forceinline__ void gemm256_f8_loop(const GemmParams& p, unsigned char* smem, const unsigned char* A, const unsigned char* W,
+                                                long m0, long n0, long kbeg, long kend, f32x16 (&acc)[4][2]) {
+  constexpr int BK = 128;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wm = wv >> 2, wn = wv & 3, grp = wv >> 2;
+  int wvs = wv;
+#ifndef MTX_EMU
+  wvs = __builtin_amdgcn_readfirstlane(wv);
+#endif
+  const long mrows = p.m - m0 < G2_BM ? p.m - m0 : G2_BM, nrows = p.n - n0 < G2_BN ? p.n - n0 : G2_BN;
+  const BufView abuf = make_buf(A + (size_t)m0 * p.lda, (unsigned)(((size_t)mrows - 1) * p.lda + p.k));
+  const BufView wbuf = make_buf(W + (size_t)n0 * p.ldw, (unsigned)(((size_t)nrows - 1) * p.ldw + p.k));
+  unsigned voff[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = (i * 8 + wv) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    if (row < G2_BM) src[i] = (m0 + row < p.m) ? A + (size_t)(m0 + row) * p.lda + c * 8 : (CLAMP ? A + (size_t)(p.m - 1) * p.lda + c * 8 : nullptr);
-    else src[i] = (n0 + row - G2_BM < p.n) ? W + (size_t)(n0 + row - G2_BM) * p.ldw + c * 8 : (CLAMP ? W + (size_t)(p.n - 1) * p.ldw + c * 8 : nullptr);
+    voff[i] = i < 4 ? (unsigned)((size_t)row * p.lda + c * 16) : (unsigned)((size_t)(row - G2_BM) * p.ldw + c * 16);
   }
-  auto srcp = [&](int i, long k0) -> const void* {
-    if (CLAMP) return (const void*)(src[i] + k0);
-    return src[i] ? (const void*)(src[i] + k0) : (const void*)g_zero16;
+  auto piece = [&](int i, int stage, long k0) {
+    buf_load16_lds(i < 4 ? abuf : wbuf, voff[i], (unsigned)k0, smem + stage * G2_STAGE + (i * 8 + wvs) * 1024);
   };
-  auto issue = [&](int stage, long k0) {
+  const int ar0 = wm * 128 + l31, wr0 = G2_BM + wn * 64 + l31;
+  int aaddr[2][2][2], waddr[2][2][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) glds16(srcp(i, k0), smem + stage * G2_STAGE + (i * 8 + wv) * 1024);
-  };
-
-  f32x16 acc[4][2];
+  for (int st_ = 0; st_ < 2; ++st_)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment rows of this lane and their swizzle term
-  int arow[4], wrow[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) arow[i] = wm * 128 + i * 32 + l31;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) wrow[j] = G2_BM + wn * 64 + j * 32 + l31;
-
-  const long nk = p.k / G2_BK;
-  if (BUF) {
-    gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, 0, nk, acc);
-  } else if (!PP) {
-    issue(0, 0);
-    for (long kt = 0; kt < nk; ++kt) {
-      MTX_WAIT_VMEM();
-      __syncthreads();
-      const bool more = kt + 1 < nk;
-      if (more && p.abl == 2) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);      // ablation: all eight pieces right after the barrier
-      const int nst = (int)((kt + 1) & 1);
-      const long nk0 = p.abl == 5 ? 0 : (kt + 1) * G2_BK;            // ablation 5: always re-read the first K tile (L2-resident source)
-      auto piece = [&](int i) {                 // one DMA instruction (1 KB) of the next tile
-        glds16(srcp(i, nk0), smem + nst * G2_STAGE + (i * 8 + wv) * 1024);
-      };
-      const unsigned char* st = smem + (kt & 1) * G2_STAGE;
-      // fragment reads run one k-step ahead of the MFMAs that consume them (two register sets)
-      v8 af[2][4], wf[2][2];
-      auto read_frags = [&](int ks, int set) {
-        const int ch = 2 * ks + hi;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) wf[set][j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
-      };
-      read_frags(0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) read_frags(ks + 1, (ks + 1) & 1);
-#ifndef MTX_EMU
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (p.abl == 3 && more) {               // two pieces ahead of each k-step's MFMAs
-          piece(2 * ks); piece(2 * ks + 1);
-#ifndef MTX_EMU
-          __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = Mma32<T>::mfma(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
-            if ((p.abl == 0 || p.abl == 5) && more) {           // the next tile's 8 DMA pieces threaded between the MFMAs: 3, 3, 2, 0 per k-step (+3 % vs a burst)
-              const int m = i * 2 + j;
-              const int first = ks == 0 ? 0 : (ks == 1 ? 3 : 6), cnt = ks < 2 ? 3 : (ks == 2 ? 2 : 0);
-              if (m == 1 && cnt > 0) piece(first);
-              if (m == 3 && cnt > 1) piece(first + 1);
-              if (m == 5 && cnt > 2) piece(first + 2);
-#ifndef MTX_EMU
-              __builtin_amdgcn_sched_barrier(0);
-#endif
-            }
-          }
-#ifndef MTX_EMU
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+      for (int e = 0; e < 2; ++e) {
+        const int ch = 4 * ks + 2 * hi + e;
+        aaddr[st_][ks][e] = st_ * G2_STAGE + ar0 * 128 + ((ch ^ ((ar0 >> 1) & 7)) << 4);
+        waddr[st_][ks][e] = st_ * G2_STAGE + wr0 * 128 + ((ch ^ ((wr0 >> 1) & 7)) << 4);
       }
-    }
-  } else {
-    // Barrier timeline B0, B1, ...: group 0 runs  L(k) B C(k) B  per k-step, group 1 the same one barrier later,
-    // so group 1's load segment L coincides with group 0's compute segment C and vice versa.
-    //  * tile kt+1 is DMA'd into the other stage from the load segments of k-steps 1 and 2 of tile kt: by then
-    //    both groups have finished (lgkmcnt(0)) their reads of tile kt-1, which used that stage;
-    //  * every wave drains its own DMA (vmcnt(0)) before the barrier that precedes group 0's first reads of
-    //    tile kt+1: group 0 at the end of C(kt,3), group 1 at the end of L(kt,3).
-    const int grp = wv >> 2;
-    issue(0, 0);
-    MTX_WAIT_VMEM();
-    __syncthreads();
-    if (grp == 1) G2_BAR();
-    for (long kt = 0; kt < nk; ++kt) {
-      const unsigned char* st = smem + (kt & 1) * G2_STAGE;
-      const bool more = kt + 1 < nk;
+  // scale rows of this lane (clamped: rows past M / N hold zero data, any finite scale will do)
+  const unsigned* sap[4];
+  const unsigned* swp[2];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int ch = 2 * ks + hi;
-        v8 af[4], wf[2];
+  for (int i = 0; i < 4; ++i) { long r = m0 + wm * 128 + i * 32 + l31; r = r < p.m ? r : p.m - 1; sap[i] = p.a_scale + r; }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + wrow[j] * 128 + ((ch ^ ((wrow[j] >> 1) & 7)) << 4));
+  for (int j = 0; j < 2; ++j) { long r = n0 + wn * 64 + j * 32 + l31; r = r < p.n ? r : p.n - 1; swp[j] = p.w_scale + r; }
+  unsigned sa_raw[4], sw_raw[2];
+  auto load_scales = [&](long kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
-        if (more && (ks == 1 || ks == 2)) {
-          const int stage = (int)((kt + 1) & 1);
-          const long k0 = (kt + 1) * G2_BK;
+    for (int i = 0; i < 4; ++i) sa_raw[i] = sap[i][kt * p.lds_a];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int pi = (ks - 1) * 4 + i;
-            glds16(srcp(pi, k0), smem + stage * G2_STAGE + (pi * 8 + wv) * 1024);
-          }
-        }
-        if (ks == 3 && grp == 1) MTX_WAIT_VMEM();
-        G2_BAR();
-#ifndef MTX_EMU
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
-#ifndef MTX_EMU
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        if (ks == 3 && grp == 0) MTX_WAIT_VMEM();
-        G2_BAR();
-      }
-    }
-    if (grp == 0) G2_BAR();
-  }
-
-  __syncthreads();
-  gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
-}
-
-// Ring schedule: the same 8-wave ping-pong, but the 128 KB of LDS is a ring of four K = 32 slices (64-byte rows,
-// chunk ^ ((row >> 2) & 3): 16 consecutive rows of one logical chunk cover a 256-byte bank row exactly once) instead
-// of two K = 64 stages.  A slice's slot is released after its two k-steps, so slice s+3 is DMA'd while slice s is
-// consumed and the wait before the barrier that publishes slice s+1 is a COUNTED vmcnt(8): the two youngest slices
-// stay in flight and every piece has two slice-times (~2k cycles) to land instead of the ~0.5-1k of the two-stage
-// loops, whose vmcnt(0) per K tile exposes HBM latency (ablation: no DMA 1460-1567 vs 1141 TFLOP/s).
-//   WAR: slot (s+3)&3 held slice s-1; both groups finished those reads (lgkmcnt(0) at the start of their C(s-1, 1))
-//        at least one barrier before anyone's L(s, 1), where the refill is issued.
-//   RAW: every wave counts its own pieces of slice s+1 down before the barrier that precedes group 0's L(s+1, 0):
-//        group 0 at the end of C(s, 1), group 1 at the end of L(s, 1) (the same physical barrier).
-constexpr int G2R_SLOT = (G2_BM + G2_BN) * 64;      // 32 KB
-#ifdef MTX_EMU
-#define MTX_WAIT_VMEM_N(n) ((void)0)
-#else
-#define MTX_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#endif
-template <typename T, int ACT>
-__global__ __launch_bounds__(512) void gemm256r_kernel(GemmParams p) {
-  typedef typename Traits<T>::v8 v8;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * G2R_SLOT];
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int wm = wv >> 2, wn = wv & 3, grp = wv >> 2;
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  long m0, n0;
-  gemm256_tile_origin(p, lin, m0, n0);
-  const long bz = blockIdx.y;
-  const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
-  const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
-  T* Cp = reinterpret_cast<T*>(p.c) + (size_t)bz * p.c_bs;
-
-  // DMA plan: piece i (0..3) of wave wv fills slot rows (i*8 + wv)*16 .. +15 (1 KB); lane -> row base + lane/4, position lane%4
-  const T* src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 8 + wv) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);
-    // rows past M / N are clamped to the last valid row: they only feed outputs the epilogue never stores
-    if (row < G2_BM) { const long m = m0 + row < p.m ? m0 + row : p.m - 1; src[i] = A + (size_t)m * p.lda + c * 8; }
-    else { const long n = n0 + row - G2_BM < p.n ? n0 + row - G2_BM : p.n - 1; src[i] = W + (size_t)n * p.ldw + c * 8; }
-  }
-  auto issue = [&](long s) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(src[i] + s * 32, smem + (int)(s & 3) * G2R_SLOT + (i * 8 + wv) * 1024);
+    for (int j = 0; j < 2; ++j) sw_raw[j] = swp[j][kt * p.lds_w];
   };
-
-  f32x16 acc[4][2];
+  load_scales(kbeg);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // byte offsets of this lane's fragment rows inside a slot, for chunk 0; the chunk term is XORed in per k-step
-  int aoff[4], woff[2], asw[4], wsw[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + l31; aoff[i] = r * 64; asw[i] = (r >> 2) & 3; }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { const int r = G2_BM + wn * 64 + j * 32 + l31; woff[j] = r * 64; wsw[j] = (r >> 2) & 3; }
-
-  const long ns = p.k / 32;
-  // the wait that makes slice `nxt` visible: everything but the pieces of the slices after it (at most two) has landed
-  auto wait_slice = [&](long nxt) {
-    if (nxt + 2 < ns) MTX_WAIT_VMEM_N(8);
-    else if (nxt + 1 < ns) MTX_WAIT_VMEM_N(4);
-    else MTX_WAIT_VMEM();
-  };
-  issue(0);
-  if (ns > 1) issue(1);
-  if (ns > 2) issue(2);
-  wait_slice(0);
+  for (int i = 0; i < 8; ++i) piece(i, (int)(kbeg & 1), kbeg * BK);
+  MTX_WAIT_VMEM();
   __syncthreads();
   if (grp == 1) G2_BAR();
-  for (long s = 0; s < ns; ++s) {
-    const unsigned char* st = smem + (int)(s & 3) * G2R_SLOT;
+  auto tile = [&](auto stage_c, long kt) {
+    constexpr int S = decltype(stage_c)::value;
+    const bool more = kt + 1 < kend;
+    unsigned sa[4], sw[2];
 #pragma unroll
-    for (int ksl = 0; ksl < 2; ++ksl) {
-      const int ch = 2 * ksl + hi;
-      v8 af[4], wf[2];
+    for (int i = 0; i < 4; ++i) sa[i] = sa_raw[i] >> (8 * hi);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + woff[j] + ((ch ^ wsw[j]) << 4));
+    for (int j = 0; j < 2; ++j) sw[j] = sw_raw[j] >> (8 * hi);
+#ifndef MTX_EMU
+    // materialise the shifted words here, in the load segment: they must not trail into the slots right in front of the asm MFMAs
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + aoff[i] + ((ch ^ asw[i]) << 4));
-      if (ksl == 1 && s + 3 < ns) issue(s + 3);
-      if (ksl == 1 && grp == 1) wait_slice(s + 1);
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(sa[i]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(sw[j]));
+#endif
+    i32x8 wf[2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ks = s >> 1, ih = s & 1;
+      i32x8 af[2];
+      if (ih == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + waddr[S][ks][0] + j * 4096);
+          const u32x4 hi4 = *reinterpret_cast<const u32x4*>(smem + waddr[S][ks][1] + j * 4096);
+          wf[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * ih + ii;
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + aaddr[S][ks][0] + i * 4096);
+        const u32x4 hi4 = *reinterpret_cast<const u32x4*>(smem + aaddr[S][ks][1] + i * 4096);
+        af[ii] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+      }
+      if (more && s == 0) load_scales(kt + 1);
+      if (more && s < 3) {
+        const long k0 = (kt + 1) * BK;
+        const int first = s * 3, cnt = s < 2 ? 3 : 2;
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) piece(first + i, 1 - S, k0);
+      }
+#ifndef MTX_EMU
+      if (s == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      if (s == 3 && grp == 1) MTX_WAIT_VMEM();
       G2_BAR();
 #ifndef MTX_EMU
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);      // the scheduler otherwise sinks the MFMAs of several segments past the barriers (fragments stay live: spills)
       __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
+        for (int j = 0; j < 2; ++j) {
+          const int i = 2 * ih + ii;
+          if (ks == 0) mfma_mx_f8<0>(acc[i][j], wf[j], af[ii], sw[j], sa[i]); else mfma_mx_f8<2>(acc[i][j], wf[j], af[ii], sw[j], sa[i]);
+        }
 #ifndef MTX_EMU
       __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
 #endif
-      if (ksl == 1 && grp == 0) wait_slice(s + 1);
+      if (s == 3 && grp == 0) MTX_WAIT_VMEM();
       G2_BAR();
     }
-  }
+  };
+  typedef std::integral_constant<int, 0> St0;
+  typedef std::integral_constant<int, 1> St1;
+  long kt = kbeg;
+  if (kt & 1) { tile(St1(), kt); ++kt; }
+  for (; kt + 1 < kend; kt += 2) { tile(St0(), kt); tile(St1(), kt + 1); }
+  if (kt < kend) tile(St0(), kt);
+#ifndef MTX_EMU
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results are read by VALU code next (the asm form hides them from the hazard recogniser)
+#endif
   if (grp == 0) G2_BAR();
-
-  __syncthreads();
-  gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
-}
-template <typename T>
-static void launch_gemm256r(const GemmParams& p, dim3 grid, void* stream) {
-  switch (p.act) {
-    case MTX_ACT_NONE: MTX_LAUNCH((gemm256r_kernel<T, MTX_ACT_NONE>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_SILU: MTX_LAUNCH((gemm256r_kernel<T, MTX_ACT_SILU>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256r_kernel<T, MTX_ACT_GELU_TANH>), grid, dim3(512), 0, stream, p); break;
-    default: MTX_LAUNCH((gemm256r_kernel<T, -1>), grid, dim3(512), 0, stream, p); break;
-  }
 }
 
-// Wave-specialised variant: 8 MFMA waves (never touch VMEM) + 4 DMA waves (one per SIMD) that stream the next
-// K tile into the other LDS stage while the MFMA waves work.  An LDS-DMA instruction costs its issuing wave
-// 60-180 cycles; in the kernel above that time is taken from the matrix pipe (both waves of a SIMD issue their
-// 8 pieces right after the barrier: no-DMA ablation 1460 vs 1150 TFLOP/s).  768 threads = 3 waves per SIMD,
-// so a wave has 168 registers: 128 accumulators + one fragment set.
 template <typename T, int ACT>
-__global__ __launch_bounds__(768) void gemm256ws_kernel(GemmParams p) {
-  typedef typename Traits<T>::v8 v8;
+__global__ __launch_bounds__(512) void gemm256_f8_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-
-  const unsigned nwg = p.tiles_m * p.tiles_n;
-  const unsigned lin = xcd_remap(blockIdx.x, nwg);
-  const unsigned GM = 4;
-  const unsigned per_group = GM * p.tiles_n;
-  const unsigned group = lin / per_group, first_m = group * GM;
-  const unsigned gsz = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
-  const long m0 = (long)(first_m + (lin % per_group) % gsz) * G2_BM;
-  const long n0 = (long)((lin % per_group) / gsz) * G2_BN;
-  const long bz = blockIdx.y;
-  const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
-  const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
-  T* Cp = reinterpret_cast<T*>(p.c) + (size_t)bz * p.c_bs;
-  const long nk = p.k / G2_BK;
-
-  if (wv >= 8) {
-    // ---- DMA wave L: LDS regions (1 KB = 8 rows of a stage) L*16 .. L*16+15; rows 0..255 are A, 256..511 W
-    const int L = wv - 8;
-    const T* src[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (L * 16 + i) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      if (row < G2_BM) src[i] = (m0 + row < p.m) ? A + (size_t)(m0 + row) * p.lda + c * 8 : nullptr;
-      else src[i] = (n0 + row - G2_BM < p.n) ? W + (size_t)(n0 + row - G2_BM) * p.ldw + c * 8 : nullptr;
-    }
-    auto issue = [&](int stage, long k0) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const void* g = src[i] ? (const void*)(src[i] + k0) : (const void*)g_zero16;
-        glds16(g, smem + stage * G2_STAGE + (L * 16 + i) * 1024);
-      }
-    };
-    issue(0, 0);
-    for (long kt = 0; kt < nk; ++kt) {
-      MTX_WAIT_VMEM();                         // tile kt has landed (this wave's part)
-      G2_BAR();                                // barrier kt: everyone's part landed; stage (kt+1)&1 is free again
-      if (kt + 1 < nk) issue((int)((kt + 1) & 1), (kt + 1) * G2_BK);
-    }
-    __syncthreads();                           // matches the MFMA waves' barrier before the epilogue
-    return;
-  }
-
-  const int wm = wv >> 2, wn = wv & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  long m0, n0;
+  gemm256_tile_origin(p, lin, m0, n0);
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -732,47 +582,11 @@ __global__ __launch_bounds__(768) void gemm256ws_kernel(GemmParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  int aoff[4], woff[2];                        // byte offset of this lane's fragment row, k-step 0, hi-half folded in
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + l31; aoff[i] = r * 128 + ((hi ^ ((r >> 1) & 1)) << 4); }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { const int r = G2_BM + wn * 64 + j * 32 + l31; woff[j] = r * 128 + ((hi ^ ((r >> 1) & 1)) << 4); }
-  // chunk (2*ks + hi) ^ ((r>>1)&7) = ((ks ^ ((r>>2)&3)) << 1) | (hi ^ ((r>>1)&1)): the ks-dependent part is the same
-  // for all rows of a lane's fragments up to bits 2..3 of r, i.e. of l31 (row bases are multiples of 32)
-  const int kx = (l31 >> 2) & 3;
-  for (long kt = 0; kt < nk; ++kt) {
-    G2_BAR();                                  // barrier kt (the DMA waves waited for tile kt before arriving)
-    const unsigned char* st = smem + (kt & 1) * G2_STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int ko = (ks ^ kx) << 5;
-      v8 af[4], wf[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(st + woff[j] + ko);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(st + aoff[i] + ko);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = Mma32<T>::mfma(wf[j], af[i], acc[i][j]);
-    }
-#ifndef MTX_EMU
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-  }
+  gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
   __syncthreads();
-  gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
+  gemm256_epilogue<T, ACT>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
 }
 
-template <typename T>
-static void launch_gemm256ws(const GemmParams& p, dim3 grid, void* stream) {
-  switch (p.act) {
-    case MTX_ACT_NONE: MTX_LAUNCH((gemm256ws_kernel<T, MTX_ACT_NONE>), grid, dim3(768), 0, stream, p); break;
-    case MTX_ACT_SILU: MTX_LAUNCH((gemm256ws_kernel<T, MTX_ACT_SILU>), grid, dim3(768), 0, stream, p); break;
-    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256ws_kernel<T, MTX_ACT_GELU_TANH>), grid, dim3(768), 0, stream, p); break;
-    default: MTX_LAUNCH((gemm256ws_kernel<T, -1>), grid, dim3(768), 0, stream, p); break;
-  }
-}
 
 // ---- stream-K tail ------------------------------------------------------------------------------------------
 // With one 256 x 256 tile per CU at a time, `rem = tiles % CUs` left-over tiles keep rem CUs busy for a whole tile
@@ -780,13 +594,13 @@ static void launch_gemm256ws(const GemmParams& p, dim3 grid, void* stream) {
 // K iterations are instead dealt out evenly: unit u takes iterations [u*I/units, (u+1)*I/units) of the rem * nk
 // iterations, i.e. the end of one tile and possibly the start of the next, and leaves an fp32 partial per piece
 // (slot 2u, 2u+1); the merge kernel adds a tile's pieces in K order and applies the usual epilogue.
-template <typename T>
+template <typename T, bool F8>
 __global__ __launch_bounds__(512) void gemm256_tail_kernel(GemmParams p) {
   typedef typename Traits<T>::v8 v8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wm = wv >> 2, wn = wv & 3;
-  const long nk = p.k / G2_BK;
+  const long nk = p.k / p.bk;
   const unsigned tiles = p.tiles_m * p.tiles_n, rem = tiles - p.n_full;
   const long I = (long)rem * nk;
   const unsigned u = blockIdx.x;
@@ -814,7 +628,8 @@ __global__ __launch_bounds__(512) void gemm256_tail_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     __syncthreads();                                            // the previous piece is done with the LDS stages
-    gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, kbeg, kend, acc);
+    if (F8) gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, kbeg, kend, acc);
+    else gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, kbeg, kend, acc);
     // fp32 partial of this piece: [256 m][256 n], a lane stores 4 consecutive n
     float* P = p.part + (size_t)(2 * u + seg) * G2_BM * G2_BN;
 #pragma unroll
@@ -833,7 +648,7 @@ __global__ __launch_bounds__(512) void gemm256_tail_kernel(GemmParams p) {
 // one workgroup per (tail tile, 32-row band): sum the pieces in K order, epilogue, 16-byte stores
 template <typename T>
 __global__ __launch_bounds__(256) void gemm256_merge_kernel(GemmParams p) {
-  const long nk = p.k / G2_BK;
+  const long nk = p.k / p.bk;
   const unsigned tiles = p.tiles_m * p.tiles_n, rem = tiles - p.n_full;
   const long I = (long)rem * nk;
   const unsigned ti = blockIdx.x / 8, band = blockIdx.x % 8;
@@ -872,7 +687,6 @@ __global__ __launch_bounds__(256) void gemm256_merge_kernel(GemmParams p) {
     *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = pack8<T>(f);
   }
 }
-
 static int gemm_num_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -886,57 +700,36 @@ static int gemm_num_cus() {
   return cus;
 }
 
-template <typename T, bool PP, bool CLAMP>
-static void launch_gemm256_ppc(const GemmParams& p, dim3 grid, void* stream) {
+template <typename T, bool F8>
+static void launch_gemm256_tiles(const GemmParams& p, dim3 grid, void* stream) {
+#define MTX_G256(ACTV) do { if (F8) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); \
+                            else MTX_LAUNCH((gemm256_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); } while (0)
   switch (p.act) {
-    case MTX_ACT_NONE: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_NONE, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_SILU: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_SILU, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_GELU_TANH, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
-    default: MTX_LAUNCH((gemm256_kernel<T, -1, PP, CLAMP>), grid, dim3(512), 0, stream, p); break;
+    case MTX_ACT_NONE: MTX_G256(MTX_ACT_NONE); break;
+    case MTX_ACT_SILU: MTX_G256(MTX_ACT_SILU); break;
+    case MTX_ACT_GELU_TANH: MTX_G256(MTX_ACT_GELU_TANH); break;
+    default: MTX_G256(-1); break;
   }
+#undef MTX_G256
 }
-template <typename T>
-static void launch_gemm256_buf(const GemmParams& p, dim3 grid, void* stream) {
-  switch (p.act) {
-    case MTX_ACT_NONE: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_NONE, true, true, true>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_SILU: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_SILU, true, true, true>), grid, dim3(512), 0, stream, p); break;
-    case MTX_ACT_GELU_TANH: MTX_LAUNCH((gemm256_kernel<T, MTX_ACT_GELU_TANH, true, true, true>), grid, dim3(512), 0, stream, p); break;
-    default: MTX_LAUNCH((gemm256_kernel<T, -1, true, true, true>), grid, dim3(512), 0, stream, p); break;
-  }
-}
-template <typename T, bool PP>
-static void launch_gemm256_pp(const GemmParams& p, dim3 grid, void* stream) {
-  const char* e = getenv("MTX_GEMM_CLAMP");              // A/B switch: "0" = the zero-block select of the first version
-  if (e && e[0] == '0') launch_gemm256_ppc<T, PP, false>(p, grid, stream);
-  else launch_gemm256_ppc<T, PP, true>(p, grid, stream);
-}
-template <typename T>
-static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream) {
+
+// measured on MI355X (tools/bench_kernels.py, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the 3/3/2/0
+// piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
+// specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
+template <typename T, bool F8>
+static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit) {
   GemmParams p = p0;
-  const char* e = getenv("MTX_GEMM256_SCHED");          // A/B switch: "buf" (default), "pingpong", "lockstep", "ring", "ws"
-  // measured on MI355X (tools/bench_kernels.py ab, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the
-  // 3/3/2/0 piece spread runs 1119-1341 TFLOP/s, 12-15 % ahead of the flat-address ping-pong (wins up to K = 4096) and one-barrier
-  // (wins above) loops it replaces; the ring is 2-5 % and the wave-specialised variant 10-15 % behind those
-  const bool fits32 = ((size_t)G2_BM * p.lda + p.k) * sizeof(T) < (1ull << 32) && ((size_t)G2_BN * p.ldw + p.k) * sizeof(T) < (1ull << 32);      // one tile's rows under a descriptor
-  const char mode = e ? e[0] : (fits32 ? 'b' : (p.k <= 4096 ? 'p' : 'l'));
   // stream-K tail when the last wave of tiles would fill less than ~70 % of the chip
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
-  const char* ns = getenv("MTX_GEMM_NOSPLIT");
-  const bool tail = fits32 && p.part != nullptr && cus <= 320 && grid.y == 1 && tiles > cus && rem > 0 && rem * 10 < cus * 7 && p.k / G2_BK >= (getenv("MTX_GEMM256_MIN_TILES") ? 8 : 64) && !(ns && ns[0] == '1');
+  const long nk = p.k / p.bk;
+  const bool tail = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles > cus && rem > 0 && rem * 10 < cus * 7 && nk >= (force ? 4 : (F8 ? 32 : 64)) && !nosplit;
   // few tiles but a long K (FLUX text-stream ff2: 24 tiles x 192 iterations): stream-K over the whole problem
-  const bool allk = fits32 && p.part != nullptr && cus <= 320 && grid.y == 1 && tiles * 2 <= cus && p.k / G2_BK >= 128 && !(ns && ns[0] == '1');
+  const bool allk = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles * 2 <= cus && nk >= (F8 ? 64 : 128) && !nosplit;
   if (allk) { p.n_full = 0; p.units = cus; }
   else if (tail) { p.n_full = tiles - rem; p.units = cus; grid.x = p.n_full; }
-  if (!allk) {
-    if (mode == 'l') launch_gemm256_pp<T, false>(p, grid, stream);
-    else if (mode == 'p') launch_gemm256_pp<T, true>(p, grid, stream);
-    else if (mode == 'r') launch_gemm256r<T>(p, grid, stream);
-    else if (mode == 'b' && fits32) launch_gemm256_buf<T>(p, grid, stream);
-    else if (mode == 'b') launch_gemm256_pp<T, true>(p, grid, stream);          // a descriptor addresses 4 GB
-    else launch_gemm256ws<T>(p, grid, stream);
-  }
+  if (!allk) launch_gemm256_tiles<T, F8>(p, grid, stream);
   if (tail || allk) {
-    MTX_LAUNCH((gemm256_tail_kernel<T>), dim3(p.units), dim3(512), 0, stream, p);
+    MTX_LAUNCH((gemm256_tail_kernel<T, F8>), dim3(p.units), dim3(512), 0, stream, p);
     MTX_LAUNCH((gemm256_merge_kernel<T>), dim3((tiles - p.n_full) * 8), dim3(256), 0, stream, p);
   }
 }
@@ -944,6 +737,8 @@ static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream) {
 int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (!a->a || !a->w || !a->c) { *err = "gemm: null operand"; return MTX_ERR_INVALID; }
   if (a->m < 1 || a->n < 1 || a->k < 1) { *err = "gemm: empty problem"; return MTX_ERR_INVALID; }
+  const bool f8 = a->in_dtype == MTX_F8;
+  if (a->in_dtype != 0 && !f8 && a->in_dtype != a->dtype) { *err = "gemm: in_dtype must be 0, dtype or MTX_F8"; return MTX_ERR_INVALID; }
   if (a->k % 8 || a->lda % 8 || a->ldw % 8) { *err = "gemm: K, lda, ldw must be multiples of 8 (16-byte chunks)"; return MTX_ERR_INVALID; }
   if (a->batch > 1 && (a->a_bstride % 8 || a->w_bstride % 8 || a->c_bstride % 8 || a->res_bstride % 8)) { *err = "gemm: batch strides must be multiples of 8"; return MTX_ERR_INVALID; }
   if (a->out_dtype != a->dtype && a->out_dtype != MTX_F32) { *err = "gemm: out_dtype must equal dtype or be f32"; return MTX_ERR_INVALID; }
@@ -956,28 +751,43 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.gate_rows_per = a->gate_rows_per > 0 ? a->gate_rows_per : 1;
   p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;
-  p.abl = getenv("MTX_GEMM_ABL") ? atoi(getenv("MTX_GEMM_ABL")) : 0;
   p.n_full = 0; p.units = 0;
   p.part = (a->workspace && a->workspace_bytes >= (int64_t)MTX_GEMM_WORKSPACE_BYTES) ? reinterpret_cast<float*>(a->workspace) : nullptr;
+  p.a_scale = reinterpret_cast<const unsigned*>(a->a_scale); p.w_scale = reinterpret_cast<const unsigned*>(a->w_scale);
+  p.lds_a = a->lds_a; p.lds_w = a->lds_w;
+  p.bk = f8 ? 128 : G2_BK;
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;
+  const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0;
   // large, aligned problems: the 256 x 256 LDS-DMA kernel (needs whole K tiles and 16-byte rows everywhere)
   const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;
   const bool vec = a->n % 8 == 0 && a->ldc % 8 == 0 && (!a->res || a->ldres % 8 == 0) && (!a->gate || a->ldgate % 8 == 0) && a->c_bstride % 8 == 0;
+  const size_t esz = f8 ? 1 : 2;
+  const bool fits32 = ((size_t)G2_BM * a->lda + a->k) * esz < (1ull << 32) && ((size_t)G2_BN * a->ldw + a->k) * esz < (1ull << 32);      // one tile's rows under a descriptor
+  if (f8) {
+    if (a->dtype != MTX_BF16 && a->dtype != MTX_F16) { *err = "gemm(fp8): dtype (epilogue / output type) must be bf16 or f16"; return MTX_ERR_INVALID; }
+    if (!a->a_scale || !a->w_scale || a->lds_a < a->m || a->lds_w < a->n) { *err = "gemm(fp8): scale planes missing or lds_a / lds_w shorter than the row count"; return MTX_ERR_INVALID; }
+    if (a->k % 128 || a->lda % 16 || a->ldw % 16 || !vec || p.out_f32 || batch != 1 || !fits32) { *err = "gemm(fp8): needs K % 128 == 0, lda / ldw % 16 == 0, N / ldc % 8 == 0, 16-bit output, batch 1"; return MTX_ERR_INVALID; }
+    p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
+    p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
+    dim3 g2(p.tiles_m * p.tiles_n, 1);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, true>(p, g2, stream, force, nosplit); else launch_gemm256<_Float16, true>(p, g2, stream, force, nosplit);
+    return MTX_OK;
+  }
   // with the descriptor-DMA loop the 256-tile kernel wins from ~24 tiles up even though most CUs idle (512x9216x3072: 55 vs 68 us,
-  // 1024x4608x1152: 24.5 vs 32.7 us); below that the 128-tile kernel's extra parallelism pays.  Tests lower it.
+  // 1024x4608x1152: 24.5 vs 32.7 us); below that the 128-tile kernel's extra parallelism pays.
   // (short K — SAM's 576-wide stage — keeps the old threshold: the tile prologue / epilogue dominates there, encoder 12.5 vs 11.8 ms)
   // and so do shapes that would pad a 256-tile row or column by more than 10 % (SAM's N = 576: 3 columns for 2.25)
   const long t256m = (a->m + G2_BM - 1) / G2_BM, t256n = (a->n + G2_BN - 1) / G2_BN;
   const bool snug = a->m * 10 >= t256m * G2_BM * 9 && a->n * 10 >= t256n * G2_BN * 9;
-  const long min_tiles = getenv("MTX_GEMM256_MIN_TILES") ? atol(getenv("MTX_GEMM256_MIN_TILES")) : ((a->k >= 1024 && snug) ? 24 : 160);
+  const long min_tiles = force ? 1 : ((a->k >= 1024 && snug) ? 24 : 160);
   const bool few_long = a->workspace != nullptr && batch == 1 && t256 * 2 <= gemm_num_cus() && a->k / G2_BK >= 128 && a->m >= 256;
-  if (!p.out_f32 && a->k % G2_BK == 0 && vec && (t256 >= min_tiles || few_long) && (a->dtype == MTX_BF16 || a->dtype == MTX_F16)) {
+  if (!p.out_f32 && a->k % G2_BK == 0 && vec && fits32 && (t256 >= min_tiles || few_long) && (a->dtype == MTX_BF16 || a->dtype == MTX_F16)) {
     p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
     p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
     dim3 g2(p.tiles_m * p.tiles_n, (unsigned)batch);
-    if (a->dtype == MTX_BF16) launch_gemm256<__bf16>(p, g2, stream); else launch_gemm256<_Float16>(p, g2, stream);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, false>(p, g2, stream, force, nosplit); else launch_gemm256<_Float16, false>(p, g2, stream, force, nosplit);
     return MTX_OK;
   }
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);

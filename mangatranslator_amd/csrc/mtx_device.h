@@ -228,6 +228,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- OCP fp8 e4m3 ------------------------------------------------------------------------------------------
+// two fp32 -> two e4m3 bytes (RNE) in the low (HI = false) or high half of `old`; callers clamp to +-448 first
+template <bool HI>
+__device__ __forceinline__ unsigned cvt_pk_fp8(float a, float b, unsigned old) {
+#ifdef MTX_EMU
+  const unsigned pk = (unsigned)emu_f32_to_e4m3(a) | ((unsigned)emu_f32_to_e4m3(b) << 8);
+  return HI ? ((old & 0x0000ffffu) | (pk << 16)) : ((old & 0xffff0000u) | pk);
+#else
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, HI);
+#endif
+}
+
 // XCD-aware, bijective remap of a linear workgroup id: workgroup b runs on XCD b%8 (observed),
 // so give each XCD a contiguous range of tiles and neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {

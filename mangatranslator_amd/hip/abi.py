@@ -2,16 +2,16 @@
 mtx_abi_sizeof() when the library is opened)."""
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums
-BF16, F16, F32, U8, I32 = 0, 1, 2, 3, 4
+BF16, F16, F32, U8, I32, F8 = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_SIGMOID, ACT_LEAKY = range(7)
 (EW_SCALE_RES, EW_ADD, EW_MUL, EW_ACT, EW_UPSAMPLE2X, EW_MAXPOOL, EW_COPY, EW_GATE_RES,
- EW_ROW_GATHER, EW_IM2COL, EW_SOFTMAX_ROWS, EW_TRANSPOSE, EW_QK_NORM_ROPE, EW_AVGPOOL2) = range(14)
+ EW_ROW_GATHER, EW_IM2COL, EW_SOFTMAX_ROWS, EW_TRANSPOSE, EW_QK_NORM_ROPE, EW_AVGPOOL2, EW_SWIGLU) = range(15)
 IMG_NCHW_F32_TO_NHWC, IMG_NHWC_TO_NCHW_F32, IMG_NHWC_TO_HWC_U8, IMG_HWC_U8_TO_NHWC = range(4)
 (OP_CONV2D, OP_GEMM, OP_ATTN, OP_NORM, OP_GROUPNORM, OP_EW, OP_CA, OP_IMG, OP_RESIZE_THRESH,
- OP_MEMSET, OP_MASK_SELECT, OP_PREPROC, OP_YOLO_DECODE, OP_DETR) = range(1, 15)
+ OP_MEMSET, OP_MASK_SELECT, OP_PREPROC, OP_YOLO_DECODE, OP_DETR, OP_QUANT) = range(1, 16)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -33,9 +33,11 @@ class GemmArgs(C.Structure):
                 ("res_bstride", i64),
                 ("gate_rows_per", i32),
                 ("act", i32), ("act_param", f32), ("alpha", f32),
-                ("dtype", i32), ("out_dtype", i32), ("workspace", vp), ("workspace_bytes", i64)]
+                ("dtype", i32), ("out_dtype", i32), ("workspace", vp), ("workspace_bytes", i64),
+                ("a_scale", vp), ("w_scale", vp), ("lds_a", i64), ("lds_w", i64), ("in_dtype", i32), ("flags", i32)]
 
 
+GEMM_FORCE_TILE256, GEMM_NO_SPLIT = 1, 2
 GEMM_WORKSPACE_BYTES = 2 * 320 * 256 * 256 * 4
 
 
@@ -119,6 +121,11 @@ class DetrArgs(C.Structure):
                 ("offset_scale", f32), ("dtype", i32)]
 
 
+class QuantArgs(C.Structure):
+    _fields_ = [("x", vp), ("q", vp), ("scale", vp),
+                ("rows", i64), ("k", i64), ("ldx", i64), ("ldq", i64), ("lds", i64), ("dtype", i32)]
+
+
 class CleanArgs(C.Structure):
     _fields_ = [("page_bgr", vp), ("masks", vp), ("rois", vp), ("offsets", vp),
                 ("base", vp), ("roi", vp), ("eroded", vp), ("thresholded", vp), ("shrunk", vp),
@@ -135,7 +142,7 @@ CLEAN_ARGS_KIND = 100      # mtx_abi_sizeof() key of the op-level-only struct
 class _OpUnion(C.Union):
     _fields_ = [("conv", ConvArgs), ("gemm", GemmArgs), ("attn", AttnArgs), ("norm", NormArgs),
                 ("gn", GroupNormArgs), ("ew", EwArgs), ("ca", CaArgs), ("img", ImgArgs),
-                ("rt", ResizeThreshArgs), ("ms", MemsetArgs), ("sel", MaskSelectArgs), ("pre", PreprocArgs), ("yd", YoloDecodeArgs), ("detr", DetrArgs)]
+                ("rt", ResizeThreshArgs), ("ms", MemsetArgs), ("sel", MaskSelectArgs), ("pre", PreprocArgs), ("yd", YoloDecodeArgs), ("detr", DetrArgs), ("quant", QuantArgs)]
 
 
 class Op(C.Structure):
@@ -145,17 +152,17 @@ class Op(C.Structure):
 ARG_TYPES = {OP_CONV2D: ConvArgs, OP_GEMM: GemmArgs, OP_ATTN: AttnArgs, OP_NORM: NormArgs,
              OP_GROUPNORM: GroupNormArgs, OP_EW: EwArgs, OP_CA: CaArgs, OP_IMG: ImgArgs,
              OP_RESIZE_THRESH: ResizeThreshArgs, OP_MEMSET: MemsetArgs,
-             OP_MASK_SELECT: MaskSelectArgs, OP_PREPROC: PreprocArgs, OP_YOLO_DECODE: YoloDecodeArgs, OP_DETR: DetrArgs}
+             OP_MASK_SELECT: MaskSelectArgs, OP_PREPROC: PreprocArgs, OP_YOLO_DECODE: YoloDecodeArgs, OP_DETR: DetrArgs, OP_QUANT: QuantArgs}
 UNION_FIELD = {OP_CONV2D: "conv", OP_GEMM: "gemm", OP_ATTN: "attn", OP_NORM: "norm",
                OP_GROUPNORM: "gn", OP_EW: "ew", OP_CA: "ca", OP_IMG: "img",
-               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms", OP_MASK_SELECT: "sel", OP_PREPROC: "pre", OP_YOLO_DECODE: "yd", OP_DETR: "detr"}
+               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms", OP_MASK_SELECT: "sel", OP_PREPROC: "pre", OP_YOLO_DECODE: "yd", OP_DETR: "detr", OP_QUANT: "quant"}
 
 # every symbol include/mtx_hip.h declares (tests check the built library exports all of them)
 EXPORTS = [
     "mtx_abi_version", "mtx_abi_sizeof", "mtx_last_error", "mtx_init", "mtx_device_info",
     "mtx_conv2d", "mtx_conv2d_tiles", "mtx_gemm", "mtx_attention", "mtx_norm", "mtx_groupnorm",
     "mtx_elementwise", "mtx_channel_attention", "mtx_image_convert", "mtx_resize_threshold",
-    "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode", "mtx_detr", "mtx_bubble_clean", "mtx_host_text_mask", "mtx_host_chamfer_l2_5x5", "mtx_host_mask_outline",
+    "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode", "mtx_detr", "mtx_quantize_mx", "mtx_bubble_clean", "mtx_host_text_mask", "mtx_host_chamfer_l2_5x5", "mtx_host_mask_outline",
     "mtx_plan_create", "mtx_plan_run", "mtx_plan_run_graph", "mtx_plan_num_ops",
     "mtx_plan_run_range", "mtx_plan_destroy", "mtx_plan_time", "mtx_plan_time_range", "mtx_plan_time_ops",
 ]

@@ -200,8 +200,15 @@ class PlanBuilder:
     def gemm(self, a_t, w_t, m, n, k, lda=None, ldw=None, out=None, ldc=None, bias=None, act=abi.ACT_NONE,
              res=None, ldres=None, gate=None, ldgate=None, gate_rows_per=1, alpha=1.0, batch=1,
              a_bs=0, w_bs=0, c_bs=0, res_bs=0, out_f32=False, a_off=0, w_off=0, c_off=0, res_off=0,
-             label="gemm"):
+             label="gemm", f8=None, flags=0):
+        """f8 = (a_scale, lds_a, w_scale, lds_w, a_scale_off, w_scale_off): a_t / w_t are e4m3 byte matrices from `quantize` (offsets in
+        bytes), the epilogue operands and the output stay in the builder's 16-bit type (include/mtx_hip.h, in_dtype == MTX_F8)"""
         g = abi.GemmArgs()
+        g.flags = flags
+        if f8 is not None:
+            a_sc, lds_a, w_sc, lds_w, a_sc_off, w_sc_off = f8
+            g.a_scale, g.w_scale = a_sc.data_ptr() + 4 * a_sc_off, w_sc.data_ptr() + 4 * w_sc_off
+            g.lds_a, g.lds_w, g.in_dtype = lds_a, lds_w, abi.F8
         if out is None:
             out = self.buf((batch, m, n) if batch > 1 else (m, n), torch.float32 if out_f32 else self.tdtype)
         g.a, g.w, g.c = _ptr(a_t, a_off), _ptr(w_t, w_off), _ptr(out, c_off)
@@ -393,6 +400,19 @@ class PlanBuilder:
         a.ref, a.ref_out, a.ref_t, a.delta = _ptr(ref_in_f32), _ptr(ref_out_f32), _ptr(ref_t), _ptr(delta)
         a.kind, a.rows, a.ld_delta, a.dtype = (1 if delta is not None else 2), rows, ld_delta, self.dtype
         self._add(abi.OP_DETR, a, label)
+
+    def quantize(self, x, rows, k, ldx=None, x_off=0, q=None, scale=None, row_off=0, lds=None, label="quantize_mx"):
+        """MX fp8 copy of rows [0, rows) of a 16-bit [*, ldx] matrix starting x_off elements in; with `q` / `scale` given the result
+        lands in rows [row_off, row_off + rows) of those buffers (q [R, k] bytes, scale [k / 128, lds] uint32).  -> (q, scale, lds)"""
+        if q is None:
+            lds = (rows + 63) // 64 * 64
+            q = self.buf((rows, k), torch.uint8)
+            scale = self.buf((k // 128, lds), torch.int32, zero=True)
+        a = abi.QuantArgs()
+        a.x, a.q, a.scale = _ptr(x, x_off), q.data_ptr() + row_off * k, scale.data_ptr() + 4 * row_off
+        a.rows, a.k, a.ldx, a.ldq, a.lds, a.dtype = rows, k, (ldx or k), k, lds, self.dtype
+        self._add(abi.OP_QUANT, a, label)
+        return q, scale, lds
 
     def memset(self, t, value=0, label="memset"):
         a = abi.MemsetArgs()

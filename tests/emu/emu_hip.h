@@ -214,6 +214,56 @@ inline emu_f32x16 emu_mfma_32x32x16(V8 a, V8 b, emu_f32x16 c) {
   emu::wave_sync();
   return d;
 }
+// ---- OCP fp8 e4m3fn (bias 7, no inf, 0x7f = NaN, max 448) --------------------------------------------------
+inline float emu_e4m3_to_f32(unsigned char b) {
+  const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+  float v;
+  if (e == 15 && m == 7) v = NAN;
+  else if (e == 0) v = ldexpf((float)m, -9);
+  else v = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+  return s ? -v : v;
+}
+inline unsigned char emu_f32_to_e4m3(float f) {          // round to nearest even, saturating
+  const unsigned char s = std::signbit(f) ? 0x80 : 0;
+  float a = fabsf(f);
+  if (std::isnan(a)) return s | 0x7f;
+  if (a >= 448.f) return s | 0x7e;
+  int e;
+  (void)frexpf(a, &e);                                   // a = mant * 2^e, mant in [0.5, 1)
+  e -= 1;                                                // a in [2^e, 2^(e+1))
+  if (a == 0.f || e < -6) return s | (unsigned char)nearbyintf(ldexpf(a, 9));       // subnormals: steps of 2^-9 (8 = the first normal)
+  int m = (int)nearbyintf((ldexpf(a, -e) - 1.0f) * 8.0f);
+  if (m == 8) { m = 0; ++e; }
+  return s | (unsigned char)(((e + 7) << 3) | m);
+}
+// D = A(32x64) * B(64x32) + C with one E8M0 scale per lane: lane l holds 32 e4m3 bytes A[l&31][32*(l>>5) + 0..31] (B alike,
+// column l&31) and applies 2^(byte OPSEL of its scale word - 127) to them (v_mfma_scale_f32_32x32x64_f8f6f4, cbsz = blgp = 0)
+typedef __attribute__((ext_vector_type(8))) int emu_i32x8;
+typedef __attribute__((ext_vector_type(16))) float emu_f32x16_;
+inline emu_f32x16_ emu_mfma_scale_32x32x64_f8(emu_i32x8 a, emu_i32x8 b, emu_f32x16_ c, int opa, int sa, int opb, int sb) {
+  emu::WaveState& w = emu::wave();
+  int l = emu::lane_id();
+  memcpy(w.xa[l], &a, 32); w.xa[l][32] = (unsigned char)(((unsigned)sa >> (8 * opa)) & 0xff);
+  memcpy(w.xb[l], &b, 32); w.xb[l][32] = (unsigned char)(((unsigned)sb >> (8 * opb)) & 0xff);
+  emu::wave_sync();
+  emu_f32x16_ d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    double s = 0.0;
+    for (int hb = 0; hb < 2; ++hb) {
+      const unsigned char* pa = w.xa[hb * 32 + row];
+      const unsigned char* pb = w.xb[hb * 32 + col];
+      double part = 0.0;
+      for (int i = 0; i < 32; ++i) part += (double)emu_e4m3_to_f32(pa[i]) * (double)emu_e4m3_to_f32(pb[i]);
+      s += ldexp(part, (int)pa[32] - 127 + (int)pb[32] - 127);
+    }
+    d[r] += (float)s;
+  }
+  emu::wave_sync();
+  return d;
+}
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, cbsz, blgp, opa, sa, opb, sb) emu_mfma_scale_32x32x64_f8(a, b, c, opa, sa, opb, sb)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16(a, b, c)
 

@@ -95,7 +95,7 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
 
 
 def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=False, with_gate=False,
-               out_f32=False, batch=1, alpha=1.0, seed=0):
+               out_f32=False, batch=1, alpha=1.0, seed=0, flags=0):
     g = torch.Generator().manual_seed(seed)
     dev, td = _dev(lib), TD[dtype]
     a = torch.randn(batch, m, k, generator=g).to(td)
@@ -123,7 +123,7 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
     out = pb.gemm(at, wt, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
                   res=pb.const(res) if res is not None else None,
                   gate=pb.const(gate) if gate is not None else None, gate_rows_per=rows_per,
-                  alpha=alpha, batch=batch, a_bs=m * k, w_bs=n * k, c_bs=m * n, out_f32=out_f32)
+                  alpha=alpha, batch=batch, a_bs=m * k, w_bs=n * k, c_bs=m * n, out_f32=out_f32, flags=flags)
     _run(pb)
     err = _relerr(out.cpu().view(batch, m, n), ref)
     assert err < TOL[dtype], f"gemm mismatch rel err {err}"
@@ -362,3 +362,95 @@ def check_softmax_transpose(lib, dtype, rows, cols, seed=0):
     assert err < TOL[dtype], f"softmax_rows mismatch rel err {err}"
     assert torch.equal(tr.cpu()[:, :rows], x.t()), "transpose must be exact"
     return err
+
+
+# ---- fp8 path (BASELINE.json config 5) --------------------------------------------------------------------------------
+def mx_quantize_ref(x: torch.Tensor):
+    """torch restatement of mtx_quantize_mx (include/mtx_hip.h): per 32 k one E8M0 exponent eb = the smallest with
+    2^(eb - 127) >= amax / 448 (fp32 arithmetic as in the kernel), q = RNE_e4m3(x * 2^(127 - eb)).
+    -> (q uint8 [rows, k], eb int32 [rows, k / 32], dequantised fp32 [rows, k])"""
+    rows, k = x.shape
+    xb = x.float().view(rows, k // 32, 32)
+    amax = xb.abs().amax(-1)
+    r = (amax * torch.tensor(1.0 / 448.0, dtype=torch.float32)).contiguous()
+    u = r.view(torch.int32)
+    eb = ((u >> 23) & 0xff) + ((u & 0x7fffff) != 0).int()
+    eb = torch.where(amax == 0, torch.full_like(eb, 127), eb.clamp(1, 253))
+    inv = torch.ldexp(torch.ones_like(amax), 127 - eb)
+    q8 = (xb * inv[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    deq = q8.float() * torch.ldexp(torch.ones_like(amax), eb - 127)[..., None]
+    return q8.view(torch.uint8).view(rows, k), eb, deq.view(rows, k)
+
+
+def check_quantize_mx(lib, dtype, rows, k, ld_extra=0, seed=0, spread=4.0):
+    """bytes and scale words bit-exact against the torch restatement (inputs with a wide dynamic range across blocks)"""
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = torch.randn(rows, k, generator=g) * torch.exp(spread * torch.randn(rows, k // 32, generator=g)).repeat_interleave(32, 1)
+    x[0, :32] = 0.0                                   # an all-zero block
+    x = x.to(td)
+    q_ref, eb_ref, _ = mx_quantize_ref(x)
+    pb = PlanBuilder(lib, dev, dtype)
+    xt = pb.buf((rows, k + ld_extra), td)
+    xt[:, :k] = x.to(dev)
+    q, sc, lds = pb.quantize(xt, rows, k, ldx=k + ld_extra)
+    _run(pb)
+    assert torch.equal(q.cpu(), q_ref), f"fp8 bytes differ in {(q.cpu() != q_ref).sum().item()} places"
+    words = sc.cpu()[:, :rows].t().contiguous()                    # [rows, k/128] int32
+    got = torch.stack([(words >> (8 * b)) & 0xff for b in range(4)], -1).view(rows, k // 32)
+    assert torch.equal(got.int(), eb_ref.int()), "scale bytes differ"
+
+
+def check_gemm_f8(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=False, with_gate=False, seed=0, flags=0,
+                  spread=1.0):
+    """C = epilogue(dequant(Aq) dequant(Wq)^T): the kernel against an fp32 product of the SAME quantised operands (so the check is
+    the kernel's arithmetic: e4m3 decode, block scales, k pairing, accumulation), plus the distance to the unquantised product."""
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    a = (torch.randn(m, k, generator=g) * torch.exp(spread * torch.randn(m, k // 32, generator=g)).repeat_interleave(32, 1)).to(td)
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).to(td)
+    b = torch.randn(n, generator=g) if with_bias else None
+    _, _, ad = mx_quantize_ref(a)
+    _, _, wd = mx_quantize_ref(w)
+    ref = ad @ wd.t()
+    full = a.float() @ w.float().t()
+    qerr = ((ref - full).norm() / full.norm()).item()
+    if b is not None:
+        ref = ref + b
+    if act == abi.ACT_GELU_TANH:
+        ref = F.gelu(ref, approximate="tanh")
+    elif act == abi.ACT_SILU:
+        ref = F.silu(ref)
+    gate = res = None
+    rows_per = max(m // 2, 1)
+    if with_gate:
+        gate = torch.randn((m + rows_per - 1) // rows_per, n, generator=g).to(td)
+        ref = ref * gate.float().repeat_interleave(rows_per, dim=0)[:m]
+    if with_res:
+        res = torch.randn(m, n, generator=g).to(td)
+        ref = ref + res.float()
+    pb = PlanBuilder(lib, dev, dtype)
+    aq, asc, lds_a = pb.quantize(pb.const(a), m, k)
+    wq, wsc, lds_w = pb.quantize(pb.const(w), n, k)
+    out = pb.gemm(aq, wq, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
+                  res=pb.const(res) if res is not None else None, gate=pb.const(gate) if gate is not None else None,
+                  gate_rows_per=rows_per, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=flags)
+    _run(pb)
+    err = _relerr(out.cpu().view(m, n), ref)
+    assert err < TOL[dtype], f"fp8 gemm mismatch rel err {err}"
+    return err, qerr
+
+
+def check_swiglu(lib, dtype, rows, hid, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = torch.randn(rows, 2 * hid, generator=g).to(td)
+    ref = F.silu(x[:, :hid].float()) * x[:, hid:].float()
+    pb = PlanBuilder(lib, dev, dtype)
+    xt = pb.const(x)
+    va = Act(xt.view(1, 1, rows, 2 * hid), 1, 1, rows, hid, 0)
+    vb = Act(xt.view(1, 1, rows, 2 * hid), 1, 1, rows, hid, hid)
+    y = pb.ew(abi.EW_SWIGLU, va, b=vb)
+    _run(pb)
+    err = _relerr(y.torch().cpu().view(rows, hid), ref)
+    assert err < TOL[dtype], f"swiglu mismatch {err}"

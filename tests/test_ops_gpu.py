@@ -116,12 +116,24 @@ def test_gemm_256_tile_kernel(hip_lib, cfg):
     oc.check_gemm(hip_lib, abi.F16, **cfg)
 
 
-@pytest.mark.parametrize("sched", ["ring", "pingpong", "lockstep", "buf"])
-def test_gemm_256_schedules(hip_lib, monkeypatch, sched):
-    monkeypatch.setenv("MTX_GEMM256_SCHED", sched)
-    oc.check_gemm(hip_lib, abi.BF16, m=8652, n=3072, k=3072, with_res=True, with_gate=True)
-    oc.check_gemm(hip_lib, abi.F16, m=4100, n=9216, k=12288 + 64, act=abi.ACT_GELU_TANH)
-    oc.check_gemm(hip_lib, abi.BF16, m=4100, n=3072, k=64)
+def test_quantize_mx(hip_lib):
+    """MX fp8 quantiser (v_cvt_pk_fp8_f32, OCP e4m3) bit-exact against the torch restatement"""
+    oc.check_quantize_mx(hip_lib, abi.BF16, rows=8652, k=3072)
+    oc.check_quantize_mx(hip_lib, abi.F16, rows=333, k=1152, ld_extra=8, spread=8.0)
+
+
+@pytest.mark.parametrize("cfg", [dict(m=8652, n=3072, k=3072, with_res=True, with_gate=True), dict(m=4100, n=9216, k=1024, act=abi.ACT_GELU_TANH),
+                                 dict(m=2048, n=5000 // 8 * 8, k=384, act=abi.ACT_SILU, with_bias=False, with_res=True, spread=2.0),
+                                 dict(m=8704, n=3072, k=12288, with_gate=True, with_res=True), dict(m=300, n=264, k=128, flags=abi.GEMM_FORCE_TILE256)])
+def test_gemm_fp8(hip_lib, cfg):
+    """v_mfma_scale_f32_32x32x64_f8f6f4 path against an fp32 product of the same quantised operands (FLUX.2-Klein shapes)"""
+    err, qerr = oc.check_gemm_f8(hip_lib, abi.BF16, **cfg)
+    print(f"fp8 gemm {cfg}: kernel rel err {err:.2e}, quantisation rel err vs the 16-bit product {qerr:.3f}")
+    assert qerr < 0.06
+
+
+def test_swiglu(hip_lib):
+    oc.check_swiglu(hip_lib, abi.BF16, rows=8652, hid=9216)
 
 
 def test_attention_prescaled_q(hip_lib):

@@ -119,30 +119,35 @@ def test_attention_long_sequence_duo_variant(emu_lib, monkeypatch):
     oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=320, d=128)
 
 
-def test_gemm_256_tile_kernel(emu_lib, monkeypatch):
-    """the 256 x 256 LDS-DMA kernel (normally used from 24 tiles up) on ragged small problems"""
-    monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
-    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
-    oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False)
-    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=4160, with_res=True)          # K > 4096: the one-barrier loop with threaded DMA
+def test_gemm_256_tile_kernel(emu_lib):
+    """the 256 x 256 LDS-DMA kernel (normally used from 24 tiles up) on ragged small problems: ping-pong loop with descriptor-based
+    LDS-DMA (range-checked zero fill), pieces spread 3/3/2/0"""
+    f = abi.GEMM_FORCE_TILE256
+    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f)
+    oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False, flags=f)
+    oc.check_gemm(emu_lib, abi.BF16, m=260, n=250 // 8 * 8, k=448, with_res=True, flags=f)
+    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=4160, with_res=True, flags=f)
 
 
-def test_gemm_256_buffer_dma_schedule(emu_lib, monkeypatch):
-    """MTX_GEMM256_SCHED=buf: ping-pong loop with descriptor-based LDS-DMA (range-checked zero fill), pieces spread 3/3/2/0"""
-    monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
-    monkeypatch.setenv("MTX_GEMM256_SCHED", "buf")
-    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
-    oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=64, batch=2, alpha=0.5, with_bias=False)
-    oc.check_gemm(emu_lib, abi.BF16, m=260, n=250 // 8 * 8, k=448, with_res=True)
+def test_quantize_mx(emu_lib):
+    """MX fp8 quantiser: bytes and E8M0 scale words bit-exact against the torch restatement"""
+    oc.check_quantize_mx(emu_lib, abi.BF16, rows=37, k=256)
+    oc.check_quantize_mx(emu_lib, abi.F16, rows=70, k=128, ld_extra=8, spread=1.0)
+    oc.check_quantize_mx(emu_lib, abi.BF16, rows=3, k=1152, spread=8.0)
 
 
-def test_gemm_256_ring_schedule(emu_lib, monkeypatch):
-    """the four-slot K = 32 ring (counted vmcnt) schedule: 1, 2, 3 and many slices, ragged M / N"""
-    monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
-    monkeypatch.setenv("MTX_GEMM256_SCHED", "ring")
-    oc.check_gemm(emu_lib, abi.BF16, m=300, n=264, k=64, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
-    oc.check_gemm(emu_lib, abi.F16, m=256, n=512, k=192, batch=2, alpha=0.5, with_bias=False)
-    oc.check_gemm(emu_lib, abi.BF16, m=260, n=250 // 8 * 8, k=448, with_res=True)
+def test_gemm_fp8_tile_kernel(emu_lib):
+    """fp8 (MX e4m3) 256-tile kernel: ragged M / N, 1, 2 and several K tiles, fused epilogue, stream-K tail (3 simulated CUs)"""
+    f = abi.GEMM_FORCE_TILE256
+    oc.check_gemm_f8(emu_lib, abi.BF16, m=300, n=264, k=128, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f)
+    oc.check_gemm_f8(emu_lib, abi.F16, m=256, n=512, k=256, with_bias=False, flags=f, spread=1.5)
+    oc.check_gemm_f8(emu_lib, abi.BF16, m=260, n=248, k=640, with_res=True, flags=f)
+    oc.check_gemm_f8(emu_lib, abi.BF16, m=1024, n=1024, k=512, with_gate=True, flags=f)      # 16 tiles on 3 CUs: one left over -> tail + merge
+
+
+def test_swiglu(emu_lib):
+    oc.check_swiglu(emu_lib, abi.BF16, rows=37, hid=72)
+    oc.check_swiglu(emu_lib, abi.F16, rows=5, hid=384)
 
 
 def test_flux_prep_kernels(emu_lib):
@@ -153,12 +158,12 @@ def test_flux_prep_kernels(emu_lib):
     oc.check_softmax_transpose(emu_lib, abi.F16, rows=70, cols=136)
 
 
-def test_gemm_stream_k_tail(emu_lib, monkeypatch):
+def test_gemm_stream_k_tail(emu_lib):
     """tiles % CUs != 0 (the simulator reports 3 CUs): the left-over tiles go through the stream-K tail + merge kernels"""
-    monkeypatch.setenv("MTX_GEMM256_MIN_TILES", "1")
+    f = abi.GEMM_FORCE_TILE256
     # 2048 x 1024 -> 8 x 4 = 32 tiles, 32 % 3 = 2 left over, K = 512 -> 8 iterations per tile dealt to 3 units
-    oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True)
-    oc.check_gemm(emu_lib, abi.F16, m=2048, n=1032, k=576, with_bias=False)       # 40 tiles: one left over, ragged N
+    oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f)
+    oc.check_gemm(emu_lib, abi.F16, m=2048, n=1032, k=576, with_bias=False, flags=f)       # 40 tiles: one left over, ragged N
 
 
 def test_gemm_stream_k_whole_problem(emu_lib):
