@@ -357,6 +357,8 @@ class FluxVAEHip:
                     x = self._conv(pb, x, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad_mode=1)
             x = self._mid(pb, x, "encoder.mid_block")
             x = self._conv(pb, self._gn(pb, x, "encoder.conv_norm_out"), "encoder.conv_out")
+            if self.cfg.get("quant_conv"):                       # AutoencoderKLFlux2: 1x1 conv over the moments
+                x = self._conv(pb, x, "quant_conv")
             plan = pb.build()
             plan.src, plan.moments = src, x
             self._plans[key] = plan
@@ -367,8 +369,8 @@ class FluxVAEHip:
         if key not in self._plans:
             rc = list(reversed(self.cfg["ch"]))
             pb = PlanBuilder(self.lib, self.device, self.dtype)
-            z = pb.act(1, h8, w8, 16)
-            x = self._conv(pb, z, "decoder.conv_in")
+            z = pb.act(1, h8, w8, self.cfg.get("latent", 16))
+            x = self._conv(pb, self._conv(pb, z, "post_quant_conv"), "decoder.conv_in") if self.cfg.get("quant_conv") else self._conv(pb, z, "decoder.conv_in")
             x = self._mid(pb, x, "decoder.mid_block")
             for i, c in enumerate(rc):
                 for j in range(3):
@@ -538,6 +540,8 @@ def synthetic_provider(shapes: dict, device, seed: int, broadcast: bool = False)
         if len(shp) >= 2:
             fan = int(np.prod(shp[1:]))
             t = torch.randn(shp, device=device, generator=gen, dtype=torch.float32).mul_(1.0 / math.sqrt(fan)).to(torch.bfloat16)
+        elif name.endswith("running_var"):
+            t = 0.5 + 1.5 * torch.rand(shp, device=device, generator=gen)
         elif "norm" in name and name.endswith("weight"):
             t = 1.0 + 0.1 * torch.randn(shp, device=device, generator=gen)
         else:

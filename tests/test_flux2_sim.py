@@ -1,0 +1,24 @@
+"""CPU tier: the FLUX.2-Klein graphs (core/ml/flux2.py) executed by the kernel simulator on tiny geometry against the fp32 oracle."""
+import flux2_checks as fc
+
+
+def test_flux2_dit_step(emu_lib):
+    fc.check_dit_step(emu_lib, "cpu")
+
+
+def test_flux2_dit_step_reference_of_other_size(emu_lib):
+    """reference-image tokens on their own grid (the pipeline caps the conditioning image at 1 MP)"""
+    fc.check_dit_step(emu_lib, "cpu", h2=4, w2=5, rh2=3, rw2=4, t_txt=8)
+
+
+def test_flux2_dit_step_fp8(emu_lib):
+    """every block linear on the MX fp8 kernel: bounded distance to the fp32 oracle"""
+    fc.check_dit_step(emu_lib, "cpu", fp8=True)
+
+
+def test_flux2_vae(emu_lib):
+    fc.check_vae(emu_lib, "cpu", h=32, w=48)
+
+
+def test_flux2_klein_pipeline(emu_lib):
+    fc.check_klein(emu_lib, "cpu", h=32, w=48, t_txt=8, steps=2)
