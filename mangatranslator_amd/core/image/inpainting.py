@@ -303,3 +303,285 @@ class FluxKontextInpainter:
             res = enc(prompt=self.prompt, prompt_2=None, device=self.DEVICE)
             self._prompt_embeds = (res[0], res[1])
         return {"prompt_embeds": self._prompt_embeds[0], "pooled_prompt_embeds": self._prompt_embeds[1]}
+
+
+# =====================================================================================================================
+# FLUX.2-Klein — the reference's DEFAULT inpainter (core/config.py:136-144; class at core/image/inpainting.py:980-1665)
+# =====================================================================================================================
+KLEIN_PROMPT = (
+    "Remove all text, including hand-drawn Japanese sound effects and onomatopoeia. "
+    "Preserve character line art, screentones, panel borders, and background details "
+    "exactly as they appear. Maintain the original contrast and shading, leaving every "
+    "area where text or a sound effect was completely blank."
+)
+
+
+def _grow_to_minimum(lo: int, hi: int, limit: int, minimum: int) -> Tuple[int, int]:
+    """[lo, hi) widened to min(minimum, limit): the missing pixels split half before / rest after, each side clipped to the page,
+    and what clipping took away is recovered by pinning the span to the edge it hit (reference :1131-1163, one axis)"""
+    want = min(minimum, limit)
+    if hi - lo >= want:
+        return lo, hi
+    extra = want - (hi - lo)
+    lo = max(0, lo - extra // 2)
+    hi = min(limit, hi + extra - extra // 2)
+    if hi - lo < want:
+        if lo == 0:
+            hi = min(limit, want)
+        else:
+            lo = max(0, limit - want)
+    return lo, hi
+
+
+class FluxKleinInpainter:
+    """Same constructor, attributes and operator surface as the reference class (core/image/inpainting.py:980-1068, 1070-1103,
+    1350-1665).  `backend` ("sdnq" / "sdcpp") and the sd.cpp quantisation names are accepted and carried into the stage-memo key,
+    but every backend is served by the one MI355X graph pair `ModelManager.load_flux_klein_4b() / _9b()` builds (core/ml/flux2.py)."""
+
+    KLEIN_MAX_STEPS = 12
+    KLEIN_DEFAULT_STEPS = 4
+    KLEIN_GUIDANCE_SCALE = 1.0
+    KLEIN_PROMPT = KLEIN_PROMPT
+    MIN_RESOLUTION = 64
+    MAX_RESOLUTION = 2048
+    RESOLUTION_MULTIPLE = 16
+    MAX_INFERENCE_PIXELS = 4_000_000
+    KLEIN_PADDING_MULTIPLIER = 2.0
+
+    def __init__(self, variant: str = "4b", device: Optional[torch.device] = None, huggingface_token: str = "",
+                 num_inference_steps: int = 4, low_vram: bool = False, luminance_correction: bool = True,
+                 upscale_small_crops: bool = True, backend: str = "sdnq", sdcpp_cache_mode: str = "none",
+                 sdcpp_diffusion_quant: str = "", sdcpp_text_encoder_quant: str = "", verbose: bool = False):
+        self.variant = variant.lower()
+        if self.variant not in ("9b", "4b"):
+            raise ValueError(f"Invalid variant '{variant}'. Must be '9b' or '4b'.")
+        self.backend = backend.lower()
+        if self.backend not in ("sdnq", "sdcpp"):
+            raise ValueError(f"Invalid Klein backend '{backend}'. Must be 'sdnq' or 'sdcpp'.")
+        from ..ml.model_manager import get_model_manager
+        self.num_inference_steps = num_inference_steps
+        self.low_vram = low_vram
+        self.luminance_correction = luminance_correction
+        self.upscale_small_crops = upscale_small_crops
+        self.sdcpp_cache_mode = sdcpp_cache_mode
+        self.sdcpp_diffusion_quant = sdcpp_diffusion_quant
+        self.sdcpp_text_encoder_quant = sdcpp_text_encoder_quant
+        self.verbose = verbose
+        self.manager = get_model_manager()
+        self.DEVICE = device if device is not None else self.manager.device
+        self.DTYPE = self.manager.dtype
+        self.huggingface_token = huggingface_token
+        self.cache = get_cache()
+        self.pipeline = None
+        self._prompt_embeds = None
+
+    # ---- model lifecycle ----------------------------------------------------------------------------------------
+    def load_models(self):
+        if self.pipeline is not None:
+            return
+        if self.huggingface_token:
+            self.manager.set_flux_hf_token(self.huggingface_token)
+        load = self.manager.load_flux_klein_9b if self.variant == "9b" else self.manager.load_flux_klein_4b
+        self.pipeline = load(low_vram=self.low_vram, verbose=self.verbose)
+
+    def unload_models(self):
+        self.pipeline = None
+        self._prompt_embeds = None
+        self.manager.unload_flux_klein_models()
+
+    # ---- geometry (reference :1126-1163, 1258-1313) ----------------------------------------------------------------
+    def _quantize_dimension(self, dim: int) -> int:
+        dim = max(self.MIN_RESOLUTION, min(self.MAX_RESOLUTION, dim))
+        return dim // self.RESOLUTION_MULTIPLE * self.RESOLUTION_MULTIPLE
+
+    def _expand_bounds_to_min_size(self, x1, y1, x2, y2, img_w, img_h):
+        x1, x2 = _grow_to_minimum(x1, x2, img_w, self.MIN_RESOLUTION)
+        y1, y2 = _grow_to_minimum(y1, y2, img_h, self.MIN_RESOLUTION)
+        return x1, y1, x2, y2
+
+    def _inference_size(self, w: int, h: int) -> Tuple[int, int]:
+        """size the crop is diffused at: ~1 MP when small crops are scaled up (the default), else capped at 4 MP; both sides
+        multiples of 16 within [64, 2048], shaved 16 px at a time (wider side first) while the product still exceeds 4 MP"""
+        pixels = w * h
+        if pixels > 0 and self.upscale_small_crops:
+            scale = math.sqrt(1_048_576 / pixels)
+        elif pixels > self.MAX_INFERENCE_PIXELS:
+            scale = math.sqrt(self.MAX_INFERENCE_PIXELS / pixels)
+        else:
+            scale = 1.0
+        nw, nh = self._quantize_dimension(int(w * scale)), self._quantize_dimension(int(h * scale))
+        while nw * nh > self.MAX_INFERENCE_PIXELS:
+            if nw >= nh and nw > self.MIN_RESOLUTION:
+                nw -= self.RESOLUTION_MULTIPLE
+            elif nh > self.MIN_RESOLUTION:
+                nh -= self.RESOLUTION_MULTIPLE
+            else:
+                break
+        return nw, nh
+
+    def _prepare_image_for_inference(self, image_pil: Image.Image, verbose: bool = False):
+        ow, oh = image_pil.size
+        nw, nh = self._inference_size(ow, oh)
+        if (nw, nh) != (ow, oh):
+            log_message(f"  - Scaling {ow}x{oh} -> {nw}x{nh}", verbose=verbose)
+            image_pil = image_pil.resize((nw, nh), Image.Resampling.LANCZOS)
+        return image_pil, ow, oh
+
+    def region_for_mask(self, mask: np.ndarray):
+        """(x, y, w, h, padding, blur) of the crop Klein works on: mask bbox + doubled context padding, at least 64 px a side,
+        sides floored to multiples of 16 and the crop slid back inside the page (reference :1390-1421)"""
+        img_h, img_w = mask.shape
+        rows, cols = np.flatnonzero(mask.any(axis=1)), np.flatnonzero(mask.any(axis=0))
+        x_min, x_max, y_min, y_max = int(cols[0]), int(cols[-1]), int(rows[0]), int(rows[-1])
+        side = max(x_max - x_min, y_max - y_min)
+        padding = int(min(int(side * CONTEXT_PADDING_RATIO), MAX_CONTEXT_PADDING) * self.KLEIN_PADDING_MULTIPLIER)
+        blur = max(MIN_BLUR_RADIUS, min(int(side * BLUR_SCALE_FACTOR), MAX_BLUR_RADIUS))
+        x1, y1 = max(0, x_min - padding), max(0, y_min - padding)
+        x2, y2 = min(img_w, x_max + 1 + padding), min(img_h, y_max + 1 + padding)
+        x1, y1, x2, y2 = self._expand_bounds_to_min_size(x1, y1, x2, y2, img_w, img_h)
+        w, h = min(self._quantize_dimension(x2 - x1), img_w), min(self._quantize_dimension(y2 - y1), img_h)
+        if x1 + w > img_w:
+            x1 = max(0, img_w - w)
+        if y1 + h > img_h:
+            y1 = max(0, img_h - h)
+        return x1, y1, w, h, padding, blur
+
+    @staticmethod
+    def _crop_alpha(mask_crop: np.ndarray, blur: int) -> np.ndarray:
+        """composite weight inside the crop: 1 on the mask, linear ramp to 0 over `blur` px of Euclidean distance (measured
+        INSIDE the crop, unlike the Kontext class)"""
+        if blur <= 0:
+            return mask_crop.astype(np.float32)
+        d_out = distance_transform_edt(~mask_crop)
+        alpha = np.zeros(mask_crop.shape, np.float32)
+        alpha[mask_crop] = 1.0
+        ramp = np.clip(1.0 - d_out / blur, 0.0, 1.0)
+        outside = d_out > 0
+        alpha[outside] = ramp[outside]
+        return alpha
+
+    # ---- luminance match (reference :1165-1256) ------------------------------------------------------------------------
+    def _compute_luminance_stats(self, image_np: np.ndarray, mask_np: np.ndarray) -> Tuple[float, float]:
+        if not np.any(mask_np):
+            return 127.5, 30.0
+        from .color import rgb_to_lab_u8
+        l_values = rgb_to_lab_u8(image_np)[:, :, 0][mask_np].astype(np.float32)
+        return float(np.mean(l_values)), float(np.std(l_values)) + 1e-6
+
+    def _match_luminance(self, generated_pil: Image.Image, original_crop_pil: Image.Image, mask_crop_np: np.ndarray,
+                         verbose: bool = False) -> Image.Image:
+        """affine remap of the patch's L channel (mean / std of the crop's unmasked pixels as reference, gain clamped to
+        [0.5, 2]) applied on the masked pixels only, plus a shift of a / b when their context means drifted by more than 1"""
+        from .color import lab_to_rgb_u8, rgb_to_lab_u8
+        context = ~mask_crop_np
+        if not np.any(context) or not np.any(mask_crop_np):
+            return generated_pil
+        original = np.asarray(original_crop_pil)
+        generated = np.asarray(generated_pil).copy()
+        o_mean, o_std = self._compute_luminance_stats(original, context)
+        g_mean, g_std = self._compute_luminance_stats(generated, context)
+        if abs(o_mean - g_mean) < 1.3 and abs(o_std - g_std) < 2.0:
+            return generated_pil
+        gain = max(0.5, min(2.0, o_std / g_std))
+        log_message(f"  - Luminance correction: mean {g_mean:.1f}->{o_mean:.1f}, std {g_std:.1f}->{o_std:.1f} (scale={gain:.2f})", verbose=verbose)
+        lab = rgb_to_lab_u8(generated).astype(np.float32)
+        lab[:, :, 0][mask_crop_np] = np.clip((lab[:, :, 0][mask_crop_np] - g_mean) * gain + o_mean, 0, 255)
+        o_lab = rgb_to_lab_u8(original).astype(np.float32)
+        for ch in (1, 2):
+            shift = float(np.mean(o_lab[:, :, ch][context])) - float(np.mean(lab[:, :, ch][context]))
+            if abs(shift) > 1.0:
+                lab[:, :, ch][mask_crop_np] = np.clip(lab[:, :, ch][mask_crop_np] + shift, 0, 255)
+        return Image.fromarray(lab_to_rgb_u8(lab.astype(np.uint8)))
+
+    # ---- the operator ---------------------------------------------------------------------------------------------
+    def inpaint_mask(self, image_pil: Image.Image, mask_np: np.ndarray, seed: int = 1, verbose: bool = False,
+                     strict_mask_clipping: bool = False, composite_clip_bbox: Optional[Tuple[int, int, int, int]] = None,
+                     ocr_params: Optional[Dict] = None) -> Image.Image:
+        mask = np.asarray(mask_np)
+        if mask.dtype != bool:
+            mask = mask.astype(bool)
+        if not mask.any():
+            return image_pil
+        log_message(f"  - Flux.2 Klein {self.variant.upper()} inpainting...", verbose=verbose)
+        img_h, img_w = mask.shape
+        x, y, w, h, padding, blur = self.region_for_mask(mask)
+        if w <= 0 or h <= 0:
+            log_message(f"  - Region has invalid size ({w}x{h}), skipping", verbose=verbose)
+            return image_pil
+        log_message(f"  - Processing region at ({x}, {y}) size {w}x{h}", verbose=verbose)
+        crop = image_pil.crop((x, y, x + w, y + h))
+        mask_crop = mask[y:y + h, x:x + w]
+        key = self._memo_key(crop, mask_crop, seed, (x, y, w, h), padding, blur, ocr_params, strict_mask_clipping, composite_clip_bbox)
+        patch = self.cache.get_inpainted_image(key) if key is not None else None
+        if patch is not None:
+            log_message("  - Using cached inpainting patch", verbose=verbose)
+        alpha = self._crop_alpha(mask_crop, blur)
+        if strict_mask_clipping:
+            alpha = alpha * mask_crop.astype(np.float32)
+        if composite_clip_bbox is not None:
+            cx1, cy1, cx2, cy2 = composite_clip_bbox
+            cx1, cx2 = max(0, min(img_w, cx1)), max(0, min(img_w, cx2))
+            cy1, cy2 = max(0, min(img_h, cy1)), max(0, min(img_h, cy2))
+            ax0, ax1, ay0, ay1 = max(0, cx1 - x), min(w, cx2 - x), max(0, cy1 - y), min(h, cy2 - y)
+            keep = np.zeros_like(alpha)
+            if ax1 > ax0 and ay1 > ay0:
+                keep[ay0:ay1, ax0:ax1] = alpha[ay0:ay1, ax0:ax1]
+            alpha = keep
+        generated_now = patch is None
+        if patch is None:
+            scaled, _, _ = self._prepare_image_for_inference(crop, verbose=verbose)
+            inf_w, inf_h = scaled.size
+            if scaled.mode == "RGBA":
+                scaled = scaled.convert("RGB")
+            log_message("  - Running inference...", verbose=verbose)
+            with self.manager.flux_inference_lock:
+                self.load_models()
+                if self.pipeline is None:
+                    log_message(f"Warning: Flux Klein {self.variant.upper()} pipeline unavailable.", always_print=True)
+                    return image_pil
+                with torch.inference_mode():
+                    gen = torch.Generator(device="cpu").manual_seed(seed)
+                    out = self.pipeline(**self._prompt_kwargs(), image=scaled, height=inf_h, width=inf_w,
+                                        guidance_scale=self.KLEIN_GUIDANCE_SCALE, num_inference_steps=self.num_inference_steps,
+                                        generator=gen)
+                    patch = out.images[0]
+            if (inf_w, inf_h) != (w, h):
+                patch = patch.resize((w, h), Image.Resampling.LANCZOS)
+            if self.luminance_correction:
+                patch = self._match_luminance(patch, crop, mask_crop, verbose=verbose)
+        result = Image.fromarray(composite_u8(np.asarray(image_pil), np.asarray(patch), alpha, x, y))
+        if generated_now and key is not None:
+            self.cache.set_inpainted_image(key, patch)
+        return result
+
+    def _memo_key(self, crop, mask_crop, seed, bbox, padding, blur, ocr_params, strict_mask_clipping, composite_clip_bbox):
+        """stage-memo key of the crop-sized patch (reference :1433-1489); None when seed == -1"""
+        if not self.cache.should_use_inpaint_cache(seed):
+            return None
+        params = {"bbox": tuple(int(v) for v in bbox), "padding": padding, "blur": blur, "variant": self.variant,
+                  "lum_corr": self.luminance_correction, "upscale_small": self.upscale_small_crops,
+                  "max_pixels": self.MAX_INFERENCE_PIXELS, "min_size": (self.MIN_RESOLUTION, self.MIN_RESOLUTION), "backend": self.backend}
+        if self.backend == "sdcpp":
+            params.update(sdcpp_cache=self.sdcpp_cache_mode, sdcpp_diffusion_quant=self.sdcpp_diffusion_quant,
+                          sdcpp_text_encoder_quant=self.sdcpp_text_encoder_quant)
+        if strict_mask_clipping:
+            params["strict_clip"] = True
+        if composite_clip_bbox is not None:
+            params["clip_bbox"] = tuple(composite_clip_bbox)
+        if ocr_params:
+            params.update(ocr_params)
+        signature = mask_crop
+        if mask_crop.size > 0:
+            size = (min(64, max(4, mask_crop.shape[0])), min(64, max(4, mask_crop.shape[1])))
+            small = torch.nn.functional.interpolate(torch.from_numpy(mask_crop.astype(np.float32))[None, None], size=size, mode="bilinear", align_corners=False)
+            signature = (small > 0.5).numpy().astype(np.uint8)[0, 0]
+        return self.cache.get_inpaint_cache_key(crop, signature, seed, self.num_inference_steps, 0.0, self.KLEIN_GUIDANCE_SCALE,
+                                                self.KLEIN_PROMPT, params)
+
+    def _prompt_kwargs(self) -> dict:
+        enc = getattr(self.pipeline, "encode_prompt", None)
+        if enc is None:
+            return {}
+        if self._prompt_embeds is None:
+            self._prompt_embeds = enc(prompt=self.KLEIN_PROMPT, device=self.DEVICE)[0]
+        return {"prompt_embeds": self._prompt_embeds}

@@ -37,28 +37,61 @@ class ModelType(Enum):
     YOLO_OSBTEXT = "yolo_osbtext"
     YOLO_PANEL = "yolo_panel"
     FLUX_KONTEXT_SDNQ_PIPELINE = "flux_kontext_sdnq_pipeline"
+    FLUX_KLEIN_9B_PIPELINE = "flux_klein_9b_pipeline"
+    FLUX_KLEIN_4B_PIPELINE = "flux_klein_4b_pipeline"
+
+
+def _dist_on() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def broadcast_status(error: Optional[str], src: int = 0) -> None:
+    """Every rank learns whether rank `src` succeeded BEFORE anyone enters a data collective: rank `src` passes its error string
+    (None = fine), the others pass None; a failure raises the same ModelError on every rank (so the reference's degrade-on-ModelError
+    paths run everywhere instead of the peers hanging in a broadcast rank 0 never joins)."""
+    if not _dist_on():
+        if error:
+            raise ModelError(error)
+        return
+    import torch.distributed as dist
+    box = [error if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    if box[0]:
+        raise ModelError(box[0])
 
 
 def broadcast_state_dict(sd: Optional[dict], template: Optional[dict] = None, src: int = 0) -> dict:
-    """One flat collective for a whole checkpoint.  Rank `src` passes `sd`; the others pass a
-    `template` (name -> shape) or the same-shaped dict.  No-op without an initialised process group."""
+    """One flat collective per dtype for a whole checkpoint.  Rank `src` passes `sd`; the others pass a `template`
+    (name -> (shape, dtype) or same-shaped tensors) or the same-shaped dict.  Integer buffers travel as integers, zero-element tensors
+    take no room.  No-op without an initialised process group."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _dist_on():
         return sd
     rank = dist.get_rank()
-    shapes = {k: tuple(v.shape) for k, v in (sd if rank == src else (template or sd)).items()}
-    keys = sorted(shapes)
-    sizes = [max(1, int(torch.tensor(shapes[k]).prod().item())) if len(shapes[k]) else 1 for k in keys]
+    ref = sd if rank == src else (template or sd)
+    meta = {}
+    for k, v in ref.items():
+        if isinstance(v, torch.Tensor):
+            meta[k] = (tuple(v.shape), v.dtype)
+        else:
+            meta[k] = (tuple(v[0]), v[1])
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-    if rank == src:
-        flat.copy_(torch.cat([sd[k].detach().float().reshape(-1) for k in keys]))
-    dist.broadcast(flat, src=src)
-    flat = flat.cpu()
-    out, off = {}, 0
-    for k, n in zip(keys, sizes):
-        out[k] = flat[off:off + n].view(shapes[k]).clone()
-        off += n
+    out = {}
+    for dt in sorted({d for _, d in meta.values()}, key=str):
+        keys = sorted(k for k, (_, d) in meta.items() if d == dt)
+        sizes = [int(torch.Size(meta[k][0]).numel()) for k in keys]
+        wire = torch.float32 if dt in (torch.float64,) and dev.type == "cuda" else dt
+        flat = torch.empty(sum(sizes), dtype=wire, device=dev)
+        if rank == src and flat.numel():
+            flat.copy_(torch.cat([sd[k].detach().reshape(-1).to(wire) for k in keys]))
+        if flat.numel():
+            dist.broadcast(flat, src=src)
+        flat = flat.cpu()
+        off = 0
+        for k, n in zip(keys, sizes):
+            out[k] = flat[off:off + n].view(meta[k][0]).to(dt).clone()
+            off += n
     return out
 
 
@@ -141,6 +174,8 @@ class ModelManager:
                 ModelType.YOLO_OSBTEXT: model_dir / "yolo" / "animetext_yolov12x.safetensors",
                 ModelType.YOLO_PANEL: model_dir / "yolo" / "manga109_panel_yolo11l.safetensors",
                 ModelType.FLUX_KONTEXT_SDNQ_PIPELINE: model_dir / "flux" / "kontext",
+                ModelType.FLUX_KLEIN_4B_PIPELINE: model_dir / "flux" / "klein-4b",
+                ModelType.FLUX_KLEIN_9B_PIPELINE: model_dir / "flux" / "klein-9b",
             }
             self.hf_token = None
             self.flux_hf_token = None
@@ -183,22 +218,40 @@ class ModelManager:
     def unload_flux_kontext_sdnq_models(self, verbose: bool = False):
         self.unload_model(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE, verbose=verbose)
 
+    def unload_flux_klein_models(self, verbose: bool = False):
+        """reference :1462-1480"""
+        self.unload_model(ModelType.FLUX_KLEIN_9B_PIPELINE, force_gc=False, verbose=verbose)
+        self.unload_model(ModelType.FLUX_KLEIN_4B_PIPELINE, force_gc=True, verbose=verbose)
+
     # ---- loaders -----------------------------------------------------------------------------------
     def _read_safetensors(self, path: Path) -> dict:
+        """rank 0 reads, then (with several ranks) a status broadcast, a shape / dtype broadcast and one flat broadcast per dtype;
+        a missing or unreadable file raises ModelError on EVERY rank"""
         import torch.distributed as dist
-        rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
-        if rank0 and not path.exists():
-            raise ModelError(f"checkpoint not found: {path} (stage it under ./models; this build never downloads)")
-        sd = None
+        rank0 = not _dist_on() or dist.get_rank() == 0
+        sd, error = None, None
         if rank0:
-            from safetensors import safe_open
-            with safe_open(str(path), framework="pt", device="cpu") as f:
-                sd = {k: f.get_tensor(k) for k in f.keys()}
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            meta = [{k: tuple(v.shape) for k, v in sd.items()}] if rank0 else [None]
+            if not path.exists():
+                error = f"checkpoint not found: {path} (stage it under ./models; this build never downloads)"
+            else:
+                try:
+                    from safetensors import safe_open
+                    with safe_open(str(path), framework="pt", device="cpu") as f:
+                        sd = {k: f.get_tensor(k) for k in f.keys()}
+                except Exception as e:                      # truncated / foreign file
+                    error = f"cannot read {path}: {e}"
+        broadcast_status(error)
+        if _dist_on():
+            meta = [{k: (tuple(v.shape), v.dtype) for k, v in sd.items()}] if rank0 else [None]
             dist.broadcast_object_list(meta, src=0)
-            sd = broadcast_state_dict(sd, template={k: torch.empty(s) for k, s in meta[0].items()})
+            sd = broadcast_state_dict(sd, template=meta[0])
         return sd
+
+    def _staged(self, path: Path, what: str) -> None:
+        """filesystem check done by rank 0 only, verdict shared: every rank raises or none does"""
+        import torch.distributed as dist
+        rank0 = not _dist_on() or dist.get_rank() == 0
+        broadcast_status(f"{what} not found: {path} (stage it under ./models; this build never downloads)" if rank0 and not path.exists() else None)
 
     def _load_rcan(self, model_type: ModelType, verbose: bool):
         with self._lock:
@@ -282,8 +335,7 @@ class ModelManager:
                 return self.models[mt]
             from .rtdetr import RTDetrHip
             root = self.model_paths[mt]
-            if not (root / "config.json").exists():
-                raise ModelError(f"RT-DETR config not found: {root / 'config.json'} (stage it under ./models; this build never downloads)")
+            self._staged(root / "config.json", "RT-DETR config")
             try:
                 from transformers import RTDetrV2Config
                 config = RTDetrV2Config.from_pretrained(str(root))
@@ -305,8 +357,7 @@ class ModelManager:
             from .sam2 import Sam2Hip
             root = self.model_paths[ModelType.SAM2]
             weights, cfg = root / "model.safetensors", root / "config.json"
-            if not cfg.exists():
-                raise ModelError(f"SAM-2.1 config not found: {cfg}")
+            self._staged(cfg, "SAM-2.1 config")
             from transformers import Sam2Config
             config = Sam2Config.from_pretrained(str(root))
             sd = self._read_safetensors(weights)
@@ -357,38 +408,118 @@ class ModelManager:
             return pipe
 
 
+    # FLUX.2-Klein (the reference's default inpainter) ------------------------------------------------------------
+    flux_klein_fp8 = True      # block linears on the MX fp8 matrix path (BASELINE.json config 5); False = all bf16
+
+    def _load_flux_klein(self, model_type: ModelType, variant: str, low_vram: bool = False, verbose: bool = False):
+        """FLUX.2-Klein as libmtx_hip graphs behind the diffusers call shape (reference :1254-1337, which loads Disty0's SDNQ 4-bit
+        pack of the same network and turns on its quantised matmul — this build's low-precision route is OCP fp8 on the CDNA4 scaled
+        matrix instructions instead, quantised here from bf16 weights).
+
+        Expected under models/flux/klein-{4b,9b} (diffusers layout, bf16): transformer/*.safetensors (+ config.json),
+        vae/*.safetensors (+ config.json), and prompt_embeds.safetensors holding `prompt_embeds [512, joint_dim]` of
+        FluxKleinInpainter.KLEIN_PROMPT (exported once with the Qwen3 text encoder, which is not on the per-page path — the reference
+        caches the same tensor, inpainting.py:1110-1124).  Returns None when nothing is staged: the inpainter then skips, like the
+        reference's "pipeline unavailable" branch."""
+        with self._lock:
+            if self.is_loaded(model_type):
+                return self.models[model_type]
+            root = self.model_paths[model_type]
+            import torch.distributed as dist
+            rank0 = not _dist_on() or dist.get_rank() == 0
+            staged = [bool(rank0 and (root / "transformer").is_dir())]
+            if _dist_on():
+                dist.broadcast_object_list(staged, src=0)
+            if not staged[0]:
+                return None
+            log_message(f"Loading Flux.2 Klein {variant.upper()} model...", verbose=verbose)
+            import json
+            from . import flux2
+            dcfg = dict(flux2.KLEIN_9B_DIT_CFG if variant == "9b" else flux2.KLEIN_4B_DIT_CFG)
+            vcfg = dict(flux2.KLEIN_VAE_CFG)
+            cfgs = [None, None]
+            if rank0:
+                for i, sub in enumerate(("transformer", "vae")):
+                    f = root / sub / "config.json"
+                    cfgs[i] = json.loads(f.read_text()) if f.exists() else None
+            if _dist_on():
+                dist.broadcast_object_list(cfgs, src=0)
+            if cfgs[0]:                                           # diffusers Flux2Transformer2DModel config
+                c = cfgs[0]
+                dcfg.update(d=c["num_attention_heads"] * c["attention_head_dim"], heads=c["num_attention_heads"], layers=c["num_layers"],
+                            single_layers=c["num_single_layers"], in_channels=c["in_channels"], joint_dim=c["joint_attention_dim"],
+                            mlp_ratio=c.get("mlp_ratio", 3.0), axes_dim=tuple(c["axes_dims_rope"]), rope_theta=c.get("rope_theta", 2000.0),
+                            guidance_embeds=c.get("guidance_embeds", False))
+            if cfgs[1]:                                           # diffusers AutoencoderKLFlux2 config
+                c = cfgs[1]
+                vcfg.update(ch=tuple(c["block_out_channels"]), groups=c["norm_num_groups"], latent=c["latent_channels"],
+                            bn_eps=c.get("batch_norm_eps", 1e-4))
+            try:
+                dit = flux2.Flux2DiTHip(_ShardedProvider(root / "transformer", flux2.dit_param_shapes(dcfg), self.device), dcfg, self.device,
+                                        fp8=self.flux_klein_fp8)
+                vae = flux2.Flux2VAEHip(_ShardedProvider(root / "vae", flux2.vae_param_shapes(vcfg), self.device, keep_dtype=("bn.",)), vcfg, self.device)
+            except ModelError:
+                raise
+            except Exception as e:
+                raise ModelError(f"Failed to load Flux.2 Klein {variant.upper()} model: {e}") from e
+            pipe = flux2.Flux2KleinHip(dit, vae)
+            emb = root / "prompt_embeds.safetensors"
+            have = [bool(rank0 and emb.exists())]
+            if _dist_on():
+                dist.broadcast_object_list(have, src=0)
+            if have[0]:
+                pipe.set_prompt_embeds(self._read_safetensors(emb)["prompt_embeds"])
+            self.models[model_type] = pipe
+            log_message(f"Flux.2 Klein {variant.upper()} model loaded successfully (libmtx_hip graphs, {'fp8 + ' if self.flux_klein_fp8 else ''}bf16).", verbose=verbose)
+            return pipe
+
+    def load_flux_klein_9b(self, low_vram: bool = False, verbose: bool = False):
+        return self._load_flux_klein(ModelType.FLUX_KLEIN_9B_PIPELINE, "9b", low_vram=low_vram, verbose=verbose)
+
+    def load_flux_klein_4b(self, low_vram: bool = False, verbose: bool = False):
+        return self._load_flux_klein(ModelType.FLUX_KLEIN_4B_PIPELINE, "4b", low_vram=low_vram, verbose=verbose)
+
+
 class _ShardedProvider:
     """name -> tensor over the *.safetensors shards of one diffusers sub-folder.  Rank 0 reads; with more
-    than one rank every tensor is handed to the others by an RCCL broadcast (start-up only)."""
+    than one rank every tensor is handed to the others by an RCCL broadcast (start-up only).  What rank 0 finds wrong (no shards,
+    missing or mis-shaped parameters) is shared through `broadcast_status` first, so every rank raises the same ModelError."""
 
-    def __init__(self, folder: Path, shapes: dict, device):
+    def __init__(self, folder: Path, shapes: dict, device, keep_dtype=()):
         import torch.distributed as dist
-        self.shapes, self.device = shapes, device
-        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.shapes, self.device, self.keep_dtype = shapes, device, tuple(keep_dtype)
+        self.multi = _dist_on()
         self.rank0 = not self.multi or dist.get_rank() == 0
         self.where = {}
+        error = None
         if self.rank0:
             from safetensors import safe_open
             files = sorted(folder.glob("*.safetensors"))
             if not files:
-                raise ModelError(f"no safetensors shards under {folder}")
-            self.handles = [safe_open(str(f), framework="pt", device="cpu") for f in files]
-            for h in self.handles:
-                for k in h.keys():
-                    self.where[k] = h
-            missing = [k for k in shapes if k not in self.where]
-            if missing:
-                raise ModelError(f"{folder}: {len(missing)} parameters missing (first: {missing[0]}); a bf16 diffusers "
+                error = f"no safetensors shards under {folder}"
+            else:
+                try:
+                    self.handles = [safe_open(str(f), framework="pt", device="cpu") for f in files]
+                    for h in self.handles:
+                        for k in h.keys():
+                            self.where[k] = h
+                    missing = [k for k in shapes if k not in self.where]
+                    bad = [k for k in shapes if k in self.where and tuple(self.where[k].get_slice(k).get_shape()) != tuple(shapes[k])]
+                    if missing:
+                        error = (f"{folder}: {len(missing)} parameters missing (first: {missing[0]}); a bf16 diffusers "
                                  "checkpoint is expected — SDNQ / nunchaku / GGUF packed weights are not read")
+                    elif bad:
+                        error = f"{bad[0]}: shape {tuple(self.where[bad[0]].get_slice(bad[0]).get_shape())} != expected {tuple(shapes[bad[0]])}"
+                except Exception as e:
+                    error = f"cannot read the shards under {folder}: {e}"
+        broadcast_status(error)
 
     def __call__(self, name: str) -> torch.Tensor:
+        dt = torch.float32 if name.startswith(self.keep_dtype) and self.keep_dtype else torch.bfloat16
         if self.rank0:
-            t = self.where[name].get_tensor(name)
-            if tuple(t.shape) != tuple(self.shapes[name]):
-                raise ModelError(f"{name}: shape {tuple(t.shape)} != expected {tuple(self.shapes[name])}")
-            t = t.to(self.device, torch.bfloat16)
+            t = self.where[name].get_tensor(name).to(self.device, dt)
         else:
-            t = torch.empty(self.shapes[name], dtype=torch.bfloat16, device=self.device)
+            t = torch.empty(self.shapes[name], dtype=dt, device=self.device)
         if self.multi:
             import torch.distributed as dist
             dist.broadcast(t, src=0)

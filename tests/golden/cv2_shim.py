@@ -10,6 +10,7 @@ from oracle import cleaning_ref as cr
 
 MORPH_ELLIPSE, THRESH_BINARY, THRESH_OTSU, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE, FILLED, DIST_L2 = 2, 0, 8, 0, 2, -1, 2
 COLOR_BGR2GRAY, COLOR_BGRA2GRAY, COLOR_RGB2BGR, COLOR_BGR2RGB, COLOR_BGR2HSV, COLOR_RGBA2BGRA, COLOR_BGRA2RGBA = 6, 10, 4, 4, 40, 5, 5
+COLOR_RGB2LAB, COLOR_LAB2RGB = 45, 57
 
 
 def getStructuringElement(shape, ksize):
@@ -79,6 +80,12 @@ def boundingRect(cnt):
 
 def cvtColor(a, code):
     a = np.asarray(a)
+    if code == COLOR_RGB2LAB:                       # FluxKleinInpainter luminance match (reference inpainting.py:1183, 1228, 1236)
+        from oracle import cv2_color_ref
+        return cv2_color_ref.rgb_to_lab_u8(a)
+    if code == COLOR_LAB2RGB:
+        from oracle import cv2_color_ref
+        return cv2_color_ref.lab_to_rgb_u8(a)
     if code in (COLOR_BGR2GRAY, COLOR_BGRA2GRAY):
         return cr.bgr_to_gray(a[..., :3])
     if code == COLOR_BGR2HSV:                       # only ever asked for one sampled pixel: S is what the caller reads
