@@ -517,7 +517,7 @@ class _ShardedProvider:
     def __call__(self, name: str) -> torch.Tensor:
         dt = torch.float32 if name.startswith(self.keep_dtype) and self.keep_dtype else torch.bfloat16
         if self.rank0:
-            t = self.where[name].get_tensor(name).to(self.device, dt)
+            t = self.where[name].get_tensor(name).to(self.device, dt, copy=True)       # never a view of the shard's mapping (it goes away with the handle)
         else:
             t = torch.empty(self.shapes[name], dtype=dt, device=self.device)
         if self.multi:

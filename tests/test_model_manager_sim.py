@@ -85,3 +85,46 @@ def test_load_flux_kontext_and_inpaint(manager):
     assert (a[far] == b[far]).all()           # pixels far from the mask are untouched by the composite
     manager.unload_flux_kontext_sdnq_models()
     assert not manager.is_loaded(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_load_flux_klein_and_inpaint(manager, fp8):
+    """the reference's default inpainter end to end on a staged tiny checkpoint: loader (config.json geometry, sharded weights, BatchNorm
+    statistics kept in fp32, cached prompt embeddings) -> FluxKleinInpainter.inpaint_mask -> composited page"""
+    import flux2_checks as f2c
+    from mangatranslator_amd.core.image.inpainting import FluxKleinInpainter
+    from mangatranslator_amd.core.ml.model_manager import ModelType
+    assert manager.load_flux_klein_4b() is None           # nothing staged
+    t, v = f2c.models(seed=4)
+    root = manager.model_paths[ModelType.FLUX_KLEIN_4B_PIPELINE]
+    (root / "transformer").mkdir(parents=True); (root / "vae").mkdir()
+    tsd = {k: x.to(torch.bfloat16).contiguous() for k, x in t.state_dict().items()}
+    keys = sorted(tsd)
+    save_file({k: tsd[k] for k in keys[::2]}, str(root / "transformer" / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: tsd[k] for k in keys[1::2]}, str(root / "transformer" / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    vsd = {k: x.contiguous() for k, x in v.state_dict().items() if not k.endswith("num_batches_tracked")}
+    save_file(vsd, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+    c = t.cfg
+    (root / "transformer" / "config.json").write_text(json.dumps(dict(
+        num_attention_heads=c["heads"], attention_head_dim=c["d"] // c["heads"], num_layers=c["layers"], num_single_layers=c["single_layers"],
+        in_channels=c["in_channels"], joint_attention_dim=c["joint_dim"], mlp_ratio=c["mlp_ratio"], axes_dims_rope=list(c["axes_dim"]),
+        rope_theta=c["rope_theta"], guidance_embeds=False)))
+    (root / "vae" / "config.json").write_text(json.dumps(dict(block_out_channels=list(v.cfg["ch"]), norm_num_groups=v.cfg["groups"],
+                                                            latent_channels=v.cfg["latent"], batch_norm_eps=v.cfg["bn_eps"])))
+    save_file({"prompt_embeds": torch.randn(8, c["joint_dim"], generator=torch.Generator().manual_seed(9))}, str(root / "prompt_embeds.safetensors"))
+    manager.flux_klein_fp8 = fp8
+    pipe = manager.load_flux_klein_4b()
+    assert pipe is not None and manager.load_flux_klein_4b() is pipe
+    assert bool(pipe.transformer.fp8) == fp8 and (pipe.transformer.blocks[0]["qkv"].q is not None) == fp8
+    assert torch.allclose(pipe.vae.bn_mean.cpu(), v.bn.running_mean)
+    inp = FluxKleinInpainter(variant="4b", num_inference_steps=1)
+    inp.upscale_small_crops = False                        # keep the simulator's crop at 64 x 64
+    page = Image.fromarray((np.random.default_rng(0).random((96, 128, 3)) * 255).astype(np.uint8))
+    mask = np.zeros((96, 128), bool); mask[40:50, 50:70] = True
+    out = inp.inpaint_mask(page, mask, seed=1)
+    a, b = np.asarray(page).astype(int), np.asarray(out).astype(int)
+    assert out.size == page.size and (a != b).any() and pipe.calls == 1
+    far = np.ones((96, 128), bool); far[10:90, 10:118] = False
+    assert (a[far] == b[far]).all()
+    inp.unload_models()
+    assert not manager.is_loaded(ModelType.FLUX_KLEIN_4B_PIPELINE)
