@@ -7,4 +7,4 @@ Layout:
           reference's callers (core/pipeline.py, main.py, app.py) find the same names
   utils/  the reference's exception types and logging shim (error contract)
 """
-__version__ = "0.1.0"
+from ._version import __version__, __version_info__  # noqa: F401

@@ -109,8 +109,20 @@ def expand_boxes_with_osb_text(image_cv, primary_boxes: torch.Tensor, model_mana
         return primary_boxes, None
 
 
+def _open_like_imread(image_path) -> Image.Image:
+    """a page opened from its path the way the reference's `cv2.imread(str(image_path))` sees it (reference detection.py:1296-1310):
+    EXIF orientation applied, 8-bit 3-channel (palette / CMYK / 16-bit sources reduced by Pillow's converter)"""
+    from PIL import ImageOps
+    img = Image.open(image_path)
+    try:
+        img = ImageOps.exif_transpose(img)
+    except Exception:
+        pass
+    return img
+
+
 def detect_speech_bubbles(image_path, model_path=None, confidence: float = 0.6, verbose: bool = False, device=None,
-                          seg_model: str = "sam2", conjoined_detection: bool = True, conjoined_confidence: float = 0.35,
+                          seg_model: str = "yolo", conjoined_detection: bool = True, conjoined_confidence: float = 0.35,
                           image_override: Optional[Image.Image] = None, osb_enabled: bool = False,
                           osb_text_verification: bool = False, osb_text_hf_token: str = "",
                           bubble_detector_model: str = "yolo_2") -> Tuple[List[dict], List[List[float]]]:
@@ -124,7 +136,7 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
     detections: List[dict] = []
     text_free_boxes: List[List[float]] = []
     try:
-        image_pil = image_override if image_override is not None else Image.open(image_path)
+        image_pil = image_override if image_override is not None else _open_like_imread(image_path)
         if image_pil.mode != "RGB":
             image_pil = image_pil.convert("RGB")
         rgb = np.asarray(image_pil)
@@ -280,7 +292,7 @@ def detect_panels(image_path, confidence: float = 0.25, device=None, verbose: bo
     model names no such class (reference `detect_panels`, :1817-1915).  Image and loader failures raise ImageProcessingError / ModelError;
     a failure while running the model degrades to `[]`, as there."""
     try:
-        image_pil = image_override if image_override is not None else Image.open(image_path)
+        image_pil = image_override if image_override is not None else _open_like_imread(image_path)
         if image_pil.mode != "RGB":
             image_pil = image_pil.convert("RGB")
         bgr = np.ascontiguousarray(np.asarray(image_pil)[..., ::-1])

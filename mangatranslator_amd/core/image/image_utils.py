@@ -228,3 +228,62 @@ def process_bubble_image_cached(bubble_image_pil: Image.Image, upscale_model, de
     fitted = resize_to_min_side(up, target_min_side, verbose)
     cache.set_upscaled_image(key, fitted, verbose)
     return fitted
+
+
+def calculate_centroid_expansion_box(cleaned_mask: np.ndarray, padding_pixels: float = 4.0, verbose: bool = False):
+    """Largest centred rectangle inside a cleaned bubble that keeps `padding_pixels` clear of the outline — consumed by the reference's
+    text renderer (core/text/text_renderer.py:162), which sits outside the MI355X hot path; restated here (reference
+    core/image/image_utils.py:173-345) so the module's import surface is whole when it is served in place of the reference's.
+
+    Distance to the outline = exact Euclidean transform of the mask with a one-pixel zero frame (page borders count as outline); anchor =
+    centre of mass of the pixels at least `padding_pixels` deep, or the deepest pixel when the centre of mass sits in a neck (less than
+    70 % of the maximum depth); the box is twice the shortest clear run (left / right, up / down) from the anchor, minus one pixel per side.
+    -> ((x, y, w, h), (cx, cy)); raises ImageProcessingError when no such box exists."""
+    from scipy.ndimage import distance_transform_edt
+    if cleaned_mask is None or not np.any(cleaned_mask):
+        raise ImageProcessingError("Invalid or empty mask provided")
+    try:
+        h, w = cleaned_mask.shape
+        framed = np.zeros((h + 2, w + 2), bool)
+        framed[1:-1, 1:-1] = np.asarray(cleaned_mask) != 0
+        depth = distance_transform_edt(framed)[1:-1, 1:-1].astype(np.float32)
+        safe = depth >= padding_pixels
+        if not safe.any():
+            log_message(f"Safe area calculation failed: padding {padding_pixels:.0f}px too large", verbose=verbose, always_print=True)
+            raise ImageProcessingError("Failed to create safe area mask")
+        ys, xs = np.nonzero(safe)
+        cx_f, cy_f = float(xs.sum() / xs.size), float(ys.sum() / ys.size)
+        deepest = float(depth.max())
+        peak_y, peak_x = np.unravel_index(int(np.argmax(depth)), depth.shape)          # first maximum in raster order
+        px, py = max(0, min(int(round(cx_f)), w - 1)), max(0, min(int(round(cy_f)), h - 1))
+        if depth[py, px] < deepest * 0.70:
+            log_message(f"Centroid in constricted region (dist={depth[py, px]:.1f} vs max={deepest:.1f}). Moving anchor to pole of inaccessibility.", verbose=verbose)
+            cx_f, cy_f = float(peak_x), float(peak_y)
+        cx, cy = int(round(cx_f)), int(round(cy_f))
+        if not (0 <= cy < h and 0 <= cx < w and safe[cy, cx]):
+            d = np.sqrt((ys - cy_f) ** 2 + (xs - cx_f) ** 2)
+            k = int(np.argmin(d))
+            cy, cx = int(ys[k]), int(xs[k])
+            cx_f, cy_f = float(cx), float(cy)
+        row, col = safe[cy], safe[:, cx]
+        gaps = np.flatnonzero(~row[:cx]);  left = cx - (int(gaps.max()) if gaps.size else 0)
+        gaps = np.flatnonzero(~row[cx:]);  right = int(gaps.min()) if gaps.size else w - cx
+        gaps = np.flatnonzero(~col[:cy]);  up = cy - (int(gaps.max()) if gaps.size else 0)
+        gaps = np.flatnonzero(~col[cy:]);  down = int(gaps.min()) if gaps.size else h - cy
+        half_w, half_h = min(left, right), min(up, down)
+        bw = 2 * max(0, half_w - 1 if half_w > 1 else half_w)
+        bh = 2 * max(0, half_h - 1 if half_h > 1 else half_h)
+        if bw <= 0 or bh <= 0:
+            log_message(f"Invalid safe area dimensions: {bw:.0f}x{bh:.0f}", verbose=verbose, always_print=True)
+            raise ImageProcessingError("Failed to create safe area mask")
+        bx, by = int(round(cx_f - bw / 2.0)), int(round(cy_f - bh / 2.0))
+        if bx >= 0 and by >= 0 and bx + bw <= w and by + bh <= h:
+            log_message(f"Safe area: {bw:.0f}x{bh:.0f} at ({cx_f:.0f}, {cy_f:.0f})", verbose=verbose)
+            return (bx, by, bw, bh), (cx_f, cy_f)
+        log_message(f"Safe area validation failed: exceeds bounds {w}x{h}", verbose=verbose, always_print=True)
+        raise ImageProcessingError("Failed to create safe area mask")
+    except ImageProcessingError:
+        pass
+    except Exception as e:
+        log_message(f"Safe area calculation failed: {e}", verbose=verbose, always_print=True)
+    raise ImageProcessingError("Safe area calculation failed")

@@ -332,3 +332,57 @@ class OutsideTextDetector:
         cx1, cy1 = (box1[0] + box1[2]) / 2, (box1[1] + box1[3]) / 2
         cx2, cy2 = (box2[0] + box2[2]) / 2, (box2[1] + box2[3]) / 2
         return bool(np.sqrt((cx1 - cx2) ** 2 + (cy1 - cy2) ** 2) <= threshold)
+
+
+# ---- OCR recogniser drivers (reference :811-990) ------------------------------------------------------------------------------
+# The recognisers themselves (manga-ocr, PaddleOCR-VL) are the LLM / OCR side of the reference, outside the MI355X hot path (SURVEY.md §8
+# out-of-scope list).  The two drivers keep the reference's contract — one string per image, "[OCR FAILED]" for an image that could not be
+# read, the same marker for every image when the recogniser cannot be had — so `core.outside_text_processor` / `core.services.translation`
+# import and degrade exactly as they do when the reference fails to load the model.
+OCR_FAILED = "[OCR FAILED]"
+
+
+def _run_recogniser(images, what: str, get_recogniser, read_one, verbose: bool) -> List[str]:
+    if not images:
+        return []
+    try:
+        recogniser = get_recogniser()
+        texts = []
+        for i, img in enumerate(images):
+            if img is None:
+                log_message(f"Image {i + 1} is None (decode failure), skipping", always_print=True)
+                texts.append(OCR_FAILED)
+                continue
+            try:
+                log_message(f"Processing image {i + 1}/{len(images)} with {what}", verbose=verbose)
+                text = read_one(recogniser, img)
+                texts.append(text.strip() if text else "")
+            except Exception as e:
+                log_message(f"{what} failed for image {i + 1}: {e}", always_print=True)
+                texts.append(OCR_FAILED)
+        return texts
+    except Exception as e:
+        log_message(f"Error with {what}: {e}", always_print=True)
+        return [OCR_FAILED] * len(images)
+
+
+def extract_text_with_manga_ocr(images: List[Image.Image], verbose: bool = False) -> List[str]:
+    return _run_recogniser(images, "manga-ocr", lambda: get_model_manager().get_manga_ocr(verbose=verbose), lambda ocr, img: ocr(img), verbose)
+
+
+def extract_text_with_paddle_ocr_vl(images: List[Image.Image], verbose: bool = False) -> List[str]:
+    def read_one(pair, img):
+        processor, model = pair
+        messages = [{"role": "user", "content": [{"type": "image", "image": img}, {"type": "text", "text": "OCR:"}]}]
+        ip = processor.image_processor
+        size = getattr(ip, "size", {}) or {}
+        lo = getattr(ip, "min_pixels", None)
+        for key in ("shortest_edge", "min_pixels"):
+            if lo is None:
+                lo = size.get(key) if isinstance(size, dict) else getattr(size, key, None)
+        inputs = processor.apply_chat_template(messages, add_generation_prompt=True, tokenize=True, return_dict=True, return_tensors="pt",
+                                               processor_kwargs={"images_kwargs": {"size": {"shortest_edge": lo if lo is not None else 28 * 28 * 130,
+                                                                                             "longest_edge": 1280 * 28 * 28}}}).to(model.device)
+        outputs = model.generate(**inputs, max_new_tokens=1024)
+        return processor.decode(outputs[0][inputs["input_ids"].shape[-1]: -1])
+    return _run_recogniser(images, "PaddleOCR-VL-1.6", lambda: get_model_manager().get_paddle_ocr_vl(verbose=verbose), read_one, verbose)

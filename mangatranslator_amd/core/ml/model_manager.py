@@ -39,6 +39,8 @@ class ModelType(Enum):
     FLUX_KONTEXT_SDNQ_PIPELINE = "flux_kontext_sdnq_pipeline"
     FLUX_KLEIN_9B_PIPELINE = "flux_klein_9b_pipeline"
     FLUX_KLEIN_4B_PIPELINE = "flux_klein_4b_pipeline"
+    MANGA_OCR = "manga_ocr"
+    PADDLE_OCR_VL = "paddle_ocr_vl"
 
 
 def _dist_on() -> bool:
@@ -325,6 +327,22 @@ class ModelManager:
             if self.is_loaded(ModelType.YOLO_PANEL):
                 return self.models[ModelType.YOLO_PANEL]
             raise ModelError("panel detector (YOLO11-L) is not available in this build")
+
+    def get_manga_ocr(self, verbose: bool = False):
+        """manga-ocr recogniser slot (reference :856-904).  The OCR side is outside the MI355X hot path: whatever recogniser object a
+        deployment put in the slot is handed out, otherwise ModelError — which `extract_text_with_manga_ocr` turns into the reference's
+        "[OCR FAILED]" markers."""
+        with self._lock:
+            if self.is_loaded(ModelType.MANGA_OCR):
+                return self.models[ModelType.MANGA_OCR]
+            raise ModelError("manga-ocr is not part of this build (OCR side); load the reference's recogniser into ModelType.MANGA_OCR")
+
+    def get_paddle_ocr_vl(self, verbose: bool = False):
+        """(processor, model) slot of PaddleOCR-VL (reference :927-980); see `get_manga_ocr`"""
+        with self._lock:
+            if self.is_loaded(ModelType.PADDLE_OCR_VL):
+                return self.models[ModelType.PADDLE_OCR_VL]
+            raise ModelError("PaddleOCR-VL is not part of this build (OCR side); load the reference's pair into ModelType.PADDLE_OCR_VL")
 
     def load_rtdetr_conjoined_bubble(self, verbose: bool = False):
         """RT-DETR-v2 secondary detector as libmtx_hip graphs with the YOLO-shaped call of the reference's adapter
