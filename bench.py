@@ -31,6 +31,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16 (no sparsity)
+FP8_PEAK_TFLOPS = 5000.0     # dense fp8 on the MX-scaled K = 64 / 128 matrix instructions (no sparsity)
 
 
 def parse():
@@ -38,12 +39,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1536)
-    ap.add_argument("--stages", default="all", help="comma list of: detect,segment,inpaint,upscale")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--stages", default=None, help="comma list of: detect,segment,inpaint,upscale,clean (default: what --config names)")
+    ap.add_argument("--config", type=int, default=4, choices=[1, 2, 3, 4, 5],
+                    help="BASELINE.json configs (1-based): 1 = YOLO detect + OpenCV-style clean, 2 = YOLO + SAM-2.1 segment only, 3 = + FLUX.1-Kontext "
+                         "inpaint (20 steps bf16), 4 = full pipeline + 2x upscale (the headline metric, default), 5 = 2048x3072 pages, FLUX.2-Klein fp8 "
+                         "inpaint + upscale")
+    ap.add_argument("--inpainter", default=None, choices=["kontext", "klein_4b", "klein_9b"], help="default: kontext (configs 3, 4), klein_4b (config 5)")
+    ap.add_argument("--no-fp8", action="store_true", help="Klein: keep the block linears in bf16 instead of the MX-fp8 matrix path")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="bring the process group up, report the ranks the collective library sees and one broadcast, then exit (no GPU work; "
+                         "with --backend gloo this runs on a CPU-only host)")
     ap.add_argument("--boxes", type=int, default=8, help="bubbles per page (SAM prompts; generator ground truth, SURVEY.md §8d)")
     ap.add_argument("--regions", type=int, default=1, help="FLUX-inpainted outside-text regions per page (R in SURVEY.md §8d)")
-    ap.add_argument("--inpaint-steps", type=int, default=20)
+    ap.add_argument("--inpaint-steps", type=int, default=None, help="default: 20 (Kontext, BASELINE config 3), 8 (Klein: the reference's flux_num_inference_steps default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -52,7 +62,62 @@ def parse():
                     help="in-context kernel timing of the roofline objects: hipGraph with minus hipGraph without the ops (HIP events), "
                          "or device wall-clock stamps around the ops inside one graph (mtx_plan_time_ops, MTX_TIME_OPS=stamp); auto = "
                          "both, stamps reported when they pass a sanity band around the difference figure")
-    return ap.parse_args()
+    a = ap.parse_args()
+    preset = {1: "detect,clean", 2: "detect,segment", 3: "detect,segment,inpaint", 4: "detect,segment,inpaint,upscale", 5: "detect,segment,inpaint,upscale"}
+    if a.stages is None or a.stages == "all":
+        a.stages = preset[a.config]
+    if a.width is None:
+        a.width = 2048 if a.config == 5 else 1024
+    if a.height is None:
+        a.height = 3072 if a.config == 5 else 1536
+    if a.inpainter is None:
+        a.inpainter = "klein_4b" if a.config == 5 else "kontext"
+    if a.inpaint_steps is None:
+        a.inpaint_steps = 20 if a.inpainter == "kontext" else 8
+    return a
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-run this very command under torch.distributed.run, one rank per
+    GPU (nccl = RCCL), rendezvous on 127.0.0.1 — so `--gpus 8` can never silently measure one GPU eight times."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MTX_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world):
+    """process-group smoke test: world size as the collective library reports it, every rank's id gathered, one 64 MB broadcast timed"""
+    import torch.distributed as dist
+    use_gpu = args.backend == "nccl"
+    if use_gpu:
+        local = 0 if os.environ.get("MTX_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    else:
+        dist.init_process_group(args.backend)
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
+    ids = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, dist.get_rank())
+    buf = torch.full((16 << 20,), float(rank == 0), device=dev)
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.broadcast(buf, src=0)
+    if use_gpu:
+        torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = bool(buf.min().item() == 1.0)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": args.gpus, "world_size": dist.get_world_size(), "ranks": sorted(ids), "backend": dist.get_backend(),
+                          "self_launched": os.environ.get("MTX_BENCH_SELF_LAUNCHED") == "1", "broadcast_64MB_ms": 1e3 * dt, "broadcast_ok": ok}))
+    dist.destroy_process_group()
 
 
 def broadcast_state_dict(sd, rank, world, device):
@@ -75,11 +140,19 @@ def broadcast_state_dict(sd, rank, world, device):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_check:
+        if world > 1:
+            launch_check(args, rank, world)
+        else:
+            print(json.dumps({"launch_check": True, "n_gpus": 1, "world_size": 1, "ranks": [0], "self_launched": False}))
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if os.environ.get("MTX_BENCH_ONE_DEVICE") == "1":     # dry run of the N > 1 code path on a one-GPU box (with --backend gloo)
         local_rank = 0
@@ -100,8 +173,9 @@ def main():
     lib = get_library()
     lib.init(local_rank)
     graph = not args.no_graph
-    want = ["detect", "segment", "inpaint", "upscale"] if args.stages == "all" else [x.strip() for x in args.stages.split(",")]
-    stages = [st for st in ("detect", "segment", "inpaint", "upscale") if st in want]
+    want = [x.strip() for x in args.stages.split(",")]
+    stages = [st for st in ("detect", "segment", "inpaint", "upscale", "clean") if st in want]
+    t_load0 = time.perf_counter()
     first = rank == 0 or world == 1
 
     # ---- models: rank 0 "reads" (seeds) the checkpoints, every other rank receives them over RCCL ---------
@@ -158,33 +232,52 @@ def main():
         sam = Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph)
         del sam_sd
     inpainter, flux = None, None
+    klein = args.inpainter.startswith("klein")
     if "inpaint" in want:
-        from mangatranslator_amd.core.image.inpainting import FluxKontextInpainter
-        from mangatranslator_amd.core.ml import flux as fx
-        # 11.9 B-parameter MMDiT + 84 M-parameter VAE, bf16, seeded on rank 0's GPU and broadcast tensor by tensor
-        dit = fx.FluxDiTHip(fx.synthetic_provider(fx.dit_param_shapes(fx.KONTEXT_DIT_CFG), device, 21, broadcast=world > 1), fx.KONTEXT_DIT_CFG, device, lib=lib)
-        vae = fx.FluxVAEHip(fx.synthetic_provider(fx.vae_param_shapes(fx.KONTEXT_VAE_CFG), device, 22, broadcast=world > 1), fx.KONTEXT_VAE_CFG, device, lib=lib)
-        flux = fx.FluxKontextHip(dit, vae, graph=graph)
-        g = torch.Generator().manual_seed(23)     # cached T5 / CLIP embeddings of "Remove all text." (random stand-ins)
-        flux.set_prompt_embeds(torch.randn(512, 4096, generator=g), torch.randn(768, generator=g))
-        inpainter = FluxKontextInpainter(device=device, num_inference_steps=args.inpaint_steps, backend="sdnq")
-        inpainter.pipeline = flux
-        # the OSB stage (core/outside_text_processor.py) builds its own inpainter and asks the manager for the pipeline
         from mangatranslator_amd.core.ml.model_manager import ModelType, get_model_manager
+        if klein:
+            # FLUX.2-Klein (the reference's default inpainter; BASELINE config 5): 3.9 B / 9.1 B-parameter Flux2 MMDiT + 84 M-parameter VAE, seeded
+            # on rank 0's GPU and broadcast tensor by tensor; block linears quantised to MX fp8 at load unless --no-fp8
+            from mangatranslator_amd.core.image.inpainting import FluxKleinInpainter
+            from mangatranslator_amd.core.ml import flux as fx
+            from mangatranslator_amd.core.ml import flux2 as f2
+            dcfg = f2.KLEIN_9B_DIT_CFG if args.inpainter == "klein_9b" else f2.KLEIN_4B_DIT_CFG
+            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8)
+            vae = f2.Flux2VAEHip(fx.synthetic_provider(f2.vae_param_shapes(f2.KLEIN_VAE_CFG), device, 22, broadcast=world > 1), f2.KLEIN_VAE_CFG, device, lib=lib)
+            flux = f2.Flux2KleinHip(dit, vae, graph=graph)
+            flux.set_prompt_embeds(torch.randn(512, dcfg["joint_dim"], generator=torch.Generator().manual_seed(23)))     # cached Qwen3 states (stand-ins)
+            mt = ModelType.FLUX_KLEIN_9B_PIPELINE if args.inpainter == "klein_9b" else ModelType.FLUX_KLEIN_4B_PIPELINE
+            method = "flux_" + args.inpainter
+        else:
+            from mangatranslator_amd.core.image.inpainting import FluxKontextInpainter
+            from mangatranslator_amd.core.ml import flux as fx
+            # 11.9 B-parameter MMDiT + 84 M-parameter VAE, bf16, seeded on rank 0's GPU and broadcast tensor by tensor
+            dit = fx.FluxDiTHip(fx.synthetic_provider(fx.dit_param_shapes(fx.KONTEXT_DIT_CFG), device, 21, broadcast=world > 1), fx.KONTEXT_DIT_CFG, device, lib=lib)
+            vae = fx.FluxVAEHip(fx.synthetic_provider(fx.vae_param_shapes(fx.KONTEXT_VAE_CFG), device, 22, broadcast=world > 1), fx.KONTEXT_VAE_CFG, device, lib=lib)
+            flux = fx.FluxKontextHip(dit, vae, graph=graph)
+            g = torch.Generator().manual_seed(23)     # cached T5 / CLIP embeddings of "Remove all text." (random stand-ins)
+            flux.set_prompt_embeds(torch.randn(512, 4096, generator=g), torch.randn(768, generator=g))
+            mt, method = ModelType.FLUX_KONTEXT_SDNQ_PIPELINE, "flux_kontext"
+        inpainter = True
+        # the OSB stage (core/outside_text_processor.py) builds its own inpainter and asks the manager for the pipeline
         from mangatranslator_amd.core.batch_coordinator import BatchRequestCoordinator
         from mangatranslator_amd.core import outside_text_processor as otp
         import types as _types
-        get_model_manager().models[ModelType.FLUX_KONTEXT_SDNQ_PIPELINE] = flux
+        get_model_manager().models[mt] = flux
         osb_cfg = _types.SimpleNamespace(
             device=device, yolo_model_path=None, request_coordinator=BatchRequestCoordinator(1),
             detection=_types.SimpleNamespace(conjoined_confidence=0.35, bubble_detector_model="yolo_2"),
             outside_text=_types.SimpleNamespace(      # the reference's OutsideTextConfig defaults (core/config.py:126-173), Kontext selected
                 enabled=True, enable_page_number_filtering=False, min_area_ignore_ratio=0.0, seed=1, huggingface_token="",
-                inpainting_method="flux_kontext", flux_backend="sdnq", flux_low_vram=False, flux_num_inference_steps=args.inpaint_steps,
+                inpainting_method=method, flux_backend="sdnq", flux_low_vram=False, flux_num_inference_steps=args.inpaint_steps,
+                flux_luminance_correction=True, flux_upscale_small_crops=True, flux_sdcpp_cache_mode="none", flux_sdcpp_diffusion_quant="",
+                flux_sdcpp_text_encoder_quant="",
                 flux_group_regions=False, flux_residual_diff_threshold=0.15, osb_confidence=0.5, osb_text_free_only=False,
                 bbox_expansion_percent_width=0.1, bbox_expansion_percent_height=0.1, osb_render_expansion_narrow_multiplier=1.0,
                 osb_render_expansion_tiny_multiplier=1.0, osb_render_expansion_aspect_ratio_threshold=0.4,
                 osb_render_expansion_area_ratio_threshold=0.005, text_box_proximity_ratio=0.02))
+
+    load_s = time.perf_counter() - t_load0          # model set-up incl. the start-up weight broadcast (outside the timed region)
 
     # ---- synthetic pages, resident in HBM -----------------------------------------------------------------
     W_, H_ = args.width, args.height
@@ -213,6 +306,23 @@ def main():
         plan0, _ = yolo._plans[(H_, W_, 1600)]
         sc = plan0.decoded[:, 4].float().sort(descending=True).values
         yolo_conf = float(sc[min(3 * args.boxes, len(sc) - 1)])
+
+    clean_args = None
+    if "clean" in want:      # bubble cleaning (reference core/image/cleaning.py:210-521) on the page's ground-truth bubble masks
+        from mangatranslator_amd.core.image import cleaning as cl
+        yy, xx = np.mgrid[0:H_, 0:W_]
+        sc_ = (W_ * H_ / 1e6) ** 0.5
+        ckw = dict(dilation_kernel=cl.structuring_element(cl.scale_kernel(cl.DILATION_KERNEL_SIZE, sc_)),
+                   constraint_erosion_kernel=cl.structuring_element(cl.scale_kernel(cl.EROSION_KERNEL_SIZE, sc_)),
+                   min_contour_area=cl.scale_area(50, sc_, minimum=50, maximum=5000), processing_scale=sc_, device=device, lib=lib)
+        shrink_ = float(cl.scale_scalar(5, sc_, minimum=0.0, maximum=64.0))
+        clean_args = []
+        for k_ in range(pool):
+            bm = []
+            for x0, y0, x1, y1 in page_boxes[k_]:
+                cx, cy, a_, b_ = (x0 + x1) / 2, (y0 + y1) / 2, (x1 - x0) / 2 - 4, (y1 - y0) / 2 - 4
+                bm.append((((xx - cx) / a_) ** 2 + ((yy - cy) / b_) ** 2 <= 1.0).astype(np.uint8) * 255)
+            clean_args.append((torch.from_numpy(np.stack(bm)).to(device), [tuple(int(v) for v in b_) for b_ in page_boxes[k_]]))
 
     stage_wall = {}
 
@@ -252,6 +362,10 @@ def main():
         if upscaler is not None:
             outs["upscale"] = upscaler.upscale_u8(pages[k])
             tl = lap("upscale", tl)
+        if clean_args is not None:
+            dm_, bbs_ = clean_args[k]
+            outs["clean"] = cl.process_bubbles(page_bgr[k], dm_, bbs_, 200, False, shrink_, **ckw)
+            tl = lap("clean", tl)
 
     def barrier():
         torch.cuda.synchronize()
@@ -282,46 +396,38 @@ def main():
         dt = float(t.item())
     pages_per_s = world * args.steps / dt
 
+    if flux is None:
+        inp_desc = None
+    elif klein:
+        c_ = flux.transformer.cfg
+        inp_desc = (f"FLUX.2-Klein-{args.inpainter[-2:].upper()} geometry ({c_['layers']} double + {c_['single_layers']} single blocks, d={c_['d']}, {c_['heads']} heads), "
+                    f"block linears {'MX fp8 e4m3 (v_mfma_scale_f32_32x32x64_f8f6f4)' if flux.transformer.fp8 else 'bf16'}, rest bf16, seeded random weights")
+    else:
+        inp_desc = "FLUX.1-Kontext-dev geometry (19 double + 38 single blocks, d=3072, 24 heads), bf16, seeded random weights"
+    stage_names = "+".join(st for st in stages)
+    headline = stages == ["detect", "segment", "inpaint", "upscale"] and (W_, H_) == (1024, 1536) and not klein
     result = {
-        "metric": "pages/sec (detect+segment+inpaint+upscale) 1024x1536",
+        "metric": "pages/sec (detect+segment+inpaint+upscale) 1024x1536" if headline else f"pages/sec ({stage_names}) {W_}x{H_}",
         "value": pages_per_s, "unit": "pages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{W_}x{H_} synthetic pages, full pipeline (BASELINE.json configs[3] per GPU): one page per step per GPU, "
-                               f"{args.boxes} bubbles, {args.regions} FLUX region(s) x {args.inpaint_steps} steps, 2x upscale; HBM-resident input",
+        "vs_baseline": None, "dtype": ("fp8 (e4m3, MX block scales) block linears + bf16" if klein and flux is not None and flux.transformer.fp8 else "bf16"),
+        "data": "synthetic",
+        "config": {"workload": f"{W_}x{H_} synthetic pages, BASELINE.json configs[{args.config - 1}] per GPU ({stage_names}): one page per step per GPU, "
+                               f"{args.boxes} bubbles" + (f", {args.regions} FLUX region(s) x {args.inpaint_steps} steps" if flux is not None else "")
+                               + (", 2x upscale" if upscaler is not None else "") + "; HBM-resident input",
+                   "baseline_config": args.config,
                    "stages": stages, "stage_memo": "cleared before every page (no cached outputs in the timed region)",
-                   "dtypes": {"detect": "f16", "segment": "bf16", "inpaint": "bf16 (fp32 latents / Euler update)", "upscale": "f16"},
+                   "dtypes": {"detect": "f16", "segment": "bf16", "inpaint": "bf16 (fp32 latents / Euler update)" + (" with MX-fp8 block linears" if klein and flux is not None and flux.transformer.fp8 else ""), "upscale": "f16"},
                    "detector": "YOLOv8m-seg @imgsz 1600 (1088x1600 letterbox) + RT-DETR-v2 R50 @640 (secondary), seeded random weights" if yolo is not None else None,
                    "segmenter": "SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights" if sam is not None else None,
-                   "inpainter": "FLUX.1-Kontext-dev geometry (19 double + 38 single blocks, d=3072, 24 heads), bf16, seeded random weights" if flux is not None else None,
+                   "inpainter": inp_desc,
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
                    "stage_wall_ms_one_page": {k_: round(v_, 2) for k_, v_ in stage_wall.items()},
-                   "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL"},
+                   "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL",
+                   "launch": {"world_size_seen_by_collectives": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
+                              "self_launched": os.environ.get("MTX_BENCH_SELF_LAUNCHED") == "1", "model_setup_and_weight_broadcast_s": round(load_s, 2)}},
     }
     cfg = result["config"]
-
-    def pmc_traffic(key_prefix):
-        """HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs; see the file's _how)"""
-        try:
-            tr = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-            for k_, v_ in tr.items():
-                if k_.startswith(key_prefix):
-                    return v_["bytes_per_launch"]
-        except Exception:
-            pass
-        return None
-
-    def pmc_mfma_util(name_part):
-        """matrix-pipe busy fraction from the committed counter pass (profiles/r01_pmc_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES over
-        SIMD-cycles of the launch) — clock-independent, unlike `frac`, which is priced against the 2.4 GHz nominal peak"""
-        try:
-            pm = json.loads((ROOT / "profiles" / "r01_pmc_mfma_util.json").read_text())["kernels"]
-            for k_, v_ in pm.items():
-                if name_part in k_:
-                    return {"mfma_util": v_["mfma_util"], "effective_clock_ghz": v_["effective_clock_ghz"], "lds_conflict_frac": v_["lds_conflict_frac"]}
-        except Exception:
-            pass
-        return None
 
     if rank == 0:
         # ---- per-stage GPU time (HIP events on the launch stream), outside the timed region ---------------
@@ -358,48 +464,57 @@ def main():
             cfg["upscale_ms"] = upscaler.plan_for(1, H_, W_).time(3)
         if flux is not None:
             key, plan = next(iter(flux.transformer._plans.items()))
-            t_txt, h2, w2, _ = key
-            fl = flux.transformer.flops_per_step(t_txt, h2, w2)
+            t_txt, h2, w2 = key[0], key[1], key[2]
+            fl = flux.transformer.flops_per_step(*key[:3]) if not klein else flux.transformer.flops_per_step(*key)
             plan.time(6)              # ~1 s of sustained load first: the chip boosts for the first few steps after an idle phase and
             step_ms = plan.time(4)    # then settles (rocprof: 0.71 ms vs 0.83 ms per attention launch); the steady state is what a page sees
+            rh2, rw2 = (key[3], key[4]) if klein else (h2, w2)
             cfg["inpaint"] = {"resolution": [w2 * 16, h2 * 16], "tokens": fl["tokens"], "dit_step_ms": step_ms,
                               "dit_tflops": (fl["gemm"] + fl["attention"]) / step_ms / 1e9,
-                              "vae_encode_ms": flux.vae.encoder_plan(h2 * 16, w2 * 16).time(2), "vae_decode_ms": flux.vae.decoder_plan(h2 * 2, w2 * 2).time(2)}
-            # ---- roofline of the dominant kernel: flash attention of one MMDiT block (52 % of a step) ------
-            # in-context timing: the whole step replayed as a hipGraph minus the same graph without its 57 attention ops
-            attn_idx = [i_ for i_, lab in enumerate(plan.labels) if lab.endswith(".attn")]
-            a_ms, a_how, a_info = in_context_ms(plan, attn_idx, 4, args.time_ops)
-            ms = a_ms / len(attn_idx)
-            tfs = fl["attention_per_layer"] / ms / 1e9
-            n_attn = len(flux.transformer.blocks) + len(flux.transformer.singles)
-            result["roofline"] = {
-                "kernel": f"attn_mma32_kernel<bf16, 128> 24 heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)",
-                "bound": "mfma", "achieved": tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic("attn_mma32_kernel") if fl["tokens"] == 8652 else None,
-                "avg_launch_ms": ms, "timing": a_how, "timing_detail": a_info, "launches_per_page": n_attn * args.inpaint_steps * args.regions,
-                "algorithmic_flops_per_launch": fl["attention_per_layer"], "pmc": pmc_mfma_util("attn_mma32_kernel"),
-            }
-            # the other MFMA-bound kernel: every 256-tile GEMM launch of one denoising step, timed one by one
-            D = flux.transformer.cfg["d"]
-            t_img = fl["tokens"] - t_txt
-            shapes = {"qkv": (3 * D, D), "proj_mlp": (4 * D, D), "proj_out": (D, 5 * D), "to_out": (D, D), "ff1": (4 * D, D), "ff2": (D, 4 * D)}
-            g_fl = 0.0
-            g_idx = []
+                              "vae_encode_ms": flux.vae.encoder_plan(rh2 * 16, rw2 * 16).time(2), "vae_decode_ms": flux.vae.decoder_plan(h2 * 2, w2 * 2).time(2)}
+            # ---- in-context time of every MFMA-bound launch of one denoising step, grouped by kernel and problem shape -----------------------
+            # (hipGraph replay of the whole step; per group: device wall-clock stamps around its ops, or graph with minus graph without them)
+            import ctypes as C_
+            from mangatranslator_amd.hip import abi as abi_
+            groups = {}
             for i_, lab in enumerate(plan.labels):
-                blk, _, name = lab.partition(".")
-                if name in shapes and blk[:3] in ("sgl", "dbl"):
-                    rows = fl["tokens"] if blk.startswith("sgl") else t_img
-                    n_, k_ = shapes[name]
-                    g_fl += 2.0 * rows * n_ * k_; g_idx.append(i_)
-            g_n = len(g_idx)
-            g_ms, g_how, g_info = in_context_ms(plan, g_idx, 4, args.time_ops)
-            result["roofline_gemm"] = {
-                "kernel": "gemm256_kernel<bf16> (256x256x64 LDS-DMA tiles), image/joint-stream linears of one MMDiT step",
-                "bound": "mfma", "achieved": g_fl / g_ms / 1e9, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": g_fl / g_ms / 1e9 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": g_ms / g_n, "timing": g_how, "timing_detail": g_info,
-                "launches_per_page": g_n * args.inpaint_steps * args.regions, "algorithmic_flops_per_launch": g_fl / g_n,
-                "pmc": pmc_mfma_util("gemm256_kernelIDF16bLi0ELb1"),
-            }
+                op_ = plan.ops[i_] if hasattr(plan, "ops") else None
+                if lab.endswith(".attn"):
+                    groups.setdefault(("attention", fl["tokens"], fl["tokens"], flux.transformer.cfg["d"]), []).append(i_)
+                elif op_ is not None and op_.kind == abi_.OP_GEMM and lab.split(".")[0][:3] in ("sgl", "dbl"):
+                    g_ = op_.u.gemm
+                    groups.setdefault(("gemm_fp8" if g_.in_dtype == abi_.F8 else "gemm_bf16", int(g_.m), int(g_.n), int(g_.k)), []).append(i_)
+            rows, tot = [], {}
+            for (kind_, m_, n_, k_), idx_ in sorted(groups.items(), key=lambda kv: -len(kv[1])):
+                flops_ = (4.0 * m_ * n_ * k_) if kind_ == "attention" else (2.0 * m_ * n_ * k_)        # attention: M = N = T, K = d_model: 4 T^2 D
+                ms_, how_, info_ = in_context_ms(plan, idx_, 3, args.time_ops)
+                peak_ = FP8_PEAK_TFLOPS if kind_ == "gemm_fp8" else MFMA_PEAK_TFLOPS
+                rows.append({"kernel": kind_, "m": m_, "n": n_, "k": k_, "launches_per_step": len(idx_), "mean_ms": ms_ / len(idx_), "timing": how_,
+                             "timing_detail": info_, "tflops": flops_ * len(idx_) / ms_ / 1e9, "frac_of_peak": flops_ * len(idx_) / ms_ / 1e9 / peak_})
+                t_ = tot.setdefault(kind_, [0.0, 0.0, 0])
+                t_[0] += flops_ * len(idx_); t_[1] += ms_; t_[2] += len(idx_)
+            cfg["inpaint"]["mfma_launch_groups"] = rows
+            cfg["inpaint"]["step_ms_accounted_by_groups"] = sum(r_["mean_ms"] * r_["launches_per_step"] for r_ in rows)
+            n_attn = len(flux.transformer.blocks) + len(flux.transformer.singles)
+
+            def roof(kind_, kernel_name, peak_):
+                f_, ms_, n_ = tot[kind_]
+                return {"kernel": kernel_name, "bound": "mfma", "achieved": f_ / ms_ / 1e9, "peak": peak_, "unit": "TFLOP/s", "frac": f_ / ms_ / 1e9 / peak_,
+                        "traffic": None, "avg_launch_ms": ms_ / n_, "timing": "in-context (see config.inpaint.mfma_launch_groups)",
+                        "launches_per_page": n_ * args.inpaint_steps * args.regions, "algorithmic_flops_per_launch": f_ / n_,
+                        "share_of_step_ms": ms_ / step_ms}
+            roofs = {}
+            if "attention" in tot:
+                roofs["attention"] = roof("attention", f"attn_mma32_kernel<bf16, 128> {flux.transformer.cfg['heads']} heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)", MFMA_PEAK_TFLOPS)
+            if "gemm_bf16" in tot:
+                roofs["gemm_bf16"] = roof("gemm_bf16", "gemm256_kernel<bf16> (256x256x64 LDS-DMA tiles) + 128-tile kernel, block linears of one MMDiT step", MFMA_PEAK_TFLOPS)
+            if "gemm_fp8" in tot:
+                roofs["gemm_fp8"] = roof("gemm_fp8", "gemm256_f8_kernel (256x256x128 LDS-DMA tiles, v_mfma_scale_f32_32x32x64_f8f6f4, MX e4m3), block linears of one MMDiT step", FP8_PEAK_TFLOPS)
+            # `roofline` = the group with the largest share of the step's time; the others ride along under their own keys
+            dom = max(roofs, key=lambda k_: roofs[k_]["share_of_step_ms"])
+            result["roofline"] = roofs.pop(dom)
+            for k_, v_ in roofs.items():
+                result["roofline_" + k_] = v_
         if upscaler is not None:
             # ---- the HBM-bound kernel the north star names: RCAN 3x3 conv 64->64 at page resolution -------
             u = upscaler.hp["unshuffle"]
@@ -413,7 +528,7 @@ def main():
             conv_roof = {
                 "kernel": "conv3x3_c64_kernel<f16> 64->64 @%dx%d" % (W_ // u, H_ // u),
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("conv3x3_c64_kernel") if (W_, H_, u) == (1024, 1536, 1) else None,
+                "traffic": None,          # PMC bytes are taken in separate rocprofv3 --pmc passes of this command (profiles/), never copied into the line
                 "avg_launch_ms": ms, "timing": "event pair around 20 eager launches", "launches_per_page": work["n_conv64"],
                 "algorithmic_bytes_per_launch": work["conv64_bytes"], "mfma_tflops": tfs, "mfma_frac": tfs / MFMA_PEAK_TFLOPS,
             }
@@ -422,7 +537,7 @@ def main():
             else:
                 result["roofline"] = conv_roof
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is a single-GPU-run item (rank 0 at N = 1 only)
-            result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"))
+            result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"), flux.transformer.cfg if (klein and flux is not None) else None)
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
@@ -456,7 +571,7 @@ def in_context_ms(plan, idx, iters, mode):
     return diff, "difference", info
 
 
-def cpu_baseline(stages, rcan_sd, W_, H_, args, inpaint_info):
+def cpu_baseline(stages, rcan_sd, W_, H_, args, inpaint_info, klein_cfg=None):
     """The oracle (CPU restatement, fp32 torch) timed on bounded samples of the same page; each stage's
     sample is scaled to the full page by its unit count (stated in `sample`)."""
     from mangatranslator_amd.utils.synthetic_pages import make_page
@@ -483,7 +598,24 @@ def cpu_baseline(stages, rcan_sd, W_, H_, args, inpaint_info):
         t = timed(lambda: sam2_ref.run(m, pg, boxes))
         parts.append(f"segment: oracle SAM-2.1 Hiera-L on the whole page, {len(boxes)} boxes {t:.2f} s"); total += t; spent += t
         del m
-    if "inpaint" in stages and inpaint_info is not None:
+    if "inpaint" in stages and inpaint_info is not None and klein_cfg is not None:
+        from oracle import flux2_ref as f2r
+        from oracle import flux_ref as fr
+        T, t_txt, D, Hh = inpaint_info["tokens"], 512, klein_cfg["d"], klein_cfg["heads"]
+        torch.manual_seed(0)
+        dbl, sgl = f2r.DoubleBlock(D, Hh, klein_cfg["mlp_ratio"]).eval(), f2r.SingleBlock(D, Hh, klein_cfg["mlp_ratio"]).eval()
+        ids = torch.zeros(T, 4); ids[:, 1] = torch.arange(T) % 64; ids[:, 2] = torch.arange(T) // 64
+        cos, sin = fr.rope_tables(ids, klein_cfg["axes_dim"], theta=klein_cfg["rope_theta"])
+        x = torch.randn(T, D)
+        mod2 = [tuple(0.1 * torch.randn(D) for _ in range(3)) for _ in range(2)]
+        td = timed(lambda: dbl(x[t_txt:], x[:t_txt], mod2, mod2, cos, sin))
+        ts = timed(lambda: sgl(x, mod2[0], cos, sin))
+        t = args.regions * args.inpaint_steps * (klein_cfg["layers"] * td + klein_cfg["single_layers"] * ts)
+        parts.append(f"inpaint: oracle Flux2 MMDiT blocks at full width and T={T}: 1 double {td:.2f} s + 1 single {ts:.2f} s, "
+                     f"x({klein_cfg['layers']}, {klein_cfg['single_layers']}) blocks x {args.inpaint_steps} steps x {args.regions} region (VAE and host math not counted)")
+        total += t; spent += td + ts
+        del dbl, sgl
+    elif "inpaint" in stages and inpaint_info is not None:
         from oracle import flux_ref as fr
         T = inpaint_info["tokens"]
         t_txt = 512
@@ -509,6 +641,18 @@ def cpu_baseline(stages, rcan_sd, W_, H_, args, inpaint_info):
         t = timed(lambda: ref(x))
         frac = (ch * cw) / float(W_ * H_)
         parts.append(f"upscale: oracle RCAN on a {cw}x{ch} crop = {frac:.4f} page {t:.2f} s"); total += t / frac; spent += t
+    if "clean" in stages:
+        from oracle import cleaning_ref as cr
+        from mangatranslator_amd.core.image import cleaning as cl
+        sc = (W_ * H_ / 1e6) ** 0.5
+        dk, ek = cr.ellipse_kernel(cl.scale_kernel(cl.DILATION_KERNEL_SIZE, sc)), cr.ellipse_kernel(cl.scale_kernel(cl.EROSION_KERNEL_SIZE, sc))
+        x0, y0, x1, y1 = (int(v) for v in boxes[0])
+        yy, xx = np.mgrid[0:H_, 0:W_]
+        bm = ((((xx - (x0 + x1) / 2) / ((x1 - x0) / 2 - 4)) ** 2 + ((yy - (y0 + y1) / 2) / ((y1 - y0) / 2 - 4)) ** 2) <= 1.0).astype(np.uint8) * 255
+        gray = cr.bgr_to_gray(np.ascontiguousarray(pg[..., ::-1]))
+        t = timed(lambda: cr.process_single_bubble(bm, gray, 200, False, float(cl.scale_scalar(5, sc, minimum=0.0, maximum=64.0)), (x0, y0, x1, y1), dk, ek,
+                                                   cl.scale_area(50, sc, minimum=50, maximum=5000), False, None, sc, np.ascontiguousarray(pg[..., ::-1])))
+        parts.append(f"clean: oracle cleaning chain on 1 of {len(boxes)} bubbles {t:.2f} s"); total += t * len(boxes); spent += t
     return {"value": 1.0 / total, "unit": "pages/s", "cores": cores, "kind": "port",
             "sample": f"{spent:.1f} s of CPU work, extrapolated to {total:.0f} s/page — " + "; ".join(parts)}
 

@@ -31,7 +31,7 @@ from scipy import ndimage
 from ..utils.exceptions import ValidationError
 from ..utils.logging import log_message
 from .batch_coordinator import expanded_mask_bbox, partition_non_overlapping_waves, paste_image_region
-from .image.inpainting import FluxKontextInpainter
+from .image.inpainting import FluxKleinInpainter, FluxKontextInpainter
 from .image.ocr_detection import OutsideTextDetector
 
 OSB_EXPANSION_PIXEL_BUFFER = 5       # kept clear around bubbles, other OSB regions and panel borders
@@ -279,8 +279,19 @@ def finish_outside_text_work(work: OutsideTextWork) -> Tuple[Image.Image, List[D
                                                  low_vram=ot.flux_low_vram if ot.flux_backend == "sdnq" else False)
             except Exception as e:
                 log_message(f"Flux Kontext unavailable ({e}), falling back to OpenCV", verbose=verbose)
-        elif method in ("flux_klein_9b", "flux_klein_4b"):
-            log_message(f"{method} is not built (SURVEY.md §8 a7 Klein variant); falling back to OpenCV", always_print=True)
+        elif method in ("flux_klein_9b", "flux_klein_4b"):          # the reference's default (core/config.py:136-144; :664-718)
+            try:
+                g = lambda name, default: getattr(ot, name, default)
+                inpainter = FluxKleinInpainter(variant=method[-2:], device=config.device, huggingface_token=ot.huggingface_token,
+                                               num_inference_steps=ot.flux_num_inference_steps, low_vram=g("flux_low_vram", False),
+                                               luminance_correction=g("flux_luminance_correction", True),
+                                               upscale_small_crops=g("flux_upscale_small_crops", True), backend=g("flux_backend", "sdnq"),
+                                               sdcpp_cache_mode=g("flux_sdcpp_cache_mode", "none"),
+                                               sdcpp_diffusion_quant=g("flux_sdcpp_diffusion_quant", ""),
+                                               sdcpp_text_encoder_quant=g("flux_sdcpp_text_encoder_quant", ""), verbose=verbose)
+                log_message(f"Using Flux.2 Klein {method[-2:].upper()} for inpainting", verbose=verbose)
+            except Exception as e:
+                log_message(f"Flux.2 Klein unavailable ({e}), falling back to OpenCV", verbose=verbose)
         if method == "none" or method == "opencv" or inpainter is None:
             inpainter = None
         if not work.mask_groups:

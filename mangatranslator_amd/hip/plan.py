@@ -427,4 +427,5 @@ class PlanBuilder:
         self.lib.check(self.lib.mtx_plan_create(arr, n, C.byref(handle)), "mtx_plan_create")
         plan = Plan(self.lib, handle.value, list(self.keep), n)
         plan.labels = list(self.labels)
+        plan.ops = list(self.ops)          # the recorded argument blocks (benchmarks group launches by kernel and shape)
         return plan
