@@ -32,7 +32,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder
+from ...hip.plan import Act, PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 
@@ -126,7 +126,7 @@ class FluxDiTHip:
                                      nqk=torch.cat([g(p + ".attn.norm_q.weight", f32), g(p + ".attn.norm_k.weight", f32)]).contiguous(),
                                      mlp=(g(p + ".proj_mlp.weight"), g(p + ".proj_mlp.bias", f32)), out=(g(p + ".proj_out.weight"), g(p + ".proj_out.bias", f32))))
         self.W = W
-        self._plans = {}
+        self._plans = PlanCache(6)           # a DiT plan pins ~T x 15 D bytes of activations: a few crop resolutions only
         self._mod_plan = None
         self._mod_cache = {}
 
@@ -278,7 +278,7 @@ class FluxVAEHip:
         self.cfg = cfg
         self.p = provider
         self._w = {}
-        self._plans = {}
+        self._plans = PlanCache(12)
 
     def _conv_w(self, name, cout_pad=0):
         if name not in self._w:

@@ -29,7 +29,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder
+from ...hip.plan import Act, PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 from .flux import FluxVAEHip, _rows, rope_table, sinusoid, synthetic_provider  # noqa: F401  (re-exported for callers)
 
@@ -130,7 +130,7 @@ class Flux2DiTHip:
             self.singles.append(dict(fused=self._weight(g(p + ".to_qkv_mlp_proj.weight"), "single_in"),
                                      nqk=torch.cat([g(p + ".norm_q.weight", f32), g(p + ".norm_k.weight", f32)]).contiguous(),
                                      out=self._weight(g(p + ".to_out.weight"), "single_out")))
-        self._plans = {}
+        self._plans = PlanCache(6)           # a plan pins ~T x 40 D bytes of activations: keep a few resolutions only
         self._mod_plan = None
         self._mod_cache = {}
 
@@ -297,8 +297,6 @@ class Flux2DiTHip:
         rw2 = w2 if rw2 is None else rw2
         key = (t_txt, h2, w2, rh2, rw2)
         if key not in self._plans:
-            if len(self._plans) >= 6:                   # a plan pins ~T x 40 D bytes of activations: keep a few resolutions only
-                self._plans.pop(next(iter(self._plans))).close()
             self._plans[key] = self._build(t_txt, h2, w2, rh2, rw2)
         return self._plans[key]
 

@@ -26,7 +26,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import PlanBuilder
+from ...hip.plan import PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 
@@ -100,8 +100,8 @@ class RCANUpscaler:
         self.dtype = abi.F16
         self._tdt = torch.float16
         self._graph = graph and not self.lib.is_simulator
-        self._lock = threading.Lock()
-        self._plans = {}
+        self._lock = threading.RLock()
+        self._plans = PlanCache(8)          # pages of one size reuse their plan; bubble crops come in any size and would pin memory for ever
         self._pack(state_dict)
 
     # ---- weights ----------------------------------------------------------------------------
@@ -146,7 +146,7 @@ class RCANUpscaler:
         hp, W = self.hp, self.W
         u = hp["unshuffle"]
         if h % u or w % u:
-            raise ModelError(f"RCAN(PU): image {w}x{h} must be divisible by {u}")
+            raise ModelError(f"RCAN(PU): plans are built on sizes divisible by {u} (callers pad: see _padded)")
         pb = PlanBuilder(self.lib, self.device, self.dtype)
         C_ = hp["n_feats"]
         x_in = pb.buf((n, 3, h, w), torch.float32)
@@ -208,35 +208,51 @@ class RCANUpscaler:
         return plan
 
     def plan_for(self, n, h, w):
-        key = (n, h, w)
+        u = self.hp["unshuffle"]
+        key = (n, h + (-h) % u, w + (-w) % u)
         with self._lock:
             if key not in self._plans:
-                self._plans[key] = self._build(n, h, w)
+                self._plans[key] = self._build(*key)
             return self._plans[key]
+
+    def _padded(self, x: torch.Tensor):
+        """[N,3,H,W] on the device, H and W brought up to multiples of the pixel-unshuffle factor by reflecting the last rows /
+        columns (the pixel-unshuffle variants of the upstream architecture pad the same way and crop the result): pages and bubble
+        crops come in any size (reference image_utils.py:369-374 calls the model on whatever it has)"""
+        u = self.hp["unshuffle"]
+        h, w = x.shape[-2:]
+        ph, pw = (-h) % u, (-w) % u
+        if ph or pw:
+            mode = "reflect" if (h > ph and w > pw) else "replicate"
+            x = torch.nn.functional.pad(x, (0, pw, 0, ph), mode=mode)
+        return x, h, w
 
     # ---- the spandrel-model call shape -----------------------------------------------------------
     @torch.no_grad()
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != 3:
             raise ModelError(f"RCAN expects [N,3,H,W], got {tuple(x.shape)}")
-        n, _, h, w = x.shape
-        plan = self.plan_for(n, h, w)
+        x, h, w = self._padded(x.to(device=self.device, dtype=torch.float32))
+        n = x.shape[0]
         with self._lock:
-            plan.x_in.copy_(x.to(device=self.device, dtype=torch.float32))
+            plan = self.plan_for(n, x.shape[2], x.shape[3])
+            plan.x_in.copy_(x)
             plan.run(graph=self._graph)
-            return plan.y_out.clone()
+            s = plan.y_out.shape[2] // x.shape[2]
+            return plan.y_out[:, :, : h * s, : w * s].clone()
 
     @torch.no_grad()
     def upscale_u8(self, page_u8: torch.Tensor) -> torch.Tensor:
         """[H,W,3] uint8 page (device or host) -> [sH,sW,3] uint8 on the device: image_to_tensor,
         model and tensor_to_image of the reference in one native plan run."""
-        h, w, _ = page_u8.shape
-        plan = self.plan_for(1, h, w)
+        x = page_u8.to(self.device).permute(2, 0, 1).unsqueeze(0).to(torch.float32) / 255.0
+        x, h, w = self._padded(x)
         with self._lock:
-            x = page_u8.to(self.device).permute(2, 0, 1).unsqueeze(0).to(torch.float32) / 255.0
+            plan = self.plan_for(1, x.shape[2], x.shape[3])
             plan.x_in.copy_(x)
             plan.run(graph=self._graph)
-            return plan.y_u8[0].clone()
+            s = plan.y_u8.shape[1] // x.shape[2]
+            return plan.y_u8[0, : h * s, : w * s].clone()
 
     def to(self, *a, **k):
         return self

@@ -24,7 +24,7 @@ from PIL import Image
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder
+from ...hip.plan import Act, PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 
@@ -67,7 +67,7 @@ class RTDetrHip:
         self.names = {int(k): str(v) for k, v in (names or id2label).items()}
         self._graph = graph and not self.lib.is_simulator
         self._lock = threading.Lock()
-        self._plans = {}
+        self._plans = PlanCache(4)
         if config.decoder_method != "default" or config.num_feature_levels != len(config.decoder_in_channels) or config.normalize_before:
             raise ModelError("RT-DETR: unsupported configuration (decoder_method / extra feature levels / pre-norm)")
         if config.learn_initial_query:

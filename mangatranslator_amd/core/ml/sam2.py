@@ -33,7 +33,7 @@ import torch.nn.functional as F
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder
+from ...hip.plan import Act, PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -86,9 +86,9 @@ class Sam2Hip:
         self._graph = graph and not self.lib.is_simulator
         self._lock = threading.Lock()
         self._enc = None
-        self._dec = {}
-        self._post = {}
-        self._pre = {}
+        self._dec = PlanCache(6)
+        self._post = PlanCache(8)
+        self._pre = PlanCache(6)
         hp = self.hp
         if hp["dec_dim"] != hp["fpn_dim"]:
             raise ModelError("SAM-2: decoder hidden size must equal the FPN width")

@@ -26,7 +26,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import PlanBuilder
+from ...hip.plan import PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 
@@ -98,7 +98,7 @@ class YoloSegHip:
         self.names = names or {i: f"class{i}" for i in range(self.a["nc"])}
         self._graph = graph and not self.lib.is_simulator
         self._lock = threading.Lock()
-        self._plans = {}
+        self._plans = PlanCache(8)
         self._pack(sd)
 
     # ---- weights ------------------------------------------------------------------------------------

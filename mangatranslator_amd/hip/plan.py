@@ -111,12 +111,57 @@ class Plan:
         if self._h:
             self.lib.mtx_plan_destroy(self._h)
             self._h = None
+            self._keep = None          # the activation buffers go back to the allocator
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+class PlanCache:
+    """shape-keyed plans with a bound: every plan pins its own activation buffers, and bubble crops / intermediate upscale passes come in
+    arbitrary sizes, so an unbounded dict grows device memory with every new size.  Least recently used plans are destroyed."""
+
+    def __init__(self, capacity: int = 8):
+        from collections import OrderedDict
+        self.capacity, self._d = max(1, int(capacity)), OrderedDict()
+
+    def __contains__(self, key):
+        return key in self._d
+
+    def __len__(self):
+        return len(self._d)
+
+    def __getitem__(self, key):
+        self._d.move_to_end(key)
+        return self._d[key]
+
+    def __setitem__(self, key, value):
+        self._d[key] = value
+        self._d.move_to_end(key)
+        while len(self._d) > self.capacity:
+            _, old = self._d.popitem(last=False)
+            for p in (old if isinstance(old, (tuple, list)) else (old,)):
+                if hasattr(p, "close"):
+                    p.close()
+
+    def get(self, key, default=None):
+        return self[key] if key in self._d else default
+
+    def items(self):
+        return self._d.items()
+
+    def values(self):
+        return self._d.values()
+
+    def clear(self):
+        while self._d:
+            _, old = self._d.popitem(last=False)
+            for p in (old if isinstance(old, (tuple, list)) else (old,)):
+                if hasattr(p, "close"):
+                    p.close()
 
 
 class PlanBuilder:

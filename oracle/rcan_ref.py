@@ -13,7 +13,8 @@ is present, so this file restates the published RCAN architecture (Zhang et al.,
       -> n_resgroups x [ n_resblocks x RCAB(conv3x3, ReLU, conv3x3, CA(avgpool,1x1,ReLU,1x1,sigmoid)) + conv3x3 ] (+skip)
       -> conv3x3 (+ long skip) -> Upsampler(conv3x3 -> 4C, PixelShuffle(2)) x log2(scale') -> conv3x3
       -> [add_mean] -> /rgb_range
-    "PU" (pixel-unshuffle) variants first fold 2x2 pixel blocks into channels (12 input channels)
+    "PU" (pixel-unshuffle) variants first fold 2x2 pixel blocks into channels (12 input channels; odd sizes are padded
+    bottom / right by reflection and the output cropped — the padding mode of the absent upstream wheel is ASSUMED: parity unpinned)
     and upsample 4x internally.
 
 State-dict keys: head.0, body.{g}.body.{b}.body.{0,2}, body.{g}.body.{b}.body.3.conv_du.{0,2},
@@ -108,16 +109,23 @@ class RCANRef(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
+        u = self.hp["unshuffle"]
+        h0, w0 = x.shape[-2:]
+        ph, pw = (-h0) % u, (-w0) % u
+        if ph or pw:        # the pixel-unshuffle variants take any size: pad bottom / right by reflection, crop the result
+            x = F.pad(x, (0, pw, 0, ph), mode="reflect" if (h0 > ph and w0 > pw) else "replicate")
         x = x * self.rgb_range
         if self.hp["mean_shift"]:
             x = self.sub_mean(x)
-        if self.hp["unshuffle"] > 1:
-            x = F.pixel_unshuffle(x, self.hp["unshuffle"])
+        if u > 1:
+            x = F.pixel_unshuffle(x, u)
         h = self.head(x)
         y = self.tail(self.body(h) + h)
         if self.hp["mean_shift"]:
             y = self.add_mean(y)
-        return y / self.rgb_range
+        y = y / self.rgb_range
+        s = y.shape[-2] // (h0 + ph)
+        return y[..., : h0 * s, : w0 * s]
 
 
 def make_state_dict(n_feats=64, n_resgroups=10, n_resblocks=20, reduction=16, scale=2, unshuffle=1,

@@ -13,13 +13,14 @@ def test_process_bubbles_vs_oracle(hip_lib, kw):
     assert cc.compare(hip_lib, "cuda:0", **kw) >= 1
 
 
-def test_page_scale_device_masks(hip_lib):
-    """1024x1536 page, masks already resident on the device (as SAM leaves them)"""
+@pytest.mark.parametrize("size", [(1024, 1536), (2048, 3072)])
+def test_page_scale_device_masks(hip_lib, size):
+    """1024x1536 and 2048x3072 (BASELINE config 5) pages, masks already resident on the device (as SAM leaves them)"""
     import torch
     from mangatranslator_amd.core.image import cleaning as cl
     from mangatranslator_amd.utils.synthetic_pages import make_page
     from oracle import cleaning_ref as cr
-    pg, boxes, _ = make_page(3, 1024, 1536, bubbles=4)
+    pg, boxes, _ = make_page(3, size[0], size[1], bubbles=4)
     page = np.ascontiguousarray(pg[..., ::-1])
     H, W = page.shape[:2]
     yy, xx = np.mgrid[0:H, 0:W]

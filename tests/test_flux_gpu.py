@@ -2,6 +2,7 @@
 import pytest
 
 import flux_checks as fc
+from parity_log import record
 
 pytestmark = pytest.mark.gpu
 
@@ -13,7 +14,7 @@ def test_dit_step_hd64(hip_lib):
 
 
 def test_dit_step_hd128(hip_lib):
-    fc.check_dit_step(hip_lib, "cuda:0", h2=8, w2=12, t_txt=32, **MID)
+    record("flux1.dit_step.mid.bf16", velocity_rel_err=fc.check_dit_step(hip_lib, "cuda:0", h2=8, w2=12, t_txt=32, **MID))
 
 
 def test_vae(hip_lib):
@@ -22,4 +23,5 @@ def test_vae(hip_lib):
 
 def test_kontext_loop(hip_lib):
     e, p = fc.check_kontext(hip_lib, "cuda:0", h=128, w=192, t_txt=32, steps=4, **MID)
+    record("flux1.kontext.4steps.mid.bf16", latent_rel_err=e, image_psnr_db=p)
     assert p >= fc.PSNR_MIN_DB

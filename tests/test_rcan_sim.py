@@ -12,3 +12,27 @@ def test_rcan_pixel_unshuffle_meanshift(emu_lib):
 
 def test_rcan_batch2(emu_lib):
     rc.check_rcan(emu_lib, "cpu", 17, 19, n_resgroups=1, n_resblocks=1, n=2)
+
+
+def test_rcan_pixel_unshuffle_odd_sizes(emu_lib):
+    """the lite (pixel-unshuffle) model — the reference's default upscaler — is called on pages and bubble crops of any
+    size; odd sides are padded up by reflection and the output cropped back to (2h, 2w)"""
+    rc.check_rcan(emu_lib, "cpu", 25, 21, n_resgroups=1, n_resblocks=1, n_feats=32, unshuffle=2)
+    rc.check_rcan(emu_lib, "cpu", 16, 19, n_resgroups=1, n_resblocks=1, n_feats=32, unshuffle=2, mean_shift=True)
+
+
+def test_rcan_plan_cache_is_bounded(emu_lib):
+    """one plan per distinct crop size used to pin device memory for ever"""
+    import torch
+    from mangatranslator_amd.core.ml.rcan import RCANUpscaler
+    from oracle.rcan_ref import make_state_dict
+    m = RCANUpscaler(make_state_dict(n_feats=32, n_resgroups=1, n_resblocks=1, unshuffle=2), device="cpu", lib=emu_lib)
+    m._plans.capacity = 3
+    first = None
+    for i, (h, w) in enumerate([(8, 8), (9, 8), (10, 12), (12, 10), (14, 8), (8, 8)]):
+        y = m(torch.rand(1, 3, h, w))
+        assert y.shape == (1, 3, 2 * h, 2 * w)
+        first = first if first is not None else m._plans[(1, 8, 8)]
+    assert len(m._plans) <= 3 and first._h is None             # the oldest plan was destroyed, and (8, 8) was simply rebuilt
+    u8 = m.upscale_u8(torch.zeros(7, 9, 3, dtype=torch.uint8))
+    assert tuple(u8.shape) == (14, 18, 3)

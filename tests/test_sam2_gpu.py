@@ -2,6 +2,7 @@
 import pytest
 
 import sam2_checks as sc
+from parity_log import record
 
 pytestmark = pytest.mark.gpu
 
@@ -13,6 +14,7 @@ def test_sam2_tiny(hip_lib):
 def test_sam2_small(hip_lib):
     err, mism = sc.check_sam2(hip_lib, "cuda:0", "small_test", h=768, w=512, n_boxes=5, seed=1)
     print(f"small_test: logits rel err {err:.4f}, mask mismatch {mism:.4%}")
+    record("sam2.small_test.768x512", logit_rel_err=err, mask_mismatch_frac=mism)
 
 
 def test_sam2_hiera_large_page(hip_lib):
@@ -21,3 +23,11 @@ def test_sam2_hiera_large_page(hip_lib):
     err, mism = sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=1536, w=1024, n_boxes=8, seed=2,
                               logit_tol=0.15, mask_tol=0.02)
     print(f"hiera_large: logits rel err {err:.4f}, mask mismatch {mism:.4%}")
+    record("sam2.hiera_large.1024x1536", logit_rel_err=err, mask_mismatch_frac=mism, boxes=8)
+
+
+def test_sam2_hiera_large_page_2048x3072(hip_lib):
+    """BASELINE config 5 page size (the encoder input stays 1024 x 1024; what grows is the antialiased down-scale and the mask up-scale)"""
+    err, mism = sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=3072, w=2048, n_boxes=8, seed=3, logit_tol=0.15, mask_tol=0.02)
+    print(f"hiera_large 2048x3072: logits rel err {err:.4f}, mask mismatch {mism:.4%}")
+    record("sam2.hiera_large.2048x3072", logit_rel_err=err, mask_mismatch_frac=mism, boxes=8)
