@@ -386,6 +386,7 @@ def main():
     if flux is not None:          # every page sent its R regions through FLUX (none classified as solid, none dropped)
         want_calls = (pool + args.warmup + args.steps) * args.regions
         assert flux.calls == want_calls, f"expected {want_calls} FLUX calls, saw {flux.calls}"
+        assert flux.completed == want_calls, f"{want_calls - flux.completed} of {want_calls} FLUX calls raised (the OSB stage turns those into flat fills)"
     if rank == 0:               # informational: wall clock of each stage of one more page, synchronised stage by stage
         stage_wall["_on"] = True
         step(0)

@@ -158,7 +158,8 @@ typedef enum mtx_ew_kind {
   MTX_EW_IM2COL = 9,      /* y[r, tap*C + c] = a[n, oy*s-pad+ky, ox*s-pad+kx, c] (zero outside);
                              i0 = k, i1 = stride, pad = k/2; optional s = int32 row map
                              (output row r takes raster output pixel idx[r]); ldy >= k*k*C       */
-  MTX_EW_SOFTMAX_ROWS = 10, /* y[r, :c] = softmax(act_param * a[r, :c]) over rows r < n*h*w (VAE attention) */
+  MTX_EW_SOFTMAX_ROWS = 10, /* y[r, :c] = softmax(act_param * a[r, :c]) over rows r < n*h*w (VAE attention); i0 > 0: only the first i0
+                               columns carry weight, the others (padding up to the 16-byte chunk) come out 0 */
   MTX_EW_TRANSPOSE = 11,  /* y[c, r] = a[r, c] for r < h*w rows, c columns (per n; ldy = row stride of y) */
   MTX_EW_AVGPOOL2 = 13,   /* 2x2 stride-2 average pool, ceil mode, divisor = in-bounds taps (ResNet-vd shortcut) */
   MTX_EW_SWIGLU = 14,     /* y = silu(a) * b   (FLUX.2 feed-forward: a, b = the two column halves of linear_in's output) */

@@ -320,15 +320,14 @@ class FluxVAEHip:
         C, T = x.c, x.h * x.w
         t = self._gn(pb, x, p + ".group_norm", silu=False)
         q = pb.gemm(t.t, self._lin(p + ".to_q")[0], T, C, C, bias=self._lin(p + ".to_q")[1], label=p + ".q")
-        k = pb.gemm(t.t, self._lin(p + ".to_k")[0], T, C, C, bias=self._lin(p + ".to_k")[1], label=p + ".k")
+        Tp = (T + 7) // 8 * 8                  # H/8 x W/8 tokens: a multiple of 4, not always of 8 (e.g. a 1296 x 784 Klein crop)
+        k = pb.buf((Tp, C), self.tdt, zero=True)
+        pb.gemm(t.t, self._lin(p + ".to_k")[0], T, C, C, bias=self._lin(p + ".to_k")[1], out=k, label=p + ".k")
         v = pb.gemm(t.t, self._lin(p + ".to_v")[0], T, C, C, bias=self._lin(p + ".to_v")[1], label=p + ".v")
-        Tp = (T + 7) // 8 * 8
         s = pb.buf((T, Tp), self.tdt, zero=True)
-        pb.gemm(q, k, T, T, C, out=s, ldc=Tp, label=p + ".qk")
+        pb.gemm(q, k, T, Tp, C, out=s, ldc=Tp, label=p + ".qk")          # the padded key rows are zero and are masked out of the softmax
         sa = Act(s.view(1, 1, T, Tp), 1, 1, T, Tp)
-        if Tp != T:
-            raise ModelError("VAE attention: token count must be a multiple of 8")
-        pb.ew(abi.EW_SOFTMAX_ROWS, sa, out=sa, act_param=1.0 / math.sqrt(C), label=p + ".softmax")
+        pb.ew(abi.EW_SOFTMAX_ROWS, sa, out=sa, act_param=1.0 / math.sqrt(C), i0=T if Tp != T else 0, label=p + ".softmax")
         vt = pb.buf((C, Tp), self.tdt, zero=True)
         pb.ew(abi.EW_TRANSPOSE, Act(v.view(1, 1, T, C), 1, 1, T, C), out=Act(vt.view(1, 1, C, Tp), 1, 1, C, Tp), label=p + ".v_t")
         o = pb.gemm(s, vt, T, C, Tp, label=p + ".pv")
@@ -397,6 +396,7 @@ class FluxKontextHip:
         self._lock = threading.Lock()
         self._embeds = None
         self.calls = 0                # pipeline invocations (benchmarks assert the expected number of FLUX regions ran)
+        self.completed = 0            # ... that returned an image (a call that raised is caught by the OSB stage and becomes a flat fill)
 
     def set_prompt_embeds(self, prompt_embeds: torch.Tensor, pooled: torch.Tensor):
         """T5 / CLIP embeddings of the (fixed) prompt — computed once per process by the caller."""
@@ -450,6 +450,7 @@ class FluxKontextHip:
             dec.run(graph=self._graph)
             out = dec.out[0].clamp(0, 1).clone()
             self.last = dict(latents=lat, sigmas=sig)
+        self.completed += 1
         return SimpleNamespace(images=[out])
 
 

@@ -335,7 +335,8 @@ class Flux2KleinHip:
         self._graph = graph and not dit.lib.is_simulator
         self._lock = threading.Lock()
         self._embeds = None
-        self.calls = 0
+        self.calls = 0                # pipeline invocations
+        self.completed = 0            # ... that returned an image (a call that raised is caught by the OSB stage and becomes a flat fill)
 
     def set_prompt_embeds(self, prompt_embeds: torch.Tensor):
         """Qwen3 hidden states of the (fixed) prompt — computed once per process by the caller"""
@@ -409,6 +410,7 @@ class Flux2KleinHip:
             dec.run(graph=self._graph)
             out = dec.out[0].clamp(0, 1).clone()
             self.last = dict(latents=lat, sigmas=sig, ref_tokens=ref_tok)
+        self.completed += 1
         if output_type == "pt":
             return SimpleNamespace(images=[out])
         from PIL import Image

@@ -245,10 +245,7 @@ constexpr int AB_QB = 256;
 
 // One K/V tile of the main loop.  STAGE is a compile-time constant so every LDS address is
 // (loop-invariant VGPR) + (immediate offset).
-// PF > 0 pins the order of the fragment reads: the K fragments of S^T run PF k-steps ahead of the MFMAs that consume them
-// and the V^T fragments of PV 2*PF steps ahead (left alone, the compiler issues each pair of reads right in front of its two
-// MFMAs, so every pair pays the LDS round trip).
-template <typename T, int DP, int STAGE, bool RAGGED, int PF = 0>
+template <typename T, int DP, int STAGE, bool RAGGED>
 __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
                                                 float& m_raw, float& lsum, const float c, const float thr,
                                                 const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
@@ -261,32 +258,13 @@ __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typen
   // ---- S^T = K Q^T: sacc[kb][r] = key 32*kb + (r&3) + 8*(r>>2) + 4*hi of this tile, query l31 ----------------
   f32x16 sacc[2];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (PF == 0) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+  for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
-        sacc[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : sacc[kb]);
-      }
-  } else {
-    v8 kf[KS][2];
-#pragma unroll
-    for (int ks = 0; ks < PF && ks < KS; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) kf[ks][kb] = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
-    MTX_SCHED_FENCE();
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + PF < KS) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) kf[ks + PF][kb] = *reinterpret_cast<const v8*>(Ks + kaddr[ks + PF] + kb * 32 * ROWB);
-      }
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) sacc[kb] = Mma32<T>::mfma(kf[ks][kb], qf[ks], ks == 0 ? zero : sacc[kb]);
-      MTX_SCHED_FENCE();
+    for (int kb = 0; kb < 2; ++kb) {
+      const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
+      sacc[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : sacc[kb]);
     }
-  }
 
   if (RAGGED) {                                // last tile of a ragged sequence: keys >= kvalid do not exist
 #pragma unroll
@@ -321,42 +299,20 @@ __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typen
     }
 
   // ---- O^T += V^T P^T: k-slot (hi, j) of step (kb, s2) is key 32*kb + 16*s2 + 8*(j>>2) + 4*hi + (j&3) ------------
-  if (PF == 0) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+  for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
-          const v4 lo = lds_read_tr16<T>(a);
-          const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-          v8 vf;
-          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-          vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
-          oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
-        }
-  } else {
-    constexpr int NS = 4 * DB, PV = 2 * PF;      // step = (kb, s2, d)
-    v8 vf[NS];
-    auto vread = [&](int st) {
-      const int d = st % DB, ks2 = st / DB;      // ks2 = kb*2 + s2: 16-key step of the tile
-      const unsigned char* a = Vs + vaddr[d] + ks2 * 16 * ROWB;
-      const v4 lo = lds_read_tr16<T>(a);
-      const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-      vf[st][0] = lo[0]; vf[st][1] = lo[1]; vf[st][2] = lo[2]; vf[st][3] = lo[3];
-      vf[st][4] = hv[0]; vf[st][5] = hv[1]; vf[st][6] = hv[2]; vf[st][7] = hv[3];
-    };
-#pragma unroll
-    for (int st = 0; st < PV && st < NS; ++st) vread(st);
-    MTX_SCHED_FENCE();
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      if (st + PV < NS) vread(st + PV);
-      oacc[st % DB] = Mma32<T>::mfma(vf[st], pb[st / DB / 2][(st / DB) & 1], oacc[st % DB]);
-      MTX_SCHED_FENCE();
-    }
-  }
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
+        const v4 lo = lds_read_tr16<T>(a);
+        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+        v8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
+        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
+      }
 }
 
 // Bias variant of the tile step: Q arrives pre-multiplied by scale * log2(e) and the S^T accumulators START at minus the running
@@ -480,89 +436,11 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
         oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
       }
 }
-
-// The two halves of a tile step, for the staggered schedule: the score phase (S^T MFMAs + row maximum + rare rescale)
-// and the value phase (exponentials -> P, PV MFMAs).  The scores stay in registers across the barrier between them.
-template <typename T, int DP, int STAGE, bool RAGGED>
-__device__ __forceinline__ void attn_score_phase(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
-                                                 f32x16 (&sacc)[2], float& m_raw, float& lsum, const float c, const float thr,
-                                                 const int (&kaddr)[DP / 16], const long kvalid, const int hi) {
-  typedef typename Traits<T>::v8 v8;
-  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
-      sacc[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : sacc[kb]);
-    }
-  if (RAGGED) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) sacc[kb][r] = -1.0e30f;
-  }
-  float tmax = fmaxf(sacc[0][0], sacc[1][0]);
-#pragma unroll
-  for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
-  tmax = half_max(tmax);
-  if (__any(tmax > m_raw + thr)) {
-    const float m_new = fmaxf(m_raw, tmax);
-    const float alpha = fast_exp2((m_raw - m_new) * c);
-    m_raw = m_new;
-    lsum *= alpha;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-  }
-}
-
-template <typename T, int DP, int STAGE>
-__device__ __forceinline__ void attn_value_phase(unsigned char* smem, f32x16 (&oacc)[DP / 32], const f32x16 (&sacc)[2], const float m_raw, float& lsum,
-                                                 const float c, const int (&vaddr)[DP / 32]) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  const unsigned char* Vs = smem + STAGE * 2 * TILE_B + TILE_B;
-  const float mc = m_raw * c;
-  v8 pb[2][2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = fast_exp2(__builtin_fmaf(sacc[kb][r], c, -mc));
-      lsum += pv;
-      pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
-    }
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
-        const v4 lo = lds_read_tr16<T>(a);
-        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-        v8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
-        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
-      }
-}
-
-// STAG = staggered schedule: the two waves of every SIMD (w and w+4) run half a tile apart — while one group issues the
-// S^T MFMAs of its tile, the other turns its scores into probabilities and runs the PV MFMAs — separated by a workgroup
-// barrier per half tile.  Tile t+1 is written to LDS at the start of the (global) segment in which group 0 runs its
-// value phase of tile t and group 1 its score phase of tile t: by then both have finished with that buffer's tile t-1.
-template <typename T, int DP, int MODE>
+// PRESCALED (MTX_ATTN_Q_PRESCALED, the FLUX graphs): q carries scale * log2(e); the S^T accumulators start at minus the running maximum
+// and no maximum is taken on the hot path (attn_bias_tile).  Otherwise the classic online softmax of attn_mma32_tile.
+template <typename T, int DP, bool PRESCALED>
 __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
-  constexpr bool STAG = MODE == 1;
-  constexpr int PF = (MODE >= 2 && MODE <= 4) ? MODE : 0;          // MODE 2, 3, 4: lockstep loop with fragment reads pinned PF k-steps ahead
-  constexpr bool BIAS = MODE == 5 || MODE == 6;     // MODE 5: Q pre-scaled, S^T accumulators start at -max (attn_bias_tile); 6: and no max on the hot path
+  constexpr bool BIAS = PRESCALED;
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
   constexpr int KS = DP / 16;                  // k-steps of S^T
@@ -665,9 +543,9 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   const long ntiles_all = (p.sk + AB_KV - 1) / AB_KV;
   const long t_begin = part * ntiles_all / nparts, ntiles = (part + 1) * ntiles_all / nparts;    // this workgroup's key tiles
   const long kv_last = ntiles == ntiles_all ? p.sk - (ntiles_all - 1) * AB_KV : AB_KV;     // valid keys in its last tile
-  if (!STAG) {
-#define ATTN_TILE(ST, RAG, KV) do { if constexpr (BIAS) attn_bias_tile<T, DP, ST, RAG, MODE == 6>(smem, qf, oacc, m_raw, lsum, minit, first, kaddr, vaddr, KV, hi); \
-                                    else attn_mma32_tile<T, DP, ST, RAG, PF>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, KV, hi); } while (0)
+  {
+#define ATTN_TILE(ST, RAG, KV) do { if constexpr (BIAS) attn_bias_tile<T, DP, ST, RAG, true>(smem, qf, oacc, m_raw, lsum, minit, first, kaddr, vaddr, KV, hi); \
+                                    else attn_mma32_tile<T, DP, ST, RAG>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, KV, hi); } while (0)
     load_tile(t_begin);
     store_tile(0);
     __syncthreads();
@@ -696,58 +574,6 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
       else ATTN_TILE(0, false, AB_KV);
     }
 #undef ATTN_TILE
-  } else {
-    // group 0 (waves 0-3) runs  [score(t)] B [feed, value(t)] B ;  group 1 the same shifted by one barrier:
-    // B [feed, score(t)] B [value(t)] ...  `feed` = tile t+1 registers -> LDS, tile t+2 -> registers; both groups feed in the
-    // same global segment.  Separate straight-line loops per group (the role is wave-uniform), ragged last tile peeled.
-    f32x16 sacc[2];
-    load_tile(t_begin);
-    store_tile(0);
-    if (t_begin + 1 < ntiles) load_tile(t_begin + 1);
-    __syncthreads();
-    const long nfull = (kv_last < AB_KV) ? ntiles - 1 : ntiles;        // tiles handled by the unmasked code
-#define ATTN_FEED(tt, stage_next) { if ((tt) + 1 < ntiles) store_tile(stage_next); if ((tt) + 2 < ntiles) load_tile((tt) + 2); }
-#define ATTN_SCORE(ST) attn_score_phase<T, DP, ST, false>(smem, qf, oacc, sacc, m_raw, lsum, c, thr, kaddr, AB_KV, hi)
-#define ATTN_VALUE(ST) attn_value_phase<T, DP, ST>(smem, oacc, sacc, m_raw, lsum, c, vaddr)
-    long tt = t_begin;
-    if ((wv >> 2) == 0) {
-      for (; tt + 1 < nfull; tt += 2) {
-        ATTN_SCORE(0); MTX_LDS_BARRIER(); ATTN_FEED(tt, 1); ATTN_VALUE(0); MTX_LDS_BARRIER();
-        ATTN_SCORE(1); MTX_LDS_BARRIER(); ATTN_FEED(tt + 1, 0); ATTN_VALUE(1); MTX_LDS_BARRIER();
-      }
-      for (; tt < ntiles; ++tt) {               // at most two tiles left, the last possibly ragged; stage = parity
-        const bool rag = tt >= nfull;
-        if (((tt - t_begin) & 1) == 0) {
-          if (rag) attn_score_phase<T, DP, 0, true>(smem, qf, oacc, sacc, m_raw, lsum, c, thr, kaddr, kv_last, hi); else ATTN_SCORE(0);
-          MTX_LDS_BARRIER(); ATTN_FEED(tt, 1); ATTN_VALUE(0); MTX_LDS_BARRIER();
-        } else {
-          if (rag) attn_score_phase<T, DP, 1, true>(smem, qf, oacc, sacc, m_raw, lsum, c, thr, kaddr, kv_last, hi); else ATTN_SCORE(1);
-          MTX_LDS_BARRIER(); ATTN_FEED(tt, 0); ATTN_VALUE(1); MTX_LDS_BARRIER();
-        }
-      }
-      MTX_LDS_BARRIER();
-    } else {
-      MTX_LDS_BARRIER();
-      for (; tt + 1 < nfull; tt += 2) {
-        ATTN_FEED(tt, 1); ATTN_SCORE(0); MTX_LDS_BARRIER(); ATTN_VALUE(0); MTX_LDS_BARRIER();
-        ATTN_FEED(tt + 1, 0); ATTN_SCORE(1); MTX_LDS_BARRIER(); ATTN_VALUE(1); MTX_LDS_BARRIER();
-      }
-      for (; tt < ntiles; ++tt) {
-        const bool rag = tt >= nfull;
-        if (((tt - t_begin) & 1) == 0) {
-          ATTN_FEED(tt, 1);
-          if (rag) attn_score_phase<T, DP, 0, true>(smem, qf, oacc, sacc, m_raw, lsum, c, thr, kaddr, kv_last, hi); else ATTN_SCORE(0);
-          MTX_LDS_BARRIER(); ATTN_VALUE(0); MTX_LDS_BARRIER();
-        } else {
-          ATTN_FEED(tt, 0);
-          if (rag) attn_score_phase<T, DP, 1, true>(smem, qf, oacc, sacc, m_raw, lsum, c, thr, kaddr, kv_last, hi); else ATTN_SCORE(1);
-          MTX_LDS_BARRIER(); ATTN_VALUE(1); MTX_LDS_BARRIER();
-        }
-      }
-    }
-#undef ATTN_FEED
-#undef ATTN_SCORE
-#undef ATTN_VALUE
   }
 
   if (nparts > 1) {
@@ -784,585 +610,10 @@ __global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
   }
 }
 
-// =====================================================================================================
-// Software-pipelined variant of the long-sequence kernel: the S^T MFMAs of tile t+1 are issued together with
-// the softmax VALU work of tile t (two score accumulators), so inside ONE wave the matrix pipe works while the
-// exponentials are computed; K/V tiles arrive by LDS-DMA (buffer_load ... lds) into a three-stage ring, which
-// frees the 16 staging registers the second accumulator needs and removes the LDS store pass.
-// Per step:  DMA(t+2) -> [max(t), rare rescale] -> [S^T(t+1) MFMAs || exp/sum/convert(t)] -> PV(t) -> wait, barrier.
-template <typename T, int DP, int VS, bool HAS_NEXT, bool RAGGED>
-__device__ __forceinline__ void attn_pipe_step(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
-                                               f32x16 (&scur)[2], f32x16 (&snext)[2], float& m_raw, float& lsum, const float c, const float thr,
-                                               const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  const unsigned char* Kn = smem + ((VS + 1) % 3) * 2 * TILE_B;        // K of tile t+1
-  const unsigned char* Vs = smem + VS * 2 * TILE_B + TILE_B;           // V of tile t
-
-  if (RAGGED) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) scur[kb][r] = -1.0e30f;
-  }
-  float tmax = fmaxf(scur[0][0], scur[1][0]);
-#pragma unroll
-  for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, scur[0][r]), scur[1][r]);
-  tmax = half_max(tmax);
-  if (__any(tmax > m_raw + thr)) {
-    const float m_new = fmaxf(m_raw, tmax);
-    const float alpha = fast_exp2((m_raw - m_new) * c);
-    m_raw = m_new;
-    lsum *= alpha;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-  }
-
-  // ---- S^T(t+1) = K Q^T on the matrix pipe while the VALU turns scores(t) into probabilities ----------------
-  if (HAS_NEXT) {
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const v8 kf = *reinterpret_cast<const v8*>(Kn + kaddr[ks] + kb * 32 * ROWB);
-        snext[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : snext[kb]);
-      }
-  }
-  const float mc = m_raw * c;
-  v8 pb[2][2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = fast_exp2(__builtin_fmaf(scur[kb][r], c, -mc));
-      lsum += pv;
-      pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
-    }
-
-  // ---- O^T += V^T P^T ----------------------------------------------------------------------------------------
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
-        const v4 lo = lds_read_tr16<T>(a);
-        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-        v8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
-        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
-      }
-  if (HAS_NEXT) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) scur[kb] = snext[kb];
-  }
-}
-
-template <typename T, int DP>
-__global__ __launch_bounds__(512) void attn_pipe_kernel(AttnParams p) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  static_assert(DP == 128, "swizzles are written for 256-byte rows");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 2 * TILE_B];      // 96 KB: three K|V stages
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
-  const long b = bh / p.heads, h = bh % p.heads;
-  const long q0 = qb * AB_QB + wv * 32;
-  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
-  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
-  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
-  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
-
-  v8 qf[KS];
-  {
-    const long qr = q0 + l31;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
-      qf[ks] = __builtin_bit_cast(v8, raw);
-    }
-  }
-  f32x16 oacc[DB];
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-  float m_raw = -1.0e30f, lsum = 0.f;
-  const float c = p.scale_log2;
-  const float thr = 8.0f / c;
-
-  // ---- LDS-DMA plan: a wave instruction moves 1 KB = 4 rows of 256 B; wave wv owns rows 8*wv .. 8*wv+7 of K and of V.
-  // lane -> (row = base + lane/16, slot lane%16); the slot holds global chunk slot ^ swizzle(row)
-  const BufView kbv = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
-  const BufView vbv = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
-  unsigned kvoff[2], vvoff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wv * 8 + i * 4 + (lane >> 4), slot = lane & 15;
-    kvoff[i] = (unsigned)((row * p.k_ss + ((slot ^ (row & 15)) << 3)) * sizeof(T));
-    vvoff[i] = (unsigned)((row * p.v_ss + ((slot ^ ((row & 3) << 2)) << 3)) * sizeof(T));
-  }
-  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
-  auto dma_tile = [&](long t, int stage) {
-    unsigned char* Ks = smem + stage * 2 * TILE_B;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      buf_load16_lds(kbv, kvoff[i], (unsigned)t * k_step, Ks + (wv * 8 + i * 4) * ROWB);
-      buf_load16_lds(vbv, vvoff[i], (unsigned)t * v_step, Ks + TILE_B + (wv * 8 + i * 4) * ROWB);
-    }
-  };
-
-  int kaddr[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
-  int vaddr[DB];
-  {
-    const int ti = lane & 15, g1 = (lane >> 4) & 1;
-    const int vrow = hi * 4 + (ti >> 2);
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-      vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
-  }
-
-  const long ntiles = (p.sk + AB_KV - 1) / AB_KV;
-  const long kv_last = p.sk - (ntiles - 1) * AB_KV;
-  dma_tile(0, 0);
-  if (ntiles > 1) dma_tile(1, 1);
-  MTX_WAIT_VMEM();
-  __syncthreads();
-  f32x16 scur[2], snext[2];
-  {  // S^T(0)
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const v8 kf = *reinterpret_cast<const v8*>(smem + kaddr[ks] + kb * 32 * ROWB);
-        scur[kb] = Mma32<T>::mfma(kf, qf[ks], ks == 0 ? zero : scur[kb]);
-      }
-  }
-  // tile t lives in stage t % 3; a step needs K(t+1), V(t) resident and puts tile t+2 in flight
-#define ATTN_PIPE_STEP(VS, NEXT, RAG, KV)                                                                           \
-  attn_pipe_step<T, DP, VS, NEXT, RAG>(smem, qf, oacc, scur, snext, m_raw, lsum, c, thr, kaddr, vaddr, KV, hi)
-#define ATTN_PIPE_SYNC() { MTX_WAIT_VMEM(); MTX_LDS_BARRIER(); }
-  long t = 0;
-  for (; t + 3 < ntiles; t += 3) {           // three full steps, every one with a successor
-    dma_tile(t + 2, 2); ATTN_PIPE_STEP(0, true, false, AB_KV); ATTN_PIPE_SYNC();
-    dma_tile(t + 3, 0); ATTN_PIPE_STEP(1, true, false, AB_KV); ATTN_PIPE_SYNC();
-    if (t + 4 < ntiles) dma_tile(t + 4, 1);
-    ATTN_PIPE_STEP(2, true, false, AB_KV); ATTN_PIPE_SYNC();
-  }
-  // 1..3 tiles left (t is a multiple of 3, so tile t sits in stage 0); only the very last may be ragged
-  const long left = ntiles - t;
-  const bool rag = kv_last < AB_KV;
-  if (left == 1) {
-    if (rag) ATTN_PIPE_STEP(0, false, true, kv_last); else ATTN_PIPE_STEP(0, false, false, AB_KV);
-  } else if (left == 2) {
-    ATTN_PIPE_STEP(0, true, false, AB_KV); ATTN_PIPE_SYNC();
-    if (rag) ATTN_PIPE_STEP(1, false, true, kv_last); else ATTN_PIPE_STEP(1, false, false, AB_KV);
-  } else {
-    dma_tile(t + 2, 2); ATTN_PIPE_STEP(0, true, false, AB_KV); ATTN_PIPE_SYNC();
-    ATTN_PIPE_STEP(1, true, false, AB_KV); ATTN_PIPE_SYNC();
-    if (rag) ATTN_PIPE_STEP(2, false, true, kv_last); else ATTN_PIPE_STEP(2, false, false, AB_KV);
-  }
-#undef ATTN_PIPE_STEP
-#undef ATTN_PIPE_SYNC
-
-  const float l = half_sum(lsum);
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  const long qr = q0 + l31;
-  if (qr < p.sq) {
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[d][g * 4 + r] * inv);
-        *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
-      }
-  }
-}
-
-// =====================================================================================================
-// One-wave-per-SIMD variant: 4 waves x 64 query rows (two 32-row blocks A, B per wave), up to 512 registers per lane.
-// Every K / V fragment read from LDS feeds two MFMAs (halves the LDS traffic per FLOP) and the straight-line step
-//   S^T(t+1) for A and B  ||  softmax A(t) -> PV A(t)  ||  softmax B(t) -> PV B(t)
-// gives the in-order wave independent matrix and VALU work to interleave without a partner wave.
-template <typename T, int DP, int VS, bool HAS_NEXT, bool RAGGED>
-__device__ __forceinline__ void attn_w64_step(unsigned char* smem, const typename Traits<T>::v8 (&qf)[2][DP / 16], f32x16 (&oacc)[2][DP / 32],
-                                              f32x16 (&scur)[2][2], f32x16 (&snext)[2][2], float (&m_raw)[2], float (&lsum)[2], const float c, const float thr,
-                                              const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  const unsigned char* Kn = smem + ((VS + 1) % 3) * 2 * TILE_B;
-  const unsigned char* Vs = smem + VS * 2 * TILE_B + TILE_B;
-
-  float mc[2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    if (RAGGED) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) scur[f][kb][r] = -1.0e30f;
-    }
-    float tmax = fmaxf(scur[f][0][0], scur[f][1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, scur[f][0][r]), scur[f][1][r]);
-    tmax = half_max(tmax);
-    if (__any(tmax > m_raw[f] + thr)) {
-      const float m_new = fmaxf(m_raw[f], tmax);
-      const float alpha = fast_exp2((m_raw[f] - m_new) * c);
-      m_raw[f] = m_new;
-      lsum[f] *= alpha;
-#pragma unroll
-      for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[f][d][r] *= alpha;
-    }
-    mc[f] = m_raw[f] * c;
-  }
-
-  if (HAS_NEXT) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const v8 kf = *reinterpret_cast<const v8*>(Kn + kaddr[ks] + kb * 32 * ROWB);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          if (ks == 0) Mma32Pinned<T>::set_vgpr(snext[f][kb], kf, qf[f][ks]); else Mma32Pinned<T>::acc_vgpr(snext[f][kb], kf, qf[f][ks]);
-        }
-      }
-  }
-  v8 pb[2][2][2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = fast_exp2(__builtin_fmaf(scur[f][kb][r], c, -mc[f]));
-        lsum[f] += pv;
-        pb[f][kb][r >> 3][r & 7] = from_f32<T>(pv);
-      }
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
-        const v4 lo = lds_read_tr16<T>(a);
-        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-        v8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) Mma32Pinned<T>::acc_agpr(oacc[f][d], vf, pb[f][kb][s2]);
-      }
-  if (HAS_NEXT) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) scur[f][kb] = snext[f][kb];
-  }
-}
-
-template <typename T, int DP>
-__global__ __launch_bounds__(256) void attn_w64_kernel(AttnParams p) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  static_assert(DP == 128, "swizzles are written for 256-byte rows");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 2 * TILE_B];
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
-  const long b = bh / p.heads, h = bh % p.heads;
-  const long q0 = qb * AB_QB + wv * 64;
-  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
-  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
-  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
-  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
-
-  v8 qf[2][KS];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const long qr = q0 + f * 32 + l31;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
-      qf[f][ks] = __builtin_bit_cast(v8, raw);
-    }
-  }
-  f32x16 oacc[2][DB];
-#pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[f][d][r] = 0.f;
-  float m_raw[2] = {-1.0e30f, -1.0e30f}, lsum[2] = {0.f, 0.f};
-  const float c = p.scale_log2;
-  const float thr = 8.0f / c;
-
-  // LDS-DMA: wave wv owns rows 16*wv .. 16*wv+15 of K and of V (4 pieces of 4 rows each)
-  const BufView kbv = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
-  const BufView vbv = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
-  unsigned kvoff[4], vvoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wv * 16 + i * 4 + (lane >> 4), slot = lane & 15;
-    kvoff[i] = (unsigned)((row * p.k_ss + ((slot ^ (row & 15)) << 3)) * sizeof(T));
-    vvoff[i] = (unsigned)((row * p.v_ss + ((slot ^ ((row & 3) << 2)) << 3)) * sizeof(T));
-  }
-  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
-  auto dma_tile = [&](long t, int stage) {
-    unsigned char* Ks = smem + stage * 2 * TILE_B;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      buf_load16_lds(kbv, kvoff[i], (unsigned)t * k_step, Ks + (wv * 16 + i * 4) * ROWB);
-      buf_load16_lds(vbv, vvoff[i], (unsigned)t * v_step, Ks + TILE_B + (wv * 16 + i * 4) * ROWB);
-    }
-  };
-  int kaddr[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
-  int vaddr[DB];
-  {
-    const int ti = lane & 15, g1 = (lane >> 4) & 1;
-    const int vrow = hi * 4 + (ti >> 2);
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-      vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
-  }
-
-  const long ntiles = (p.sk + AB_KV - 1) / AB_KV;
-  const long kv_last = p.sk - (ntiles - 1) * AB_KV;
-  dma_tile(0, 0);
-  if (ntiles > 1) dma_tile(1, 1);
-  MTX_WAIT_VMEM();
-  __syncthreads();
-  f32x16 scur[2][2], snext[2][2];
-  {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const v8 kf = *reinterpret_cast<const v8*>(smem + kaddr[ks] + kb * 32 * ROWB);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          if (ks == 0) Mma32Pinned<T>::set_vgpr(scur[f][kb], kf, qf[f][ks]); else Mma32Pinned<T>::acc_vgpr(scur[f][kb], kf, qf[f][ks]);
-        }
-      }
-  }
-#define ATTN_W64_STEP(VS, NEXT, RAG, KV)                                                                           \
-  attn_w64_step<T, DP, VS, NEXT, RAG>(smem, qf, oacc, scur, snext, m_raw, lsum, c, thr, kaddr, vaddr, KV, hi)
-#define ATTN_W64_SYNC() { MTX_WAIT_VMEM(); MTX_LDS_BARRIER(); }
-  long t = 0;
-  for (; t + 3 < ntiles; t += 3) {
-    dma_tile(t + 2, 2); ATTN_W64_STEP(0, true, false, AB_KV); ATTN_W64_SYNC();
-    dma_tile(t + 3, 0); ATTN_W64_STEP(1, true, false, AB_KV); ATTN_W64_SYNC();
-    if (t + 4 < ntiles) dma_tile(t + 4, 1);
-    ATTN_W64_STEP(2, true, false, AB_KV); ATTN_W64_SYNC();
-  }
-  const long left = ntiles - t;
-  const bool rag = kv_last < AB_KV;
-  if (left == 1) {
-    if (rag) ATTN_W64_STEP(0, false, true, kv_last); else ATTN_W64_STEP(0, false, false, AB_KV);
-  } else if (left == 2) {
-    ATTN_W64_STEP(0, true, false, AB_KV); ATTN_W64_SYNC();
-    if (rag) ATTN_W64_STEP(1, false, true, kv_last); else ATTN_W64_STEP(1, false, false, AB_KV);
-  } else {
-    dma_tile(t + 2, 2); ATTN_W64_STEP(0, true, false, AB_KV); ATTN_W64_SYNC();
-    ATTN_W64_STEP(1, true, false, AB_KV); ATTN_W64_SYNC();
-    if (rag) ATTN_W64_STEP(2, false, true, kv_last); else ATTN_W64_STEP(2, false, false, AB_KV);
-  }
-#undef ATTN_W64_STEP
-#undef ATTN_W64_SYNC
-
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const float l = half_sum(lsum[f]);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    const long qr = q0 + f * 32 + l31;
-    if (qr < p.sq) {
-#pragma unroll
-      for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          v4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[f][d][g * 4 + r] * inv);
-          *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
-        }
-    }
-  }
-}
-
-// =====================================================================================================
-// Two-workgroups-per-CU variant of the long-sequence kernel: 4 waves x 32 query rows = 128 queries per workgroup, 64 KB of LDS
-// (two K|V stages), at most 256 registers, so TWO workgroups share a CU and every SIMD hosts one wave of each.  The per-tile
-// barrier of the 8-wave kernel re-aligns the two waves of a SIMD at every tile, so their MFMA phases (2 x 1024 cycles per tile
-// pair) and their VALU softmax phases (2 x ~900) add up instead of overlapping (measured: MFMA busy 53 %, tile time = the sum).
-// Two independent workgroups have no common barrier: they start at different times and drift, and one's matrix phase runs under
-// the other's softmax.  Price: every K/V tile is staged twice per CU (once per workgroup).
-//   * K/V tiles arrive by LDS-DMA (buffer_load ... lds, swizzles applied on the source address): no staging registers, no ds_write;
-//     tile t+1 is put in flight right after the barrier that ends tile t-1 and waited for (vmcnt(0)) before the barrier that ends t.
-//   * compute of a tile = attn_mma32_tile (same fragment layouts, same deferred-max softmax).
-constexpr int AD_QB = 128;
-template <typename T, int DP>
-__global__ __launch_bounds__(256, 2) void attn_duo_kernel(AttnParams p) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  static_assert(DP == 128, "swizzles are written for 256-byte rows");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B];          // 64 KB: two K|V stages
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  unsigned vb, part = 0, nparts = 1;
-  if (blockIdx.x < p.n_full) vb = xcd_remap(blockIdx.x, p.n_full);
-  else { const unsigned i = blockIdx.x - p.n_full; vb = p.n_full + i / p.split; part = i % p.split; nparts = p.split; }
-  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
-  const long b = bh / p.heads, h = bh % p.heads;
-  const long q0 = qb * AD_QB + wv * 32;
-  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
-  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
-  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
-  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
-
-  v8 qf[KS];
-  {
-    const long qr = q0 + l31;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
-      qf[ks] = __builtin_bit_cast(v8, raw);
-    }
-  }
-  f32x16 oacc[DB];
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-  float m_raw = -1.0e30f, lsum = 0.f;
-  const float c = p.scale_log2;
-  const float thr = 8.0f / c;
-
-  // LDS-DMA plan: one wave instruction moves 1 KB = 4 rows of 256 B; wave wv owns rows 16*wv .. 16*wv+15 of K and of V.
-  // lane -> (row = base + lane/16, slot lane%16); the slot holds global chunk slot ^ swizzle(row)
-  const BufView kbv = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
-  const BufView vbv = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
-  unsigned kvoff[4], vvoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wv * 16 + i * 4 + (lane >> 4), slot = lane & 15;
-    kvoff[i] = (unsigned)((row * p.k_ss + ((slot ^ (row & 15)) << 3)) * sizeof(T));
-    vvoff[i] = (unsigned)((row * p.v_ss + ((slot ^ ((row & 3) << 2)) << 3)) * sizeof(T));
-  }
-  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
-  auto dma_tile = [&](long t, int stage) {
-    unsigned char* Ks = smem + stage * 2 * TILE_B;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      buf_load16_lds(kbv, kvoff[i], (unsigned)t * k_step, Ks + (wv * 16 + i * 4) * ROWB);
-      buf_load16_lds(vbv, vvoff[i], (unsigned)t * v_step, Ks + TILE_B + (wv * 16 + i * 4) * ROWB);
-    }
-  };
-
-  int kaddr[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
-  int vaddr[DB];
-  {
-    const int ti = lane & 15, g1 = (lane >> 4) & 1;
-    const int vrow = hi * 4 + (ti >> 2);
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-      vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
-  }
-
-  const long ntiles_all = (p.sk + AB_KV - 1) / AB_KV;
-  const long t_begin = part * ntiles_all / nparts, ntiles = (part + 1) * ntiles_all / nparts;
-  const long kv_last = ntiles == ntiles_all ? p.sk - (ntiles_all - 1) * AB_KV : AB_KV;
-  dma_tile(t_begin, 0);
-  MTX_WAIT_VMEM();
-  __syncthreads();
-#define ATTN_DUO_SYNC() { MTX_WAIT_VMEM(); MTX_LDS_BARRIER(); }
-  long t = t_begin;
-  for (; t + 2 < ntiles; t += 2) {             // two full tiles per iteration: the stage is a compile-time constant
-    dma_tile(t + 1, 1);
-    attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
-    ATTN_DUO_SYNC();
-    dma_tile(t + 2, 0);
-    attn_mma32_tile<T, DP, 1, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
-    ATTN_DUO_SYNC();
-  }
-  if (t + 2 == ntiles) {                       // two tiles left, the second possibly ragged
-    dma_tile(t + 1, 1);
-    attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
-    ATTN_DUO_SYNC();
-    if (kv_last < AB_KV) attn_mma32_tile<T, DP, 1, true>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
-    else attn_mma32_tile<T, DP, 1, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
-  } else {
-    if (kv_last < AB_KV) attn_mma32_tile<T, DP, 0, true>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, kv_last, hi);
-    else attn_mma32_tile<T, DP, 0, false>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, AB_KV, hi);
-  }
-#undef ATTN_DUO_SYNC
-
-  if (nparts > 1) {                            // key-split tail: unnormalised O^T (fp32), row maximum and row sum for the merge kernel
-    const unsigned slot = blockIdx.x - p.n_full;
-    const int row = wv * 32 + l31;
-    float* PO = p.part_o + ((size_t)slot * AD_QB + row) * DP;
-    const float lrow = half_sum(lsum);
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 o = {oacc[d][g * 4 + 0], oacc[d][g * 4 + 1], oacc[d][g * 4 + 2], oacc[d][g * 4 + 3]};
-        *reinterpret_cast<f32x4*>(PO + d * 32 + g * 8 + hi * 4) = o;
-      }
-    if (hi == 0) { p.part_ml[((size_t)slot * AD_QB + row) * 2] = m_raw; p.part_ml[((size_t)slot * AD_QB + row) * 2 + 1] = lrow; }
-    return;
-  }
-  const float l = half_sum(lsum);
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  const long qr = q0 + l31;
-  if (qr < p.sq) {
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[d][g * 4 + r] * inv);
-        *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
-      }
-  }
-}
-
 // merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
-template <typename T, int DP, int QB = AB_QB>
+template <typename T, int DP>
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
-  constexpr unsigned BANDS = QB / 32;
+  constexpr unsigned BANDS = AB_QB / 32;
   const unsigned tail = blockIdx.x / BANDS, band = blockIdx.x % BANDS;      // tail query block, 32-row band
   const unsigned vb = p.n_full + tail;
   const long bh = vb / p.qblocks, qb = vb % p.qblocks;
@@ -1370,13 +621,13 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
   T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
   for (int idx = threadIdx.x; idx < 32 * (DP / 8); idx += 256) {
     const int row = band * 32 + idx / (DP / 8), ch = idx % (DP / 8);
-    const long qr = qb * QB + row;
+    const long qr = qb * AB_QB + row;
     if (qr >= p.sq) continue;
     float M = -1.0e30f;
-    for (unsigned s = 0; s < p.split; ++s) { const float m = p.part_ml[((size_t)(tail * p.split + s) * QB + row) * 2]; M = m > M ? m : M; }
+    for (unsigned s = 0; s < p.split; ++s) { const float m = p.part_ml[((size_t)(tail * p.split + s) * AB_QB + row) * 2]; M = m > M ? m : M; }
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
     for (unsigned s = 0; s < p.split; ++s) {
-      const size_t base = (size_t)(tail * p.split + s) * QB + row;
+      const size_t base = (size_t)(tail * p.split + s) * AB_QB + row;
       const float w = fast_exp2((p.part_ml[base * 2] - M) * p.scale_log2);
       L += w * p.part_ml[base * 2 + 1];
       const float* po = p.part_o + base * DP + ch * 8;
@@ -1409,23 +660,6 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
   if (p.d == 128 && p.sq >= 1024 && p.sk >= 256) {       // long sequences: the 8-wave 32x32x16 kernel
     p.qblocks = (unsigned)((p.sq + AB_QB - 1) / AB_QB);
     const unsigned total = (unsigned)(p.batch * p.heads) * p.qblocks;
-    const char* e = getenv("MTX_ATTN_KERNEL");           // A/B switch: "pipe" = the S^T-pipelined LDS-DMA variant (no tail split)
-    if (e && e[0] == 'd') {                              // "duo": 128-query workgroups, two per CU
-      p.qblocks = (unsigned)((p.sq + AD_QB - 1) / AD_QB);
-      const unsigned total2 = (unsigned)(p.batch * p.heads) * p.qblocks, slots = 2u * (unsigned)attn_num_cus(), rem2 = total2 % slots;
-      const unsigned nt = (unsigned)((p.sk + AB_KV - 1) / AB_KV);
-      unsigned split2 = (rem2 > 0 && total2 > slots) ? slots / rem2 : 1;
-      if (split2 > 8) split2 = 8;
-      if (split2 > nt / 2) split2 = nt / 2;
-      const char* ns2 = getenv("MTX_ATTN_NOSPLIT");
-      if (split2 < 2 || p.part_o == nullptr || (ns2 && ns2[0] == '1')) { p.n_full = total2; p.split = 1; }
-      else { p.n_full = total2 - rem2; p.split = split2; }
-      MTX_LAUNCH((attn_duo_kernel<T, 128>), dim3(p.n_full + (total2 - p.n_full) * p.split), dim3(256), 0, stream, p);
-      if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128, AD_QB>), dim3((total2 - p.n_full) * (AD_QB / 32)), dim3(256), 0, stream, p);
-      return MTX_OK;
-    }
-    if (e && e[0] == 'p') { MTX_LAUNCH((attn_pipe_kernel<T, 128>), dim3(total), dim3(512), 0, stream, p); return MTX_OK; }
-    if (e && e[0] == 'w') { MTX_LAUNCH((attn_w64_kernel<T, 128>), dim3(total), dim3(256), 0, stream, p); return MTX_OK; }
     // one workgroup per CU at a time: a partial last wave of `rem` query blocks leaves most of the chip idle for a
     // whole block time, so cut those blocks into `split` key ranges (fp32 partials in the caller's scratch) + merge
     const unsigned cus = (unsigned)attn_num_cus(), rem = total % cus;
@@ -1433,20 +667,13 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     unsigned split = (rem > 0 && total > cus) ? cus / rem : 1;
     if (split > 8) split = 8;
     if (split > ntiles / 2) split = ntiles / 2;          // at least two key tiles per part
-    const char* ns = getenv("MTX_ATTN_NOSPLIT");
-    if (split < 2 || p.part_o == nullptr || (ns && ns[0] == '1')) { p.n_full = total; p.split = 1; }
+    if (split < 2 || p.part_o == nullptr) { p.n_full = total; p.split = 1; }
     else { p.n_full = total - rem; p.split = split; }
     const unsigned g = p.n_full + (total - p.n_full) * p.split;
-    // one barrier per tile is the default; "stag" = the half-tile staggered schedule (measured equal: 1092 vs 1091 TFLOP/s —
-    // the two waves of a SIMD already drift into complementary phases between barriers)
-    if (e && e[0] == 's') MTX_LAUNCH((attn_mma32_kernel<T, 128, 1>), dim3(g), dim3(512), 0, stream, p);
-    else if (e && e[0] == '2') MTX_LAUNCH((attn_mma32_kernel<T, 128, 2>), dim3(g), dim3(512), 0, stream, p);
-    else if (e && e[0] == '3') MTX_LAUNCH((attn_mma32_kernel<T, 128, 3>), dim3(g), dim3(512), 0, stream, p);
-    else if (e && e[0] == '4') MTX_LAUNCH((attn_mma32_kernel<T, 128, 4>), dim3(g), dim3(512), 0, stream, p);
-    else if (e && e[0] == 'b') MTX_LAUNCH((attn_mma32_kernel<T, 128, 5>), dim3(g), dim3(512), 0, stream, p);
-    else if (e && e[0] == 'n') MTX_LAUNCH((attn_mma32_kernel<T, 128, 6>), dim3(g), dim3(512), 0, stream, p);
-    else if (p.prescaled && !e) MTX_LAUNCH((attn_mma32_kernel<T, 128, 6>), dim3(g), dim3(512), 0, stream, p);      // exact: no rounding added by the x 1.0
-    else MTX_LAUNCH((attn_mma32_kernel<T, 128, 0>), dim3(g), dim3(512), 0, stream, p);
+    // schedules tried against this one and dropped (DESIGN.md §9 keeps the numbers): half-tile staggered wave groups, fragment reads
+    // pinned 2-4 k-steps ahead, an S^T-pipelined LDS-DMA ring, 4 waves x 64 rows, two 128-query workgroups per CU — all equal or slower
+    if (p.prescaled) MTX_LAUNCH((attn_mma32_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+    else MTX_LAUNCH((attn_mma32_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
     if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
     return MTX_OK;
   }

@@ -318,7 +318,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
 }
 
 static int g_num_cus = 0;
-static int abl_mode() { const char* e = getenv("MTX_C64_ABL"); return e ? atoi(e) : 0; }
 
 static int c64_num_cus(const char** err) {
   if (g_num_cus == 0) {
@@ -367,19 +366,13 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
       hipMemsetAsync(a->chan_sum, 0, (size_t)a->n * grid * 8 * a->cout * sizeof(float), (hipStream_t)stream) != hipSuccess) {
     *err = "conv2d: chan_sum memset failed"; return MTX_ERR_HIP;
   }
-  const int abl = abl_mode();
 #define C64_GO(TT, AB, AC, SM) MTX_LAUNCH((conv3x3_c64_kernel<TT, AB, AC, SM>), dim3(grid), dim3(512), 0, stream, p)
 #define C64_ACT(TT, SM) do { if (a->act == MTX_ACT_NONE) C64_GO(TT, 0, MTX_ACT_NONE, SM); else if (a->act == MTX_ACT_RELU) C64_GO(TT, 0, MTX_ACT_RELU, SM); \
                              else C64_GO(TT, 0, -1, SM); } while (0)
   const bool sum = a->chan_sum != nullptr;
   if (a->dtype == MTX_BF16) { if (sum) C64_ACT(__bf16, true); else C64_ACT(__bf16, false); }
   else if (a->dtype == MTX_F16) {
-    if (abl == 1) C64_GO(_Float16, 1, MTX_ACT_RELU, false);
-    else if (abl == 3) C64_GO(_Float16, 3, MTX_ACT_RELU, false);
-    else if (abl == 4) C64_GO(_Float16, 4, MTX_ACT_RELU, false);
-    else if (abl == 5 && !sum && a->act == MTX_ACT_RELU) C64_GO(_Float16, 5, MTX_ACT_RELU, false);
-    else if (abl == 5 && !sum && a->act == MTX_ACT_NONE) C64_GO(_Float16, 5, MTX_ACT_NONE, false);
-    else if (sum) C64_ACT(_Float16, true);
+    if (sum) C64_ACT(_Float16, true);
     else C64_ACT(_Float16, false);
   }
   else { *err = "conv2d: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }

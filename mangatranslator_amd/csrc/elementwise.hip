@@ -142,12 +142,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(mtx_ew_args p) {
   T* Y = reinterpret_cast<T*>(p.y) + row * p.ldy;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long nch = p.c / 8;
+  const long valid = p.i0 > 0 ? p.i0 : p.c;          // columns >= valid are padding: no weight, output 0
   const float sc = p.act_param * 1.4426950408889634f;
   float m = -3.0e38f;
   for (long ch = tid; ch < nch; ch += 256) {
     float f[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m = f[e] > m ? f[e] : m;
+    for (int e = 0; e < 8; ++e) m = (ch * 8 + e < valid && f[e] > m) ? f[e] : m;
   }
   m = wave_max(m);
   if (lane == 0) red[wv] = m;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(mtx_ew_args p) {
   for (long ch = tid; ch < nch; ch += 256) {
     float f[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s += exp2f((f[e] - m) * sc);
+    for (int e = 0; e < 8; ++e) s += ch * 8 + e < valid ? exp2f((f[e] - m) * sc) : 0.f;
   }
   s = wave_sum(s);
   if (lane == 0) red[4 + wv] = s;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(mtx_ew_args p) {
   for (long ch = tid; ch < nch; ch += 256) {
     float f[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = exp2f((f[e] - m) * sc) * inv;
+    for (int e = 0; e < 8; ++e) f[e] = ch * 8 + e < valid ? exp2f((f[e] - m) * sc) * inv : 0.f;
     *reinterpret_cast<u32x4*>(Y + ch * 8) = pack8<T>(f);
   }
 }

@@ -414,9 +414,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 // instruction, twice the bf16 rate).  A 128-byte LDS row now holds 128 k, so a stage is one K = 128 tile = two k-steps; each
 // k-step is split into two segments of 4 MFMAs (64 cycles each) so a segment still occupies the matrix pipe for 256 cycles and
 // the bytes the DMA and the fragment reads move per pipe cycle are those of the 16-bit kernel.
-//   * lane (row l31, half hi) of k-step ks feeds the instruction the 32 bytes of logical chunks 4 ks + 2 hi, +1 — one MX block,
-//     index 2 ks + hi of the K tile — for both operands, so the pairing of k indices between A and W is by construction and
-//     one scale byte per lane applies: byte 2 ks of (scale word >> 8 hi).
+//   * operand layout of the instruction, measured with tools/probes/mx_probe.hip (profiles/r02_mx_probe.txt): lane (row, half h) holds
+//     k = 16 h + 0..15 in its first 16 bytes and k = 32 + 16 h + 0..15 in its second 16 bytes; the 32 k of MX block b (b = 0, 1) take
+//     their scale from lane (row, b).  So lane (row l31, half hi) of k-step ks reads logical chunks 4 ks + hi (block 2 ks) and
+//     4 ks + 2 + hi (block 2 ks + 1) and SUPPLIES the scale of block 2 ks + hi: byte 2 ks of (scale word >> 8 hi).
 //   * the scale words of tile kt+1 (4 A rows + 2 W rows per lane) are fetched with plain global loads in the first load segment
 //     of tile kt and first touched after the vmcnt(0) that ends the tile.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -465,7 +466,7 @@ __device__ __forceinline__ void gemm256_f8_loop(const GemmParams& p, unsigned ch
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int ch = 4 * ks + 2 * hi + e;
+        const int ch = 4 * ks + 2 * e + hi;
         aaddr[st_][ks][e] = st_ * G2_STAGE + ar0 * 128 + ((ch ^ ((ar0 >> 1) & 7)) << 4);
         waddr[st_][ks][e] = st_ * G2_STAGE + wr0 * 128 + ((ch ^ ((wr0 >> 1) & 7)) << 4);
       }

@@ -236,8 +236,10 @@ inline unsigned char emu_f32_to_e4m3(float f) {          // round to nearest eve
   if (m == 8) { m = 0; ++e; }
   return s | (unsigned char)(((e + 7) << 3) | m);
 }
-// D = A(32x64) * B(64x32) + C with one E8M0 scale per lane: lane l holds 32 e4m3 bytes A[l&31][32*(l>>5) + 0..31] (B alike,
-// column l&31) and applies 2^(byte OPSEL of its scale word - 127) to them (v_mfma_scale_f32_32x32x64_f8f6f4, cbsz = blgp = 0)
+// D = A(32x64) * B(64x32) + C, MX block scales (v_mfma_scale_f32_32x32x64_f8f6f4, cbsz = blgp = 0), as measured on gfx950 with
+// tools/probes/mx_probe.hip: lane l = (row l&31, half h = l>>5) holds e4m3 bytes A[row][16 h + 0..15] in its first 16 bytes and
+// A[row][32 + 16 h + 0..15] in its second 16 bytes (B alike, column l&31); the 32 k of block b = 0, 1 are scaled by 2^(byte OPSEL of the
+// scale word of lane (row, b) - 127).
 typedef __attribute__((ext_vector_type(8))) int emu_i32x8;
 typedef __attribute__((ext_vector_type(16))) float emu_f32x16_;
 inline emu_f32x16_ emu_mfma_scale_32x32x64_f8(emu_i32x8 a, emu_i32x8 b, emu_f32x16_ c, int opa, int sa, int opb, int sb) {
@@ -251,12 +253,14 @@ inline emu_f32x16_ emu_mfma_scale_32x32x64_f8(emu_i32x8 a, emu_i32x8 b, emu_f32x
   for (int r = 0; r < 16; ++r) {
     int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
     double s = 0.0;
-    for (int hb = 0; hb < 2; ++hb) {
-      const unsigned char* pa = w.xa[hb * 32 + row];
-      const unsigned char* pb = w.xb[hb * 32 + col];
+    for (int blk = 0; blk < 2; ++blk) {                       // MX block: k = 32 blk .. 32 blk + 31, scales from lanes (row, blk), (col, blk)
       double part = 0.0;
-      for (int i = 0; i < 32; ++i) part += (double)emu_e4m3_to_f32(pa[i]) * (double)emu_e4m3_to_f32(pb[i]);
-      s += ldexp(part, (int)pa[32] - 127 + (int)pb[32] - 127);
+      for (int hb = 0; hb < 2; ++hb) {                        // the lane half that holds k = 32 blk + 16 hb + 0..15, in its bytes 16 blk ..
+        const unsigned char* pa = w.xa[hb * 32 + row] + 16 * blk;
+        const unsigned char* pb = w.xb[hb * 32 + col] + 16 * blk;
+        for (int i = 0; i < 16; ++i) part += (double)emu_e4m3_to_f32(pa[i]) * (double)emu_e4m3_to_f32(pb[i]);
+      }
+      s += ldexp(part, (int)w.xa[blk * 32 + row][32] - 127 + (int)w.xb[blk * 32 + col][32] - 127);
     }
     d[r] += (float)s;
   }

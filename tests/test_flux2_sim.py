@@ -20,5 +20,11 @@ def test_flux2_vae(emu_lib):
     fc.check_vae(emu_lib, "cpu", h=32, w=48)
 
 
+def test_flux2_vae_token_count_not_multiple_of_8(emu_lib):
+    """a 48 x 80 crop has 6 x 10 = 60 latent positions in the mid-block attention: the key axis is padded to 64 and masked in the softmax
+    (Klein crops are any multiple of 16, e.g. 1296 x 784 -> 15876 positions; the first config-5 bench run raised here)"""
+    fc.check_vae(emu_lib, "cpu", h=48, w=80)
+
+
 def test_flux2_klein_pipeline(emu_lib):
     fc.check_klein(emu_lib, "cpu", h=32, w=48, t_txt=8, steps=2)

@@ -101,14 +101,6 @@ def test_attention_long_sequence_kernel(hip_lib, cfg):
     oc.check_attention(hip_lib, abi.F16, **cfg)
 
 
-@pytest.mark.parametrize("kernel", ["2", "3", "stag", "pipe", "duo", "bias"])
-def test_attention_long_sequence_variants(hip_lib, monkeypatch, kernel):
-    """the A/B schedules of the long-sequence kernel (MTX_ATTN_KERNEL) compute the same attention"""
-    monkeypatch.setenv("MTX_ATTN_KERNEL", kernel)
-    oc.check_attention(hip_lib, abi.BF16, batch=1, heads=3, sq=2100, sk=2100, d=128, qmul=4.0)
-    oc.check_attention(hip_lib, abi.F16, batch=1, heads=2, sq=1100, sk=449, d=128)
-
-
 @pytest.mark.parametrize("cfg", [dict(m=8652, n=3072, k=3072, with_res=True, with_gate=True), dict(m=4100, n=9216, k=1024, act=abi.ACT_GELU_TANH),
                                  dict(m=2048, n=5000 // 8 * 8, k=320, act=abi.ACT_SILU, with_bias=False, with_res=True)])
 def test_gemm_256_tile_kernel(hip_lib, cfg):

@@ -89,19 +89,6 @@ def test_attention_long_sequence_kernel(emu_lib):
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1024, sk=448, d=128, qmul=3.0)      # 7 tiles: one left
 
 
-def test_attention_long_sequence_prefetch_variant(emu_lib, monkeypatch):
-    """MTX_ATTN_KERNEL=2: the same loop with the K / V^T fragment reads pinned ahead of their MFMAs"""
-    monkeypatch.setenv("MTX_ATTN_KERNEL", "2")
-    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0)
-
-
-def test_attention_long_sequence_bias_variant(emu_lib, monkeypatch):
-    """MTX_ATTN_KERNEL=bias: pre-scaled Q, S^T accumulators seeded with minus the running maximum (peaked rows force refreshes)"""
-    monkeypatch.setenv("MTX_ATTN_KERNEL", "bias")
-    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0)
-    oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=448, d=128, qmul=6.0)
-
-
 def test_attention_prescaled_q(emu_lib):
     """MTX_ATTN_Q_PRESCALED (what the FLUX graph passes): the long-sequence kernel runs without a per-score multiply-add and takes
     the row maximum only on the first tile or when a partial row sum explodes; short sequences go through the generic kernel"""
@@ -110,13 +97,6 @@ def test_attention_prescaled_q(emu_lib):
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1024, sk=448, d=128, qmul=40.0, prescaled=True)      # logits of +-500: refresh path
     oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=449, d=128, qmul=40.0, prescaled=True)       # f16 probabilities: limit 3e4
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=2, sq=100, sk=130, d=64, prescaled=True)
-
-
-def test_attention_long_sequence_duo_variant(emu_lib, monkeypatch):
-    """MTX_ATTN_KERNEL=duo: 128-query workgroups (two per CU), K/V by LDS-DMA; ragged last tile, key-split tail (3 simulated CUs)"""
-    monkeypatch.setenv("MTX_ATTN_KERNEL", "duo")
-    oc.check_attention(emu_lib, abi.BF16, batch=1, heads=1, sq=1030, sk=330, d=128, qmul=3.0)
-    oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=320, d=128)
 
 
 def test_gemm_256_tile_kernel(emu_lib):
