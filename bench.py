@@ -126,9 +126,10 @@ def broadcast_state_dict(sd, rank, world, device):
     keys = sorted(sd.keys())
     shapes = [tuple(sd[k].shape) for k in keys]
     sizes = [int(np.prod(s)) if len(s) else 1 for s in shapes]
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    cdev = device if dist.get_backend() == "nccl" else torch.device("cpu")       # gloo (dry runs of the N > 1 path) moves host tensors
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=cdev)
     if rank == 0:
-        flat.copy_(torch.cat([sd[k].float().reshape(-1) for k in keys]).to(device))
+        flat.copy_(torch.cat([sd[k].float().reshape(-1) for k in keys]).to(cdev))
     dist.broadcast(flat, src=0)
     out, off = {}, 0
     flat = flat.cpu()
@@ -392,7 +393,7 @@ def main():
         step(0)
         stage_wall.pop("_on")
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     pages_per_s = world * args.steps / dt

@@ -550,6 +550,11 @@ def synthetic_provider(shapes: dict, device, seed: int, broadcast: bool = False)
         if broadcast:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                dist.broadcast(t, src=0)
+                if dist.get_backend() == "nccl":
+                    dist.broadcast(t, src=0)
+                else:                                  # gloo dry runs: host staging
+                    h = t.cpu()
+                    dist.broadcast(h, src=0)
+                    t = h.to(device)
         return t
     return get
