@@ -115,7 +115,12 @@ class OutsideTextDetector:
         try:
             image_pil = image_override if image_override is not None else Image.open(image_path)
             image_pil = image_pil if image_pil.mode == "RGB" else image_pil.convert("RGB")
-            image_cv = np.ascontiguousarray(np.asarray(image_pil)[..., ::-1])         # BGR, what the detectors take
+            _bgr = []
+
+            def image_cv_():          # BGR, what the detectors take — made on first use (a 6 MP page costs 40 ms of host copy, and
+                if not _bgr:          # with provided bubbles + text_free boxes no detector runs at all)
+                    _bgr.append(np.ascontiguousarray(np.asarray(image_pil)[..., ::-1]))
+                return _bgr[0]
         except Exception as e:
             raise ImageProcessingError(f"Error loading image: {e}")
 
@@ -144,7 +149,7 @@ class OutsideTextDetector:
                 res, yolo_boxes = remembered
             else:
                 model = self.manager.load_yolo_speech_bubble(yolo_model_path if yolo_model_path is not None else bubble_detector_model)
-                res = model(image_cv, conf=confidence, device=self.device, verbose=False,
+                res = model(image_cv_(), conf=confidence, device=self.device, verbose=False,
                             imgsz=1600 if bubble_detector_model == "yolo_2" else 640, retina_masks=True)[0]
                 yolo_boxes = res.boxes.xyxy if res.boxes is not None else torch.tensor([])
                 self.cache.set_yolo_detection(key, (res, yolo_boxes))
@@ -154,7 +159,7 @@ class OutsideTextDetector:
         if (text_free_only and not text_free_boxes) or not provided:
             try:
                 sec_model = self.manager.load_rtdetr_conjoined_bubble()
-                sec = sec_model(image_cv, conf=conjoined_confidence, device=self.device, verbose=False, imgsz=640)[0]
+                sec = sec_model(image_cv_(), conf=conjoined_confidence, device=self.device, verbose=False, imgsz=640)[0]
                 sec_boxes = sec.boxes.xyxy if sec.boxes is not None else torch.tensor([])
                 sec_cls = sec.boxes.cls if sec.boxes is not None else torch.tensor([])
                 bubble_id = tf_id = None
@@ -201,7 +206,7 @@ class OutsideTextDetector:
                     res, osb_boxes, osb_confs = remembered
                 else:
                     osb_model = self.manager.load_yolo_osbtext(token=self.hf_token)
-                    res = osb_model(image_cv, conf=confidence, device=self.device, verbose=False, imgsz=640)[0]
+                    res = osb_model(image_cv_(), conf=confidence, device=self.device, verbose=False, imgsz=640)[0]
                     osb_boxes = res.boxes.xyxy if res.boxes is not None else None
                     osb_confs = res.boxes.conf if res.boxes is not None else None
                     self.cache.set_yolo_detection(key if key is not None else osb_key(), (res, osb_boxes, osb_confs))

@@ -140,6 +140,22 @@ def build_bubble_guard_mask(bubble_data, img_w: int, img_h: int, verbose: bool =
     """union of the bubbles' masks (their boxes where a mask is missing), dilated by an 11 x 11 square (reference :507-543;
     cv2.dilate with its default constant border == a maximum filter with zero padding)"""
     total = np.zeros((img_h, img_w), dtype=bool)
+    r = BUBBLE_GUARD_KERNEL // 2
+
+    def grow(window_mask, x0, y0):
+        """OR the dilation of one bubble into `total`: dilation distributes over the union, and a bubble's dilation is confined to its
+        bounding window grown by the kernel radius — same pixels as one maximum filter over the whole page (134 ms at 6 MP), at the
+        cost of the bubbles' own areas"""
+        ys, xs = np.flatnonzero(window_mask.any(axis=1)), np.flatnonzero(window_mask.any(axis=0))
+        if ys.size == 0:
+            return
+        wy0, wy1, wx0, wx1 = int(ys[0]), int(ys[-1]) + 1, int(xs[0]), int(xs[-1]) + 1
+        gy0, gy1 = max(0, y0 + wy0 - r), min(img_h, y0 + wy1 + r)
+        gx0, gx1 = max(0, x0 + wx0 - r), min(img_w, x0 + wx1 + r)
+        win = np.zeros((gy1 - gy0, gx1 - gx0), np.uint8)
+        win[y0 + wy0 - gy0: y0 + wy1 - gy0, x0 + wx0 - gx0: x0 + wx1 - gx0] = window_mask[wy0:wy1, wx0:wx1]
+        total[gy0:gy1, gx0:gx1] |= ndimage.maximum_filter(win, size=BUBBLE_GUARD_KERNEL, mode="constant", cval=0).astype(bool)
+
     for bubble in bubble_data or []:
         try:
             mask = bubble.get("sam_mask") if isinstance(bubble, dict) else None
@@ -147,21 +163,18 @@ def build_bubble_guard_mask(bubble_data, img_w: int, img_h: int, verbose: bool =
                 m = np.asarray(mask)
                 if m.ndim == 3:
                     m = m[..., 0]
-                m = m > 0
                 if m.shape[0] == img_h and m.shape[1] == img_w:
-                    total |= m
+                    grow(m > 0, 0, 0)
                     continue
             bbox = bubble.get("bbox") if isinstance(bubble, dict) else None
             if bbox and len(bbox) == 4:
                 x0, y0, x1, y1 = [int(c) for c in bbox]
                 x0, x1 = max(0, min(img_w, x0)), max(0, min(img_w, x1))
                 y0, y1 = max(0, min(img_h, y0)), max(0, min(img_h, y1))
-                if x1 > x0 and y1 > y0:
-                    total[y0:y1, x0:x1] = True
+                if x1 > x0 and y1 > y0:                      # a rectangle dilated by a square is the rectangle grown by its radius
+                    total[max(0, y0 - r): min(img_h, y1 + r), max(0, x0 - r): min(img_w, x1 + r)] = True
         except Exception as e:
             log_message(f"Warning: Failed to apply bubble mask for OSB exclusion: {e}", verbose=verbose)
-    if np.any(total):
-        total = ndimage.maximum_filter(total.astype(np.uint8), size=BUBBLE_GUARD_KERNEL, mode="constant", cval=0).astype(bool)
     return total
 
 

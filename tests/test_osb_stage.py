@@ -115,3 +115,35 @@ def test_synthetic_bench_page_sends_its_block_to_flux(monkeypatch):
     assert len(changed) > 0
     cx0, cy0, cx1, cy1 = [int(v) for v in text_boxes[0]]
     assert changed[:, 1].min() >= cx0 and changed[:, 1].max() < cx1 and changed[:, 0].min() >= cy0 and changed[:, 0].max() < cy1
+
+
+def test_bubble_guard_mask_equals_full_page_dilation():
+    """the windowed per-bubble dilation is the same set as one 11 x 11 maximum filter over the whole page (what cv2.dilate computes)"""
+    import numpy as np
+    from scipy import ndimage
+    from mangatranslator_amd.core import outside_text_processor as otp
+    rng = np.random.default_rng(4)
+    H, W = 140, 190
+    yy, xx = np.mgrid[0:H, 0:W]
+    bubbles = []
+    for k in range(6):
+        cx, cy, a, b = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(3, 40), rng.uniform(3, 30)
+        m = (((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 <= 1.0)
+        if k % 3 == 0:
+            bubbles.append({"bbox": (cx - a, cy - b, cx + a, cy + b)})                       # no mask: the box stands in
+        elif k % 3 == 1:
+            bubbles.append({"bbox": (0, 0, 1, 1), "sam_mask": m.astype(np.uint8) * 255})
+        else:
+            bubbles.append({"bbox": (0, 0, 1, 1), "sam_mask": np.repeat(m[..., None], 3, -1)})  # HxWx3 mask
+    bubbles.append({"bbox": (0, 0, 1, 1), "sam_mask": np.zeros((H, W), bool)})                # empty mask
+    total = np.zeros((H, W), bool)
+    for bub in bubbles:
+        m = bub.get("sam_mask")
+        if m is not None:
+            m = np.asarray(m)
+            total |= (m[..., 0] if m.ndim == 3 else m) > 0
+        else:
+            x0, y0, x1, y1 = [int(c) for c in bub["bbox"]]
+            total[max(0, y0):max(0, min(H, y1)), max(0, x0):max(0, min(W, x1))] = True
+    want = ndimage.maximum_filter(total.astype(np.uint8), size=11, mode="constant", cval=0).astype(bool)
+    assert np.array_equal(otp.build_bubble_guard_mask(bubbles, W, H), want)
