@@ -319,9 +319,10 @@ def clean_speech_bubbles(image_input: Union[str, Path, Image.Image], model_path,
                          thresholding_value: int = 200, use_otsu_threshold: bool = False, roi_shrink_px: int = 5, verbose: bool = False,
                          processing_scale: float = 1.0, conjoined_confidence=0.35, inpaint_colored_bubbles: bool = False,
                          bubble_detector_model: str = "yolo_2", request_coordinator: Optional[Any] = None, lib=None, **flux_options):
-    """-> (cleaned BGR[A] ndarray, list of per-bubble dicts) like the reference (:524-1048).  Colored-bubble FLUX
-    inpainting (`inpaint_colored_bubbles`) classifies the bubbles but the repaint itself goes through
-    `FluxKontextInpainter` in the caller; here every processed bubble takes the flat fill."""
+    """-> (cleaned BGR[A] ndarray, list of per-bubble dicts) like the reference (:524-1048).  With `inpaint_colored_bubbles` the bubbles
+    whose interior is not a flat colour are repainted by the configured FLUX inpainter on their text mask only (`flux_options`: the
+    reference's `inpaint_method`, `flux_*` keyword arguments, :856-1015) — through the request coordinator in waves of non-overlapping
+    context boxes when there are several; every other processed bubble takes the grouped flat fill."""
     try:
         if isinstance(image_input, (str, Path)):
             pil_image, image_path = Image.open(image_input), image_input
@@ -380,6 +381,10 @@ def clean_speech_bubbles(image_input: Union[str, Path, Image.Image], model_path,
                 processed.append({"mask": final_mask, "base_mask": base, "color": sample if sample else fill, "bbox": det.get("bbox"),
                                   "is_colored": is_colored, "text_bbox": text_bbox, "text_color_bgr": text_color, "is_sam": is_sam, "inpainted": False})
                 log_message(f"Detection {det.get('bbox')}: processed successfully", verbose=verbose)
+        method = flux_options.get("inpaint_method", "flux_kontext")
+        colored = [b for b in processed if b.get("is_colored", False)]
+        if inpaint_colored_bubbles and method not in ("opencv", "none") and colored:
+            cleaned = _repaint_colored_bubbles(cleaned, colored, method, device, request_coordinator, flux_options, verbose)
         groups = {}
         for b in processed:
             if not b.get("inpainted", False):
@@ -398,6 +403,81 @@ def clean_speech_bubbles(image_input: Union[str, Path, Image.Image], model_path,
         raise
     except Exception as e:
         raise CleaningError(f"Error cleaning speech bubbles: {str(e)}")
+
+
+def _repaint_colored_bubbles(cleaned: np.ndarray, colored: list, method: str, device, coordinator, opt: dict, verbose: bool) -> np.ndarray:
+    """FLUX repaint of the text of non-flat bubbles (reference :63-152, :856-1015).  A failure of one bubble leaves it to the flat fill;
+    a failure of the whole step leaves every bubble to it.  The reference's round trip of intermediate pages through temporary PNG files
+    is a memory measure with no effect on the pixels and has no counterpart here."""
+    import random
+    from ..batch_coordinator import expanded_mask_bbox, partition_non_overlapping_waves, paste_image_region
+    from .inpainting import FluxKleinInpainter, FluxKontextInpainter
+    log_message(f"Inpainting {len(colored)} colored bubbles with Flux", always_print=True)
+    working = Image.fromarray(np.ascontiguousarray(cleaned[..., 2::-1]))          # BGR[A] -> RGB
+    seed = opt.get("flux_seed", 1)
+    base_seed = random.randint(1, 999999) if seed == -1 else max(0, int(seed))
+    try:
+        backend = opt.get("flux_backend", "sdnq")
+        if method in ("flux_klein_9b", "flux_klein_4b"):
+            inpainter = FluxKleinInpainter(variant=method[-2:], device=device, huggingface_token=opt.get("flux_hf_token", ""),
+                                           num_inference_steps=int(opt.get("flux_num_inference_steps", 8)), low_vram=opt.get("flux_low_vram", False),
+                                           luminance_correction=opt.get("flux_luminance_correction", True),
+                                           upscale_small_crops=opt.get("flux_upscale_small_crops", True), backend=backend,
+                                           sdcpp_cache_mode=opt.get("flux_sdcpp_cache_mode", "none"),
+                                           sdcpp_diffusion_quant=opt.get("flux_sdcpp_diffusion_quant", "Q4_K_M"),
+                                           sdcpp_text_encoder_quant=opt.get("flux_sdcpp_text_encoder_quant", ""), verbose=verbose)
+        else:
+            inpainter = FluxKontextInpainter(device=device, huggingface_token=opt.get("flux_hf_token", ""),
+                                             num_inference_steps=int(opt.get("flux_num_inference_steps", 8)),
+                                             residual_diff_threshold=float(opt.get("flux_residual_diff_threshold", 0.15)), backend=backend,
+                                             low_vram=opt.get("flux_low_vram", False) if backend == "sdnq" else False,
+                                             sdcpp_cache_mode=opt.get("flux_sdcpp_cache_mode", "none"),
+                                             sdcpp_diffusion_quant=opt.get("flux_sdcpp_diffusion_quant", "Q4_K_M"),
+                                             sdcpp_text_encoder_quant=opt.get("flux_sdcpp_text_encoder_quant", ""))
+
+        def resample(page, info, mask):           # the bubble's colour for the renderer: mean grey of the repainted pixels (:50-60)
+            px = np.asarray(page.convert("RGB"))[..., ::-1][mask]
+            if px.size > 0:
+                v = int(np.clip(np.mean(px), 0, 255))
+                info["color"] = (v, v, v)
+
+        if coordinator is not None and len(colored) > 1:
+            cands = [dict(info=b, mask=b["mask"].astype(bool), seed=base_seed + i if base_seed > 0 else base_seed, bbox=b.get("bbox"),
+                          context=expanded_mask_bbox(b["mask"].astype(bool), working.size)) for i, b in enumerate(colored)]
+            waves = partition_non_overlapping_waves(cands, lambda c: c["context"])
+            log_message(f"Scheduling colored-bubble Flux in {len(waves)} wave(s)", verbose=verbose)
+            for wave in waves:
+                base = working
+
+                def make_job(c):
+                    def job():
+                        try:
+                            return c, inpainter.inpaint_mask(base.copy(), c["mask"], seed=c["seed"], verbose=verbose,
+                                                             ocr_params={"type": "colored_bubble", "bbox": c["bbox"]}), None
+                        except Exception as e:      # noqa: BLE001
+                            return c, None, e
+                    return job
+                for c, image, err in coordinator.map_ordered([make_job(c) for c in wave]):
+                    if err is not None:
+                        log_message(f"Flux inpainting failed for bubble {c['bbox']}: {err}; falling back to standard fill", always_print=True)
+                        continue
+                    working = image if c["context"] is None else paste_image_region(working, image, c["context"])
+                    c["info"]["inpainted"] = True
+                    resample(working, c["info"], c["mask"])
+        else:
+            for i, b in enumerate(colored):
+                mask = b["mask"].astype(bool)
+                kw = dict(seed=base_seed + i if base_seed > 0 else base_seed, verbose=verbose, ocr_params={"type": "colored_bubble", "bbox": b.get("bbox")})
+                try:
+                    working = coordinator.run(inpainter.inpaint_mask, working, mask, **kw) if coordinator is not None else inpainter.inpaint_mask(working, mask, **kw)
+                    b["inpainted"] = True
+                    resample(working, b, mask)
+                except Exception as e:      # noqa: BLE001
+                    log_message(f"Flux inpainting failed for bubble {b.get('bbox')}: {e}; falling back to standard fill", always_print=True)
+        return np.ascontiguousarray(np.asarray(working.convert("RGB"))[..., ::-1])       # BGR, 3 channels from here on (as the reference, :997-999)
+    except Exception as e:      # noqa: BLE001
+        log_message(f"Flux inpainting aborted; falling back to standard fill: {e}", always_print=True)
+        return cleaned
 
 
 def retry_cleaning_with_otsu(image, bubble_info, thresholding_value, roi_shrink_px, processing_scale: float = 1.0, verbose: bool = False,

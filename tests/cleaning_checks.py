@@ -6,7 +6,7 @@ from mangatranslator_amd.core.image import cleaning as cl
 from oracle import cleaning_ref as cr
 
 
-def make_page(seed=0, H=220, W=260, dark=False, touch_border=False):
+def make_page(seed=0, H=220, W=260, dark=False, touch_border=False, gradient=False):
     """BGR page with elliptical bubbles that carry strokes, ring letters ('o' shapes), dots and 1-px hairlines."""
     rng = np.random.default_rng(seed)
     page = np.full((H, W, 3), 90 if not dark else 200, np.uint8)
@@ -20,6 +20,9 @@ def make_page(seed=0, H=220, W=260, dark=False, touch_border=False):
         bg = 20 if dark else 245
         fg = 235 if dark else 25
         page[inside] = (np.clip(bg + rng.integers(-6, 7, (H, W, 1)), 0, 255).astype(np.uint8) * np.ones((1, 1, 3), np.uint8))[inside]
+        if gradient:                                            # a non-flat interior (coloured / screentoned bubble): light ramp left to right
+            ramp = np.clip(140 + 110 * (xx - (cx - a)) / (2.0 * a), 0, 255).astype(np.uint8)
+            page[inside] = np.stack([ramp, np.clip(ramp.astype(int) - 6, 0, 255).astype(np.uint8), ramp], -1)[inside]
         page[ring] = fg
         for _ in range(6):                                      # strokes
             sx, sy = int(cx + rng.uniform(-0.5, 0.5) * a), int(cy + rng.uniform(-0.5, 0.5) * b)

@@ -91,9 +91,9 @@ def cvtColor(a, code):
     if code == COLOR_BGR2HSV:                       # only ever asked for one sampled pixel: S is what the caller reads
         b, g, r = (int(v) for v in a.reshape(-1, a.shape[-1])[0][:3])
         return np.array([[[0, cr.bgr_pixel_saturation(b, g, r), max(b, g, r)]]], np.uint8)
-    if a.shape[-1] == 4:                            # RGBA <-> BGRA
+    if code == COLOR_RGBA2BGRA:                     # (== COLOR_BGRA2RGBA) four channels in, four out
         return np.ascontiguousarray(a[..., [2, 1, 0, 3]])
-    return np.ascontiguousarray(a[..., ::-1])       # RGB <-> BGR
+    return np.ascontiguousarray(a[..., 2::-1])      # COLOR_RGB2BGR / COLOR_BGR2RGB: three channels out, whatever comes in (alpha dropped)
 
 
 namespace = types.SimpleNamespace(**{k: v for k, v in globals().items() if not k.startswith("_") and k not in ("types", "np", "cr")})

@@ -599,6 +599,10 @@ CLEAN_CASES = {      # name -> (page kwargs, operator kwargs, neighbours?, RGBA 
     "otsu": (dict(seed=2), dict(use_otsu_threshold=True), False, False),
     "scaled": (dict(seed=3), dict(processing_scale=1.5, roi_shrink_px=4), False, False),
     "colored": (dict(seed=4), dict(inpaint_colored_bubbles=True, inpaint_method="none"), False, False),
+    # colored bubbles repainted by the configured FLUX inpainter (stand-in class): one by one, and in coordinator waves; BGRA page too
+    "colored_flux": (dict(seed=4, gradient=True), dict(inpaint_colored_bubbles=True, inpaint_method="flux_klein_4b", flux_seed=5, flux_num_inference_steps=3, thresholding_value=120), False, False),
+    "colored_flux_waves": (dict(seed=4, gradient=True), dict(inpaint_colored_bubbles=True, inpaint_method="flux_kontext", flux_seed=0, _coordinator=2, thresholding_value=120), False, True),
+    "colored_flux_fails": (dict(seed=4, gradient=True), dict(inpaint_colored_bubbles=True, inpaint_method="flux_klein_9b", flux_seed=7, _fail=True, thresholding_value=120), False, False),
     "neighbors": (dict(seed=5), dict(), True, False),
     "border_rgba": (dict(seed=6, touch_border=True), dict(thresholding_value=180), False, True),
     "retry": (dict(seed=7, dark=True), dict(thresholding_value=250), False, False),       # nothing passes 250 on a dark bubble -> Otsu retry
@@ -617,8 +621,18 @@ def gen_cleaning():
     from core.image import image_utils as refu
     refc.cv2 = cv2_shim.namespace
     refu.cv2 = cv2_shim.namespace
+    sys.path.insert(0, str(HERE.parent))
+    from standin_inpainter import StandInInpainter        # deterministic stand-in for both FLUX inpainter classes (records its calls)
+    refc.FluxKleinInpainter = StandInInpainter
+    refc.FluxKontextInpainter = StandInInpainter
     out = {}
     for name, (pkw, okw, neigh, rgba) in CLEAN_CASES.items():
+        okw = dict(okw)
+        StandInInpainter.calls.clear()
+        StandInInpainter.fail = bool(okw.pop("_fail", False))
+        nco = okw.pop("_coordinator", 0)
+        if nco:
+            okw["request_coordinator"] = batch_coordinator.BatchRequestCoordinator(nco)
         page, masks, bboxes = cleaning_checks.make_page(**pkw)
         dets = []
         for i, (m, bb) in enumerate(zip(masks, bboxes)):
@@ -629,12 +643,18 @@ def gen_cleaning():
         rgb = page[..., ::-1]
         pil = Image.fromarray(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]) if rgba else np.ascontiguousarray(rgb))
         cleaned, info = refc.clean_speech_bubbles(pil, None, pre_computed_detections=dets, **okw)
+        okw.pop("request_coordinator", None)
+        if nco:
+            okw["_coordinator"] = nco
+        if StandInInpainter.fail:
+            okw["_fail"] = True
         CLEAN_ARRAYS[f"{name}_cleaned"] = np.asarray(cleaned)
         CLEAN_ARRAYS[f"{name}_masks"] = np.packbits(np.stack([b["mask"] > 0 for b in info])) if info else np.zeros(0, np.uint8)
         out[name] = dict(page=pkw, op={k: v for k, v in okw.items()}, neighbors=neigh, rgba=rgba,
                          bubbles=[dict(bbox=[int(v) for v in b["bbox"]], color=[int(v) for v in b["color"]], is_colored=bool(b["is_colored"]),
                                        text_bbox=[int(v) for v in b["text_bbox"]] if b.get("text_bbox") is not None else None,
-                                       is_sam=bool(b["is_sam"])) for b in info])
+                                       is_sam=bool(b["is_sam"]), inpainted=bool(b.get("inpainted", False))) for b in info],
+                         inpaint_calls=sorted(StandInInpainter.calls, key=lambda c: c["seed"]))
     return out
 
 
@@ -714,6 +734,10 @@ def gen_batch():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cleaning":          # regenerate the cleaning-flow fixtures only
+        json.dump(gen_cleaning(), open(HERE / "cleaning_flow.json", "w"))
+        np.savez_compressed(HERE / "cleaning_flow_arrays.npz", **CLEAN_ARRAYS)
+        raise SystemExit(0)
     json.dump(gen_upscale(), open(HERE / "upscale_flow.json", "w"))
     np.savez_compressed(HERE / "upscale_flow_arrays.npz", **UPSCALE_ARRAYS)
     json.dump(gen_cleaning(), open(HERE / "cleaning_flow.json", "w"))

@@ -40,8 +40,22 @@ def _check(emu_lib, name):
         dets.append(d)
     rgb = page[..., ::-1]
     pil = Image.fromarray(np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)]) if g["rgba"] else np.ascontiguousarray(rgb))
-    op = {k: v for k, v in g["op"].items() if k != "inpaint_method"}
-    cleaned, info = cleaning.clean_speech_bubbles(pil, None, pre_computed_detections=dets, lib=emu_lib, **op)
+    op = dict(g["op"])
+    from mangatranslator_amd.core import batch_coordinator
+    from mangatranslator_amd.core.image import inpainting
+    from standin_inpainter import StandInInpainter           # the generator's stand-in, plugged in place of both FLUX inpainter classes
+    StandInInpainter.calls.clear()
+    StandInInpainter.fail = bool(op.pop("_fail", False))
+    nco = op.pop("_coordinator", 0)
+    if nco:
+        op["request_coordinator"] = batch_coordinator.BatchRequestCoordinator(nco)
+    saved = inpainting.FluxKleinInpainter, inpainting.FluxKontextInpainter
+    inpainting.FluxKleinInpainter = inpainting.FluxKontextInpainter = StandInInpainter
+    try:
+        cleaned, info = cleaning.clean_speech_bubbles(pil, None, pre_computed_detections=dets, lib=emu_lib, **op)
+    finally:
+        inpainting.FluxKleinInpainter, inpainting.FluxKontextInpainter = saved
+    assert sorted(StandInInpainter.calls, key=lambda c: c["seed"]) == g.get("inpaint_calls", [])
     want = ARR[f"{name}_cleaned"]
     assert cleaned.shape == want.shape and np.array_equal(cleaned, want), f"{(cleaned != want).any(-1).sum()} pixels differ"
     assert len(info) == len(g["bubbles"])
@@ -49,6 +63,6 @@ def _check(emu_lib, name):
     bits = np.unpackbits(ARR[f"{name}_masks"])[:len(info) * H * W].reshape(len(info), H, W).astype(bool) if info else []
     for b, w, m in zip(info, g["bubbles"], bits):
         assert [int(v) for v in b["bbox"]] == w["bbox"] and [int(v) for v in b["color"]] == w["color"]
-        assert bool(b["is_colored"]) == w["is_colored"] and bool(b["is_sam"]) == w["is_sam"]
+        assert bool(b["is_colored"]) == w["is_colored"] and bool(b["is_sam"]) == w["is_sam"] and bool(b.get("inpainted", False)) == w.get("inpainted", False)
         assert ([int(v) for v in b["text_bbox"]] if b.get("text_bbox") is not None else None) == w["text_bbox"]
         assert np.array_equal(b["mask"] > 0, m)
