@@ -76,6 +76,11 @@ typedef struct mtx_conv2d_args {
   int32_t pad_mode;              /* 0: pad k/2 on every side; 1: no pad top/left, 1 bottom/right
                                     (diffusers Downsample2D: F.pad(0,1,0,1) + conv k3 s2 p0)     */
   int32_t act_after_res;     /* 1: y = act(conv(x) + bias + res_scale * res)  (ResNet bottleneck), 0: act before the residual */
+  /* optional DEVICE pointer to {valid_h, valid_w} (stride-1 convs): the image occupies only the top-left valid_h x valid_w pixels of
+   * the h x w_in canvas; every output pixel at or beyond it is written as ZERO (and left out of chan_sum), so the next layer sees
+   * exactly the zero padding an image of that size would have.  One plan built on a bucket size then serves every smaller image
+   * (bubble crops of arbitrary size, reference core/services/translation.py:2097-2258) by rewriting two integers. */
+  const int32_t* valid_hw;
 } mtx_conv2d_args;
 
 /* C[M,N] = epilogue(A[M,K] * W[N,K]^T)   A row stride lda, C row stride ldc (elements).
@@ -184,6 +189,7 @@ typedef struct mtx_ew_args {
 typedef struct mtx_ca_args {
   const float* chan_sum; const float* w1; const float* b1; const float* w2; const float* b2;
   float* s; int32_t n, tiles, c, cr; float inv_hw;
+  const float* inv_hw_dev;       /* optional DEVICE scalar that replaces inv_hw (bucket plans: 1 / (valid_h * valid_w)) */
 } mtx_ca_args;
 
 /* image <-> tensor conversions at the page boundary (core/image/image_utils.py:351-366). */
@@ -201,6 +207,7 @@ typedef struct mtx_img_args {
   int32_t unshuffle;      /* 1 or 2 (pixel-unshuffle factor folded into the layout change) */
   float mul; float add[4];
   int32_t kind; int32_t dtype;
+  const int32_t* valid_hw;       /* optional DEVICE {valid_h, valid_w} in SOURCE pixels (kinds 0 and 3): destination pixels beyond are zero */
 } mtx_img_args;
 
 /* bilinear resize of fp32/T logits to page size fused with the >0 threshold

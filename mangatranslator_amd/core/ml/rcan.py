@@ -101,7 +101,8 @@ class RCANUpscaler:
         self._tdt = torch.float16
         self._graph = graph and not self.lib.is_simulator
         self._lock = threading.RLock()
-        self._plans = PlanCache(8)          # pages of one size reuse their plan; bubble crops come in any size and would pin memory for ever
+        self._plans = PlanCache(8)          # pages of one size reuse their plan
+        self._buckets = PlanCache(16)       # bubble crops (any size up to BUCKET_MAX) share masked bucket plans
         self._pack(state_dict)
 
     # ---- weights ----------------------------------------------------------------------------
@@ -142,7 +143,9 @@ class RCANUpscaler:
             self.add_bias = [0.0, 0.0, 0.0]
 
     # ---- graph ------------------------------------------------------------------------------
-    def _build(self, n, h, w):
+    def _build(self, n, h, w, bucket: bool = False):
+        """bucket: the plan is built on an h x w CANVAS and every layer masks its output to the image size it finds in `plan.valid`
+        (include/mtx_hip.h `valid_hw`): one plan serves every image that fits, with the zero padding of its true size"""
         hp, W = self.hp, self.W
         u = hp["unshuffle"]
         if h % u or w % u:
@@ -153,9 +156,14 @@ class RCANUpscaler:
         cin_pad = (3 * u * u + 7) // 8 * 8
         hh, ww = h // u, w // u
         a0 = pb.act(n, hh, ww, cin_pad)
+        valid_src = pb.buf((2,), torch.int32, zero=True) if bucket else None       # image size in source pixels
+        valid = pb.buf((2,), torch.int32, zero=True) if bucket else None           # ... on the trunk's grid (after the pixel unshuffle)
+        valid_up = [pb.buf((2,), torch.int32, zero=True) for _ in hp["up_keys"]] if bucket else []       # ... after each 2x stage
+        inv_hw_dev = pb.buf((1,), torch.float32, zero=True) if bucket else None
+        vk = dict(valid_hw=valid) if bucket else {}
         pb.image_convert(abi.IMG_NCHW_F32_TO_NHWC, x_in, a0.t, n, h, w, cin_pad, unshuffle=u,
-                         mul=self.rgb_range, add=self.sub_bias, label="to_nhwc")
-        head = pb.conv2d(a0, *W["head"], cout=C_, label="head")
+                         mul=self.rgb_range, add=self.sub_bias, label="to_nhwc", valid_hw=valid_src)
+        head = pb.conv2d(a0, *W["head"], cout=C_, label="head", **vk)
         tiles = pb.conv_tiles(head)
         chan_sum = pb.buf((n, tiles, C_), torch.float32)
         s_buf = pb.buf((n, C_), torch.float32)
@@ -178,21 +186,21 @@ class RCANUpscaler:
         for g in range(hp["n_resgroups"]):
             gin = cur
             for b in range(hp["n_resblocks"]):
-                pb.conv2d(cur, *W[f"g{g}b{b}c1"], cout=C_, act=abi.ACT_RELU, out=t1, label=f"g{g}b{b}.conv1")
-                pb.conv2d(t1, *W[f"g{g}b{b}c2"], cout=C_, out=t2, chan_sum=chan_sum, label=f"g{g}b{b}.conv2")
+                pb.conv2d(cur, *W[f"g{g}b{b}c1"], cout=C_, act=abi.ACT_RELU, out=t1, label=f"g{g}b{b}.conv1", **vk)
+                pb.conv2d(t1, *W[f"g{g}b{b}c2"], cout=C_, out=t2, chan_sum=chan_sum, label=f"g{g}b{b}.conv2", **vk)
                 w1, b1, w2, b2 = W[f"g{g}b{b}ca"]
-                pb.channel_attention(chan_sum, w1, b1, w2, b2, s_buf, n, tiles, C_, hp["cr"], inv_hw, label=f"g{g}b{b}.ca")
+                pb.channel_attention(chan_sum, w1, b1, w2, b2, s_buf, n, tiles, C_, hp["cr"], inv_hw, label=f"g{g}b{b}.ca", inv_hw_dev=inv_hw_dev)
                 nxt = next_buf([cur, gin, head])
                 pb.ew(abi.EW_SCALE_RES, t2, b=cur, s=s_buf, out=nxt, lds=C_, label=f"g{g}b{b}.scale_skip")
                 cur = nxt
             nxt = next_buf([cur, gin, head])
-            pb.conv2d(cur, *W[f"g{g}tail"], cout=C_, res=gin, out=nxt, label=f"g{g}.tail")
+            pb.conv2d(cur, *W[f"g{g}tail"], cout=C_, res=gin, out=nxt, label=f"g{g}.tail", **vk)
             cur = nxt
-        body = pb.conv2d(cur, *W["body_tail"], cout=C_, res=head, out=t1, label="body_tail")
+        body = pb.conv2d(cur, *W["body_tail"], cout=C_, res=head, out=t1, label="body_tail", **vk)
         up = body
-        for i in range(len(hp["up_keys"])):
-            up = pb.conv2d(up, *W[f"up{i}"], cout=4 * C_, pixel_shuffle=2, label=f"up{i}")
-        y8 = pb.conv2d(up, *W["tail"], cout=8, label="tail")
+        for i in range(len(hp["up_keys"])):       # the mask of a pixel-shuffle conv is taken on its INPUT grid
+            up = pb.conv2d(up, *W[f"up{i}"], cout=4 * C_, pixel_shuffle=2, label=f"up{i}", valid_hw=(valid if i == 0 else valid_up[i - 1]) if bucket else None)
+        y8 = pb.conv2d(up, *W["tail"], cout=8, label="tail", valid_hw=valid_up[-1] if (bucket and valid_up) else (valid if bucket else None))
         oh, ow = up.h, up.w
         y_out = pb.buf((n, 3, oh, ow), torch.float32)
         inv = 1.0 / self.rgb_range
@@ -205,7 +213,30 @@ class RCANUpscaler:
         plan = pb.build()
         plan.x_in, plan.y_out, plan.y8, plan.y_u8 = x_in, y_out, y8, y_u8
         plan.out_scale = (inv, [v * inv for v in self.add_bias])
+        plan.valid_bufs = (valid_src, valid, valid_up, inv_hw_dev) if bucket else None
         return plan
+
+    BUCKET = 64            # bucket plans: canvas sides are multiples of this ...
+    BUCKET_MAX = 256       # ... up to this (larger images — pages — get a plan of their own size)
+
+    def _bucket_plan(self, h, w):
+        """(plan, canvas_h, canvas_w) for an image of h x w source pixels (already a multiple of the unshuffle factor), or None"""
+        if max(h, w) > self.BUCKET_MAX:
+            return None
+        bh, bw = (h + self.BUCKET - 1) // self.BUCKET * self.BUCKET, (w + self.BUCKET - 1) // self.BUCKET * self.BUCKET
+        key = ("bucket", bh, bw)
+        with self._lock:
+            if key not in self._buckets:
+                self._buckets[key] = self._build(1, bh, bw, bucket=True)
+            plan = self._buckets[key]
+        u = self.hp["unshuffle"]
+        vs, v, vup, inv = plan.valid_bufs
+        vs.copy_(torch.tensor([h, w], dtype=torch.int32))
+        v.copy_(torch.tensor([h // u, w // u], dtype=torch.int32))
+        for i, t in enumerate(vup):
+            t.copy_(torch.tensor([(h // u) << (i + 1), (w // u) << (i + 1)], dtype=torch.int32))
+        inv.fill_(1.0 / float((h // u) * (w // u)))
+        return plan, bh, bw
 
     def plan_for(self, n, h, w):
         u = self.hp["unshuffle"]
@@ -235,6 +266,13 @@ class RCANUpscaler:
         x, h, w = self._padded(x.to(device=self.device, dtype=torch.float32))
         n = x.shape[0]
         with self._lock:
+            bp = self._bucket_plan(x.shape[2], x.shape[3]) if n == 1 else None
+            if bp is not None:            # small image (bubble crop): masked run on a shared canvas
+                plan, bh, bw = bp
+                plan.x_in[:, :, : x.shape[2], : x.shape[3]].copy_(x)
+                plan.run(graph=self._graph)
+                s = plan.y_out.shape[2] // bh
+                return plan.y_out[:, :, : h * s, : w * s].clone()
             plan = self.plan_for(n, x.shape[2], x.shape[3])
             plan.x_in.copy_(x)
             plan.run(graph=self._graph)
@@ -248,6 +286,13 @@ class RCANUpscaler:
         x = page_u8.to(self.device).permute(2, 0, 1).unsqueeze(0).to(torch.float32) / 255.0
         x, h, w = self._padded(x)
         with self._lock:
+            bp = self._bucket_plan(x.shape[2], x.shape[3])
+            if bp is not None:
+                plan, bh, bw = bp
+                plan.x_in[:, :, : x.shape[2], : x.shape[3]].copy_(x)
+                plan.run(graph=self._graph)
+                s = plan.y_u8.shape[1] // bh
+                return plan.y_u8[0, : h * s, : w * s].clone()
             plan = self.plan_for(1, x.shape[2], x.shape[3])
             plan.x_in.copy_(x)
             plan.run(graph=self._graph)

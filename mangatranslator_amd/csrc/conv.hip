@@ -33,6 +33,7 @@ struct ConvParams {
   int res_bcast;
   int pad_lo;       // zero padding on the top/left side
   int tiles_x, tiles_y, nblk;
+  const int* valid_hw;   // device {valid_h, valid_w} or null (stride 1 only): outputs beyond are zero
 };
 
 template <int KS, int S>
@@ -185,11 +186,13 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
   float csum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+  const int vh = p.valid_hw ? p.valid_hw[0] : p.ho, vw = p.valid_hw ? p.valid_hw[1] : p.wo;
   for (int idx = tid; idx < C::NPIX * 8; idx += 256) {
     const int pt = idx >> 3;
     const int oy = ty0 + (pt >> 4), ox = tx0 + (pt & 15);
     if (oy < p.ho && ox < p.wo && co < p.cout) {
       u32x4 raw = *reinterpret_cast<const u32x4*>(outs + pt * 128 + ((c ^ (pt & 7)) << 4));
+      const bool outside = oy >= vh || ox >= vw;          // beyond the image inside a bucket canvas: zero, no sums, no residual
       size_t opix;
       int oc = co;
       if (p.ps == 2) {
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
       } else {
         opix = ((size_t)img * p.ho + oy) * (size_t)p.wo + ox;
       }
-      if (p.chan_sum != nullptr || p.res != nullptr) {
+      if (outside) raw = u32x4{0u, 0u, 0u, 0u};
+      else if (p.chan_sum != nullptr || p.res != nullptr) {
         float f[8];
         unpack8<T>(raw, f);
         if (p.chan_sum != nullptr) {
@@ -291,6 +295,7 @@ int conv2d_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.n = a->n; p.h = a->h; p.w_in = a->w_in; p.cin = a->cin; p.cout = a->cout;
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldres = a->ldres;
   p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.act_after = (a->act_after_res && a->res != nullptr) ? 1 : 0; p.ps = a->pixel_shuffle; p.res_bcast = a->res_broadcast_n;
+  p.valid_hw = a->stride == 1 ? a->valid_hw : nullptr;
   int rc;
   if (a->dtype == MTX_BF16) rc = launch_conv_t<__bf16>(a, p, stream, tiles);
   else if (a->dtype == MTX_F16) rc = launch_conv_t<_Float16>(a, p, stream, tiles);

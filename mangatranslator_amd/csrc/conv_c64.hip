@@ -36,6 +36,7 @@ struct ConvC64Params {
   int ps;
   int res_bcast;
   int tiles_x, tiles_y;
+  const int* valid_hw;   // device {valid_h, valid_w} or null: outputs beyond are zero and left out of the channel sums
 };
 
 constexpr int C64_T = 16;                                  // tile edge (pixels)
@@ -266,11 +267,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
         } else {
           size_t pix_off[4];
-          bool pix_ok[4];
+          bool pix_ok[4], pix_in[4];
+          const int vh = p.valid_hw ? p.valid_hw[0] : p.h, vw = p.valid_hw ? p.valid_hw[1] : p.w_in;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int oy = ty0 + wv * 4 + i, ox = tx0 + l15;
             pix_ok[i] = oy < p.h && ox < p.w_in;
+            pix_in[i] = oy < vh && ox < vw;                    // inside the image (bucket plans: the canvas is larger)
             pix_off[i] = p.ps == 2 ? ((size_t)img * (2 * p.h) + 2 * oy) * (size_t)(2 * p.w_in) + 2 * ox
                                    : ((size_t)img * p.h + oy) * (size_t)p.w_in + ox;
           }
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
               float f[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) f[r] = apply_act_t<ACT>(acc[i][j][r] + b4[r], p.act, p.act_param);
-              if (want_sum && pix_ok[i] && ch_ok) {   // pooled statistics of the values as stored (rounded to T)
+              if (want_sum && pix_ok[i] && pix_in[i] && ch_ok) {   // pooled statistics of the values as stored (rounded to T)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { f[r] = to_f32(from_f32<T>(f[r])); csum[j][r] += f[r]; }
               }
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
               }
               v4 o;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(f[r]);
+              for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(pix_in[i] ? f[r] : 0.f);
               if (pix_ok[i] && ch_ok)
                 *reinterpret_cast<v4*>(p.y + ((pix_off[i] + sub) * (size_t)p.ldy + oc) * sizeof(T)) = o;
             }
@@ -358,6 +361,7 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.n = a->n; p.h = a->h; p.w_in = a->w_in; p.cin = a->cin; p.cout = a->cout;
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldres = a->ldres;
   p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.ps = a->pixel_shuffle; p.res_bcast = a->res_broadcast_n;
+  p.valid_hw = a->valid_hw;
   p.tiles_x = (a->w_in + C64_T - 1) / C64_T;
   p.tiles_y = (a->h + C64_T - 1) / C64_T;
   if (c64_num_cus(err) < 0) return MTX_ERR_HIP;

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
   for (int c = tid; c < p.c; c += 1024) {
     float s = 0.f;
     for (int k = 0; k < per; ++k) s += part[k * p.c + c];
-    mean[c] = s * p.inv_hw;
+    mean[c] = s * (p.inv_hw_dev ? *p.inv_hw_dev : p.inv_hw);
   }
   __syncthreads();
   for (int r = tid; r < p.cr; r += 1024) {
@@ -363,10 +363,15 @@ __global__ __launch_bounds__(256) void img_kernel(mtx_img_args p) {
     const long oh = p.h / u, ow = p.w / u;
     const long total = p.n * oh * ow;
     T* D = reinterpret_cast<T*>(p.dst);
+    const long vh = p.valid_hw ? p.valid_hw[0] : p.h, vw = p.valid_hw ? p.valid_hw[1] : p.w;
     for (long idx = tid0; idx < total; idx += step) {
       const long x = idx % ow, y = (idx / ow) % oh, n = idx / (ow * oh);
       T* o = D + idx * p.c_pad;
       int oc = 0;
+      if (y * u >= vh || x * u >= vw) {            // beyond the image inside a bucket canvas
+        for (; oc < p.c_pad; ++oc) o[oc] = from_f32<T>(0.f);
+        continue;
+      }
       // torch.pixel_unshuffle channel order: c*u*u + dy*u + dx
       for (int c = 0; c < 3; ++c)
         for (int dy = 0; dy < u; ++dy)

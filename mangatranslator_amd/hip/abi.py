@@ -22,7 +22,8 @@ class ConvArgs(C.Structure):
                 ("ksize", i32), ("stride", i32),
                 ("ldx", i32), ("ldy", i32), ("ldres", i32),
                 ("act", i32), ("act_param", f32), ("res_scale", f32),
-                ("pixel_shuffle", i32), ("dtype", i32), ("res_broadcast_n", i32), ("pad_mode", i32), ("act_after_res", i32)]
+                ("pixel_shuffle", i32), ("dtype", i32), ("res_broadcast_n", i32), ("pad_mode", i32), ("act_after_res", i32),
+                ("valid_hw", vp)]
 
 
 class GemmArgs(C.Structure):
@@ -74,7 +75,7 @@ class EwArgs(C.Structure):
 
 class CaArgs(C.Structure):
     _fields_ = [("chan_sum", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("s", vp),
-                ("n", i32), ("tiles", i32), ("c", i32), ("cr", i32), ("inv_hw", f32)]
+                ("n", i32), ("tiles", i32), ("c", i32), ("cr", i32), ("inv_hw", f32), ("inv_hw_dev", vp)]
 
 
 class ImgArgs(C.Structure):
@@ -82,7 +83,7 @@ class ImgArgs(C.Structure):
                 ("n", i64), ("h", i64), ("w", i64),
                 ("c_pad", i32), ("unshuffle", i32),
                 ("mul", f32), ("add", f32 * 4),
-                ("kind", i32), ("dtype", i32)]
+                ("kind", i32), ("dtype", i32), ("valid_hw", vp)]
 
 
 class ResizeThreshArgs(C.Structure):

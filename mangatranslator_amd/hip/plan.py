@@ -209,7 +209,7 @@ class PlanBuilder:
                act: int = abi.ACT_NONE, act_param: float = 0.0, res: Optional[Act] = None,
                res_scale: float = 1.0, out: Optional[Act] = None, pixel_shuffle: int = 0,
                chan_sum=None, res_broadcast: bool = False, pad_mode: int = 0, act_after_res: bool = False,
-               label: str = "conv") -> Act:
+               label: str = "conv", valid_hw=None) -> Act:
         pad_total = 1 if pad_mode == 1 else 2 * (ksize // 2)
         ho = (x.h + pad_total - ksize) // stride + 1
         wo = (x.w + pad_total - ksize) // stride + 1
@@ -231,6 +231,7 @@ class PlanBuilder:
         a.res_broadcast_n = 1 if res_broadcast else 0
         a.pad_mode = pad_mode
         a.act_after_res = 1 if act_after_res else 0
+        a.valid_hw = _ptr(valid_hw)
         self._add(abi.OP_CONV2D, a, label)
         return out
 
@@ -336,15 +337,17 @@ class PlanBuilder:
         self._add(abi.OP_EW, e, label)
         return out
 
-    def channel_attention(self, chan_sum, w1, b1, w2, b2, s_out, n, tiles, c, cr, inv_hw, label="ca"):
+    def channel_attention(self, chan_sum, w1, b1, w2, b2, s_out, n, tiles, c, cr, inv_hw, label="ca", inv_hw_dev=None):
         a = abi.CaArgs()
+        a.inv_hw_dev = _ptr(inv_hw_dev)
         a.chan_sum, a.w1, a.b1, a.w2, a.b2, a.s = (_ptr(chan_sum), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(s_out))
         a.n, a.tiles, a.c, a.cr, a.inv_hw = n, tiles, c, cr, inv_hw
         self._add(abi.OP_CA, a, label)
         return s_out
 
-    def image_convert(self, kind, src, dst, n, h, w, c_pad, unshuffle=1, mul=1.0, add=(0.0, 0.0, 0.0), label="img"):
+    def image_convert(self, kind, src, dst, n, h, w, c_pad, unshuffle=1, mul=1.0, add=(0.0, 0.0, 0.0), label="img", valid_hw=None):
         a = abi.ImgArgs()
+        a.valid_hw = _ptr(valid_hw)
         a.src, a.dst = _ptr(src), _ptr(dst)
         a.n, a.h, a.w, a.c_pad, a.unshuffle, a.mul = n, h, w, c_pad, unshuffle, mul
         for i in range(3):

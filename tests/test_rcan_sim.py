@@ -22,17 +22,27 @@ def test_rcan_pixel_unshuffle_odd_sizes(emu_lib):
 
 
 def test_rcan_plan_cache_is_bounded(emu_lib):
-    """one plan per distinct crop size used to pin device memory for ever"""
+    """one plan per distinct crop size used to pin device memory for ever.  Small images (bubble crops) now share
+    masked bucket plans; larger ones keep exact-size plans in an LRU that destroys what it evicts."""
     import torch
     from mangatranslator_amd.core.ml.rcan import RCANUpscaler
-    from oracle.rcan_ref import make_state_dict
-    m = RCANUpscaler(make_state_dict(n_feats=32, n_resgroups=1, n_resblocks=1, unshuffle=2), device="cpu", lib=emu_lib)
-    m._plans.capacity = 3
-    first = None
-    for i, (h, w) in enumerate([(8, 8), (9, 8), (10, 12), (12, 10), (14, 8), (8, 8)]):
-        y = m(torch.rand(1, 3, h, w))
+    from oracle.rcan_ref import load_ref, make_state_dict
+    sd = make_state_dict(n_feats=32, n_resgroups=1, n_resblocks=1, unshuffle=2)
+    m = RCANUpscaler(sd, device="cpu", lib=emu_lib)
+    ref = load_ref(sd)
+    g = torch.Generator().manual_seed(0)
+    for (h, w) in [(30, 40), (9, 8), (40, 12), (12, 10), (31, 33), (9, 8)]:          # big first: smaller crops then meet its left-overs in the buffers
+        x = torch.rand(1, 3, h, w, generator=g)
+        y = m(x)
         assert y.shape == (1, 3, 2 * h, 2 * w)
-        first = first if first is not None else m._plans[(1, 8, 8)]
-    assert len(m._plans) <= 3 and first._h is None             # the oldest plan was destroyed, and (8, 8) was simply rebuilt
+        assert (y.cpu() - ref(x)).abs().max() < 2e-2, (h, w)                      # the masked canvas run == the image's own zero padding
+    assert len(m._buckets) == 1 and len(m._plans) == 0                             # one 64 x 64 canvas served all six sizes
     u8 = m.upscale_u8(torch.zeros(7, 9, 3, dtype=torch.uint8))
     assert tuple(u8.shape) == (14, 18, 3)
+    m.BUCKET_MAX = 0                                                               # exact-size plans (what pages use): bounded LRU
+    m._plans.capacity = 3
+    first = None
+    for (h, w) in [(8, 8), (10, 8), (10, 12), (12, 10), (14, 8), (8, 8)]:
+        assert m(torch.rand(1, 3, h, w)).shape == (1, 3, 2 * h, 2 * w)
+        first = first if first is not None else m._plans[(1, 8, 8)]
+    assert len(m._plans) <= 3 and first._h is None             # the oldest plan was destroyed, and (8, 8) was simply rebuilt
