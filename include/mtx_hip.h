@@ -167,6 +167,9 @@ typedef enum mtx_ew_kind {
                                columns carry weight, the others (padding up to the 16-byte chunk) come out 0 */
   MTX_EW_TRANSPOSE = 11,  /* y[c, r] = a[r, c] for r < h*w rows, c columns (per n; ldy = row stride of y) */
   MTX_EW_AVGPOOL2 = 13,   /* 2x2 stride-2 average pool, ceil mode, divisor = in-bounds taps (ResNet-vd shortcut) */
+  MTX_EW_DWCONV = 15,     /* depthwise k x k convolution, stride 1, pad k/2 (i0 = k: 3 or 7): y[.., c] = act(sum_t a[.. + t, c] * w[t][c] + bias[c]);
+                             s = weights T [k*k][C] (tap-major), b = fp32 bias [C] (may be null) — YOLO11 head / C2PSA and YOLO12 area-attention
+                             positional convs (ultralytics DWConv, Conv(g = c)) */
   MTX_EW_SWIGLU = 14,     /* y = silu(a) * b   (FLUX.2 feed-forward: a, b = the two column halves of linear_in's output) */
   MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
                              i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then

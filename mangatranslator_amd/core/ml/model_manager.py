@@ -240,14 +240,35 @@ class ModelManager:
                     from safetensors import safe_open
                     with safe_open(str(path), framework="pt", device="cpu") as f:
                         sd = {k: f.get_tensor(k) for k in f.keys()}
+                        self._last_metadata = dict(f.metadata() or {})
                 except Exception as e:                      # truncated / foreign file
                     error = f"cannot read {path}: {e}"
         broadcast_status(error)
         if _dist_on():
-            meta = [{k: (tuple(v.shape), v.dtype) for k, v in sd.items()}] if rank0 else [None]
+            meta = [{k: (tuple(v.shape), v.dtype) for k, v in sd.items()}, getattr(self, "_last_metadata", {})] if rank0 else [None, None]
             dist.broadcast_object_list(meta, src=0)
+            self._last_metadata = meta[1] or {}
             sd = broadcast_state_dict(sd, template=meta[0])
         return sd
+
+    def _detector_from_state_dict(self, sd: dict, default_names: Optional[dict] = None):
+        """ultralytics detector checkpoint (exported with tools/export_ultralytics_state_dict.py) -> the graph of its family: YOLOv8-seg
+        (`YoloSegHip`) or YOLO11 / YOLO11-seg / YOLO12 (`Yolo11Hip`), told apart by the blocks the state dict holds.  Class names come
+        from the file's `names` metadata (what ultralytics keeps in the .pt)."""
+        import ast
+        names = None
+        raw = getattr(self, "_last_metadata", {}).get("names")
+        if raw:
+            try:
+                names = {int(k): str(v) for k, v in dict(ast.literal_eval(raw)).items()}
+            except (ValueError, SyntaxError):
+                names = None
+        names = names or default_names
+        if "model.10.m.0.attn.qkv.conv.weight" in sd or "model.6.m.0.0.attn.qkv.conv.weight" in sd:
+            from .yolo11 import Yolo11Hip
+            return Yolo11Hip(sd, device=self.device, names=names)
+        from .yolo import YoloSegHip
+        return YoloSegHip(sd, device=self.device, names=names)
 
     def _staged(self, path: Path, what: str) -> None:
         """filesystem check done by rank 0 only, verdict shared: every rank raises or none does"""
@@ -293,9 +314,8 @@ class ModelManager:
             mt, path = self._resolve_speech_bubble_model(model_path)
             if self.is_loaded(mt):
                 return self.models[mt]
-            from .yolo import YoloSegHip
             sd = self._read_safetensors(path)
-            model = YoloSegHip(sd, device=self.device, names={0: "speech_bubble"})
+            model = self._detector_from_state_dict(sd, {0: "speech_bubble"})        # yolo_1 is a YOLOv8m-seg, the default yolo_2 a YOLO11-seg
             self.models[mt] = model
             log_message(f"YOLO bubble detector loaded ({mt.value}).", verbose=verbose)
             return model
@@ -310,23 +330,40 @@ class ModelManager:
         log_message("All models unloaded.", verbose=verbose)
 
     def load_yolo_osbtext(self, token: Optional[str] = None, verbose: bool = False):
-        """OSB text detector (YOLO12x "AnimeText", reference :780-808).  The YOLO12 graph (A2C2f area attention) is not built in
-        this round: the loader raises ModelError, and the callers degrade exactly as the reference does when the
-        gated checkpoint cannot be fetched — `detect_outside_text` falls back to the secondary detector's text_free boxes
-        (ocr_detection.py:447-468) and `detect_speech_bubbles` skips OSB text verification (detection.py:196-198)."""
+        """OSB text detector (AnimeText YOLO12x, reference :780-808) as a libmtx_hip graph (core/ml/yolo11.py).  A checkpoint that is not
+        staged raises ModelError, and the callers degrade exactly as the reference does when the gated checkpoint cannot be fetched —
+        `detect_outside_text` falls back to the secondary detector's text_free boxes (ocr_detection.py:447-468) and
+        `detect_speech_bubbles` skips OSB text verification (detection.py:196-198)."""
         with self._lock:
             if self.is_loaded(ModelType.YOLO_OSBTEXT):
                 return self.models[ModelType.YOLO_OSBTEXT]
-            raise ModelError("OSB text detector (YOLO12x) is not available in this build; using the text_free fallback")
+            try:
+                sd = self._read_safetensors(self.model_paths[ModelType.YOLO_OSBTEXT])
+                model = self._detector_from_state_dict(sd, {0: "text"})
+            except ModelError:
+                raise
+            except Exception as e:
+                raise ModelError(f"Failed to load OSB Text model: {e}") from e
+            self.models[ModelType.YOLO_OSBTEXT] = model
+            log_message("OSB text detector loaded.", verbose=verbose)
+            return model
 
     def load_yolo_panel(self, verbose: bool = False):
-        """Panel detector (YOLO11-L, reference :810-838).  The YOLO11 graph (C3k2 / C2PSA blocks, depthwise head) is not built in this
-        round: the loader hands out whatever object a deployment put in the slot and otherwise raises ModelError, which
-        `detect_panels` turns into the reference's ModelError and the page flow into "Panel detection failed ... Using global sorting"."""
+        """Panel detector (YOLO11-L, reference :810-838) as a libmtx_hip graph (core/ml/yolo11.py); ModelError when the checkpoint is not
+        staged, which `detect_panels` passes on and the page flow turns into "Panel detection failed ... Using global sorting"."""
         with self._lock:
             if self.is_loaded(ModelType.YOLO_PANEL):
                 return self.models[ModelType.YOLO_PANEL]
-            raise ModelError("panel detector (YOLO11-L) is not available in this build")
+            try:
+                sd = self._read_safetensors(self.model_paths[ModelType.YOLO_PANEL])
+                model = self._detector_from_state_dict(sd, {0: "frame"})
+            except ModelError:
+                raise
+            except Exception as e:
+                raise ModelError(f"Failed to load panel detection model: {e}") from e
+            self.models[ModelType.YOLO_PANEL] = model
+            log_message("Panel detector loaded.", verbose=verbose)
+            return model
 
     def get_manga_ocr(self, verbose: bool = False):
         """manga-ocr recogniser slot (reference :856-904).  The OCR side is outside the MI355X hot path: whatever recogniser object a

@@ -94,12 +94,15 @@ class YoloSegHip:
         self.device = torch.device(device)
         self.dtype, self.tdt = abi.F16, torch.float16
         sd = fold_batchnorm({k: v.detach().float().cpu() for k, v in state_dict.items()})
-        self.a = derive_arch(sd)
+        self.a = self._derive(sd)
         self.names = names or {i: f"class{i}" for i in range(self.a["nc"])}
         self._graph = graph and not self.lib.is_simulator
         self._lock = threading.Lock()
         self._plans = PlanCache(8)
         self._pack(sd)
+
+    def _derive(self, sd):
+        return derive_arch(sd)
 
     # ---- weights ------------------------------------------------------------------------------------
     def _pack(self, sd):
@@ -259,6 +262,8 @@ class YoloSegHip:
             pb_[:, [1, 3]] = ((pb_[:, [1, 3]] - padh) / gain).clip(0, h0)
             boxes_t = torch.from_numpy(pb_).to(self.device)
             res.boxes = _Boxes(boxes_t, torch.from_numpy(sc).to(self.device), torch.from_numpy(cl.astype(np.float32)).to(self.device))
+            if nm == 0:                    # detect-only head (panel / outside-text detectors): boxes are the whole result
+                return [res]
             # retina masks
             mh, mw = plan.proto.h, plan.proto.w
             gm = min(mh / h0, mw / w0)

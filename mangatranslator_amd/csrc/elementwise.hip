@@ -66,6 +66,26 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
       if (Bp) { float g[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] += g[e]; }
+    } else if (kind == MTX_EW_DWCONV) {
+      const int k = p.i0, pd = k / 2;
+      const float* bias = reinterpret_cast<const float*>(p.b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = bias ? bias[c + e] : 0.f;
+      for (int dy = 0; dy < k; ++dy) {
+        const long iy = y - pd + dy;
+        if (iy < 0 || iy >= p.h) continue;
+        for (int dx = 0; dx < k; ++dx) {
+          const long ix = x - pd + dx;
+          if (ix < 0 || ix >= p.w) continue;
+          float g[8], wv[8];
+          unpack8<T>(*reinterpret_cast<const u32x4*>(A + ((n * p.h + iy) * p.w + ix) * p.lda + c), g);
+          unpack8<T>(*reinterpret_cast<const u32x4*>(Sp + (long)(dy * k + dx) * p.c + c), wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += g[e] * wv[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = apply_act(f[e], p.act, p.act_param);
     } else if (kind == MTX_EW_AVGPOOL2) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = 0.f;
@@ -285,10 +305,11 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
     return MTX_OK;
   }
   if (!a->a || !a->y) { *err = "elementwise: null operand"; return MTX_ERR_INVALID; }
-  if (a->c % 8 || a->lda % 8 || a->ldy % 8 || (a->b && a->ldb % 8)) { *err = "elementwise: C and pixel strides must be multiples of 8"; return MTX_ERR_INVALID; }
+  if (a->c % 8 || a->lda % 8 || a->ldy % 8 || (a->b && a->ldb % 8 && a->kind != MTX_EW_DWCONV)) { *err = "elementwise: C and pixel strides must be multiples of 8"; return MTX_ERR_INVALID; }
   if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_ADD || a->kind == MTX_EW_MUL || a->kind == MTX_EW_GATE_RES || a->kind == MTX_EW_SWIGLU) && !a->b) { *err = "elementwise: missing operand b"; return MTX_ERR_INVALID; }
   if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_GATE_RES) && !a->s) { *err = "elementwise: missing operand s"; return MTX_ERR_INVALID; }
   if (a->kind == MTX_EW_MAXPOOL && (a->i0 < 1 || a->i1 < 1)) { *err = "elementwise: maxpool needs kernel/stride"; return MTX_ERR_INVALID; }
+  if (a->kind == MTX_EW_DWCONV && (!a->s || (a->i0 & 1) == 0 || a->i0 < 1 || a->i0 > 7)) { *err = "elementwise: dwconv needs weights in s and an odd kernel <= 7"; return MTX_ERR_INVALID; }
   long oh = a->h, ow = a->w;
   if (a->kind == MTX_EW_UPSAMPLE2X) { oh *= 2; ow *= 2; }
   if (a->kind == MTX_EW_MAXPOOL) { const int pd = (a->i0 & 1) ? a->i0 / 2 : 0; oh = (a->h + 2 * pd - a->i0) / a->i1 + 1; ow = (a->w + 2 * pd - a->i0) / a->i1 + 1; }

@@ -337,6 +337,18 @@ class PlanBuilder:
         self._add(abi.OP_EW, e, label)
         return out
 
+    def dwconv(self, x: Act, w_taps, bias, ksize: int, act=abi.ACT_NONE, out: Optional[Act] = None, label="dwconv") -> Act:
+        """depthwise k x k, stride 1 (include/mtx_hip.h MTX_EW_DWCONV): w_taps T [k*k, C], bias fp32 [C] or None"""
+        if out is None:
+            out = self.act(x.n, x.h, x.w, x.c)
+        e = abi.EwArgs()
+        e.a, e.b, e.s, e.y = x.ptr, _ptr(bias), _ptr(w_taps), out.ptr
+        e.n, e.h, e.w, e.c = x.n, x.h, x.w, x.c
+        e.lda, e.ldb, e.ldy, e.lds = x.ld, 0, out.ld, 0
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_DWCONV, act, 0.0, ksize, 0, self.dtype
+        self._add(abi.OP_EW, e, label)
+        return out
+
     def channel_attention(self, chan_sum, w1, b1, w2, b2, s_out, n, tiles, c, cr, inv_hw, label="ca", inv_hw_dev=None):
         a = abi.CaArgs()
         a.inv_hw_dev = _ptr(inv_hw_dev)

@@ -128,3 +128,31 @@ def test_load_flux_klein_and_inpaint(manager, fp8):
     assert (a[far] == b[far]).all()
     inp.unload_models()
     assert not manager.is_loaded(ModelType.FLUX_KLEIN_4B_PIPELINE)
+
+
+def test_load_yolo11_family_detectors(manager):
+    """the default bubble detector (YOLO11-seg), the panel detector (YOLO11) and the OSB text detector (YOLO12) load through the same
+    state-dict reader as YOLOv8-seg and are told apart by their blocks; class names come from the file's metadata"""
+    from oracle import yolo11_ref as y11
+    from mangatranslator_amd.core.ml.model_manager import ModelType
+    from mangatranslator_amd.core.ml.yolo11 import Yolo11Hip
+    from mangatranslator_amd.utils.exceptions import ModelError
+    with pytest.raises(ModelError):
+        manager.load_yolo_panel()
+    with pytest.raises(ModelError):
+        manager.load_yolo_osbtext()
+    for mt, fam, seg, names in ((ModelType.YOLO_PANEL, "11", False, {0: "body", 1: "frame"}), (ModelType.YOLO_OSBTEXT, "12", False, {0: "text"}),
+                                (ModelType.YOLO_SPEECH_BUBBLE_2, "11", True, {0: "speech_bubble"})):
+        net = y11.make_model(fam, "n", len(names), seg, seed=1)
+        path = manager.model_paths[mt]
+        path.parent.mkdir(parents=True, exist_ok=True)
+        save_file({k: v.contiguous() for k, v in net.state_dict().items()}, str(path), metadata={"names": repr(names)})
+    panel, osb, bubble = manager.load_yolo_panel(), manager.load_yolo_osbtext(), manager.load_yolo_speech_bubble("yolo_2")
+    assert isinstance(panel, Yolo11Hip) and panel.a["family"] == "11" and not panel.a["seg"] and panel.names == {0: "body", 1: "frame"}
+    assert isinstance(osb, Yolo11Hip) and osb.a["family"] == "12" and osb.names == {0: "text"}
+    assert isinstance(bubble, Yolo11Hip) and bubble.a["seg"] and manager.load_yolo_panel() is panel
+    page = (np.random.default_rng(0).random((96, 64, 3)) * 255).astype(np.uint8)
+    res = panel(page, conf=0.0, imgsz=64, max_det=5)[0]                 # the ultralytics call shape; detect-only: boxes, no masks
+    assert res.masks is None and len(res.boxes) == 5 and res.boxes.xyxy.shape == (5, 4)
+    res = bubble(page, conf=0.0, imgsz=64, max_det=3)[0]
+    assert len(res.masks) == 3 and tuple(res.masks.data.shape[1:]) == (96, 64)

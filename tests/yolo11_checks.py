@@ -1,0 +1,75 @@
+"""YOLO11 / YOLO12 parity: libmtx_hip graphs (core/ml/yolo11.py) vs the fp32 CPU oracle (oracle/yolo11_ref.py): decoded head (boxes,
+scores, mask coefficients), final boxes after NMS, retina masks for the seg variant."""
+import numpy as np
+import torch
+
+from mangatranslator_amd.core.ml.yolo11 import Yolo11Hip
+from oracle import yolo11_ref as yr
+
+
+def make_page(h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    page = np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (xx * yy // 7) % 256], -1).astype(np.float32)
+    page += rng.normal(0, 12, page.shape)
+    return np.clip(page, 0, 255).astype(np.uint8)
+
+
+def check(lib, device, family="11", scale="n", seg=False, h=96, w=64, imgsz=64, seed=0, nc=1, tol=2e-2, mask_tol=0.03, n_det=12):
+    from oracle import yolo_ref
+    net = yr.make_model(family, scale, nc, seg, seed=seed)
+    page = make_page(h, w, seed + 1)
+    x, lp = yolo_ref.letterbox(page, imgsz)
+    # a random-weight head saturates: rescale the last conv of the box / class branches so their logits have unit spread, as a trained
+    # head's do — otherwise the DFL expectation and the sigmoid amplify f16 rounding into whole bins (same device as yolo_checks.py)
+    head = net.model[-1]
+    grabbed = {}
+    hooks = [head.cv2[l][1].register_forward_hook(lambda m, i, o, l=l: grabbed.__setitem__(("b", l), o)) for l in range(3)]
+    hooks += [head.cv3[l][1].register_forward_hook(lambda m, i, o, l=l: grabbed.__setitem__(("c", l), o)) for l in range(3)]
+    net(x)
+    for hk in hooks:
+        hk.remove()
+    with torch.no_grad():
+        for l in range(3):
+            sb = head.cv2[l][2](grabbed[("b", l)]).std().item()
+            head.cv2[l][2].weight.div_(sb); head.cv2[l][2].bias.div_(sb)
+            sc_ = head.cv3[l][2](grabbed[("c", l)]).std().item()
+            head.cv3[l][2].weight.div_(sc_); head.cv3[l][2].bias.fill_(-1.0)
+        for p_ in net.parameters():
+            p_.copy_(p_.to(torch.float16).float())
+    hip = Yolo11Hip(net.state_dict(), device=device, lib=lib, names={i: f"c{i}" for i in range(nc)})
+    assert hip.a["family"] == family and hip.a["seg"] == seg
+    pred, _ = net(x)
+    scores = pred[0, 4:4 + nc].max(0).values
+    conf = float(scores.sort(descending=True).values[min(n_det, scores.numel() - 1)])      # about a dozen candidates pass
+    ref = yr.predict(net, page, imgsz=imgsz, conf=conf)
+    res = hip(page, conf=conf, imgsz=imgsz)[0]
+    plan, _ = hip._plans[(h, w, imgsz)]
+    dec = plan.decoded.float().cpu().t()
+    want = ref["pred"]
+    box_err = (dec[:4] - want[:4]).abs().max().item()                      # letterboxed pixels
+    box_med = (dec[:4] - want[:4]).abs().median().item()
+    e_cls = (dec[4:4 + nc] - want[4:4 + nc]).abs().max().item()
+    print(f"YOLO{family}{scale}{'-seg' if seg else ''} @{lp['W']}x{lp['H']}: decoded boxes max {box_err:.3f} px (median {box_med:.4f}), class score abs err {e_cls:.4f}")
+    assert box_err < 2.0 and box_med < 0.05 and e_cls < tol
+    if seg:
+        e_mc = ((dec[4 + nc:] - want[4 + nc:]).abs().max() / want[4 + nc:].abs().max()).item()
+        assert e_mc < 2 * tol, e_mc
+    n_ref = len(ref["boxes"])
+    got = res.boxes.xyxy.cpu().numpy() if res.boxes is not None else np.zeros((0, 4), np.float32)
+    assert abs(len(got) - n_ref) <= 2, (len(got), n_ref)                   # the same set, threshold ties aside: match by position
+    matched, mism = 0, []
+    masks = res.masks.data.cpu().numpy().astype(bool) if (seg and len(got)) else None
+    for i, rb in enumerate(ref["boxes"]):
+        if not len(got):
+            break
+        d = np.abs(got - rb[None]).max(1)
+        j = int(d.argmin())
+        if d[j] < 3.0:
+            matched += 1
+            if seg:
+                mism.append(float((masks[j] != ref["masks"][i]).mean()))
+    assert matched >= n_ref - 2, (matched, n_ref)
+    if seg and mism:
+        assert max(mism) < mask_tol, f"mask mismatch {max(mism):.4%}"
+    return box_err, e_cls
