@@ -7,7 +7,7 @@ def test_yolo11n_detect(emu_lib):
 
 
 def test_yolo11n_seg(emu_lib):
-    yc.check(emu_lib, "cpu", "11", "n", True, seed=2)
+    yc.check(emu_lib, "cpu", "11", "n", True, h=192, w=128, imgsz=128, seed=2)
 
 
 def test_yolo12n_detect(emu_lib):
