@@ -16,6 +16,9 @@ def make_page(h, w, seed):
     return np.clip(page, 0, 255).astype(np.uint8)
 
 
+stats = {}          # figures of the last check (recorded by the GPU tests)
+
+
 def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, logit_tol=0.08, mask_tol=0.01):
     model, cfg = sr.make_model(size, seed)
     page = make_page(h, w, seed)
@@ -31,8 +34,20 @@ def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, l
     iou_ref = ref["iou_scores"][0, :, 0]
     iou_sel = iou.cpu()[torch.arange(n_boxes), sel.cpu().long()]
     iou_err = (iou_sel - iou_ref).abs().max().item()
-    mism = (masks.cpu().bool() != ref["masks"]).float().mean().item()
+    diff = masks.cpu().bool() != ref["masks"]
+    mism = diff.float().mean().item()
     assert err < logit_tol, f"low-res mask logits differ: rel err {err:.4f}"
     assert iou_err < 0.03, f"iou scores differ by {iou_err:.4f}"
     assert mism < mask_tol, f"{mism:.4%} of page-resolution mask pixels differ"
+    # the sharp statement (BASELINE.json: bit-exact masks after the threshold): the page-resolution logit is a convex combination of
+    # low-resolution logits, so it is off by at most the largest low-resolution error `delta`; every pixel whose fp32 logit is farther
+    # than delta from the threshold MUST come out the same, and only pixels inside that band may flip
+    import torch.nn.functional as F
+    delta = (low.float().cpu() - low_ref).abs().max().item()
+    up_ref = F.interpolate(ref["pred_masks"][0].float(), (h, w), mode="bilinear", align_corners=False)[:, 0]
+    decided = up_ref.abs() > delta
+    wrong_decided = int((diff & decided).sum().item())
+    band = float((~decided).float().mean().item())
+    stats.update(logit_rel_err=err, logit_abs_err=delta, mask_mismatch_frac=mism, undecidable_band_frac=band, decided_pixels_wrong=wrong_decided)
+    assert wrong_decided == 0, f"{wrong_decided} pixels outside the +-{delta:.3f} logit band differ"
     return err, mism

@@ -21,13 +21,13 @@ def test_sam2_hiera_large_page(hip_lib):
     """Full Hiera-L geometry (48 blocks, 1024x1024 input, head_dim 72) with seeded weights on a
     1024x1536 page with 8 boxes; the CPU oracle pass takes ~10 s."""
     err, mism = sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=1536, w=1024, n_boxes=8, seed=2,
-                              logit_tol=0.15, mask_tol=0.02)
+                              logit_tol=0.06, mask_tol=0.01)          # measured (profiles/r02_parity.json): 0.031 / 0.45 %
     print(f"hiera_large: logits rel err {err:.4f}, mask mismatch {mism:.4%}")
-    record("sam2.hiera_large.1024x1536", logit_rel_err=err, mask_mismatch_frac=mism, boxes=8)
+    record("sam2.hiera_large.1024x1536", boxes=8, **sc.stats)
 
 
 def test_sam2_hiera_large_page_2048x3072(hip_lib):
     """BASELINE config 5 page size (the encoder input stays 1024 x 1024; what grows is the antialiased down-scale and the mask up-scale)"""
-    err, mism = sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=3072, w=2048, n_boxes=8, seed=3, logit_tol=0.15, mask_tol=0.02)
+    err, mism = sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=3072, w=2048, n_boxes=8, seed=3, logit_tol=0.06, mask_tol=0.01)
     print(f"hiera_large 2048x3072: logits rel err {err:.4f}, mask mismatch {mism:.4%}")
-    record("sam2.hiera_large.2048x3072", logit_rel_err=err, mask_mismatch_frac=mism, boxes=8)
+    record("sam2.hiera_large.2048x3072", boxes=8, **sc.stats)
