@@ -37,6 +37,7 @@ struct ConvC64Params {
   int res_bcast;
   int tiles_x, tiles_y;
   const int* valid_hw;   // device {valid_h, valid_w} or null: outputs beyond are zero and left out of the channel sums
+  unsigned y_bytes;      // extent of the output tensor (buffer-descriptor stores; < 4 GiB, see conv_c64_applicable)
 };
 
 constexpr int C64_T = 16;                                  // tile edge (pixels)
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   }
   if (tid < 64) bias_s[tid] = (p.bias != nullptr && tid < p.cout) ? p.bias[tid] : 0.f;
   const int nks = p.cin > 32 ? 2 : 1;
+  const BufView ybuf = make_buf(p.y, p.y_bytes);
 
   // tile owned by this group in pair-iteration k (or ~0u when past the end)
   auto tile_of = [&](unsigned k) -> unsigned {
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       const unsigned k = (s - (unsigned)grp - 1) >> 1;
       const unsigned lin = k < K ? tile_of(k) : ~0u;
       const unsigned lin1 = k + 1 < K ? tile_of(k + 1) : ~0u;
+      bool stored = false;
       // the next tile's halo goes in flight FIRST (this group's halo buffer is idle from the slot barrier on), so its latency runs
       // behind the epilogue below (whole RCAN graph 92.4 vs 96.5 ms with it issued after the stores; ABL 5 = that older order)
       if (ABL != 3 && ABL != 5 && lin1 != ~0u) dma_halo(lin1);
@@ -266,7 +269,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
         } else {
-          size_t pix_off[4];
+          // stores go through a buffer descriptor: lanes outside the image or past cout pass an out-of-range
+          // offset (dropped by the range check), so every wave issues exactly 16 store instructions per tile
+          unsigned pix_off[4];
           bool pix_ok[4], pix_in[4];
           const int vh = p.valid_hw ? p.valid_hw[0] : p.h, vw = p.valid_hw ? p.valid_hw[1] : p.w_in;
 #pragma unroll
@@ -274,8 +279,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
             const int oy = ty0 + wv * 4 + i, ox = tx0 + l15;
             pix_ok[i] = oy < p.h && ox < p.w_in;
             pix_in[i] = oy < vh && ox < vw;                    // inside the image (bucket plans: the canvas is larger)
-            pix_off[i] = p.ps == 2 ? ((size_t)img * (2 * p.h) + 2 * oy) * (size_t)(2 * p.w_in) + 2 * ox
-                                   : ((size_t)img * p.h + oy) * (size_t)p.w_in + ox;
+            pix_off[i] = p.ps == 2 ? ((unsigned)img * (2u * p.h) + 2u * oy) * (2u * p.w_in) + 2u * ox
+                                   : ((unsigned)img * p.h + oy) * (unsigned)p.w_in + ox;
           }
           const int cps = p.cout >> 2;
 #pragma unroll
@@ -283,8 +288,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
             const int co = j * 16 + q * 4;
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + co);
             int oc = co;
-            size_t sub = 0;
-            if (p.ps == 2) { const int g = co / cps; oc = co - g * cps; sub = (size_t)(g >> 1) * (size_t)(2 * p.w_in) + (g & 1); }
+            unsigned sub = 0;
+            if (p.ps == 2) { const int g = co / cps; oc = co - g * cps; sub = (unsigned)(g >> 1) * (2u * p.w_in) + (g & 1); }
             const bool ch_ok = co < p.cout;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -303,17 +308,20 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
               v4 o;
 #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(pix_in[i] ? f[r] : 0.f);
-              if (pix_ok[i] && ch_ok)
-                *reinterpret_cast<v4*>(p.y + ((pix_off[i] + sub) * (size_t)p.ldy + oc) * sizeof(T)) = o;
+              const unsigned voff = (pix_ok[i] && ch_ok) ? ((pix_off[i] + sub) * (unsigned)p.ldy + (unsigned)oc) * (unsigned)sizeof(T)
+                                                         : p.y_bytes;
+              buf_store8(ybuf, voff, __builtin_bit_cast(u32x2, o));
             }
           }
+          stored = true;
         }
       }
       // (2) next tile's halo by LDS-DMA into this group's (now idle) halo buffer, then drain: the
       //     DMA and this tile's stores must have landed before the barrier that opens our MFMA slot.
       //     The drain overlaps the other group's MFMA slot.
+      //     The 16 stores are the youngest operations on the counter and are NOT waited for: they retire under the next slots.
       if (ABL == 5 && lin1 != ~0u) dma_halo(lin1);
-      MTX_WAIT_VMEM();
+      if (stored && ABL != 5 && ABL != 6) MTX_WAIT_VMEM_BUT(16); else MTX_WAIT_VMEM();
     }
     MTX_LDS_BARRIER();
   }
@@ -349,8 +357,14 @@ int conv_c64_tiles(int n, int h, int w) {
   return (int)c64_grid(n, h, w) * 8;
 }
 
+static unsigned long long conv_c64_out_bytes(const mtx_conv2d_args* a) {
+  const unsigned long long px = (unsigned long long)a->n * a->h * a->w_in * (a->pixel_shuffle == 2 ? 4 : 1);
+  return px * (unsigned long long)a->ldy * (a->dtype == MTX_F32 ? 4 : 2);
+}
+
 bool conv_c64_applicable(const mtx_conv2d_args* a) {
   if (a->act_after_res) return false;
+  if (conv_c64_out_bytes(a) >= 0xFFFFFFF0ull) return false;   // 32-bit store offsets
   return a->ksize == 3 && a->stride == 1 && a->cin <= 64 && a->cout <= 64;
 }
 
@@ -362,6 +376,7 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldres = a->ldres;
   p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.ps = a->pixel_shuffle; p.res_bcast = a->res_broadcast_n;
   p.valid_hw = a->valid_hw;
+  p.y_bytes = (unsigned)conv_c64_out_bytes(a);
   p.tiles_x = (a->w_in + C64_T - 1) / C64_T;
   p.tiles_y = (a->h + C64_T - 1) / C64_T;
   if (c64_num_cus(err) < 0) return MTX_ERR_HIP;

@@ -53,8 +53,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 #ifdef MTX_EMU
 #define MTX_WAIT_VMEM() ((void)0)
+#define MTX_WAIT_VMEM_BUT(n) ((void)0)
 #else
 #define MTX_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// gfx950 retires vector memory operations in issue order on one counter (loads AND stores), so
+// "all but the youngest n" is how a wave waits for its loads without waiting for the n stores it
+// issued after them.  n must be the EXACT number of operations issued since the last one waited for.
+#define MTX_WAIT_VMEM_BUT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -275,6 +280,17 @@ __device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, uns
   return r;
 #else
   return __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)voff, (int)soff, 0);
+#endif
+}
+
+// 8-byte store through a buffer descriptor.  A lane that must not write passes an offset >= the
+// descriptor's size: the range check drops it, and the instruction is still ISSUED by the wave — the
+// number of stores in flight does not depend on predicates (see MTX_WAIT_VMEM_BUT).
+__device__ __forceinline__ void buf_store8(const BufView& b, unsigned voff, u32x2 v) {
+#ifdef MTX_EMU
+  if ((unsigned long)voff + 8 <= b.bytes) memcpy(const_cast<unsigned char*>(b.base) + voff, &v, 8);
+#else
+  __builtin_amdgcn_raw_buffer_store_b64(v, b.rsrc, (int)voff, 0, 0);
 #endif
 }
 
