@@ -158,7 +158,7 @@ def _upscale_image(model, image: Image.Image, device: torch.device) -> Image.Ima
     fast = getattr(model, "upscale_u8", None)
     if fast is not None:      # uint8 page in, uint8 page out: both conversions fused into the plan
         rgb = image if image.mode == "RGB" else image.convert("RGB")
-        return Image.fromarray(fast(torch.from_numpy(np.asarray(rgb))).cpu().numpy())
+        return Image.fromarray(fast(torch.from_numpy(np.array(rgb))).cpu().numpy())
     with torch.no_grad():
         return tensor_to_image(model(image_to_tensor(image, device)))
 

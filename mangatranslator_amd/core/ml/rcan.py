@@ -102,7 +102,7 @@ class RCANUpscaler:
         self._graph = graph and not self.lib.is_simulator
         self._lock = threading.RLock()
         self._plans = PlanCache(8)          # pages of one size reuse their plan
-        self._buckets = PlanCache(16)       # bubble crops (any size up to BUCKET_MAX) share masked bucket plans
+        self._buckets = PlanCache(32)       # bubble crops (any size up to BUCKET_MAX) share masked bucket plans
         self._pack(state_dict)
 
     # ---- weights ----------------------------------------------------------------------------
@@ -217,7 +217,8 @@ class RCANUpscaler:
         return plan
 
     BUCKET = 64            # bucket plans: canvas sides are multiples of this ...
-    BUCKET_MAX = 256       # ... up to this (larger images — pages — get a plan of their own size)
+    BUCKET_MAX = 512       # ... up to this: a crop below the minimum side takes up to two passes, the second on <= 2 x its size
+                           # (larger images — pages — get a plan of their own size)
 
     def _bucket_plan(self, h, w):
         """(plan, canvas_h, canvas_w) for an image of h x w source pixels (already a multiple of the unshuffle factor), or None"""

@@ -47,9 +47,32 @@ constexpr int C64_HALO_BYTES = C64_HPIX * 128;
 constexpr int C64_BIAS_BYTES = 64 * 4;
 constexpr int C64_SMEM = C64_W_BYTES + 2 * C64_HALO_BYTES + C64_BIAS_BYTES;
 
+// MFMA in place as `asm volatile`: issue order = program order (the builtin form is free to move, and with one
+// wave per SIMD on the matrix pipe the order of reads and MFMAs is the whole schedule).  C64_FENCE pins a plain LDS
+// read between two MFMAs; the compiler still places (and counts) the s_waitcnt in front of each consumer.
+#ifdef MTX_EMU
+template <typename T> __device__ __forceinline__ void mfma_inplace(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) {
+  c = Traits<T>::mfma(a, b, c);
+}
+#define C64_FENCE() ((void)0)
+#define C64_MFMA_DRAIN() ((void)0)
+#else
+template <typename T> __device__ __forceinline__ void mfma_inplace(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b);
+template <> __device__ __forceinline__ void mfma_inplace<_Float16>(f32x4& c, const f16x8& a, const f16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void mfma_inplace<__bf16>(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+#define C64_FENCE() asm volatile("" ::: "memory")
+// the accumulators are read by vector ALU code next; the asm form hides the MFMAs from the hazard recogniser
+#define C64_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory")
+#endif
+
 // ABL: timing-only ablations for profiling (tools/probe_conv.py); 0 = the real kernel
 template <typename T, int ABL, int ACT, bool SUM>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
+  constexpr int nks_c = 2;                         // k-steps of 32 input channels (narrower inputs read zero chunks: the 3 -> 64 head conv is one launch per page)
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
   typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
@@ -79,8 +102,22 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
     *reinterpret_cast<u32x4*>(wts + row * 128 + ((c ^ (co & 7)) << 4)) = v;
   }
   if (tid < 64) bias_s[tid] = (p.bias != nullptr && tid < p.cout) ? p.bias[tid] : 0.f;
-  const int nks = p.cin > 32 ? 2 : 1;
   const BufView ybuf = make_buf(p.y, p.y_bytes);
+  // Fragment addresses of the MFMA loop, computed ONCE: with the halo swizzled by column, the address of
+  // (tile row i, tap (ky, kx), k-step ks) is xa[kx][ks] + (i + ky) * 18 * 128 and a filter fragment is
+  // wa[ks] + tap * 8 KiB + j * 2 KiB — every read of the loop is base register + immediate, and the loop
+  // carries no vector ALU instruction at all (MFMA issue shares the VALU port with them).
+  const unsigned char* wa[2];
+  const unsigned char* xa[3][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    wa[ks] = wts + l15 * 128 + (((ks * 4 + q) ^ (l15 & 7)) << 4);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int hx = l15 + kx;
+      xa[kx][ks] = halo + ((wv * 4) * C64_HW + hx) * 128 + (((ks * 4 + q) ^ (hx & 7)) << 4);
+    }
+  }
 
   // tile owned by this group in pair-iteration k (or ~0u when past the end)
   auto tile_of = [&](unsigned k) -> unsigned {
@@ -92,7 +129,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
 
   // halo staging by LDS-DMA (no staging registers): DMA instruction m of a group fills LDS rows
   // 8m .. 8m+7 of the group's halo; lane l -> row 8m + l/8, 16-byte slot l%8, which must hold chunk
-  // (slot ^ (row & 7)) of that pixel — the swizzle is applied on the per-lane SOURCE address.
+  // (slot ^ (halo column & 7)) of that pixel — the swizzle is applied on the per-lane SOURCE address.
   // Out-of-image pixels read the zero page.
   constexpr int C64_NDMA = (C64_HPIX * 8 + 63) / 64;      // 41 wave-instructions per halo
   auto dma_halo = [&](unsigned lin_in) {
@@ -110,8 +147,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       const int m = __builtin_amdgcn_readfirstlane(wv + it * 4);
       if (m < C64_NDMA) {
         const int slot = m * 64 + lane;
-        const int hp = slot >> 3, c = (slot & 7) ^ (hp & 7);
+        const int hp = slot >> 3;
         const int hy = hp / C64_HW, hx = hp - hy * C64_HW;
+        const int c = (slot & 7) ^ (hx & 7);              // swizzle by halo COLUMN: a row step is a constant LDS offset for the readers
         const int gy = iy0 + hy, gx = ix0 + hx, ch = c * 8;
         const unsigned char* src = g_zero16;
         if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_in && ch < p.cin)
@@ -173,51 +211,56 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // wave wv owns tile rows 4wv .. 4wv+3 (4 fragments of 16 px) x 64 couts (4 fragments)
-        auto load_frags = [&](int tap, int ks, v8 (&wf)[4], v8 (&xf)[4]) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-          const int cch = ks * 4 + q;
+        // wave wv owns tile rows 4wv .. 4wv+3 (4 fragments of 16 px) x 64 couts (4 fragments).
+        // Step order (kx, ks) outer, ky inner: the six halo-row fragments of one (kx, ks) serve all three ky
+        // (tile row i under tap row ky reads halo row i + ky), so a tile costs 36 + 72 fragment reads for 288 MFMAs.
+        auto load_w = [&](int st, v8 (&wf)[4]) {           // st = (kx * NKS + ks) * 3 + ky
+          const int g = st / 3, ky = st - g * 3, kx = g / nks_c, ks = g - kx * nks_c, tap = ky * 3 + kx;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int row = tap * 64 + j * 16 + l15;
-            wf[j] = *reinterpret_cast<const v8*>(wts + row * 128 + ((cch ^ (l15 & 7)) << 4));
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int lp = (wv * 4 + i + ky) * C64_HW + l15 + kx;
-            xf[i] = *reinterpret_cast<const v8*>(halo + lp * 128 + ((cch ^ (lp & 7)) << 4));
-          }
+          for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const v8*>(wa[ks] + tap * 8192 + j * 2048);
         };
-        auto mfma16 = [&](v8 (&wf)[4], v8 (&xf)[4]) {
+        auto load_x2 = [&](int g, int r0, v8 (&xr)[6]) {    // halo rows r0, r0 + 1 of group g
+          const int kx = g / nks_c, ks = g - kx * nks_c;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = Traits<T>::mfma(wf[j], xf[i], acc[i][j]);
+          for (int r = r0; r < r0 + 2; ++r) xr[r] = *reinterpret_cast<const v8*>(xa[kx][ks] + r * (C64_HW * 128));
         };
         if (ABL != 1) {
-          // two fragment sets: the LDS reads of step n+1 are in flight behind the 16 MFMAs of step n
-          // (one wave per SIMD runs this loop, nothing else hides its LDS latency)
-          v8 wfA[4], xfA[4], wfB[4], xfB[4];
-          if (nks == 2) {
-            load_frags(0, 0, wfA, xfA);
-#pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-              load_frags(tap, 1, wfB, xfB);
-              mfma16(wfA, xfA);
-              if (tap < 8) load_frags(tap + 1, 0, wfA, xfA);
-              mfma16(wfB, xfB);
-            }
-          } else {
-            load_frags(0, 0, wfA, xfA);
-#pragma unroll 1
-            for (int tap = 0; tap < 8; tap += 2) {
-              load_frags(tap + 1, 0, wfB, xfB);
-              mfma16(wfA, xfA);
-              load_frags(tap + 2, 0, wfA, xfA);
-              mfma16(wfB, xfB);
-            }
-            mfma16(wfA, xfA);
+          // ONE wave per SIMD runs this loop (its SIMD-mate is in the memory slot), so nothing but the wave's own
+          // instruction order hides the LDS round trip.  The loop is fully unrolled; every read is base register +
+          // immediate (no vector ALU instruction in the loop); the MFMAs are `asm volatile` and the reads sit between
+          // compiler fences, so the order below IS the issue order: the six reads that feed LATER steps (next step's
+          // four filter fragments, two halo rows of the next (kx, ks)) go out behind the first six MFMAs of the
+          // current step, ten MFMAs (160 cycles) ahead of the wait in front of the next step.
+          v8 wf[2][4], xr[2][6];
+          constexpr int NG = 3 * nks_c, NST = NG * 3;
+          load_x2(0, 0, xr[0]); load_x2(0, 2, xr[0]); load_x2(0, 4, xr[0]);
+          load_w(0, wf[0]);
+#pragma unroll
+          for (int st = 0; st < NST; ++st) {
+            const int g = st / 3, ky = st - g * 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                mfma_inplace<T>(acc[i][j], wf[st & 1][j], xr[g & 1][i + ky]);
+                const int idx = j * 4 + i;
+                if (idx < 6 && st + 1 < NST) {
+                  const int rd = idx;                            // which read goes out behind this MFMA
+                  if (rd < 4) {
+                    C64_FENCE();
+                    const int s1 = st + 1, g1 = s1 / 3, ky1 = s1 - g1 * 3, kx1 = g1 / nks_c, ks1 = g1 - kx1 * nks_c, tap1 = ky1 * 3 + kx1;
+                    wf[s1 & 1][rd] = *reinterpret_cast<const v8*>(wa[ks1] + tap1 * 8192 + rd * 2048);
+                    C64_FENCE();
+                  } else if (rd < 6 && g + 1 < NG) {
+                    C64_FENCE();
+                    const int g1 = g + 1, kx1 = g1 / nks_c, ks1 = g1 - kx1 * nks_c, r = 2 * ky + (rd - 4);
+                    xr[g1 & 1][r] = *reinterpret_cast<const v8*>(xa[kx1][ks1] + r * (C64_HW * 128));
+                    C64_FENCE();
+                  }
+                }
+              }
           }
+          C64_MFMA_DRAIN();
         }
         if (p.res != nullptr) {   // this tile's residual, issued after the MFMA loop (its registers are not live inside it);
           // the latency hides behind the slot barrier and the next halo's LDS writes

@@ -16,7 +16,9 @@ def _run(args, env=None, timeout=600):
     e.update(env or {})
     r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT), env=e)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-3000:]
+    if not (r.returncode == 0 and lines):        # the ranks' own tracebacks come first; torchrun's summary of them fills the tail
+        at = r.stderr.find("Traceback")
+        raise AssertionError(r.stdout[-1500:] + (r.stderr[at:at + 4000] if at >= 0 else r.stderr[-4000:]))
     return json.loads(lines[-1])
 
 

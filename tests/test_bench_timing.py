@@ -43,3 +43,13 @@ def test_in_context_ms(mode, diff, stamp, fails, want, how):
     assert ("stamp_error" in info) == (fails and mode != "difference")
     assert "MTX_TIME_OPS" not in os.environ                      # never leaks into later plan timings
     assert plan.modes[:2] == ["difference", "difference"]
+
+
+def test_small_groups_take_their_stamps():
+    """a group that is a few percent of the replay has no usable difference figure (two 160 ms replays differ by more than it lasts)"""
+    plan = _Plan(0.67, 0.09, False)
+    idx = list(range(19))
+    total, used, _ = bench.in_context_ms(plan, idx, 4, "auto", replay_ms=160.0)          # 12.7 ms by difference, 1.7 ms stamped
+    assert used == "stamp" and total / 19 == pytest.approx(0.09)
+    total, used, _ = bench.in_context_ms(_Plan(0.80, 0.30, False), list(range(57)), 4, "auto", replay_ms=160.0)   # a big group keeps the band
+    assert used == "difference"
