@@ -103,6 +103,14 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   }
   if (tid < 64) bias_s[tid] = (p.bias != nullptr && tid < p.cout) ? p.bias[tid] : 0.f;
   const BufView ybuf = make_buf(p.y, p.y_bytes);
+  // ABL 7 (tools/probes/conv_probe.hip): wave 0 of each group of workgroups 0 and 97 writes the shader clock at the phase
+  // boundaries of every slot into chan_sum, viewed as uint64 [2 workgroups][2 groups][64 slots][8 events]
+  auto stamp = [&](unsigned s_, int ev) {
+#ifndef MTX_EMU
+    if (ABL == 7 && (blockIdx.x == 0 || blockIdx.x == 97) && wv == 0 && lane == 0 && s_ < 64)
+      reinterpret_cast<unsigned long long*>(p.chan_sum)[((((blockIdx.x ? 1 : 0) * 2 + grp) * 64 + s_) * 8) + ev] = __builtin_readcyclecounter();
+#endif
+  };
   // Fragment addresses of the MFMA loop, computed ONCE: with the halo swizzled by column, the address of
   // (tile row i, tap (ky, kx), k-step ks) is xa[kx][ks] + (i + ky) * 18 * 128 and a filter fragment is
   // wa[ks] + tap * 8 KiB + j * 2 KiB — every read of the loop is base register + immediate, and the loop
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
 
   for (unsigned s = 0; s < 2 * K + 1; ++s) {
     const bool mfma_slot = (int)(s & 1u) == grp;
+    stamp(s, 0);
     if (mfma_slot) {
       // ================= MFMA slot: tile k of this group ============================================
       const unsigned k = (s - (unsigned)grp) >> 1;
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
           }
           C64_MFMA_DRAIN();
         }
+        stamp(s, 1);
         if (p.res != nullptr) {   // this tile's residual, issued after the MFMA loop (its registers are not live inside it);
           // the latency hides behind the slot barrier and the next halo's LDS writes
 #pragma unroll
@@ -296,6 +306,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       // the next tile's halo goes in flight FIRST (this group's halo buffer is idle from the slot barrier on), so its latency runs
       // behind the epilogue below (whole RCAN graph 92.4 vs 96.5 ms with it issued after the stores; ABL 5 = that older order)
       if (ABL != 3 && ABL != 5 && lin1 != ~0u) dma_halo(lin1);
+      stamp(s, 2);
       // (1) epilogue straight from the accumulators: bias, activation, residual, 8-byte NHWC stores
       if (lin != ~0u) {
         const int img = (int)(lin / tiles_per_img);
@@ -364,9 +375,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       //     The drain overlaps the other group's MFMA slot.
       //     The 16 stores are the youngest operations on the counter and are NOT waited for: they retire under the next slots.
       if (ABL == 5 && lin1 != ~0u) dma_halo(lin1);
+      stamp(s, 3);
       if (stored && ABL != 5 && ABL != 6) MTX_WAIT_VMEM_BUT(16); else MTX_WAIT_VMEM();
+      stamp(s, 4);
     }
+    stamp(s, 5);
     MTX_LDS_BARRIER();
+    stamp(s, 6);
   }
   if (SUM && sum_img >= 0) flush_sums(sum_img);
 }

@@ -40,7 +40,7 @@ def make_page(index: int, width: int = 1024, height: int = 1536, bubbles: int = 
         grad = np.linspace(90, 230, rw)[None, :, None] + np.linspace(-25, 25, rh)[:, None, None]
         page[y0:y0 + rh, x0:x0 + rw] = grad
         for _ in range(14):
-            sx, sy = int(rng.integers(x0 + 6, x0 + rw - 6)), int(rng.integers(y0 + 6, y0 + rh - 26))
+            sx, sy = int(rng.integers(x0 + 6, max(x0 + 7, x0 + rw - 6))), int(rng.integers(y0 + 6, max(y0 + 7, y0 + rh - 26)))   # (max: pages narrower than ~280 px)
             page[sy:sy + 20, sx:sx + 3] = 15
         regions.append([x0, y0, x0 + rw, y0 + rh])
     return np.clip(page, 0, 255).astype(np.uint8), np.asarray(boxes, dtype=np.float32), regions

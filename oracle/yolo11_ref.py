@@ -281,6 +281,33 @@ def make_model(family="11", scale="n", nc=1, seg=False, seed=0):
 
 
 @torch.no_grad()
+def calibrate(net, x):
+    """Data-dependent conditioning of a seeded network (test infrastructure): one forward pass over `x` in which every convolution's
+    weights and bias are rescaled so that its output on this input has zero mean and unit spread.  A plain seeded network loses the
+    input-dependent part of its features within a dozen layers (each SiLU layer shrinks it, the biases do not shrink), and a parity
+    check on spatially constant features would only test how constants propagate."""
+    hooks = []
+
+    def fix(mod, inp, out):
+        s, m = out.std().item(), out.mean().item()
+        if not (s > 1e-12):
+            return out
+        mod.weight.div_(s)
+        if mod.bias is not None:
+            mod.bias.sub_(m).div_(s)
+            return (out - m) / s
+        return out / s
+
+    for mod in net.modules():
+        if isinstance(mod, nn.Conv2d) and mod.weight.requires_grad:          # the DFL projection is a constant, not a parameter
+            hooks.append(mod.register_forward_hook(fix))
+    net(x)
+    for h in hooks:
+        h.remove()
+    return net
+
+
+@torch.no_grad()
 def predict(net, img_bgr, imgsz=640, conf=0.25):
     from .yolo_ref import letterbox, postprocess
     x, lp = letterbox(img_bgr, imgsz)

@@ -20,6 +20,7 @@ def check(lib, device, family="11", scale="n", seg=False, h=96, w=64, imgsz=64, 
     net = yr.make_model(family, scale, nc, seg, seed=seed)
     page = make_page(h, w, seed + 1)
     x, lp = yolo_ref.letterbox(page, imgsz)
+    yr.calibrate(net, x)                  # every layer's output zero-mean / unit-spread on this page: the features stay input-dependent at depth
     # a random-weight head saturates: rescale the last conv of the box / class branches so their logits have unit spread, as a trained
     # head's do — otherwise the DFL expectation and the sigmoid amplify f16 rounding into whole bins (same device as yolo_checks.py)
     head = net.model[-1]
@@ -59,17 +60,23 @@ def check(lib, device, family="11", scale="n", seg=False, h=96, w=64, imgsz=64, 
     got = res.boxes.xyxy.cpu().numpy() if res.boxes is not None else np.zeros((0, 4), np.float32)
     assert abs(len(got) - n_ref) <= 2, (len(got), n_ref)                   # the same set, threshold ties aside: match by position
     matched, mism = 0, []
+    got_conf = res.boxes.conf.cpu().numpy() if res.boxes is not None else np.zeros(0, np.float32)
     masks = res.masks.data.cpu().numpy().astype(bool) if (seg and len(got)) else None
     for i, rb in enumerate(ref["boxes"]):
         if not len(got):
             break
         d = np.abs(got - rb[None]).max(1)
-        j = int(d.argmin())
+        near = np.nonzero(d < 3.0)[0]                                      # boxes clipped to the page can coincide: tell them apart by score
+        j = int(near[np.abs(got_conf[near] - ref["conf"][i]).argmin()]) if len(near) else int(d.argmin())
         if d[j] < 3.0:
             matched += 1
-            if seg:
+            # two overlapping candidates whose scores tie within f16 rounding may swap places in the NMS order: the surviving box is
+            # then a NEIGHBOUR anchor's (a pixel or two away, unrelated mask coefficients in a seeded network).  Masks are compared
+            # where the survivor is the same anchor, i.e. its box agrees to within the decoded-box error.
+            if seg and d[j] < max(0.6, 3.0 * box_err / min(lp["H"] / h, lp["W"] / w)) and abs(got_conf[j] - ref["conf"][i]) < 3 * e_cls + 1e-4:
                 mism.append(float((masks[j] != ref["masks"][i]).mean()))
     assert matched >= n_ref - 2, (matched, n_ref)
-    if seg and mism:
+    if seg and n_ref:
+        assert len(mism) >= max(1, n_ref // 2), (len(mism), n_ref)
         assert max(mism) < mask_tol, f"mask mismatch {max(mism):.4%}"
     return box_err, e_cls
