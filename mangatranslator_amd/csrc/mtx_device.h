@@ -286,11 +286,11 @@ __device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, uns
 // 8-byte store through a buffer descriptor.  A lane that must not write passes an offset >= the
 // descriptor's size: the range check drops it, and the instruction is still ISSUED by the wave — the
 // number of stores in flight does not depend on predicates (see MTX_WAIT_VMEM_BUT).
-__device__ __forceinline__ void buf_store8(const BufView& b, unsigned voff, u32x2 v) {
+__device__ __forceinline__ void buf_store8(const BufView& b, unsigned voff, u32x2 v, unsigned soff = 0) {
 #ifdef MTX_EMU
-  if ((unsigned long)voff + 8 <= b.bytes) memcpy(const_cast<unsigned char*>(b.base) + voff, &v, 8);
+  if ((unsigned long)voff + 8 <= b.bytes) memcpy(const_cast<unsigned char*>(b.base) + voff + soff, &v, 8);   // the range check covers voff only
 #else
-  __builtin_amdgcn_raw_buffer_store_b64(v, b.rsrc, (int)voff, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(v, b.rsrc, (int)voff, (int)soff, 0);
 #endif
 }
 

@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
     dict(n=1, h=16, w=16, cin=128, cout=64, ksize=1, stride=1, act=abi.ACT_LEAKY),
     dict(n=1, h=10, w=18, cin=32, cout=128, ksize=3, stride=1, pixel_shuffle=2, with_res=True),
     dict(n=2, h=18, w=20, cin=64, cout=64, ksize=3, stride=1, with_sum=True, act=abi.ACT_RELU),
+    dict(n=2, h=52, w=50, cin=64, cout=64, ksize=3, stride=1, with_sum=True, act=abi.ACT_RELU),      # interior tiles: the descriptor DMA / packed epilogue paths
+    dict(n=1, h=50, w=67, cin=40, cout=64, ksize=3, stride=1, ldx_extra=8),
     # page-scale shapes
     dict(n=1, h=384, w=256, cin=64, cout=64, ksize=3, stride=1, with_res=True, with_sum=True),
     dict(n=1, h=200, w=136, cin=192, cout=384, ksize=3, stride=2, act=abi.ACT_SILU),

@@ -16,6 +16,8 @@ from mangatranslator_amd.hip import abi
     dict(n=1, h=16, w=16, cin=128, cout=64, ksize=1, stride=1, act=abi.ACT_LEAKY),
     dict(n=1, h=10, w=18, cin=32, cout=128, ksize=3, stride=1, pixel_shuffle=2, with_res=True),
     dict(n=2, h=18, w=20, cin=64, cout=64, ksize=3, stride=1, with_sum=True, act=abi.ACT_RELU),
+    dict(n=2, h=52, w=50, cin=64, cout=64, ksize=3, stride=1, with_sum=True, act=abi.ACT_RELU),      # interior tiles: the descriptor DMA / packed epilogue paths
+    dict(n=1, h=50, w=67, cin=40, cout=64, ksize=3, stride=1, ldx_extra=8),
 ])
 def test_conv(emu_lib, dtype, cfg):
     if dtype == abi.F16 and cfg.get("stride") == 2:

@@ -1,5 +1,6 @@
 // conv_probe.hip — where a slot of the persistent RCAN conv goes (gfx950): the real kernel source, launched directly.
-//   timing of the kernel and of its ablations (1: no MFMA, 3: no halo DMA, 4: no epilogue / stores, 6: drain instead of the counted wait)
+//   timing of the kernel and of its ablations (1: no MFMA, 3: no halo DMA, 4: no epilogue / stores, 6: drain instead of the counted wait,
+//   8: the generic per-tile address / bounds paths also on interior tiles)
 //   ABL 7: shader-clock stamps at the phase boundaries of every slot, for wave 0 of both groups of workgroups 0 and 97
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/conv_probe.hip -o tools/probes/conv_probe
 #include "../../mangatranslator_amd/csrc/conv_c64.hip"
@@ -31,12 +32,13 @@ int main(int argc, char** argv) {
   ConvC64Params p{};
   p.x = (const unsigned char*)dx; p.w = (const unsigned char*)dw; p.bias = db; p.res = nullptr; p.y = (unsigned char*)dy; p.chan_sum = (float*)dst;
   p.n = 1; p.h = H; p.w_in = W; p.cin = 64; p.cout = 64; p.ldx = 64; p.ldy = 64; p.ldres = 0; p.act = MTX_ACT_RELU; p.act_param = 0; p.res_scale = 0;
-  p.ps = 0; p.res_bcast = 0; p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 15) / 16; p.valid_hw = nullptr; p.y_bytes = (unsigned)(px * 128);
+  p.ps = 0; p.res_bcast = 0; p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 15) / 16; p.valid_hw = nullptr; p.y_bytes = (unsigned)(px * 128); p.x_bytes = (unsigned)(px * 128);
   const unsigned grid = c64_grid(1, H, W);
   const double bytes = (double)px * 256 + 73728;
   printf("conv 64->64 %dx%d, grid %u\n", W, H, grid);
   float t;
   t = run<0>(p, grid, 20); printf("ABL 0 (the kernel)            %7.1f us  %6.0f GB/s\n", t, bytes / t / 1e3);
+  t = run<8>(p, grid, 20); printf("ABL 8 (generic DMA / epilogue)%7.1f us\n", t);
   t = run<6>(p, grid, 20); printf("ABL 6 (drain, not counted)    %7.1f us\n", t);
   t = run<1>(p, grid, 20); printf("ABL 1 (no MFMA)               %7.1f us\n", t);
   t = run<3>(p, grid, 20); printf("ABL 3 (no halo DMA)           %7.1f us\n", t);
