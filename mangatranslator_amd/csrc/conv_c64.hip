@@ -46,6 +46,7 @@ constexpr int C64_HW = C64_T + 2, C64_HPIX = C64_HW * C64_HW;   // 18 x 18 = 324
 constexpr int C64_W_BYTES = 9 * 64 * 128;
 constexpr int C64_HALO_BYTES = (C64_HPIX + 4) * 128;          // + 4 rows: the last DMA instruction of a halo covers rows 320 .. 327
 constexpr int C64_BIAS_BYTES = 64 * 4;
+constexpr int C64_MFMA_NOP = 0;                                     // s_nop after every MFMA of the loop (0: none)
 constexpr int C64_NDMA_C = (C64_HPIX * 8 + 63) / 64;              // 41 wave-instructions of 1 KiB per halo
 constexpr int C64_SMEM = C64_W_BYTES + 2 * C64_HALO_BYTES + C64_BIAS_BYTES;
 
@@ -56,12 +57,20 @@ constexpr int C64_SMEM = C64_W_BYTES + 2 * C64_HALO_BYTES + C64_BIAS_BYTES;
 template <typename T> __device__ __forceinline__ void mfma_inplace(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) {
   c = Traits<T>::mfma(a, b, c);
 }
+template <typename T, int NOP> __device__ __forceinline__ void mfma_inplace_nop(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) {
+  c = Traits<T>::mfma(a, b, c);
+}
 #define C64_FENCE() ((void)0)
 #define C64_MFMA_DRAIN() ((void)0)
 #else
 template <typename T> __device__ __forceinline__ void mfma_inplace(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b);
 template <> __device__ __forceinline__ void mfma_inplace<_Float16>(f32x4& c, const f16x8& a, const f16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// the same followed by s_nop NOP: the wave steps back from the issue port while its MFMA runs (see the MFMA loop)
+template <typename T, int NOP> __device__ __forceinline__ void mfma_inplace_nop(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) {
+  mfma_inplace<T>(c, a, b);
+  if (NOP > 0) asm volatile("s_nop %0" :: "n"(NOP - 1));
 }
 template <> __device__ __forceinline__ void mfma_inplace<__bf16>(f32x4& c, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
@@ -300,9 +309,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                mfma_inplace<T>(acc[i][j], wf[st & 1][j], xr[g & 1][i + ky]);
+                if (ABL != 11) mfma_inplace_nop<T, (ABL == 12 ? 1 : ABL == 13 ? 2 : ABL == 14 ? 3 : C64_MFMA_NOP)>(acc[i][j], wf[st & 1][j], xr[g & 1][i + ky]);      // ABL 11: the LDS reads without the MFMAs
+                else { asm volatile("s_nop 3" :: "v"(wf[st & 1][j]), "v"(xr[g & 1][i + ky])); }
                 const int idx = j * 4 + i;
-                if (idx < 6 && st + 1 < NST) {
+                if (ABL != 10 && idx < 6 && st + 1 < NST) {                                    // ABL 10: the MFMAs without the LDS reads
                   const int rd = idx;                            // which read goes out behind this MFMA
                   if (rd < 4) {
                     C64_FENCE();

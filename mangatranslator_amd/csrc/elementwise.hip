@@ -343,7 +343,19 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
     float s = 0.f;
     if (sub < per) {
       const float* src = p.chan_sum + (size_t)n * p.tiles * p.c + c;
-      for (int t = sub; t < p.tiles; t += per) s += src[(size_t)t * p.c];
+      // eight loads in flight per thread: the rows come from L2 one round trip apiece, and a chain of dependent adds
+      // around single loads made this kernel 33 us for 2 048 partial rows (RCAN runs it 200 times per page)
+      int t = sub;
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (; t + 7 * per < p.tiles; t += 8 * per) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(t + k * per) * p.c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += v[k];
+      }
+      for (; t < p.tiles; t += per) s += src[(size_t)t * p.c];
+      s += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     part[tid] = s;
   }

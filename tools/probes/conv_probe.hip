@@ -39,6 +39,12 @@ int main(int argc, char** argv) {
   float t;
   t = run<0>(p, grid, 20); printf("ABL 0 (the kernel)            %7.1f us  %6.0f GB/s\n", t, bytes / t / 1e3);
   t = run<8>(p, grid, 20); printf("ABL 8 (generic DMA / epilogue)%7.1f us\n", t);
+  t = run<10>(p, grid, 20); printf("ABL 10 (MFMA loop without its LDS reads) %7.1f us\n", t);
+  t = run<11>(p, grid, 20); printf("ABL 11 (LDS reads without the MFMAs)     %7.1f us\n", t);
+  t = run<12>(p, grid, 20); printf("ABL 12 (s_nop 0 after each MFMA)  %7.1f us\n", t);
+  t = run<13>(p, grid, 20); printf("ABL 13 (s_nop 1 after each MFMA)  %7.1f us\n", t);
+  t = run<14>(p, grid, 20); printf("ABL 14 (s_nop 2 after each MFMA)  %7.1f us\n", t);
+  t = run<5>(p, grid, 20); printf("ABL 5 (stores first, then the DMA, drain)  %7.1f us\n", t);
   t = run<6>(p, grid, 20); printf("ABL 6 (drain, not counted)    %7.1f us\n", t);
   t = run<1>(p, grid, 20); printf("ABL 1 (no MFMA)               %7.1f us\n", t);
   t = run<3>(p, grid, 20); printf("ABL 3 (no halo DMA)           %7.1f us\n", t);
