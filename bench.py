@@ -47,6 +47,12 @@ def parse():
                          "inpaint (20 steps bf16), 4 = full pipeline + 2x upscale (the headline metric, default), 5 = 2048x3072 pages, FLUX.2-Klein fp8 "
                          "inpaint + upscale")
     ap.add_argument("--inpainter", default=None, choices=["kontext", "klein_4b", "klein_9b"], help="default: kontext (configs 3, 4), klein_4b (config 5)")
+    ap.add_argument("--bubble-detector", default="yolo_2", choices=["yolo_1", "yolo_2"],
+                    help="primary bubble detector of the detect stage: yolo_2 = the reference's default (core/config.py:18; a YOLO11-seg, run here at "
+                         "the m scale) or yolo_1 = YOLOv8m-seg")
+    ap.add_argument("--no-aux-detectors", action="store_true",
+                    help="leave out the panel (YOLO11-L @640) and outside-text (YOLO12x @640) detectors that the reference runs on every page by "
+                         "default (core/config.py:20-21); RT-DETR-v2 always runs")
     ap.add_argument("--no-fp8", action="store_true", help="Klein: keep the block linears in bf16 instead of the MX-fp8 matrix path")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the stages of a page strictly one after another; default: two pages in flight — detect / segment / OSB prepare of "
@@ -196,6 +202,7 @@ def main():
             rcan_sd = broadcast_state_dict(rcan_sd, rank, world, device)
         upscaler = RCANUpscaler(rcan_sd, device=device, lib=lib, graph=graph)
     yolo = rtdetr = None
+    aux_detectors = []
     if "detect" in want:
         from mangatranslator_amd.core.ml.yolo import YoloSegHip
         from oracle.yolo_ref import make_model as make_yolo       # seeded YOLOv8m-seg (the reference's yolo_1 geometry)
@@ -208,6 +215,26 @@ def main():
         if world > 1:
             ysd = broadcast_state_dict(ysd, rank, world, device)
         yolo = YoloSegHip(ysd, device=device, lib=lib, graph=graph)
+        if args.bubble_detector == "yolo_2" or not args.no_aux_detectors:
+            from mangatranslator_amd.core.ml.yolo11 import Yolo11Hip
+            from oracle import yolo11_ref as y11
+
+            def seeded_y11(family, scale, seg, seed):
+                """seeded network of the published architecture, head tamed like the YOLOv8 one above"""
+                n_ = y11.make_model(family, scale, 1, seg, seed=seed if first else 0)
+                with torch.no_grad():
+                    hd = n_.model[-1]
+                    for l in range(3):
+                        hd.cv3[l][2].weight.mul_(0.05); hd.cv3[l][2].bias.fill_(-2.0)       # scores ~ 0.12: below every threshold used here
+                        hd.cv2[l][2].weight.mul_(0.1)
+                sd_ = n_.state_dict()
+                if world > 1:
+                    sd_ = broadcast_state_dict(sd_, rank, world, device)
+                return Yolo11Hip(sd_, device=device, lib=lib, graph=graph)
+            if args.bubble_detector == "yolo_2":
+                yolo = seeded_y11("11", "m", True, 13)          # manga109-segmentation-bubble: a YOLO11-seg (its scale is not stated upstream: m assumed)
+            if not args.no_aux_detectors:
+                aux_detectors = [("panel", seeded_y11("11", "l", False, 17), 0.25), ("osb_text", seeded_y11("12", "x", False, 19), 0.4)]
         # secondary detector of the same stage: RT-DETR-v2 R50 @640 (reference detection.py:1401-1407, on by default)
         from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
         from oracle.rtdetr_ref import make_model as make_rtdetr
@@ -350,6 +377,8 @@ def main():
         if yolo is not None:
             outs["detect"] = yolo(page_bgr[k], conf=yolo_conf, imgsz=1600)[0]
             outs["detect2"] = rtdetr(page_bgr[k], conf=0.35, imgsz=640)[0]
+            for name_, det_, conf_ in aux_detectors:             # panel / outside-text detectors: imgsz 640 (reference detection.py:1867-1873, 144-150)
+                outs["detect_" + name_] = det_(page_bgr[k], conf=conf_, imgsz=640)[0]
             tl = lap("detect", tl)
         if sam is not None:      # prompts: the generator's ground-truth boxes (fixed unit count)
             outs["segment"] = sam.segment(pages[k], page_boxes[k])
@@ -451,7 +480,9 @@ def main():
                    "baseline_config": args.config,
                    "stages": stages, "stage_memo": "cleared before every page (no cached outputs in the timed region)",
                    "dtypes": {"detect": "f16", "segment": "bf16", "inpaint": "bf16 (fp32 latents / Euler update)" + (" with MX-fp8 block linears" if klein and flux is not None and flux.transformer.fp8 else ""), "upscale": "f16"},
-                   "detector": "YOLOv8m-seg @imgsz 1600 (1088x1600 letterbox) + RT-DETR-v2 R50 @640 (secondary), seeded random weights" if yolo is not None else None,
+                   "detector": (("YOLO11m-seg (yolo_2, the reference's default)" if args.bubble_detector == "yolo_2" else "YOLOv8m-seg (yolo_1)")
+                                + " @imgsz 1600 + RT-DETR-v2 R50 @640 (secondary)"
+                                + (" + YOLO11-L panel detector @640 + YOLO12x outside-text detector @640" if aux_detectors else "") + ", seeded random weights") if yolo is not None else None,
                    "segmenter": "SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights" if sam is not None else None,
                    "inpainter": inp_desc,
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
@@ -471,13 +502,14 @@ def main():
             cfg["segment_ms"] = {"preprocess": pre.time(5), "encoder": enc.time(5), "decoder": dec.time(5), "upsample_threshold": post.time(5)}
         if yolo is not None:
             cfg["detect_net_ms"] = yolo._plans[(H_, W_, 1600)][0].time(5)
+            cfg["detect_aux_ms"] = {name_: det_._plans[(H_, W_, 640)][0].time(5) for name_, det_, _ in aux_detectors}
             ra, rb = rtdetr.plans(640, 640)
             cfg["detect_rtdetr_ms"] = {"backbone_encoder": ra.time(5), "decoder": rb.time(5)}
         # wall clock of a stage (one page, synchronised) against the GPU time of its graphs: what is left is host work (NMS, prompt set-up,
         # downloads) — the share the page pipeline hides behind the next page's GPU work
         split = {}
         if yolo is not None and "detect" in stage_wall:
-            gpu_ = cfg["detect_net_ms"] + sum(cfg["detect_rtdetr_ms"].values())
+            gpu_ = cfg["detect_net_ms"] + sum(cfg["detect_rtdetr_ms"].values()) + sum(cfg["detect_aux_ms"].values())
             split["detect"] = {"wall_ms": round(stage_wall["detect"], 2), "gpu_graph_ms": round(gpu_, 2), "host_ms": round(stage_wall["detect"] - gpu_, 2)}
         if sam is not None and "segment" in stage_wall:
             gpu_ = sum(cfg["segment_ms"].values())
@@ -638,10 +670,24 @@ def cpu_baseline(stages, rcan_sd, W_, H_, args, inpaint_info, klein_cfg=None):
 
     if "detect" in stages:
         from oracle import yolo_ref
-        net = yolo_ref.make_model("m", 1, seed=3)
         bgr = np.ascontiguousarray(pg[..., ::-1])
-        t = timed(lambda: yolo_ref.predict(net, bgr, imgsz=1600, conf=0.99))
-        parts.append(f"detect: oracle YOLOv8m-seg on the whole page {t:.2f} s"); total += t; spent += t
+        if args.bubble_detector == "yolo_2":
+            from oracle import yolo11_ref as y11p
+            net = y11p.make_model("11", "m", 1, True, seed=3)
+            t = timed(lambda: y11p.predict(net, bgr, imgsz=1600, conf=0.99))
+            parts.append(f"detect: oracle YOLO11m-seg on the whole page {t:.2f} s"); total += t; spent += t
+        else:
+            net = yolo_ref.make_model("m", 1, seed=3)
+            t = timed(lambda: yolo_ref.predict(net, bgr, imgsz=1600, conf=0.99))
+            parts.append(f"detect: oracle YOLOv8m-seg on the whole page {t:.2f} s"); total += t; spent += t
+        del net
+        if not args.no_aux_detectors:
+            from oracle import yolo11_ref as y11
+            for nm_, fam_, sc_ in (("panel YOLO11-L", "11", "l"), ("outside-text YOLO12x", "12", "x")):
+                n_ = y11.make_model(fam_, sc_, 1, False, seed=3)
+                t = timed(lambda: y11.predict(n_, bgr, imgsz=640, conf=0.99))
+                parts.append(f"{nm_} @640 {t:.2f} s"); total += t; spent += t
+                del n_
     if "segment" in stages:
         from oracle import sam2_ref
         m, _ = sam2_ref.make_model("hiera_large", seed=11)

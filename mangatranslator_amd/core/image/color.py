@@ -26,17 +26,29 @@ def _descale(x, n):
     return (x + (1 << (n - 1))) >> n
 
 
+_GAMMA32, _CBRT32, _COEF32 = _GAMMA_TAB.astype(np.int32), _CBRT_TAB.astype(np.int32), _COEF.astype(np.int32)
+
+
 def rgb_to_lab_u8(rgb: np.ndarray) -> np.ndarray:
-    """uint8 [..., 3] RGB -> uint8 [..., 3] (L, a, b)"""
-    lin = _GAMMA_TAB[np.asarray(rgb, np.uint8)[..., :3]]                              # [..., 3] int64
-    xyz = _descale(lin @ _COEF.T, _LAB_SHIFT)
-    f = _CBRT_TAB[np.clip(xyz, 0, _CBRT_TAB.size - 1)]
-    fx, fy, fz = f[..., 0], f[..., 1], f[..., 2]
+    """uint8 [..., 3] RGB -> uint8 [..., 3] (L, a, b).  int32 throughout (every intermediate stays below 2^26): three table lookups and
+    nine multiply-adds per pixel; the luminance match of a 1 MP crop calls this twice per region on the host"""
+    src = np.asarray(rgb, np.uint8)
+    r, g, b_ = _GAMMA32[src[..., 0]], _GAMMA32[src[..., 1]], _GAMMA32[src[..., 2]]
+    half = np.int32(1 << (_LAB_SHIFT - 1))
+    f = []
+    for c in range(3):
+        xyz = (r * _COEF32[c, 0] + g * _COEF32[c, 1] + b_ * _COEF32[c, 2] + half) >> _LAB_SHIFT
+        np.clip(xyz, 0, _CBRT32.size - 1, out=xyz)
+        f.append(_CBRT32[xyz])
+    fx, fy, fz = f
     lshift = -((16 * 255 * (1 << _LAB_SHIFT2) + 50) // 100)
-    L = _descale(((116 * 255 + 50) // 100) * fy + lshift, _LAB_SHIFT2)
-    a = _descale(500 * (fx - fy) + 128 * (1 << _LAB_SHIFT2), _LAB_SHIFT2)
-    b = _descale(200 * (fy - fz) + 128 * (1 << _LAB_SHIFT2), _LAB_SHIFT2)
-    return np.clip(np.stack([L, a, b], -1), 0, 255).astype(np.uint8)
+    h2 = np.int32(1 << (_LAB_SHIFT2 - 1))
+    out = np.empty(src.shape[:-1] + (3,), np.uint8)
+    L = (np.int32((116 * 255 + 50) // 100) * fy + np.int32(lshift) + h2) >> _LAB_SHIFT2
+    a = (np.int32(500) * (fx - fy) + np.int32(128 * (1 << _LAB_SHIFT2)) + h2) >> _LAB_SHIFT2
+    b = (np.int32(200) * (fy - fz) + np.int32(128 * (1 << _LAB_SHIFT2)) + h2) >> _LAB_SHIFT2
+    out[..., 0], out[..., 1], out[..., 2] = np.clip(L, 0, 255), np.clip(a, 0, 255), np.clip(b, 0, 255)
+    return out
 
 
 def lab_to_rgb_u8(lab: np.ndarray) -> np.ndarray:

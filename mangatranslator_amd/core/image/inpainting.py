@@ -461,34 +461,35 @@ class FluxKleinInpainter:
         return alpha
 
     # ---- luminance match (reference :1165-1256) ------------------------------------------------------------------------
-    def _compute_luminance_stats(self, image_np: np.ndarray, mask_np: np.ndarray) -> Tuple[float, float]:
+    def _compute_luminance_stats(self, image_np: np.ndarray, mask_np: np.ndarray, lab: Optional[np.ndarray] = None) -> Tuple[float, float]:
+        """`lab`: the image's Lab conversion when the caller already has it (the match below needs it again)"""
         if not np.any(mask_np):
             return 127.5, 30.0
         from .color import rgb_to_lab_u8
-        l_values = rgb_to_lab_u8(image_np)[:, :, 0][mask_np].astype(np.float32)
+        l_values = (rgb_to_lab_u8(image_np) if lab is None else lab)[:, :, 0][mask_np].astype(np.float32)
         return float(np.mean(l_values)), float(np.std(l_values)) + 1e-6
 
     def _match_luminance(self, generated_pil: Image.Image, original_crop_pil: Image.Image, mask_crop_np: np.ndarray,
                          verbose: bool = False) -> Image.Image:
         """affine remap of the patch's L channel (mean / std of the crop's unmasked pixels as reference, gain clamped to
-        [0.5, 2]) applied on the masked pixels only, plus a shift of a / b when their context means drifted by more than 1"""
+        [0.5, 2]) applied on the masked pixels only, plus a shift of a / b when their context means drifted by more than 1.
+        Each image is converted to Lab once (the reference converts each twice: once for the statistics, once for the remap)."""
         from .color import lab_to_rgb_u8, rgb_to_lab_u8
         context = ~mask_crop_np
         if not np.any(context) or not np.any(mask_crop_np):
             return generated_pil
-        original = np.asarray(original_crop_pil)
-        generated = np.asarray(generated_pil).copy()
-        o_mean, o_std = self._compute_luminance_stats(original, context)
-        g_mean, g_std = self._compute_luminance_stats(generated, context)
+        o_lab8 = rgb_to_lab_u8(np.asarray(original_crop_pil))
+        g_lab8 = rgb_to_lab_u8(np.asarray(generated_pil))
+        o_mean, o_std = self._compute_luminance_stats(None, context, lab=o_lab8)
+        g_mean, g_std = self._compute_luminance_stats(None, context, lab=g_lab8)
         if abs(o_mean - g_mean) < 1.3 and abs(o_std - g_std) < 2.0:
             return generated_pil
         gain = max(0.5, min(2.0, o_std / g_std))
         log_message(f"  - Luminance correction: mean {g_mean:.1f}->{o_mean:.1f}, std {g_std:.1f}->{o_std:.1f} (scale={gain:.2f})", verbose=verbose)
-        lab = rgb_to_lab_u8(generated).astype(np.float32)
+        lab = g_lab8.astype(np.float32)
         lab[:, :, 0][mask_crop_np] = np.clip((lab[:, :, 0][mask_crop_np] - g_mean) * gain + o_mean, 0, 255)
-        o_lab = rgb_to_lab_u8(original).astype(np.float32)
         for ch in (1, 2):
-            shift = float(np.mean(o_lab[:, :, ch][context])) - float(np.mean(lab[:, :, ch][context]))
+            shift = float(np.mean(o_lab8[:, :, ch][context].astype(np.float32))) - float(np.mean(lab[:, :, ch][context]))
             if abs(shift) > 1.0:
                 lab[:, :, ch][mask_crop_np] = np.clip(lab[:, :, ch][mask_crop_np] + shift, 0, 255)
         return Image.fromarray(lab_to_rgb_u8(lab.astype(np.uint8)))
