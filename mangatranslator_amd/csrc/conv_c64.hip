@@ -148,9 +148,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
     const int hp = slot >> 3, hy = hp / C64_HW, hx = hp - hy * C64_HW, ch = (((slot & 7) ^ (hx & 7))) * 8;
     dma_off[it] = (hp < C64_HPIX && ch < p.cin) ? (unsigned)(((hy * p.w_in + hx) * p.ldx + ch) * (int)sizeof(T)) : p.x_bytes;   // out of range: zeros
   }
+  // stores of the fast path: 16 bytes per lane.  A lane's accumulators hold channel quads 16j + 4q (8-byte units scattered over the
+  // pixel's 128-byte line); one v_permlane16_swap per dword between the lanes q and q ^ 1 of a pixel turns two units into one
+  // contiguous 16-byte chunk, so a store instruction writes a 64-byte half line per pixel and a tile takes 8 of them, not 16
   unsigned st_off[4];
+  const unsigned chunk_off = (q & 1) ? 32u + 8u * (unsigned)(q - 1) : 8u * (unsigned)q;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) st_off[i] = (unsigned)((((wv * 4 + i) * p.w_in + l15) * p.ldy + q * 4) * (int)sizeof(T));
+  for (int i = 0; i < 4; ++i) st_off[i] = (unsigned)(((wv * 4 + i) * p.w_in + l15) * p.ldy * (int)sizeof(T)) + (ABL == 16 ? (unsigned)(q * 4 * sizeof(T)) : chunk_off);
   const bool fast_ok = p.ps == 0 && p.cout == 64 && p.res == nullptr && p.valid_hw == nullptr && ABL != 8;
   // ABL 7 (tools/probes/conv_probe.hip): wave 0 of each group of workgroups 0 and 97 writes the shader clock at the phase
   // boundaries of every slot into chan_sum, viewed as uint64 [2 workgroups][2 groups][64 slots][8 events]
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       const unsigned k = (s - (unsigned)grp - 1) >> 1;
       const unsigned lin = k < K ? tile_of(k) : ~0u;
       const unsigned lin1 = k + 1 < K ? tile_of(k + 1) : ~0u;
-      bool stored = false;
+      int stored_n = 0;                       // store instructions this wave issued in this slot (exact: see the wait below)
       // the next tile's halo goes in flight FIRST (this group's halo buffer is idle from the slot barrier on), so its latency runs
       // behind the epilogue below (whole RCAN graph 92.4 vs 96.5 ms with it issued after the stores; ABL 5 = that older order)
       if (ABL != 3 && ABL != 5 && ABL != 15 && lin1 != ~0u) dma_halo(lin1);
@@ -379,20 +383,35 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
         const bool fast = fast_ok && (ACT == MTX_ACT_NONE || ACT == MTX_ACT_RELU) && ty0 + C64_T <= p.h && tx0 + C64_T <= p.w_in;
         if (ABL != 4 && fast) {
           const unsigned sbase = (unsigned)((((size_t)img * p.h + ty0) * p.w_in + tx0) * (size_t)p.ldy * sizeof(T));
+          f32x4 b4[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + j * 16 + q * 4);
+          for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const f32x4*>(bias_s + j * 16 + q * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const v4 o = epi_pack<T, ACT>(acc[i][j] + b4, p.act, p.act_param);
+          for (int i = 0; i < 4; ++i) {
+            u32x2 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const v4 ov = epi_pack<T, ACT>(acc[i][j] + b4[j], p.act, p.act_param);
               if (want_sum) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) csum[j][r] += to_f32(o[r]);
+                for (int r = 0; r < 4; ++r) csum[j][r] += to_f32(ov[r]);
               }
-              buf_store8(ybuf, st_off[i] + (unsigned)(j * 16 * sizeof(T)), __builtin_bit_cast(u32x2, o), sbase);
+              o[j] = __builtin_bit_cast(u32x2, ov);
+            }
+            if (ABL == 16) {              // ablation: the 8-byte stores (32-byte segments per pixel)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) buf_store8(ybuf, st_off[i] + (unsigned)(j * 16 * sizeof(T)), o[j], sbase);
+            } else {
+#pragma unroll
+              for (int jp = 0; jp < 2; ++jp) {
+                uint32_t a0 = o[2 * jp][0], a1 = o[2 * jp][1], c0 = o[2 * jp + 1][0], c1 = o[2 * jp + 1][1];
+                row_pair_exchange(a0, c0);
+                row_pair_exchange(a1, c1);
+                buf_store16(ybuf, st_off[i] + (unsigned)(jp * 32 * sizeof(T)), u32x4{a0, a1, c0, c1}, sbase);
+              }
             }
           }
-          stored = true;
+          stored_n = ABL == 16 ? 16 : 8;
         } else
         if (ABL == 4) {   // keep EVERY accumulator live (an ablation must not let the MFMAs be DCE'd)
 #pragma unroll
@@ -444,18 +463,20 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
               buf_store8(ybuf, voff, __builtin_bit_cast(u32x2, o));
             }
           }
-          stored = true;
+          stored_n = 16;
         }
       }
       // (2) next tile's halo by LDS-DMA into this group's (now idle) halo buffer, then drain: the
       //     DMA and this tile's stores must have landed before the barrier that opens our MFMA slot.
       //     The drain overlaps the other group's MFMA slot.
-      //     The 16 stores are the youngest operations on the counter and are NOT waited for: they retire under the next slots.
+      //     The tile's 8 (fast path) or 16 stores are the youngest operations on the counter and are NOT waited for: they retire under the next slots.
       if ((ABL == 5 || ABL == 15) && lin1 != ~0u) dma_halo(lin1);
       stamp(s, 3);
       // ABL 15 (timing only, results wrong): stores, then the DMA, and NO wait — what a third halo buffer (a slot of slack for the DMA) would run like
       if (ABL == 15) { } else
-      if (stored && ABL != 5 && ABL != 6) MTX_WAIT_VMEM_BUT(16); else MTX_WAIT_VMEM();
+      if (ABL == 5 || ABL == 6 || stored_n == 0) MTX_WAIT_VMEM();
+      else if (stored_n == 8) MTX_WAIT_VMEM_BUT(8);
+      else MTX_WAIT_VMEM_BUT(16);
       stamp(s, 4);
     }
     stamp(s, 5);

@@ -294,6 +294,31 @@ __device__ __forceinline__ void buf_store8(const BufView& b, unsigned voff, u32x
 #endif
 }
 
+__device__ __forceinline__ void buf_store16(const BufView& b, unsigned voff, u32x4 v, unsigned soff = 0) {
+#ifdef MTX_EMU
+  if ((unsigned long)voff + 16 <= b.bytes) memcpy(const_cast<unsigned char*>(b.base) + voff + soff, &v, 16);
+#else
+  __builtin_amdgcn_raw_buffer_store_b128(v, b.rsrc, (int)voff, (int)soff, 0);
+  // A 16-byte store reads its data registers over several cycles.  With an SGPR soffset the compiler assumes the hardware covers a
+  // vector write to those registers in the very next instruction; on gfx950 it does not: the last lanes of each row were stored
+  // from the NEXT values (measured: r02 visit N/P, lanes 12..15 of every row held the following v_pk_add_f32's fp32 bits).
+  // Keeping the data live across two wait states keeps the registers from being reused that early.
+  asm volatile("s_nop 1" : "+v"(v));
+#endif
+}
+
+// v_permlane16_swap: the lanes of an ODD 16-lane row trade their `a` for the `b` of the lane 16 below them (even row).
+// After it an even-row lane holds (its own a, its upper neighbour's a) and an odd-row lane (its lower neighbour's b, its own b).
+__device__ __forceinline__ void row_pair_exchange(uint32_t& a, uint32_t& b) {
+#ifdef MTX_EMU
+  const uint32_t pa = __shfl_xor(a, 16, 64), pb = __shfl_xor(b, 16, 64);
+  if ((emu::lane_id() >> 4) & 1) a = pb; else b = pa;
+#else
+  auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+#endif
+}
+
 // the same, straight into LDS (LDS-DMA): lane l's 16 bytes land at lds_wave_base + 16 l
 __device__ __forceinline__ void buf_load16_lds(const BufView& b, unsigned voff, unsigned soff, void* lds_wave_base) {
 #ifdef MTX_EMU

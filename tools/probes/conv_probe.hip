@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
   t = run<14>(p, grid, 20); printf("ABL 14 (s_nop 2 after each MFMA)  %7.1f us\n", t);
   t = run<5>(p, grid, 20); printf("ABL 5 (stores first, then the DMA, drain)  %7.1f us\n", t);
   t = run<15>(p, grid, 20); printf("ABL 15 (stores, then DMA, no wait: 3-buffer what-if)  %7.1f us\n", t);
+  t = run<16>(p, grid, 20); printf("ABL 16 (8-byte stores, no lane exchange)  %7.1f us\n", t);
   t = run<6>(p, grid, 20); printf("ABL 6 (drain, not counted)    %7.1f us\n", t);
   t = run<1>(p, grid, 20); printf("ABL 1 (no MFMA)               %7.1f us\n", t);
   t = run<3>(p, grid, 20); printf("ABL 3 (no halo DMA)           %7.1f us\n", t);
