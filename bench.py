@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-aux-detectors", action="store_true",
                     help="leave out the panel (YOLO11-L @640) and outside-text (YOLO12x @640) detectors that the reference runs on every page by "
                          "default (core/config.py:20-21); RT-DETR-v2 always runs")
+    ap.add_argument("--no-lanes", action="store_true", help="FLUX.1: keep the text stream's ops in line with the image stream's (one lane)")
     ap.add_argument("--no-fp8", action="store_true", help="Klein: keep the block linears in bf16 instead of the MX-fp8 matrix path")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the stages of a page strictly one after another; default: two pages in flight — detect / segment / OSB prepare of "
@@ -283,7 +284,8 @@ def main():
             from mangatranslator_amd.core.image.inpainting import FluxKontextInpainter
             from mangatranslator_amd.core.ml import flux as fx
             # 11.9 B-parameter MMDiT + 84 M-parameter VAE, bf16, seeded on rank 0's GPU and broadcast tensor by tensor
-            dit = fx.FluxDiTHip(fx.synthetic_provider(fx.dit_param_shapes(fx.KONTEXT_DIT_CFG), device, 21, broadcast=world > 1), fx.KONTEXT_DIT_CFG, device, lib=lib)
+            dit = fx.FluxDiTHip(fx.synthetic_provider(fx.dit_param_shapes(fx.KONTEXT_DIT_CFG), device, 21, broadcast=world > 1), fx.KONTEXT_DIT_CFG, device, lib=lib,
+                                text_stream_on_side_lane=not args.no_lanes)
             vae = fx.FluxVAEHip(fx.synthetic_provider(fx.vae_param_shapes(fx.KONTEXT_VAE_CFG), device, 22, broadcast=world > 1), fx.KONTEXT_VAE_CFG, device, lib=lib)
             flux = fx.FluxKontextHip(dit, vae, graph=graph)
             g = torch.Generator().manual_seed(23)     # cached T5 / CLIP embeddings of "Remove all text." (random stand-ins)
@@ -545,8 +547,10 @@ def main():
             key, plan = next(iter(flux.transformer._plans.items()))
             t_txt, h2, w2 = key[0], key[1], key[2]
             fl = flux.transformer.flops_per_step(*key[:3]) if not klein else flux.transformer.flops_per_step(*key)
-            plan.time(6)              # ~1 s of sustained load first: the chip boosts for the first few steps after an idle phase and
-            step_ms = plan.time(4)    # then settles (rocprof: 0.71 ms vs 0.83 ms per attention launch); the steady state is what a page sees
+            plan.time(6, graph=True)              # ~1 s of sustained load first: the chip boosts for the first few steps after an idle phase and
+            step_ms = plan.time(4, graph=True)    # then settles (rocprof: 0.71 ms vs 0.83 ms per attention launch); the steady state is what a page
+            # sees.  Timed as the hipGraph replay the pipeline runs (with the text stream on its side lane), not as eager launches
+            cfg["dit_step_ms_one_lane_eager"] = plan.time(2)
             rh2, rw2 = (key[3], key[4]) if klein else (h2, w2)
             cfg["inpaint"] = {"resolution": [w2 * 16, h2 * 16], "tokens": fl["tokens"], "dit_step_ms": step_ms,
                               "dit_tflops": (fl["gemm"] + fl["attention"]) / step_ms / 1e9,

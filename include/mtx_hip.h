@@ -316,8 +316,14 @@ typedef enum mtx_op_kind {
 
 typedef struct mtx_memset_args { void* ptr; int64_t bytes; int32_t value; } mtx_memset_args;
 
+/* `lane`: 0 = the plan's main stream.  MTX_LANE_SIDE puts the op on the plan's side stream: a run of side ops starts after everything
+   the main lane has issued before it and then runs BESIDE the main ops that follow; the first later main op that needs its results
+   carries MTX_LANE_JOIN (the main lane waits for the side lane there; the end of a plan always joins).  Program order is a valid
+   serial order, so an executor may ignore lanes (mtx_plan_run_range, the timing entry points and the simulator do). */
+#define MTX_LANE_SIDE 1
+#define MTX_LANE_JOIN 2
 typedef struct mtx_op {
-  int32_t kind; int32_t reserved;
+  int32_t kind; int32_t lane;
   union {
     mtx_conv2d_args conv; mtx_gemm_args gemm; mtx_attn_args attn; mtx_norm_args norm;
     mtx_groupnorm_args gn; mtx_ew_args ew; mtx_ca_args ca; mtx_img_args img;

@@ -78,8 +78,10 @@ def image_ids(h2, w2, first) -> np.ndarray:
 
 
 class FluxDiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None):
-        """provider(name) -> tensor with diffusers' FluxTransformer2DModel parameter of that name."""
+    def __init__(self, provider, cfg: dict, device, lib=None, text_stream_on_side_lane: bool = True):
+        """provider(name) -> tensor with diffusers' FluxTransformer2DModel parameter of that name.
+        text_stream_on_side_lane: run the double-stream blocks' text ops beside the image ops (plan lanes); False keeps one lane"""
+        self.side_lane = text_stream_on_side_lane
         self.lib = lib if lib is not None else get_library()
         self.device = torch.device(device)
         self.dtype, self.tdt = abi.BF16, torch.bfloat16
@@ -175,7 +177,7 @@ class FluxDiTHip:
         t_noise = h2 * w2
         t_img = t_noise * (1 + n_ref)
         T = t_txt + t_img
-        pb = PlanBuilder(self.lib, self.device, self.dtype)
+        pb = PlanBuilder(self.lib, self.device, self.dtype, lanes=self.side_lane)
         lat = pb.buf((t_img, cfg["in_channels"]), self.tdt)       # [noise tokens ; reference tokens]
         ctx_in = pb.buf((t_txt, cfg["joint_dim"]), self.tdt)      # prompt embeddings
         mod = pb.buf((self.n_vec, D), self.tdt)
@@ -214,26 +216,33 @@ class FluxDiTHip:
             pb.attention(qkv, qkv, qkv, out_t, 1, H, T, T, hd, (0, 3 * D, hd), (0, 3 * D, hd), (0, 3 * D, hd), (0, out_ld, hd),
                          1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True)
 
+        # Double-stream blocks: the text stream's ops (512 rows: GEMMs of 24 - 96 tiles that cannot fill the chip, 4 % of a step when run in
+        # line) go to the plan's SIDE lane and run beside the image stream's ops; the lanes meet at the joint attention and at the next block.
+        # The two streams touch disjoint row ranges of every shared buffer.
         for i, B in enumerate(self.blocks):
             b0 = i * 12
             tag = f"dbl{i}"
+            with pb.side():
+                adaln(0, t_txt, b0 + 6, b0 + 7, tag + ".norm1_ctx")
+                pb.gemm(nrm, B["cqkv"][0], t_txt, 3 * D, D, bias=B["cqkv"][1], out=qkv, label=tag + ".qkv_ctx")
+                rope(qkv, 0, t_txt, B["cnqk"], 3 * D, tag + ".rope_qk_ctx")
             adaln(t_txt, T, b0 + 0, b0 + 1, tag + ".norm1")
-            adaln(0, t_txt, b0 + 6, b0 + 7, tag + ".norm1_ctx")
             pb.gemm(nrm, B["qkv"][0], t_img, 3 * D, D, bias=B["qkv"][1], out=qkv, a_off=t_txt * D, c_off=t_txt * 3 * D, label=tag + ".qkv")
-            pb.gemm(nrm, B["cqkv"][0], t_txt, 3 * D, D, bias=B["cqkv"][1], out=qkv, label=tag + ".qkv_ctx")
             rope(qkv, t_txt, T, B["nqk"], 3 * D, tag + ".rope_qk")
-            rope(qkv, 0, t_txt, B["cnqk"], 3 * D, tag + ".rope_qk_ctx")
+            pb.join()
             attention(o, D, tag + ".attn")
+            with pb.side():
+                pb.gemm(o, B["cout"][0], t_txt, D, D, bias=B["cout"][1], gate=mod[b0 + 8], gate_rows_per=t_txt, res=x, out=x, label=tag + ".to_add_out")
+                adaln(0, t_txt, b0 + 9, b0 + 10, tag + ".norm2_ctx")
+                pb.gemm(nrm, B["cff1"][0], t_txt, 4 * D, D, bias=B["cff1"][1], act=abi.ACT_GELU_TANH, out=hid, label=tag + ".ff1_ctx")
+                pb.gemm(hid, B["cff2"][0], t_txt, D, 4 * D, bias=B["cff2"][1], gate=mod[b0 + 11], gate_rows_per=t_txt, res=x, out=x, label=tag + ".ff2_ctx")
             pb.gemm(o, B["out"][0], t_img, D, D, bias=B["out"][1], gate=mod[b0 + 2], gate_rows_per=t_img, res=x, out=x,
                     a_off=t_txt * D, c_off=t_txt * D, res_off=t_txt * D, label=tag + ".to_out")
-            pb.gemm(o, B["cout"][0], t_txt, D, D, bias=B["cout"][1], gate=mod[b0 + 8], gate_rows_per=t_txt, res=x, out=x, label=tag + ".to_add_out")
             adaln(t_txt, T, b0 + 3, b0 + 4, tag + ".norm2")
-            adaln(0, t_txt, b0 + 9, b0 + 10, tag + ".norm2_ctx")
             pb.gemm(nrm, B["ff1"][0], t_img, 4 * D, D, bias=B["ff1"][1], act=abi.ACT_GELU_TANH, out=hid, a_off=t_txt * D, c_off=t_txt * 4 * D, label=tag + ".ff1")
             pb.gemm(hid, B["ff2"][0], t_img, D, 4 * D, bias=B["ff2"][1], gate=mod[b0 + 5], gate_rows_per=t_img, res=x, out=x,
                     a_off=t_txt * 4 * D, c_off=t_txt * D, res_off=t_txt * D, label=tag + ".ff2")
-            pb.gemm(nrm, B["cff1"][0], t_txt, 4 * D, D, bias=B["cff1"][1], act=abi.ACT_GELU_TANH, out=hid, label=tag + ".ff1_ctx")
-            pb.gemm(hid, B["cff2"][0], t_txt, D, 4 * D, bias=B["cff2"][1], gate=mod[b0 + 11], gate_rows_per=t_txt, res=x, out=x, label=tag + ".ff2_ctx")
+        pb.join()                 # the single-stream blocks read every row
         s0 = cfg["layers"] * 12
         for i, S in enumerate(self.singles):
             b0 = s0 + i * 3

@@ -50,6 +50,8 @@ struct Plan {
 #ifndef MTX_EMU
   hipGraphExec_t exec = nullptr;
   hipGraph_t graph = nullptr;
+  hipStream_t side = nullptr;              // MTX_LANE_SIDE ops (created on first use)
+  std::vector<hipEvent_t> events;          // one per fork / join point of the op list
 #endif
 };
 
@@ -258,9 +260,53 @@ int mtx_plan_run_range(void* plan, int first, int last, void* stream) {
   return MTX_OK;
 }
 
+// Whole plan with its lanes: side runs fork from the main stream at their first op and join at the next op that carries
+// MTX_LANE_JOIN (or at the end).  The same code records the fork / join edges when the main stream is being captured into a hipGraph
+// (event record + stream wait inside a capture become graph dependencies), so a replayed plan keeps the two branches parallel.
 int mtx_plan_run(void* plan, void* stream) {
   if (!plan) return fail(MTX_ERR_INVALID, "mtx_plan_run: null plan");
-  return mtx_plan_run_range(plan, 0, (int)static_cast<Plan*>(plan)->ops.size() - 1, stream);
+  Plan* p = static_cast<Plan*>(plan);
+  const int n = (int)p->ops.size();
+#ifdef MTX_EMU
+  return mtx_plan_run_range(plan, 0, n - 1, stream);
+#else
+  bool lanes = false;
+  for (const mtx_op& op : p->ops) lanes = lanes || (op.lane & MTX_LANE_SIDE);
+  if (!lanes || stream == nullptr) return mtx_plan_run_range(plan, 0, n - 1, stream);     // the legacy default stream cannot fork
+  hipStream_t main_s = (hipStream_t)stream;
+  if (!p->side && hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) return fail(MTX_ERR_HIP, "mtx_plan_run: side stream");
+  size_t ev = 0;
+  auto next_event = [&]() -> hipEvent_t {
+    if (ev == p->events.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      p->events.push_back(e);
+    }
+    return p->events[ev++];
+  };
+  auto edge = [&](hipStream_t from, hipStream_t to) -> bool {       // `to` continues after everything issued on `from` so far
+    hipEvent_t e = next_event();
+    return e && hipEventRecord(e, from) == hipSuccess && hipStreamWaitEvent(to, e, 0) == hipSuccess;
+  };
+  bool side_open = false, prev_side = false;
+  for (int i = 0; i < n; ++i) {
+    const mtx_op& op = p->ops[(size_t)i];
+    const bool on_side = (op.lane & MTX_LANE_SIDE) != 0;
+    if (!on_side && (op.lane & MTX_LANE_JOIN) && side_open) {
+      if (!edge(p->side, main_s)) return fail(MTX_ERR_HIP, "mtx_plan_run: join failed");
+      side_open = false;
+    }
+    if (on_side && !prev_side) {                                     // a side run begins: it sees every main op recorded before it
+      if (!edge(main_s, p->side)) return fail(MTX_ERR_HIP, "mtx_plan_run: fork failed");
+      side_open = true;
+    }
+    int rc = run_op(op, on_side ? (void*)p->side : stream);
+    if (rc != MTX_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; if (side_open) edge(p->side, main_s); return rc; }
+    prev_side = on_side;
+  }
+  if (side_open && !edge(p->side, main_s)) return fail(MTX_ERR_HIP, "mtx_plan_run: final join failed");
+  return MTX_OK;
+#endif
 }
 
 int mtx_plan_run_graph(void* plan, void* stream) {
@@ -295,6 +341,8 @@ void mtx_plan_destroy(void* plan) {
 #ifndef MTX_EMU
   if (p->exec) hipGraphExecDestroy(p->exec);
   if (p->graph) hipGraphDestroy(p->graph);
+  for (hipEvent_t e : p->events) hipEventDestroy(e);
+  if (p->side) hipStreamDestroy(p->side);
 #endif
   delete p;
 }

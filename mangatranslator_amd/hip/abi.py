@@ -146,8 +146,11 @@ class _OpUnion(C.Union):
                 ("rt", ResizeThreshArgs), ("ms", MemsetArgs), ("sel", MaskSelectArgs), ("pre", PreprocArgs), ("yd", YoloDecodeArgs), ("detr", DetrArgs), ("quant", QuantArgs)]
 
 
+LANE_SIDE, LANE_JOIN = 1, 2
+
+
 class Op(C.Structure):
-    _fields_ = [("kind", i32), ("reserved", i32), ("u", _OpUnion)]
+    _fields_ = [("kind", i32), ("lane", i32), ("u", _OpUnion)]
 
 
 ARG_TYPES = {OP_CONV2D: ConvArgs, OP_GEMM: GemmArgs, OP_ATTN: AttnArgs, OP_NORM: NormArgs,

@@ -165,12 +165,14 @@ class PlanCache:
 
 
 class PlanBuilder:
-    def __init__(self, lib, device, dtype: int = abi.BF16):
+    def __init__(self, lib, device, dtype: int = abi.BF16, lanes: bool = True):
         self.lib = lib
+        self._lanes = lanes                     # False: `with pb.side()` records on the main lane (one in-order stream)
         self.device = torch.device(device)
         self.dtype = dtype
         self.tdtype = _TORCH_DT[dtype]
         self.ops: List[abi.Op] = []
+        self._side, self._join_next = False, False
         self.labels: List[str] = []
         self.keep: list = []
 
@@ -197,9 +199,28 @@ class PlanBuilder:
         return t
 
     # ---- op recording ---------------------------------------------------------------------
+    # ---- lanes (include/mtx_hip.h, MTX_LANE_*): ops recorded inside `with pb.side():` go to the plan's side stream and run beside the
+    # main ops recorded after the block; `pb.join()` makes the next main op wait for them
+    def side(self):
+        pb = self
+
+        class _Side:
+            def __enter__(self_):
+                pb._side = pb._lanes
+
+            def __exit__(self_, *exc):
+                pb._side = False
+        return _Side()
+
+    def join(self):
+        self._join_next = True
+
     def _add(self, kind: int, args, label: str) -> int:
         op = abi.Op()
         op.kind = kind
+        op.lane = (abi.LANE_SIDE if self._side else 0) | (abi.LANE_JOIN if (self._join_next and not self._side) else 0)
+        if self._join_next and not self._side:
+            self._join_next = False
         setattr(op.u, abi.UNION_FIELD[kind], args)
         self.ops.append(op)
         self.labels.append(label)
@@ -269,9 +290,11 @@ class PlanBuilder:
         g.dtype, g.out_dtype = self.dtype, (abi.F32 if out_f32 else self.dtype)
         if ((m >= 2048 and n >= 1024 and k >= 512) or (m >= 256 and k >= 8192)) and batch == 1 and not out_f32:
             # large problems: one shared scratch per plan for the stream-K tail of the 256-tile kernel (ops of a plan run in order)
-            if getattr(self, "_gemm_ws", None) is None:
-                self._gemm_ws = self.buf((abi.GEMM_WORKSPACE_BYTES,), torch.uint8)
-            g.workspace, g.workspace_bytes = self._gemm_ws.data_ptr(), abi.GEMM_WORKSPACE_BYTES
+            # (side-lane ops run beside main-lane ops: they get a scratch of their own)
+            ws_name = "_gemm_ws_side" if self._side else "_gemm_ws"
+            if getattr(self, ws_name, None) is None:
+                setattr(self, ws_name, self.buf((abi.GEMM_WORKSPACE_BYTES,), torch.uint8))
+            g.workspace, g.workspace_bytes = getattr(self, ws_name).data_ptr(), abi.GEMM_WORKSPACE_BYTES
         self._add(abi.OP_GEMM, g, label)
         return out
 
