@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 2, GPU visit L: whole GPU suite on the final kernels; bench lines (default with two pages in flight; serial pair plain + rocprofv3 for the
+# round 2, GPU visits L and U (final): whole GPU suite on the final kernels; bench lines (default with two pages in flight; serial pair plain + rocprofv3 for the
 # roofline check; config 5; upscale only); kernel-trace summaries that separate queue time-sharing from kernel time
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
@@ -15,7 +15,7 @@ prof() {   # prof <tag> <bench args...>
 {
 echo "== whole gpu suite"; timeout 3000 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -8
 echo "== default bench (two pages in flight)"; timeout 1200 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_default.out 2> gpurun_out/bench_default.err; grep '^{' gpurun_out/bench_default.out > gpurun_out/r02_bench_default.json; wc -c gpurun_out/r02_bench_default.json
-echo "== default bench under rocprofv3"; prof default --steps 10 --warmup 3
+echo "== (rocprofv3 crashed on the two-thread default run in visit L: the serial pair below is the profiled one)"
 echo "== serial bench (--no-overlap), plain"; timeout 1200 python bench.py --steps 10 --warmup 3 --no-overlap --no-cpu-baseline > gpurun_out/bench_serial.out 2> gpurun_out/bench_serial.err; grep '^{' gpurun_out/bench_serial.out > gpurun_out/r02_bench_serial.json
 echo "== serial bench under rocprofv3"; prof serial --steps 10 --warmup 3 --no-overlap
 echo "== config 5"; timeout 900 python bench.py --config 5 --steps 8 --warmup 2 > gpurun_out/bench5.out 2> gpurun_out/bench5.err; grep '^{' gpurun_out/bench5.out > gpurun_out/r02_bench_config5.json; wc -c gpurun_out/r02_bench_config5.json
