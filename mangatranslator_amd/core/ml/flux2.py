@@ -246,32 +246,43 @@ class Flux2DiTHip:
             pb.ew(abi.EW_SWIGLU, a_, b=b_, out=_rows(dst, r0, r1, dst_c0, hid), label=label)
 
         res_gate = lambda i, rows: dict(gate=mod[i], gate_rows_per=rows, res=x)
+        # double-stream blocks: norms, quantisers and SwiGLU run over both streams at once; the text stream's four linears (512 rows, a
+        # fraction of one wave of tiles) ride the plan's side lane beside the image stream's
         for i, B in enumerate(self.blocks):
             tag = f"dbl{i}"
+            pb.join()
             adaln(t_txt, T, 0, 1, tag + ".norm1")
             adaln(0, t_txt, 6, 7, tag + ".norm1_ctx")
             if f8:
                 quant(nrm, D, nrm8, 0, T, tag + ".norm1.q")
+            with pb.side():
+                linear(nrm, nrm8 if f8 else None, B["cqkv"], 0, t_txt, 3 * D, D, qkv, label=tag + ".qkv_ctx")
             linear(nrm, nrm8 if f8 else None, B["qkv"], t_txt, T, 3 * D, D, qkv, label=tag + ".qkv")
-            linear(nrm, nrm8 if f8 else None, B["cqkv"], 0, t_txt, 3 * D, D, qkv, label=tag + ".qkv_ctx")
+            pb.join()
             rope(qkv, t_txt, T, B["nqk"], 3 * D, tag + ".rope_qk")
             rope(qkv, 0, t_txt, B["cnqk"], 3 * D, tag + ".rope_qk_ctx")
             attention(qkv, 3 * D, o, D, tag + ".attn")
             if f8:
                 quant(o, D, o8, 0, T, tag + ".attn.q")
+            with pb.side():
+                linear(o, o8 if f8 else None, B["cout"], 0, t_txt, D, D, x, label=tag + ".to_add_out", **res_gate(8, t_txt))
             linear(o, o8 if f8 else None, B["out"], t_txt, T, D, D, x, res_off=t_txt * D, label=tag + ".to_out", **res_gate(2, t_img))
-            linear(o, o8 if f8 else None, B["cout"], 0, t_txt, D, D, x, label=tag + ".to_add_out", **res_gate(8, t_txt))
+            pb.join()
             adaln(t_txt, T, 3, 4, tag + ".norm2")
             adaln(0, t_txt, 9, 10, tag + ".norm2_ctx")
             if f8:
                 quant(nrm, D, nrm8, 0, T, tag + ".norm2.q")
+            with pb.side():
+                linear(nrm, nrm8 if f8 else None, B["cff_in"], 0, t_txt, 2 * hid, D, ffh, label=tag + ".ff_in_ctx")
             linear(nrm, nrm8 if f8 else None, B["ff_in"], t_txt, T, 2 * hid, D, ffh, label=tag + ".ff_in")
-            linear(nrm, nrm8 if f8 else None, B["cff_in"], 0, t_txt, 2 * hid, D, ffh, label=tag + ".ff_in_ctx")
+            pb.join()
             swiglu(ffh, 2 * hid, 0, 0, T, ffa, hid, 0, tag + ".swiglu")
             if f8:
                 quant(ffa, hid, ffa8, 0, T, tag + ".swiglu.q")
+            with pb.side():
+                linear(ffa, ffa8 if f8 else None, B["cff_out"], 0, t_txt, D, hid, x, label=tag + ".ff_out_ctx", **res_gate(11, t_txt))
             linear(ffa, ffa8 if f8 else None, B["ff_out"], t_txt, T, D, hid, x, res_off=t_txt * D, label=tag + ".ff_out", **res_gate(5, t_img))
-            linear(ffa, ffa8 if f8 else None, B["cff_out"], 0, t_txt, D, hid, x, label=tag + ".ff_out_ctx", **res_gate(11, t_txt))
+        pb.join()
         for i, S in enumerate(self.singles):
             tag = f"sgl{i}"
             adaln(0, T, 12, 13, tag + ".norm")
