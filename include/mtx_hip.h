@@ -36,7 +36,7 @@ extern "C" {
 #define MTX_API
 #endif
 
-#define MTX_ABI_VERSION 2
+#define MTX_ABI_VERSION 3
 
 typedef enum mtx_status {
   MTX_OK = 0,
@@ -81,6 +81,10 @@ typedef struct mtx_conv2d_args {
    * exactly the zero padding an image of that size would have.  One plan built on a bucket size then serves every smaller image
    * (bubble crops of arbitrary size, reference core/services/translation.py:2097-2258) by rewriting two integers. */
   const int32_t* valid_hw;
+  /* optional DEVICE [n][cout] per-channel factor on the conv result, applied after the activation and before the residual:
+   * y = out_scale * act(conv(x) + bias) + res_scale * res.  RCAN's second RCAB conv writes x + s * conv2(t) with it (the channel
+   * attention s is known before the conv runs, see mtx_ca_args.t), so no separate scale-and-add pass reads the activations again. */
+  const float* out_scale;
 } mtx_conv2d_args;
 
 /* C[M,N] = epilogue(A[M,K] * W[N,K]^T)   A row stride lda, C row stride ldc (elements).
@@ -193,6 +197,14 @@ typedef struct mtx_ca_args {
   const float* chan_sum; const float* w1; const float* b1; const float* w2; const float* b2;
   float* s; int32_t n, tiles, c, cr; float inv_hw;
   const float* inv_hw_dev;       /* optional DEVICE scalar that replaces inv_hw (bucket plans: 1 / (valid_h * valid_w)) */
+  /* "pool before the conv" (t != NULL): chan_sum holds the channel sums of t [n, h, w, ldt] (dtype `dtype`), and the pooled vector the
+   * MLP sees is mean(conv3x3(t; conv_w, zero padding 1) + conv_b) — obtained WITHOUT running the conv, by linearity:
+   *   sum_p conv(t)[p][co] = sum_tap sum_ci W[co][tap][ci] * S_tap[ci],  S_tap = total - excluded border row - excluded border column + corner
+   * with the border sums read straight from t (2 rows + 2 columns).  conv_w is the packed conv weight [c][9][c] of type `dtype`.
+   * valid_hw (optional DEVICE {h, w}) replaces h, w (bucket plans). */
+  const void* t; const void* conv_w; const float* conv_b;
+  int32_t h, w, ldt, dtype;
+  const int32_t* valid_hw;
 } mtx_ca_args;
 
 /* image <-> tensor conversions at the page boundary (core/image/image_utils.py:351-366). */

@@ -91,7 +91,10 @@ class RCANUpscaler:
     """Callable like the spandrel model descriptor: `model(tensor[N,3,H,W] f32) -> [N,3,sH,sW] f32`.
     Thread-safe (up to 20 reference worker threads share one instance)."""
 
-    def __init__(self, state_dict: dict, device="cuda", rgb_range: float = 255.0, lib=None, graph: bool = True):
+    def __init__(self, state_dict: dict, device="cuda", rgb_range: float = 255.0, lib=None, graph: bool = True, pool_before_conv: bool = True):
+        """pool_before_conv: the channel attention of an RCAB is computed from the sums of conv1's output before conv2 runs, and conv2
+        writes x + s * conv2(t) itself (3 launches, 5 activation passes per RCAB); False: the 4-launch / 7-pass form (conv2 -> pool ->
+        attention -> scale-and-add pass).  Needs n_feats <= 64 in multiples of 8 (mtx_ca_args.t)"""
         self.lib = lib if lib is not None else get_library()
         self.device = torch.device(device)
         self.hp = derive_rcan_hparams(state_dict)
@@ -104,6 +107,7 @@ class RCANUpscaler:
         self._plans = PlanCache(8)          # pages of one size reuse their plan
         self._buckets = PlanCache(32)       # bubble crops (any size up to BUCKET_MAX) share masked bucket plans
         self._pack(state_dict)
+        self.pool_before_conv = pool_before_conv and self.hp["n_feats"] <= 64 and self.hp["n_feats"] % 8 == 0
 
     # ---- weights ----------------------------------------------------------------------------
     def _pack(self, sd):
@@ -186,12 +190,22 @@ class RCANUpscaler:
         for g in range(hp["n_resgroups"]):
             gin = cur
             for b in range(hp["n_resblocks"]):
-                pb.conv2d(cur, *W[f"g{g}b{b}c1"], cout=C_, act=abi.ACT_RELU, out=t1, label=f"g{g}b{b}.conv1", **vk)
-                pb.conv2d(t1, *W[f"g{g}b{b}c2"], cout=C_, out=t2, chan_sum=chan_sum, label=f"g{g}b{b}.conv2", **vk)
                 w1, b1, w2, b2 = W[f"g{g}b{b}ca"]
-                pb.channel_attention(chan_sum, w1, b1, w2, b2, s_buf, n, tiles, C_, hp["cr"], inv_hw, label=f"g{g}b{b}.ca", inv_hw_dev=inv_hw_dev)
                 nxt = next_buf([cur, gin, head])
-                pb.ew(abi.EW_SCALE_RES, t2, b=cur, s=s_buf, out=nxt, lds=C_, label=f"g{g}b{b}.scale_skip")
+                if self.pool_before_conv:
+                    # RCAB in three launches and five activation passes (was four and seven): conv1 also sums its output t; the channel
+                    # attention of conv2(t) follows from those sums by linearity (mtx_ca_args.t) BEFORE conv2 runs; conv2 then writes
+                    # x + s * (conv2(t) + b) itself, in fp32 with one rounding — no separate scale-and-add pass over the activations
+                    pb.conv2d(cur, *W[f"g{g}b{b}c1"], cout=C_, act=abi.ACT_RELU, out=t1, chan_sum=chan_sum, label=f"g{g}b{b}.conv1", **vk)
+                    cw, cb = W[f"g{g}b{b}c2"]
+                    pb.channel_attention(chan_sum, w1, b1, w2, b2, s_buf, n, tiles, C_, hp["cr"], inv_hw, label=f"g{g}b{b}.ca", inv_hw_dev=inv_hw_dev,
+                                         before_conv=(t1, cw, cb), valid_hw=valid)
+                    pb.conv2d(t1, cw, cb, cout=C_, out=nxt, res=cur, out_scale=s_buf, label=f"g{g}b{b}.conv2", **vk)
+                else:
+                    pb.conv2d(cur, *W[f"g{g}b{b}c1"], cout=C_, act=abi.ACT_RELU, out=t1, label=f"g{g}b{b}.conv1", **vk)
+                    pb.conv2d(t1, *W[f"g{g}b{b}c2"], cout=C_, out=t2, chan_sum=chan_sum, label=f"g{g}b{b}.conv2", **vk)
+                    pb.channel_attention(chan_sum, w1, b1, w2, b2, s_buf, n, tiles, C_, hp["cr"], inv_hw, label=f"g{g}b{b}.ca", inv_hw_dev=inv_hw_dev)
+                    pb.ew(abi.EW_SCALE_RES, t2, b=cur, s=s_buf, out=nxt, lds=C_, label=f"g{g}b{b}.scale_skip")
                 cur = nxt
             nxt = next_buf([cur, gin, head])
             pb.conv2d(cur, *W[f"g{g}tail"], cout=C_, res=gin, out=nxt, label=f"g{g}.tail", **vk)

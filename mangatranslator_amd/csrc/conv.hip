@@ -34,6 +34,7 @@ struct ConvParams {
   int pad_lo;       // zero padding on the top/left side
   int tiles_x, tiles_y, nblk;
   const int* valid_hw;   // device {valid_h, valid_w} or null (stride 1 only): outputs beyond are zero
+  const float* out_scale;   // device [n][cout] factor on act(conv + bias), before the residual (or null)
 };
 
 template <int KS, int S>
@@ -204,9 +205,14 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
         opix = ((size_t)img * p.ho + oy) * (size_t)p.wo + ox;
       }
       if (outside) raw = u32x4{0u, 0u, 0u, 0u};
-      else if (p.chan_sum != nullptr || p.res != nullptr) {
+      else if (p.chan_sum != nullptr || p.res != nullptr || p.out_scale != nullptr) {
         float f[8];
         unpack8<T>(raw, f);
+        if (p.out_scale != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= p.out_scale[(size_t)img * p.cout + co + e];
+          if (p.res == nullptr) raw = pack8<T>(f);
+        }
         if (p.chan_sum != nullptr) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) csum[e] += f[e];
@@ -296,6 +302,7 @@ int conv2d_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.ldx = a->ldx; p.ldy = a->ldy; p.ldres = a->ldres;
   p.act = a->act; p.act_param = a->act_param; p.res_scale = a->res_scale; p.act_after = (a->act_after_res && a->res != nullptr) ? 1 : 0; p.ps = a->pixel_shuffle; p.res_bcast = a->res_broadcast_n;
   p.valid_hw = a->stride == 1 ? a->valid_hw : nullptr;
+  p.out_scale = a->out_scale;
   int rc;
   if (a->dtype == MTX_BF16) rc = launch_conv_t<__bf16>(a, p, stream, tiles);
   else if (a->dtype == MTX_F16) rc = launch_conv_t<_Float16>(a, p, stream, tiles);

@@ -39,13 +39,15 @@ struct ConvC64Params {
   const int* valid_hw;   // device {valid_h, valid_w} or null: outputs beyond are zero and left out of the channel sums
   unsigned y_bytes;      // extent of the output tensor (buffer-descriptor stores; < 4 GiB, see conv_c64_applicable)
   unsigned x_bytes;      // extent of the input tensor (buffer-descriptor halo DMA of interior tiles)
+  const float* out_scale;   // device [n][cout] factor on act(conv + bias), before the residual (or null)
+  unsigned res_bytes;    // extent of the residual tensor (0: no descriptor path for it)
 };
 
 constexpr int C64_T = 16;                                  // tile edge (pixels)
 constexpr int C64_HW = C64_T + 2, C64_HPIX = C64_HW * C64_HW;   // 18 x 18 = 324 halo pixels
 constexpr int C64_W_BYTES = 9 * 64 * 128;
 constexpr int C64_HALO_BYTES = (C64_HPIX + 4) * 128;          // + 4 rows: the last DMA instruction of a halo covers rows 320 .. 327
-constexpr int C64_BIAS_BYTES = 64 * 4;
+constexpr int C64_BIAS_BYTES = 64 * 4 + 2 * 64 * 4;       // bias + one per-channel output-scale row per group
 constexpr int C64_MFMA_NOP = 0;                                     // s_nop after every MFMA of the loop (0: none)
 constexpr int C64_NDMA_C = (C64_HPIX * 8 + 63) / 64;              // 41 wave-instructions of 1 KiB per halo
 constexpr int C64_SMEM = C64_W_BYTES + 2 * C64_HALO_BYTES + C64_BIAS_BYTES;
@@ -102,8 +104,12 @@ template <> __device__ __forceinline__ f16x4 epi_pack<_Float16, MTX_ACT_NONE>(f3
 template <> __device__ __forceinline__ f16x4 epi_pack<_Float16, MTX_ACT_RELU>(f32x4 v, int, float) { return epi_pack_f16<MTX_ACT_RELU>(v); }
 #endif
 
+__device__ __forceinline__ int grp_of(unsigned tid) { return (int)(tid >> 8); }
+
 // ABL: timing-only ablations for profiling (tools/probe_conv.py); 0 = the real kernel
-template <typename T, int ABL, int ACT, bool SUM>
+// SUM: fused channel sums (p.chan_sum); RES: residual input (p.res) — separate variants because each keeps 16 - 36 registers alive across
+// the slot barrier; a launch that wants both goes to the generic kernel (conv_c64_applicable)
+template <typename T, int ABL, int ACT, bool SUM, bool RES = false>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   constexpr int nks_c = 2;                         // k-steps of 32 input channels (narrower inputs read zero chunks: the 3 -> 64 head conv is one launch per page)
   typedef typename Traits<T>::v8 v8;
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   // bias lives in LDS: a global load inside the tile loop would sit behind earlier stores on the
   // in-order vmcnt counter and expose their latency
   float* bias_s = reinterpret_cast<float*>(smem + C64_W_BYTES + 2 * C64_HALO_BYTES);
+  float* scale_s = bias_s + 64 + grp_of(threadIdx.x) * 64;      // this group's out_scale row (refreshed per tile in the MFMA slot)
 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
   const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);           // wave-uniform group id
@@ -135,6 +142,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
     *reinterpret_cast<u32x4*>(wts + row * 128 + ((c ^ (co & 7)) << 4)) = v;
   }
   if (tid < 64) bias_s[tid] = (p.bias != nullptr && tid < p.cout) ? p.bias[tid] : 0.f;
+  if (p.out_scale != nullptr && tid >= 64 && tid < 192)       // one image: its output factors once, for both groups (several images: per tile, below)
+    bias_s[tid] = ((tid & 63) < p.cout) ? p.out_scale[tid & 63] : 0.f;
   const BufView ybuf = make_buf(p.y, p.y_bytes);
   const BufView xbuf = make_buf(p.x, p.x_bytes);
   // INTERIOR tiles (halo and outputs inside the image; the common case by far): everything per-lane is tile-invariant and
@@ -155,7 +164,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   const unsigned chunk_off = (q & 1) ? 32u + 8u * (unsigned)(q - 1) : 8u * (unsigned)q;
 #pragma unroll
   for (int i = 0; i < 4; ++i) st_off[i] = (unsigned)(((wv * 4 + i) * p.w_in + l15) * p.ldy * (int)sizeof(T)) + (ABL == 16 ? (unsigned)(q * 4 * sizeof(T)) : chunk_off);
-  const bool fast_ok = p.ps == 0 && p.cout == 64 && p.res == nullptr && p.valid_hw == nullptr && ABL != 8;
+  const bool fast_ok = p.ps == 0 && p.cout == 64 && p.valid_hw == nullptr && ABL != 8 && (!RES || (!p.res_bcast && p.res_bytes != 0));
+  const bool has_post = RES || p.out_scale != nullptr;        // fp32 scale / residual after the activation
+  const BufView rbuf = make_buf(RES ? p.res : p.x, p.res_bytes);
+  unsigned res_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) res_off[i] = (unsigned)((((wv * 4 + i) * p.w_in + l15) * p.ldres + q * 4) * (int)sizeof(T));
   // ABL 7 (tools/probes/conv_probe.hip): wave 0 of each group of workgroups 0 and 97 writes the shader clock at the phase
   // boundaries of every slot into chan_sum, viewed as uint64 [2 workgroups][2 groups][64 slots][8 events]
   auto stamp = [&](unsigned s_, int ev) {
@@ -335,7 +349,17 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
           C64_MFMA_DRAIN();
         }
         stamp(s, 1);
-        if (p.res != nullptr) {   // this tile's residual, issued after the MFMA loop (its registers are not live inside it);
+        if (p.out_scale != nullptr && p.n > 1 && gt < 64)       // several images: this tile's per-channel output factors -> the group's LDS row (read after the slot barrier)
+          scale_s[gt] = gt < p.cout ? p.out_scale[(size_t)img * p.cout + gt] : 0.f;
+        if (RES && fast_ok && ty0 + C64_T <= p.h && tx0 + C64_T <= p.w_in) {
+          // residual of a tile that lies inside the image: 16 descriptor loads with tile-invariant lane offsets
+          const unsigned sbase = (unsigned)((((size_t)img * p.h + ty0) * p.w_in + tx0) * (size_t)p.ldres * sizeof(T));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[i][j] = buf_load8(rbuf, res_off[i] + (unsigned)(j * 16 * sizeof(T)), sbase);
+        } else
+        if (RES) {   // this tile's residual, issued after the MFMA loop (its registers are not live inside it);
           // the latency hides behind the slot barrier and the next halo's LDS writes
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -383,18 +407,39 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
         const bool fast = fast_ok && (ACT == MTX_ACT_NONE || ACT == MTX_ACT_RELU) && ty0 + C64_T <= p.h && tx0 + C64_T <= p.w_in;
         if (ABL != 4 && fast) {
           const unsigned sbase = (unsigned)((((size_t)img * p.h + ty0) * p.w_in + tx0) * (size_t)p.ldy * sizeof(T));
-          f32x4 b4[4];
+          f32x4 b4[4], sc4[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const f32x4*>(bias_s + j * 16 + q * 4);
+          for (int j = 0; j < 4; ++j) {
+            b4[j] = *reinterpret_cast<const f32x4*>(bias_s + j * 16 + q * 4);
+            sc4[j] = p.out_scale != nullptr ? *reinterpret_cast<const f32x4*>(scale_s + j * 16 + q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             u32x2 o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const v4 ov = epi_pack<T, ACT>(acc[i][j] + b4[j], p.act, p.act_param);
-              if (want_sum) {
+              v4 ov;
+              if (!has_post) {
+                ov = epi_pack<T, ACT>(acc[i][j] + b4[j], p.act, p.act_param);
+                if (want_sum) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) csum[j][r] += to_f32(ov[r]);
+                  for (int r = 0; r < 4; ++r) csum[j][r] += to_f32(ov[r]);
+                }
+              } else {       // y = out_scale * act(conv + bias) + res_scale * res, in fp32 with one rounding
+                f32x4 v = acc[i][j] + b4[j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(v[r], p.act, p.act_param);
+                if (want_sum) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) csum[j][r] += to_f32(from_f32<T>(v[r]));
+                }
+                if (p.out_scale != nullptr) v = v * sc4[j];
+                if (RES) {
+                  const v4 g4 = __builtin_bit_cast(v4, rv[i][j]);
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) v[r] += p.res_scale * to_f32(g4[r]);
+                }
+                ov = epi_pack<T, MTX_ACT_NONE>(v, 0, 0.f);
               }
               o[j] = __builtin_bit_cast(u32x2, ov);
             }
@@ -450,7 +495,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { f[r] = to_f32(from_f32<T>(f[r])); csum[j][r] += f[r]; }
               }
-              if (p.res != nullptr) {
+              if (p.out_scale != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] *= scale_s[co + r];
+              }
+              if (RES) {
                 const v4 g4 = __builtin_bit_cast(v4, rv[i][j]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) f[r] += p.res_scale * to_f32(g4[r]);
@@ -522,6 +571,7 @@ static unsigned long long conv_c64_out_bytes(const mtx_conv2d_args* a) {
 
 bool conv_c64_applicable(const mtx_conv2d_args* a) {
   if (a->act_after_res) return false;
+  if (a->chan_sum != nullptr && a->res != nullptr) return false;        // no variant carries both register sets
   if (conv_c64_out_bytes(a) >= 0xFFFFFFF0ull) return false;   // 32-bit store offsets
   if ((unsigned long long)a->n * a->h * a->w_in * a->ldx * 2 >= 0xFFFFFFF0ull) return false;
   return a->ksize == 3 && a->stride == 1 && a->cin <= 64 && a->cout <= 64;
@@ -537,6 +587,11 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.valid_hw = a->valid_hw;
   p.y_bytes = (unsigned)conv_c64_out_bytes(a);
   p.x_bytes = (unsigned)((unsigned long long)a->n * a->h * a->w_in * a->ldx * 2);
+  p.out_scale = a->out_scale;
+  {
+    const unsigned long long rb = a->res ? (unsigned long long)(a->res_broadcast_n ? 1 : a->n) * a->h * a->w_in * (a->pixel_shuffle == 2 ? 4 : 1) * a->ldres * 2 : 0;
+    p.res_bytes = rb < 0xFFFFFFF0ull ? (unsigned)rb : 0u;
+  }
   p.tiles_x = (a->w_in + C64_T - 1) / C64_T;
   p.tiles_y = (a->h + C64_T - 1) / C64_T;
   if (c64_num_cus(err) < 0) return MTX_ERR_HIP;
@@ -545,15 +600,13 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
       hipMemsetAsync(a->chan_sum, 0, (size_t)a->n * grid * 8 * a->cout * sizeof(float), (hipStream_t)stream) != hipSuccess) {
     *err = "conv2d: chan_sum memset failed"; return MTX_ERR_HIP;
   }
-#define C64_GO(TT, AB, AC, SM) MTX_LAUNCH((conv3x3_c64_kernel<TT, AB, AC, SM>), dim3(grid), dim3(512), 0, stream, p)
-#define C64_ACT(TT, SM) do { if (a->act == MTX_ACT_NONE) C64_GO(TT, 0, MTX_ACT_NONE, SM); else if (a->act == MTX_ACT_RELU) C64_GO(TT, 0, MTX_ACT_RELU, SM); \
-                             else C64_GO(TT, 0, -1, SM); } while (0)
+#define C64_GO(TT, AB, AC, SM, RS) MTX_LAUNCH((conv3x3_c64_kernel<TT, AB, AC, SM, RS>), dim3(grid), dim3(512), 0, stream, p)
+#define C64_ACT(TT, SM, RS) do { if (a->act == MTX_ACT_NONE) C64_GO(TT, 0, MTX_ACT_NONE, SM, RS); else if (a->act == MTX_ACT_RELU) C64_GO(TT, 0, MTX_ACT_RELU, SM, RS); \
+                                 else C64_GO(TT, 0, -1, SM, RS); } while (0)
+#define C64_VAR(TT) do { if (sum) C64_ACT(TT, true, false); else if (a->res != nullptr) C64_ACT(TT, false, true); else C64_ACT(TT, false, false); } while (0)
   const bool sum = a->chan_sum != nullptr;
-  if (a->dtype == MTX_BF16) { if (sum) C64_ACT(__bf16, true); else C64_ACT(__bf16, false); }
-  else if (a->dtype == MTX_F16) {
-    if (sum) C64_ACT(_Float16, true);
-    else C64_ACT(_Float16, false);
-  }
+  if (a->dtype == MTX_BF16) C64_VAR(__bf16);
+  else if (a->dtype == MTX_F16) C64_VAR(_Float16);
   else { *err = "conv2d: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
   return MTX_OK;
 }

@@ -331,6 +331,11 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
 }
 
 // ---- RCAN channel attention squeeze/excite: one workgroup per image ---------------------------
+// Two forms.  Classic: chan_sum holds the channel sums of the tensor to pool.  "Pool before the conv" (p.t != null): chan_sum holds the
+// sums of t, the INPUT of a 3x3 conv, and the pooled vector is mean(conv(t) + b) by linearity —
+//   sum_p conv(t)[p][co] = sum_tap sum_ci W[co][tap][ci] * S_tap[ci],   S_tap = total - (border row the tap never reaches) - (border column) + (corner)
+// — so the attention factors exist before the conv runs and the conv can write x + s * conv(t) itself (mtx_conv2d_args.out_scale).
+template <typename T>
 __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
   __shared__ float mean[512];
   __shared__ float hid[128];
@@ -360,12 +365,93 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
     part[tid] = s;
   }
   __syncthreads();
+  const float inv_hw = p.inv_hw_dev ? *p.inv_hw_dev : p.inv_hw;
   for (int c = tid; c < p.c; c += 1024) {
     float s = 0.f;
     for (int k = 0; k < per; ++k) s += part[k * p.c + c];
-    mean[c] = s * (p.inv_hw_dev ? *p.inv_hw_dev : p.inv_hw);
+    mean[c] = p.t != nullptr ? s : s * inv_hw;          // pool-before-conv: the TOTAL of t, turned into the conv's mean below
   }
   __syncthreads();
+  if (p.t != nullptr) {                                 // C <= 64 (checked by the launcher)
+    __shared__ float red[4 * 32 * 64];                  // strip partials [4 strips][32 pixel subsets][64 ch]; then the 9 * 8 * C dot partials
+    __shared__ float strip[4][64];                      // top row, bottom row, left column, right column
+    __shared__ float corner[4][64];                     // (0,0) (0,W-1) (H-1,0) (H-1,W-1)
+    __shared__ float stap[9][64];
+    float* redall = red;
+    const int H = p.valid_hw ? p.valid_hw[0] : p.h, W = p.valid_hw ? p.valid_hw[1] : p.w;
+    const T* tb = reinterpret_cast<const T*>(p.t) + (size_t)n * p.h * p.w * p.ldt;
+    {   // the four border strips at once: 256 threads per strip = 8 channel chunks x 32 pixel subsets, four loads in flight per thread
+      const int k = tid >> 8, c8 = tid & 7, sub = (tid >> 3) & 31;
+      const int npx = k < 2 ? W : H;
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (c8 * 8 < p.c) {
+        auto at = [&](int px) -> u32x4 {
+          const int y = k == 0 ? 0 : (k == 1 ? H - 1 : px), x = k == 2 ? 0 : (k == 3 ? W - 1 : px);
+          return *reinterpret_cast<const u32x4*>(tb + ((size_t)y * p.w + x) * p.ldt + c8 * 8);
+        };
+        int px = sub;
+        for (; px + 96 < npx; px += 128) {
+          u32x4 r4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r4[j] = at(px + 32 * j);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float f[8];
+            unpack8<T>(r4[j], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += f[e];
+          }
+        }
+        for (; px < npx; px += 32) {
+          float f[8];
+          unpack8<T>(at(px), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += f[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) redall[(k * 32 + sub) * 64 + c8 * 8 + e] = a[e];
+    }
+    __syncthreads();
+    if (tid < 4 * 64) {
+      const int k = tid >> 6, c = tid & 63;
+      float s = 0.f;
+      for (int j = 0; j < 32; ++j) s += redall[(k * 32 + j) * 64 + c];
+      strip[k][c] = s;
+      const int y = (k & 2) ? H - 1 : 0, x = (k & 1) ? W - 1 : 0;
+      corner[k][c] = c < p.c ? to_f32(tb[((size_t)y * p.w + x) * p.ldt + c]) : 0.f;
+    }
+    __syncthreads();
+    if (tid < 9 * 64) {
+      const int tap = tid >> 6, c = tid & 63, dy = tap / 3 - 1, dx = tap % 3 - 1;
+      float s = mean[c];
+      if (dy == 1) s -= strip[0][c]; else if (dy == -1) s -= strip[1][c];      // a tap one row DOWN never reads row 0 for an in-image output, ...
+      if (dx == 1) s -= strip[2][c]; else if (dx == -1) s -= strip[3][c];
+      if (dy != 0 && dx != 0) s += corner[(dy == -1 ? 2 : 0) + (dx == -1 ? 1 : 0)][c];
+      stap[tap][c] = s;
+    }
+    __syncthreads();
+    {   // mean of conv(t) + b: one 16-byte filter chunk (8 input channels of one tap of one output channel) per item, 4.5 items per thread
+      const int chunks = p.c / 8, per_co = 9 * chunks, items = p.c * per_co;
+      for (int it = tid; it < items; it += 1024) {
+        const int co = it / per_co, rem = it - co * per_co, tap = rem / chunks, c8 = rem - tap * chunks;
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.conv_w) + ((size_t)co * 9 + tap) * p.c + c8 * 8);
+        float f[8];
+        unpack8<T>(raw, f);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e] * stap[tap][c8 * 8 + e];
+        redall[it] = s;
+      }
+      __syncthreads();
+      if (tid < p.c) {
+        float s = 0.f;
+        for (int k = 0; k < per_co; ++k) s += redall[tid * per_co + k];
+        mean[tid] = (p.conv_b ? p.conv_b[tid] : 0.f) + s * inv_hw;
+      }
+      __syncthreads();
+    }
+  }
   for (int r = tid; r < p.cr; r += 1024) {
     float s = p.b1 ? p.b1[r] : 0.f;
     for (int c = 0; c < p.c; ++c) s += p.w1[r * p.c + c] * mean[c];
@@ -382,7 +468,14 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
 int ca_launch(const mtx_ca_args* a, void* stream, const char** err) {
   if (!a->chan_sum || !a->w1 || !a->w2 || !a->s) { *err = "channel_attention: null operand"; return MTX_ERR_INVALID; }
   if (a->c > 512 || a->cr > 128 || a->c < 1 || a->cr < 1) { *err = "channel_attention: C <= 512 and C/r <= 128"; return MTX_ERR_INVALID; }
-  MTX_LAUNCH(ca_kernel, dim3((unsigned)a->n), dim3(1024), 0, stream, *a);
+  if (a->t != nullptr) {
+    if (!a->conv_w || a->c > 64 || a->c % 8 || a->ldt % 8 || a->h < 1 || a->w < 1) { *err = "channel_attention (pool before the conv): needs conv_w, C <= 64 in multiples of 8, ldt % 8 == 0"; return MTX_ERR_INVALID; }
+    if (a->dtype == MTX_BF16) MTX_LAUNCH(ca_kernel<__bf16>, dim3((unsigned)a->n), dim3(1024), 0, stream, *a);
+    else if (a->dtype == MTX_F16) MTX_LAUNCH(ca_kernel<_Float16>, dim3((unsigned)a->n), dim3(1024), 0, stream, *a);
+    else { *err = "channel_attention: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+    return MTX_OK;
+  }
+  MTX_LAUNCH(ca_kernel<_Float16>, dim3((unsigned)a->n), dim3(1024), 0, stream, *a);
   return MTX_OK;
 }
 

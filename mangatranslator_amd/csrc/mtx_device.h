@@ -283,6 +283,16 @@ __device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, uns
 #endif
 }
 
+__device__ __forceinline__ u32x2 buf_load8(const BufView& b, unsigned voff, unsigned soff) {
+#ifdef MTX_EMU
+  u32x2 r = u32x2{0u, 0u};
+  if ((unsigned long)voff + 8 <= b.bytes) memcpy(&r, b.base + voff + soff, 8);
+  return r;
+#else
+  return __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, (int)voff, (int)soff, 0);
+#endif
+}
+
 // 8-byte store through a buffer descriptor.  A lane that must not write passes an offset >= the
 // descriptor's size: the range check drops it, and the instruction is still ISSUED by the wave — the
 // number of stores in flight does not depend on predicates (see MTX_WAIT_VMEM_BUT).

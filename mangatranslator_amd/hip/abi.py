@@ -2,7 +2,7 @@
 mtx_abi_sizeof() when the library is opened)."""
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums
 BF16, F16, F32, U8, I32, F8 = 0, 1, 2, 3, 4, 5
@@ -23,7 +23,7 @@ class ConvArgs(C.Structure):
                 ("ldx", i32), ("ldy", i32), ("ldres", i32),
                 ("act", i32), ("act_param", f32), ("res_scale", f32),
                 ("pixel_shuffle", i32), ("dtype", i32), ("res_broadcast_n", i32), ("pad_mode", i32), ("act_after_res", i32),
-                ("valid_hw", vp)]
+                ("valid_hw", vp), ("out_scale", vp)]
 
 
 class GemmArgs(C.Structure):
@@ -75,7 +75,8 @@ class EwArgs(C.Structure):
 
 class CaArgs(C.Structure):
     _fields_ = [("chan_sum", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("s", vp),
-                ("n", i32), ("tiles", i32), ("c", i32), ("cr", i32), ("inv_hw", f32), ("inv_hw_dev", vp)]
+                ("n", i32), ("tiles", i32), ("c", i32), ("cr", i32), ("inv_hw", f32), ("inv_hw_dev", vp),
+                ("t", vp), ("conv_w", vp), ("conv_b", vp), ("h", i32), ("w", i32), ("ldt", i32), ("dtype", i32), ("valid_hw", vp)]
 
 
 class ImgArgs(C.Structure):

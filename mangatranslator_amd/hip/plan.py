@@ -230,7 +230,7 @@ class PlanBuilder:
                act: int = abi.ACT_NONE, act_param: float = 0.0, res: Optional[Act] = None,
                res_scale: float = 1.0, out: Optional[Act] = None, pixel_shuffle: int = 0,
                chan_sum=None, res_broadcast: bool = False, pad_mode: int = 0, act_after_res: bool = False,
-               label: str = "conv", valid_hw=None) -> Act:
+               label: str = "conv", valid_hw=None, out_scale=None) -> Act:
         pad_total = 1 if pad_mode == 1 else 2 * (ksize // 2)
         ho = (x.h + pad_total - ksize) // stride + 1
         wo = (x.w + pad_total - ksize) // stride + 1
@@ -253,6 +253,7 @@ class PlanBuilder:
         a.pad_mode = pad_mode
         a.act_after_res = 1 if act_after_res else 0
         a.valid_hw = _ptr(valid_hw)
+        a.out_scale = _ptr(out_scale)        # device [n][cout] f32: y = out_scale * act(conv + bias) + res_scale * res
         self._add(abi.OP_CONV2D, a, label)
         return out
 
@@ -372,11 +373,19 @@ class PlanBuilder:
         self._add(abi.OP_EW, e, label)
         return out
 
-    def channel_attention(self, chan_sum, w1, b1, w2, b2, s_out, n, tiles, c, cr, inv_hw, label="ca", inv_hw_dev=None):
+    def channel_attention(self, chan_sum, w1, b1, w2, b2, s_out, n, tiles, c, cr, inv_hw, label="ca", inv_hw_dev=None,
+                          before_conv=None, valid_hw=None):
+        """before_conv = (t: Act, conv_w_packed, conv_bias): chan_sum holds the sums of t and the factors are those of
+        mean(conv3x3(t) + bias) — available before that conv runs (include/mtx_hip.h, mtx_ca_args.t)"""
         a = abi.CaArgs()
         a.inv_hw_dev = _ptr(inv_hw_dev)
         a.chan_sum, a.w1, a.b1, a.w2, a.b2, a.s = (_ptr(chan_sum), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(s_out))
         a.n, a.tiles, a.c, a.cr, a.inv_hw = n, tiles, c, cr, inv_hw
+        if before_conv is not None:
+            t, cw, cb = before_conv
+            a.t, a.conv_w, a.conv_b = t.ptr, _ptr(cw), _ptr(cb)
+            a.h, a.w, a.ldt, a.dtype = t.h, t.w, t.ld, self.dtype
+            a.valid_hw = _ptr(valid_hw)
         self._add(abi.OP_CA, a, label)
         return s_out
 

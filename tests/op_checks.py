@@ -454,3 +454,52 @@ def check_swiglu(lib, dtype, rows, hid, seed=0):
     _run(pb)
     err = _relerr(y.torch().cpu().view(rows, hid), ref)
     assert err < TOL[dtype], f"swiglu mismatch {err}"
+
+
+def check_rcab_tail(lib, dtype, n=2, h=37, w=29, c=64, cr=4, canvas=None, seed=0):
+    """The two ops that close an RCAB in the pool-before-conv form, against torch on the same rounded operands:
+    (1) channel attention of mean(conv3x3(t) + b) from the channel sums of t (linearity; border rows / columns / corners read from t),
+    (2) conv with a per-channel output factor and a residual: y = s * (conv(t) + b) + x.
+    canvas=(H, W): t lives on a larger canvas and the image size comes from a device-side valid_hw (bucket plans)."""
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    H, W = canvas if canvas else (h, w)
+    t = torch.zeros(n, H, W, c)
+    t[:, :h, :w] = torch.relu(torch.randn(n, h, w, c, generator=g))
+    x = torch.randn(n, H, W, c, generator=g)
+    wt = torch.randn(c, c, 3, 3, generator=g) / math.sqrt(c * 9)
+    b = torch.randn(c, generator=g) * 0.1
+    w1, b1 = torch.randn(cr, c, generator=g) / math.sqrt(c), torch.randn(cr, generator=g) * 0.1
+    w2, b2 = torch.randn(c, cr, generator=g) / math.sqrt(cr), torch.randn(c, generator=g) * 0.1
+    tq, xq, wq = t.to(td).float(), x.to(td).float(), wt.to(td).float()
+    u = F.conv2d(tq[:, :h, :w].permute(0, 3, 1, 2), wq, b, padding=1)                   # the image alone: its own zero padding
+    m = u.mean((2, 3))
+    s_ref = torch.sigmoid(F.linear(torch.relu(F.linear(m, w1, b1)), w2, b2))
+    y_ref = (s_ref[:, :, None, None] * u + xq[:, :h, :w].permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+
+    pb = PlanBuilder(lib, dev, dtype)
+    tb = pb.act(n, H, W, c); tb.t.copy_(tq.to(td))
+    xb = pb.act(n, H, W, c); xb.t.copy_(xq.to(td))
+    wpk = pb.const(wt.permute(0, 2, 3, 1).reshape(c, 9, c), td)
+    bias = pb.const(b, torch.float32)
+    valid = None
+    if canvas:
+        valid = pb.buf((2,), torch.int32); valid.copy_(torch.tensor([h, w], dtype=torch.int32))
+    # channel sums of t as a conv with SUM would leave them: any split into partial rows
+    tiles = 5
+    cs = pb.buf((n, tiles, c), torch.float32, zero=True)
+    tot = tq.sum((1, 2))
+    cs[:, 0] = (tot * 0.25).to(cs.device); cs[:, 3] = (tot * 0.75).to(cs.device)
+    s_buf = pb.buf((n, c), torch.float32)
+    pb.channel_attention(cs, pb.const(w1, torch.float32), pb.const(b1, torch.float32), pb.const(w2, torch.float32), pb.const(b2, torch.float32),
+                         s_buf, n, tiles, c, cr, 1.0 / (h * w), before_conv=(tb, wpk, bias), valid_hw=valid)
+    y = pb.conv2d(tb, wpk, bias, c, 3, 1, res=xb, out_scale=s_buf, valid_hw=valid)
+    _run(pb)
+    e_s = (s_buf.cpu() - s_ref).abs().max().item()
+    assert e_s < 2e-3, f"channel attention (pool before the conv) off by {e_s}"
+    out = y.torch().cpu().float()
+    err = _relerr(out[:, :h, :w], y_ref)
+    assert err < TOL[dtype], f"scaled conv + residual mismatch rel err {err}"
+    if canvas:
+        assert float(out[:, h:].abs().max()) == 0.0 and float(out[:, :, w:].abs().max()) == 0.0      # beyond the image: zeros
+    return e_s, err

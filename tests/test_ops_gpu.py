@@ -154,3 +154,11 @@ def test_gemm_stream_k(hip_lib):
     oc.check_gemm(hip_lib, abi.BF16, m=512, n=3072, k=12288, with_res=True, with_gate=True)        # whole problem dealt over K
     oc.check_gemm(hip_lib, abi.BF16, m=8624, n=3072, k=15360, act=abi.ACT_NONE, with_res=True, with_gate=True)   # left-over tiles only
     oc.check_gemm(hip_lib, abi.F16, m=8112, n=3072, k=12288)
+
+
+@pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])
+def test_rcab_tail_pool_before_conv(hip_lib, dtype):
+    """RCAN's RCAB tail: channel attention from the sums of conv2's INPUT, conv2 writing x + s * conv2(t) (interior and border tiles)"""
+    oc.check_rcab_tail(hip_lib, dtype, n=2, h=37, w=29)
+    oc.check_rcab_tail(hip_lib, dtype, n=1, h=50, w=52)
+    oc.check_rcab_tail(hip_lib, dtype, n=1, h=21, w=40, canvas=(64, 64))

@@ -151,3 +151,11 @@ def test_gemm_stream_k_tail(emu_lib):
 def test_gemm_stream_k_whole_problem(emu_lib):
     """few tiles, long K: every tile's K range is dealt across the units (no full-tile launch at all)"""
     oc.check_gemm(emu_lib, abi.BF16, m=256, n=200, k=8192, with_res=True, with_gate=True)
+
+
+@pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])
+def test_rcab_tail_pool_before_conv(emu_lib, dtype):
+    """RCAN's RCAB tail: channel attention from the sums of conv2's INPUT, conv2 writing x + s * conv2(t) (interior and border tiles)"""
+    oc.check_rcab_tail(emu_lib, dtype, n=2, h=37, w=29)
+    oc.check_rcab_tail(emu_lib, dtype, n=1, h=50, w=52)
+    oc.check_rcab_tail(emu_lib, dtype, n=1, h=21, w=40, canvas=(64, 64))
