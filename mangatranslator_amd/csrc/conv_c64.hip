@@ -165,11 +165,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) st_off[i] = (unsigned)(((wv * 4 + i) * p.w_in + l15) * p.ldy * (int)sizeof(T)) + (ABL == 16 ? (unsigned)(q * 4 * sizeof(T)) : chunk_off);
   const bool fast_ok = p.ps == 0 && p.cout == 64 && p.valid_hw == nullptr && ABL != 8 && (!RES || (!p.res_bcast && p.res_bytes != 0));
+  constexpr bool FAST_ACT = ACT == MTX_ACT_NONE || ACT == MTX_ACT_RELU;       // the activations the interior-tile paths are written for
   const bool has_post = RES || p.out_scale != nullptr;        // fp32 scale / residual after the activation
   const BufView rbuf = make_buf(RES ? p.res : p.x, p.res_bytes);
   unsigned res_off[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) res_off[i] = (unsigned)((((wv * 4 + i) * p.w_in + l15) * p.ldres + q * 4) * (int)sizeof(T));
+  for (int i = 0; i < 4; ++i) res_off[i] = (unsigned)(((wv * 4 + i) * p.w_in + l15) * p.ldres * (int)sizeof(T)) + chunk_off;     // 16-byte chunks, like the stores
   // ABL 7 (tools/probes/conv_probe.hip): wave 0 of each group of workgroups 0 and 97 writes the shader clock at the phase
   // boundaries of every slot into chan_sum, viewed as uint64 [2 workgroups][2 groups][64 slots][8 events]
   auto stamp = [&](unsigned s_, int ev) {
@@ -351,13 +352,17 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
         stamp(s, 1);
         if (p.out_scale != nullptr && p.n > 1 && gt < 64)       // several images: this tile's per-channel output factors -> the group's LDS row (read after the slot barrier)
           scale_s[gt] = gt < p.cout ? p.out_scale[(size_t)img * p.cout + gt] : 0.f;
-        if (RES && fast_ok && ty0 + C64_T <= p.h && tx0 + C64_T <= p.w_in) {
-          // residual of a tile that lies inside the image: 16 descriptor loads with tile-invariant lane offsets
+        if (RES && FAST_ACT && fast_ok && ty0 + C64_T <= p.h && tx0 + C64_T <= p.w_in) {
+          // residual of a tile that lies inside the image: 8 descriptor loads of 16 bytes with tile-invariant lane offsets, in the
+          // lane-exchanged layout of the stores (64-byte half lines per pixel); the epilogue's exchange puts the quads back
           const unsigned sbase = (unsigned)((((size_t)img * p.h + ty0) * p.w_in + tx0) * (size_t)p.ldres * sizeof(T));
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rv[i][j] = buf_load8(rbuf, res_off[i] + (unsigned)(j * 16 * sizeof(T)), sbase);
+            for (int jp = 0; jp < 2; ++jp) {
+              const u32x4 r4 = buf_load16(rbuf, res_off[i] + (unsigned)(jp * 32 * sizeof(T)), sbase);
+              rv[i][2 * jp] = u32x2_t{r4[0], r4[1]}; rv[i][2 * jp + 1] = u32x2_t{r4[2], r4[3]};
+            }
         } else
         if (RES) {   // this tile's residual, issued after the MFMA loop (its registers are not live inside it);
           // the latency hides behind the slot barrier and the next halo's LDS writes
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
           if (sum_img >= 0) flush_sums(sum_img);
           sum_img = img;
         }
-        const bool fast = fast_ok && (ACT == MTX_ACT_NONE || ACT == MTX_ACT_RELU) && ty0 + C64_T <= p.h && tx0 + C64_T <= p.w_in;
+        const bool fast = fast_ok && FAST_ACT && ty0 + C64_T <= p.h && tx0 + C64_T <= p.w_in;
         if (ABL != 4 && fast) {
           const unsigned sbase = (unsigned)((((size_t)img * p.h + ty0) * p.w_in + tx0) * (size_t)p.ldy * sizeof(T));
           f32x4 b4[4], sc4[4];
@@ -416,6 +421,15 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             u32x2 o[4];
+            if (RES) {               // the residual arrived as 16-byte chunks in the exchanged layout: the same exchange restores this lane's quads
+#pragma unroll
+              for (int jp = 0; jp < 2; ++jp) {
+                uint32_t a0 = rv[i][2 * jp][0], a1 = rv[i][2 * jp][1], c0 = rv[i][2 * jp + 1][0], c1 = rv[i][2 * jp + 1][1];
+                row_pair_exchange(a0, c0);
+                row_pair_exchange(a1, c1);
+                rv[i][2 * jp] = u32x2_t{a0, a1}; rv[i][2 * jp + 1] = u32x2_t{c0, c1};
+              }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               v4 ov;

@@ -341,30 +341,49 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
   __shared__ float hid[128];
   __shared__ float part[1024];
   const int n = blockIdx.x, tid = threadIdx.x;
-  // partial-sum rows are reduced by all 1024 threads: thread -> (row subset, channel)
-  const int per = 1024 / p.c > 0 ? 1024 / p.c : 1;          // row subsets (C <= 512 -> >= 2)
-  {
+  // partial-sum rows are reduced by all 1024 threads
+  int per;                                                // row subsets
+  if (p.c % 4 == 0 && p.c <= 256) {
+    // thread -> (row subset, 4-channel group): 16-byte loads, eight in flight (the rows come from L2 one round trip apiece; a chain of
+    // dependent adds around single 4-byte loads made this kernel 33 us for 2 048 rows — RCAN runs it 200 times per page)
+    const int c4n = p.c / 4;
+    per = 1024 / c4n;
+    const int c4 = tid % c4n, sub = tid / c4n;
+    f32x4 acc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (sub < per) {
+      const float* src = p.chan_sum + (size_t)n * p.tiles * p.c + c4 * 4;
+      int t = sub;
+      for (; t + 7 * per < p.tiles; t += 8 * per) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)(t + k * per) * p.c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc4 += v[k];
+      }
+      for (; t < p.tiles; t += per) acc4 += *reinterpret_cast<const f32x4*>(src + (size_t)t * p.c);
+    }
+    __shared__ float part4[1024 * 4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part4[(sub * c4n + c4) * 4 + e] = acc4[e];
+    __syncthreads();
+    for (int c = tid; c < p.c; c += 1024) {
+      float s = 0.f;
+      for (int k = 0; k < per; ++k) s += part4[k * p.c + c];
+      part[c] = s;                                        // the channel totals
+    }
+    __syncthreads();
+    per = 1;
+  } else {
+    per = 1024 / p.c > 0 ? 1024 / p.c : 1;
     const int c = tid % p.c, sub = tid / p.c;
     float s = 0.f;
     if (sub < per) {
       const float* src = p.chan_sum + (size_t)n * p.tiles * p.c + c;
-      // eight loads in flight per thread: the rows come from L2 one round trip apiece, and a chain of dependent adds
-      // around single loads made this kernel 33 us for 2 048 partial rows (RCAN runs it 200 times per page)
-      int t = sub;
-      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (; t + 7 * per < p.tiles; t += 8 * per) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(t + k * per) * p.c];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] += v[k];
-      }
-      for (; t < p.tiles; t += per) s += src[(size_t)t * p.c];
-      s += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      for (int t = sub; t < p.tiles; t += per) s += src[(size_t)t * p.c];
     }
     part[tid] = s;
+    __syncthreads();
   }
-  __syncthreads();
   const float inv_hw = p.inv_hw_dev ? *p.inv_hw_dev : p.inv_hw;
   for (int c = tid; c < p.c; c += 1024) {
     float s = 0.f;
