@@ -353,12 +353,12 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
     if (sub < per) {
       const float* src = p.chan_sum + (size_t)n * p.tiles * p.c + c4 * 4;
       int t = sub;
-      for (; t + 7 * per < p.tiles; t += 8 * per) {
-        f32x4 v[8];
+      for (; t + 15 * per < p.tiles; t += 16 * per) {
+        f32x4 v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)(t + k * per) * p.c);
+        for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)(t + k * per) * p.c);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc4 += v[k];
+        for (int k = 0; k < 16; ++k) acc4 += v[k];
       }
       for (; t < p.tiles; t += per) acc4 += *reinterpret_cast<const f32x4*>(src + (size_t)t * p.c);
     }
@@ -409,12 +409,12 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
           return *reinterpret_cast<const u32x4*>(tb + ((size_t)y * p.w + x) * p.ldt + c8 * 8);
         };
         int px = sub;
-        for (; px + 96 < npx; px += 128) {
-          u32x4 r4[4];
+        for (; px + 224 < npx; px += 256) {             // eight pixels in flight per thread
+          u32x4 r4[8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) r4[j] = at(px + 32 * j);
+          for (int j = 0; j < 8; ++j) r4[j] = at(px + 32 * j);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 8; ++j) {
             float f[8];
             unpack8<T>(r4[j], f);
 #pragma unroll
