@@ -48,7 +48,6 @@ constexpr int C64_HW = C64_T + 2, C64_HPIX = C64_HW * C64_HW;   // 18 x 18 = 324
 constexpr int C64_W_BYTES = 9 * 64 * 128;
 constexpr int C64_HALO_BYTES = (C64_HPIX + 4) * 128;          // + 4 rows: the last DMA instruction of a halo covers rows 320 .. 327
 constexpr int C64_BIAS_BYTES = 64 * 4 + 2 * 64 * 4;       // bias + one per-channel output-scale row per group
-constexpr int C64_MFMA_NOP = 0;                                     // s_nop after every MFMA of the loop (0: none)
 constexpr int C64_NDMA_C = (C64_HPIX * 8 + 63) / 64;              // 41 wave-instructions of 1 KiB per halo
 constexpr int C64_SMEM = C64_W_BYTES + 2 * C64_HALO_BYTES + C64_BIAS_BYTES;
 
@@ -59,20 +58,12 @@ constexpr int C64_SMEM = C64_W_BYTES + 2 * C64_HALO_BYTES + C64_BIAS_BYTES;
 template <typename T> __device__ __forceinline__ void mfma_inplace(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) {
   c = Traits<T>::mfma(a, b, c);
 }
-template <typename T, int NOP> __device__ __forceinline__ void mfma_inplace_nop(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) {
-  c = Traits<T>::mfma(a, b, c);
-}
 #define C64_FENCE() ((void)0)
 #define C64_MFMA_DRAIN() ((void)0)
 #else
 template <typename T> __device__ __forceinline__ void mfma_inplace(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b);
 template <> __device__ __forceinline__ void mfma_inplace<_Float16>(f32x4& c, const f16x8& a, const f16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-// the same followed by s_nop NOP: the wave steps back from the issue port while its MFMA runs (see the MFMA loop)
-template <typename T, int NOP> __device__ __forceinline__ void mfma_inplace_nop(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) {
-  mfma_inplace<T>(c, a, b);
-  if (NOP > 0) asm volatile("s_nop %0" :: "n"(NOP - 1));
 }
 template <> __device__ __forceinline__ void mfma_inplace<__bf16>(f32x4& c, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
@@ -106,7 +97,10 @@ template <> __device__ __forceinline__ f16x4 epi_pack<_Float16, MTX_ACT_RELU>(f3
 
 __device__ __forceinline__ int grp_of(unsigned tid) { return (int)(tid >> 8); }
 
-// ABL: timing-only ablations for profiling (tools/probe_conv.py); 0 = the real kernel
+// ABL: timing-only ablations for tools/probes/conv_probe.hip; 0 = the real kernel.  1: no MFMA loop, 3: no halo DMA, 4: no epilogue / stores,
+// 7: shader-clock stamps at the phase boundaries, 8: the generic per-tile address / bounds paths on interior tiles too.  (The what-ifs that
+// settled design questions — LDS reads or MFMAs alone, s_nop behind every MFMA, stores before the DMA, no wait at all, 8-byte stores — are
+// recorded with their numbers in DESIGN.md section 5 and were taken out of the source.)
 // SUM: fused channel sums (p.chan_sum); RES: residual input (p.res) — separate variants because each keeps 16 - 36 registers alive across
 // the slot barrier; a launch that wants both goes to the generic kernel (conv_c64_applicable)
 template <typename T, int ABL, int ACT, bool SUM, bool RES = false>
@@ -163,7 +157,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   unsigned st_off[4];
   const unsigned chunk_off = (q & 1) ? 32u + 8u * (unsigned)(q - 1) : 8u * (unsigned)q;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) st_off[i] = (unsigned)(((wv * 4 + i) * p.w_in + l15) * p.ldy * (int)sizeof(T)) + (ABL == 16 ? (unsigned)(q * 4 * sizeof(T)) : chunk_off);
+  for (int i = 0; i < 4; ++i) st_off[i] = (unsigned)(((wv * 4 + i) * p.w_in + l15) * p.ldy * (int)sizeof(T)) + chunk_off;
   const bool fast_ok = p.ps == 0 && p.cout == 64 && p.valid_hw == nullptr && ABL != 8 && (!RES || (!p.res_bcast && p.res_bytes != 0));
   constexpr bool FAST_ACT = ACT == MTX_ACT_NONE || ACT == MTX_ACT_RELU;       // the activations the interior-tile paths are written for
   const bool has_post = RES || p.out_scale != nullptr;        // fp32 scale / residual after the activation
@@ -328,10 +322,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                if (ABL != 11) mfma_inplace_nop<T, (ABL == 12 ? 1 : ABL == 13 ? 2 : ABL == 14 ? 3 : C64_MFMA_NOP)>(acc[i][j], wf[st & 1][j], xr[g & 1][i + ky]);      // ABL 11: the LDS reads without the MFMAs
-                else { asm volatile("s_nop 3" :: "v"(wf[st & 1][j]), "v"(xr[g & 1][i + ky])); }
+                mfma_inplace<T>(acc[i][j], wf[st & 1][j], xr[g & 1][i + ky]);
                 const int idx = j * 4 + i;
-                if (ABL != 10 && idx < 6 && st + 1 < NST) {                                    // ABL 10: the MFMAs without the LDS reads
+                if (idx < 6 && st + 1 < NST) {
                   const int rd = idx;                            // which read goes out behind this MFMA
                   if (rd < 4) {
                     C64_FENCE();
@@ -396,8 +389,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       const unsigned lin1 = k + 1 < K ? tile_of(k + 1) : ~0u;
       int stored_n = 0;                       // store instructions this wave issued in this slot (exact: see the wait below)
       // the next tile's halo goes in flight FIRST (this group's halo buffer is idle from the slot barrier on), so its latency runs
-      // behind the epilogue below (whole RCAN graph 92.4 vs 96.5 ms with it issued after the stores; ABL 5 = that older order)
-      if (ABL != 3 && ABL != 5 && ABL != 15 && lin1 != ~0u) dma_halo(lin1);
+      // behind the epilogue below (whole RCAN graph 92.4 vs 96.5 ms with it issued after the stores)
+      if (ABL != 3 && lin1 != ~0u) dma_halo(lin1);
       stamp(s, 2);
       // (1) epilogue straight from the accumulators: bias, activation, residual, 8-byte NHWC stores
       if (lin != ~0u) {
@@ -457,20 +450,15 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
               }
               o[j] = __builtin_bit_cast(u32x2, ov);
             }
-            if (ABL == 16) {              // ablation: the 8-byte stores (32-byte segments per pixel)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) buf_store8(ybuf, st_off[i] + (unsigned)(j * 16 * sizeof(T)), o[j], sbase);
-            } else {
-#pragma unroll
-              for (int jp = 0; jp < 2; ++jp) {
-                uint32_t a0 = o[2 * jp][0], a1 = o[2 * jp][1], c0 = o[2 * jp + 1][0], c1 = o[2 * jp + 1][1];
-                row_pair_exchange(a0, c0);
-                row_pair_exchange(a1, c1);
-                buf_store16(ybuf, st_off[i] + (unsigned)(jp * 32 * sizeof(T)), u32x4{a0, a1, c0, c1}, sbase);
-              }
+            for (int jp = 0; jp < 2; ++jp) {
+              uint32_t a0 = o[2 * jp][0], a1 = o[2 * jp][1], c0 = o[2 * jp + 1][0], c1 = o[2 * jp + 1][1];
+              row_pair_exchange(a0, c0);
+              row_pair_exchange(a1, c1);
+              buf_store16(ybuf, st_off[i] + (unsigned)(jp * 32 * sizeof(T)), u32x4{a0, a1, c0, c1}, sbase);
             }
           }
-          stored_n = ABL == 16 ? 16 : 8;
+          stored_n = 8;
         } else
         if (ABL == 4) {   // keep EVERY accumulator live (an ablation must not let the MFMAs be DCE'd)
 #pragma unroll
@@ -533,11 +521,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       //     DMA and this tile's stores must have landed before the barrier that opens our MFMA slot.
       //     The drain overlaps the other group's MFMA slot.
       //     The tile's 8 (fast path) or 16 stores are the youngest operations on the counter and are NOT waited for: they retire under the next slots.
-      if ((ABL == 5 || ABL == 15) && lin1 != ~0u) dma_halo(lin1);
       stamp(s, 3);
-      // ABL 15 (timing only, results wrong): stores, then the DMA, and NO wait — what a third halo buffer (a slot of slack for the DMA) would run like
-      if (ABL == 15) { } else
-      if (ABL == 5 || ABL == 6 || stored_n == 0) MTX_WAIT_VMEM();
+      if (stored_n == 0) MTX_WAIT_VMEM();
       else if (stored_n == 8) MTX_WAIT_VMEM_BUT(8);
       else MTX_WAIT_VMEM_BUT(16);
       stamp(s, 4);

@@ -1,6 +1,6 @@
 // conv_probe.hip — where a slot of the persistent RCAN conv goes (gfx950): the real kernel source, launched directly.
-//   timing of the kernel and of its ablations (1: no MFMA, 3: no halo DMA, 4: no epilogue / stores, 6: drain instead of the counted wait,
-//   8: the generic per-tile address / bounds paths also on interior tiles)
+//   timing of the kernel and of its ablations (1: no MFMA, 3: no halo DMA, 4: no epilogue / stores, 8: the generic per-tile address / bounds
+//   paths also on interior tiles); the what-ifs of round 2 (profiles/r02_conv_probe_visit_n.log) are no longer in the kernel source
 //   ABL 7: shader-clock stamps at the phase boundaries of every slot, for wave 0 of both groups of workgroups 0 and 97
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/conv_probe.hip -o tools/probes/conv_probe
 #include "../../mangatranslator_amd/csrc/conv_c64.hip"
@@ -39,15 +39,6 @@ int main(int argc, char** argv) {
   float t;
   t = run<0>(p, grid, 20); printf("ABL 0 (the kernel)            %7.1f us  %6.0f GB/s\n", t, bytes / t / 1e3);
   t = run<8>(p, grid, 20); printf("ABL 8 (generic DMA / epilogue)%7.1f us\n", t);
-  t = run<10>(p, grid, 20); printf("ABL 10 (MFMA loop without its LDS reads) %7.1f us\n", t);
-  t = run<11>(p, grid, 20); printf("ABL 11 (LDS reads without the MFMAs)     %7.1f us\n", t);
-  t = run<12>(p, grid, 20); printf("ABL 12 (s_nop 0 after each MFMA)  %7.1f us\n", t);
-  t = run<13>(p, grid, 20); printf("ABL 13 (s_nop 1 after each MFMA)  %7.1f us\n", t);
-  t = run<14>(p, grid, 20); printf("ABL 14 (s_nop 2 after each MFMA)  %7.1f us\n", t);
-  t = run<5>(p, grid, 20); printf("ABL 5 (stores first, then the DMA, drain)  %7.1f us\n", t);
-  t = run<15>(p, grid, 20); printf("ABL 15 (stores, then DMA, no wait: 3-buffer what-if)  %7.1f us\n", t);
-  t = run<16>(p, grid, 20); printf("ABL 16 (8-byte stores, no lane exchange)  %7.1f us\n", t);
-  t = run<6>(p, grid, 20); printf("ABL 6 (drain, not counted)    %7.1f us\n", t);
   t = run<1>(p, grid, 20); printf("ABL 1 (no MFMA)               %7.1f us\n", t);
   t = run<3>(p, grid, 20); printf("ABL 3 (no halo DMA)           %7.1f us\n", t);
   t = run<4>(p, grid, 20); printf("ABL 4 (no epilogue / stores)  %7.1f us\n", t);
