@@ -193,7 +193,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   auto tile_of = [&](unsigned k) -> unsigned {
     const unsigned pid = blockIdx.x + k * gridDim.x;
     if (pid >= npairs) return ~0u;
-    const unsigned lin = 2u * xcd_remap(pid, npairs) + (unsigned)grp;
+    // XCD-contiguous order only when the grid is a multiple of 8: then a workgroup's pairs — hence its images — come in increasing order
+    // (its XCD is fixed and the index inside the XCD's run grows with k), which the channel-sum rows below rely on
+    const unsigned vp = (gridDim.x % 8u == 0u) ? xcd_remap(pid, npairs) : pid;
+    const unsigned lin = 2u * vp + (unsigned)grp;
     return lin < total ? lin : ~0u;
   };
 
@@ -245,7 +248,22 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
+  // Every wave owns one chan_sum row per image and WRITES each of them exactly once (its images come in increasing order): the sums of
+  // an image when it moves on to the next, zeros for the images it never touched — no memset in front of the launch.
   int sum_img = -1;
+  auto sum_row = [&](int img_) -> float* {
+    return p.chan_sum + ((size_t)img_ * (gridDim.x * 8) + blockIdx.x * 8 + (tid >> 6)) * p.cout;
+  };
+  auto zero_rows = [&](int from, int to) {            // images [from, to)
+    for (int im = from; im < to; ++im)
+      if (l15 == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j * 16 + q * 4 + r < p.cout) sum_row(im)[j * 16 + q * 4 + r] = 0.f;
+      }
+  };
   auto flush_sums = [&](int img_) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -253,8 +271,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
       for (int r = 0; r < 4; ++r) {
         float v = csum[j][r];
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-        if (l15 == 0 && j * 16 + q * 4 + r < p.cout)
-          p.chan_sum[((size_t)img_ * (gridDim.x * 8) + blockIdx.x * 8 + (tid >> 6)) * p.cout + j * 16 + q * 4 + r] += v;   // the row is this wave's alone and zeroed before the launch; a wave may come back to an image (tile order is per XCD)
+        if (l15 == 0 && j * 16 + q * 4 + r < p.cout) sum_row(img_)[j * 16 + q * 4 + r] = v;
         csum[j][r] = 0.f;
       }
   };
@@ -400,6 +417,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
         const bool want_sum = SUM;
         if (want_sum && img != sum_img) {
           if (sum_img >= 0) flush_sums(sum_img);
+          zero_rows(sum_img + 1, img);                   // images this wave skipped (or everything before its first one)
           sum_img = img;
         }
         const bool fast = fast_ok && FAST_ACT && ty0 + C64_T <= p.h && tx0 + C64_T <= p.w_in;
@@ -531,7 +549,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
     MTX_LDS_BARRIER();
     stamp(s, 6);
   }
-  if (SUM && sum_img >= 0) flush_sums(sum_img);
+  if (SUM) {
+    if (sum_img >= 0) flush_sums(sum_img);
+    zero_rows(sum_img + 1, p.n);
+  }
 }
 
 static int g_num_cus = 0;
@@ -595,10 +616,6 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.tiles_y = (a->h + C64_T - 1) / C64_T;
   if (c64_num_cus(err) < 0) return MTX_ERR_HIP;
   const unsigned grid = c64_grid(a->n, a->h, a->w_in);
-  if (a->chan_sum != nullptr &&
-      hipMemsetAsync(a->chan_sum, 0, (size_t)a->n * grid * 8 * a->cout * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    *err = "conv2d: chan_sum memset failed"; return MTX_ERR_HIP;
-  }
 #define C64_GO(TT, AB, AC, SM, RS) MTX_LAUNCH((conv3x3_c64_kernel<TT, AB, AC, SM, RS>), dim3(grid), dim3(512), 0, stream, p)
 #define C64_ACT(TT, SM, RS) do { if (a->act == MTX_ACT_NONE) C64_GO(TT, 0, MTX_ACT_NONE, SM, RS); else if (a->act == MTX_ACT_RELU) C64_GO(TT, 0, MTX_ACT_RELU, SM, RS); \
                                  else C64_GO(TT, 0, -1, SM, RS); } while (0)

@@ -409,7 +409,19 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
           return *reinterpret_cast<const u32x4*>(tb + ((size_t)y * p.w + x) * p.ldt + c8 * 8);
         };
         int px = sub;
-        for (; px + 224 < npx; px += 256) {             // eight pixels in flight per thread
+        for (; px + 480 < npx; px += 512) {             // sixteen pixels in flight per thread
+          u32x4 r4[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) r4[j] = at(px + 32 * j);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            float f[8];
+            unpack8<T>(r4[j], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += f[e];
+          }
+        }
+        for (; px + 224 < npx; px += 256) {             // eight
           u32x4 r4[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) r4[j] = at(px + 32 * j);

@@ -82,6 +82,7 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
     if with_sum:
         tiles = pb.conv_tiles(xb, ksize, stride)
         cs = pb.buf((n, tiles, cout), torch.float32, zero=True)
+        cs.fill_(777.0)          # the conv owns every row: stale values must not survive a launch (no memset in front of it)
     y = pb.conv2d(xb, wpk, bias, cout, ksize, stride, act=act, act_param=0.1, res=rb, res_scale=0.5,
                   pixel_shuffle=pixel_shuffle, chan_sum=cs)
     _run(pb)
