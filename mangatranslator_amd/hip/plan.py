@@ -257,9 +257,14 @@ class PlanBuilder:
         self._add(abi.OP_CONV2D, a, label)
         return out
 
-    def conv_tiles(self, x: Act, ksize=3, stride=1) -> int:
+    def conv_tiles(self, x: Act, ksize=3, stride=1, cout=None, with_res=False) -> int:
+        """rows per image of the chan_sum buffer the conv with these arguments fills (which kernel runs — hence how many partial rows it
+        writes — depends on the channel counts and on whether a residual comes with the sums)"""
         a = abi.ConvArgs()
-        a.n, a.h, a.w_in, a.cin, a.cout, a.ksize, a.stride = x.n, x.h, x.w, x.c, 8, ksize, stride
+        a.n, a.h, a.w_in, a.cin, a.cout, a.ksize, a.stride = x.n, x.h, x.w, x.c, (cout if cout is not None else x.c), ksize, stride
+        a.ldx, a.ldy, a.dtype = x.ld, (cout if cout is not None else x.c), self.dtype
+        a.chan_sum = x.ptr                       # non-null markers: only their presence matters here
+        a.res = x.ptr if with_res else None
         t = self.lib.mtx_conv2d_tiles(C.byref(a))
         if t < 0:
             raise ModelError(f"mtx_conv2d_tiles: {self.lib.last_error()}")

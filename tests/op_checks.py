@@ -80,7 +80,7 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
         rb.t.copy_(res.permute(0, 2, 3, 1).to(td))
     cs = None
     if with_sum:
-        tiles = pb.conv_tiles(xb, ksize, stride)
+        tiles = pb.conv_tiles(xb, ksize, stride, cout=cout, with_res=with_res)
         cs = pb.buf((n, tiles, cout), torch.float32, zero=True)
         cs.fill_(777.0)          # the conv owns every row: stale values must not survive a launch (no memset in front of it)
     y = pb.conv2d(xb, wpk, bias, cout, ksize, stride, act=act, act_param=0.1, res=rb, res_scale=0.5,

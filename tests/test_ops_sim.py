@@ -18,6 +18,7 @@ from mangatranslator_amd.hip import abi
     dict(n=2, h=18, w=20, cin=64, cout=64, ksize=3, stride=1, with_sum=True, act=abi.ACT_RELU),
     dict(n=2, h=52, w=50, cin=64, cout=64, ksize=3, stride=1, with_sum=True, act=abi.ACT_RELU),      # interior tiles: the descriptor DMA / packed epilogue paths
     dict(n=1, h=50, w=67, cin=40, cout=64, ksize=3, stride=1, ldx_extra=8),
+    dict(n=1, h=40, w=24, cin=64, cout=64, ksize=3, stride=1, with_res=True, with_sum=True),       # sums AND residual: the generic kernel and its own row count
 ])
 def test_conv(emu_lib, dtype, cfg):
     if dtype == abi.F16 and cfg.get("stride") == 2:
