@@ -142,16 +142,17 @@ def test_flux_prep_kernels(emu_lib):
 
 
 def test_gemm_stream_k_tail(emu_lib):
-    """tiles % CUs != 0 (the simulator reports 3 CUs): the left-over tiles go through the stream-K tail + merge kernels"""
+    """tiles % CUs != 0 (the simulator reports 3 CUs): the left-over tiles go through the stream-K tail + merge kernels; a second and
+    third run of the same plan must reproduce the first bit for bit"""
     f = abi.GEMM_FORCE_TILE256
     # 2048 x 1024 -> 8 x 4 = 32 tiles, 32 % 3 = 2 left over, K = 512 -> 8 iterations per tile dealt to 3 units
-    oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f)
-    oc.check_gemm(emu_lib, abi.F16, m=2048, n=1032, k=576, with_bias=False, flags=f)       # 40 tiles: one left over, ragged N
+    oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f, runs=3)
+    oc.check_gemm(emu_lib, abi.F16, m=2048, n=1032, k=576, with_bias=False, flags=f, runs=2)
 
 
 def test_gemm_stream_k_whole_problem(emu_lib):
     """few tiles, long K: every tile's K range is dealt across the units (no full-tile launch at all)"""
-    oc.check_gemm(emu_lib, abi.BF16, m=256, n=200, k=8192, with_res=True, with_gate=True)
+    oc.check_gemm(emu_lib, abi.BF16, m=256, n=200, k=8192, with_res=True, with_gate=True, runs=2)
 
 
 @pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])

@@ -32,10 +32,11 @@ def attn(T, heads=24, d=128, iters=10):
     print(f"attn T={T} heads={heads}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
-def gemm(M, N, K, iters=20, f8=False):
+def gemm(M, N, K, iters=20, f8=False, pad=0):
+    """pad > 0: rows of A and W are `pad` elements apart more than K (leading-dimension padding, an address-interleave probe)"""
     pb = PlanBuilder(lib, dev, abi.BF16)
-    a = pb.buf((M, K), torch.bfloat16); a.normal_()
-    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
+    a = pb.buf((M, K + pad), torch.bfloat16); a.normal_()
+    w = pb.buf((N, K + pad), torch.bfloat16); w.normal_(0, K ** -0.5)
     if f8:
         q = PlanBuilder(lib, dev, abi.BF16)
         aq, asc, la = q.quantize(a, M, K)
@@ -44,9 +45,9 @@ def gemm(M, N, K, iters=20, f8=False):
         pb.keep += [aq, asc, wq, wsc]
         pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0))
     else:
-        pb.gemm(a, w, M, N, K)
+        pb.gemm(a, w, M, N, K, lda=K + pad, ldw=K + pad)
     ms = _time(pb.build(), iters)
-    print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+    print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}{f' ld+{pad}' if pad else ''}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
 def quant(rows, K, iters=20):
@@ -78,6 +79,8 @@ if __name__ == "__main__":
             quant(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "conv":
             conv(int(args[1]), int(args[2])); args = args[3:]
+        elif args[0] == "gemmp":
+            gemm(int(args[1]), int(args[2]), int(args[3]), pad=int(args[4])); args = args[5:]
         elif args[0] in ("gemm", "gemm8"):
             gemm(int(args[1]), int(args[2]), int(args[3]), f8=args[0] == "gemm8"); args = args[4:]
         else:
