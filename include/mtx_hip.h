@@ -205,7 +205,16 @@ typedef struct mtx_ca_args {
   const void* t; const void* conv_w; const float* conv_b;
   int32_t h, w, ldt, dtype;
   const int32_t* valid_hw;
+  /* optional, pool-before-conv form only: with a scratch the launch uses MTX_CA_SPLIT workgroups per image instead of one (one
+   * workgroup reading 2 048 sum rows and 5 120 border pixels was 29 us of latency between an RCAB's two convs, 200 times per page):
+   * each reduces a share of the sum rows and border strips, hands its partial record over write-through and draws a ticket; the
+   * workgroup that draws the last ticket adds the records up in a fixed order, runs the MLP and puts the counter back to zero.
+   * Layout: n * MTX_CA_SPLIT * MTX_CA_RECORD floats, then n uint32 counters that MUST BE ZERO before the first launch (MTX_CA_SCRATCH_BYTES(n)). */
+  float* scratch;
 } mtx_ca_args;
+#define MTX_CA_SPLIT 32
+#define MTX_CA_RECORD 320      /* channel totals [64] + border strips [4][64] */
+#define MTX_CA_SCRATCH_BYTES(n) ((size_t)(n) * (MTX_CA_SPLIT * MTX_CA_RECORD * 4 + 4))
 
 /* image <-> tensor conversions at the page boundary (core/image/image_utils.py:351-366). */
 typedef enum mtx_img_kind {

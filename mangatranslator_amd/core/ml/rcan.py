@@ -91,10 +91,13 @@ class RCANUpscaler:
     """Callable like the spandrel model descriptor: `model(tensor[N,3,H,W] f32) -> [N,3,sH,sW] f32`.
     Thread-safe (up to 20 reference worker threads share one instance)."""
 
-    def __init__(self, state_dict: dict, device="cuda", rgb_range: float = 255.0, lib=None, graph: bool = True, pool_before_conv: bool = True):
+    def __init__(self, state_dict: dict, device="cuda", rgb_range: float = 255.0, lib=None, graph: bool = True, pool_before_conv: bool = True,
+                 ca_split: bool = True):
         """pool_before_conv: the channel attention of an RCAB is computed from the sums of conv1's output before conv2 runs, and conv2
         writes x + s * conv2(t) itself (3 launches, 5 activation passes per RCAB); False: the 4-launch / 7-pass form (conv2 -> pool ->
-        attention -> scale-and-add pass).  Needs n_feats <= 64 in multiples of 8 (mtx_ca_args.t)"""
+        attention -> scale-and-add pass).  Needs n_feats <= 64 in multiples of 8 (mtx_ca_args.t).
+        ca_split: the attention launch between the two convs runs on MTX_CA_SPLIT workgroups per image (mtx_ca_args.scratch); False: one
+        workgroup per image (round 2's form, kept for same-box A/Bs)"""
         self.lib = lib if lib is not None else get_library()
         self.device = torch.device(device)
         self.hp = derive_rcan_hparams(state_dict)
@@ -108,6 +111,7 @@ class RCANUpscaler:
         self._buckets = PlanCache(32)       # bubble crops (any size up to BUCKET_MAX) share masked bucket plans
         self._pack(state_dict)
         self.pool_before_conv = pool_before_conv and self.hp["n_feats"] <= 64 and self.hp["n_feats"] % 8 == 0
+        self.ca_split = ca_split
 
     # ---- weights ----------------------------------------------------------------------------
     def _pack(self, sd):
@@ -199,7 +203,7 @@ class RCANUpscaler:
                     pb.conv2d(cur, *W[f"g{g}b{b}c1"], cout=C_, act=abi.ACT_RELU, out=t1, chan_sum=chan_sum, label=f"g{g}b{b}.conv1", **vk)
                     cw, cb = W[f"g{g}b{b}c2"]
                     pb.channel_attention(chan_sum, w1, b1, w2, b2, s_buf, n, tiles, C_, hp["cr"], inv_hw, label=f"g{g}b{b}.ca", inv_hw_dev=inv_hw_dev,
-                                         before_conv=(t1, cw, cb), valid_hw=valid)
+                                         before_conv=(t1, cw, cb), valid_hw=valid, split=self.ca_split)
                     pb.conv2d(t1, cw, cb, cout=C_, out=nxt, res=cur, out_scale=s_buf, label=f"g{g}b{b}.conv2", **vk)
                 else:
                     pb.conv2d(cur, *W[f"g{g}b{b}c1"], cout=C_, act=abi.ACT_RELU, out=t1, label=f"g{g}b{b}.conv1", **vk)

@@ -335,6 +335,66 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
 // sums of t, the INPUT of a 3x3 conv, and the pooled vector is mean(conv(t) + b) by linearity —
 //   sum_p conv(t)[p][co] = sum_tap sum_ci W[co][tap][ci] * S_tap[ci],   S_tap = total - (border row the tap never reaches) - (border column) + (corner)
 // — so the attention factors exist before the conv runs and the conv can write x + s * conv(t) itself (mtx_conv2d_args.out_scale).
+// pool-before-conv, second half: from the channel totals of t (mean[]) and its four border-strip sums to mean(conv3x3(t) + b), left in
+// mean[].  Run by all 1024 threads of a workgroup; `red` is LDS scratch of at least 9 * 8 * 64 floats.
+template <typename T>
+__device__ __forceinline__ void ca_conv_mean(const mtx_ca_args& p, int n, float* mean, float (*strip)[64], float* red, float inv_hw, int H, int W) {
+  __shared__ float corner[4][64];                       // (0,0) (0,W-1) (H-1,0) (H-1,W-1)
+  __shared__ float stap[9][64];
+  const int tid = threadIdx.x;
+  const T* tb = reinterpret_cast<const T*>(p.t) + (size_t)n * p.h * p.w * p.ldt;
+  if (tid < 4 * 64) {
+    const int k = tid >> 6, c = tid & 63;
+    const int y = (k & 2) ? H - 1 : 0, x = (k & 1) ? W - 1 : 0;
+    corner[k][c] = c < p.c ? to_f32(tb[((size_t)y * p.w + x) * p.ldt + c]) : 0.f;
+  }
+  __syncthreads();
+  if (tid < 9 * 64) {
+    const int tap = tid >> 6, c = tid & 63, dy = tap / 3 - 1, dx = tap % 3 - 1;
+    float s = mean[c];
+    if (dy == 1) s -= strip[0][c]; else if (dy == -1) s -= strip[1][c];      // a tap one row DOWN never reads row 0 for an in-image output, ...
+    if (dx == 1) s -= strip[2][c]; else if (dx == -1) s -= strip[3][c];
+    if (dy != 0 && dx != 0) s += corner[(dy == -1 ? 2 : 0) + (dx == -1 ? 1 : 0)][c];
+    stap[tap][c] = s;
+  }
+  __syncthreads();
+  // mean of conv(t) + b: one 16-byte filter chunk (8 input channels of one tap of one output channel) per item, 4.5 items per thread
+  const int chunks = p.c / 8, per_co = 9 * chunks, items = p.c * per_co;
+  for (int it = tid; it < items; it += 1024) {
+    const int co = it / per_co, rem = it - co * per_co, tap = rem / chunks, c8 = rem - tap * chunks;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.conv_w) + ((size_t)co * 9 + tap) * p.c + c8 * 8);
+    float f[8];
+    unpack8<T>(raw, f);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += f[e] * stap[tap][c8 * 8 + e];
+    red[it] = s;
+  }
+  __syncthreads();
+  if (tid < p.c) {
+    float s = 0.f;
+    for (int k = 0; k < per_co; ++k) s += red[tid * per_co + k];
+    mean[tid] = (p.conv_b ? p.conv_b[tid] : 0.f) + s * inv_hw;
+  }
+  __syncthreads();
+}
+
+// the squeeze / excite MLP on the pooled vector in mean[]: s = sigmoid(W2 relu(W1 mean + b1) + b2)
+__device__ __forceinline__ void ca_mlp(const mtx_ca_args& p, int n, const float* mean, float* hid) {
+  const int tid = threadIdx.x;
+  for (int r = tid; r < p.cr; r += 1024) {
+    float s = p.b1 ? p.b1[r] : 0.f;
+    for (int c = 0; c < p.c; ++c) s += p.w1[r * p.c + c] * mean[c];
+    hid[r] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < p.c; c += 1024) {
+    float s = p.b2 ? p.b2[c] : 0.f;
+    for (int r = 0; r < p.cr; ++r) s += p.w2[c * p.cr + r] * hid[r];
+    p.s[(size_t)n * p.c + c] = 1.f / (1.f + __expf(-s));
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
   __shared__ float mean[512];
@@ -394,8 +454,6 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
   if (p.t != nullptr) {                                 // C <= 64 (checked by the launcher)
     __shared__ float red[4 * 32 * 64];                  // strip partials [4 strips][32 pixel subsets][64 ch]; then the 9 * 8 * C dot partials
     __shared__ float strip[4][64];                      // top row, bottom row, left column, right column
-    __shared__ float corner[4][64];                     // (0,0) (0,W-1) (H-1,0) (H-1,W-1)
-    __shared__ float stap[9][64];
     float* redall = red;
     const int H = p.valid_hw ? p.valid_hw[0] : p.h, W = p.valid_hw ? p.valid_hw[1] : p.w;
     const T* tb = reinterpret_cast<const T*>(p.t) + (size_t)n * p.h * p.w * p.ldt;
@@ -449,50 +507,169 @@ __global__ __launch_bounds__(1024) void ca_kernel(mtx_ca_args p) {
       float s = 0.f;
       for (int j = 0; j < 32; ++j) s += redall[(k * 32 + j) * 64 + c];
       strip[k][c] = s;
-      const int y = (k & 2) ? H - 1 : 0, x = (k & 1) ? W - 1 : 0;
-      corner[k][c] = c < p.c ? to_f32(tb[((size_t)y * p.w + x) * p.ldt + c]) : 0.f;
     }
     __syncthreads();
-    if (tid < 9 * 64) {
-      const int tap = tid >> 6, c = tid & 63, dy = tap / 3 - 1, dx = tap % 3 - 1;
-      float s = mean[c];
-      if (dy == 1) s -= strip[0][c]; else if (dy == -1) s -= strip[1][c];      // a tap one row DOWN never reads row 0 for an in-image output, ...
-      if (dx == 1) s -= strip[2][c]; else if (dx == -1) s -= strip[3][c];
-      if (dy != 0 && dx != 0) s += corner[(dy == -1 ? 2 : 0) + (dx == -1 ? 1 : 0)][c];
-      stap[tap][c] = s;
-    }
-    __syncthreads();
-    {   // mean of conv(t) + b: one 16-byte filter chunk (8 input channels of one tap of one output channel) per item, 4.5 items per thread
-      const int chunks = p.c / 8, per_co = 9 * chunks, items = p.c * per_co;
-      for (int it = tid; it < items; it += 1024) {
-        const int co = it / per_co, rem = it - co * per_co, tap = rem / chunks, c8 = rem - tap * chunks;
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.conv_w) + ((size_t)co * 9 + tap) * p.c + c8 * 8);
-        float f[8];
-        unpack8<T>(raw, f);
-        float s = 0.f;
+    ca_conv_mean<T>(p, n, mean, strip, redall, inv_hw, H, W);
+  }
+  ca_mlp(p, n, mean, hid);
+}
+
+// Pool-before-conv with MTX_CA_SPLIT workgroups per image (mtx_ca_args.scratch).  Workgroup g of image n reduces its share of the
+// sum rows (row t belongs to g when (t / 64) % SPLIT == g) and of the four border strips (pixel px when (px / 32) % SPLIT == g) — at
+// 1024 x 1536 that is one 16-byte row chunk and one or two 16-byte pixel chunks per thread — and leaves a record
+// {totals[64], strips[4][64]} in the scratch with write-through stores; then every wave drains, the workgroup meets and one lane draws
+// a ticket.  Whoever draws the last ticket acquires, adds the SPLIT records up in the order g = 0, 1, ... (the result does not depend
+// on who came last), runs the conv-mean and the MLP, and resets the counter.
+// The launch sits between an RCAB's two convs and is pure latency, so EVERY workgroup issues all the loads the last arriver will
+// need (its filter chunks, the MLP weights, the corner pixels) at the very start, beside its row and strip loads: the finishing
+// workgroup then runs from registers instead of paying a memory round trip per stage (29 us single workgroup -> 15 us split -> this).
+template <typename T>
+__global__ __launch_bounds__(1024) void ca_split_kernel(mtx_ca_args p) {
+  __shared__ float mean[64];
+  __shared__ float hid[128];
+  __shared__ float red[4 * 32 * 64];                    // row partials [64 subsets][64 ch] / strip partials [4][32][64]; later the dot partials
+  __shared__ float strip[4][64];
+  __shared__ float corner[4][64];
+  __shared__ float stap[9][64];
+  __shared__ unsigned last_flag;
+  const int n = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int G = MTX_CA_SPLIT;
+  float* rec = p.scratch + ((size_t)n * G + g) * MTX_CA_RECORD;
+  unsigned* counter = reinterpret_cast<unsigned*>(p.scratch + (size_t)p.n * G * MTX_CA_RECORD) + n;
+  const int H = p.valid_hw ? p.valid_hw[0] : p.h, W = p.valid_hw ? p.valid_hw[1] : p.w;
+  const T* tb = reinterpret_cast<const T*>(p.t) + (size_t)n * p.h * p.w * p.ldt;
+  // ---- everything anybody will need, issued before the first wait
+  const int chunks = p.c / 8, per_co = 9 * chunks, items = p.c * per_co;           // filter chunks: <= 4608, at most 5 per thread
+  u32x4 wq[5];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += f[e] * stap[tap][c8 * 8 + e];
-        redall[it] = s;
-      }
-      __syncthreads();
-      if (tid < p.c) {
-        float s = 0.f;
-        for (int k = 0; k < per_co; ++k) s += redall[tid * per_co + k];
-        mean[tid] = (p.conv_b ? p.conv_b[tid] : 0.f) + s * inv_hw;
-      }
-      __syncthreads();
+  for (int j = 0; j < 5; ++j) {
+    const int it = tid + 1024 * j;
+    wq[j] = u32x4{0u, 0u, 0u, 0u};
+    if (it < items) {
+      const int co = it / per_co, rem = it - co * per_co, tap = rem / chunks, c8 = rem - tap * chunks;
+      wq[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.conv_w) + ((size_t)co * 9 + tap) * p.c + c8 * 8);
     }
   }
-  for (int r = tid; r < p.cr; r += 1024) {
-    float s = p.b1 ? p.b1[r] : 0.f;
-    for (int c = 0; c < p.c; ++c) s += p.w1[r * p.c + c] * mean[c];
-    hid[r] = s > 0.f ? s : 0.f;
+  float w1v = 0.f, w2v = 0.f, b1v = 0.f, b2v = 0.f, cbv = 0.f, cornerv = 0.f;
+  if (tid < p.cr * p.c && tid < 1024) { w1v = p.w1[tid]; w2v = p.w2[tid]; }        // C * Cr <= 1024 (checked by the launcher)
+  if (tid < p.cr && p.b1) b1v = p.b1[tid];
+  if (tid < p.c) { if (p.b2) b2v = p.b2[tid]; if (p.conv_b) cbv = p.conv_b[tid]; }
+  if (tid < 4 * 64 && (tid & 63) < p.c) {
+    const int k = tid >> 6, y = (k & 2) ? H - 1 : 0, x = (k & 1) ? W - 1 : 0;
+    cornerv = to_f32(tb[((size_t)y * p.w + x) * p.ldt + (tid & 63)]);
+  }
+  const float inv_hw = p.inv_hw_dev ? *p.inv_hw_dev : p.inv_hw;
+  f32x4 acc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  {   // sum rows: thread -> (row subset of 64, 4-channel group of 16)
+    const int c4 = tid & 15, sub = tid >> 4;
+    if (c4 * 4 < p.c) {
+      const float* src = p.chan_sum + (size_t)n * p.tiles * p.c + c4 * 4;
+      for (int t = sub + 64 * g; t < p.tiles; t += 64 * G) acc4 += *reinterpret_cast<const f32x4*>(src + (size_t)t * p.c);
+    }
+  }
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  {   // border strips: 256 threads per strip = 8 channel chunks x 32 pixel subsets
+    const int k = tid >> 8, c8 = tid & 7, sub = (tid >> 3) & 31;
+    const int npx = k < 2 ? W : H;
+    if (c8 * 8 < p.c) {
+      for (int px = sub + 32 * g; px < npx; px += 32 * G) {
+        const int y = k == 0 ? 0 : (k == 1 ? H - 1 : px), x = k == 2 ? 0 : (k == 3 ? W - 1 : px);
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(tb + ((size_t)y * p.w + x) * p.ldt + c8 * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += f[e];
+      }
+    }
+  }
+  // ---- this workgroup's record
+  {
+    const int c4 = tid & 15, sub = tid >> 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[sub * 64 + c4 * 4 + e] = acc4[e];
   }
   __syncthreads();
-  for (int c = tid; c < p.c; c += 1024) {
-    float s = p.b2 ? p.b2[c] : 0.f;
-    for (int r = 0; r < p.cr; ++r) s += p.w2[c * p.cr + r] * hid[r];
-    p.s[(size_t)n * p.c + c] = 1.f / (1.f + __expf(-s));
+  if (tid < 64) {
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += red[k * 64 + tid];
+    agent_store(rec + tid, s);
+  }
+  __syncthreads();
+  {
+    const int k = tid >> 8, c8 = tid & 7, sub = (tid >> 3) & 31;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(k * 32 + sub) * 64 + c8 * 8 + e] = a[e];
+  }
+  __syncthreads();
+  if (tid < 4 * 64) {
+    const int k = tid >> 6, c = tid & 63;
+    float s = 0.f;
+    for (int j = 0; j < 32; ++j) s += red[(k * 32 + j) * 64 + c];
+    agent_store(rec + 64 + tid, s);
+  }
+  MTX_WAIT_VMEM();                                       // every storing wave drains its write-through stores
+  __syncthreads();
+  if (tid == 0) last_flag = agent_ticket(counter) + 1 == (unsigned)G;
+  __syncthreads();
+  if (!last_flag) return;                                // (workgroup-uniform)
+  // ---- the last arriver: records -> totals and strips -> per-tap sums -> mean(conv(t) + b) -> MLP
+  if (tid == 0) { agent_acquire(); agent_store(counter, 0u); }      // zero again for the next launch (a launch boundary away)
+  __syncthreads();
+  if (tid < MTX_CA_RECORD) {
+    const float* r0 = p.scratch + (size_t)n * G * MTX_CA_RECORD + tid;
+    float v[MTX_CA_SPLIT];
+#pragma unroll
+    for (int j = 0; j < G; ++j) v[j] = r0[j * MTX_CA_RECORD];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < G; ++j) s += v[j];
+    if (tid < 64) mean[tid] = s; else strip[(tid - 64) >> 6][(tid - 64) & 63] = s;
+  }
+  if (tid < 4 * 64) corner[tid >> 6][tid & 63] = cornerv;
+  __syncthreads();
+  if (tid < 9 * 64) {
+    const int tap = tid >> 6, c = tid & 63, dy = tap / 3 - 1, dx = tap % 3 - 1;
+    float s = mean[c];
+    if (dy == 1) s -= strip[0][c]; else if (dy == -1) s -= strip[1][c];      // a tap one row DOWN never reads row 0 for an in-image output, ...
+    if (dx == 1) s -= strip[2][c]; else if (dx == -1) s -= strip[3][c];
+    if (dy != 0 && dx != 0) s += corner[(dy == -1 ? 2 : 0) + (dx == -1 ? 1 : 0)][c];
+    stap[tap][c] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int it = tid + 1024 * j;
+    if (it < items) {
+      const int rem = it % per_co, tap = rem / chunks, c8 = rem - tap * chunks;
+      float f[8];
+      unpack8<T>(wq[j], f);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[e] * stap[tap][c8 * 8 + e];
+      red[it] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < p.c) {
+    float s = 0.f;
+    for (int k = 0; k < per_co; ++k) s += red[tid * per_co + k];
+    mean[tid] = cbv + s * inv_hw;
+  }
+  __syncthreads();
+  // MLP from the prefetched weights: thread r * C + c holds w1[r][c]; thread c * Cr + r holds w2[c][r]
+  if (tid < p.cr * p.c) red[tid] = w1v * mean[tid % p.c];
+  __syncthreads();
+  if (tid < p.cr) {
+    float s = b1v;
+    for (int c = 0; c < p.c; ++c) s += red[tid * p.c + c];
+    hid[tid] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  if (tid < p.cr * p.c) red[tid] = w2v * hid[tid % p.cr];
+  __syncthreads();
+  if (tid < p.c) {
+    float s = b2v;
+    for (int r = 0; r < p.cr; ++r) s += red[tid * p.cr + r];
+    p.s[(size_t)n * p.c + tid] = 1.f / (1.f + __expf(-s));
   }
 }
 
@@ -501,6 +678,13 @@ int ca_launch(const mtx_ca_args* a, void* stream, const char** err) {
   if (a->c > 512 || a->cr > 128 || a->c < 1 || a->cr < 1) { *err = "channel_attention: C <= 512 and C/r <= 128"; return MTX_ERR_INVALID; }
   if (a->t != nullptr) {
     if (!a->conv_w || a->c > 64 || a->c % 8 || a->ldt % 8 || a->h < 1 || a->w < 1) { *err = "channel_attention (pool before the conv): needs conv_w, C <= 64 in multiples of 8, ldt % 8 == 0"; return MTX_ERR_INVALID; }
+    if (a->scratch != nullptr && a->c * a->cr <= 1024) {
+      const dim3 grid((unsigned)a->n, MTX_CA_SPLIT);
+      if (a->dtype == MTX_BF16) MTX_LAUNCH(ca_split_kernel<__bf16>, grid, dim3(1024), 0, stream, *a);
+      else if (a->dtype == MTX_F16) MTX_LAUNCH(ca_split_kernel<_Float16>, grid, dim3(1024), 0, stream, *a);
+      else { *err = "channel_attention: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+      return MTX_OK;
+    }
     if (a->dtype == MTX_BF16) MTX_LAUNCH(ca_kernel<__bf16>, dim3((unsigned)a->n), dim3(1024), 0, stream, *a);
     else if (a->dtype == MTX_F16) MTX_LAUNCH(ca_kernel<_Float16>, dim3((unsigned)a->n), dim3(1024), 0, stream, *a);
     else { *err = "channel_attention: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }

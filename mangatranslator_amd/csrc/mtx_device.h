@@ -255,6 +255,35 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + idx;
 }
 
+// ---- hand-offs between workgroups of ONE launch (cdna_hip_programming.md Guideline 16) ------------------------
+// The per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores.  Small records are
+// handed over like this: the writer stores them WRITE-THROUGH (sc1: a relaxed agent-scope atomic store, 4 bytes per lane), every
+// storing wave drains (vmcnt(0)), the workgroup meets at a barrier, ONE lane draws a ticket from a counter (relaxed agent-scope
+// atomic); the reader — the workgroup that drew the last ticket — runs ONE agent-scope acquire (drops its stale lines), meets at a
+// barrier and reads with plain loads.  Nobody waits for anybody, so nothing depends on dispatch order or residency.
+// (A plain-store + agent RELEASE publish also works but writes back the whole XCD L2's dirty lines: measured 35-80 us per episode behind
+// a GEMM's 256 KB fp32 slabs, profiles/r03_gemm_one_launch_streamk_ab.log.)
+__device__ __forceinline__ void agent_store(unsigned* word, unsigned v) {
+#ifdef MTX_EMU
+  reinterpret_cast<std::atomic<unsigned>*>(word)->store(v);
+#else
+  __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void agent_store(float* word, float v) { agent_store(reinterpret_cast<unsigned*>(word), __builtin_bit_cast(unsigned, v)); }
+__device__ __forceinline__ unsigned agent_ticket(unsigned* counter) {          // returns the value before the increment
+#ifdef MTX_EMU
+  return reinterpret_cast<std::atomic<unsigned>*>(counter)->fetch_add(1u);
+#else
+  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void agent_acquire() {
+#ifndef MTX_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+
 // 16 bytes through a buffer descriptor: byte offset = voff (per lane) + soff (wave-uniform); reads past
 // `bytes` return zeros (the hardware range check), which is how rows >= sk become zero rows.
 struct BufView {

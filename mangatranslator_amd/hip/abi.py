@@ -76,7 +76,15 @@ class EwArgs(C.Structure):
 class CaArgs(C.Structure):
     _fields_ = [("chan_sum", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("s", vp),
                 ("n", i32), ("tiles", i32), ("c", i32), ("cr", i32), ("inv_hw", f32), ("inv_hw_dev", vp),
-                ("t", vp), ("conv_w", vp), ("conv_b", vp), ("h", i32), ("w", i32), ("ldt", i32), ("dtype", i32), ("valid_hw", vp)]
+                ("t", vp), ("conv_w", vp), ("conv_b", vp), ("h", i32), ("w", i32), ("ldt", i32), ("dtype", i32), ("valid_hw", vp),
+                ("scratch", vp)]
+
+
+CA_SPLIT, CA_RECORD = 32, 320
+
+
+def ca_scratch_bytes(n: int) -> int:
+    return n * (CA_SPLIT * CA_RECORD * 4 + 4)
 
 
 class ImgArgs(C.Structure):

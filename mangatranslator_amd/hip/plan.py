@@ -379,7 +379,7 @@ class PlanBuilder:
         return out
 
     def channel_attention(self, chan_sum, w1, b1, w2, b2, s_out, n, tiles, c, cr, inv_hw, label="ca", inv_hw_dev=None,
-                          before_conv=None, valid_hw=None):
+                          before_conv=None, valid_hw=None, split=True):
         """before_conv = (t: Act, conv_w_packed, conv_bias): chan_sum holds the sums of t and the factors are those of
         mean(conv3x3(t) + bias) — available before that conv runs (include/mtx_hip.h, mtx_ca_args.t)"""
         a = abi.CaArgs()
@@ -391,6 +391,13 @@ class PlanBuilder:
             a.t, a.conv_w, a.conv_b = t.ptr, _ptr(cw), _ptr(cb)
             a.h, a.w, a.ldt, a.dtype = t.h, t.w, t.ld, self.dtype
             a.valid_hw = _ptr(valid_hw)
+            if split:
+                # MTX_CA_SPLIT workgroups per image: partial records + arrival counters (zero once; every launch leaves them zero).
+                # One scratch per builder and image count: the ops of a plan run one after the other.
+                key = f"_ca_scratch_{n}"
+                if getattr(self, key, None) is None:
+                    setattr(self, key, self.buf((abi.ca_scratch_bytes(n) // 4,), torch.float32, zero=True))
+                a.scratch = getattr(self, key).data_ptr()
         self._add(abi.OP_CA, a, label)
         return s_out
 
