@@ -112,3 +112,83 @@ def check_kontext(lib, device, h=64, w=96, t_txt=16, steps=3, **kw):
     print(f"Kontext {steps} steps {w}x{h}: latent rel err {e:.4f}, image PSNR {p:.1f} dB")
     assert e < 3e-2
     return e, p
+
+
+def named_provider(shapes: dict, device, seed: int):
+    """Seeded parameters that depend on (seed, name) only — any caller, in any order, gets the same tensor for a name.  Matrices are
+    bf16 values (generated on `device`, where a 12 B-parameter network takes seconds), so the fp32 oracle and the bf16 graph see the
+    same weights exactly."""
+    import zlib
+
+    def get(name):
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + zlib.crc32(name.encode()))
+        shp = shapes[name]
+        if len(shp) >= 2:
+            fan = int(np.prod(shp[1:]))
+            return torch.randn(shp, device=device, generator=g, dtype=torch.float32).mul_(1.0 / math.sqrt(fan)).to(torch.bfloat16)
+        if "norm" in name and name.endswith("weight"):
+            return (1.0 + 0.1 * torch.randn(shp, device=device, generator=g)).to(torch.bfloat16).float()
+        return (0.02 * torch.randn(shp, device=device, generator=g)).to(torch.bfloat16).float()
+    return get
+
+
+@torch.no_grad()
+def oracle_step_streamed(cfg: dict, get, lat, timestep, guidance, pooled, pe, txt_ids, img_ids):
+    """oracle/flux_ref.py's FluxTransformer.forward with ONE block resident at a time: every block module is built, filled from
+    `get(name)` (fp32 copies of the tensors the graph was built from), run and dropped — the 11.9 B-parameter network never needs its
+    48 GB of fp32 weights at once."""
+    d, heads = cfg["d"], cfg["heads"]
+
+    def fill(mod, prefix):
+        for k, p in mod.named_parameters():
+            p.copy_(get(prefix + k).float().cpu())
+        return mod.eval()
+
+    def lin(prefix, dout, din):
+        return fill(torch.nn.Linear(din, dout), prefix + ".")
+
+    x = lin("x_embedder", d, cfg["in_channels"])(lat)
+    c = lin("context_embedder", d, cfg["joint_dim"])(pe)
+    tte = fill(fr.TimeTextEmbed(d, cfg["pooled_dim"]), "time_text_embed.")
+    temb = tte(torch.tensor([timestep * 1000.0]), torch.tensor([guidance * 1000.0]), pooled[None])[0]
+    cos, sin = fr.rope_tables(torch.cat([txt_ids, img_ids]), cfg["axes_dim"])
+    for i in range(cfg["layers"]):
+        b = fill(fr.DoubleBlock(d, heads), f"transformer_blocks.{i}.")
+        x, c = b(x, c, temb, cos, sin)
+        del b
+    j = torch.cat([c, x])
+    for i in range(cfg["single_layers"]):
+        b = fill(fr.SingleBlock(d, heads), f"single_transformer_blocks.{i}.")
+        j = b(j, temb, cos, sin)
+        del b
+    x = j[c.shape[0]:]
+    scale, shift = fill(fr.AdaNorm(d, 2), "norm_out.")(temb)
+    return lin("proj_out", cfg["in_channels"], d)(torch.nn.functional.layer_norm(x, (d,), eps=1e-6) * (1 + scale) + shift)
+
+
+def check_full_depth_step(lib, device, h2=24, w2=32, t_txt=512, tol=6e-2, seed=4):
+    """ONE denoising step of the REAL FLUX.1-Kontext geometry — 19 double + 38 single blocks, d = 3072, 24 heads, T = t_txt + 2 h2 w2
+    tokens — against the fp32 oracle on the same (bf16-valued) weights.  Until round 3 the full depth was only ever run at d = 256 and
+    the full width at 1 + 1 blocks."""
+    cfg = dict(fx.KONTEXT_DIT_CFG)
+    shapes = fx.dit_param_shapes(cfg)
+    get = named_provider(shapes, device, seed)
+    dit = fx.FluxDiTHip(get, cfg, device, lib=lib)
+    g = torch.Generator().manual_seed(seed)
+    tn = h2 * w2
+    lat = torch.randn(2 * tn, 64, generator=g).to(torch.bfloat16).float()
+    pe = torch.randn(t_txt, cfg["joint_dim"], generator=g).to(torch.bfloat16).float()
+    pooled = torch.randn(cfg["pooled_dim"], generator=g).to(torch.bfloat16).float()
+    ids = torch.cat([fr.image_ids(h2, w2, 0), fr.image_ids(h2, w2, 1)])
+    plan = dit.plan_for(t_txt, h2, w2, 1)
+    plan.ctx_in.copy_(pe.to(device, torch.bfloat16))
+    plan.lat.copy_(lat.to(device, torch.bfloat16))
+    plan.mod.copy_(dit.modulation(0.7, 2.5, pooled.to(device, torch.bfloat16)))
+    plan.run()
+    vel = plan.vel.float().cpu()
+    ref = oracle_step_streamed(cfg, get, lat, 0.7, 2.5, pooled, pe, torch.zeros(t_txt, 3), ids)[:tn]
+    e = rel(vel, ref)
+    cosine = torch.nn.functional.cosine_similarity(vel.reshape(-1), ref.reshape(-1), dim=0).item()
+    print(f"full-depth DiT step (19 + 38 blocks, d = 3072, T = {plan.T}): velocity rel err {e:.4f}, cosine {cosine:.6f}")
+    assert e < tol
+    return e, cosine

@@ -45,7 +45,7 @@ def test_klein_fp8_vs_bf16_psnr(hip_lib):
     p_all = f2c.check_klein_fp8_vs_bf16(hip_lib, "cuda:0", h=128, w=192, t_txt=32, steps=4, **DEEP)
     p_mlp = f2c.check_klein_fp8_vs_bf16(hip_lib, "cuda:0", h=128, w=192, t_txt=32, steps=4, fp8=("ff_in", "ff_out", "single_in", "single_out"), **DEEP)
     record("flux2.klein.4steps.klein_depth.fp8_vs_bf16", psnr_all_linears_db=p_all, psnr_mlp_and_single_only_db=p_mlp)
-    assert p_all >= 30.0        # measured figure recorded; the 40 dB bar of BASELINE.json is quoted against the CPU reference, see DESIGN.md §3
+    assert p_all >= f2c.PSNR_MIN_DB and p_mlp >= f2c.PSNR_MIN_DB        # BASELINE.json's 40 dB bar, held by the fp8 pipeline against the bf16 pipeline (r02 measured 41.9)
 
 
 def test_full_width_blocks_flux1(hip_lib):

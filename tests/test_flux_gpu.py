@@ -25,3 +25,9 @@ def test_kontext_loop(hip_lib):
     e, p = fc.check_kontext(hip_lib, "cuda:0", h=128, w=192, t_txt=32, steps=4, **MID)
     record("flux1.kontext.4steps.mid.bf16", latent_rel_err=e, image_psnr_db=p)
     assert p >= fc.PSNR_MIN_DB
+
+
+def test_full_depth_kontext_step(hip_lib):
+    """57 blocks at d = 3072, T = 2 048: one step of the real geometry against a single fp32 pass of the oracle (streamed block by block)"""
+    e, c = fc.check_full_depth_step(hip_lib, "cuda:0")
+    record("flux1.full_depth_step.19+38.d3072.T2048", velocity_rel_err=e, cosine=c)
