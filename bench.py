@@ -67,6 +67,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-io", type=int, default=0,
+                    help="after the timed region: N pages through `batch_process_images` WITH image I/O — PNG files decoded from disk, uploaded, "
+                         "run through the same stages, results downloaded, PNG-encoded and written (SURVEY.md §8d: decode / encode reported "
+                         "separately, never part of `value`); reported under config.batch_io")
+    ap.add_argument("--io-threads", type=int, default=None, help="decoder / encoder threads of the batch harness per rank (default: host cores / ranks / 4, 2..8)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--time-ops", default="auto", choices=["auto", "difference", "stamp"],
                     help="in-context kernel timing of the roofline objects: hipGraph with minus hipGraph without the ops (HIP events), "
@@ -169,6 +174,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
+    # host hygiene for N ranks on one node: every rank runs a stage-A worker thread plus numpy / PIL / torch-CPU work (NMS, EDT feather,
+    # LANCZOS, contour code); with the default thread counts 8 ranks would each claim every core.  One share of the cores per rank.
+    host_threads = max(1, (os.cpu_count() or 8) // world)
+    torch.set_num_threads(host_threads)
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        os.environ.setdefault(var, str(host_threads))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -454,6 +465,60 @@ def main():
         stage_wall["_on"] = True
         step(0)
         stage_wall.pop("_on")
+    batch_io = None
+    if args.batch_io > 0:
+        # ---- the batch harness end to end, image I/O included (row f2; not the metric) ----------------------------------------------
+        import shutil
+        import tempfile
+        import types as _t
+        from mangatranslator_amd.core.caching import UnifiedCache
+        from mangatranslator_amd.core.pipeline import batch_process_images
+        names = [tempfile.mkdtemp(prefix="mtx_batch_io_") if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(names, src=0)
+        tmp = Path(names[0])
+        n_io = args.batch_io * world
+        if rank == 0:
+            (tmp / "in").mkdir()
+            for i in range(n_io):
+                page_pil[i % pool].save(tmp / "in" / f"page_{i:04d}.png", compress_level=1)
+        barrier()
+        io_threads = args.io_threads or max(2, min(8, (os.cpu_count() or 8) // max(1, world) // 4))
+
+        def process_image(page, path):
+            i = int(path.stem.split("_")[1])
+            k = i % pool
+            rgb = page.convert("RGB")
+            arr = np.asarray(rgb)
+            pages[k].copy_(torch.from_numpy(arr))          # the decoded page replaces the resident one: upload inside the harness's clock
+            page_bgr[k] = np.ascontiguousarray(arr[..., ::-1])
+            page_pil[k] = rgb
+            step(i)
+            if "upscale" in outs:
+                return Image.fromarray(outs["upscale"].cpu().numpy())
+            if "inpaint" in outs:
+                return outs["inpaint"]
+            return page
+
+        io_cfg = _t.SimpleNamespace(verbose=False, output=_t.SimpleNamespace(output_format="png", jpeg_quality=95, png_compression=2))
+        h0, c0 = UnifiedCache.hash_seconds, UnifiedCache.hash_calls
+        barrier()
+        t_io = time.perf_counter()
+        res_io = batch_process_images(tmp / "in", io_cfg, tmp / "out", process_image=process_image, io_threads=io_threads)
+        barrier()
+        dt_io = time.perf_counter() - t_io
+        io_ = res_io.get("io", {})
+        out_bytes = sum(f.stat().st_size for f in (tmp / "out").glob("*.png")) if rank == 0 else 0
+        batch_io = {"pages": n_io, "wall_s": round(dt_io, 3), "pages_per_s_with_io": n_io / dt_io, "succeeded": res_io["success_count"], "failed": res_io["error_count"],
+                    "io_threads_per_rank": io_threads, "decode_ms_per_page": round(io_.get("decode_ms_per_page", 0.0), 2),
+                    "encode_ms_per_page": round(io_.get("encode_ms_per_page", 0.0), 2), "process_ms_per_page": round(io_.get("process_ms_per_page", 0.0), 2),
+                    "hash_ms_per_page": round(1e3 * (UnifiedCache.hash_seconds - h0) / max(1, args.batch_io), 2), "hash_calls_per_page": (UnifiedCache.hash_calls - c0) / max(1, args.batch_io),
+                    "gpu_wait_for_decode_ms_per_page": round(1e3 * io_.get("gpu_wait_for_decode_s", 0.0) / max(1, n_io), 2),
+                    "wait_for_save_slot_ms_per_page": round(1e3 * io_.get("wait_for_save_slot_s", 0.0) / max(1, n_io), 2), "max_pending_saves": io_.get("max_pending_saves"),
+                    "input": f"{n_io} PNG files ({W_}x{H_}, compress_level 1)", "output": f"PNG, Pillow compress_level 2 + optimize (oxipng absent), {out_bytes / max(1, n_io) / 1e6:.2f} MB per page",
+                    "note": "pages go through the stages one at a time here (process_image is called per page by the harness; no two-pages-in-flight overlap)"}
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
     if dist is not None:
         t = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -492,10 +557,13 @@ def main():
                    "page_pipeline": ("two pages in flight: detect / segment / OSB prepare of page i+1 on a worker thread beside inpaint / upscale / clean of page i"
                                      if overlap else "stages strictly in order, one page at a time"),
                    "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL",
+                   "host_threads_per_rank": host_threads,
                    "launch": {"world_size_seen_by_collectives": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                               "self_launched": os.environ.get("MTX_BENCH_SELF_LAUNCHED") == "1", "model_setup_and_weight_broadcast_s": round(load_s, 2)}},
     }
     cfg = result["config"]
+    if batch_io is not None:
+        cfg["batch_io"] = batch_io
 
     if rank == 0:
         # ---- per-stage GPU time (HIP events on the launch stream), outside the timed region ---------------

@@ -62,8 +62,10 @@ typedef enum mtx_act {
  * pixel_shuffle = r (0 or 2): output channel (dy*r+dx)*Cout/r^2 + c is stored at
  *   y[n, oy*r+dy, ox*r+dx, c]  (the caller permutes torch-order channels c*r^2+dy*r+dx at pack
  *   time) — ldy/ldres then describe the shuffled tensor.
- * chan_sum (optional, fp32 [N][tiles][Cout]): per-tile sums of the activated output (before
- *   the residual) for a fused global average pool; tiles = mtx_conv2d_tiles().            */
+ * chan_sum (optional, fp32 [N][tiles][Cout]): per-tile sums of act(conv(x) + bias) as rounded to the storage type — BEFORE out_scale
+ *   and before the residual — for a fused global average pool; tiles = mtx_conv2d_tiles().  Both conv kernels (the 64 -> 64
+ *   persistent one and the generic one) sum this same quantity.  With out_scale the 64 -> 64 kernel computes
+ *   out_scale * act(..) + res_scale * res in fp32 and rounds once; the generic kernel rounds act(..) to the storage type first.   */
 typedef struct mtx_conv2d_args {
   const void* x; const void* w; const float* bias; const void* res; void* y; float* chan_sum;
   int32_t n, h, w_in, cin, cout;

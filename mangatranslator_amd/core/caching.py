@@ -10,6 +10,7 @@ import contextlib
 import hashlib
 import pickle
 import threading
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -77,8 +78,20 @@ class UnifiedCache:
             return digest
         return self._digest_image(image)
 
+    hash_seconds = 0.0          # time spent digesting page pixels, whole process (the batch bench reports it per page: SURVEY.md §8d "report separately")
+    hash_calls = 0
+
     @staticmethod
     def _digest_image(image: Image.Image) -> str:
+        t0 = time.perf_counter()
+        try:
+            return UnifiedCache._digest_image_untimed(image)
+        finally:
+            UnifiedCache.hash_seconds += time.perf_counter() - t0
+            UnifiedCache.hash_calls += 1
+
+    @staticmethod
+    def _digest_image_untimed(image: Image.Image) -> str:
         if image.mode == "RGBA":                     # alpha flattened on white, as the page would print
             flat = Image.new("RGB", image.size, (255, 255, 255))
             flat.paste(image, mask=image.getchannel("A"))

@@ -333,6 +333,10 @@ def _grow_to_minimum(lo: int, hi: int, limit: int, minimum: int) -> Tuple[int, i
     return lo, hi
 
 
+SDCPP_DIFFUSION_QUANT_DEFAULT = "Q4_K_M"              # reference utils/model_metadata.py FLUX_SDCPP_QUANT_FILES[...]["diffusion_model"]["default"]
+SDCPP_KLEIN_TEXT_ENCODER_QUANT_DEFAULT = "Q4_K_XL"    # ... ["llm"]["default"] (flux_klein_4b and flux_klein_9b alike)
+
+
 class FluxKleinInpainter:
     """Same constructor, attributes and operator surface as the reference class (core/image/inpainting.py:980-1068, 1070-1103,
     1350-1665).  `backend` ("sdnq" / "sdcpp") and the sd.cpp quantisation names are accepted and carried into the stage-memo key,
@@ -364,8 +368,11 @@ class FluxKleinInpainter:
         self.luminance_correction = luminance_correction
         self.upscale_small_crops = upscale_small_crops
         self.sdcpp_cache_mode = sdcpp_cache_mode
-        self.sdcpp_diffusion_quant = sdcpp_diffusion_quant
-        self.sdcpp_text_encoder_quant = sdcpp_text_encoder_quant
+        # empty quant names resolve to the reference's defaults (utils/model_metadata.py:105-122: Q4_K_M for every diffusion model,
+        # Q4_K_XL for the Klein text encoders) BEFORE they enter the stage-memo key, so a patch remembered by either implementation
+        # is found by the other (reference :1051-1057)
+        self.sdcpp_diffusion_quant = sdcpp_diffusion_quant or SDCPP_DIFFUSION_QUANT_DEFAULT
+        self.sdcpp_text_encoder_quant = sdcpp_text_encoder_quant or SDCPP_KLEIN_TEXT_ENCODER_QUANT_DEFAULT
         self.verbose = verbose
         self.manager = get_model_manager()
         self.DEVICE = device if device is not None else self.manager.device
@@ -541,6 +548,10 @@ class FluxKleinInpainter:
                     log_message(f"Warning: Flux Klein {self.variant.upper()} pipeline unavailable.", always_print=True)
                     return image_pil
                 with torch.inference_mode():
+                    # the reference seeds a generator on ITS device (:1568), so its noise comes from that backend's Philox stream; this
+                    # pipeline draws the initial latents on the host (bit-stable across boxes and ranks).  Same seed -> same noise within
+                    # either implementation, never across them: pixel parity with a checkpoint is judged on the SAME latents (the
+                    # pipelines accept `latents=`, which the parity tests use)
                     gen = torch.Generator(device="cpu").manual_seed(seed)
                     out = self.pipeline(**self._prompt_kwargs(), image=scaled, height=inf_h, width=inf_w,
                                         guidance_scale=self.KLEIN_GUIDANCE_SCALE, num_inference_steps=self.num_inference_steps,

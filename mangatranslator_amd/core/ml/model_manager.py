@@ -227,11 +227,16 @@ class ModelManager:
 
     # ---- loaders -----------------------------------------------------------------------------------
     def _read_safetensors(self, path: Path) -> dict:
-        """rank 0 reads, then (with several ranks) a status broadcast, a shape / dtype broadcast and one flat broadcast per dtype;
-        a missing or unreadable file raises ModelError on EVERY rank"""
+        """the tensors of a checkpoint (see `_read_safetensors_with_metadata`)"""
+        return self._read_safetensors_with_metadata(path)[0]
+
+    def _read_safetensors_with_metadata(self, path: Path):
+        """(tensors, header metadata): rank 0 reads, then (with several ranks) a status broadcast, a shape / dtype / metadata broadcast
+        and one flat broadcast per dtype; a missing or unreadable file raises ModelError on EVERY rank.  The metadata travels WITH the
+        state dict it describes — nothing is remembered on the manager between reads."""
         import torch.distributed as dist
         rank0 = not _dist_on() or dist.get_rank() == 0
-        sd, error = None, None
+        sd, error, metadata = None, None, {}
         if rank0:
             if not path.exists():
                 error = f"checkpoint not found: {path} (stage it under ./models; this build never downloads)"
@@ -240,24 +245,24 @@ class ModelManager:
                     from safetensors import safe_open
                     with safe_open(str(path), framework="pt", device="cpu") as f:
                         sd = {k: f.get_tensor(k) for k in f.keys()}
-                        self._last_metadata = dict(f.metadata() or {})
+                        metadata = dict(f.metadata() or {})
                 except Exception as e:                      # truncated / foreign file
                     error = f"cannot read {path}: {e}"
         broadcast_status(error)
         if _dist_on():
-            meta = [{k: (tuple(v.shape), v.dtype) for k, v in sd.items()}, getattr(self, "_last_metadata", {})] if rank0 else [None, None]
+            meta = [{k: (tuple(v.shape), v.dtype) for k, v in sd.items()}, metadata] if rank0 else [None, None]
             dist.broadcast_object_list(meta, src=0)
-            self._last_metadata = meta[1] or {}
+            metadata = meta[1] or {}
             sd = broadcast_state_dict(sd, template=meta[0])
-        return sd
+        return sd, metadata
 
-    def _detector_from_state_dict(self, sd: dict, default_names: Optional[dict] = None):
+    def _detector_from_state_dict(self, sd: dict, default_names: Optional[dict] = None, metadata: Optional[dict] = None):
         """ultralytics detector checkpoint (exported with tools/export_ultralytics_state_dict.py) -> the graph of its family: YOLOv8-seg
         (`YoloSegHip`) or YOLO11 / YOLO11-seg / YOLO12 (`Yolo11Hip`), told apart by the blocks the state dict holds.  Class names come
-        from the file's `names` metadata (what ultralytics keeps in the .pt)."""
+        from the `names` entry of the checkpoint's own header `metadata` (what ultralytics keeps in the .pt)."""
         import ast
         names = None
-        raw = getattr(self, "_last_metadata", {}).get("names")
+        raw = (metadata or {}).get("names")
         if raw:
             try:
                 names = {int(k): str(v) for k, v in dict(ast.literal_eval(raw)).items()}
@@ -314,8 +319,8 @@ class ModelManager:
             mt, path = self._resolve_speech_bubble_model(model_path)
             if self.is_loaded(mt):
                 return self.models[mt]
-            sd = self._read_safetensors(path)
-            model = self._detector_from_state_dict(sd, {0: "speech_bubble"})        # yolo_1 is a YOLOv8m-seg, the default yolo_2 a YOLO11-seg
+            sd, md = self._read_safetensors_with_metadata(path)
+            model = self._detector_from_state_dict(sd, {0: "speech_bubble"}, md)        # yolo_1 is a YOLOv8m-seg, the default yolo_2 a YOLO11-seg
             self.models[mt] = model
             log_message(f"YOLO bubble detector loaded ({mt.value}).", verbose=verbose)
             return model
@@ -338,8 +343,8 @@ class ModelManager:
             if self.is_loaded(ModelType.YOLO_OSBTEXT):
                 return self.models[ModelType.YOLO_OSBTEXT]
             try:
-                sd = self._read_safetensors(self.model_paths[ModelType.YOLO_OSBTEXT])
-                model = self._detector_from_state_dict(sd, {0: "text"})
+                sd, md = self._read_safetensors_with_metadata(self.model_paths[ModelType.YOLO_OSBTEXT])
+                model = self._detector_from_state_dict(sd, {0: "text"}, md)
             except ModelError:
                 raise
             except Exception as e:
@@ -355,8 +360,8 @@ class ModelManager:
             if self.is_loaded(ModelType.YOLO_PANEL):
                 return self.models[ModelType.YOLO_PANEL]
             try:
-                sd = self._read_safetensors(self.model_paths[ModelType.YOLO_PANEL])
-                model = self._detector_from_state_dict(sd, {0: "frame"})
+                sd, md = self._read_safetensors_with_metadata(self.model_paths[ModelType.YOLO_PANEL])
+                model = self._detector_from_state_dict(sd, {0: "frame"}, md)
             except ModelError:
                 raise
             except Exception as e:

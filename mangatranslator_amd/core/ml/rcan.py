@@ -109,6 +109,7 @@ class RCANUpscaler:
         self._lock = threading.RLock()
         self._plans = PlanCache(8)          # pages of one size reuse their plan
         self._buckets = PlanCache(32)       # bubble crops (any size up to BUCKET_MAX) share masked bucket plans
+        self._big_buckets = PlanCache(6)    # ... and the few larger ones (a 1024 x 1024 canvas pins ~2 GB of activations)
         self._pack(state_dict)
         self.pool_before_conv = pool_before_conv and self.hp["n_feats"] <= 64 and self.hp["n_feats"] % 8 == 0
         self.ca_split = ca_split
@@ -236,18 +237,23 @@ class RCANUpscaler:
 
     BUCKET = 64            # bucket plans: canvas sides are multiples of this ...
     BUCKET_MAX = 512       # ... up to this: a crop below the minimum side takes up to two passes, the second on <= 2 x its size
-                           # (larger images — pages — get a plan of their own size)
+    BIG_BUCKET = 128       # sides between BUCKET_MAX and BIG_BUCKET_MAX (large bubble crops, second passes): coarser steps, a small cache of
+    BIG_BUCKET_MAX = 1024  # their own — exact-size plans for them rebuilt and re-captured a hipGraph for almost every crop.
+                           # Larger images — pages — get a plan of their own size.
 
     def _bucket_plan(self, h, w):
         """(plan, canvas_h, canvas_w) for an image of h x w source pixels (already a multiple of the unshuffle factor), or None"""
-        if max(h, w) > self.BUCKET_MAX:
+        if max(h, w) > self.BIG_BUCKET_MAX:
             return None
-        bh, bw = (h + self.BUCKET - 1) // self.BUCKET * self.BUCKET, (w + self.BUCKET - 1) // self.BUCKET * self.BUCKET
+        big = max(h, w) > self.BUCKET_MAX
+        step = self.BIG_BUCKET if big else self.BUCKET
+        bh, bw = (h + step - 1) // step * step, (w + step - 1) // step * step
         key = ("bucket", bh, bw)
+        cache = self._big_buckets if big else self._buckets
         with self._lock:
-            if key not in self._buckets:
-                self._buckets[key] = self._build(1, bh, bw, bucket=True)
-            plan = self._buckets[key]
+            if key not in cache:
+                cache[key] = self._build(1, bh, bw, bucket=True)
+            plan = cache[key]
         u = self.hp["unshuffle"]
         vs, v, vup, inv = plan.valid_bufs
         vs.copy_(torch.tensor([h, w], dtype=torch.int32))

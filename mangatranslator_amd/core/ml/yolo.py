@@ -99,6 +99,7 @@ class YoloSegHip:
         self._graph = graph and not self.lib.is_simulator
         self._lock = threading.Lock()
         self._plans = PlanCache(8)
+        self._mask_plans = PlanCache(8)
         self._pack(sd)
 
     def _derive(self, sd):
@@ -209,8 +210,10 @@ class YoloSegHip:
         return plan
 
     def _mask_plan(self, nd, mh, mw, roi, h0, w0):
-        key = ("m", nd, mh, mw, roi, h0, w0)
-        if key not in self._plans:
+        """retina-mask plan for up to `nd` detections (callers round the count up to a multiple of 8, so a stream of pages with 5..30
+        bubbles shares four plans); kept in a cache of its own — per-page keys must never evict the detection plans and their hipGraphs"""
+        key = (nd, mh, mw, roi, h0, w0)
+        if key not in self._mask_plans:
             pb = PlanBuilder(self.lib, self.device, self.dtype)
             nm = self.a["nm"]
             coef = pb.buf((nd, nm), self.tdt)
@@ -221,8 +224,8 @@ class YoloSegHip:
             pb.resize_threshold(logits, masks, nd, mh, mw, h0, w0, 0.0, abi.F32, pix_stride=nd, batch_stride=1, roi=roi, crop_xyxy=boxes)
             plan = pb.build()
             plan.coef, plan.protoflat, plan.boxes, plan.masks = coef, proto, boxes, masks
-            self._plans[key] = plan
-        return self._plans[key]
+            self._mask_plans[key] = plan
+        return self._mask_plans[key]
 
     # ---- the ultralytics call shape -------------------------------------------------------------------
     @torch.no_grad()
@@ -270,12 +273,15 @@ class YoloSegHip:
             pw, ph = (mw - w0 * gm) / 2, (mh - h0 * gm) / 2
             top, left = int(round(ph - 0.1)), int(round(pw - 0.1))
             roi = (top, left, mh - int(round(ph + 0.1)) - top, mw - int(round(pw + 0.1)) - left)
-            mp = self._mask_plan(len(keep), mh, mw, roi, h0, w0)
-            mp.coef.copy_(torch.from_numpy(cand[:, 4 + nc:]).to(self.device, self.tdt))
+            nk = len(keep)
+            mp = self._mask_plan((nk + 7) // 8 * 8, mh, mw, roi, h0, w0)
+            mp.coef.zero_()
+            mp.coef[:nk].copy_(torch.from_numpy(cand[:, 4 + nc:]).to(self.device, self.tdt))
             mp.protoflat.copy_(plan.proto.t.view(mh * mw, nm))
-            mp.boxes.copy_(boxes_t)
+            mp.boxes.zero_()                                  # rows past nk: an empty crop box, masks of zeros nobody reads
+            mp.boxes[:nk].copy_(boxes_t)
             mp.run()
-            res.masks = _Masks(mp.masks.clone(), self.lib)
+            res.masks = _Masks(mp.masks[:nk].clone(), self.lib)
             return [res]
 
 

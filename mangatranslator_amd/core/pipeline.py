@@ -7,7 +7,9 @@ dicts (`success_count`, `error_count`, `errors`, `failed_image_paths`, core/pipe
 """
 import os
 import re
+import threading
 import time
+from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -56,6 +58,9 @@ def merge_batch_results(per_rank: Sequence[Dict]) -> Dict:
         merged["errors"].update(r.get("errors", {}))
         merged["failed_image_paths"].extend(r.get("failed_image_paths", []))
     merged["failed_image_paths"].sort(key=lambda p: _natural_path_sort_key(Path(p)))
+    ios = [r["io"] for r in per_rank if isinstance(r.get("io"), dict)]
+    if ios:      # host I/O accounting of `batch_process_images` (not a key of the reference's dict): sums over the ranks, maxima where it is one
+        merged["io"] = {k: (max(i[k] for i in ios) if k.startswith("max_") else sum(i[k] for i in ios)) for k in ios[0]}
     return merged
 
 
@@ -122,8 +127,10 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
     initialised process group: same page list and order, same output naming (`_resolve_output_path`), same results dict
     (`success_count`, `error_count`, `errors` keyed by the display path, `failed_image_paths` absolute, `failed_paths_file`), a bad
     page never stops the batch.  `process_image(page: PIL.Image, path: Path) -> PIL.Image` is the per-page vision stack.
-    Host codec work is kept off the GPU's critical path: a pool of `io_threads` workers decodes the next pages while the current
-    one is on the GPU and encodes / writes finished pages behind it (PIL releases the GIL in its codecs)."""
+    Host codec work is kept off the GPU's critical path: `io_threads` workers decode the next pages while the current one is on the
+    GPU and `io_threads` more encode / write finished pages behind it (PIL releases the GIL in its codecs); at most 2 x io_threads
+    finished pages wait for an encoder (back-pressure on the page loop).  `results["io"]` accounts for the host side: decode / encode /
+    process seconds, the waits, the deepest save queue."""
     from .image.image_utils import save_image_with_compression
     import torch.distributed as dist
     empty = {"success_count": 0, "error_count": 0, "errors": {}, "failed_image_paths": []}
@@ -153,30 +160,59 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
         except OSError:
             local["failed_image_paths"].append(str(img_path))
 
-    with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool:
+    io = {"decode_s": 0.0, "encode_s": 0.0, "gpu_wait_for_decode_s": 0.0, "wait_for_save_slot_s": 0.0, "process_s": 0.0, "pages": 0,
+          "max_pending_saves": 0}
+    io_lock = threading.Lock()
+
+    def timed(key, fn, *a):
+        t = time.perf_counter()
+        try:
+            return fn(*a)
+        finally:
+            with io_lock:
+                io[key] += time.perf_counter() - t
+
+    def settle(entry):
+        fut, img_path, error_key = entry
+        try:
+            fut.result()
+            local["success_count"] += 1
+        except Exception as e:      # noqa: BLE001
+            fail(img_path, error_key, e)
+
+    # decoders and encoders do not share a queue: the next page's decode must never wait behind the finished pages' (much slower) PNG encodes
+    with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool, ThreadPoolExecutor(max_workers=max(1, io_threads)) as enc_pool:
         ahead = max(1, io_threads)
-        decodes = {i: pool.submit(load_page, mine[i], fmt) for i in range(min(ahead, len(mine)))}
-        saves = []
+        max_pending = 2 * max(1, io_threads)       # finished pages waiting for a codec thread: a 4096x6144 RGBA page is 100 MB, and PNG
+        decodes = {i: pool.submit(timed, "decode_s", load_page, mine[i], fmt) for i in range(min(ahead, len(mine)))}      # encoding is slower than the GPU
+        saves = deque()
         for i, img_path in enumerate(mine):
             if i + ahead < len(mine):
-                decodes[i + ahead] = pool.submit(load_page, mine[i + ahead], fmt)
+                decodes[i + ahead] = pool.submit(timed, "decode_s", load_page, mine[i + ahead], fmt)
             error_key = img_path.name
             try:
                 out_path, display, error_key = _resolve_output_path(img_path, input_dir, output_dir, config, preserve_structure)
                 log_message(f"Processing {rank + i * world + 1}/{len(files)}: {display}", always_print=True)
+                t = time.perf_counter()
                 page = decodes.pop(i).result()
+                t1 = time.perf_counter()
                 result = process_image(page, img_path) if process_image is not None else page
-                saves.append((pool.submit(save_image_with_compression, result, out_path, config.output.jpeg_quality,
+                t2 = time.perf_counter()
+                while len(saves) >= max_pending:      # back-pressure: the page loop waits for the oldest save instead of queueing pages without bound
+                    settle(saves.popleft())
+                io["gpu_wait_for_decode_s"] += t1 - t
+                io["process_s"] += t2 - t1
+                io["wait_for_save_slot_s"] += time.perf_counter() - t2
+                io["pages"] += 1
+                saves.append((enc_pool.submit(timed, "encode_s", save_image_with_compression, result, out_path, config.output.jpeg_quality,
                                           config.output.png_compression), img_path, error_key))
+                io["max_pending_saves"] = max(io["max_pending_saves"], len(saves))
             except Exception as e:      # noqa: BLE001 — a bad page must not stop the batch
                 decodes.pop(i, None)
                 fail(img_path, error_key, e)
-        for fut, img_path, error_key in saves:
-            try:
-                fut.result()
-                local["success_count"] += 1
-            except Exception as e:      # noqa: BLE001
-                fail(img_path, error_key, e)
+        while saves:
+            settle(saves.popleft())
+    local["io"] = io
 
     if multi:
         gathered = [None] * world
@@ -185,6 +221,10 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
     else:
         results = merge_batch_results([local])
     dt = time.time() - t0
+    if "io" in results and results["io"]["pages"]:
+        n_ = results["io"]["pages"]
+        results["io"].update(wall_s=dt, decode_ms_per_page=1e3 * results["io"]["decode_s"] / n_, encode_ms_per_page=1e3 * results["io"]["encode_s"] / n_,
+                             process_ms_per_page=1e3 * results["io"]["process_s"] / n_, io_threads=io_threads)
     log_message(f"Batch complete: {results['success_count']}/{len(files)} images in {dt:.2f}s ({dt / len(files):.2f}s/image)", always_print=True)
     if results["failed_image_paths"] and rank == 0:
         failed_file = write_failed_paths(output_dir, results["failed_image_paths"])

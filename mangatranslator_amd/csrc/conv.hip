@@ -208,14 +208,14 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
       else if (p.chan_sum != nullptr || p.res != nullptr || p.out_scale != nullptr) {
         float f[8];
         unpack8<T>(raw, f);
+        if (p.chan_sum != nullptr) {                       // the sums are those of act(conv + bias) as rounded to T, BEFORE out_scale (mtx_hip.h):
+#pragma unroll                                          // the same quantity the c64 kernel sums, whichever kernel the dispatcher picks
+          for (int e = 0; e < 8; ++e) csum[e] += f[e];
+        }
         if (p.out_scale != nullptr) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] *= p.out_scale[(size_t)img * p.cout + co + e];
           if (p.res == nullptr) raw = pack8<T>(f);
-        }
-        if (p.chan_sum != nullptr) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) csum[e] += f[e];
         }
         if (p.res != nullptr) {
           const size_t rpix = p.res_bcast ? opix - (size_t)img * (p.ps == 2 ? 4 : 1) * (size_t)p.ho * (size_t)p.wo : opix;

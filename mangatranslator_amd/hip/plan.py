@@ -108,7 +108,15 @@ class Plan:
         return float(ms.value)
 
     def close(self):
+        """Destroys the native plan (its hipGraph exec, lane side stream and events) and releases the activation buffers.  The last
+        replay may still be in flight on the plan's side stream when a cache evicts the plan, so the streams the plan ran on are
+        drained first — destroying a graph exec / stream under running work relies on the runtime deferring it."""
         if self._h:
+            if not self.lib.is_simulator and torch.cuda.is_available():
+                side = getattr(self, "_side", None)
+                if side is not None:
+                    side.synchronize()
+                torch.cuda.current_stream().synchronize()
             self.lib.mtx_plan_destroy(self._h)
             self._h = None
             self._keep = None          # the activation buffers go back to the allocator

@@ -166,7 +166,7 @@ def oracle_step_streamed(cfg: dict, get, lat, timestep, guidance, pooled, pe, tx
     return lin("proj_out", cfg["in_channels"], d)(torch.nn.functional.layer_norm(x, (d,), eps=1e-6) * (1 + scale) + shift)
 
 
-def check_full_depth_step(lib, device, h2=24, w2=32, t_txt=512, tol=6e-2, seed=4):
+def check_full_depth_step(lib, device, h2=24, w2=32, t_txt=512, tol=3e-2, seed=4):          # measured 1.27 %, cosine 0.99992 (profiles/r03_parity.json)
     """ONE denoising step of the REAL FLUX.1-Kontext geometry — 19 double + 38 single blocks, d = 3072, 24 heads, T = t_txt + 2 h2 w2
     tokens — against the fp32 oracle on the same (bf16-valued) weights.  Until round 3 the full depth was only ever run at d = 256 and
     the full width at 1 + 1 blocks."""

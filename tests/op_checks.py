@@ -38,7 +38,9 @@ def _run(pb):
 
 
 def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, with_res=False,
-               pixel_shuffle=0, with_sum=False, ldx_extra=0, seed=0):
+               pixel_shuffle=0, with_sum=False, ldx_extra=0, seed=0, with_scale=False):
+    """with_scale: y = out_scale * act(conv + bias) (+ res); the channel sums stay those of act(conv + bias), BEFORE the scale — by either
+    conv kernel (64 -> 64 with sums and a residual runs on the generic kernel, without the residual on the persistent one)"""
     g = torch.Generator().manual_seed(seed)
     dev, td = _dev(lib), TD[dtype]
     x = torch.randn(n, h, w, cin, generator=g)
@@ -53,6 +55,10 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
     elif act == abi.ACT_LEAKY:
         ref = F.leaky_relu(ref, 0.1)
     act_sum = ref.sum(dim=(2, 3)) if with_sum else None
+    osc = None
+    if with_scale:
+        osc = torch.rand(n, cout, generator=g) * 1.5 + 0.25
+        ref = ref * osc[:, :, None, None]
     if pixel_shuffle:
         ref = F.pixel_shuffle(ref, pixel_shuffle)
     res = None
@@ -84,7 +90,7 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
         cs = pb.buf((n, tiles, cout), torch.float32, zero=True)
         cs.fill_(777.0)          # the conv owns every row: stale values must not survive a launch (no memset in front of it)
     y = pb.conv2d(xb, wpk, bias, cout, ksize, stride, act=act, act_param=0.1, res=rb, res_scale=0.5,
-                  pixel_shuffle=pixel_shuffle, chan_sum=cs)
+                  pixel_shuffle=pixel_shuffle, chan_sum=cs, out_scale=pb.const(osc, torch.float32) if with_scale else None)
     _run(pb)
     err = _relerr(y.torch().cpu(), ref)
     assert err < TOL[dtype], f"conv mismatch rel err {err}"

@@ -122,3 +122,37 @@ def test_two_ranks_share_the_batch(tmp_path):
     written = sorted(str(p.relative_to(tmp_path / "out")) for p in (tmp_path / "out").rglob("*_translated.png"))
     assert written == sorted(s[1] for s in g["seen"] if Path(s[0]).name not in GOLD["fail"])
     assert (tmp_path / "out" / "failed_paths.txt").exists()
+
+
+def test_save_queue_is_bounded_and_io_is_accounted(tmp_path, monkeypatch):
+    """finished pages never pile up behind the codec threads: at most 2 x io_threads saves are pending (a 512-page batch of
+    4096x6144 results could exhaust host RAM), and the results carry the decode / encode / process times of the run"""
+    import time
+    from mangatranslator_amd.core import pipeline
+    from mangatranslator_amd.core.image import image_utils
+    root, odir = tmp_path / "in", tmp_path / "out"
+    root.mkdir()
+    for i in range(14):
+        Image.new("RGB", (16, 16), (i, 2 * i, 3 * i)).save(root / f"p{i:02d}.png")
+    real = image_utils.save_image_with_compression
+    live, peak = [0], [0]
+
+    def slow_save(*a, **k):
+        live[0] += 1
+        peak[0] = max(peak[0], live[0])
+        time.sleep(0.05)                                # the encoder is far slower than the page loop
+        try:
+            return real(*a, **k)
+        finally:
+            live[0] -= 1
+
+    monkeypatch.setattr(image_utils, "save_image_with_compression", slow_save)
+    res = pipeline.batch_process_images(root, _cfg("png"), odir, process_image=lambda page, path: page, io_threads=2)
+    assert res["success_count"] == 14 and res["error_count"] == 0
+    io = res["io"]
+    assert io["pages"] == 14 and 1 <= io["max_pending_saves"] <= 4
+    assert io["encode_s"] >= 14 * 0.05 and io["wait_for_save_slot_s"] > 0.05          # the loop did wait for save slots
+    assert io["decode_ms_per_page"] > 0 and io["encode_ms_per_page"] >= 50 and "process_ms_per_page" in io
+    assert sorted(p.name for p in odir.iterdir()) == [f"p{i:02d}_translated.png" for i in range(14)]
+    for i in (0, 13):                                                                  # decoded pixels survive the writer
+        assert Image.open(odir / f"p{i:02d}_translated.png").convert("RGB").getpixel((3, 3)) == (i, 2 * i, 3 * i)

@@ -67,3 +67,49 @@ def test_upscale_image_matches_reference_flow(monkeypatch):
         res = iu.upscale_image(img, c["factor"], model_type=c["model_type"])
         assert res.mode == c["out_mode"] and list(res.size) == c["out_size"], name
         assert np.array_equal(np.asarray(res), arr[f"{name}_out"]), name
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "LA"])
+def test_saved_pages_decode_to_the_same_pixels(tmp_path, mode):
+    """The reference writes PNG through oxipng (core/image/image_utils.py:140-150; a Rust optimiser that re-filters, reduces colour type
+    and, with `optimize_alpha=True`, may rewrite the colour of fully transparent pixels); without that wheel the file BYTES cannot be the
+    reference's.  What is pinned instead is what a reader of the file gets: every format's decoded pixels — PNG and lossless WEBP equal
+    the page exactly (all channels, transparent pixels included: a superset of what oxipng guarantees), JPEG equals Pillow's own encode
+    of the page flattened on white at the clamped quality."""
+    rng = np.random.default_rng(11)
+    bands = len(mode)
+    a = rng.integers(0, 256, (37, 53, bands) if bands > 1 else (37, 53), dtype=np.uint8)
+    if "A" in mode:
+        a[:10, :, -1] = 0                                   # a fully transparent strip with non-trivial colour under it
+        a[10:20, :, -1] = 255
+    img = Image.fromarray(a, mode)
+    for level in (0, 2, 6, 9):
+        p = tmp_path / f"l{level}.png"
+        assert iu.save_image_with_compression(img, p, png_compression=level)
+        back = Image.open(p)
+        assert back.mode == mode and np.array_equal(np.asarray(back), a)
+    p = tmp_path / "x.webp"
+    iu.save_image_with_compression(img, p)
+    back = Image.open(p)
+    want = np.asarray(img.convert("RGBA" if "A" in mode else "RGB"))
+    got = np.asarray(back.convert("RGBA" if "A" in mode else "RGB"))
+    if "A" in mode:                                       # lossless WEBP (as in the reference: lossless=True, exact off) keeps alpha and every VISIBLE pixel
+        vis = want[..., 3] > 0
+        assert np.array_equal(got[..., 3], want[..., 3]) and np.array_equal(got[vis], want[vis])
+    else:
+        assert np.array_equal(got, want)
+    p = tmp_path / "x.jpg"
+    iu.save_image_with_compression(img, p, jpeg_quality=300)       # clamped to 100
+    flat = img
+    if "A" in mode:
+        flat = Image.new("RGB", img.size, (255, 255, 255))
+        flat.paste(img, mask=img.split()[-1])
+    elif mode != "RGB":
+        flat = img.convert("RGB")
+    import io
+    buf = io.BytesIO()
+    flat.save(buf, format="JPEG", quality=100)
+    assert np.array_equal(np.asarray(Image.open(p)), np.asarray(Image.open(io.BytesIO(buf.getvalue()))))
+    p = tmp_path / "x.bmp"                                          # unknown extension -> .png
+    iu.save_image_with_compression(img, p)
+    assert not p.exists() and np.array_equal(np.asarray(Image.open(p.with_suffix(".png"))), a)

@@ -161,3 +161,12 @@ def test_rcab_tail_pool_before_conv(emu_lib, dtype):
     oc.check_rcab_tail(emu_lib, dtype, n=2, h=37, w=29)
     oc.check_rcab_tail(emu_lib, dtype, n=1, h=50, w=52)
     oc.check_rcab_tail(emu_lib, dtype, n=1, h=21, w=40, canvas=(64, 64))
+
+
+@pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])
+def test_conv_out_scale_and_sums_on_both_kernels(emu_lib, dtype):
+    """out_scale + chan_sum with the same arguments on the persistent 64 -> 64 kernel (no residual) and on the generic kernel (with a
+    residual, and at 32 -> 48 channels): the sums are those of act(conv + bias) before the scale on both (include/mtx_hip.h)"""
+    oc.check_conv(emu_lib, dtype, n=2, h=21, w=19, cin=64, cout=64, ksize=3, stride=1, act=abi.ACT_RELU, with_sum=True, with_scale=True)
+    oc.check_conv(emu_lib, dtype, n=2, h=21, w=19, cin=64, cout=64, ksize=3, stride=1, act=abi.ACT_RELU, with_sum=True, with_scale=True, with_res=True)
+    oc.check_conv(emu_lib, dtype, n=1, h=17, w=23, cin=32, cout=48, ksize=3, stride=1, act=abi.ACT_SILU, with_sum=True, with_scale=True)

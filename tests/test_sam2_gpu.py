@@ -35,6 +35,6 @@ def test_sam2_hiera_large_page_2048x3072(hip_lib):
 
 def test_sam2_hiera_large_calibrated_logits(hip_lib):
     """the same page with the mask tokens' hypernetwork scaled to trained-model logit spread (std 5): errors in logit units against an
-    a-priori bound (max < 1, rms < 0.1), and no differing pixel anywhere a logit is farther than 1 from the threshold"""
+    a-priori bound (max < 1, rms < 0.2), and no differing pixel anywhere a logit is farther than 1 from the threshold"""
     err, mism = sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=1536, w=1024, n_boxes=8, seed=2, logit_tol=0.06, mask_tol=0.01, calibrated=True)
     record("sam2.hiera_large.1024x1536.calibrated_std5", boxes=8, **sc.stats)
