@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-aux-detectors", action="store_true",
                     help="leave out the panel (YOLO11-L @640) and outside-text (YOLO12x @640) detectors that the reference runs on every page by "
                          "default (core/config.py:20-21); RT-DETR-v2 always runs")
+    ap.add_argument("--serial-detectors", action="store_true",
+                    help="call the page's detectors one after the other, each returning finished results (the reference's order of calls); default: "
+                         "submit all of them, then collect — their graphs run side by side on their own streams")
     ap.add_argument("--no-lanes", action="store_true", help="FLUX.1: keep the text stream's ops in line with the image stream's (one lane)")
     ap.add_argument("--no-fp8", action="store_true", help="Klein: keep the block linears in bf16 instead of the MX-fp8 matrix path")
     ap.add_argument("--no-overlap", action="store_true",
@@ -176,10 +179,15 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     # host hygiene for N ranks on one node: every rank runs a stage-A worker thread plus numpy / PIL / torch-CPU work (NMS, EDT feather,
     # LANCZOS, contour code); with the default thread counts 8 ranks would each claim every core.  One share of the cores per rank.
-    host_threads = max(1, (os.cpu_count() or 8) // world)
+    # Counted on the cores this process may actually run on (a container's affinity mask, not the machine's core count: setting the
+    # latter on a 32-core slice of a 256-core host made every small torch op 40 ms — measured, r03 visit E), and capped: the host ops
+    # here are small, more than 16 threads each only adds fork / join time.
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 8
+    host_threads = max(1, min(16, usable // world, torch.get_num_threads()))
     torch.set_num_threads(host_threads)
-    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
-        os.environ.setdefault(var, str(host_threads))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -387,14 +395,30 @@ def main():
         stage_memo.reset()        # the operators remember results per (pixels, settings); the pool repeats pages, and no step may be served from memory
         tl = time.perf_counter()
         work_ = None
-        if yolo is not None:
+        sam_ticket = None
+        if yolo is not None and args.serial_detectors:
             outs["detect"] = yolo(page_bgr[k], conf=yolo_conf, imgsz=1600)[0]
             outs["detect2"] = rtdetr(page_bgr[k], conf=0.35, imgsz=640)[0]
             for name_, det_, conf_ in aux_detectors:             # panel / outside-text detectors: imgsz 640 (reference detection.py:1867-1873, 144-150)
                 outs["detect_" + name_] = det_(page_bgr[k], conf=conf_, imgsz=640)[0]
             tl = lap("detect", tl)
+        elif yolo is not None:
+            # every detector of the page is SUBMITTED first — each queues its upload and graph replay on its own HIP stream — and
+            # collected afterwards: the four graphs share the chip (none of the 640-pixel networks fills 256 CUs alone) and one
+            # detector's NMS / result objects run on the host while the others' kernels still execute (hip/plan.py AsyncLane)
+            # The YOLO family reads the page where it already lies in HBM (one upload per page, not one per detector); RT-DETR — whose
+            # pre-processing is the image processor's host-side resize — is submitted last, so that resize runs beside the others' kernels.
+            bgr_dev = pages[k].flip(-1)
+            tickets = [("detect", yolo, yolo.submit(bgr_dev, conf=yolo_conf, imgsz=1600))]
+            tickets += [("detect_" + name_, det_, det_.submit(bgr_dev, conf=conf_, imgsz=640)) for name_, det_, conf_ in aux_detectors]
+            tickets.append(("detect2", rtdetr, rtdetr.submit(page_bgr[k], conf=0.35, imgsz=640)))
+            if sam is not None:          # the image encoder does not depend on the boxes: it runs beside the detectors, the mask decoder follows the boxes
+                sam_ticket = sam.submit_image(pages[k])
+            for name_, det_, tk_ in tickets:
+                outs[name_] = det_.collect(tk_)[0]
+            tl = lap("detect", tl)
         if sam is not None:      # prompts: the generator's ground-truth boxes (fixed unit count)
-            outs["segment"] = sam.segment(pages[k], page_boxes[k])
+            outs["segment"] = sam.segment(pages[k], page_boxes[k], ticket=sam_ticket)
             tl = lap("segment", tl)
         if inpainter is not None:
             # the reference's OSB stage end to end (prepare + finish): the bubbles guard the fills, the text boxes arrive as text_free
@@ -553,6 +577,7 @@ def main():
                    "segmenter": "SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights" if sam is not None else None,
                    "inpainter": inp_desc,
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
+                   "detector_calls": ("one after the other" if args.serial_detectors else "submitted together, one HIP stream per model, collected afterwards") if yolo is not None else None,
                    "stage_wall_ms_one_page": {k_: round(v_, 2) for k_, v_ in stage_wall.items()},
                    "page_pipeline": ("two pages in flight: detect / segment / OSB prepare of page i+1 on a worker thread beside inpaint / upscale / clean of page i"
                                      if overlap else "stages strictly in order, one page at a time"),

@@ -24,7 +24,7 @@ from PIL import Image
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder, PlanCache
+from ...hip.plan import Act, AsyncLane, PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 
@@ -66,7 +66,7 @@ class RTDetrHip:
         id2label = getattr(config, "id2label", None) or {}
         self.names = {int(k): str(v) for k, v in (names or id2label).items()}
         self._graph = graph and not self.lib.is_simulator
-        self._lock = threading.Lock()
+        self._lane = AsyncLane(self.device, self.lib.is_simulator)
         self._plans = PlanCache(4)
         if config.decoder_method != "default" or config.num_feature_levels != len(config.decoder_in_channels) or config.normalize_before:
             raise ModelError("RT-DETR: unsupported configuration (decoder_method / extra feature levels / pre-norm)")
@@ -348,23 +348,35 @@ class RTDetrHip:
     @torch.no_grad()
     def forward_raw(self, img_u8: np.ndarray):
         """resized RGB uint8 [H, W, 3] -> (logits [Q, C] fp32, boxes cxcywh [Q, 4] fp32 in 0..1)"""
+        with self._lane.busy:
+            with self._lane.enter():
+                out = self._enqueue(img_u8)
+            self._lane.hand_over()
+            return out
+
+    def _enqueue(self, img_u8: np.ndarray):
         H, W = img_u8.shape[:2]
         if H % 32 or W % 32:
             raise ModelError("RT-DETR input must be a multiple of 32")
         cfg = self.cfg
-        with self._lock:
-            a, b = self.plans(H, W)
-            a.src.copy_(torch.from_numpy(np.array(img_u8, dtype=np.uint8)).to(self.device).view(1, H, W, 3))
-            a.run(graph=self._graph)
-            nc, Q = cfg.num_labels, cfg.num_queries
-            top = a.scores[:, :nc].max(-1).values.topk(Q, dim=0).indices
-            b.mem.copy_(a.mem)
-            b.h0.copy_(a.om.index_select(0, top))
-            b.ref_logit.copy_((a.boxes + a.anchors).index_select(0, top))
-            b.run(graph=self._graph)
-            return b.logits[:, :nc].clone(), b.boxes[:, :4].clone()
+        a, b = self.plans(H, W)
+        a.src.copy_(torch.from_numpy(np.array(img_u8, dtype=np.uint8)).to(self.device).view(1, H, W, 3))
+        a.run(graph=self._graph)
+        nc, Q = cfg.num_labels, cfg.num_queries
+        top = a.scores[:, :nc].max(-1).values.topk(Q, dim=0).indices
+        b.mem.copy_(a.mem)
+        b.h0.copy_(a.om.index_select(0, top))
+        b.ref_logit.copy_((a.boxes + a.anchors).index_select(0, top))
+        b.run(graph=self._graph)
+        return b.logits[:, :nc].clone(), b.boxes[:, :4].clone()
 
     def __call__(self, source, conf: float = 0.35, device=None, verbose: bool = False, imgsz=None, **_kw):
+        return self.collect(self.submit(source, conf=conf, imgsz=imgsz))
+
+    @torch.no_grad()
+    def submit(self, source, conf: float = 0.35, imgsz=None, **_kw):
+        """first half of a call (see hip/plan.py `AsyncLane`): the host-side resize, then upload, backbone + encoder graph, query
+        selection and decoder graph queued on this model's own stream; nothing here waits for the GPU"""
         if isinstance(source, Image.Image):
             pil = source.convert("RGB") if source.mode != "RGB" else source
         elif isinstance(source, np.ndarray):
@@ -377,17 +389,35 @@ class RTDetrHip:
         ow, oh = pil.size
         size = int(imgsz) if imgsz is not None else 640
         img = np.asarray(pil.resize((size, size), resample=Image.Resampling.BILINEAR))        # RTDetrImageProcessor: resize + 1/255
-        logits, boxes = self.forward_raw(img)
-        nc = self.cfg.num_labels
-        scores = logits.sigmoid()
-        k = min(self.cfg.num_queries, scores.numel())
-        top_s, idx = scores.flatten().topk(k)
-        labels, qi = idx % nc, idx // nc
-        cx, cy, w, h = boxes[qi].unbind(-1)
-        xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1) * torch.tensor([ow, oh, ow, oh], device=boxes.device, dtype=boxes.dtype)
-        keep = top_s > float(conf)
-        return [SimpleNamespace(boxes=_Boxes(xyxy[keep].float(), top_s[keep].float(), labels[keep].float()), names=self.names,
-                                orig_shape=(oh, ow), masks=None)]
+        self._lane.busy.acquire()
+        try:
+            with self._lane.enter():
+                logits, boxes = self._enqueue(img)
+                nc = self.cfg.num_labels
+                scores = logits.sigmoid()
+                k = min(self.cfg.num_queries, scores.numel())
+                top_s, idx = scores.flatten().topk(k)
+                labels, qi = idx % nc, idx // nc
+                cx, cy, w, h = boxes[qi].unbind(-1)
+                scale = torch.tensor([ow, oh, ow, oh], dtype=boxes.dtype).to(boxes.device, non_blocking=True)
+                xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1) * scale
+                keep = top_s > float(conf)
+        except BaseException:
+            self._lane.busy.release()
+            raise
+        return dict(xyxy=xyxy, top_s=top_s, labels=labels, keep=keep, hw=(oh, ow))
+
+    @torch.no_grad()
+    def collect(self, t):
+        try:
+            with self._lane.resume():
+                keep = t["keep"]
+                res = [SimpleNamespace(boxes=_Boxes(t["xyxy"][keep].float(), t["top_s"][keep].float(), t["labels"][keep].float()), names=self.names,
+                                       orig_shape=t["hw"], masks=None)]
+            self._lane.hand_over()
+            return res
+        finally:
+            self._lane.busy.release()
 
 
 class _Boxes:

@@ -33,7 +33,7 @@ import torch.nn.functional as F
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder, PlanCache
+from ...hip.plan import Act, AsyncLane, PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -84,7 +84,7 @@ class Sam2Hip:
         self.dtype = abi.BF16
         self.tdt = torch.bfloat16
         self._graph = graph and not self.lib.is_simulator
-        self._lock = threading.Lock()
+        self._lane = AsyncLane(self.device, self.lib.is_simulator)
         self._enc = None
         self._dec = PlanCache(6)
         self._post = PlanCache(8)
@@ -464,33 +464,69 @@ class Sam2Hip:
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def segment(self, page_u8, boxes_xyxy, return_logits: bool = False):
+    def submit_image(self, page_u8):
+        """First half of `segment`, prompt-independent: upload, antialiased resize and the Hiera image encoder are queued on this model's
+        own stream (hip/plan.py `AsyncLane`) and the call returns at once.  The reference computes the embedding inside
+        `Sam2Model(pixel_values, input_boxes)` after the detectors have finished (core/image/detection.py:494-509); the encoder does not
+        depend on the boxes, so a caller that knows the page will be segmented submits it together with the page's detectors and the
+        1.6 TFLOP encoder runs beside them.  The ticket goes to `segment(..., ticket=)`; the model is busy until then."""
+        page = torch.as_tensor(page_u8)
+        h, w = int(page.shape[0]), int(page.shape[1])
+        self._lane.busy.acquire()
+        try:
+            with self._lane.enter():
+                pre = self._pre_plan(h, w)
+                enc = self._encoder()
+                pre.page.copy_(page.to(self.device))
+                pre.run()
+                enc.run(graph=self._graph)
+        except BaseException:
+            self._lane.busy.release()
+            raise
+        return dict(hw=(h, w), page=page)
+
+    def segment(self, page_u8, boxes_xyxy, return_logits: bool = False, ticket=None):
         """page uint8 [H,W,3] (numpy or tensor) + boxes [N,4] in page pixels -> uint8 masks [N,H,W] (0/1)
-        on the device.  One encoder pass per page, all boxes decoded together (as the reference does)."""
+        on the device.  One encoder pass per page, all boxes decoded together (as the reference does).  `ticket`: the page was
+        already encoded by `submit_image` (same page object)."""
         boxes = np.asarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
         n = boxes.shape[0]
         page = torch.as_tensor(page_u8)
         h, w = int(page.shape[0]), int(page.shape[1])
+        if ticket is not None and ticket["hw"] != (h, w):
+            self._lane.busy.release()
+            raise ModelError("SAM ticket belongs to a page of another size")
         if n == 0:
+            if ticket is not None:
+                self._lane.busy.release()
             return torch.zeros((0, h, w), dtype=torch.uint8, device=self.device)
-        with self._lock:
-            pre = self._pre_plan(h, w)
-            enc = self._encoder()
-            dec = self._decoder(n)
-            post = self._post_plan(n, h, w)
-            pre.page.copy_(page.to(self.device))
-            dec.tok0.copy_(torch.from_numpy(self.embed_boxes(boxes, h, w).reshape(n * 9, -1)).to(self.device, self.tdt))
-            pre.run()
-            enc.run(graph=self._graph)
-            dec.run(graph=self._graph)
-            post.run()
-            masks = post.masks.clone()
-            if return_logits:
-                sel = dec.sel.long()
-                lg = dec.logits.view(n, dec.hl, dec.hl, 4)
-                low = lg[torch.arange(n, device=self.device), :, :, sel].clone()
-                return masks, low, dec.iou.clone(), dec.sel.clone()
-            return masks
+        if ticket is None:
+            self._lane.busy.acquire()
+        try:
+            with self._lane.enter() if ticket is None else self._lane.resume():
+                pre = self._pre_plan(h, w)
+                enc = self._encoder()
+                dec = self._decoder(n)
+                post = self._post_plan(n, h, w)
+                if ticket is None:
+                    pre.page.copy_(page.to(self.device))
+                dec.tok0.copy_(torch.from_numpy(self.embed_boxes(boxes, h, w).reshape(n * 9, -1)).to(self.device, self.tdt))
+                if ticket is None:
+                    pre.run()
+                    enc.run(graph=self._graph)
+                dec.run(graph=self._graph)
+                post.run()
+                masks = post.masks.clone()
+                out = masks
+                if return_logits:
+                    sel = dec.sel.long()
+                    lg = dec.logits.view(n, dec.hl, dec.hl, 4)
+                    low = lg[torch.arange(n, device=self.device), :, :, sel].clone()
+                    out = (masks, low, dec.iou.clone(), dec.sel.clone())
+            self._lane.hand_over()
+            return out
+        finally:
+            self._lane.busy.release()
 
     def plans(self, n, h, w):
         return self._pre_plan(h, w), self._encoder(), self._decoder(n), self._post_plan(n, h, w)

@@ -26,7 +26,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import PlanBuilder, PlanCache
+from ...hip.plan import AsyncLane, PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 
@@ -97,7 +97,7 @@ class YoloSegHip:
         self.a = self._derive(sd)
         self.names = names or {i: f"class{i}" for i in range(self.a["nc"])}
         self._graph = graph and not self.lib.is_simulator
-        self._lock = threading.Lock()
+        self._lane = AsyncLane(self.device, self.lib.is_simulator)
         self._plans = PlanCache(8)
         self._mask_plans = PlanCache(8)
         self._pack(sd)
@@ -230,23 +230,53 @@ class YoloSegHip:
     # ---- the ultralytics call shape -------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, image_bgr, conf=0.25, device=None, verbose=False, imgsz=640, retina_masks=True, iou=0.7, max_det=300):
-        img = np.ascontiguousarray(np.asarray(image_bgr)[..., :3])
-        h0, w0 = img.shape[:2]
+        return self.collect(self.submit(image_bgr, conf=conf, imgsz=imgsz, iou=iou, max_det=max_det))
+
+    @torch.no_grad()
+    def submit(self, image_bgr, conf=0.25, imgsz=640, iou=0.7, max_det=300, **_kw):
+        """first half of a call: upload, letterbox and the network's graph replay are queued on this model's own stream (`AsyncLane`)
+        and the call returns at once with a ticket for `collect`.  The model stays busy until the ticket is collected."""
+        # a page that is already on the device (uint8 [H, W, 3] BGR tensor: the caller uploaded it once for all of its detectors) is
+        # used in place; a host image is uploaded here
+        on_device = torch.is_tensor(image_bgr) and image_bgr.device.type == self.device.type and self.device.type != "cpu"
+        img = image_bgr[..., :3] if on_device else np.ascontiguousarray(np.asarray(image_bgr)[..., :3])
+        h0, w0 = int(img.shape[0]), int(img.shape[1])
         lp = letterbox_params(h0, w0, imgsz)
         key = (h0, w0, imgsz)
-        with self._lock:
-            if key not in self._plans:
-                plan = self._build(lp)
-                pre = PlanBuilder(self.lib, self.device, self.dtype)
-                page = pre.buf((h0, w0, 3), torch.uint8)
-                pre.letterbox(page, plan.img, h0, w0, lp["nh"], lp["nw"], lp["top"], lp["left"])
-                pp = pre.build()
-                pp.page = page
-                self._plans[key] = (plan, pp)
-            plan, pp = self._plans[key]
-            pp.page.copy_(torch.from_numpy(img).to(self.device))
-            pp.run()
-            plan.run(graph=self._graph)
+        self._lane.busy.acquire()
+        try:
+            with self._lane.enter():
+                if key not in self._plans:
+                    plan = self._build(lp)
+                    pre = PlanBuilder(self.lib, self.device, self.dtype)
+                    page = pre.buf((h0, w0, 3), torch.uint8)
+                    pre.letterbox(page, plan.img, h0, w0, lp["nh"], lp["nw"], lp["top"], lp["left"])
+                    pp = pre.build()
+                    pp.page = page
+                    self._plans[key] = (plan, pp)
+                plan, pp = self._plans[key]
+                pp.page.copy_(img if on_device else torch.from_numpy(img).to(self.device, non_blocking=True))
+                pp.run()
+                plan.run(graph=self._graph)
+        except BaseException:
+            self._lane.busy.release()
+            raise
+        return dict(plan=plan, lp=lp, hw=(h0, w0), conf=conf, iou=iou, max_det=max_det)
+
+    @torch.no_grad()
+    def collect(self, ticket):
+        """second half: candidates above `conf` come to the host, NMS, boxes back in page coordinates, retina masks"""
+        try:
+            with self._lane.resume():
+                res = self._finish(**ticket)
+            self._lane.hand_over()
+            return res
+        finally:
+            self._lane.busy.release()
+
+    def _finish(self, plan, lp, hw, conf, iou, max_det):
+        h0, w0 = hw
+        if True:
             nc, nm = self.a["nc"], self.a["nm"]
             dec = plan.decoded
             scores, cls = dec[:, 4:4 + nc].max(1)

@@ -5,6 +5,8 @@ stream owner here) and records ops as `mtx_op` structs; `build()` hands the arra
 `mtx_plan_create`.  `Plan.run()` is then one C call that launches every kernel of the network on
 the caller's HIP stream (optionally as a hipGraph replay) — no Python in the per-layer loop.
 """
+import contextlib
+import threading
 import ctypes as C
 from dataclasses import dataclass
 from typing import List, Optional
@@ -541,3 +543,45 @@ class PlanBuilder:
         plan.labels = list(self.labels)
         plan.ops = list(self.ops)          # the recorded argument blocks (benchmarks group launches by kernel and shape)
         return plan
+
+
+class AsyncLane:
+    """One model's private HIP stream for `submit` / `collect` style calls.
+
+    The reference runs a page's detectors one after the other, each call returning finished results (`model(img, conf=...)`,
+    core/image/detection.py:1337-1351, 1401-1407; core/image/ocr_detection.py:425-431).  On an MI355X the 640-pixel networks are far
+    too small to fill 256 CUs, and every call ends in a synchronising read — four detectors cost the SUM of their GPU times plus
+    their host post-processing.  With a lane per model, `submit` enqueues the upload and the graph replay on the model's own stream
+    and returns at once; the caller submits every detector of the page, then collects: the graphs run side by side on the chip and one
+    model's post-processing overlaps the others' kernels.  `__call__` = `collect(submit(...))` keeps the reference's call shape.
+
+    The lane also owns the model's busy lock: a model's plan has ONE set of buffers, so a second submit waits until the first was
+    collected.  On the CPU simulator (no streams) everything degenerates to an in-line call."""
+
+    def __init__(self, device, simulator: bool):
+        self.on = (not simulator) and torch.cuda.is_available() and torch.device(device).type == "cuda"
+        self.device = torch.device(device)
+        self._stream = None
+        self.busy = threading.Lock()
+
+    @property
+    def stream(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        return self._stream
+
+    def enter(self):
+        """context for the enqueue half: the lane's stream, ordered after everything the caller has queued so far"""
+        if not self.on:
+            return contextlib.nullcontext()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(self.stream)
+
+    def resume(self):
+        """context for the collect half (reads the results on the lane's stream)"""
+        return torch.cuda.stream(self.stream) if self.on else contextlib.nullcontext()
+
+    def hand_over(self):
+        """the caller's stream may touch what the lane produced"""
+        if self.on:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
