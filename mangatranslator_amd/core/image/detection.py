@@ -153,12 +153,32 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
     cache = get_cache()
     yolo_key = cache.get_yolo_cache_key(image_pil, detector_memo_path(manager, model_path, bubble_detector_model), confidence)
     remembered = cache.get_yolo_detection(yolo_key)
+    early_secondary, early_secondary_error = None, None
     if remembered is not None:
         log_message("Using cached YOLO detections", verbose=verbose)
         primary_results, primary_boxes = remembered
     else:
         imgsz = 1600 if bubble_detector_model == "yolo_2" else 640
-        primary_results = primary_model(bgr, conf=confidence, device=device, verbose=False, imgsz=imgsz, retina_masks=True)[0]
+        if hasattr(primary_model, "submit"):
+            # both detectors of the page are queued before either is waited for (hip/plan.py AsyncLane): the secondary network's graph
+            # runs beside the primary's and the primary's NMS / mask assembly beside the secondary's kernels.  The reference calls them
+            # one after the other (:1337-1351, 1401-1407) and skips the secondary on a page without bubbles; here its result is simply
+            # dropped in that case.  A secondary that cannot be loaded or queued fails where the reference would have met it, below.
+            ticket = primary_model.submit(bgr, conf=confidence, imgsz=imgsz)
+            if conjoined_detection:
+                try:
+                    sm = manager.load_rtdetr_conjoined_bubble()
+                    early_secondary = (sm, sm.submit(bgr, conf=conjoined_confidence, imgsz=640)) if hasattr(sm, "submit") else None
+                except Exception as e:      # noqa: BLE001
+                    early_secondary_error = e
+            try:
+                primary_results = primary_model.collect(ticket)[0]
+            except BaseException:
+                if early_secondary is not None:
+                    early_secondary[0].collect(early_secondary[1])      # never leave a model busy behind a failed page
+                raise
+        else:
+            primary_results = primary_model(bgr, conf=confidence, device=device, verbose=False, imgsz=imgsz, retina_masks=True)[0]
         primary_boxes = primary_results.boxes.xyxy if primary_results.boxes is not None else torch.zeros((0, 4))
         cache.set_yolo_detection(yolo_key, (primary_results, primary_boxes))
     primary_sources = [("primary", i) for i in range(len(primary_boxes))]
@@ -170,14 +190,22 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
         primary_boxes, primary_sources = primary_boxes[keep], [primary_sources[i] for i in keep]
     if len(primary_boxes) == 0:
         log_message("No detections found", verbose=verbose)
+        if early_secondary is not None:
+            early_secondary[0].collect(early_secondary[1])          # frees the model; the reference never ran it on such a page
         return detections, text_free_boxes
     log_message(f"Detected {len(primary_boxes)} speech bubbles with YOLO", always_print=True)
 
     secondary_boxes, secondary_sources, secondary_results = torch.zeros((0, 4)), [], None
     if conjoined_detection:
         try:
-            secondary_model = manager.load_rtdetr_conjoined_bubble()
-            secondary_results = secondary_model(bgr, conf=conjoined_confidence, device=device, verbose=False, imgsz=640)[0]
+            if early_secondary_error is not None:
+                raise early_secondary_error
+            if early_secondary is not None:
+                secondary_model = early_secondary[0]
+                secondary_results, early_secondary = secondary_model.collect(early_secondary[1])[0], None
+            else:
+                secondary_model = manager.load_rtdetr_conjoined_bubble()
+                secondary_results = secondary_model(bgr, conf=conjoined_confidence, device=device, verbose=False, imgsz=640)[0]
             secondary_boxes = secondary_results.boxes.xyxy if secondary_results.boxes is not None else torch.zeros((0, 4))
             secondary_sources = [("secondary", i) for i in range(len(secondary_boxes))]
             if len(secondary_boxes) > 1:
