@@ -57,6 +57,7 @@ def parse():
                     help="call the page's detectors one after the other, each returning finished results (the reference's order of calls); default: "
                          "submit all of them, then collect — their graphs run side by side on their own streams")
     ap.add_argument("--no-lanes", action="store_true", help="FLUX.1: keep the text stream's ops in line with the image stream's (one lane)")
+    ap.add_argument("--no-fused-quant", action="store_true", help="Klein fp8: separate quantiser passes behind the norms and SwiGLU (round 2's form) instead of producers that write the fp8 operands themselves")
     ap.add_argument("--no-fp8", action="store_true", help="Klein: keep the block linears in bf16 instead of the MX-fp8 matrix path")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the stages of a page strictly one after another; default: two pages in flight — detect / segment / OSB prepare of "
@@ -293,7 +294,7 @@ def main():
             from mangatranslator_amd.core.ml import flux as fx
             from mangatranslator_amd.core.ml import flux2 as f2
             dcfg = f2.KLEIN_9B_DIT_CFG if args.inpainter == "klein_9b" else f2.KLEIN_4B_DIT_CFG
-            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8)
+            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8, fused_quant=not args.no_fused_quant)
             vae = f2.Flux2VAEHip(fx.synthetic_provider(f2.vae_param_shapes(f2.KLEIN_VAE_CFG), device, 22, broadcast=world > 1), f2.KLEIN_VAE_CFG, device, lib=lib)
             flux = f2.Flux2KleinHip(dit, vae, graph=graph)
             flux.set_prompt_embeds(torch.randn(512, dcfg["joint_dim"], generator=torch.Generator().manual_seed(23)))     # cached Qwen3 states (stand-ins)

@@ -147,6 +147,10 @@ typedef struct mtx_norm_args {
   int64_t rows, c, ldx, ldy, rows_per, ldmod;
   float eps; int32_t kind; int32_t dtype;
   int32_t act;                   /* activation applied last (Sam2 upscaler: LayerNorm -> GELU) */
+  /* optional MX fp8 twin of the result (the operand format of the fp8 GEMM, see mtx_quant_args): q [rows][ldq] e4m3 bytes and the
+   * E8M0 scale plane q_scale[(c / 128) * lds_q + row], quantised from the result as rounded to `dtype` — bit-identical to running
+   * mtx_quantize_mx on y.  With q given, y may be NULL (no 16-bit consumer: the 16-bit store is skipped).  C % 128 == 0. */
+  void* q; void* q_scale; int64_t ldq, lds_q;
 } mtx_norm_args;
 
 /* GroupNorm over NHWC [N, HW, C] with G groups, optional fused SiLU. */
@@ -329,7 +333,12 @@ typedef struct mtx_quant_args {
   const void* x; void* q; void* scale;
   int64_t rows, k, ldx, ldq, lds;
   int32_t dtype;                 /* MTX_BF16 / MTX_F16: type of x */
+  /* op MTX_QUANT_SWIGLU: the matrix that is quantised is silu(x) * b (b: [rows, K], row stride ldb), rounded to `dtype` first —
+   * bit-identical to MTX_EW_SWIGLU followed by a plain quantise; y (optional, row stride ldy) also receives that 16-bit result. */
+  int32_t op; const void* b; int64_t ldb; void* y; int64_t ldy;
 } mtx_quant_args;
+#define MTX_QUANT_PLAIN 0
+#define MTX_QUANT_SWIGLU 1
 
 typedef enum mtx_op_kind {
   MTX_OP_CONV2D = 1, MTX_OP_GEMM = 2, MTX_OP_ATTN = 3, MTX_OP_NORM = 4, MTX_OP_GROUPNORM = 5,

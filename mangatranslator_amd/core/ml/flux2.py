@@ -82,7 +82,7 @@ class _W:
 
 
 class Flux2DiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False):
+    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True):
         """provider(name) -> tensor with diffusers' Flux2Transformer2DModel parameter of that name.
         fp8: False, True (= every block linear) or a tuple of names out of FP8_ALL."""
         self.lib = lib if lib is not None else get_library()
@@ -95,6 +95,7 @@ class Flux2DiTHip:
         if self.hd not in (64, 128) or sum(cfg["axes_dim"]) != self.hd:
             raise ModelError("FLUX.2 DiT: head dim must be 64 or 128 and equal sum(axes_dims_rope)")
         self.fp8 = FP8_ALL if fp8 is True else tuple(fp8 or ())
+        self.fused_quant = fused_quant      # norms and SwiGLU write the fp8 linears' operands themselves; False: separate quantiser passes (round 2's form, for A/Bs)
         if self.fp8 and (D % 128 or self.hid % 128):
             raise ModelError("FLUX.2 DiT fp8 path: d and the MLP width must be multiples of 128")
         g = lambda n, dt=None: provider(n).detach().to(self.device, dt if dt is not None else self.tdt).contiguous()
@@ -223,9 +224,15 @@ class Flux2DiTHip:
         pb.gemm(ctx_in, W["context_embedder"], t_txt, D, cfg["joint_dim"], out=x, label="context_embedder")
         pb.gemm(lat, W["x_embedder"], t_img, D, cfg["in_channels"], out=x, c_off=t_txt * D, label="x_embedder")
 
-        def adaln(r0, r1, shift_i, scale_i, label):
-            pb.norm(x, nrm, r1 - r0, D, eps=1e-6, kind=0, mod_scale=mod[scale_i], mod_shift=mod[shift_i], rows_per=r1 - r0, ldmod=D,
-                    x_off=r0 * D, y_off=r0 * D, label=label)
+        def adaln(r0, r1, shift_i, scale_i, label, consumers=()):
+            """adaLN LayerNorm of rows [r0, r1).  With fp8 consumers the kernel writes their MX fp8 operand itself (mtx_norm_args.q:
+            bit-identical to a quantiser pass over its 16-bit output, which is then only written if some consumer still reads 16-bit)"""
+            to8 = f8 and self.fused_quant and any(w.q is not None for w in consumers)
+            need16 = not to8 or any(w.q is None for w in consumers)
+            pb.norm(x, nrm if need16 else None, r1 - r0, D, eps=1e-6, kind=0, mod_scale=mod[scale_i], mod_shift=mod[shift_i], rows_per=r1 - r0, ldmod=D,
+                    x_off=r0 * D, y_off=r0 * D, label=label, q8=nrm8 if to8 else None, q_row_off=r0, lds_q=lds)
+            if f8 and not to8:
+                quant(nrm, D, nrm8, r0, r1, label + ".q")
 
         def rope(buf, r0, r1, gamma_qk, ld, label):
             v = _rows(buf, r0, r1, 0, 2 * D)
@@ -240,10 +247,22 @@ class Flux2DiTHip:
             pb.attention(src, src, src, out_t, 1, H, T, T, hd, (0, ld, hd), (0, ld, hd), (0, ld, hd), (0, out_ld, hd),
                          1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True)
 
-        def swiglu(src, ld, c0, r0, r1, dst, dst_ld, dst_c0, label):
+        def swiglu(src, ld, c0, r0, r1, dst, dst_ld, dst_c0, label, dst8=None, consumers=()):
+            """silu(a) * b of the two halves of a fused projection.  With fp8 consumers: one pass that writes their MX fp8 operand
+            (MTX_QUANT_SWIGLU) and the 16-bit result only if somebody still reads it"""
+            to8 = dst8 is not None and self.fused_quant and any(w.q is not None for w in consumers)
+            need16 = not to8 or any(w.q is None for w in consumers)
+            if to8:
+                pb.quantize(src, r1 - r0, hid, ldx=ld, x_off=r0 * ld + c0, q=dst8[0], scale=dst8[1], row_off=r0, lds=lds, ldq=dst_ld, q_col_off=dst_c0,
+                            swiglu_b=src, b_off=r0 * ld + c0 + hid, ldb=ld, y=dst if need16 else None, y_off=r0 * dst_ld + dst_c0, ldy=dst_ld,
+                            label=label + ".q")
+                return
             a_ = _rows(src, r0, r1, c0, hid)
             b_ = _rows(src, r0, r1, c0 + hid, hid)
             pb.ew(abi.EW_SWIGLU, a_, b=b_, out=_rows(dst, r0, r1, dst_c0, hid), label=label)
+            if dst8 is not None:
+                pb.quantize(dst, r1 - r0, hid, ldx=dst_ld, x_off=r0 * dst_ld + dst_c0, q=dst8[0], scale=dst8[1], row_off=r0, lds=lds, ldq=dst_ld,
+                            q_col_off=dst_c0, label=label + ".q")
 
         res_gate = lambda i, rows: dict(gate=mod[i], gate_rows_per=rows, res=x)
         # double-stream blocks: norms, quantisers and SwiGLU run over both streams at once; the text stream's four linears (512 rows, a
@@ -251,10 +270,8 @@ class Flux2DiTHip:
         for i, B in enumerate(self.blocks):
             tag = f"dbl{i}"
             pb.join()
-            adaln(t_txt, T, 0, 1, tag + ".norm1")
-            adaln(0, t_txt, 6, 7, tag + ".norm1_ctx")
-            if f8:
-                quant(nrm, D, nrm8, 0, T, tag + ".norm1.q")
+            adaln(t_txt, T, 0, 1, tag + ".norm1", (B["qkv"],))
+            adaln(0, t_txt, 6, 7, tag + ".norm1_ctx", (B["cqkv"],))
             with pb.side():
                 linear(nrm, nrm8 if f8 else None, B["cqkv"], 0, t_txt, 3 * D, D, qkv, label=tag + ".qkv_ctx")
             linear(nrm, nrm8 if f8 else None, B["qkv"], t_txt, T, 3 * D, D, qkv, label=tag + ".qkv")
@@ -268,32 +285,27 @@ class Flux2DiTHip:
                 linear(o, o8 if f8 else None, B["cout"], 0, t_txt, D, D, x, label=tag + ".to_add_out", **res_gate(8, t_txt))
             linear(o, o8 if f8 else None, B["out"], t_txt, T, D, D, x, res_off=t_txt * D, label=tag + ".to_out", **res_gate(2, t_img))
             pb.join()
-            adaln(t_txt, T, 3, 4, tag + ".norm2")
-            adaln(0, t_txt, 9, 10, tag + ".norm2_ctx")
-            if f8:
-                quant(nrm, D, nrm8, 0, T, tag + ".norm2.q")
+            adaln(t_txt, T, 3, 4, tag + ".norm2", (B["ff_in"],))
+            adaln(0, t_txt, 9, 10, tag + ".norm2_ctx", (B["cff_in"],))
             with pb.side():
                 linear(nrm, nrm8 if f8 else None, B["cff_in"], 0, t_txt, 2 * hid, D, ffh, label=tag + ".ff_in_ctx")
             linear(nrm, nrm8 if f8 else None, B["ff_in"], t_txt, T, 2 * hid, D, ffh, label=tag + ".ff_in")
             pb.join()
-            swiglu(ffh, 2 * hid, 0, 0, T, ffa, hid, 0, tag + ".swiglu")
-            if f8:
-                quant(ffa, hid, ffa8, 0, T, tag + ".swiglu.q")
+            swiglu(ffh, 2 * hid, 0, t_txt, T, ffa, hid, 0, tag + ".swiglu", ffa8 if f8 else None, (B["ff_out"],))
+            swiglu(ffh, 2 * hid, 0, 0, t_txt, ffa, hid, 0, tag + ".swiglu_ctx", ffa8 if f8 else None, (B["cff_out"],))
             with pb.side():
                 linear(ffa, ffa8 if f8 else None, B["cff_out"], 0, t_txt, D, hid, x, label=tag + ".ff_out_ctx", **res_gate(11, t_txt))
             linear(ffa, ffa8 if f8 else None, B["ff_out"], t_txt, T, D, hid, x, res_off=t_txt * D, label=tag + ".ff_out", **res_gate(5, t_img))
         pb.join()
         for i, S in enumerate(self.singles):
             tag = f"sgl{i}"
-            adaln(0, T, 12, 13, tag + ".norm")
-            if f8:
-                quant(nrm, D, nrm8, 0, T, tag + ".norm.q")
+            adaln(0, T, 12, 13, tag + ".norm", (S["fused"],))
             linear(nrm, nrm8 if f8 else None, S["fused"], 0, T, FW, D, big, label=tag + ".to_qkv_mlp")
             rope(big, 0, T, S["nqk"], FW, tag + ".rope_qk")
             attention(big, FW, cat, D + hid, tag + ".attn")
-            swiglu(big, FW, 3 * D, 0, T, cat, D + hid, D, tag + ".swiglu")
-            if f8:
-                quant(cat, D + hid, cat8, 0, T, tag + ".cat.q")
+            swiglu(big, FW, 3 * D, 0, T, cat, D + hid, D, tag + ".swiglu", cat8 if f8 else None, (S["out"],))
+            if f8 and S["out"].q is not None:          # the attention half of the concatenation: its own quantiser pass over columns [0, D)
+                pb.quantize(cat, T, D, ldx=D + hid, q=cat8[0], scale=cat8[1], lds=lds, ldq=D + hid, label=tag + ".attn.q")
             linear(cat, cat8 if f8 else None, S["out"], 0, T, D, D + hid, x, label=tag + ".to_out", **res_gate(14, T))
         pb.norm(x, nrm, t_noise, D, eps=1e-6, kind=0, mod_scale=mod[15], mod_shift=mod[16], rows_per=t_noise, ldmod=D,
                 x_off=t_txt * D, y_off=t_txt * D, label="norm_out")

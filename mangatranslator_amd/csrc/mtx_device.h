@@ -245,6 +245,31 @@ __device__ __forceinline__ unsigned cvt_pk_fp8(float a, float b, unsigned old) {
 #endif
 }
 
+// One lane's share of an MX block quantisation (mtx_quant_args): the lane holds 8 consecutive k (chunk c8 of its row), lanes 4 g .. 4 g + 3
+// of a wave hold one 32-k block, 16 adjacent lanes one uint32 of four E8M0 scale bytes.  Every lane of the wave must call this (shuffles);
+// lanes without data pass zeros.  Out: the 8 e4m3 bytes (w0, w1) and the group's scale word (to be stored by the lane with (c8 & 15) == 0).
+__device__ __forceinline__ void mx_quantize_chunk(float (&f)[8], long c8, unsigned& w0, unsigned& w1, unsigned& word) {
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float a = fabsf(f[e]); amax = a > amax ? a : amax; }
+  { float o = __shfl_xor(amax, 1, 64); amax = o > amax ? o : amax; }
+  { float o = __shfl_xor(amax, 2, 64); amax = o > amax ? o : amax; }
+  // smallest power of two 2^(eb - 127) >= amax / 448
+  const float r = amax * (1.0f / 448.0f);
+  const unsigned u = __builtin_bit_cast(unsigned, r);
+  int eb = (int)((u >> 23) & 0xff) + ((u & 0x7fffffu) ? 1 : 0);
+  eb = amax == 0.f ? 127 : (eb < 1 ? 1 : (eb > 253 ? 253 : eb));
+  const float inv = __builtin_bit_cast(float, (unsigned)(254 - eb) << 23);      // 2^(127 - eb)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { float v = f[e] * inv; v = v > 448.f ? 448.f : (v < -448.f ? -448.f : v); f[e] = v; }
+  w0 = 0; w1 = 0;
+  w0 = cvt_pk_fp8<false>(f[0], f[1], w0); w0 = cvt_pk_fp8<true>(f[2], f[3], w0);
+  w1 = cvt_pk_fp8<false>(f[4], f[5], w1); w1 = cvt_pk_fp8<true>(f[6], f[7], w1);
+  word = (unsigned)eb << (8 * (int)((c8 & 15) >> 2));
+  word |= __shfl_xor(word, 4, 64);
+  word |= __shfl_xor(word, 8, 64);
+}
+
 // XCD-aware, bijective remap of a linear workgroup id: workgroup b runs on XCD b%8 (observed),
 // so give each XCD a contiguous range of tiles and neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {

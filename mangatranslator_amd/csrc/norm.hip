@@ -70,13 +70,40 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = apply_act(o[e], p.act, 0.f);
       }
-      *reinterpret_cast<u32x4*>(Y + ch * 8) = pack8<T>(o);
+      if (p.y != nullptr) *reinterpret_cast<u32x4*>(Y + ch * 8) = pack8<T>(o);
+      if (p.q != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = to_f32(from_f32<T>(o[e]));      // what the quantiser would read back from y: rounded to T
+      }
+    }
+  }
+  if (p.q != nullptr) {
+    // MX fp8 twin of the row (mtx_quant_args' format) straight from the registers: the fp8 linears that follow read nothing else, so the
+    // separate quantiser pass (2 B read + 1 B written per element) — and, without a 16-bit consumer, the 16-bit store — disappear.
+    // C % 128 == 0 (checked by the launcher): chunk ch = lane + 64 i is valid for a whole 16-lane group or not at all.
+    unsigned char* Q = reinterpret_cast<unsigned char*>(p.q) + row * p.ldq;
+    unsigned* S = reinterpret_cast<unsigned*>(p.q_scale);
+#pragma unroll
+    for (int i = 0; i < NORM_MAXCH; ++i) {
+      const long ch = lane + (long)i * 64;
+      if ((long)i * 64 < nch) {                     // wave-uniform
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = ch < nch ? v[i][e] : 0.f;
+        unsigned w0, w1, word;
+        mx_quantize_chunk(f, ch, w0, w1, word);
+        if (ch < nch) {
+          *reinterpret_cast<u32x2*>(Q + ch * 8) = u32x2{w0, w1};
+          if ((ch & 15) == 0) S[(ch >> 4) * p.lds_q + row] = word;
+        }
+      }
     }
   }
 }
 
 int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
-  if (!a->x || !a->y) { *err = "norm: null operand"; return MTX_ERR_INVALID; }
+  if (!a->x || (!a->y && !a->q)) { *err = "norm: null operand"; return MTX_ERR_INVALID; }
+  if (a->q && (!a->q_scale || a->c % 128 || a->ldq % 8 || a->lds_q < a->rows)) { *err = "norm (fp8 twin): needs q_scale, C % 128 == 0, ldq % 8 == 0, lds_q >= rows"; return MTX_ERR_INVALID; }
   if (a->c % 8 || a->ldx % 8 || a->ldy % 8 || a->c > NORM_MAXCH * 64 * 8 || a->c < 8) { *err = "norm: C must be a multiple of 8, <= 6144"; return MTX_ERR_INVALID; }
   if ((a->mod_scale || a->mod_shift) && (a->ldmod % 8 || a->rows_per < 1)) { *err = "norm: bad modulation layout"; return MTX_ERR_INVALID; }
   if (a->kind != 0 && a->kind != 1) { *err = "norm: kind must be 0 (LayerNorm) or 1 (RMSNorm)"; return MTX_ERR_INVALID; }

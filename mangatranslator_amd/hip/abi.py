@@ -57,7 +57,8 @@ ATTN_WORKSPACE_BYTES = 256 * (256 * 128 * 4 + 256 * 2 * 4)
 class NormArgs(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("mod_scale", vp), ("mod_shift", vp),
                 ("rows", i64), ("c", i64), ("ldx", i64), ("ldy", i64), ("rows_per", i64), ("ldmod", i64),
-                ("eps", f32), ("kind", i32), ("dtype", i32), ("act", i32)]
+                ("eps", f32), ("kind", i32), ("dtype", i32), ("act", i32),
+                ("q", vp), ("q_scale", vp), ("ldq", i64), ("lds_q", i64)]
 
 
 class GroupNormArgs(C.Structure):
@@ -133,7 +134,11 @@ class DetrArgs(C.Structure):
 
 class QuantArgs(C.Structure):
     _fields_ = [("x", vp), ("q", vp), ("scale", vp),
-                ("rows", i64), ("k", i64), ("ldx", i64), ("ldq", i64), ("lds", i64), ("dtype", i32)]
+                ("rows", i64), ("k", i64), ("ldx", i64), ("ldq", i64), ("lds", i64), ("dtype", i32),
+                ("op", i32), ("b", vp), ("ldb", i64), ("y", vp), ("ldy", i64)]
+
+
+QUANT_PLAIN, QUANT_SWIGLU = 0, 1
 
 
 class CleanArgs(C.Structure):

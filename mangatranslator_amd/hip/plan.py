@@ -333,9 +333,14 @@ class PlanBuilder:
 
     def norm(self, x, y, rows, c, ldx=None, ldy=None, gamma=None, beta=None, eps=1e-6, kind=0,
              mod_scale=None, mod_shift=None, rows_per=0, ldmod=0, x_off=0, y_off=0, act=abi.ACT_NONE,
-             label="norm"):
+             label="norm", q8=None, q_row_off=0, lds_q=0):
+        """q8 = (q bytes [R, c], scale plane [c / 128, lds_q]): also (or, with y None, only) the MX fp8 twin of the result, rows landing
+        at q_row_off (include/mtx_hip.h mtx_norm_args.q)"""
         a = abi.NormArgs()
-        a.x, a.y = _ptr(x, x_off), _ptr(y, y_off)
+        a.x, a.y = _ptr(x, x_off), (_ptr(y, y_off) if y is not None else None)
+        if q8 is not None:
+            a.q, a.q_scale = q8[0].data_ptr() + q_row_off * c, q8[1].data_ptr() + 4 * q_row_off
+            a.ldq, a.lds_q = c, lds_q
         a.gamma, a.beta = _ptr(gamma), _ptr(beta)
         a.mod_scale, a.mod_shift = _ptr(mod_scale), _ptr(mod_shift)
         a.rows, a.c, a.ldx, a.ldy = rows, c, (ldx or c), (ldy or c)
@@ -515,16 +520,25 @@ class PlanBuilder:
         a.kind, a.rows, a.ld_delta, a.dtype = (1 if delta is not None else 2), rows, ld_delta, self.dtype
         self._add(abi.OP_DETR, a, label)
 
-    def quantize(self, x, rows, k, ldx=None, x_off=0, q=None, scale=None, row_off=0, lds=None, label="quantize_mx"):
+    def quantize(self, x, rows, k, ldx=None, x_off=0, q=None, scale=None, row_off=0, lds=None, label="quantize_mx",
+                 ldq=None, q_col_off=0, swiglu_b=None, b_off=0, ldb=None, y=None, y_off=0, ldy=None):
         """MX fp8 copy of rows [0, rows) of a 16-bit [*, ldx] matrix starting x_off elements in; with `q` / `scale` given the result
-        lands in rows [row_off, row_off + rows) of those buffers (q [R, k] bytes, scale [k / 128, lds] uint32).  -> (q, scale, lds)"""
+        lands in rows [row_off, row_off + rows) of those buffers (q [R, ldq] bytes from column q_col_off on, scale [K / 128, lds] uint32
+        from plane q_col_off / 128 on).  swiglu_b: the quantised matrix is silu(x) * swiglu_b (MTX_QUANT_SWIGLU; y: its 16-bit copy).
+        -> (q, scale, lds)"""
         if q is None:
             lds = (rows + 63) // 64 * 64
             q = self.buf((rows, k), torch.uint8)
             scale = self.buf((k // 128, lds), torch.int32, zero=True)
+        ldq = ldq or k
+        assert q_col_off % 128 == 0
         a = abi.QuantArgs()
-        a.x, a.q, a.scale = _ptr(x, x_off), q.data_ptr() + row_off * k, scale.data_ptr() + 4 * row_off
-        a.rows, a.k, a.ldx, a.ldq, a.lds, a.dtype = rows, k, (ldx or k), k, lds, self.dtype
+        a.x, a.q, a.scale = _ptr(x, x_off), q.data_ptr() + row_off * ldq + q_col_off, scale.data_ptr() + 4 * (row_off + (q_col_off // 128) * lds)
+        a.rows, a.k, a.ldx, a.ldq, a.lds, a.dtype = rows, k, (ldx or k), ldq, lds, self.dtype
+        if swiglu_b is not None:
+            a.op, a.b, a.ldb = abi.QUANT_SWIGLU, _ptr(swiglu_b, b_off), (ldb or ldx or k)
+            if y is not None:
+                a.y, a.ldy = _ptr(y, y_off), (ldy or k)
         self._add(abi.OP_QUANT, a, label)
         return q, scale, lds
 

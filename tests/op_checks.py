@@ -415,6 +415,49 @@ def check_quantize_mx(lib, dtype, rows, k, ld_extra=0, seed=0, spread=4.0):
     assert torch.equal(got.int(), eb_ref.int()), "scale bytes differ"
 
 
+def check_fused_quantisers(lib, dtype, rows, c, hid, seed=0):
+    """The fp8 twins written by the producers themselves — adaLN LayerNorm (mtx_norm_args.q) and SwiGLU (MTX_QUANT_SWIGLU) — must be
+    bit-identical to the two-pass form (producer writes 16-bit, mtx_quantize_mx reads it back): bytes, scale words, and the optional
+    16-bit copies; rows land at a row offset inside larger twin buffers, as in the FLUX.2 graph."""
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = (torch.randn(rows, c, generator=g) * torch.exp(1.5 * torch.randn(rows, 1, generator=g)) + 0.3).to(td)
+    ms, mh = (0.3 * torch.randn(2, c, generator=g)).to(td), (0.2 * torch.randn(2, c, generator=g)).to(td)
+    ab = (2.0 * torch.randn(rows, 2 * hid, generator=g)).to(td)
+    rows_per = (rows + 1) // 2
+    r_off, R = 5, rows + 9
+    lds = (R + 63) // 64 * 64
+    pb = PlanBuilder(lib, dev, dtype)
+    xt, mst, mht, abt = pb.const(x), pb.const(ms), pb.const(mh), pb.const(ab)
+    # two-pass reference path
+    y2 = pb.buf((rows, c), td)
+    pb.norm(xt, y2, rows, c, eps=1e-6, kind=0, mod_scale=mst, mod_shift=mht, rows_per=rows_per, ldmod=c)
+    q2, s2 = pb.buf((R, c), torch.uint8, zero=True), pb.buf((c // 128, lds), torch.int32, zero=True)
+    pb.quantize(y2, rows, c, q=q2, scale=s2, row_off=r_off, lds=lds)
+    va = Act(abt.view(1, 1, rows, 2 * hid), 1, 1, rows, hid, 0)
+    vb = Act(abt.view(1, 1, rows, 2 * hid), 1, 1, rows, hid, hid)
+    sw2 = pb.ew(abi.EW_SWIGLU, va, b=vb)
+    qs2, ss2 = pb.buf((R, 2 * hid), torch.uint8, zero=True), pb.buf((2 * hid // 128, lds), torch.int32, zero=True)
+    pb.quantize(sw2.t, rows, hid, q=qs2, scale=ss2, row_off=r_off, lds=lds, ldq=2 * hid, q_col_off=hid)      # lands in the right half of a wider twin
+    # fused path
+    y1 = pb.buf((rows, c), td)
+    q1, s1 = pb.buf((R, c), torch.uint8, zero=True), pb.buf((c // 128, lds), torch.int32, zero=True)
+    pb.norm(xt, y1, rows, c, eps=1e-6, kind=0, mod_scale=mst, mod_shift=mht, rows_per=rows_per, ldmod=c, q8=(q1, s1), q_row_off=r_off, lds_q=lds)
+    q1b, s1b = pb.buf((R, c), torch.uint8, zero=True), pb.buf((c // 128, lds), torch.int32, zero=True)
+    pb.norm(xt, None, rows, c, eps=1e-6, kind=0, mod_scale=mst, mod_shift=mht, rows_per=rows_per, ldmod=c, q8=(q1b, s1b), q_row_off=r_off, lds_q=lds)
+    qs1, ss1 = pb.buf((R, 2 * hid), torch.uint8, zero=True), pb.buf((2 * hid // 128, lds), torch.int32, zero=True)
+    sw1 = pb.buf((rows, hid), td)
+    pb.quantize(abt, rows, hid, ldx=2 * hid, q=qs1, scale=ss1, row_off=r_off, lds=lds, ldq=2 * hid, q_col_off=hid,
+                swiglu_b=abt, b_off=hid, ldb=2 * hid, y=sw1, ldy=hid)
+    _run(pb)
+    assert torch.equal(y1, y2), "16-bit norm output changed"
+    for a_, b_, what in ((q1, q2, "norm bytes"), (s1, s2, "norm scales"), (q1b, q2, "norm bytes (no 16-bit output)"), (s1b, s2, "norm scales (no 16-bit output)"),
+                         (qs1, qs2, "SwiGLU bytes"), (ss1, ss2, "SwiGLU scales")):
+        assert torch.equal(a_, b_), f"{what}: {(a_ != b_).sum().item()} differ"
+    assert torch.equal(sw1, sw2.t.view(rows, hid)), "16-bit SwiGLU copy differs"
+    assert q1.any() and qs1.any()
+
+
 def check_gemm_f8(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=False, with_gate=False, seed=0, flags=0,
                   spread=1.0):
     """C = epilogue(dequant(Aq) dequant(Wq)^T): the kernel against an fp32 product of the SAME quantised operands (so the check is

@@ -162,3 +162,9 @@ def test_rcab_tail_pool_before_conv(hip_lib, dtype):
     oc.check_rcab_tail(hip_lib, dtype, n=2, h=37, w=29)
     oc.check_rcab_tail(hip_lib, dtype, n=1, h=50, w=52)
     oc.check_rcab_tail(hip_lib, dtype, n=1, h=21, w=40, canvas=(64, 64))
+
+
+def test_producers_write_their_fp8_twins(hip_lib):
+    """adaLN norm and SwiGLU quantise their own output for the fp8 linears (Klein-4B width): bit-identical to producer + mtx_quantize_mx"""
+    oc.check_fused_quantisers(hip_lib, abi.BF16, rows=8512, c=3072, hid=9216)
+    oc.check_fused_quantisers(hip_lib, abi.BF16, rows=333, c=1152, hid=384, seed=1)

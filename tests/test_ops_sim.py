@@ -170,3 +170,9 @@ def test_conv_out_scale_and_sums_on_both_kernels(emu_lib, dtype):
     oc.check_conv(emu_lib, dtype, n=2, h=21, w=19, cin=64, cout=64, ksize=3, stride=1, act=abi.ACT_RELU, with_sum=True, with_scale=True)
     oc.check_conv(emu_lib, dtype, n=2, h=21, w=19, cin=64, cout=64, ksize=3, stride=1, act=abi.ACT_RELU, with_sum=True, with_scale=True, with_res=True)
     oc.check_conv(emu_lib, dtype, n=1, h=17, w=23, cin=32, cout=48, ksize=3, stride=1, act=abi.ACT_SILU, with_sum=True, with_scale=True)
+
+
+def test_producers_write_their_fp8_twins(emu_lib):
+    """adaLN norm and SwiGLU quantise their own output for the fp8 linears: bit-identical to producer + mtx_quantize_mx"""
+    oc.check_fused_quantisers(emu_lib, abi.BF16, rows=37, c=256, hid=128)
+    oc.check_fused_quantisers(emu_lib, abi.F16, rows=70, c=1152, hid=384, seed=1)
