@@ -367,7 +367,7 @@ class Flux2KleinHip:
 
     def encode_prompt(self, prompt=None, device=None, **kw):
         if self._embeds is None:
-            raise ModelError("FLUX.2 text encoder (Qwen3) is not part of the MI355X hot path: provide cached prompt embeddings with set_prompt_embeds()")
+            raise ModelError("FLUX.2 text encoder (Qwen3) is not part of the MI355X hot path: export them once with `python tools/export_prompt_embeds.py klein <pipeline snapshot>` (writes prompt_embeds.safetensors next to the transformer) or hand them to set_prompt_embeds()")
         n = self._embeds.shape[0]
         text_ids = torch.zeros(1, n, 4)
         text_ids[0, :, 3] = torch.arange(n)

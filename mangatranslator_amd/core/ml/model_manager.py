@@ -551,6 +551,7 @@ class _ShardedProvider:
         self.multi = _dist_on()
         self.rank0 = not self.multi or dist.get_rank() == 0
         self.where = {}
+        self.sdnq = None
         error = None
         if self.rank0:
             from safetensors import safe_open
@@ -563,11 +564,17 @@ class _ShardedProvider:
                     for h in self.handles:
                         for k in h.keys():
                             self.where[k] = h
+                    # SDNQ-packed parameters (the reference's Disty0/*-SDNQ-* repositories: `<base>.weight` in packed uint8 beside
+                    # `<base>.scale` [+ zero_point, svd_up, svd_down]) are expanded to bf16 at load by core/ml/sdnq.py
+                    packed = {k for k in shapes if k.endswith(".weight") and k[:-len(".weight")] + ".scale" in self.where}
+                    if packed:
+                        from .sdnq import SdnqReader
+                        self.sdnq = SdnqReader(folder)
                     missing = [k for k in shapes if k not in self.where]
-                    bad = [k for k in shapes if k in self.where and tuple(self.where[k].get_slice(k).get_shape()) != tuple(shapes[k])]
+                    bad = [k for k in shapes if k in self.where and k not in packed and tuple(self.where[k].get_slice(k).get_shape()) != tuple(shapes[k])]
                     if missing:
-                        error = (f"{folder}: {len(missing)} parameters missing (first: {missing[0]}); a bf16 diffusers "
-                                 "checkpoint is expected — SDNQ / nunchaku / GGUF packed weights are not read")
+                        error = (f"{folder}: {len(missing)} parameters missing (first: {missing[0]}); a bf16 or SDNQ-packed diffusers "
+                                 "checkpoint is expected — nunchaku / GGUF packed weights are not read")
                     elif bad:
                         error = f"{bad[0]}: shape {tuple(self.where[bad[0]].get_slice(bad[0]).get_shape())} != expected {tuple(shapes[bad[0]])}"
                 except Exception as e:
@@ -577,7 +584,10 @@ class _ShardedProvider:
     def __call__(self, name: str) -> torch.Tensor:
         dt = torch.float32 if name.startswith(self.keep_dtype) and self.keep_dtype else torch.bfloat16
         if self.rank0:
-            t = self.where[name].get_tensor(name).to(self.device, dt, copy=True)       # never a view of the shard's mapping (it goes away with the handle)
+            if self.sdnq is not None and self.sdnq.is_packed(name):
+                t = self.sdnq.get(name, self.shapes[name]).to(self.device, dt)
+            else:
+                t = self.where[name].get_tensor(name).to(self.device, dt, copy=True)   # never a view of the shard's mapping (it goes away with the handle)
         else:
             t = torch.empty(self.shapes[name], dtype=dt, device=self.device)
         if self.multi:

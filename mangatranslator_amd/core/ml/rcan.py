@@ -87,6 +87,27 @@ def pack_bias(b: torch.Tensor, shuffle: bool = False, cout_pad: int = 0) -> torc
     return out
 
 
+def read_safetensors_header(path) -> dict:
+    """{tensor name: shape} from a .safetensors file's JSON header alone (8-byte little-endian length, then the JSON): the
+    hyper-parameters of an upscaler checkpoint can be told without reading 20-60 MB of weights"""
+    import json
+    import struct
+    with open(path, "rb") as f:
+        (n,) = struct.unpack("<Q", f.read(8))
+        if n <= 0 or n > (100 << 20):
+            raise ModelError(f"{path}: not a safetensors file (header length {n})")
+        head = json.loads(f.read(n).decode("utf-8"))
+    return {k: tuple(v["shape"]) for k, v in head.items() if k != "__metadata__"}
+
+
+def rcan_hparams_from_header(path) -> dict:
+    """`derive_rcan_hparams` on the shapes in a checkpoint's header (2x-AnimeSharpV4_RCAN / _Fast_RCAN_PU, reference
+    core/ml/model_manager.py:617-700): n_feats, n_resgroups, n_resblocks, reduction, scale and the pixel-unshuffle factor of the
+    "PU" variants come from the tensor shapes, nothing is assumed"""
+    shapes = read_safetensors_header(path)
+    return derive_rcan_hparams({k: torch.empty(s, device="meta") for k, s in shapes.items()})
+
+
 class RCANUpscaler:
     """Callable like the spandrel model descriptor: `model(tensor[N,3,H,W] f32) -> [N,3,sH,sW] f32`.
     Thread-safe (up to 20 reference worker threads share one instance)."""
