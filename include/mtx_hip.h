@@ -340,10 +340,36 @@ typedef struct mtx_quant_args {
 #define MTX_QUANT_PLAIN 0
 #define MTX_QUANT_SWIGLU 1
 
+/* The inpainting stage's image arithmetic around the diffusion pipeline, on the device (csrc/pagetail.hip; reference
+ * core/image/inpainting.py:543-611, 877-968, 1187-1313, 1577-1665): all on uint8 HWC images, row strides ld_* in BYTES.
+ *  MTX_TAIL_RESAMPLE   one axis of Pillow's 8-bit resize (Image.resize with BILINEAR / BICUBIC / LANCZOS), bit-exact: output
+ *                      coordinate o reads src positions bounds[2o] .. + bounds[2o+1] with the fixed-point taps coeff[o * ksize ..]
+ *                      (22 fractional bits, built like Pillow's precompute_coeffs + normalize_coeffs_8bpc by the caller).
+ *                      axis 0: dst [out_h][out_w] from src rows src_row0 .. (horizontal pass); axis 1: vertical pass.
+ *  MTX_TAIL_COMPOSITE  dst (the page, page_c channels, IN PLACE) window [y, y + out_h) x [x, x + out_w) = patch * alpha + page * (1 - alpha)
+ *                      in fp32 with the reference's operation order, truncated to uint8 (bit-exact with the numpy expression).
+ *  MTX_TAIL_LAB_STATS  OpenCV fixed-point RGB -> Lab of src (generated patch) and other (original crop); over the pixels with
+ *                      mask == 0: sums[0..8] += {n, L, L^2, a, b of src, L, L^2, a, b of other} as exact uint64 (zero them first).
+ *  MTX_TAIL_LAB_REMAP  dst = Lab -> RGB of (Lab(src) with L' = (L - params[0]) * params[1] + params[2], a' = a + params[3] if params[5],
+ *                      b' = b + params[4] if params[6] on the pixels with mask != 0, clipped and truncated to uint8).
+ * gamma_tab [256], cbrt_tab [cbrt_n], lab_coef [9]: OpenCV's tables (int32), uploaded once by the caller. */
+typedef enum mtx_tail_kind { MTX_TAIL_RESAMPLE = 0, MTX_TAIL_COMPOSITE = 1, MTX_TAIL_LAB_STATS = 2, MTX_TAIL_LAB_REMAP = 3 } mtx_tail_kind;
+typedef struct mtx_tail_args {
+  int32_t kind;
+  const void* src; void* dst;
+  int32_t out_h, out_w, c;
+  int64_t ld_src, ld_dst;
+  const int32_t* bounds; const int32_t* coeff; int32_t ksize, axis, src_row0;                 /* RESAMPLE */
+  const float* alpha; int64_t ld_alpha; int32_t x, y, page_c;                                  /* COMPOSITE (ld_alpha in floats) */
+  const int32_t* gamma_tab; const int32_t* cbrt_tab; const int32_t* lab_coef; int32_t cbrt_n; /* LAB_* */
+  const uint8_t* mask; int64_t ld_mask; const void* other; int64_t ld_other;
+  unsigned long long* sums; const float* params;
+} mtx_tail_args;
+
 typedef enum mtx_op_kind {
   MTX_OP_CONV2D = 1, MTX_OP_GEMM = 2, MTX_OP_ATTN = 3, MTX_OP_NORM = 4, MTX_OP_GROUPNORM = 5,
   MTX_OP_EW = 6, MTX_OP_CA = 7, MTX_OP_IMG = 8, MTX_OP_RESIZE_THRESH = 9, MTX_OP_MEMSET = 10,
-  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12, MTX_OP_YOLO_DECODE = 13, MTX_OP_DETR = 14, MTX_OP_QUANT = 15
+  MTX_OP_MASK_SELECT = 11, MTX_OP_PREPROC = 12, MTX_OP_YOLO_DECODE = 13, MTX_OP_DETR = 14, MTX_OP_QUANT = 15, MTX_OP_TAIL = 16
 } mtx_op_kind;
 
 typedef struct mtx_memset_args { void* ptr; int64_t bytes; int32_t value; } mtx_memset_args;
@@ -359,7 +385,7 @@ typedef struct mtx_op {
   union {
     mtx_conv2d_args conv; mtx_gemm_args gemm; mtx_attn_args attn; mtx_norm_args norm;
     mtx_groupnorm_args gn; mtx_ew_args ew; mtx_ca_args ca; mtx_img_args img;
-    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre; mtx_yolo_decode_args yd; mtx_detr_args detr; mtx_quant_args quant;
+    mtx_resize_thresh_args rt; mtx_memset_args ms; mtx_mask_select_args sel; mtx_preproc_args pre; mtx_yolo_decode_args yd; mtx_detr_args detr; mtx_quant_args quant; mtx_tail_args tail;
   } u;
 } mtx_op;
 
@@ -387,6 +413,7 @@ MTX_API int mtx_yolo_decode(const mtx_yolo_decode_args* a, void* stream);
 MTX_API int mtx_bubble_clean(const mtx_clean_args* a, void* stream);
 MTX_API int mtx_detr(const mtx_detr_args* a, void* stream);
 MTX_API int mtx_quantize_mx(const mtx_quant_args* a, void* stream);
+MTX_API int mtx_page_tail(const mtx_tail_args* a, void* stream);
 /* contour half of the same chain, host side on one crop (cleaning.py:340-386): external contours of the
  * thresholded crop -> area / centroid filter -> filled union -> largest blob -> final mask + bounding box.
  * Returns the number of accepted text fragments (0 = nothing to clean).                                */

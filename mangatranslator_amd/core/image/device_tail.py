@@ -1,0 +1,227 @@
+"""The inpainting stage's image arithmetic around the diffusion pipeline, kept in HBM (csrc/pagetail.hip, include/mtx_hip.h mtx_tail_args).
+
+Reference (host, PIL / numpy / OpenCV): `core/image/inpainting.py:1258-1313` (`_prepare_image_for_inference`: LANCZOS to the inference
+size), `:1577-1665` (LANCZOS back, `_match_luminance`, composite), `:543-611, 877-968` (Kontext).  Here:
+
+    resize()           Pillow's 8-bit `Image.resize` — BILINEAR / BICUBIC / LANCZOS — bit for bit: the taps are built on the host exactly as
+                       Pillow's `precompute_coeffs` + `normalize_coeffs_8bpc` build them (float64, libm `sin`, truncating casts; cached per
+                       size), the two integer passes run on the device
+    match_luminance()  the reference's Lab luminance match: OpenCV's fixed-point RGB -> Lab on the device (exact), the context statistics
+                       from exact integer sums, the affine remap and the float Lab -> RGB on the device
+    composite()        patch * alpha + page * (1 - alpha) in fp32, truncated — bit-identical to `composite_u8`
+
+Everything is uint8 HWC torch tensors on the model's device; PyTorch is the allocator only.  There is no host fallback in here: callers
+that have no device tail use the host functions of `inpainting.py` (the reference's own arithmetic) as before."""
+import ctypes as C
+import math
+from functools import lru_cache
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from ...hip import abi
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _sinc(x: float) -> float:
+    if x == 0.0:
+        return 1.0
+    x = x * math.pi
+    return math.sin(x) / x
+
+
+def _lanczos(x: float) -> float:
+    return _sinc(x) * _sinc(x / 3) if -3.0 <= x < 3.0 else 0.0
+
+
+def _bilinear(x: float) -> float:
+    x = -x if x < 0.0 else x
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5
+    x = -x if x < 0.0 else x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+FILTERS = {"lanczos": (_lanczos, 3.0), "bilinear": (_bilinear, 1.0), "bicubic": (_bicubic, 2.0)}
+
+
+@lru_cache(maxsize=256)
+def pil_resample_tables(in_size: int, out_size: int, filter_name: str = "lanczos") -> Tuple[np.ndarray, np.ndarray, int]:
+    """(bounds int32 [out, 2] = (first source index, tap count), taps int32 [out, ksize], ksize) of one axis of
+    `Image.resize((.., out_size), filter)` over the whole axis (box = (0, in_size)) — Pillow's Resample.c `precompute_coeffs` and
+    `normalize_coeffs_8bpc`, statement by statement: float64 arithmetic, libm `sin` (math.sin, not numpy's vectorised one), C
+    truncation for the (int) casts, the taps' sum accumulated in index order"""
+    filt, fsupport = FILTERS[filter_name]
+    in0, in1 = 0.0, float(np.float32(in_size))
+    filterscale = scale = (in1 - in0) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = fsupport * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    taps = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    one = float(1 << PRECISION_BITS)
+    for xx in range(out_size):
+        center = in0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [filt((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        for x in range(xmax):
+            v = k[x] / ww if ww != 0.0 else k[x]
+            taps[xx, x] = int(-0.5 + v * one) if v < 0 else int(0.5 + v * one)
+        bounds[xx] = (xmin, xmax)
+    return bounds, taps, ksize
+
+
+class DeviceTail:
+    def __init__(self, lib, device):
+        from .color import _CBRT32, _COEF32, _GAMMA32
+        self.lib, self.device = lib, torch.device(device)
+        self._gamma = torch.from_numpy(_GAMMA32.astype(np.int32)).to(self.device)
+        self._cbrt = torch.from_numpy(_CBRT32.astype(np.int32)).to(self.device)
+        self._coef = torch.from_numpy(_COEF32.astype(np.int32).reshape(-1)).to(self.device)
+        self._tables = {}
+
+    # ---- plumbing ----------------------------------------------------------------------------------------------------------
+    def _stream(self):
+        if self.lib.is_simulator or self.device.type != "cuda":
+            return C.c_void_p(0)
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _run(self, a: abi.TailArgs):
+        self.lib.check(self.lib.mtx_page_tail(C.byref(a), self._stream()), "mtx_page_tail")
+
+    def _dev_tables(self, in_size, out_size, filt):
+        key = (in_size, out_size, filt)
+        if key not in self._tables:
+            b, t, k = pil_resample_tables(in_size, out_size, filt)
+            if len(self._tables) > 64:
+                self._tables.clear()
+            self._tables[key] = (torch.from_numpy(b).to(self.device), torch.from_numpy(t).to(self.device), k, int(b[0, 0]), int(b[-1, 0] + b[-1, 1]))
+        return self._tables[key]
+
+    @staticmethod
+    def _u8(img) -> torch.Tensor:
+        assert img.dtype == torch.uint8 and img.dim() == 3 and img.is_contiguous() and 1 <= img.shape[2] <= 4
+        return img
+
+    # ---- Pillow resize ---------------------------------------------------------------------------------------------------------
+    def resize(self, img: torch.Tensor, size: Tuple[int, int], resample: str = "lanczos") -> torch.Tensor:
+        """uint8 [H, W, C] on the device -> uint8 [h, w, C], `Image.fromarray(img).resize((w, h), resample)` bit for bit (whole-image box,
+        no reducing gap; RGB / L data — Pillow premultiplies alpha for RGBA, which the inpainting crops never are)"""
+        img = self._u8(img)
+        H, W, Cn = img.shape
+        w, h = int(size[0]), int(size[1])
+        if (w, h) == (W, H):
+            return img.clone()
+        cur, cur_h = img, H
+        row0 = 0
+        if w != W:                                                      # horizontal pass over the rows the vertical pass will read
+            bh, th, kh, _, _ = self._dev_tables(W, w, resample)
+            if h != H:
+                _, _, _, first, last = self._dev_tables(H, h, resample)
+            else:
+                first, last = 0, H
+            tmp = torch.empty((last - first, w, Cn), dtype=torch.uint8, device=self.device)
+            a = abi.TailArgs()
+            a.kind, a.src, a.dst = abi.TAIL_RESAMPLE, img.data_ptr(), tmp.data_ptr()
+            a.out_h, a.out_w, a.c, a.ld_src, a.ld_dst = last - first, w, Cn, W * Cn, w * Cn
+            a.bounds, a.coeff, a.ksize, a.axis, a.src_row0 = bh.data_ptr(), th.data_ptr(), kh, 0, first
+            self._run(a)
+            cur, cur_h, row0 = tmp, last - first, first
+        if h != H:
+            bv, tv, kv, first, _ = self._dev_tables(H, h, resample)
+            if row0:                                                    # the intermediate starts at source row `first`
+                bv = bv.clone()
+                bv[:, 0] -= row0
+            out = torch.empty((h, w, Cn), dtype=torch.uint8, device=self.device)
+            a = abi.TailArgs()
+            a.kind, a.src, a.dst = abi.TAIL_RESAMPLE, cur.data_ptr(), out.data_ptr()
+            a.out_h, a.out_w, a.c, a.ld_src, a.ld_dst = h, w, Cn, w * Cn, w * Cn
+            a.bounds, a.coeff, a.ksize, a.axis, a.src_row0 = bv.data_ptr(), tv.data_ptr(), kv, 1, 0
+            self._keep = (cur, bv)
+            self._run(a)
+            cur = out
+        return cur
+
+    # ---- alpha composite -------------------------------------------------------------------------------------------------------
+    def composite(self, page: torch.Tensor, patch: torch.Tensor, alpha: torch.Tensor, x: int, y: int) -> torch.Tensor:
+        """IN PLACE on `page` (uint8 [H, W, Cp]): window at (x, y) = patch * alpha + page * (1 - alpha), like `composite_u8`"""
+        page, patch = self._u8(page), self._u8(patch)
+        assert alpha.dtype == torch.float32 and alpha.is_contiguous() and tuple(alpha.shape) == tuple(patch.shape[:2])
+        h, w = patch.shape[:2]
+        h, w = max(0, min(h, page.shape[0] - y)), max(0, min(w, page.shape[1] - x))
+        if h == 0 or w == 0:
+            return page
+        a = abi.TailArgs()
+        a.kind, a.src, a.dst = abi.TAIL_COMPOSITE, patch.data_ptr(), page.data_ptr()
+        a.out_h, a.out_w, a.c, a.ld_src, a.ld_dst = h, w, min(patch.shape[2], page.shape[2]), patch.shape[1] * patch.shape[2], page.shape[1] * page.shape[2]
+        a.alpha, a.ld_alpha, a.x, a.y, a.page_c = alpha.data_ptr(), alpha.shape[1], x, y, page.shape[2]
+        self._run(a)
+        return page
+
+    # ---- Lab luminance match (reference inpainting.py:1165-1256) ------------------------------------------------------------------
+    def _lab_args(self, kind, src, mask):
+        a = abi.TailArgs()
+        a.kind, a.src = kind, src.data_ptr()
+        a.out_h, a.out_w, a.c, a.ld_src = src.shape[0], src.shape[1], 3, src.shape[1] * 3
+        a.gamma_tab, a.cbrt_tab, a.lab_coef, a.cbrt_n = self._gamma.data_ptr(), self._cbrt.data_ptr(), self._coef.data_ptr(), int(self._cbrt.numel())
+        a.mask, a.ld_mask = mask.data_ptr(), mask.shape[1]
+        return a
+
+    def match_luminance(self, patch: torch.Tensor, crop: torch.Tensor, mask: torch.Tensor, log=None) -> torch.Tensor:
+        """`FluxKleinInpainter._match_luminance` on device tensors (patch, crop uint8 [h, w, 3]; mask uint8 [h, w], non-zero = masked).
+        The context statistics come from exact integer sums over the fixed-point Lab values; the decision and the remap constants are
+        computed on the host from them in float64 -> float32 (the reference takes float32 means / stds of the same integers: equal up to
+        summation order, i.e. ~1e-7 relative)."""
+        patch, crop = self._u8(patch), self._u8(crop)
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and tuple(mask.shape) == tuple(patch.shape[:2]) == tuple(crop.shape[:2])
+        n_px = patch.shape[0] * patch.shape[1]
+        sums = torch.zeros(9, dtype=torch.int64, device=self.device)
+        a = self._lab_args(abi.TAIL_LAB_STATS, patch, mask)
+        a.dst = patch.data_ptr()                                        # unused by the kernel, must not be null
+        a.other, a.ld_other, a.sums = crop.data_ptr(), crop.shape[1] * 3, sums.data_ptr()
+        self._run(a)
+        s = [int(v) for v in sums.cpu().tolist()]
+        n = s[0]
+        if n == 0 or n == n_px:                                         # no context or no mask
+            return patch
+
+        def mean_std(sl, sl2):
+            m = sl / n
+            return np.float32(m), np.float32(math.sqrt(max(sl2 / n - m * m, 0.0))) + np.float32(1e-6)
+        g_mean, g_std = mean_std(s[1], s[2])
+        o_mean, o_std = mean_std(s[5], s[6])
+        if abs(float(o_mean) - float(g_mean)) < 1.3 and abs(float(o_std) - float(g_std)) < 2.0:
+            return patch
+        gain = max(0.5, min(2.0, float(o_std) / float(g_std)))
+        if log is not None:
+            log(f"  - Luminance correction: mean {float(g_mean):.1f}->{float(o_mean):.1f}, std {float(g_std):.1f}->{float(o_std):.1f} (scale={gain:.2f})")
+        shift_a = float(np.float32(s[7] / n)) - float(np.float32(s[3] / n))
+        shift_b = float(np.float32(s[8] / n)) - float(np.float32(s[4] / n))
+        params = torch.tensor([float(g_mean), gain, float(o_mean), shift_a, shift_b, float(abs(shift_a) > 1.0), float(abs(shift_b) > 1.0), 0.0],
+                              dtype=torch.float32).to(self.device)
+        out = torch.empty_like(patch)
+        a = self._lab_args(abi.TAIL_LAB_REMAP, patch, mask)
+        a.dst, a.ld_dst, a.params = out.data_ptr(), out.shape[1] * 3, params.data_ptr()
+        self._keep = (params, sums)
+        self._run(a)
+        return out

@@ -248,6 +248,31 @@ class FluxKontextInpainter:
         if patch is not None:
             log_message("  - Using cached inpainting patch", verbose=verbose)
             return Image.fromarray(composite_u8(np.asarray(image_pil), np.asarray(patch), alpha, x, y))
+        tail = self._device_tail()
+        if tail is not None:
+            # LANCZOS to the preferred Kontext resolution, the pipeline, LANCZOS back and the composite without leaving HBM
+            # (core/image/device_tail.py: Pillow's resize and the composite bit for bit)
+            dev = tail.device
+            crop_dev = torch.from_numpy(np.array(crop if crop.mode == "RGB" else crop.convert("RGB"))).to(dev)
+            inf_w, inf_h = nearest_preferred_resolution(w, h, self.PREFERED_KONTEXT_RESOLUTIONS) if w and h else (w, h)
+            scaled = tail.resize(crop_dev, (inf_w, inf_h), "lanczos")
+            with self.manager.flux_inference_lock:
+                with torch.inference_mode():
+                    gen = torch.Generator(device="cpu").manual_seed(seed)
+                    out = self.pipeline(image=scaled, width=inf_w, height=inf_h, num_inference_steps=self.num_inference_steps,
+                                        guidance_scale=self.guidance_scale, generator=gen, output_type="pt",
+                                        max_area=inf_w * inf_h, **self._prompt_kwargs())
+                    img = torch.nan_to_num(out.images[0].float(), nan=0.0, posinf=1.0, neginf=0.0).clamp_(0, 1)
+                    patch_dev = img.mul(255).round().to(torch.uint8).permute(1, 2, 0).contiguous()
+            patch_dev = tail.resize(patch_dev, (w, h), "lanczos")
+            if key is not None:
+                self.cache.set_inpainted_image(key, Image.fromarray(patch_dev.cpu().numpy()))
+            page = torch.from_numpy(np.array(image_pil)).to(dev)          # a copy: the composite is in place
+            if page.dim() == 2:
+                page = page[..., None]
+            tail.composite(page.contiguous(), patch_dev, torch.from_numpy(np.ascontiguousarray(alpha, dtype=np.float32)).to(dev), x, y)
+            out_np = page.cpu().numpy()
+            return Image.fromarray(out_np[..., 0] if out_np.shape[2] == 1 else out_np, image_pil.mode)
         scaled = self.flux_kontext_image_scale(crop)
         inf_w, inf_h = scaled.size
         if scaled.mode == "RGBA":
@@ -271,6 +296,24 @@ class FluxKontextInpainter:
             self.cache.set_inpainted_image(key, patch)
         page = np.asarray(image_pil)
         return Image.fromarray(composite_u8(page, np.asarray(patch), alpha, x, y))
+
+    device_tail = True          # False: the host path (PIL / numpy), the reference's own arithmetic
+
+    def _device_tail(self):
+        """the DeviceTail of the pipeline's device, or None (host path): needs a loaded pipeline made of libmtx_hip graphs"""
+        if not self.device_tail:
+            return None
+        t = getattr(self, "_tail", None)
+        if t is not None:
+            return t
+        self.load_models()
+        pipe = self.pipeline
+        lib = getattr(getattr(pipe, "transformer", None), "lib", None)
+        if pipe is None or lib is None or not hasattr(pipe, "device"):
+            return None
+        from .device_tail import DeviceTail
+        self._tail = DeviceTail(lib, pipe.device)
+        return self._tail
 
     def _memo_key(self, crop, mask_crop, seed, bbox, padding, blur, ocr_params, strict_mask_clipping, composite_clip_bbox):
         """Key of the crop-sized patch in the stage memo (reference :781-827): crop pixels, a <= 64x64 bilinear signature of the mask
@@ -536,6 +579,16 @@ class FluxKleinInpainter:
                 keep[ay0:ay1, ax0:ax1] = alpha[ay0:ay1, ax0:ax1]
             alpha = keep
         generated_now = patch is None
+        tail = self._device_tail() if patch is None else None
+        if tail is not None:
+            # the whole chain around the pipeline stays in HBM (core/image/device_tail.py): LANCZOS to the inference size, the pipeline,
+            # LANCZOS back, the luminance match and the composite — Pillow's resize and the composite bit for bit, the Lab leg within a level
+            result, patch = self._inpaint_on_device(tail, image_pil, crop, mask_crop, alpha, x, y, w, h, seed, verbose)
+            if result is None:
+                return image_pil
+            if key is not None:
+                self.cache.set_inpainted_image(key, patch)
+            return result
         if patch is None:
             scaled, _, _ = self._prepare_image_for_inference(crop, verbose=verbose)
             inf_w, inf_h = scaled.size
@@ -565,6 +618,58 @@ class FluxKleinInpainter:
         if generated_now and key is not None:
             self.cache.set_inpainted_image(key, patch)
         return result
+
+    # ---- the same operator with the image arithmetic on the device ------------------------------------------------------------
+    device_tail = True          # False: the host path (PIL / numpy), the reference's own arithmetic
+
+    def _device_tail(self):
+        """the DeviceTail of this inpainter's device, or None (host path): needs a pipeline that lives on a GPU (or the test simulator)
+        and takes / returns device tensors, and an RGB crop"""
+        if not self.device_tail:
+            return None
+        t = getattr(self, "_tail", None)
+        if t is not None:
+            return t
+        self.load_models()
+        pipe = self.pipeline
+        lib = getattr(getattr(pipe, "transformer", None), "lib", None)
+        if pipe is None or lib is None or not hasattr(pipe, "device"):
+            return None
+        from .device_tail import DeviceTail
+        self._tail = DeviceTail(lib, pipe.device)
+        return self._tail
+
+    def _inpaint_on_device(self, tail, image_pil, crop, mask_crop, alpha, x, y, w, h, seed, verbose):
+        dev = tail.device
+        crop_rgb = crop if crop.mode == "RGB" else crop.convert("RGB")
+        crop_dev = torch.from_numpy(np.array(crop_rgb)).to(dev)
+        inf_w, inf_h = self._inference_size(w, h)
+        if (inf_w, inf_h) != (w, h):
+            log_message(f"  - Scaling {w}x{h} -> {inf_w}x{inf_h}", verbose=verbose)
+        scaled = tail.resize(crop_dev, (inf_w, inf_h), "lanczos")
+        log_message("  - Running inference...", verbose=verbose)
+        with self.manager.flux_inference_lock:
+            self.load_models()
+            if self.pipeline is None:
+                log_message(f"Warning: Flux Klein {self.variant.upper()} pipeline unavailable.", always_print=True)
+                return None, None
+            with torch.inference_mode():
+                gen = torch.Generator(device="cpu").manual_seed(seed)
+                out = self.pipeline(**self._prompt_kwargs(), image=scaled, height=inf_h, width=inf_w, guidance_scale=self.KLEIN_GUIDANCE_SCALE,
+                                    num_inference_steps=self.num_inference_steps, generator=gen, output_type="pt").images[0]
+                patch = out.mul(255).round().to(torch.uint8).permute(1, 2, 0).contiguous()       # what the "pil" output type holds
+        if (inf_w, inf_h) != (w, h):
+            patch = tail.resize(patch, (w, h), "lanczos")
+        if self.luminance_correction:
+            patch = tail.match_luminance(patch, crop_dev, torch.from_numpy(np.ascontiguousarray(mask_crop, dtype=np.uint8)).to(dev),
+                                         log=lambda m: log_message(m, verbose=verbose))
+        page = torch.from_numpy(np.array(image_pil)).to(dev)          # a copy: the composite is in place
+        if page.dim() == 2:
+            page = page[..., None]
+        tail.composite(page.contiguous(), patch, torch.from_numpy(np.ascontiguousarray(alpha, dtype=np.float32)).to(dev), x, y)
+        out_np = page.cpu().numpy()
+        result = Image.fromarray(out_np[..., 0] if out_np.shape[2] == 1 else out_np, image_pil.mode)
+        return result, Image.fromarray(patch.cpu().numpy())
 
     def _memo_key(self, crop, mask_crop, seed, bbox, padding, blur, ocr_params, strict_mask_clipping, composite_clip_bbox):
         """stage-memo key of the crop-sized patch (reference :1433-1489); None when seed == -1"""

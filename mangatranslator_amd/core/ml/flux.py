@@ -424,8 +424,12 @@ class FluxKontextHip:
             prompt_embeds, pooled_prompt_embeds, _ = self.encode_prompt()
         pe = prompt_embeds.reshape(-1, prompt_embeds.shape[-1])
         pooled = pooled_prompt_embeds.reshape(-1)
-        img = np.asarray(image.convert("RGB").resize((width, height))) if hasattr(image, "convert") else np.asarray(image)
-        H, W = img.shape[:2]
+        img_dev = image if torch.is_tensor(image) and image.dtype == torch.uint8 and image.dim() == 3 else None      # already on the device, already at size
+        if img_dev is not None:
+            img = img_dev
+        else:
+            img = np.asarray(image.convert("RGB").resize((width, height))) if hasattr(image, "convert") else np.asarray(image)
+        H, W = int(img.shape[0]), int(img.shape[1])
         if H % 16 or W % 16:
             raise ModelError(f"FLUX Kontext needs H, W multiples of 16, got {W}x{H}")
         h8, w8, h2, w2 = H // 8, W // 8, H // 16, W // 16
@@ -433,7 +437,7 @@ class FluxKontextHip:
         vc = vae.cfg
         with self._lock:
             enc = vae.encoder_plan(H, W)
-            enc.src.copy_(torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device).view(1, H, W, 3))
+            enc.src.copy_((img_dev if img_dev is not None else torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device)).reshape(1, H, W, 3))
             enc.run(graph=self._graph)
             mean = enc.moments.t[0, :, :, :16].float().permute(2, 0, 1)[None]
             ref = (mean - vc["shift_factor"]) * vc["scaling_factor"]

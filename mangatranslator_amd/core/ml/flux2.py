@@ -396,7 +396,12 @@ class Flux2KleinHip:
         if prompt_embeds is None:
             prompt_embeds, _ = self.encode_prompt()
         pe = prompt_embeds.reshape(-1, prompt_embeds.shape[-1])
-        ref = self._reference_image(image)
+        ref_dev = None
+        if torch.is_tensor(image) and image.dtype == torch.uint8 and image.dim() == 3 and image.shape[0] % 16 == 0 and image.shape[1] % 16 == 0 \
+                and image.shape[0] * image.shape[1] <= 1024 * 1024:
+            ref_dev, ref = image, image            # a conditioning image that is already on the device and needs none of the host-side fitting
+        else:
+            ref = self._reference_image(image.cpu().numpy() if torch.is_tensor(image) else image)
         RH, RW = ref.shape[:2]
         H = int(height) if height is not None else RH
         W = int(width) if width is not None else RW
@@ -408,7 +413,7 @@ class Flux2KleinHip:
         L = C // 4
         with self._lock:
             enc = vae.encoder_plan(RH, RW)
-            enc.src.copy_(torch.from_numpy(ref.copy()).to(self.device).view(1, RH, RW, 3))
+            enc.src.copy_((ref_dev if ref_dev is not None else torch.from_numpy(ref.copy()).to(self.device)).reshape(1, RH, RW, 3))
             enc.run(graph=self._graph)
             mean = enc.moments.t[0, :, :, :L].float()                                          # [RH/8, RW/8, L]
             tok = mean.view(rh2, 2, rw2, 2, L).permute(0, 2, 4, 1, 3).reshape(rh2 * rw2, C)    # channel = c*4 + dy*2 + dx

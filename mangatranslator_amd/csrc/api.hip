@@ -28,6 +28,7 @@ int yolo_decode_launch(const mtx_yolo_decode_args*, void*, const char**);
 int clean_launch(const mtx_clean_args*, void*, const char**);
 int detr_launch(const mtx_detr_args*, void*, const char**);
 int quant_launch(const mtx_quant_args*, void*, const char**);
+int tail_launch(const mtx_tail_args*, void*, const char**);
 
 static thread_local std::string g_err;
 
@@ -73,6 +74,7 @@ static int run_op(const mtx_op& op, void* stream) {
     case MTX_OP_YOLO_DECODE: rc = yolo_decode_launch(&op.u.yd, stream, &err); break;
     case MTX_OP_DETR: rc = detr_launch(&op.u.detr, stream, &err); break;
     case MTX_OP_QUANT: rc = quant_launch(&op.u.quant, stream, &err); break;
+    case MTX_OP_TAIL: rc = tail_launch(&op.u.tail, stream, &err); break;
     case MTX_OP_MEMSET:
       if (hipMemsetAsync(op.u.ms.ptr, op.u.ms.value, (size_t)op.u.ms.bytes, (hipStream_t)stream) != hipSuccess) { rc = MTX_ERR_HIP; err = "memset failed"; }
       else rc = MTX_OK;
@@ -167,6 +169,7 @@ size_t mtx_abi_sizeof(int kind) {
     case MTX_OP_YOLO_DECODE: return sizeof(mtx_yolo_decode_args);
     case MTX_OP_DETR: return sizeof(mtx_detr_args);
     case MTX_OP_QUANT: return sizeof(mtx_quant_args);
+    case MTX_OP_TAIL: return sizeof(mtx_tail_args);
     case 100: return sizeof(mtx_clean_args);       /* op-level only (not a plan op) */
     default: return 0;
   }
@@ -229,6 +232,7 @@ MTX_OP_ENTRY(mtx_yolo_decode, mtx_yolo_decode_args, yolo_decode_launch)
 MTX_OP_ENTRY(mtx_bubble_clean, mtx_clean_args, clean_launch)
 MTX_OP_ENTRY(mtx_detr, mtx_detr_args, detr_launch)
 MTX_OP_ENTRY(mtx_quantize_mx, mtx_quant_args, quant_launch)
+MTX_OP_ENTRY(mtx_page_tail, mtx_tail_args, tail_launch)
 
 int mtx_conv2d_tiles(const mtx_conv2d_args* a) {
   if (!a) return fail(MTX_ERR_INVALID, "mtx_conv2d_tiles: null args");

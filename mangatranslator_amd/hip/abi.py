@@ -11,7 +11,7 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_SIGMOID, ACT_LEAKY = 
  EW_ROW_GATHER, EW_IM2COL, EW_SOFTMAX_ROWS, EW_TRANSPOSE, EW_QK_NORM_ROPE, EW_AVGPOOL2, EW_SWIGLU, EW_DWCONV) = range(16)
 IMG_NCHW_F32_TO_NHWC, IMG_NHWC_TO_NCHW_F32, IMG_NHWC_TO_HWC_U8, IMG_HWC_U8_TO_NHWC = range(4)
 (OP_CONV2D, OP_GEMM, OP_ATTN, OP_NORM, OP_GROUPNORM, OP_EW, OP_CA, OP_IMG, OP_RESIZE_THRESH,
- OP_MEMSET, OP_MASK_SELECT, OP_PREPROC, OP_YOLO_DECODE, OP_DETR, OP_QUANT) = range(1, 16)
+ OP_MEMSET, OP_MASK_SELECT, OP_PREPROC, OP_YOLO_DECODE, OP_DETR, OP_QUANT, OP_TAIL) = range(1, 17)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -141,6 +141,17 @@ class QuantArgs(C.Structure):
 QUANT_PLAIN, QUANT_SWIGLU = 0, 1
 
 
+class TailArgs(C.Structure):
+    _fields_ = [("kind", i32), ("src", vp), ("dst", vp), ("out_h", i32), ("out_w", i32), ("c", i32), ("ld_src", i64), ("ld_dst", i64),
+                ("bounds", vp), ("coeff", vp), ("ksize", i32), ("axis", i32), ("src_row0", i32),
+                ("alpha", vp), ("ld_alpha", i64), ("x", i32), ("y", i32), ("page_c", i32),
+                ("gamma_tab", vp), ("cbrt_tab", vp), ("lab_coef", vp), ("cbrt_n", i32),
+                ("mask", vp), ("ld_mask", i64), ("other", vp), ("ld_other", i64), ("sums", vp), ("params", vp)]
+
+
+TAIL_RESAMPLE, TAIL_COMPOSITE, TAIL_LAB_STATS, TAIL_LAB_REMAP = 0, 1, 2, 3
+
+
 class CleanArgs(C.Structure):
     _fields_ = [("page_bgr", vp), ("masks", vp), ("rois", vp), ("offsets", vp),
                 ("base", vp), ("roi", vp), ("eroded", vp), ("thresholded", vp), ("shrunk", vp),
@@ -157,7 +168,7 @@ CLEAN_ARGS_KIND = 100      # mtx_abi_sizeof() key of the op-level-only struct
 class _OpUnion(C.Union):
     _fields_ = [("conv", ConvArgs), ("gemm", GemmArgs), ("attn", AttnArgs), ("norm", NormArgs),
                 ("gn", GroupNormArgs), ("ew", EwArgs), ("ca", CaArgs), ("img", ImgArgs),
-                ("rt", ResizeThreshArgs), ("ms", MemsetArgs), ("sel", MaskSelectArgs), ("pre", PreprocArgs), ("yd", YoloDecodeArgs), ("detr", DetrArgs), ("quant", QuantArgs)]
+                ("rt", ResizeThreshArgs), ("ms", MemsetArgs), ("sel", MaskSelectArgs), ("pre", PreprocArgs), ("yd", YoloDecodeArgs), ("detr", DetrArgs), ("quant", QuantArgs), ("tail", TailArgs)]
 
 
 LANE_SIDE, LANE_JOIN = 1, 2
@@ -170,17 +181,17 @@ class Op(C.Structure):
 ARG_TYPES = {OP_CONV2D: ConvArgs, OP_GEMM: GemmArgs, OP_ATTN: AttnArgs, OP_NORM: NormArgs,
              OP_GROUPNORM: GroupNormArgs, OP_EW: EwArgs, OP_CA: CaArgs, OP_IMG: ImgArgs,
              OP_RESIZE_THRESH: ResizeThreshArgs, OP_MEMSET: MemsetArgs,
-             OP_MASK_SELECT: MaskSelectArgs, OP_PREPROC: PreprocArgs, OP_YOLO_DECODE: YoloDecodeArgs, OP_DETR: DetrArgs, OP_QUANT: QuantArgs}
+             OP_MASK_SELECT: MaskSelectArgs, OP_PREPROC: PreprocArgs, OP_YOLO_DECODE: YoloDecodeArgs, OP_DETR: DetrArgs, OP_QUANT: QuantArgs, OP_TAIL: TailArgs}
 UNION_FIELD = {OP_CONV2D: "conv", OP_GEMM: "gemm", OP_ATTN: "attn", OP_NORM: "norm",
                OP_GROUPNORM: "gn", OP_EW: "ew", OP_CA: "ca", OP_IMG: "img",
-               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms", OP_MASK_SELECT: "sel", OP_PREPROC: "pre", OP_YOLO_DECODE: "yd", OP_DETR: "detr", OP_QUANT: "quant"}
+               OP_RESIZE_THRESH: "rt", OP_MEMSET: "ms", OP_MASK_SELECT: "sel", OP_PREPROC: "pre", OP_YOLO_DECODE: "yd", OP_DETR: "detr", OP_QUANT: "quant", OP_TAIL: "tail"}
 
 # every symbol include/mtx_hip.h declares (tests check the built library exports all of them)
 EXPORTS = [
     "mtx_abi_version", "mtx_abi_sizeof", "mtx_last_error", "mtx_init", "mtx_device_info",
     "mtx_conv2d", "mtx_conv2d_tiles", "mtx_gemm", "mtx_attention", "mtx_norm", "mtx_groupnorm",
     "mtx_elementwise", "mtx_channel_attention", "mtx_image_convert", "mtx_resize_threshold",
-    "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode", "mtx_detr", "mtx_quantize_mx", "mtx_bubble_clean", "mtx_host_text_mask", "mtx_host_chamfer_l2_5x5", "mtx_host_mask_outline",
+    "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode", "mtx_detr", "mtx_quantize_mx", "mtx_page_tail", "mtx_bubble_clean", "mtx_host_text_mask", "mtx_host_chamfer_l2_5x5", "mtx_host_mask_outline",
     "mtx_plan_create", "mtx_plan_run", "mtx_plan_run_graph", "mtx_plan_num_ops",
     "mtx_plan_run_range", "mtx_plan_destroy", "mtx_plan_time", "mtx_plan_time_range", "mtx_plan_time_ops",
 ]

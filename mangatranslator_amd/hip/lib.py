@@ -47,7 +47,7 @@ class MtxLibrary:
                         ("mtx_resize_threshold", abi.ResizeThreshArgs),
                         ("mtx_mask_select", abi.MaskSelectArgs), ("mtx_preprocess", abi.PreprocArgs),
                         ("mtx_yolo_decode", abi.YoloDecodeArgs), ("mtx_bubble_clean", abi.CleanArgs), ("mtx_detr", abi.DetrArgs),
-                        ("mtx_quantize_mx", abi.QuantArgs)):
+                        ("mtx_quantize_mx", abi.QuantArgs), ("mtx_page_tail", abi.TailArgs)):
             getattr(d, name).argtypes = [C.POINTER(t), C.c_void_p]
         d.mtx_host_text_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_double, C.c_void_p, C.POINTER(C.c_int)]

@@ -307,6 +307,7 @@ inline float atomicAdd(float* p, float v) {
   return old;
 }
 inline int atomicAdd(int* p, int v) { return reinterpret_cast<std::atomic<int>*>(p)->fetch_add(v); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return reinterpret_cast<std::atomic<unsigned long long>*>(p)->fetch_add(v); }
 
 #define MTX_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
