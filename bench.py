@@ -71,6 +71,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-traffic", action="store_true",
+                    help="fill roofline.traffic: re-run THIS command (same configuration, one page) twice under `rocprofv3 --pmc FETCH_SIZE` / "
+                         "`--pmc WRITE_SIZE` with --kernel-trace (separate passes, counters only) and average the dominant kernel group's bytes per "
+                         "launch — fabric-side bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  Adds two model set-ups to the run.")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--batch-io", type=int, default=0,
                     help="after the timed region: N pages through `batch_process_images` WITH image I/O — PNG files decoded from disk, uploaded, "
                          "run through the same stages, results downloaded, PNG-encoded and written (SURVEY.md §8d: decode / encode reported "
@@ -721,11 +726,66 @@ def main():
             else:
                 result["roofline"] = conv_roof
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is a single-GPU-run item (rank 0 at N = 1 only)
+            if args.with_traffic and not args.traffic_child and "roofline" in result:
+                result["roofline"]["traffic"], result["roofline"]["traffic_detail"] = measure_traffic(result["roofline"]["kernel"])
             result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"), flux.transformer.cfg if (klein and flux is not None) else None)
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_traffic(kernel_desc: str):
+    """HBM-side bytes per launch of the dominant kernel group, from counter passes over this very bench command (one page, nothing else
+    changed): `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and a second pass with WRITE_SIZE (they do not fit one pass on gfx950; counters
+    only, never combined with sys / hip trace domains).  FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE counts 128-byte requests at 64 B
+    on gfx950 and is doubled (MI355X_MICROARCH.md, HBM).  Infinity-Cache hits are counted, so this is fabric-side traffic."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    want = "attn_mma32" if kernel_desc.startswith("attn") else ("conv3x3_c64" if kernel_desc.startswith("conv") else "gemm256")
+    base = [a_ for a_ in sys.argv[1:] if a_ not in ("--with-traffic",)]
+    for flag in ("--steps", "--warmup"):
+        if flag in base:
+            i_ = base.index(flag)
+            del base[i_:i_ + 2]
+    child = [sys.executable, str(Path(__file__).resolve())] + base + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-overlap", "--traffic-child"]
+    per = {}
+    detail = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py " + " ".join(child[2:]), "kernels": {}}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="mtx_pmc_")
+        try:
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=1500)
+            files = glob.glob(tmp + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"error": f"{counter} pass failed (rc {r.returncode}): {r.stderr[-300:]}"}
+            tot, n = {}, {}
+            for fn in files:
+                for row in csv.DictReader(open(fn)):
+                    if row["Counter_Name"] == counter and want in row["Kernel_Name"]:
+                        k_ = row["Kernel_Name"][:90]
+                        tot[k_] = tot.get(k_, 0.0) + float(row["Counter_Value"]); n[k_] = n.get(k_, 0) + 1
+            per[counter] = (tot, n)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    rd_t, rd_n = per["FETCH_SIZE"]
+    wr_t, wr_n = per["WRITE_SIZE"]
+    launches = sum(rd_n.values())
+    if launches == 0:
+        return None, {"error": f"no '{want}' dispatches in the counter pass"}
+    rd = 2.0 * 1024.0 * sum(rd_t.values()) / launches
+    wr = 1024.0 * sum(wr_t.values()) / max(1, sum(wr_n.values()))
+    for k_ in rd_t:
+        detail["kernels"][k_] = {"launches": rd_n[k_], "read_bytes_per_launch": round(2.0 * 1024.0 * rd_t[k_] / rd_n[k_]),
+                                 "write_bytes_per_launch": round(1024.0 * wr_t.get(k_, 0.0) / max(1, wr_n.get(k_, 1)))}
+    detail.update(launches=launches, read_bytes_per_launch=round(rd), write_bytes_per_launch=round(wr),
+                  note="fabric-side bytes (Infinity-Cache hits counted), mean over every launch of the group in one page")
+    return rd + wr, detail
 
 
 def in_context_ms(plan, idx, iters, mode, replay_ms=None):

@@ -85,12 +85,13 @@ class StandInPipeline:
         a = image if torch.is_tensor(image) else torch.from_numpy(np.asarray(image.convert("RGB")).copy())
         assert tuple(a.shape[:2]) == (height, width)
         self.calls.append((output_type, tuple(a.shape)))
-        noise = torch.rand(a.shape, generator=generator) * 4.0
-        f = (a.flip(1).float() * 0.55 + 30.0 + noise.to(a.device)).clamp(0, 255) / 255.0
-        f = f.permute(2, 0, 1).contiguous()
+        # integer arithmetic only: the SAME bytes whether the image came in on the host or on the device (float ops differ in the last bit
+        # between the two, which a LANCZOS pass and a Lab round trip then turn into a level or two)
+        noise = torch.randint(0, 5, a.shape, generator=generator, dtype=torch.int32).to(a.device)
+        u8 = ((a.flip(1).to(torch.int32) * 141 >> 8) + 30 + noise).clamp(0, 255).to(torch.uint8)
         if output_type == "pt":
-            return types.SimpleNamespace(images=[f])
-        return types.SimpleNamespace(images=[Image.fromarray(f.mul(255).round().to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy())])
+            return types.SimpleNamespace(images=[(u8.float() / 255.0).permute(2, 0, 1).contiguous()])      # x / 255 * 255 rounds back to x
+        return types.SimpleNamespace(images=[Image.fromarray(u8.cpu().numpy())])
 
 
 def check_klein_operator(lib, page_hw=(300, 400), mask_box=(120, 150, 200, 260), page_mode="RGB"):
