@@ -725,9 +725,9 @@ def main():
                 result["roofline_upscale_conv"] = conv_roof
             else:
                 result["roofline"] = conv_roof
+        if args.with_traffic and not args.traffic_child and world == 1 and "roofline" in result:
+            result["roofline"]["traffic"], result["roofline"]["traffic_detail"] = measure_traffic(result["roofline"]["kernel"])
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is a single-GPU-run item (rank 0 at N = 1 only)
-            if args.with_traffic and not args.traffic_child and "roofline" in result:
-                result["roofline"]["traffic"], result["roofline"]["traffic_detail"] = measure_traffic(result["roofline"]["kernel"])
             result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"), flux.transformer.cfg if (klein and flux is not None) else None)
         print(json.dumps(result))
     if dist is not None:
@@ -749,18 +749,30 @@ def measure_traffic(kernel_desc: str):
         return None, {"error": "rocprofv3 not on PATH"}
     want = "attn_mma32" if kernel_desc.startswith("attn") else ("conv3x3_c64" if kernel_desc.startswith("conv") else "gemm256")
     base = [a_ for a_ in sys.argv[1:] if a_ not in ("--with-traffic",)]
-    for flag in ("--steps", "--warmup"):
+    for flag in ("--steps", "--warmup", "--stages", "--inpaint-steps", "--batch-io"):
         if flag in base:
             i_ = base.index(flag)
             del base[i_:i_ + 2]
-    child = [sys.executable, str(Path(__file__).resolve())] + base + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-overlap", "--traffic-child"]
+    # only the stage that owns the kernel, and ONE denoising step: every launch of a group moves the same bytes, and a counter pass costs
+    # tens of milliseconds per dispatch (a whole 20-step page under --pmc ran past 25 minutes, r03)
+    base += ["--stages", "upscale"] if want == "conv3x3_c64" else ["--stages", "inpaint", "--inpaint-steps", "1"]
+    child = [sys.executable, str(Path(__file__).resolve())] + base + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-overlap", "--no-graph", "--traffic-child"]          # eager launches: rocprofv3's counter mode segfaulted on hipGraph replays (r03); the kernels and their arguments are the same
     per = {}
+    import types as types_
     detail = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py " + " ".join(child[2:]), "kernels": {}}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="mtx_pmc_")
         try:
-            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--"] + child,
-                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=1500)
+            import signal
+            proc = subprocess.Popen(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--"] + child,
+                                    cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                _, err_ = proc.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)          # the profiler AND the bench process under it (its own process group)
+                proc.communicate()
+                return None, {"error": f"{counter} pass did not finish in 300 s"}
+            r = types_.SimpleNamespace(returncode=proc.returncode, stderr=err_)
             files = glob.glob(tmp + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
                 return None, {"error": f"{counter} pass failed (rc {r.returncode}): {r.stderr[-300:]}"}

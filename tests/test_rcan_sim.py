@@ -39,7 +39,7 @@ def test_rcan_plan_cache_is_bounded(emu_lib):
     assert len(m._buckets) == 1 and len(m._plans) == 0                             # one 64 x 64 canvas served all six sizes
     u8 = m.upscale_u8(torch.zeros(7, 9, 3, dtype=torch.uint8))
     assert tuple(u8.shape) == (14, 18, 3)
-    m.BUCKET_MAX = 0                                                               # exact-size plans (what pages use): bounded LRU
+    m.BUCKET_MAX = m.BIG_BUCKET_MAX = 0                                            # exact-size plans (what pages use): bounded LRU
     m._plans.capacity = 3
     first = None
     for (h, w) in [(8, 8), (10, 8), (10, 12), (12, 10), (14, 8), (8, 8)]:
