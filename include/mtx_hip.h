@@ -427,6 +427,13 @@ MTX_API int mtx_host_text_mask(const uint8_t* thr, const uint8_t* eroded, int w,
  * mask).  Writes up to `cap` (x, y) pairs, returns the outline's point count (call again if it exceeds cap), 0 for an empty mask. */
 MTX_API int mtx_host_mask_outline(const uint8_t* mask, int w, int h, int* xy, int cap);
 
+/* host side: PNG writer of the batch harness (csrc/host_png.cpp; replaces Pillow + oxipng of reference core/image/image_utils.py:140-150):
+ * uint8 [h][w][channels] (1 = L, 2 = LA, 3 = RGB, 4 = RGBA) -> a PNG file image in `out`.  reduce != 0: lossless colour-type reductions
+ * (opaque alpha dropped, R == G == B -> grey), as oxipng does.  level 0..9 = zlib level, `threads` stripes deflated concurrently.
+ * Returns the file's length (call again with a larger buffer when it exceeds out_cap; out may be NULL to ask), < 0 on error. */
+MTX_API int64_t mtx_host_png_encode(const uint8_t* pixels, int w, int h, int channels, int level, int threads, int reduce,
+                                    uint8_t* out, int64_t out_cap);
+
 /* ---- plans: a network forward as one native call ----------------------------------------- */
 MTX_API int mtx_plan_create(const mtx_op* ops, int n_ops, void** plan);
 MTX_API int mtx_plan_run(void* plan, void* stream);            /* eager launch of every op, in order */

@@ -54,10 +54,12 @@ def save_image_with_compression(image: Image.Image, output_path, jpeg_quality: i
                 pass
             except Exception as e:                                   # oxipng.PngError
                 log_message(f"oxipng optimization failed: {e}. Falling back to Pillow save.", always_print=True)
+            if data is None:
+                data = _native_png(image, level)
             if data is not None:
                 with open(output_path, "wb") as f:
                     f.write(data)
-            else:
+            else:                                                    # neither optimiser: the reference's own Pillow fallback
                 image.save(str(output_path), format="PNG", compress_level=level, optimize=True)
         else:
             image.save(str(output_path), format=fmt, **opts)
@@ -65,6 +67,36 @@ def save_image_with_compression(image: Image.Image, output_path, jpeg_quality: i
     except Exception as e:
         log_message(f"Error saving image to {output_path}: {e}", always_print=True)
         raise ImageProcessingError(f"Failed to save image to {output_path}") from e
+
+
+_OXIPNG_TO_ZLIB = {0: 1, 1: 4, 2: 6, 3: 7, 4: 8, 5: 9, 6: 9}
+PNG_THREADS = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+
+
+def _native_png(image: Image.Image, level: int):
+    """The page as a PNG file image from the native writer (csrc/host_png.cpp: colour-type reductions, per-row filter choice, stripes
+    deflated on several threads — what oxipng does for the reference, image_utils.py:140-150), or None when the kernel library cannot
+    be loaded or the mode is not one of L / LA / RGB / RGBA.  Lossless: a reader decodes the page's pixels exactly; like with oxipng the
+    decoded MODE follows the file (an opaque RGBA page comes back as RGB, a grey one as L)."""
+    if image.mode not in ("L", "LA", "RGB", "RGBA"):
+        return None
+    try:
+        from ...hip.lib import get_library
+        lib = get_library()
+    except Exception:      # noqa: BLE001 — no kernel library on this host: the caller falls back to Pillow
+        return None
+    a = np.ascontiguousarray(np.asarray(image))
+    h, w = a.shape[:2]
+    c = 1 if a.ndim == 2 else a.shape[2]
+    cap = h * (w * c + 1) + h * (w * c + 1) // 500 + (1 << 20)
+    buf = np.empty(cap, np.uint8)
+    n = lib.mtx_host_png_encode(a.ctypes.data, w, h, c, _OXIPNG_TO_ZLIB[level], PNG_THREADS, 1, buf.ctypes.data, cap)
+    if n > cap:
+        buf = np.empty(n, np.uint8)
+        n = lib.mtx_host_png_encode(a.ctypes.data, w, h, c, _OXIPNG_TO_ZLIB[level], PNG_THREADS, 1, buf.ctypes.data, n)
+    if n <= 0:
+        return None
+    return buf[:n].tobytes()
 
 
 def pil_to_cv2(pil_image: Image.Image) -> np.ndarray:

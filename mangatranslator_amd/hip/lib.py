@@ -53,6 +53,8 @@ class MtxLibrary:
                                          C.c_double, C.c_void_p, C.POINTER(C.c_int)]
         d.mtx_host_chamfer_l2_5x5.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         d.mtx_host_mask_outline.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        d.mtx_host_png_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        d.mtx_host_png_encode.restype = C.c_int64
         d.mtx_conv2d_tiles.argtypes = [C.POINTER(abi.ConvArgs)]
         d.mtx_plan_create.argtypes = [C.POINTER(abi.Op), C.c_int, C.POINTER(C.c_void_p)]
         d.mtx_plan_run.argtypes = [C.c_void_p, C.c_void_p]

@@ -113,3 +113,31 @@ def test_saved_pages_decode_to_the_same_pixels(tmp_path, mode):
     p = tmp_path / "x.bmp"                                          # unknown extension -> .png
     iu.save_image_with_compression(img, p)
     assert not p.exists() and np.array_equal(np.asarray(Image.open(p.with_suffix(".png"))), a)
+
+
+def test_native_png_writer_reduces_like_oxipng_and_stays_lossless(tmp_path):
+    """csrc/host_png.cpp behind `save_image_with_compression`: opaque alpha is dropped, R == G == B becomes grey (the decoded mode follows
+    the file, as with the reference's oxipng pass), every decoded pixel equals the page; stripes of a tall image concatenate into one
+    valid zlib stream (Pillow decodes it); all compression levels"""
+    if iu._native_png(Image.new("L", (4, 4)), 2) is None:
+        pytest.skip("kernel library not built here")
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 256, (700, 300), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (700, 300, 3), dtype=np.uint8)
+    cases = {"grey RGBA, opaque": (np.dstack([g, g, g, np.full_like(g, 255)]), "RGBA", "L"),
+             "grey RGB": (np.dstack([g, g, g]), "RGB", "L"),
+             "colour RGBA, opaque": (np.dstack([rgb, np.full_like(g, 255)]), "RGBA", "RGB"),
+             "grey RGBA, one transparent pixel": (np.dstack([g, g, g, np.where(np.arange(g.size).reshape(g.shape) == 777, 0, 255).astype(np.uint8)]), "RGBA", "LA"),
+             "colour RGBA with alpha": (np.dstack([rgb, g]), "RGBA", "RGBA"), "L": (g, "L", "L"), "LA opaque": (np.dstack([g, np.full_like(g, 255)]), "LA", "L")}
+    for name, (arr, mode, want_mode) in cases.items():
+        img = Image.fromarray(arr, mode)
+        for level in (0, 2, 6):
+            p = tmp_path / "x.png"
+            iu.save_image_with_compression(img, p, png_compression=level)
+            back = Image.open(p)
+            back.load()
+            assert back.mode == want_mode, (name, level, back.mode)
+            assert np.array_equal(np.asarray(back.convert(mode)), arr), (name, level)
+    big = Image.fromarray(rng.integers(0, 256, (3000, 1200, 3), dtype=np.uint8).astype(np.uint8) // 64 * 64, "RGB")      # > 8 stripes' worth of rows
+    iu.save_image_with_compression(big, tmp_path / "big.png")
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "big.png")), np.asarray(big))

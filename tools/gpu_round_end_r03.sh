@@ -34,7 +34,6 @@ serial)
 configs)
   { for c in 1 2 3; do echo "== config $c"; st=30; [ $c = 3 ] && st=6; timeout 1200 python bench.py --config $c --steps $st --warmup 3 > gpurun_out/bench_c$c.out 2> gpurun_out/bench_c$c.err; line gpurun_out/bench_c$c.out gpurun_out/r03_bench_config$c.json; done
     echo "== config 5"; timeout 1200 python bench.py --config 5 --steps 8 --warmup 2 > gpurun_out/bench_c5.out 2> gpurun_out/bench_c5.err; line gpurun_out/bench_c5.out gpurun_out/r03_bench_config5.json
-    echo "== config 5 under rocprofv3"; prof config5 --config 5 --steps 4 --warmup 2
     echo "== upscale only"; timeout 300 python bench.py --stages upscale --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_up.out 2>/dev/null; line gpurun_out/bench_up.out gpurun_out/r03_bench_upscale_only.json
   } > gpurun_out/r03_end_configs.log 2>&1; cat gpurun_out/r03_end_configs.log ;;
 io)
