@@ -642,7 +642,7 @@ def main():
             cfg["clean_ms_not_in_metric"] = f"failed: {e}"
         if upscaler is not None:
             cfg["upscale_ms"] = upscaler.plan_for(1, H_, W_).time(3)
-        if flux is not None:
+        if flux is not None and not args.traffic_child:      # (the counter child only needs the page's own launches: no timing replays)
             key, plan = next(iter(flux.transformer._plans.items()))
             t_txt, h2, w2 = key[0], key[1], key[2]
             fl = flux.transformer.flops_per_step(*key[:3]) if not klein else flux.transformer.flops_per_step(*key)
@@ -697,7 +697,7 @@ def main():
             result["roofline"] = roofs.pop(dom)
             for k_, v_ in roofs.items():
                 result["roofline_" + k_] = v_
-        if upscaler is not None:
+        if upscaler is not None and not args.traffic_child:
             # ---- the HBM-bound kernel the north star names: RCAN 3x3 conv 64->64 at page resolution -------
             u = upscaler.hp["unshuffle"]
             plan = upscaler.plan_for(1, H_, W_)
