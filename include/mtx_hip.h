@@ -36,7 +36,7 @@ extern "C" {
 #define MTX_API
 #endif
 
-#define MTX_ABI_VERSION 3
+#define MTX_ABI_VERSION 4
 
 typedef enum mtx_status {
   MTX_OK = 0,

@@ -2,7 +2,7 @@
 mtx_abi_sizeof() when the library is opened)."""
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums
 BF16, F16, F32, U8, I32, F8 = 0, 1, 2, 3, 4, 5
