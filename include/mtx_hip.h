@@ -352,8 +352,16 @@ typedef struct mtx_quant_args {
  *                      mask == 0: sums[0..8] += {n, L, L^2, a, b of src, L, L^2, a, b of other} as exact uint64 (zero them first).
  *  MTX_TAIL_LAB_REMAP  dst = Lab -> RGB of (Lab(src) with L' = (L - params[0]) * params[1] + params[2], a' = a + params[3] if params[5],
  *                      b' = b + params[4] if params[6] on the pixels with mask != 0, clipped and truncated to uint8).
- * gamma_tab [256], cbrt_tab [cbrt_n], lab_coef [9]: OpenCV's tables (int32), uploaded once by the caller. */
-typedef enum mtx_tail_kind { MTX_TAIL_RESAMPLE = 0, MTX_TAIL_COMPOSITE = 1, MTX_TAIL_LAB_STATS = 2, MTX_TAIL_LAB_REMAP = 3 } mtx_tail_kind;
+ * gamma_tab [256], cbrt_tab [cbrt_n], lab_coef [9]: OpenCV's tables (int32), uploaded once by the caller.
+ *  MTX_TAIL_EDT_COLS   src = mask uint8 [out_h][out_w] (ld_src; nonzero = set), dst = uint8 g (ld_dst): distance to the nearest set pixel of
+ *                      the same column, ksize = radius R (1..254); R + 1 = none within R.
+ *  MTX_TAIL_EDT_ROWS   src = g, dst = float32 weight (ld_dst in floats): 1 on the mask, params[d^2] off it where d^2 = the exact squared
+ *                      Euclidean distance to the mask if <= R^2, else 0 (params: float [R * R + 1], the host's float64 ramp
+ *                      clip(1 - sqrt(d^2) / R, 0, 1) rounded to float32 — scipy.ndimage.distance_transform_edt + the numpy expression of
+ *                      reference core/image/inpainting.py:1126-1163, bit for bit).  axis != 0: strict (0 off the mask).  Weights outside the
+ *                      rectangle [x, page_c) x [y, cbrt_n) are 0 (composite_clip_bbox; pass 0, out_w, 0, out_h for none). */
+typedef enum mtx_tail_kind { MTX_TAIL_RESAMPLE = 0, MTX_TAIL_COMPOSITE = 1, MTX_TAIL_LAB_STATS = 2, MTX_TAIL_LAB_REMAP = 3,
+                             MTX_TAIL_EDT_COLS = 4, MTX_TAIL_EDT_ROWS = 5 } mtx_tail_kind;
 typedef struct mtx_tail_args {
   int32_t kind;
   const void* src; void* dst;

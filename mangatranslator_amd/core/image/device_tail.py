@@ -9,6 +9,8 @@ size), `:1577-1665` (LANCZOS back, `_match_luminance`, composite), `:543-611, 87
     match_luminance()  the reference's Lab luminance match: OpenCV's fixed-point RGB -> Lab on the device (exact), the context statistics
                        from exact integer sums, the affine remap and the float Lab -> RGB on the device
     composite()        patch * alpha + page * (1 - alpha) in fp32, truncated — bit-identical to `composite_u8`
+    feather()          the composite weight from the mask: exact Euclidean distance inside a window of the blur radius (integer squared
+                       distances), the ramp from a float64-built table — bit-identical to scipy's EDT + the numpy ramp
 
 Everything is uint8 HWC torch tensors on the model's device; PyTorch is the allocator only.  There is no host fallback in here: callers
 that have no device tail use the host functions of `inpainting.py` (the reference's own arithmetic) as before."""
@@ -99,6 +101,7 @@ class DeviceTail:
         self._cbrt = torch.from_numpy(_CBRT32.astype(np.int32)).to(self.device)
         self._coef = torch.from_numpy(_COEF32.astype(np.int32).reshape(-1)).to(self.device)
         self._tables = {}
+        self._ramps = {}
 
     # ---- plumbing ----------------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -177,6 +180,43 @@ class DeviceTail:
         a.alpha, a.ld_alpha, a.x, a.y, a.page_c = alpha.data_ptr(), alpha.shape[1], x, y, page.shape[2]
         self._run(a)
         return page
+
+    # ---- feathered composite weight (reference inpainting.py:1126-1163: scipy EDT + linear ramp) -----------------------------------------
+    def feather(self, mask: torch.Tensor, blur: int, strict: bool = False, clip=None) -> torch.Tensor:
+        """float32 [h, w] composite weight of a crop from its mask (uint8 [h, w] on the device, non-zero = masked): 1 on the mask, the
+        linear ramp clip(1 - d / blur, 0, 1) over the EXACT Euclidean distance d to it elsewhere — `FluxKleinInpainter._crop_alpha` bit
+        for bit (the ramp is read from a table indexed by the integer d^2, built here in float64 like the numpy expression).  `strict`:
+        zero off the mask; `clip` = (x0, y0, x1, y1) inside the crop: zero outside it (composite_clip_bbox)."""
+        assert mask.dtype == torch.uint8 and mask.dim() == 2 and mask.is_contiguous()
+        h, w = int(mask.shape[0]), int(mask.shape[1])
+        if blur <= 0:
+            alpha = (mask != 0).to(torch.float32)
+            if clip is not None:
+                keep = torch.zeros_like(alpha)
+                x0, y0, x1, y1 = clip
+                if x1 > x0 and y1 > y0:
+                    keep[y0:y1, x0:x1] = alpha[y0:y1, x0:x1]
+                alpha = keep
+            return alpha
+        R = int(blur)
+        lut = self._ramps.get(R)
+        if lut is None:
+            d = np.sqrt(np.arange(R * R + 1, dtype=np.float64))
+            lut = self._ramps[R] = torch.from_numpy(np.clip(1.0 - d / R, 0.0, 1.0).astype(np.float32)).to(self.device)
+        g = torch.empty((h, w), dtype=torch.uint8, device=self.device)
+        alpha = torch.empty((h, w), dtype=torch.float32, device=self.device)
+        a = abi.TailArgs()
+        a.kind, a.src, a.dst = abi.TAIL_EDT_COLS, mask.data_ptr(), g.data_ptr()
+        a.out_h, a.out_w, a.c, a.ld_src, a.ld_dst, a.ksize = h, w, 1, w, w, R
+        self._run(a)
+        x0, y0, x1, y1 = (0, 0, w, h) if clip is None else (max(0, int(clip[0])), max(0, int(clip[1])), min(w, int(clip[2])), min(h, int(clip[3])))
+        a = abi.TailArgs()
+        a.kind, a.src, a.dst = abi.TAIL_EDT_ROWS, g.data_ptr(), alpha.data_ptr()
+        a.out_h, a.out_w, a.c, a.ld_src, a.ld_dst, a.ksize = h, w, 1, w, w, R
+        a.params, a.axis, a.x, a.y, a.page_c, a.cbrt_n = lut.data_ptr(), int(bool(strict)), x0, y0, x1, y1
+        self._keep = (g, lut)
+        self._run(a)
+        return alpha
 
     # ---- Lab luminance match (reference inpainting.py:1165-1256) ------------------------------------------------------------------
     def _lab_args(self, kind, src, mask):

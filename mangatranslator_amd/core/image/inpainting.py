@@ -566,29 +566,34 @@ class FluxKleinInpainter:
         patch = self.cache.get_inpainted_image(key) if key is not None else None
         if patch is not None:
             log_message("  - Using cached inpainting patch", verbose=verbose)
-        alpha = self._crop_alpha(mask_crop, blur)
-        if strict_mask_clipping:
-            alpha = alpha * mask_crop.astype(np.float32)
+        clip_rect = None                                   # composite_clip_bbox in crop coordinates
         if composite_clip_bbox is not None:
             cx1, cy1, cx2, cy2 = composite_clip_bbox
             cx1, cx2 = max(0, min(img_w, cx1)), max(0, min(img_w, cx2))
             cy1, cy2 = max(0, min(img_h, cy1)), max(0, min(img_h, cy2))
-            ax0, ax1, ay0, ay1 = max(0, cx1 - x), min(w, cx2 - x), max(0, cy1 - y), min(h, cy2 - y)
-            keep = np.zeros_like(alpha)
-            if ax1 > ax0 and ay1 > ay0:
-                keep[ay0:ay1, ax0:ax1] = alpha[ay0:ay1, ax0:ax1]
-            alpha = keep
+            clip_rect = (max(0, cx1 - x), max(0, cy1 - y), min(w, cx2 - x), min(h, cy2 - y))
         generated_now = patch is None
         tail = self._device_tail() if patch is None else None
         if tail is not None:
-            # the whole chain around the pipeline stays in HBM (core/image/device_tail.py): LANCZOS to the inference size, the pipeline,
-            # LANCZOS back, the luminance match and the composite — Pillow's resize and the composite bit for bit, the Lab leg within a level
-            result, patch = self._inpaint_on_device(tail, image_pil, crop, mask_crop, alpha, x, y, w, h, seed, verbose)
+            # the whole chain around the pipeline stays in HBM (core/image/device_tail.py): the feather weight from the mask (exact EDT in
+            # a window of the blur radius), LANCZOS to the inference size, the pipeline, LANCZOS back, the luminance match and the
+            # composite — weight, resize and composite bit for bit, the Lab leg within a level
+            result, patch = self._inpaint_on_device(tail, image_pil, crop, mask_crop, (blur, strict_mask_clipping, clip_rect), x, y, w, h, seed,
+                                                    verbose)
             if result is None:
                 return image_pil
             if key is not None:
                 self.cache.set_inpainted_image(key, patch)
             return result
+        alpha = self._crop_alpha(mask_crop, blur)
+        if strict_mask_clipping:
+            alpha = alpha * mask_crop.astype(np.float32)
+        if clip_rect is not None:
+            ax0, ay0, ax1, ay1 = clip_rect
+            keep = np.zeros_like(alpha)
+            if ax1 > ax0 and ay1 > ay0:
+                keep[ay0:ay1, ax0:ax1] = alpha[ay0:ay1, ax0:ax1]
+            alpha = keep
         if patch is None:
             scaled, _, _ = self._prepare_image_for_inference(crop, verbose=verbose)
             inf_w, inf_h = scaled.size
@@ -639,8 +644,10 @@ class FluxKleinInpainter:
         self._tail = DeviceTail(lib, pipe.device)
         return self._tail
 
-    def _inpaint_on_device(self, tail, image_pil, crop, mask_crop, alpha, x, y, w, h, seed, verbose):
+    def _inpaint_on_device(self, tail, image_pil, crop, mask_crop, feather, x, y, w, h, seed, verbose):
+        """`feather` = (blur, strict, clip rectangle in crop coordinates or None): what the composite weight is made from"""
         dev = tail.device
+        mask_dev = torch.from_numpy(np.ascontiguousarray(mask_crop, dtype=np.uint8)).to(dev)
         crop_rgb = crop if crop.mode == "RGB" else crop.convert("RGB")
         crop_dev = torch.from_numpy(np.array(crop_rgb)).to(dev)
         inf_w, inf_h = self._inference_size(w, h)
@@ -661,12 +668,12 @@ class FluxKleinInpainter:
         if (inf_w, inf_h) != (w, h):
             patch = tail.resize(patch, (w, h), "lanczos")
         if self.luminance_correction:
-            patch = tail.match_luminance(patch, crop_dev, torch.from_numpy(np.ascontiguousarray(mask_crop, dtype=np.uint8)).to(dev),
-                                         log=lambda m: log_message(m, verbose=verbose))
+            patch = tail.match_luminance(patch, crop_dev, mask_dev, log=lambda m: log_message(m, verbose=verbose))
         page = torch.from_numpy(np.array(image_pil)).to(dev)          # a copy: the composite is in place
         if page.dim() == 2:
             page = page[..., None]
-        tail.composite(page.contiguous(), patch, torch.from_numpy(np.ascontiguousarray(alpha, dtype=np.float32)).to(dev), x, y)
+        blur, strict, clip_rect = feather
+        tail.composite(page.contiguous(), patch, tail.feather(mask_dev, blur, strict, clip_rect), x, y)
         out_np = page.cpu().numpy()
         result = Image.fromarray(out_np[..., 0] if out_np.shape[2] == 1 else out_np, image_pil.mode)
         return result, Image.fromarray(patch.cpu().numpy())

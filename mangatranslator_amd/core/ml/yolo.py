@@ -276,43 +276,42 @@ class YoloSegHip:
 
     def _finish(self, plan, lp, hw, conf, iou, max_det):
         h0, w0 = hw
-        if True:
-            nc, nm = self.a["nc"], self.a["nm"]
-            dec = plan.decoded
-            scores, cls = dec[:, 4:4 + nc].max(1)
-            idx = torch.nonzero(scores > conf).flatten()
-            cand = dec[idx].cpu().numpy()
-            sc, cl = scores[idx].cpu().numpy(), cls[idx].cpu().numpy()
-            res = SimpleNamespace(orig_shape=(h0, w0), names=self.names, boxes=None, masks=None)
-            if len(cand) == 0:
-                return [res]
-            keep = nms_xyxy(cand[:, :4] + cl[:, None].astype(np.float32) * 7680.0, sc, iou)[:max_det]
-            cand, sc, cl = cand[keep], sc[keep], cl[keep]
-            gain = min(lp["H"] / h0, lp["W"] / w0)
-            padw, padh = round((lp["W"] - w0 * gain) / 2 - 0.1), round((lp["H"] - h0 * gain) / 2 - 0.1)
-            pb_ = cand[:, :4].astype(np.float32).copy()
-            pb_[:, [0, 2]] = ((pb_[:, [0, 2]] - padw) / gain).clip(0, w0)
-            pb_[:, [1, 3]] = ((pb_[:, [1, 3]] - padh) / gain).clip(0, h0)
-            boxes_t = torch.from_numpy(pb_).to(self.device)
-            res.boxes = _Boxes(boxes_t, torch.from_numpy(sc).to(self.device), torch.from_numpy(cl.astype(np.float32)).to(self.device))
-            if nm == 0:                    # detect-only head (panel / outside-text detectors): boxes are the whole result
-                return [res]
-            # retina masks
-            mh, mw = plan.proto.h, plan.proto.w
-            gm = min(mh / h0, mw / w0)
-            pw, ph = (mw - w0 * gm) / 2, (mh - h0 * gm) / 2
-            top, left = int(round(ph - 0.1)), int(round(pw - 0.1))
-            roi = (top, left, mh - int(round(ph + 0.1)) - top, mw - int(round(pw + 0.1)) - left)
-            nk = len(keep)
-            mp = self._mask_plan((nk + 7) // 8 * 8, mh, mw, roi, h0, w0)
-            mp.coef.zero_()
-            mp.coef[:nk].copy_(torch.from_numpy(cand[:, 4 + nc:]).to(self.device, self.tdt))
-            mp.protoflat.copy_(plan.proto.t.view(mh * mw, nm))
-            mp.boxes.zero_()                                  # rows past nk: an empty crop box, masks of zeros nobody reads
-            mp.boxes[:nk].copy_(boxes_t)
-            mp.run()
-            res.masks = _Masks(mp.masks[:nk].clone(), self.lib)
+        nc, nm = self.a["nc"], self.a["nm"]
+        dec = plan.decoded
+        scores, cls = dec[:, 4:4 + nc].max(1)
+        idx = torch.nonzero(scores > conf).flatten()
+        cand = dec[idx].cpu().numpy()
+        sc, cl = scores[idx].cpu().numpy(), cls[idx].cpu().numpy()
+        res = SimpleNamespace(orig_shape=(h0, w0), names=self.names, boxes=None, masks=None)
+        if len(cand) == 0:
             return [res]
+        keep = nms_xyxy(cand[:, :4] + cl[:, None].astype(np.float32) * 7680.0, sc, iou)[:max_det]
+        cand, sc, cl = cand[keep], sc[keep], cl[keep]
+        gain = min(lp["H"] / h0, lp["W"] / w0)
+        padw, padh = round((lp["W"] - w0 * gain) / 2 - 0.1), round((lp["H"] - h0 * gain) / 2 - 0.1)
+        pb_ = cand[:, :4].astype(np.float32).copy()
+        pb_[:, [0, 2]] = ((pb_[:, [0, 2]] - padw) / gain).clip(0, w0)
+        pb_[:, [1, 3]] = ((pb_[:, [1, 3]] - padh) / gain).clip(0, h0)
+        boxes_t = torch.from_numpy(pb_).to(self.device)
+        res.boxes = _Boxes(boxes_t, torch.from_numpy(sc).to(self.device), torch.from_numpy(cl.astype(np.float32)).to(self.device))
+        if nm == 0:                    # detect-only head (panel / outside-text detectors): boxes are the whole result
+            return [res]
+        # retina masks
+        mh, mw = plan.proto.h, plan.proto.w
+        gm = min(mh / h0, mw / w0)
+        pw, ph = (mw - w0 * gm) / 2, (mh - h0 * gm) / 2
+        top, left = int(round(ph - 0.1)), int(round(pw - 0.1))
+        roi = (top, left, mh - int(round(ph + 0.1)) - top, mw - int(round(pw + 0.1)) - left)
+        nk = len(keep)
+        mp = self._mask_plan((nk + 7) // 8 * 8, mh, mw, roi, h0, w0)
+        mp.coef.zero_()
+        mp.coef[:nk].copy_(torch.from_numpy(cand[:, 4 + nc:]).to(self.device, self.tdt))
+        mp.protoflat.copy_(plan.proto.t.view(mh * mw, nm))
+        mp.boxes.zero_()                                  # rows past nk: an empty crop box, masks of zeros nobody reads
+        mp.boxes[:nk].copy_(boxes_t)
+        mp.run()
+        res.masks = _Masks(mp.masks[:nk].clone(), self.lib)
+        return [res]
 
 
 class _Boxes:

@@ -262,8 +262,8 @@ def process_page_vision(page, config, image_path="page.png", image_format: Optio
     to FLUX or flat fill) -> bubble cleaning -> optional final upscale -> target mode.  `page` is the decoded PIL page already in its
     target mode (`load_page`); the result is what the reference hands to `save_image_with_compression` in `cleaning_only` mode.
     Stage failures degrade exactly as there: detection errors -> no bubbles (:804-807), cleaning errors -> the uncleaned page
-    (:94-123), OSB errors -> the page as it was.  Panel detection (`use_panel_sorting`): the operator is here, the YOLO11-L graph is not — without a
-    model in the manager's slot the page proceeds with panels = None, the reference's own failure path.
+    (:94-123), OSB errors -> the page as it was.  Panel detection (`use_panel_sorting`): `detect_panels` on the YOLO11-L graph (core/ml/yolo11.py); a failing loader or
+    model leaves panels = None, the reference's own failure path.
     Returns `(page_out, info)` with the detections, the per-bubble cleaning records and the processing scale."""
     import math
     import numpy as np

@@ -12,6 +12,7 @@
 //              (round-to-nearest intrinsics), truncated to uint8: bit-identical to the numpy expression.
 //   LAB_STATS / LAB_REMAP  OpenCV's fixed-point 8-bit RGB -> Lab (integer tables: exact), the sums the luminance match needs as
 //              exact integers, the affine L / a / b remap on the masked pixels and the float Lab -> RGB way back.
+//   EDT_COLS / EDT_ROWS    the feathered composite weight: exact Euclidean distance to the mask inside a window of the blur radius.
 // All HBM-bound byte work: one thread per output pixel, coalesced rows; nothing here is reshaped into a GEMM.
 #include "mtx_device.h"
 
@@ -171,9 +172,64 @@ __global__ __launch_bounds__(256) void tail_lab_remap_kernel(mtx_tail_args p) {
   }
 }
 
+// ---- feather: exact Euclidean distance to the mask, up to `radius`, as the composite weight ----------------------------------------
+// The reference's weight is 1 on the mask and clip(1 - d / blur, 0, 1) outside it, d = scipy's exact Euclidean distance transform of the
+// crop (core/image/inpainting.py:1126-1163; blur <= MAX_BLUR_RADIUS = 10).  Only distances below `blur` matter, so the transform is
+// evaluated in a window: pass 1 (columns) g[y][x] = min |dy| <= R with mask[y + dy][x] set (R + 1: none), pass 2 (rows)
+// d^2 = min over |dx| <= R of dx^2 + g[y][x + dx]^2 — exact integers, the same squared distances the separable EDT produces wherever
+// d < R; beyond that the weight is 0 either way.  The weight itself comes from a table indexed by d^2 (built on the host in float64
+// and rounded to float32 exactly like the numpy expression), so no device sqrt / division rounding enters.
+__global__ __launch_bounds__(256) void tail_edt_cols_kernel(mtx_tail_args p) {
+  const long total = (long)p.out_h * p.out_w;
+  const uint8_t* M = reinterpret_cast<const uint8_t*>(p.src);
+  uint8_t* G = reinterpret_cast<uint8_t*>(p.dst);
+  const int R = p.ksize;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int py = (int)(idx / p.out_w), px = (int)(idx % p.out_w);
+    int g = R + 1;
+    for (int dy = 0; dy <= R; ++dy) {
+      const bool up = py - dy >= 0 && M[(long)(py - dy) * p.ld_src + px] != 0;
+      const bool dn = py + dy < p.out_h && M[(long)(py + dy) * p.ld_src + px] != 0;
+      if (up || dn) { g = dy; break; }
+    }
+    G[(long)py * p.ld_dst + px] = (uint8_t)g;
+  }
+}
+
+// x, y, page_c, cbrt_n: the rectangle [x, page_c) x [y, cbrt_n) outside which the weight is 0 (composite_clip_bbox); axis != 0: strict
+// (weight 0 off the mask); params: the table [R * R + 1]
+__global__ __launch_bounds__(256) void tail_edt_rows_kernel(mtx_tail_args p) {
+  const long total = (long)p.out_h * p.out_w;
+  const uint8_t* G = reinterpret_cast<const uint8_t*>(p.src);
+  float* A = reinterpret_cast<float*>(p.dst);
+  const int R = p.ksize, R2 = R * R;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int py = (int)(idx / p.out_w), px = (int)(idx % p.out_w);
+    const uint8_t* row = G + (long)py * p.ld_src;
+    float a = 0.f;
+    if (px >= p.x && px < p.page_c && py >= p.y && py < p.cbrt_n) {
+      if (row[px] == 0) a = 1.f;
+      else if (p.axis == 0) {
+        int best = R2 + 1;
+        for (int dx = -R; dx <= R; ++dx) {
+          const int qx = px + dx;
+          if (qx < 0 || qx >= p.out_w) continue;
+          const int g = row[qx];
+          if (g > R) continue;
+          const int d2 = dx * dx + g * g;
+          best = d2 < best ? d2 : best;
+        }
+        a = best <= R2 ? p.params[best] : 0.f;
+      }
+    }
+    A[(long)py * p.ld_dst + px] = a;
+  }
+}
+
 int tail_launch(const mtx_tail_args* a, void* stream, const char** err) {
   if (!a->src || !a->dst || a->out_h < 0 || a->out_w < 0) { *err = "page tail: null operand"; return MTX_ERR_INVALID; }
-  if (a->c < 1 || a->c > 4) { *err = "page tail: 1..4 channels"; return MTX_ERR_INVALID; }
+  const bool edt = a->kind == MTX_TAIL_EDT_COLS || a->kind == MTX_TAIL_EDT_ROWS;
+  if (!edt && (a->c < 1 || a->c > 4)) { *err = "page tail: 1..4 channels"; return MTX_ERR_INVALID; }
   const long total = (long)a->out_h * a->out_w;
   if (total == 0) return MTX_OK;
   long blocks = (total + 255) / 256;
@@ -195,6 +251,14 @@ int tail_launch(const mtx_tail_args* a, void* stream, const char** err) {
     case MTX_TAIL_LAB_REMAP:
       if (!a->gamma_tab || !a->cbrt_tab || !a->lab_coef || !a->mask || !a->params || a->c != 3) { *err = "page tail (Lab remap): tables / mask / params"; return MTX_ERR_INVALID; }
       MTX_LAUNCH(tail_lab_remap_kernel, grid, block, 0, stream, *a);
+      return MTX_OK;
+    case MTX_TAIL_EDT_COLS:
+      if (a->ksize < 1 || a->ksize > 254) { *err = "page tail (feather): radius 1..254"; return MTX_ERR_INVALID; }
+      MTX_LAUNCH(tail_edt_cols_kernel, grid, block, 0, stream, *a);
+      return MTX_OK;
+    case MTX_TAIL_EDT_ROWS:
+      if (a->ksize < 1 || a->ksize > 254 || !a->params) { *err = "page tail (feather): radius 1..254, weight table"; return MTX_ERR_INVALID; }
+      MTX_LAUNCH(tail_edt_rows_kernel, grid, block, 0, stream, *a);
       return MTX_OK;
     default: *err = "page tail: unknown kind"; return MTX_ERR_INVALID;
   }

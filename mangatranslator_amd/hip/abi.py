@@ -149,7 +149,7 @@ class TailArgs(C.Structure):
                 ("mask", vp), ("ld_mask", i64), ("other", vp), ("ld_other", i64), ("sums", vp), ("params", vp)]
 
 
-TAIL_RESAMPLE, TAIL_COMPOSITE, TAIL_LAB_STATS, TAIL_LAB_REMAP = 0, 1, 2, 3
+TAIL_RESAMPLE, TAIL_COMPOSITE, TAIL_LAB_STATS, TAIL_LAB_REMAP, TAIL_EDT_COLS, TAIL_EDT_ROWS = 0, 1, 2, 3, 4, 5
 
 
 class CleanArgs(C.Structure):

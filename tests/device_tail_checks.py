@@ -44,6 +44,47 @@ def check_composite(lib, seed=0):
         assert np.array_equal(got, ref), f"composite on a {page_c}-channel page: {(got != ref).sum()} bytes differ"
 
 
+def check_feather(lib, sizes=((61, 83), (40, 40), (97, 30)), radii=(1, 2, 3, 7, 10), seed=0):
+    """the composite weight from the mask on the device against `FluxKleinInpainter._crop_alpha` (scipy's exact EDT + the float64 ramp,
+    rounded to float32), the strict variant and the clip rectangle of `inpaint_mask`: EQUAL as float32 bit patterns.  Masks: blobs, thin
+    lines, single pixels, pixels on the crop's border, a nearly full and an empty crop."""
+    dev = _dev(lib)
+    tail = DeviceTail(lib, dev)
+    rng = np.random.default_rng(seed)
+    n = 0
+    for (h, w) in sizes:
+        yy, xx = np.mgrid[0:h, 0:w]
+        masks = {
+            "blobs": ((xx - w * 0.3) ** 2 / 90.0 + (yy - h * 0.4) ** 2 / 40.0 < 1.0) | ((xx - w * 0.8) ** 2 + (yy - h * 0.75) ** 2 < 30.0),
+            "lines and points": (yy == h // 2) & (xx % 9 < 5) | (xx == 3) & (yy % 7 == 0) | (xx == w - 1) & (yy == h - 1) | (xx == 0) & (yy == 0),
+            "noise": rng.random((h, w)) < 0.004,
+            "nearly full": ~((xx == w // 2) & (yy == h // 3)),
+            "empty": np.zeros((h, w), bool),
+        }
+        for name, m in masks.items():
+            m = np.ascontiguousarray(m)
+            md = torch.from_numpy(m.astype(np.uint8)).to(dev)
+            for R in radii:
+                for strict, clip in ((False, None), (True, None), (False, (w // 5, h // 6, w - 7, h - 2)), (False, (5, 5, 5, 9))):
+                    if name == "empty":
+                        ref = np.zeros((h, w), np.float32)       # scipy's EDT of an all-background crop is not what the operator ever sees (it returns early)
+                    else:
+                        ref = ip.FluxKleinInpainter._crop_alpha(m, R)
+                    if strict:
+                        ref = ref * m.astype(np.float32)
+                    if clip is not None:
+                        keep = np.zeros_like(ref)
+                        x0, y0, x1, y1 = clip
+                        if x1 > x0 and y1 > y0:
+                            keep[y0:y1, x0:x1] = ref[y0:y1, x0:x1]
+                        ref = keep
+                    got = tail.feather(md, R, strict, clip).cpu().numpy()
+                    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), ref.astype(np.float32).view(np.uint32)), \
+                        f"{name} {w}x{h} R={R} strict={strict} clip={clip}: {(got != ref).sum()} weights differ (max {np.abs(got - ref).max()})"
+                    n += 1
+    return n
+
+
 def check_luminance(lib, h=96, w=128, seed=0):
     """the luminance match of a patch that is darker and flatter than its surroundings (the case the reference corrects), and of one that
     needs no correction (returned untouched)"""

@@ -17,6 +17,10 @@ def test_composite_is_numpy_bit_for_bit(hip_lib):
     dc.check_composite(hip_lib)
 
 
+def test_feather_weight_is_scipy_edt_bit_for_bit(hip_lib):
+    dc.check_feather(hip_lib, sizes=((611, 833), (97, 30), (1280, 700)), radii=(1, 2, 5, 10))
+
+
 def test_luminance_match(hip_lib):
     psnr, frac = dc.check_luminance(hip_lib, h=528, w=688)
     record("device_tail.luminance_match.688x528", psnr_db_vs_host_path=psnr, bytes_differing_frac=frac)

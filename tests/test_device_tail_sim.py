@@ -32,6 +32,10 @@ def test_composite_is_numpy_bit_for_bit(emu_lib):
     dc.check_composite(emu_lib)
 
 
+def test_feather_weight_is_scipy_edt_bit_for_bit(emu_lib):
+    assert dc.check_feather(emu_lib, sizes=((61, 83), (40, 33)), radii=(1, 3, 10)) == 2 * 5 * 3 * 4
+
+
 def test_luminance_match(emu_lib):
     psnr, frac = dc.check_luminance(emu_lib)
     assert psnr >= 60.0
