@@ -23,6 +23,33 @@ import sys
 import time
 from pathlib import Path
 
+
+
+def _early_hw_queues(argv):
+    """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4); streams that share a queue run their work one
+    after the other.  A page's detect stage keeps five model streams busy at once (hip/plan.py AsyncLane: four detectors + the SAM encoder),
+    so with four queues two of its graphs always wait for each other: measured on an MI355X (profiles/r03_hw_queues_ab.log), BASELINE
+    config 2 29.1 -> 31.4 pages/s and config 1 46.5 -> 49.2 with eight queues.  The same setting LOSES where the back half of the page
+    pipeline saturates the chip with big kernels (config 5, two pages in flight: 1.20 -> 1.10 pages/s on boxes of the same clock class —
+    detector kernels that truly run beside the 256-workgroup GEMM / conv waves cost those waves a second round), so it is chosen here only
+    for the stage sets without diffusion / upscaling, and reported in the line (config.hw_queues).  It has to be in the environment
+    before the HIP runtime starts, hence this look at argv ahead of `import torch`; a value the caller exported wins."""
+    def opt(name, default):
+        for i, a in enumerate(argv):
+            if a == name and i + 1 < len(argv):
+                return argv[i + 1]
+            if a.startswith(name + "="):
+                return a.split("=", 1)[1]
+        return default
+    stages = opt("--stages", None)
+    if stages in (None, "all"):
+        stages = {"1": "detect,clean", "2": "detect,segment"}.get(opt("--config", "4"), "detect,segment,inpaint,upscale")
+    if not ({"inpaint", "upscale"} & {x.strip() for x in stages.split(",")}):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+_early_hw_queues(sys.argv[1:])
+
 import numpy as np
 import torch
 
@@ -395,6 +422,11 @@ def main():
     from mangatranslator_amd.core.caching import get_cache
     stage_memo = get_cache()
 
+    # BASELINE config 2 (detect + segment, nothing behind them): the two stages are the two halves of the page pipeline — the SAM mask decoder of
+    # page i (its encoder already ran beside the detectors) beside the detectors of page i + 1
+    seg_in_b = (yolo is not None and sam is not None and inpainter is None and upscaler is None and clean_args is None
+                and not args.no_overlap and not args.serial_detectors)
+
     def stage_a(i):
         """front half of page i: the stages whose host share is large (NMS, prompt handling, OSB region logic)"""
         k = i % pool
@@ -423,6 +455,8 @@ def main():
             for name_, det_, tk_ in tickets:
                 outs[name_] = det_.collect(tk_)[0]
             tl = lap("detect", tl)
+        if sam is not None and seg_in_b:          # detect + segment only: the mask decoder of this page runs beside the next page's detectors
+            return ("segment", sam_ticket)
         if sam is not None:      # prompts: the generator's ground-truth boxes (fixed unit count)
             outs["segment"] = sam.segment(pages[k], page_boxes[k], ticket=sam_ticket)
             tl = lap("segment", tl)
@@ -441,6 +475,10 @@ def main():
         """back half of page i: GPU-bound"""
         k = i % pool
         tl = time.perf_counter()
+        if seg_in_b:
+            outs["segment"] = sam.segment(pages[k], page_boxes[k], ticket=work_[1])
+            tl = lap("segment", tl)
+            return
         if inpainter is not None:
             outs["inpaint"], _ = otp.finish_outside_text_work(work_) if work_ is not None else (page_pil[k], [])
             tl = lap("inpaint_finish", tl)
@@ -456,6 +494,7 @@ def main():
         stage_b(i, stage_a(i))
 
     overlap = not args.no_overlap and (yolo is not None or sam is not None) and (inpainter is not None or upscaler is not None or clean_args is not None)
+    overlap = overlap or seg_in_b
 
     def run_steps(n):
         """n pages; with overlap, page i+1's front half runs on a worker thread beside page i's back half (a page still goes through its
@@ -585,10 +624,11 @@ def main():
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
                    "detector_calls": ("one after the other" if args.serial_detectors else "submitted together, one HIP stream per model, collected afterwards") if yolo is not None else None,
                    "stage_wall_ms_one_page": {k_: round(v_, 2) for k_, v_ in stage_wall.items()},
-                   "page_pipeline": ("two pages in flight: detect / segment / OSB prepare of page i+1 on a worker thread beside inpaint / upscale / clean of page i"
+                   "page_pipeline": ("two pages in flight: detectors (+ SAM encoder) of page i+1 on a worker thread beside the SAM mask decoder of page i" if seg_in_b else
+                                     "two pages in flight: detect / segment / OSB prepare of page i+1 on a worker thread beside inpaint / upscale / clean of page i"
                                      if overlap else "stages strictly in order, one page at a time"),
                    "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL",
-                   "host_threads_per_rank": host_threads,
+                   "host_threads_per_rank": host_threads, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                    "launch": {"world_size_seen_by_collectives": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                               "self_launched": os.environ.get("MTX_BENCH_SELF_LAUNCHED") == "1", "model_setup_and_weight_broadcast_s": round(load_s, 2)}},
     }
