@@ -181,13 +181,18 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
             primary_results = primary_model(bgr, conf=confidence, device=device, verbose=False, imgsz=imgsz, retina_masks=True)[0]
         primary_boxes = primary_results.boxes.xyxy if primary_results.boxes is not None else torch.zeros((0, 4))
         cache.set_yolo_detection(yolo_key, (primary_results, primary_boxes))
-    primary_sources = [("primary", i) for i in range(len(primary_boxes))]
-    if len(primary_boxes) > 1:
-        keep = box_ops.deduplicate_primary_boxes(primary_boxes, primary_results.boxes.conf, IOU_DUPLICATE_THRESHOLD)
-        primary_boxes, primary_sources = primary_boxes[keep], [primary_sources[i] for i in keep]
-    if len(primary_boxes) > 1:
-        keep = box_ops.remove_contained_boxes(primary_boxes)
-        primary_boxes, primary_sources = primary_boxes[keep], [primary_sources[i] for i in keep]
+    try:
+        primary_sources = [("primary", i) for i in range(len(primary_boxes))]
+        if len(primary_boxes) > 1:
+            keep = box_ops.deduplicate_primary_boxes(primary_boxes, primary_results.boxes.conf, IOU_DUPLICATE_THRESHOLD)
+            primary_boxes, primary_sources = primary_boxes[keep], [primary_sources[i] for i in keep]
+        if len(primary_boxes) > 1:
+            keep = box_ops.remove_contained_boxes(primary_boxes)
+            primary_boxes, primary_sources = primary_boxes[keep], [primary_sources[i] for i in keep]
+    except BaseException:
+        if early_secondary is not None:
+            early_secondary[0].collect(early_secondary[1])              # a queued model is always collected: its lane stays busy until then
+        raise
     if len(primary_boxes) == 0:
         log_message("No detections found", verbose=verbose)
         if early_secondary is not None:
