@@ -112,6 +112,15 @@ typedef struct mtx_gemm_args {
    * in_dtype == 0 (or == dtype): the 16-bit path above. */
   const void* a_scale; const void* w_scale; int64_t lds_a, lds_w; int32_t in_dtype;
   int32_t flags;                 /* MTX_GEMM_* bits (tests / kernel benches; 0 in production graphs) */
+  /* SwiGLU + MX-fp8 epilogue (in_dtype == MTX_F8 only; FLUX.2's gated MLP, reference diffusers Flux2FeedForward / Flux2SwiGLU behind
+   * core/image/inpainting.py:1577-1589): the GEMM columns from glu_col0 on are 64-column spans [32 x a | 32 x b] — the caller has
+   * permuted W's rows so — and leave the kernel as the MX e4m3 operand of the next linear instead of 16-bit values:
+   *   h = round_T(silu(round_T(a)) * round_T(b))  (what MTX_QUANT_SWIGLU computes from the 16-bit projection),  span u -> the 32
+   *   bytes glu_q[m * glu_ldq + 32 u ..] and byte (u & 3) of the scale word glu_scale[(u >> 2) * glu_lds + m].
+   * Columns below glu_col0 take the usual epilogue into c.  glu_col0 % 256 == 0, (n - glu_col0) % 256 == 0, no bias / gate / res /
+   * act on the launch, glu_q 16-byte aligned with glu_ldq % 16 == 0.  NULL glu_q = off.  (Built and checked on the CPU simulator in
+   * round 3; not yet run on hardware — FLUX.2 graphs do not use it by default.) */
+  void* glu_q; void* glu_scale; int64_t glu_ldq, glu_lds, glu_col0;
 } mtx_gemm_args;
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
 #define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the stream-K tail */

@@ -29,7 +29,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder, PlanCache
+from ...hip.plan import Act, PlanBuilder, PlanCache, glu_interleave
 from ...utils.exceptions import ModelError
 from .flux import FluxVAEHip, _rows, rope_table, sinusoid, synthetic_provider  # noqa: F401  (re-exported for callers)
 
@@ -82,7 +82,7 @@ class _W:
 
 
 class Flux2DiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True):
+    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=False):
         """provider(name) -> tensor with diffusers' Flux2Transformer2DModel parameter of that name.
         fp8: False, True (= every block linear) or a tuple of names out of FP8_ALL."""
         self.lib = lib if lib is not None else get_library()
@@ -96,6 +96,10 @@ class Flux2DiTHip:
             raise ModelError("FLUX.2 DiT: head dim must be 64 or 128 and equal sum(axes_dims_rope)")
         self.fp8 = FP8_ALL if fp8 is True else tuple(fp8 or ())
         self.fused_quant = fused_quant      # norms and SwiGLU write the fp8 linears' operands themselves; False: separate quantiser passes (round 2's form, for A/Bs)
+        # glu_epilogue: the MLP-in linears' fp8 GEMM applies SwiGLU and writes the MX fp8 operand of MLP-out itself (mtx_gemm_args.glu_*): no
+        # [T, 2 * hidden] projection, no SwiGLU-quantiser launch.  Bit-identical on the simulator; NOT yet run on hardware (round 3), so off
+        # by default.  Needs every linear of the MLP on the fp8 path.
+        self.glu_epilogue = bool(glu_epilogue) and all(k in self.fp8 for k in ("ff_in", "ff_out", "single_in", "single_out")) and (3 * D) % 256 == 0
         if self.fp8 and (D % 128 or self.hid % 128):
             raise ModelError("FLUX.2 DiT fp8 path: d and the MLP width must be multiples of 128")
         g = lambda n, dt=None: provider(n).detach().to(self.device, dt if dt is not None else self.tdt).contiguous()
@@ -124,20 +128,23 @@ class Flux2DiTHip:
                 nqk=torch.cat([g(p + ".attn.norm_q.weight", f32), g(p + ".attn.norm_k.weight", f32)]).contiguous(),
                 cnqk=torch.cat([g(p + ".attn.norm_added_q.weight", f32), g(p + ".attn.norm_added_k.weight", f32)]).contiguous(),
                 out=self._weight(g(p + ".attn.to_out.0.weight"), "out"), cout=self._weight(g(p + ".attn.to_add_out.weight"), "out"),
-                ff_in=self._weight(g(p + ".ff.linear_in.weight"), "ff_in"), ff_out=self._weight(g(p + ".ff.linear_out.weight"), "ff_out"),
-                cff_in=self._weight(g(p + ".ff_context.linear_in.weight"), "ff_in"), cff_out=self._weight(g(p + ".ff_context.linear_out.weight"), "ff_out")))
+                ff_in=self._weight(g(p + ".ff.linear_in.weight"), "ff_in", glu_col0=0), ff_out=self._weight(g(p + ".ff.linear_out.weight"), "ff_out"),
+                cff_in=self._weight(g(p + ".ff_context.linear_in.weight"), "ff_in", glu_col0=0),
+                cff_out=self._weight(g(p + ".ff_context.linear_out.weight"), "ff_out")))
         for i in range(cfg["single_layers"]):
             p = f"single_transformer_blocks.{i}.attn"
-            self.singles.append(dict(fused=self._weight(g(p + ".to_qkv_mlp_proj.weight"), "single_in"),
+            self.singles.append(dict(fused=self._weight(g(p + ".to_qkv_mlp_proj.weight"), "single_in", glu_col0=3 * D),
                                      nqk=torch.cat([g(p + ".norm_q.weight", f32), g(p + ".norm_k.weight", f32)]).contiguous(),
                                      out=self._weight(g(p + ".to_out.weight"), "single_out")))
         self._plans = PlanCache(6)           # a plan pins ~T x 40 D bytes of activations: keep a few resolutions only
         self._mod_plan = None
         self._mod_cache = {}
 
-    def _weight(self, w16: torch.Tensor, kind: str) -> _W:
+    def _weight(self, w16: torch.Tensor, kind: str, glu_col0=None) -> _W:
         if kind not in self.fp8:
             return _W(w16=w16)
+        if glu_col0 is not None and self.glu_epilogue:       # rows in [32 a | 32 b] runs from glu_col0 on (hip/plan.py glu_interleave)
+            w16 = w16[glu_interleave(glu_col0, self.hid).to(w16.device)].contiguous()
         n, k = w16.shape
         pb = PlanBuilder(self.lib, self.device, self.dtype)
         q, scale, lds = pb.quantize(w16, n, k)
@@ -287,12 +294,14 @@ class Flux2DiTHip:
             pb.join()
             adaln(t_txt, T, 3, 4, tag + ".norm2", (B["ff_in"],))
             adaln(0, t_txt, 9, 10, tag + ".norm2_ctx", (B["cff_in"],))
+            glu = (lambda r0: dict(glu=(ffa8[0], ffa8[1], hid, lds, 0, r0, 0))) if self.glu_epilogue else (lambda r0: {})
             with pb.side():
-                linear(nrm, nrm8 if f8 else None, B["cff_in"], 0, t_txt, 2 * hid, D, ffh, label=tag + ".ff_in_ctx")
-            linear(nrm, nrm8 if f8 else None, B["ff_in"], t_txt, T, 2 * hid, D, ffh, label=tag + ".ff_in")
+                linear(nrm, nrm8 if f8 else None, B["cff_in"], 0, t_txt, 2 * hid, D, ffh, label=tag + ".ff_in_ctx", **glu(0))
+            linear(nrm, nrm8 if f8 else None, B["ff_in"], t_txt, T, 2 * hid, D, ffh, label=tag + ".ff_in", **glu(t_txt))
             pb.join()
-            swiglu(ffh, 2 * hid, 0, t_txt, T, ffa, hid, 0, tag + ".swiglu", ffa8 if f8 else None, (B["ff_out"],))
-            swiglu(ffh, 2 * hid, 0, 0, t_txt, ffa, hid, 0, tag + ".swiglu_ctx", ffa8 if f8 else None, (B["cff_out"],))
+            if not self.glu_epilogue:
+                swiglu(ffh, 2 * hid, 0, t_txt, T, ffa, hid, 0, tag + ".swiglu", ffa8 if f8 else None, (B["ff_out"],))
+                swiglu(ffh, 2 * hid, 0, 0, t_txt, ffa, hid, 0, tag + ".swiglu_ctx", ffa8 if f8 else None, (B["cff_out"],))
             with pb.side():
                 linear(ffa, ffa8 if f8 else None, B["cff_out"], 0, t_txt, D, hid, x, label=tag + ".ff_out_ctx", **res_gate(11, t_txt))
             linear(ffa, ffa8 if f8 else None, B["ff_out"], t_txt, T, D, hid, x, res_off=t_txt * D, label=tag + ".ff_out", **res_gate(5, t_img))
@@ -300,10 +309,12 @@ class Flux2DiTHip:
         for i, S in enumerate(self.singles):
             tag = f"sgl{i}"
             adaln(0, T, 12, 13, tag + ".norm", (S["fused"],))
-            linear(nrm, nrm8 if f8 else None, S["fused"], 0, T, FW, D, big, label=tag + ".to_qkv_mlp")
+            linear(nrm, nrm8 if f8 else None, S["fused"], 0, T, FW, D, big, label=tag + ".to_qkv_mlp",
+                   **(dict(glu=(cat8[0], cat8[1], D + hid, lds, 3 * D, 0, D)) if self.glu_epilogue else {}))
             rope(big, 0, T, S["nqk"], FW, tag + ".rope_qk")
             attention(big, FW, cat, D + hid, tag + ".attn")
-            swiglu(big, FW, 3 * D, 0, T, cat, D + hid, D, tag + ".swiglu", cat8 if f8 else None, (S["out"],))
+            if not self.glu_epilogue:
+                swiglu(big, FW, 3 * D, 0, T, cat, D + hid, D, tag + ".swiglu", cat8 if f8 else None, (S["out"],))
             if f8 and S["out"].q is not None:          # the attention half of the concatenation: its own quantiser pass over columns [0, D)
                 pb.quantize(cat, T, D, ldx=D + hid, q=cat8[0], scale=cat8[1], lds=lds, ldq=D + hid, label=tag + ".attn.q")
             linear(cat, cat8 if f8 else None, S["out"], 0, T, D, D + hid, x, label=tag + ".to_out", **res_gate(14, T))

@@ -28,6 +28,8 @@ struct GemmParams {
   // fp8 path (in_dtype == MTX_F8): MX scale planes, one uint32 (4 E8M0 bytes) per row and 128 k
   const unsigned* a_scale; const unsigned* w_scale; long lds_a, lds_w;
   int bk;           // K elements per LDS stage row: 64 (16-bit operands) or 128 (fp8); a row is 128 bytes either way
+  // SwiGLU + MX-fp8 epilogue of the fp8 kernel (mtx_gemm_args.glu_*): columns >= glu_col0 are [32 a | 32 b] spans
+  unsigned char* glu_q; unsigned* glu_scale; long glu_ldq, glu_lds, glu_col0;
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -588,6 +590,72 @@ __global__ __launch_bounds__(512) void gemm256_f8_kernel(GemmParams p) {
   gemm256_epilogue<T, ACT>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
 }
 
+// The gated-MLP form of the same kernel (mtx_gemm_args.glu_*): tiles whose columns lie at or beyond glu_col0 hold, per wave, the "a"
+// half of 32 outputs in acc[.][0] and the "b" half in acc[.][1] (the caller interleaved W's rows in 32-row runs), so silu(a) * b and its
+// MX quantisation happen in registers: a lane owns 16 of a row's 32 outputs, lane ^ 32 the other 16 — one xor-shuffle for the block's
+// maximum, one exchange of two dwords so that each lane ends up with 16 contiguous bytes — and the 16-bit [T, 2 * hidden] projection
+// (FLUX.2-Klein: 314 MB written and read back per linear) never exists.  Arithmetic as in quant.hip's MTX_QUANT_SWIGLU on the rounded
+// 16-bit projection: bit-identical to GEMM -> SwiGLU-quantiser.
+template <typename T>
+__global__ __launch_bounds__(512) void gemm256_f8_glu_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  long m0, n0;
+  gemm256_tile_origin(p, lin, m0, n0);
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
+  __syncthreads();
+  if (n0 < p.glu_col0) {                                  // (workgroup-uniform: glu_col0 is a multiple of the tile width)
+    gemm256_epilogue<T, MTX_ACT_NONE>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
+    return;
+  }
+  const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 2, wn = wv & 3;
+  const long span = (n0 - p.glu_col0) / 64 + wn;          // 32 outputs: columns 32 * span .. of the quantised matrix
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = m0 + wm * 128 + i * 32 + l31;
+    float h[16];
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float a = to_f32(from_f32<T>(acc[i][0][e] * p.alpha)), b = to_f32(from_f32<T>(acc[i][1][e] * p.alpha));
+      h[e] = to_f32(from_f32<T>(a / (1.f + __expf(-a)) * b));
+      const float v = fabsf(h[e]);
+      amax = v > amax ? v : amax;
+    }
+    { const float o = __shfl_xor(amax, 32, 64); amax = o > amax ? o : amax; }
+    const float r = amax * (1.0f / 448.0f);
+    const unsigned u = __builtin_bit_cast(unsigned, r);
+    int eb = (int)((u >> 23) & 0xff) + ((u & 0x7fffffu) ? 1 : 0);
+    eb = amax == 0.f ? 127 : (eb < 1 ? 1 : (eb > 253 ? 253 : eb));
+    const float inv = __builtin_bit_cast(float, (unsigned)(254 - eb) << 23);
+    unsigned w[4];                                         // w[g]: outputs 8 g + 4 hi + 0..3 of the span
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float q4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float v = h[g * 4 + e] * inv; q4[e] = v > 448.f ? 448.f : (v < -448.f ? -448.f : v); }
+      w[g] = 0;
+      w[g] = cvt_pk_fp8<false>(q4[0], q4[1], w[g]); w[g] = cvt_pk_fp8<true>(q4[2], q4[3], w[g]);
+    }
+    // lane (hi = 0) keeps bytes 0..15 of the span (g = 0, 1), lane ^ 32 bytes 16..31 (g = 2, 3): swap the two dwords the other needs
+    const unsigned s0 = hi ? w[0] : w[2], s1 = hi ? w[1] : w[3];
+    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 32, 64), r1 = (unsigned)__shfl_xor((int)s1, 32, 64);
+    const u32x4 out = hi ? u32x4{r0, w[2], r1, w[3]} : u32x4{w[0], r0, w[1], r1};
+    if (m < p.m) {
+      *reinterpret_cast<u32x4*>(p.glu_q + (size_t)m * p.glu_ldq + span * 32 + hi * 16) = out;
+      if (hi == 0) reinterpret_cast<unsigned char*>(p.glu_scale + (size_t)(span >> 2) * p.glu_lds + m)[span & 3] = (unsigned char)eb;
+    }
+  }
+}
+
 
 // ---- stream-K tail ------------------------------------------------------------------------------------------
 // With one 256 x 256 tile per CU at a time, `rem = tiles % CUs` left-over tiles keep rem CUs busy for a whole tile
@@ -739,6 +807,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (!a->a || !a->w || !a->c) { *err = "gemm: null operand"; return MTX_ERR_INVALID; }
   if (a->m < 1 || a->n < 1 || a->k < 1) { *err = "gemm: empty problem"; return MTX_ERR_INVALID; }
   const bool f8 = a->in_dtype == MTX_F8;
+  if (a->glu_q != nullptr && !f8) { *err = "gemm: the SwiGLU epilogue exists on the fp8 kernel only"; return MTX_ERR_INVALID; }
   if (a->in_dtype != 0 && !f8 && a->in_dtype != a->dtype) { *err = "gemm: in_dtype must be 0, dtype or MTX_F8"; return MTX_ERR_INVALID; }
   if (a->k % 8 || a->lda % 8 || a->ldw % 8) { *err = "gemm: K, lda, ldw must be multiples of 8 (16-byte chunks)"; return MTX_ERR_INVALID; }
   if (a->batch > 1 && (a->a_bstride % 8 || a->w_bstride % 8 || a->c_bstride % 8 || a->res_bstride % 8)) { *err = "gemm: batch strides must be multiples of 8"; return MTX_ERR_INVALID; }
@@ -756,6 +825,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.part = (a->workspace && a->workspace_bytes >= (int64_t)MTX_GEMM_WORKSPACE_BYTES) ? reinterpret_cast<float*>(a->workspace) : nullptr;
   p.a_scale = reinterpret_cast<const unsigned*>(a->a_scale); p.w_scale = reinterpret_cast<const unsigned*>(a->w_scale);
   p.lds_a = a->lds_a; p.lds_w = a->lds_w;
+  p.glu_q = nullptr; p.glu_scale = nullptr; p.glu_ldq = p.glu_lds = p.glu_col0 = 0;
   p.bk = f8 ? 128 : G2_BK;
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
@@ -773,6 +843,18 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
     p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
     p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
     dim3 g2(p.tiles_m * p.tiles_n, 1);
+    if (a->glu_q != nullptr) {
+      if (!a->glu_scale || a->glu_col0 < 0 || a->glu_col0 % G2_BN || a->glu_col0 >= a->n || (a->n - a->glu_col0) % G2_BN || a->glu_ldq % 16 ||
+          ((size_t)a->glu_q & 15) || a->glu_lds < a->m || a->bias || a->gate || a->res || a->act != MTX_ACT_NONE) {
+        *err = "gemm(fp8, SwiGLU epilogue): needs glu_col0 and n - glu_col0 multiples of 256, glu_ldq % 16 == 0, glu_lds >= m, and no bias / gate / res / act";
+        return MTX_ERR_INVALID;
+      }
+      p.glu_q = reinterpret_cast<unsigned char*>(a->glu_q); p.glu_scale = reinterpret_cast<unsigned*>(a->glu_scale);
+      p.glu_ldq = a->glu_ldq; p.glu_lds = a->glu_lds; p.glu_col0 = a->glu_col0;
+      if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm256_f8_glu_kernel<__bf16>), g2, dim3(512), 0, stream, p);
+      else MTX_LAUNCH((gemm256_f8_glu_kernel<_Float16>), g2, dim3(512), 0, stream, p);
+      return MTX_OK;
+    }
     if (a->dtype == MTX_BF16) launch_gemm256<__bf16, true>(p, g2, stream, force, nosplit); else launch_gemm256<_Float16, true>(p, g2, stream, force, nosplit);
     return MTX_OK;
   }

@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
                 ("gate_rows_per", i32),
                 ("act", i32), ("act_param", f32), ("alpha", f32),
                 ("dtype", i32), ("out_dtype", i32), ("workspace", vp), ("workspace_bytes", i64),
-                ("a_scale", vp), ("w_scale", vp), ("lds_a", i64), ("lds_w", i64), ("in_dtype", i32), ("flags", i32)]
+                ("a_scale", vp), ("w_scale", vp), ("lds_a", i64), ("lds_w", i64), ("in_dtype", i32), ("flags", i32),
+                ("glu_q", vp), ("glu_scale", vp), ("glu_ldq", i64), ("glu_lds", i64), ("glu_col0", i64)]
 
 
 GEMM_FORCE_TILE256, GEMM_NO_SPLIT = 1, 2

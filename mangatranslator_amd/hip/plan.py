@@ -283,11 +283,21 @@ class PlanBuilder:
     def gemm(self, a_t, w_t, m, n, k, lda=None, ldw=None, out=None, ldc=None, bias=None, act=abi.ACT_NONE,
              res=None, ldres=None, gate=None, ldgate=None, gate_rows_per=1, alpha=1.0, batch=1,
              a_bs=0, w_bs=0, c_bs=0, res_bs=0, out_f32=False, a_off=0, w_off=0, c_off=0, res_off=0,
-             label="gemm", f8=None, flags=0):
+             label="gemm", f8=None, flags=0, glu=None):
         """f8 = (a_scale, lds_a, w_scale, lds_w, a_scale_off, w_scale_off): a_t / w_t are e4m3 byte matrices from `quantize` (offsets in
-        bytes), the epilogue operands and the output stay in the builder's 16-bit type (include/mtx_hip.h, in_dtype == MTX_F8)"""
+        bytes), the epilogue operands and the output stay in the builder's 16-bit type (include/mtx_hip.h, in_dtype == MTX_F8).
+        glu = (q, scale, ldq, lds, col0, row_off, q_col_off): the columns from col0 on are [32 a | 32 b] spans (`glu_interleave` order of
+        w's rows) and land as the MX fp8 matrix silu(a) * b in rows [row_off, row_off + m) of q / scale from byte column q_col_off on
+        (mtx_gemm_args.glu_*); with col0 == 0 no 16-bit output exists at all"""
         g = abi.GemmArgs()
         g.flags = flags
+        if glu is not None:
+            gq, gsc, gldq, glds, gcol0, grow, gqcol = glu
+            assert f8 is not None and gqcol % 128 == 0 and gcol0 % 256 == 0
+            g.glu_q, g.glu_scale = gq.data_ptr() + grow * gldq + gqcol, gsc.data_ptr() + 4 * (grow + (gqcol // 128) * glds)
+            g.glu_ldq, g.glu_lds, g.glu_col0 = gldq, glds, gcol0
+            if out is None and gcol0 == 0:
+                out = self.buf((8,), self.tdtype)          # never written: every tile takes the gated epilogue
         if f8 is not None:
             a_sc, lds_a, w_sc, lds_w, a_sc_off, w_sc_off = f8
             g.a_scale, g.w_scale = a_sc.data_ptr() + 4 * a_sc_off, w_sc.data_ptr() + 4 * w_sc_off
@@ -557,6 +567,16 @@ class PlanBuilder:
         plan.labels = list(self.labels)
         plan.ops = list(self.ops)          # the recorded argument blocks (benchmarks group launches by kernel and shape)
         return plan
+
+
+def glu_interleave(col0: int, hid: int) -> torch.Tensor:
+    """Row order of a fused [col0 + 2 * hid, K] projection for the gated epilogue of the fp8 GEMM (mtx_gemm_args.glu_*): rows below col0
+    stay, then runs of 32 "a" rows (col0 + 32 u ..) each followed by the 32 "b" rows of the same outputs (col0 + hid + 32 u ..).
+    `w[glu_interleave(col0, hid)]` is the weight to hand to the kernel."""
+    assert hid % 32 == 0
+    u = torch.arange(hid // 32)[:, None, None] * 32 + torch.arange(32)[None, None, :]                # [U, 1, 32]
+    pair = torch.cat([col0 + u, col0 + hid + u], 1).reshape(-1)                                      # a-run, b-run per u
+    return torch.cat([torch.arange(col0), pair])
 
 
 class AsyncLane:

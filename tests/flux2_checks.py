@@ -34,14 +34,14 @@ def models(seed=0, **kw):
     return t, v
 
 
-def hip_models(t, v, lib, device, fp8=False):
+def hip_models(t, v, lib, device, fp8=False, **dit_kw):
     tsd, vsd = t.state_dict(), v.state_dict()
     c = t.cfg
     dcfg = dict(d=c["d"], heads=c["heads"], layers=c["layers"], single_layers=c["single_layers"], in_channels=c["in_channels"],
                 joint_dim=c["joint_dim"], mlp_ratio=c["mlp_ratio"], axes_dim=tuple(c["axes_dim"]), rope_theta=c["rope_theta"],
                 guidance_embeds=c["guidance_embeds"])
     vcfg = dict(ch=tuple(v.cfg["ch"]), groups=v.cfg["groups"], latent=v.cfg["latent"], quant_conv=True, bn_eps=v.cfg["bn_eps"])
-    dit = f2.Flux2DiTHip(lambda n: tsd[n], dcfg, device, lib=lib, fp8=fp8)
+    dit = f2.Flux2DiTHip(lambda n: tsd[n], dcfg, device, lib=lib, fp8=fp8, **dit_kw)
     vae = f2.Flux2VAEHip(lambda n: vsd[n], vcfg, device, lib=lib)
     return dit, vae
 
@@ -78,6 +78,25 @@ def check_dit_step(lib, device, h2=4, w2=6, rh2=None, rw2=None, t_txt=16, tol=3e
     print(f"FLUX.2 DiT step ({t.cfg['layers']}+{t.cfg['single_layers']} blocks, d={t.cfg['d']}, T={plan.T}, fp8={bool(fp8)}): velocity rel err {e:.4f}")
     assert e < (fp8_tol if fp8 else tol)
     return e
+
+
+def check_glu_epilogue_step(lib, device, h2=4, w2=6, t_txt=16, **kw):
+    """one denoising step with the gated epilogue in the MLP-in GEMMs (Flux2DiTHip(glu_epilogue=True)) against the same step with the
+    separate SwiGLU-quantiser launches: the velocities must be IDENTICAL (the fused epilogue reproduces the bytes and scales, so
+    everything downstream sees the same operands), and the fused plan must hold no SwiGLU launch"""
+    from mangatranslator_amd.hip import abi
+    t, v = models(**kw)
+    lat, pe = step_inputs(t, h2, w2, h2, w2, t_txt)
+    vels, nq = [], []
+    for glu in (False, True):
+        dit, _ = hip_models(t, v, lib, device, fp8=True, glu_epilogue=glu)
+        assert dit.glu_epilogue == glu, "geometry does not allow the gated epilogue (3 d must be a multiple of 256)"
+        vel, plan = run_step(dit, lat, pe, h2, w2, h2, w2, 0.7, device)
+        vels.append(vel)
+        nq.append(sum(1 for o in plan.ops if o.kind == abi.OP_QUANT and o.u.quant.op == abi.QUANT_SWIGLU))
+    assert nq[0] == 2 * t.cfg["layers"] + t.cfg["single_layers"] and nq[1] == 0, nq
+    assert torch.equal(vels[0], vels[1]), f"gated epilogue changes the step: rel {rel(vels[1], vels[0]):.3e}"
+    return nq
 
 
 def check_vae(lib, device, h=64, w=96, tol=3e-2, **kw):

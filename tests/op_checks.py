@@ -7,6 +7,7 @@ to validate kernel index arithmetic, and on a real MI355X through the product li
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -496,6 +497,44 @@ def check_gemm_f8(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_re
     err = _relerr(out.cpu().view(m, n), ref)
     assert err < TOL[dtype], f"fp8 gemm mismatch rel err {err}"
     return err, qerr
+
+
+def check_gemm_f8_glu(lib, dtype, m, col0, hid, k, seed=0, row_off=0, q_col_off=0, spread=1.0):
+    """The gated epilogue of the fp8 GEMM (mtx_gemm_args.glu_*) against the two launches it replaces — fp8 GEMM into a 16-bit
+    [m, col0 + 2 hid] projection, then the SwiGLU quantiser (MTX_QUANT_SWIGLU) — on the same operands: the e4m3 bytes, the E8M0 scale
+    bytes and the ungated columns [0, col0) must be IDENTICAL (the fused form rounds a and b to the 16-bit type exactly where the
+    projection would have been stored).  Rows land at row_off, bytes at q_col_off of a wider operand buffer, like in the FLUX.2 graphs."""
+    from mangatranslator_amd.hip.plan import glu_interleave
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    n = col0 + 2 * hid
+    a = (torch.randn(m, k, generator=g) * torch.exp(spread * torch.randn(m, k // 32, generator=g)).repeat_interleave(32, 1)).to(td)
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k) * 1.5).to(td)
+    R, QW = row_off + m + 3, q_col_off + hid
+    lds = (R + 63) // 64 * 64
+    outs = []
+    for fused in (False, True):
+        pb = PlanBuilder(lib, dev, dtype)
+        aq, asc, lds_a = pb.quantize(pb.const(a), m, k)
+        wq, wsc, lds_w = pb.quantize(pb.const(w[glu_interleave(col0, hid)].contiguous() if fused else w), n, k)
+        q8 = pb.buf((R, QW), torch.uint8, zero=True)
+        sc = pb.buf((QW // 128, lds), torch.int32, zero=True)
+        if fused:
+            c = pb.gemm(aq, wq, m, n, k, out=pb.buf((m, n), TD[dtype], zero=True) if col0 else None, f8=(asc, lds_a, wsc, lds_w, 0, 0),
+                        flags=abi.GEMM_FORCE_TILE256, glu=(q8, sc, QW, lds, col0, row_off, q_col_off))
+        else:
+            c = pb.gemm(aq, wq, m, n, k, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=abi.GEMM_FORCE_TILE256)
+            pb.quantize(c, m, hid, ldx=n, x_off=col0, q=q8, scale=sc, row_off=row_off, lds=lds, ldq=QW, q_col_off=q_col_off,
+                        swiglu_b=c, b_off=col0 + hid, ldb=n)
+        _run(pb)
+        outs.append((q8.cpu().numpy().copy(), sc.cpu().numpy().copy(), c.cpu().float().numpy()[:, :col0].copy() if col0 else None))
+    (q0, s0, c0), (q1, s1, c1) = outs
+    assert q0.any() and s0.any()
+    assert np.array_equal(q0, q1), f"gated epilogue: {(q0 != q1).sum()} of {q0.size} e4m3 bytes differ"
+    assert np.array_equal(s0, s1), f"gated epilogue: {(s0 != s1).sum()} scale words differ"
+    if col0:
+        assert np.array_equal(c0, c1), "gated epilogue: the ungated columns differ"
+    assert not q1[:row_off].any() and not q1[row_off + m:].any() and not q1[:, :q_col_off].any(), "bytes outside the target window were written"
 
 
 def check_swiglu(lib, dtype, rows, hid, seed=0):

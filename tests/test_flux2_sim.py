@@ -11,6 +11,11 @@ def test_flux2_dit_step_reference_of_other_size(emu_lib):
     fc.check_dit_step(emu_lib, "cpu", h2=4, w2=5, rh2=3, rw2=4, t_txt=8)
 
 
+def test_flux2_gated_epilogue_step_is_identical(emu_lib):
+    """SwiGLU + MX quantisation inside the MLP-in GEMMs: same velocity bits, no SwiGLU launch left in the step"""
+    fc.check_glu_epilogue_step(emu_lib, "cpu", d=256, heads=2, axes_dim=(32, 32, 32, 32), layers=1, single_layers=2)
+
+
 def test_flux2_dit_step_fp8(emu_lib):
     """every block linear on the MX fp8 kernel: bounded distance to the fp32 oracle"""
     fc.check_dit_step(emu_lib, "cpu", fp8=True)

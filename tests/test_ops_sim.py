@@ -128,6 +128,14 @@ def test_gemm_fp8_tile_kernel(emu_lib):
     oc.check_gemm_f8(emu_lib, abi.BF16, m=1024, n=1024, k=512, with_gate=True, flags=f)      # 16 tiles on 3 CUs: one left over -> tail + merge
 
 
+def test_gemm_fp8_gated_epilogue(emu_lib):
+    """SwiGLU + MX quantisation inside the fp8 GEMM's epilogue == fp8 GEMM -> SwiGLU quantiser, byte for byte (ragged m, rows and
+    bytes landing inside a wider operand buffer, ungated columns in front as in FLUX.2's fused single-block projection)"""
+    oc.check_gemm_f8_glu(emu_lib, abi.BF16, m=300, col0=0, hid=128, k=256)
+    oc.check_gemm_f8_glu(emu_lib, abi.BF16, m=260, col0=256, hid=256, k=128, row_off=5, q_col_off=128, seed=1, spread=1.5)
+    oc.check_gemm_f8_glu(emu_lib, abi.F16, m=256, col0=0, hid=128, k=384, seed=2)
+
+
 def test_swiglu(emu_lib):
     oc.check_swiglu(emu_lib, abi.BF16, rows=37, hid=72)
     oc.check_swiglu(emu_lib, abi.F16, rows=5, hid=384)
