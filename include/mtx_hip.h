@@ -140,6 +140,11 @@ typedef struct mtx_attn_args {
    * (MTX_ATTN_WORKSPACE_BYTES is always enough); NULL = never split */
   void* workspace; int64_t workspace_bytes;
   int32_t flags;                 /* MTX_ATTN_* bits */
+  /* MX fp8 output (long-sequence kernel only: d = 128, sq >= 1024, sk >= 256, batch 1): the rows leave as the e4m3 operand of the next
+   * linear — q8[row * ldq8 + head * 128 + ..] and one scale word per head and row, q8_scale[head * lds_q8 + row] — exactly what
+   * mtx_quantize_mx makes of the 16-bit output (rounded to `dtype` first); `o` may then be NULL.  (Built and checked on the CPU simulator
+   * in round 3; not yet run on hardware — FLUX.2 graphs do not use it by default.) */
+  void* q8; void* q8_scale; int64_t ldq8, lds_q8;
 } mtx_attn_args;
 /* q already carries scale * log2(e) (folded into the producer, e.g. the pre-scaled rotary table of MTX_EW_QK_NORM_ROPE): `scale`
  * is ignored, scores are used as base-2 logits as they come out of the matrix pipe.  The long-sequence kernel then seeds its score

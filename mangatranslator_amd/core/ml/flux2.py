@@ -82,7 +82,7 @@ class _W:
 
 
 class Flux2DiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=False):
+    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=False, attn_q8=False):
         """provider(name) -> tensor with diffusers' Flux2Transformer2DModel parameter of that name.
         fp8: False, True (= every block linear) or a tuple of names out of FP8_ALL."""
         self.lib = lib if lib is not None else get_library()
@@ -100,6 +100,9 @@ class Flux2DiTHip:
         # [T, 2 * hidden] projection, no SwiGLU-quantiser launch.  Bit-identical on the simulator; NOT yet run on hardware (round 3), so off
         # by default.  Needs every linear of the MLP on the fp8 path.
         self.glu_epilogue = bool(glu_epilogue) and all(k in self.fp8 for k in ("ff_in", "ff_out", "single_in", "single_out")) and (3 * D) % 256 == 0
+        # attn_q8: the joint attention writes the MX fp8 operand of the output projections itself (mtx_attn_args.q8; long-sequence kernel, so only
+        # for T >= 1024 and head dim 128) — with glu_epilogue no quantiser launch is left in a step.  Same status: simulator-verified, off by default.
+        self.attn_q8 = bool(attn_q8) and all(k in self.fp8 for k in ("out", "single_out")) and self.hd == 128
         if self.fp8 and (D % 128 or self.hid % 128):
             raise ModelError("FLUX.2 DiT fp8 path: d and the MLP width must be multiples of 128")
         g = lambda n, dt=None: provider(n).detach().to(self.device, dt if dt is not None else self.tdt).contiguous()
@@ -250,9 +253,11 @@ class Flux2DiTHip:
             e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 0, 1e-6, hd, H, self.dtype
             pb._add(abi.OP_EW, e, label)
 
-        def attention(src, ld, out_t, out_ld, label):
-            pb.attention(src, src, src, out_t, 1, H, T, T, hd, (0, ld, hd), (0, ld, hd), (0, ld, hd), (0, out_ld, hd),
-                         1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True)
+        aq8 = self.attn_q8 and f8 and T >= 1024
+
+        def attention(src, ld, out_t, out_ld, label, q8=None):
+            pb.attention(src, src, src, None if q8 is not None else out_t, 1, H, T, T, hd, (0, ld, hd), (0, ld, hd), (0, ld, hd), (0, out_ld, hd),
+                         1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True, q8=q8)
 
         def swiglu(src, ld, c0, r0, r1, dst, dst_ld, dst_c0, label, dst8=None, consumers=()):
             """silu(a) * b of the two halves of a fused projection.  With fp8 consumers: one pass that writes their MX fp8 operand
@@ -285,8 +290,8 @@ class Flux2DiTHip:
             pb.join()
             rope(qkv, t_txt, T, B["nqk"], 3 * D, tag + ".rope_qk")
             rope(qkv, 0, t_txt, B["cnqk"], 3 * D, tag + ".rope_qk_ctx")
-            attention(qkv, 3 * D, o, D, tag + ".attn")
-            if f8:
+            attention(qkv, 3 * D, o, D, tag + ".attn", q8=(o8[0], o8[1], D, lds, 0) if aq8 else None)
+            if f8 and not aq8:
                 quant(o, D, o8, 0, T, tag + ".attn.q")
             with pb.side():
                 linear(o, o8 if f8 else None, B["cout"], 0, t_txt, D, D, x, label=tag + ".to_add_out", **res_gate(8, t_txt))
@@ -312,10 +317,10 @@ class Flux2DiTHip:
             linear(nrm, nrm8 if f8 else None, S["fused"], 0, T, FW, D, big, label=tag + ".to_qkv_mlp",
                    **(dict(glu=(cat8[0], cat8[1], D + hid, lds, 3 * D, 0, D)) if self.glu_epilogue else {}))
             rope(big, 0, T, S["nqk"], FW, tag + ".rope_qk")
-            attention(big, FW, cat, D + hid, tag + ".attn")
+            attention(big, FW, cat, D + hid, tag + ".attn", q8=(cat8[0], cat8[1], D + hid, lds, 0) if aq8 else None)
             if not self.glu_epilogue:
                 swiglu(big, FW, 3 * D, 0, T, cat, D + hid, D, tag + ".swiglu", cat8 if f8 else None, (S["out"],))
-            if f8 and S["out"].q is not None:          # the attention half of the concatenation: its own quantiser pass over columns [0, D)
+            if f8 and S["out"].q is not None and not aq8:          # the attention half of the concatenation: its own quantiser pass over columns [0, D)
                 pb.quantize(cat, T, D, ldx=D + hid, q=cat8[0], scale=cat8[1], lds=lds, ldq=D + hid, label=tag + ".attn.q")
             linear(cat, cat8 if f8 else None, S["out"], 0, T, D, D + hid, x, label=tag + ".to_out", **res_gate(14, T))
         pb.norm(x, nrm, t_noise, D, eps=1e-6, kind=0, mod_scale=mod[15], mod_shift=mod[16], rows_per=t_noise, ldmod=D,

@@ -27,6 +27,8 @@ struct AttnParams {
   unsigned n_full, split;
   float* part_o; float* part_ml;
   int prescaled;                 // q carries scale * log2(e): scale_log2 == 1
+  // MX fp8 output of the long-sequence kernel (mtx_attn_args.q8): bytes [sq][ldq8] (head h at byte column h * d), scale words [heads * d / 128][lds_q8]
+  unsigned char* q8; unsigned* q8_scale; long ldq8, lds_q8;
 };
 
 constexpr int AT_KV = 64;      // keys per tile
@@ -436,179 +438,16 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
         oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
       }
 }
-// PRESCALED (MTX_ATTN_Q_PRESCALED, the FLUX graphs): q carries scale * log2(e); the S^T accumulators start at minus the running maximum
-// and no maximum is taken on the hot path (attn_bias_tile).  Otherwise the classic online softmax of attn_mma32_tile.
-template <typename T, int DP, bool PRESCALED>
-__global__ __launch_bounds__(512) void attn_mma32_kernel(AttnParams p) {
-  constexpr bool BIAS = PRESCALED;
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int KS = DP / 16;                  // k-steps of S^T
-  constexpr int DB = DP / 32;                  // 32-row blocks of O^T
-  constexpr int ROWB = DP * 2;                 // bytes per K / V row
-  constexpr int CPR = DP / 8;                  // 16-byte chunks per row
-  constexpr int TILE_B = AB_KV * ROWB;
-  constexpr int NLD = AB_KV * CPR / 512;       // chunks per thread per operand per tile
-  static_assert(DP == 128, "swizzles are written for 256-byte rows");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B];
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  unsigned vb, part = 0, nparts = 1;
-  if (blockIdx.x < p.n_full) vb = xcd_remap(blockIdx.x, p.n_full);
-  else { const unsigned i = blockIdx.x - p.n_full; vb = p.n_full + i / p.split; part = i % p.split; nparts = p.split; }
-  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
-  const long b = bh / p.heads, h = bh % p.heads;
-  const long q0 = qb * AB_QB + wv * 32;
-  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
-  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
-  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
-  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
-
-  // Q^T fragments (B operand: column = query l31, k = d 16*ks + 8*hi + j)
-  v8 qf[KS];
-  {
-    const long qr = q0 + l31;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
-      qf[ks] = __builtin_bit_cast(v8, raw);
-      if (BIAS) {                              // Q <- Q * scale * log2(e), rounded back to the storage type
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(to_f32(qf[ks][e]) * p.scale_log2);
-      }
-    }
-  }
-
-  f32x16 oacc[DB];
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-  float m_raw = BIAS ? 0.f : -1.0e30f, lsum = 0.f;     // BIAS: m_raw holds M in log2 units
-  const float c = p.scale_log2;
-  const float thr = 8.0f / c;                  // refresh the max when a row's tile max grows by > 2^8
-  f32x16 minit;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
-  bool first = true;
-
-  // ---- global -> register staging through buffer descriptors (no per-load predicates, no 64-bit VALU math)
-  const BufView kb_ = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
-  const BufView vb_ = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
-  unsigned kvoff[NLD], vvoff[NLD];
-  int ksw[NLD], vsw[NLD];
-#pragma unroll
-  for (int it = 0; it < NLD; ++it) {
-    const int idx = tid + it * 512;
-    const int ch = idx % CPR, row = idx / CPR;
-    kvoff[it] = (unsigned)((row * p.k_ss + ch * 8) * sizeof(T));
-    vvoff[it] = (unsigned)((row * p.v_ss + ch * 8) * sizeof(T));
-    ksw[it] = row * ROWB + ((ch ^ (row & 15)) << 4);
-    vsw[it] = TILE_B + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4);
-  }
-  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
-  u32x4 rk[NLD], rv[NLD];
-  auto load_tile = [&](long t) {
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      rk[it] = buf_load16(kb_, kvoff[it], (unsigned)t * k_step);
-      rv[it] = buf_load16(vb_, vvoff[it], (unsigned)t * v_step);
-    }
-  };
-  auto store_tile = [&](int stage) {
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      *reinterpret_cast<u32x4*>(smem + stage * 2 * TILE_B + ksw[it]) = rk[it];
-      *reinterpret_cast<u32x4*>(smem + stage * 2 * TILE_B + vsw[it]) = rv[it];
-    }
-  };
-
-  // ---- loop-invariant LDS fragment addresses (byte offsets inside a stage) ---------------------------------
-  // K: row l31 (+32*kb), chunk (2*ks + hi) ^ (l31 & 15)
-  int kaddr[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
-  // V^T by transpose reads: 16-lane group g1 covers d 16*g1..+15 of a 32-row block; lane i of the group
-  // addresses key 4*hi + (i>>2) (+ step base), d 4*(i&3)..+3; chunk swizzle 4*(key & 3) = 4*(i>>2)
-  int vaddr[DB];
-  {
-    const int ti = lane & 15, g1 = (lane >> 4) & 1;
-    const int vrow = hi * 4 + (ti >> 2);
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-      vaddr[d] = vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
-  }
-
-  const long ntiles_all = (p.sk + AB_KV - 1) / AB_KV;
-  const long t_begin = part * ntiles_all / nparts, ntiles = (part + 1) * ntiles_all / nparts;    // this workgroup's key tiles
-  const long kv_last = ntiles == ntiles_all ? p.sk - (ntiles_all - 1) * AB_KV : AB_KV;     // valid keys in its last tile
-  {
-#define ATTN_TILE(ST, RAG, KV) do { if constexpr (BIAS) attn_bias_tile<T, DP, ST, RAG, true>(smem, qf, oacc, m_raw, lsum, minit, first, kaddr, vaddr, KV, hi); \
-                                    else attn_mma32_tile<T, DP, ST, RAG>(smem, qf, oacc, m_raw, lsum, c, thr, kaddr, vaddr, KV, hi); } while (0)
-    load_tile(t_begin);
-    store_tile(0);
-    __syncthreads();
-    long t = t_begin;
-    // full tiles, two per iteration so the LDS stage is a compile-time constant
-    for (; t + 2 < ntiles; t += 2) {
-      load_tile(t + 1);
-      ATTN_TILE(0, false, AB_KV);
-      store_tile(1);
-      MTX_LDS_BARRIER();
-      load_tile(t + 2);
-      ATTN_TILE(1, false, AB_KV);
-      store_tile(0);
-      MTX_LDS_BARRIER();
-    }
-    // one or two tiles left; the very last one may be ragged
-    if (t + 2 == ntiles) {
-      load_tile(t + 1);
-      ATTN_TILE(0, false, AB_KV);
-      store_tile(1);
-      MTX_LDS_BARRIER();
-      if (kv_last < AB_KV) ATTN_TILE(1, true, kv_last);
-      else ATTN_TILE(1, false, AB_KV);
-    } else {
-      if (kv_last < AB_KV) ATTN_TILE(0, true, kv_last);
-      else ATTN_TILE(0, false, AB_KV);
-    }
-#undef ATTN_TILE
-  }
-
-  if (nparts > 1) {
-    // ---- key-split tail: leave the unnormalised O^T (fp32), the row maximum and the row sum for the merge kernel
-    const unsigned slot = blockIdx.x - p.n_full;
-    const int row = wv * 32 + l31;
-    float* PO = p.part_o + ((size_t)slot * AB_QB + row) * DP;
-    const float lrow = half_sum(lsum);
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 o = {oacc[d][g * 4 + 0], oacc[d][g * 4 + 1], oacc[d][g * 4 + 2], oacc[d][g * 4 + 3]};
-        *reinterpret_cast<f32x4*>(PO + d * 32 + g * 8 + hi * 4) = o;
-      }
-    if (hi == 0) { p.part_ml[((size_t)slot * AB_QB + row) * 2] = BIAS ? m_raw / c : m_raw; p.part_ml[((size_t)slot * AB_QB + row) * 2 + 1] = lrow; }
-    return;
-  }
-
-  // ---- finish: the two lane halves of a row add their partial sums; 4 consecutive d per store -----------
-  const float l = half_sum(lsum);
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  const long qr = q0 + l31;
-  if (qr < p.sq) {
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[d][g * 4 + r] * inv);
-        *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
-      }
-  }
-}
+#define ATTN_MMA32_NAME attn_mma32_kernel
+#define ATTN_MMA32_Q8 0
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_Q8
+#define ATTN_MMA32_NAME attn_mma32_q8_kernel
+#define ATTN_MMA32_Q8 1
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_Q8
 
 // merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
 template <typename T, int DP>
@@ -638,6 +477,43 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] *= inv;
     *reinterpret_cast<u32x4*>(O + qr * p.o_ss + ch * 8) = pack8<T>(acc);
+  }
+}
+
+// the same merge for the MX fp8 output (mtx_attn_args.q8): a thread owns 8 consecutive head-dim values of a row, 4 adjacent lanes one
+// 32-wide block, 16 adjacent lanes the head's 128 columns = one scale word — the lane roles of mx_quantize_chunk
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_merge_q8_kernel(AttnParams p) {
+  constexpr unsigned BANDS = AB_QB / 32;
+  static_assert(DP == 128, "one scale word per head and row");
+  const unsigned tail = blockIdx.x / BANDS, band = blockIdx.x % BANDS;
+  const unsigned vb = p.n_full + tail;
+  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
+  const long h = bh % p.heads;
+  for (int idx = threadIdx.x; idx < 32 * (DP / 8); idx += 256) {          // 512 items: two full passes, wave-uniform
+    const int row = band * 32 + idx / (DP / 8), ch = idx % (DP / 8);
+    const long qr = qb * AB_QB + row;
+    const bool valid = qr < p.sq;
+    float M = -1.0e30f;
+    for (unsigned s = 0; s < p.split; ++s) { const float m = p.part_ml[((size_t)(tail * p.split + s) * AB_QB + row) * 2]; M = m > M ? m : M; }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
+    for (unsigned s = 0; s < p.split; ++s) {
+      const size_t base = (size_t)(tail * p.split + s) * AB_QB + row;
+      const float w = fast_exp2((p.part_ml[base * 2] - M) * p.scale_log2);
+      L += w * p.part_ml[base * 2 + 1];
+      const float* po = p.part_o + base * DP + ch * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += w * po[e];
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = valid ? to_f32(from_f32<T>(acc[e] * inv)) : 0.f;
+    unsigned w0, w1, word;
+    mx_quantize_chunk(acc, ch, w0, w1, word);
+    if (valid) {
+      *reinterpret_cast<u32x2*>(p.q8 + (size_t)qr * p.ldq8 + h * DP + ch * 8) = u32x2{w0, w1};
+      if (ch == 0) p.q8_scale[(size_t)h * p.lds_q8 + qr] = word;
+    }
   }
 }
 
@@ -672,11 +548,18 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     const unsigned g = p.n_full + (total - p.n_full) * p.split;
     // schedules tried against this one and dropped (DESIGN.md §9 keeps the numbers): half-tile staggered wave groups, fragment reads
     // pinned 2-4 k-steps ahead, an S^T-pipelined LDS-DMA ring, 4 waves x 64 rows, two 128-query workgroups per CU — all equal or slower
+    if (p.q8 != nullptr) {
+      if (p.prescaled) MTX_LAUNCH((attn_mma32_q8_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+      else MTX_LAUNCH((attn_mma32_q8_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
+      if (p.split > 1) MTX_LAUNCH((attn_merge_q8_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
+      return MTX_OK;
+    }
     if (p.prescaled) MTX_LAUNCH((attn_mma32_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
     else MTX_LAUNCH((attn_mma32_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
     if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
     return MTX_OK;
   }
+  if (p.q8 != nullptr) return MTX_ERR_UNSUPPORTED;
   const unsigned grid = (unsigned)(p.batch * p.heads) * p.qblocks;
   if (p.d <= 32) MTX_LAUNCH((attn_kernel<T, 32>), dim3(grid), dim3(256), 0, stream, p);
   else if (p.d <= 64) MTX_LAUNCH((attn_kernel<T, 64>), dim3(grid), dim3(256), 0, stream, p);
@@ -686,7 +569,9 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
 }
 
 int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
-  if (!a->q || !a->k || !a->v || !a->o) { *err = "attention: null operand"; return MTX_ERR_INVALID; }
+  if (!a->q || !a->k || !a->v || (!a->o && !a->q8)) { *err = "attention: null operand"; return MTX_ERR_INVALID; }
+  if (a->q8 != nullptr && (!a->q8_scale || a->batch != 1 || a->d != 128 || a->sq < 1024 || a->sk < 256 || a->ldq8 % 16 || ((size_t)a->q8 & 15) || a->lds_q8 < a->sq)) {
+    *err = "attention (MX fp8 output): long-sequence kernel only (d = 128, sq >= 1024, sk >= 256, batch 1), ldq8 % 16 == 0, lds_q8 >= sq"; return MTX_ERR_INVALID; }
   if (a->d < 8 || a->d > 128 || a->d % 8) { *err = "attention: head dim must be a multiple of 8, <= 128"; return MTX_ERR_INVALID; }
   if (a->d % 4 || a->q_ss % 8 || a->k_ss % 8 || a->v_ss % 8 || a->o_ss % 4 || a->q_hs % 8 || a->k_hs % 8 || a->v_hs % 8 || a->o_hs % 4 ||
       a->q_bs % 8 || a->k_bs % 8 || a->v_bs % 8 || a->o_bs % 4) { *err = "attention: strides must keep 16-byte alignment"; return MTX_ERR_INVALID; }
@@ -700,6 +585,7 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   p.scale_log2 = p.prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
   p.n_full = 0; p.split = 1; p.part_o = nullptr; p.part_ml = nullptr;
+  p.q8 = reinterpret_cast<unsigned char*>(a->q8); p.q8_scale = reinterpret_cast<unsigned*>(a->q8_scale); p.ldq8 = a->ldq8; p.lds_q8 = a->lds_q8;
   if (a->workspace && a->workspace_bytes >= (int64_t)MTX_ATTN_WORKSPACE_BYTES) {      // 256 slots of [256][128] fp32 + [256][2] fp32
     p.part_o = reinterpret_cast<float*>(a->workspace);
     p.part_ml = p.part_o + (size_t)256 * AB_QB * 128;

@@ -48,7 +48,8 @@ class AttnArgs(C.Structure):
                 ("batch", i64), ("heads", i64), ("sq", i64), ("sk", i64), ("d", i64),
                 ("q_bs", i64), ("q_ss", i64), ("q_hs", i64), ("k_bs", i64), ("k_ss", i64), ("k_hs", i64),
                 ("v_bs", i64), ("v_ss", i64), ("v_hs", i64), ("o_bs", i64), ("o_ss", i64), ("o_hs", i64),
-                ("scale", f32), ("dtype", i32), ("workspace", vp), ("workspace_bytes", i64), ("flags", i32)]
+                ("scale", f32), ("dtype", i32), ("workspace", vp), ("workspace_bytes", i64), ("flags", i32),
+                ("q8", vp), ("q8_scale", vp), ("ldq8", i64), ("lds_q8", i64)]
 
 
 ATTN_Q_PRESCALED = 1

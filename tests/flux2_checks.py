@@ -99,6 +99,26 @@ def check_glu_epilogue_step(lib, device, h2=4, w2=6, t_txt=16, **kw):
     return nq
 
 
+def check_no_quantiser_step(lib, device, h2=22, w2=24, t_txt=16, **kw):
+    """a denoising step long enough for the long-sequence attention kernel (T >= 1024) with BOTH epilogue fusions — gated MLP-in GEMMs and
+    attention with MX fp8 output — against the step with the separate quantiser launches: identical velocity, and not one quantiser
+    launch (mtx_quantize_mx) left in the plan"""
+    from mangatranslator_amd.hip import abi
+    t, v = models(**kw)
+    lat, pe = step_inputs(t, h2, w2, h2, w2, t_txt)
+    vels, nq = [], []
+    for on in (False, True):
+        dit, _ = hip_models(t, v, lib, device, fp8=True, glu_epilogue=on, attn_q8=on)
+        assert dit.glu_epilogue == on and dit.attn_q8 == on
+        vel, plan = run_step(dit, lat, pe, h2, w2, h2, w2, 0.7, device)
+        assert plan.T >= 1024
+        vels.append(vel)
+        nq.append(sum(1 for o in plan.ops if o.kind == abi.OP_QUANT))
+    assert nq[0] > 0 and nq[1] == 0, nq
+    assert torch.equal(vels[0], vels[1]), f"epilogue fusions change the step: rel {rel(vels[1], vels[0]):.3e}"
+    return nq
+
+
 def check_vae(lib, device, h=64, w=96, tol=3e-2, **kw):
     t, v = models(**kw)
     _, vae = hip_models(t, v, lib, device)

@@ -191,6 +191,43 @@ def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, presc
     return err
 
 
+def check_attention_q8(lib, dtype, heads, sq, sk, seed=0, prescaled=True, col_off=0, extra_cols=0):
+    """the long-sequence attention kernel with MX fp8 output (mtx_attn_args.q8) against the two launches it replaces — the same kernel
+    into a 16-bit [sq, heads * 128] matrix, then mtx_quantize_mx — on the same operands: e4m3 bytes and scale words IDENTICAL, also for
+    the query blocks that go through the key-split tail (their rows are quantised by the merge kernel).  col_off / extra_cols: the
+    result lands inside a wider operand buffer (FLUX.2's single-block concatenation)."""
+    d = 128
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    scale = 1.0 / math.sqrt(d)
+    q = torch.randn(1, sq, heads, d, generator=g)
+    q = (q * (scale * 1.4426950408889634)).to(td) if prescaled else q.to(td)
+    k = torch.randn(1, sk, heads, d, generator=g).to(td)
+    v = (torch.randn(1, sk, heads, d, generator=g) * torch.exp(torch.randn(1, sk, heads, 1, generator=g))).to(td)
+    D = heads * d
+    ldq = col_off + D + extra_cols
+    lds = (sq + 63) // 64 * 64
+    outs = []
+    for fused in (False, True):
+        pb = PlanBuilder(lib, dev, dtype)
+        qt, kt, vt = pb.const(q), pb.const(k), pb.const(v)
+        q8 = pb.buf((sq, ldq), torch.uint8, zero=True)
+        sc = pb.buf((ldq // 128, lds), torch.int32, zero=True)
+        strides = ((sq * D, D, d), (sk * D, D, d), (sk * D, D, d), (sq * D, D, d))
+        if fused:
+            pb.attention(qt, kt, vt, None, 1, heads, sq, sk, d, *strides, scale, q_prescaled=prescaled, q8=(q8, sc, ldq, lds, col_off))
+        else:
+            o = pb.buf((sq, D), td, zero=True)
+            pb.attention(qt, kt, vt, o, 1, heads, sq, sk, d, *strides, scale, q_prescaled=prescaled)
+            pb.quantize(o, sq, D, q=q8, scale=sc, lds=lds, ldq=ldq, q_col_off=col_off)
+        _run(pb)
+        outs.append((q8.cpu().numpy().copy(), sc.cpu().numpy().copy()))
+    (q0, s0), (q1, s1) = outs
+    assert q0.any() and s0.any()
+    assert np.array_equal(q0, q1), f"attention with fp8 output: {(q0 != q1).sum()} of {q0.size} e4m3 bytes differ"
+    assert np.array_equal(s0, s1), f"attention with fp8 output: {(s0 != s1).sum()} scale words differ"
+
+
 def check_norm(lib, dtype, rows, c, kind=0, affine=True, modulate=False, seed=0):
     g = torch.Generator().manual_seed(seed)
     dev, td = _dev(lib), TD[dtype]

@@ -16,6 +16,12 @@ def test_flux2_gated_epilogue_step_is_identical(emu_lib):
     fc.check_glu_epilogue_step(emu_lib, "cpu", d=256, heads=2, axes_dim=(32, 32, 32, 32), layers=1, single_layers=2)
 
 
+def test_flux2_step_without_a_quantiser_launch(emu_lib):
+    """both epilogue fusions at a sequence length that takes the long-sequence attention kernel (T = 1072): same velocity bits, zero
+    mtx_quantize_mx launches in the step"""
+    fc.check_no_quantiser_step(emu_lib, "cpu", d=256, heads=2, axes_dim=(32, 32, 32, 32), layers=1, single_layers=1)
+
+
 def test_flux2_dit_step_fp8(emu_lib):
     """every block linear on the MX fp8 kernel: bounded distance to the fp32 oracle"""
     fc.check_dit_step(emu_lib, "cpu", fp8=True)

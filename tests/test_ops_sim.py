@@ -102,6 +102,13 @@ def test_attention_prescaled_q(emu_lib):
     oc.check_attention(emu_lib, abi.BF16, batch=1, heads=2, sq=100, sk=130, d=64, prescaled=True)
 
 
+def test_attention_fp8_output(emu_lib):
+    """the long-sequence kernel writing the MX fp8 operand of the next linear (mtx_attn_args.q8) == the same kernel -> mtx_quantize_mx, byte
+    for byte and scale word for scale word; 10 query blocks on 3 simulated CUs: one goes through the key-split tail + the quantising merge"""
+    oc.check_attention_q8(emu_lib, abi.BF16, heads=2, sq=1030, sk=330)
+    oc.check_attention_q8(emu_lib, abi.F16, heads=1, sq=1024, sk=256, prescaled=False, col_off=128, extra_cols=128, seed=1)
+
+
 def test_gemm_256_tile_kernel(emu_lib):
     """the 256 x 256 LDS-DMA kernel (normally used from 24 tiles up) on ragged small problems: ping-pong loop with descriptor-based
     LDS-DMA (range-checked zero fill), pieces spread 3/3/2/0"""
