@@ -54,3 +54,19 @@ def test_two_ranks_on_one_device():
                 "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env={"MTX_BENCH_ONE_DEVICE": "1"}, timeout=900)
     assert rep["n_gpus"] == 2 and rep["config"]["launch"]["world_size_seen_by_collectives"] == 2 and rep["config"]["launch"]["self_launched"]
     assert rep["value"] > 0 and rep["scaling"] == "weak"
+
+
+def test_hardware_queue_choice(monkeypatch):
+    """bench.py asks ROCm for eight hardware queues only for the stage sets without diffusion / upscaling (measured: helps the detect
+    stage's five model streams, costs config 5 — DESIGN.md §6), before torch is imported, and never overrides the caller's value"""
+    sys.path.insert(0, str(ROOT))
+    import importlib
+    bench = importlib.import_module("bench")
+    for argv, want in ((["--config", "2"], "8"), (["--config=1", "--steps", "3"], "8"), (["--stages", "detect"], "8"), ([], None), (["--config", "5"], None),
+                       (["--config", "3"], None), (["--stages", "upscale"], None), (["--gpus", "8", "--steps", "5", "--warmup", "2"], None)):
+        monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+        bench._early_hw_queues(argv)
+        assert os.environ.get("GPU_MAX_HW_QUEUES") == want, (argv, os.environ.get("GPU_MAX_HW_QUEUES"))
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    bench._early_hw_queues(["--config", "2"])
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "2"
