@@ -22,6 +22,29 @@ def test_tap_tables_reproduce_pillow_on_an_impulse():
             assert np.array_equal(mine, ref), (n_in, n_out, filt, pos)
 
 
+def test_tap_tables_over_many_geometries():
+    """the tables alone (no kernel): a numpy evaluation of one resampling pass — int32 accumulation from 2^21, >> 22, clip — over 120
+    random (in, out) size pairs and the three filters equals Pillow's horizontal and vertical passes on a random strip; catches the
+    rounding of the window bounds and of the normalised taps at sizes the kernel tests do not visit (1-pixel axes, 3x up, 7.3x down)"""
+    rng = np.random.default_rng(11)
+    filters = (("lanczos", Image.Resampling.LANCZOS), ("bilinear", Image.Resampling.BILINEAR), ("bicubic", Image.Resampling.BICUBIC))
+    pairs = [(1, 1), (1, 7), (7, 1), (2, 3), (3, 2), (100, 300), (300, 41), (41, 300), (1023, 1024), (1024, 1023), (640, 88)]
+    pairs += [(int(a), int(b)) for a, b in zip(rng.integers(1, 700, 109), rng.integers(1, 700, 109))]
+    for i, (n_in, n_out) in enumerate(pairs):
+        name, pil_f = filters[i % 3]
+        bounds, taps, ksize = pil_resample_tables(n_in, n_out, name)
+        strip = rng.integers(0, 256, (3, n_in), dtype=np.uint8)
+        strip[1] = np.where(np.arange(n_in) % 5 < 2, 255, 0)                 # hard edges: ringing into the clip
+        idx = np.clip(bounds[:, :1] + np.arange(ksize)[None, :], 0, n_in - 1)                       # [out, ksize]
+        valid = np.arange(ksize)[None, :] < bounds[:, 1:2]
+        acc = (strip[:, idx].astype(np.int64) * np.where(valid, taps, 0)[None]).sum(-1) + (1 << 21)
+        mine = np.clip(acc >> 22, 0, 255).astype(np.uint8)
+        ref_h = np.asarray(Image.fromarray(strip, "L").resize((n_out, 3), pil_f))
+        assert np.array_equal(mine, ref_h), (n_in, n_out, name, "horizontal")
+        ref_v = np.asarray(Image.fromarray(np.ascontiguousarray(strip.T), "L").resize((3, n_out), pil_f))
+        assert np.array_equal(mine.T, ref_v), (n_in, n_out, name, "vertical")
+
+
 def test_resize_is_pillow_bit_for_bit(emu_lib):
     dc.check_resize(emu_lib, [((64, 48, 3), (37, 29), "lanczos"), ((37, 29, 3), (64, 48), "lanczos"), ((50, 40, 3), (50, 23), "lanczos"),
                               ((50, 40, 3), (81, 40), "lanczos"), ((33, 21, 1), (16, 16), "lanczos"), ((45, 30, 3), (20, 41), "bilinear"),
