@@ -108,9 +108,9 @@ def parse():
                          "run through the same stages, results downloaded, PNG-encoded and written (SURVEY.md §8d: decode / encode reported "
                          "separately, never part of `value`); reported under config.batch_io")
     ap.add_argument("--io-threads", type=int, default=None, help="decoder / encoder threads of the batch harness per rank (default: host cores / ranks / 4, 2..8)")
-    ap.add_argument("--glu-epilogue", action="store_true",
-                    help="FLUX.2-Klein fp8 path: SwiGLU + MX quantisation inside the MLP-in GEMMs and MX fp8 output of the attention kernel (mtx_gemm_args.glu_*, mtx_attn_args.q8; simulator-verified in round 3, "
-                         "not yet run on hardware: off by default)")
+    ap.add_argument("--no-glu-epilogue", action="store_true",
+                    help="FLUX.2-Klein fp8 path, for A/Bs: separate SwiGLU / attention-output quantiser launches instead of the epilogue fusions "
+                         "(mtx_gemm_args.glu_*, mtx_attn_args.q8) that are the default since round 4")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--time-ops", default="auto", choices=["auto", "difference", "stamp"],
                     help="in-context kernel timing of the roofline objects: hipGraph with minus hipGraph without the ops (HIP events), "
@@ -329,7 +329,7 @@ def main():
             from mangatranslator_amd.core.ml import flux as fx
             from mangatranslator_amd.core.ml import flux2 as f2
             dcfg = f2.KLEIN_9B_DIT_CFG if args.inpainter == "klein_9b" else f2.KLEIN_4B_DIT_CFG
-            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8, fused_quant=not args.no_fused_quant, glu_epilogue=args.glu_epilogue, attn_q8=args.glu_epilogue)
+            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8, fused_quant=not args.no_fused_quant, glu_epilogue=not args.no_glu_epilogue, attn_q8=not args.no_glu_epilogue)
             vae = f2.Flux2VAEHip(fx.synthetic_provider(f2.vae_param_shapes(f2.KLEIN_VAE_CFG), device, 22, broadcast=world > 1), f2.KLEIN_VAE_CFG, device, lib=lib)
             flux = f2.Flux2KleinHip(dit, vae, graph=graph)
             flux.set_prompt_embeds(torch.randn(512, dcfg["joint_dim"], generator=torch.Generator().manual_seed(23)))     # cached Qwen3 states (stand-ins)

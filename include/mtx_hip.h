@@ -36,7 +36,7 @@ extern "C" {
 #define MTX_API
 #endif
 
-#define MTX_ABI_VERSION 4
+#define MTX_ABI_VERSION 5
 
 typedef enum mtx_status {
   MTX_OK = 0,
@@ -382,7 +382,7 @@ typedef struct mtx_tail_args {
   int32_t out_h, out_w, c;
   int64_t ld_src, ld_dst;
   const int32_t* bounds; const int32_t* coeff; int32_t ksize, axis, src_row0;                 /* RESAMPLE */
-  const float* alpha; int64_t ld_alpha; int32_t x, y, page_c;                                  /* COMPOSITE (ld_alpha in floats) */
+  const float* alpha; int64_t ld_alpha; int32_t x, y, page_c, src_c;                           /* COMPOSITE (ld_alpha in floats; c = channels blended, src_c = bytes per patch pixel, 0 = c) */
   const int32_t* gamma_tab; const int32_t* cbrt_tab; const int32_t* lab_coef; int32_t cbrt_n; /* LAB_* */
   const uint8_t* mask; int64_t ld_mask; const void* other; int64_t ld_other;
   unsigned long long* sums; const float* params;

@@ -177,7 +177,7 @@ class DeviceTail:
         a = abi.TailArgs()
         a.kind, a.src, a.dst = abi.TAIL_COMPOSITE, patch.data_ptr(), page.data_ptr()
         a.out_h, a.out_w, a.c, a.ld_src, a.ld_dst = h, w, min(patch.shape[2], page.shape[2]), patch.shape[1] * patch.shape[2], page.shape[1] * page.shape[2]
-        a.alpha, a.ld_alpha, a.x, a.y, a.page_c = alpha.data_ptr(), alpha.shape[1], x, y, page.shape[2]
+        a.alpha, a.ld_alpha, a.x, a.y, a.page_c, a.src_c = alpha.data_ptr(), alpha.shape[1], x, y, page.shape[2], patch.shape[2]
         self._run(a)
         return page
 

@@ -138,6 +138,17 @@ def composite_u8(page: np.ndarray, patch: np.ndarray, alpha: np.ndarray, x: int,
     return out
 
 
+
+def _opaque_for_device_resize(crop: Image.Image) -> bool:
+    """The device resize works on RGB bytes.  Pillow resizes an image with an alpha band on PREMULTIPLIED colours (reference and host path:
+    resize first, convert afterwards), so convert-then-resize equals it only while every pixel is opaque; L / RGB crops have no alpha."""
+    if crop.mode in ("RGB", "L"):
+        return True
+    if crop.mode == "RGBA":
+        return crop.getchannel("A").getextrema()[0] == 255
+    return False
+
+
 class FluxKontextInpainter:
     def __init__(self, device: Optional[torch.device] = None, huggingface_token: str = "", num_inference_steps: int = 8,
                  residual_diff_threshold: float = 0.15, backend: str = "nunchaku", low_vram: bool = False,
@@ -175,6 +186,7 @@ class FluxKontextInpainter:
     def unload_models(self):
         self.pipeline = None
         self._prompt_embeds = None
+        self._tail = None               # the DeviceTail belongs to the unloaded pipeline's device / library
         self.manager.unload_flux_kontext_sdnq_models()
 
     # ---- geometry -----------------------------------------------------------------------------------
@@ -248,7 +260,7 @@ class FluxKontextInpainter:
         if patch is not None:
             log_message("  - Using cached inpainting patch", verbose=verbose)
             return Image.fromarray(composite_u8(np.asarray(image_pil), np.asarray(patch), alpha, x, y))
-        tail = self._device_tail()
+        tail = self._device_tail() if _opaque_for_device_resize(crop) else None      # translucent crops: the host path (premultiplied resize)
         if tail is not None:
             # LANCZOS to the preferred Kontext resolution, the pipeline, LANCZOS back and the composite without leaving HBM
             # (core/image/device_tail.py: Pillow's resize and the composite bit for bit)
@@ -257,6 +269,10 @@ class FluxKontextInpainter:
             inf_w, inf_h = nearest_preferred_resolution(w, h, self.PREFERED_KONTEXT_RESOLUTIONS) if w and h else (w, h)
             scaled = tail.resize(crop_dev, (inf_w, inf_h), "lanczos")
             with self.manager.flux_inference_lock:
+                self.load_models()
+                if self.pipeline is None:
+                    log_message("Warning: Flux Kontext pipeline not available. Skipping inpainting.", always_print=True)
+                    return image_pil
                 with torch.inference_mode():
                     gen = torch.Generator(device="cpu").manual_seed(seed)
                     out = self.pipeline(image=scaled, width=inf_w, height=inf_h, num_inference_steps=self.num_inference_steps,
@@ -437,6 +453,7 @@ class FluxKleinInpainter:
     def unload_models(self):
         self.pipeline = None
         self._prompt_embeds = None
+        self._tail = None
         self.manager.unload_flux_klein_models()
 
     # ---- geometry (reference :1126-1163, 1258-1313) ----------------------------------------------------------------
@@ -573,7 +590,7 @@ class FluxKleinInpainter:
             cy1, cy2 = max(0, min(img_h, cy1)), max(0, min(img_h, cy2))
             clip_rect = (max(0, cx1 - x), max(0, cy1 - y), min(w, cx2 - x), min(h, cy2 - y))
         generated_now = patch is None
-        tail = self._device_tail() if patch is None else None
+        tail = self._device_tail() if patch is None and _opaque_for_device_resize(crop) else None     # translucent crops: the host path
         if tail is not None:
             # the whole chain around the pipeline stays in HBM (core/image/device_tail.py): the feather weight from the mask (exact EDT in
             # a window of the blur radius), LANCZOS to the inference size, the pipeline, LANCZOS back, the luminance match and the

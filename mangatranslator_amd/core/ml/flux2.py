@@ -82,7 +82,7 @@ class _W:
 
 
 class Flux2DiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=False, attn_q8=False):
+    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=True, attn_q8=True):
         """provider(name) -> tensor with diffusers' Flux2Transformer2DModel parameter of that name.
         fp8: False, True (= every block linear) or a tuple of names out of FP8_ALL."""
         self.lib = lib if lib is not None else get_library()
@@ -97,11 +97,12 @@ class Flux2DiTHip:
         self.fp8 = FP8_ALL if fp8 is True else tuple(fp8 or ())
         self.fused_quant = fused_quant      # norms and SwiGLU write the fp8 linears' operands themselves; False: separate quantiser passes (round 2's form, for A/Bs)
         # glu_epilogue: the MLP-in linears' fp8 GEMM applies SwiGLU and writes the MX fp8 operand of MLP-out itself (mtx_gemm_args.glu_*): no
-        # [T, 2 * hidden] projection, no SwiGLU-quantiser launch.  Bit-identical on the simulator; NOT yet run on hardware (round 3), so off
-        # by default.  Needs every linear of the MLP on the fp8 path.
+        # [T, 2 * hidden] projection, no SwiGLU-quantiser launch.  Bit-identical to the separate launches on the simulator and on gfx950 at Klein's
+        # shapes (tests/test_ops_gpu.py::test_gemm_f8_glu_epilogue); default since round 4 (DiT step 52.3 -> 48.9 ms with both fusions).
+        # Needs every linear of the MLP on the fp8 path; False = the separate launches, for A/Bs.
         self.glu_epilogue = bool(glu_epilogue) and all(k in self.fp8 for k in ("ff_in", "ff_out", "single_in", "single_out")) and (3 * D) % 256 == 0
         # attn_q8: the joint attention writes the MX fp8 operand of the output projections itself (mtx_attn_args.q8; long-sequence kernel, so only
-        # for T >= 1024 and head dim 128) — with glu_epilogue no quantiser launch is left in a step.  Same status: simulator-verified, off by default.
+        # for T >= 1024 and head dim 128) — with glu_epilogue no quantiser launch is left in a step (tests/test_ops_gpu.py::test_attention_mx_fp8_output).
         self.attn_q8 = bool(attn_q8) and all(k in self.fp8 for k in ("out", "single_out")) and self.hd == 128
         if self.fp8 and (D % 128 or self.hid % 128):
             raise ModelError("FLUX.2 DiT fp8 path: d and the MLP width must be multiples of 128")

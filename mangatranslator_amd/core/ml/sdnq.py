@@ -15,7 +15,7 @@ the flattened tensor), `scale`, optional `zero_point`, optional `svd_up` / `svd_
 `quantization_config` in config.json (`weights_dtype`, overridden per module by `modules_dtype_dict`).  Everything here is driven by
 the SHAPES found in the file (packed element count vs the logical shape gives the bit width, the scale's shape gives the grouping),
 so a mismatch with the real format fails loudly (`ModelError`) instead of producing wrong weights silently; the arithmetic is
-covered by a round-trip test against a writer that follows the same published layout (tests/test_sdnq.py) — that test cannot
+covered by a round-trip test against a writer that follows the same published layout (tests/test_checkpoint_readiness.py) — that test cannot
 vouch for the provenance, only for self-consistency.  tools/pin_oracles.py --models is where a real checkpoint gets compared.
 """
 import json
@@ -40,8 +40,11 @@ def unpack_bits(packed: torch.Tensor, bits: int, count: int) -> torch.Tensor:
         out = ((p[:, None] >> shifts[None, :]) & ((1 << bits) - 1)).reshape(-1)
     else:
         raise ModelError(f"SDNQ: {bits}-bit packing is not supported (uint8 / 4 / 2 / 1)")
-    if out.numel() < count:
-        raise ModelError(f"SDNQ: packed tensor holds {out.numel()} values, {count} expected")
+    need = (count * bits + 7) // 8
+    if p.numel() != need:
+        # over-supply is as wrong as under-supply: a 4-bit reading of an 8-bit tensor would otherwise take its first nibbles silently
+        raise ModelError(f"SDNQ: {p.numel()} packed bytes for {count} values of {bits} bits ({need} bytes expected) — the configured bit "
+                         f"width does not match the stored tensor")
     return out[:count]
 
 
@@ -74,6 +77,9 @@ def dequantize(weight: torch.Tensor, scale: torch.Tensor, shape: Tuple[int, ...]
             bits = weight.numel() * 8 // count
         else:
             raise ModelError(f"SDNQ: cannot tell the bit width of a {tuple(weight.shape)} {weight.dtype} tensor for logical shape {tuple(shape)}")
+    elif weight.dtype in (torch.int8, torch.uint8) and weight.numel() != (count * bits + 7) // 8:
+        raise ModelError(f"SDNQ: config says {bits}-bit weights but a {tuple(weight.shape)} {weight.dtype} tensor for logical shape "
+                         f"{tuple(shape)} holds {weight.numel() * 8 / count:g} bits per value")
     q = unpack_bits(weight.view(torch.uint8) if weight.dtype == torch.int8 else weight, bits, count).to(torch.float32)
     if zero_point is None:
         q = q - float(1 << (bits - 1))                               # symmetric types are stored offset by half their range

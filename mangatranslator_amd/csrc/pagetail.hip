@@ -73,11 +73,12 @@ __global__ __launch_bounds__(256) void tail_composite_kernel(mtx_tail_args p) {
   const long total = (long)p.out_h * p.out_w;
   const uint8_t* S = reinterpret_cast<const uint8_t*>(p.src);
   uint8_t* D = reinterpret_cast<uint8_t*>(p.dst);
+  const int src_c = p.src_c > 0 ? p.src_c : p.c;                               // a patch with more channels than the page blends its first c
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int py = (int)(idx / p.out_w), px = (int)(idx % p.out_w);
     const float a = p.alpha[(long)py * p.ld_alpha + px];
     const float one_minus = rn_add(1.0f, -a);
-    const uint8_t* s = S + ((long)py * p.ld_src + (long)px * p.c);
+    const uint8_t* s = S + ((long)py * p.ld_src + (long)px * src_c);
     uint8_t* d = D + ((long)(p.y + py) * p.ld_dst + (long)(p.x + px) * p.page_c);
     for (int c = 0; c < p.page_c; ++c) {
       const float sv = c < p.c ? rn_div((float)s[c], 255.0f) : 1.0f;           // a page with more channels than the patch: opaque source alpha
@@ -241,7 +242,7 @@ int tail_launch(const mtx_tail_args* a, void* stream, const char** err) {
       MTX_LAUNCH(tail_resample_kernel, grid, block, 0, stream, *a);
       return MTX_OK;
     case MTX_TAIL_COMPOSITE:
-      if (!a->alpha || a->page_c < a->c || a->page_c > 4 || a->x < 0 || a->y < 0) { *err = "page tail (composite): alpha / page channels / origin"; return MTX_ERR_INVALID; }
+      if (!a->alpha || a->page_c < a->c || a->page_c > 4 || a->x < 0 || a->y < 0 || (a->src_c != 0 && a->src_c < a->c)) { *err = "page tail (composite): alpha / page channels / origin"; return MTX_ERR_INVALID; }
       MTX_LAUNCH(tail_composite_kernel, grid, block, 0, stream, *a);
       return MTX_OK;
     case MTX_TAIL_LAB_STATS:

@@ -34,12 +34,14 @@ def check_composite(lib, seed=0):
     dev = _dev(lib)
     tail = DeviceTail(lib, dev)
     rng = np.random.default_rng(seed)
-    for page_c, (ph, pw), (h, w), (x, y) in ((3, (90, 120), (40, 56), (30, 20)), (4, (64, 64), (32, 48), (16, 40)), (3, (50, 70), (30, 30), (60, 35))):
+    # page_c 1 = an "L" page under an RGB patch (the patch is read with ITS pixel stride, its first channel is blended)
+    for page_c, (ph, pw), (h, w), (x, y) in ((3, (90, 120), (40, 56), (30, 20)), (4, (64, 64), (32, 48), (16, 40)), (3, (50, 70), (30, 30), (60, 35)),
+                                             (1, (64, 64), (32, 48), (16, 40)), (2, (40, 50), (20, 20), (35, 10))):
         page = rng.integers(0, 256, (ph, pw, page_c), dtype=np.uint8)
         patch = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         alpha = np.clip(rng.normal(0.5, 0.5, (h, w)), 0, 1).astype(np.float32)
         alpha[:5] = 1.0; alpha[-5:] = 0.0
-        ref = ip.composite_u8(page, patch, alpha, x, y)
+        ref = ip.composite_u8(page[..., 0] if page_c == 1 else page, patch, alpha, x, y).reshape(page.shape)
         got = tail.composite(torch.from_numpy(page.copy()).to(dev), torch.from_numpy(patch).to(dev), torch.from_numpy(alpha).to(dev), x, y).cpu().numpy()
         assert np.array_equal(got, ref), f"composite on a {page_c}-channel page: {(got != ref).sum()} bytes differ"
 

@@ -59,6 +59,23 @@ def test_sdnq_round_trip(bits, group, asym, rank):
     assert torch.equal(sdnq.unpack_bits(sdnq.pack_bits(q, bits), bits, 1001), q)
 
 
+def test_sdnq_bit_width_from_the_config_must_match_the_tensor():
+    """a config that names uint4 for a module stored in 8 bits (a `modules_dtype_dict` pattern that did not match) must raise,
+    not return the first nibbles"""
+    w = torch.randn(16, 64, generator=torch.Generator().manual_seed(3))
+    parts = _quantize_like_sdnq(w, 8, 32, True, 0)
+    ok = sdnq.dequantize(parts["weight"], parts["scale"], (16, 64), parts.get("zero_point"), bits=8)
+    assert ok.shape == (16, 64)
+    for wrong in (4, 2):
+        with pytest.raises(ModelError):
+            sdnq.dequantize(parts["weight"], parts["scale"], (16, 64), parts.get("zero_point"), bits=wrong)
+    p4 = _quantize_like_sdnq(w, 4, 32, True, 0)
+    with pytest.raises(ModelError):
+        sdnq.dequantize(p4["weight"], p4["scale"], (16, 64), p4.get("zero_point"), bits=8)
+    with pytest.raises(ModelError):
+        sdnq.unpack_bits(torch.zeros(9, dtype=torch.uint8), 4, 16)          # one byte too many
+
+
 def test_sdnq_shards_through_the_flux_provider(tmp_path):
     """a diffusers sub-folder with one packed linear, one plain bf16 linear and a bias: the manager's provider hands out bf16 tensors
     of the logical shapes, the packed one within quantisation error of the original; a folder whose packed element count does not fit

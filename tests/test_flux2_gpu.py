@@ -68,4 +68,4 @@ def test_klein_step_without_quantiser_launch(hip_lib):
     quantiser launches, and no mtx_quantize_mx launch is left in the plan."""
     f2c.check_no_quantiser_step(hip_lib, "cuda:0", h2=32, w2=32, t_txt=16, d=3072, heads=24, axes_dim=(32, 32, 32, 32), layers=1, single_layers=2,
                                 joint_dim=7680)
-    f2c.check_glu_epilogue_step(hip_lib, "cuda:0")
+    f2c.check_glu_epilogue_step(hip_lib, "cuda:0", d=256, heads=2, axes_dim=(32, 32, 32, 32), layers=1, single_layers=2)
