@@ -103,8 +103,8 @@ typedef struct mtx_gemm_args {
   int32_t gate_rows_per;
   int32_t act; float act_param; float alpha;   /* acc *= alpha before bias */
   int32_t dtype; int32_t out_dtype;            /* out_dtype: MTX_BF16/F16 (=dtype) or MTX_F32 */
-  /* optional scratch for the 256-tile kernel's stream-K tail (fp32 partial tiles); NULL = never split.
-   * MTX_GEMM_WORKSPACE_BYTES is always enough (2 pieces per CU, up to 320 CUs). */
+  /* optional scratch for the 256-tile kernel's K-slice tail (fp32 partial tiles + one ticket per tile in its last 4 KiB); NULL = never
+   * split.  MTX_GEMM_WORKSPACE_BYTES exactly; ZEROED ONCE by the caller — the library leaves the tickets at zero after every launch. */
   void* workspace; int64_t workspace_bytes;
   /* in_dtype == MTX_F8 (the CDNA4 fp8 path, BASELINE.json config 5): a and w are e4m3 bytes ([M, K] / [N, K], lda / ldw in
    * elements = bytes) with MX scale planes as written by mtx_quantize_mx: a_scale[(k / 128) * lds_a + m], w_scale[(k / 128) *
@@ -123,7 +123,8 @@ typedef struct mtx_gemm_args {
   void* glu_q; void* glu_scale; int64_t glu_ldq, glu_lds, glu_col0;
 } mtx_gemm_args;
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
-#define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the stream-K tail */
+#define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the K-slice tail */
+#define MTX_GEMM_OLD_TAIL 4        /* round 3's stream-K tail + merge launch instead of the K-slice tail (A/B only; goes when the A/B is settled) */
 #define MTX_GEMM_WORKSPACE_BYTES (2 * 320 * 256 * 256 * 4)
 
 /* softmax(scale * Q K^T) V, non-causal, one launch for [batch, heads].
@@ -422,6 +423,9 @@ MTX_API int mtx_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_
 MTX_API int mtx_conv2d(const mtx_conv2d_args* a, void* stream);
 MTX_API int mtx_conv2d_tiles(const mtx_conv2d_args* a);   /* spatial tiles per image (chan_sum rows) */
 MTX_API int mtx_gemm(const mtx_gemm_args* a, void* stream);
+/* how THIS THREAD's last 256-tile GEMM launch was cut (test / tooling introspection): tiles computed whole, K slices of the left-over
+ * tiles (1 = none) and the number of (slice, tile) pieces of the K-slice tail */
+MTX_API int mtx_gemm_last_split(int* whole_tiles, int* k_slices, int* tail_pieces);
 MTX_API int mtx_attention(const mtx_attn_args* a, void* stream);
 MTX_API int mtx_norm(const mtx_norm_args* a, void* stream);
 MTX_API int mtx_groupnorm(const mtx_groupnorm_args* a, void* stream);

@@ -77,12 +77,14 @@ def window_order(hs: int, ws_: int, win: int) -> np.ndarray:
 
 
 class Sam2Hip:
-    def __init__(self, state_dict: dict, config, device="cuda", lib=None, graph: bool = True):
+    def __init__(self, state_dict: dict, config, device="cuda", lib=None, graph: bool = True, dtype: int = abi.BF16):
         self.lib = lib if lib is not None else get_library()
         self.device = torch.device(device)
         self.hp = hiera_hparams(config)
-        self.dtype = abi.BF16
-        self.tdt = torch.bfloat16
+        if dtype not in (abi.BF16, abi.F16):
+            raise ModelError("SAM-2: storage dtype must be bf16 or f16")
+        self.dtype = dtype
+        self.tdt = torch.bfloat16 if dtype == abi.BF16 else torch.float16
         self._graph = graph and not self.lib.is_simulator
         self._lane = AsyncLane(self.device, self.lib.is_simulator)
         self._enc = None

@@ -15,6 +15,7 @@ namespace mtx {
 int conv2d_launch(const mtx_conv2d_args*, void*, const char**);
 int conv2d_tiles(const mtx_conv2d_args*);
 int gemm_launch(const mtx_gemm_args*, void*, const char**);
+void gemm_last_split(int*);
 int attn_launch(const mtx_attn_args*, void*, const char**);
 int norm_launch(const mtx_norm_args*, void*, const char**);
 int groupnorm_launch(const mtx_groupnorm_args*, void*, const char**);
@@ -233,6 +234,15 @@ MTX_OP_ENTRY(mtx_bubble_clean, mtx_clean_args, clean_launch)
 MTX_OP_ENTRY(mtx_detr, mtx_detr_args, detr_launch)
 MTX_OP_ENTRY(mtx_quantize_mx, mtx_quant_args, quant_launch)
 MTX_OP_ENTRY(mtx_page_tail, mtx_tail_args, tail_launch)
+
+int mtx_gemm_last_split(int* whole_tiles, int* k_slices, int* tail_pieces) {
+  int v[3];
+  gemm_last_split(v);
+  if (whole_tiles) *whole_tiles = v[0];
+  if (k_slices) *k_slices = v[1];
+  if (tail_pieces) *tail_pieces = v[2];
+  return MTX_OK;
+}
 
 int mtx_conv2d_tiles(const mtx_conv2d_args* a) {
   if (!a) return fail(MTX_ERR_INVALID, "mtx_conv2d_tiles: null args");

@@ -25,6 +25,9 @@ struct GemmParams {
   unsigned tiles_m, tiles_n;
   // stream-K tail: tiles [n_full, tiles) are cut into `units` equal runs of K iterations; fp32 partials in `part`
   unsigned n_full, units; float* part;
+  // K-slice tail (round 4): tiles [n_full, tiles) x `slices` equal K ranges of `slice_len` iterations; piece (slice j, tail tile t) keeps
+  // its fp32 partial in slot j * rem + t of `part`; `tickets[t]` counts the finished slices of tile t (zero between launches)
+  unsigned slices, slice_len; unsigned* tickets;
   // fp8 path (in_dtype == MTX_F8): MX scale planes, one uint32 (4 E8M0 bytes) per row and 128 k
   const unsigned* a_scale; const unsigned* w_scale; long lds_a, lds_w;
   int bk;           // K elements per LDS stage row: 64 (16-bit operands) or 128 (fp8); a row is 128 bytes either way
@@ -756,6 +759,82 @@ __global__ __launch_bounds__(256) void gemm256_merge_kernel(GemmParams p) {
     *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = pack8<T>(f);
   }
 }
+// ---- K-slice tail with a last-arriver fix-up (round 4) ---------------------------------------------------------------------
+// The stream-K tail above deals out the left-over tiles' iterations evenly, so no two of its units ever read the same operand rows at the
+// same time: 2.45 GB fetched per 8812 x 3072 x 15360 launch (PMC, profiles/r03_pmc_traffic.json) at 9 TB/s — the tail ran at the fabric's
+// limit, not the matrix pipe's (MFMA busy 0.36) — and a second launch (merge) summed the pieces.  Here every left-over tile is cut at
+// the SAME K positions into `slices` pieces; piece p = (slice p / rem, tile p % rem), and the XCD-contiguous workgroup order gives an
+// XCD a run of neighbouring tiles of ONE slice, which walk K in step and share their A / W panels through that XCD's L2 like the
+// whole-tile kernel's workgroups do.  A piece publishes its fp32 partial write-through (sc1) in the lane-contiguous order of its
+// accumulators (1 KB per wave store), drains, and draws a ticket of its tile; the piece that draws the last one acquires, adds the
+// tile's partials IN SLICE ORDER (its own from registers: the sum does not depend on who came last) and runs the whole-tile epilogue.
+// No merge launch; tickets return to zero.
+template <typename T, bool F8, int ACT>
+__global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
+  __shared__ int last_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned tiles = p.tiles_m * p.tiles_n, rem = tiles - p.n_full;
+  const unsigned piece = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned sl = piece / rem, ti = piece % rem;
+  const long nk = p.k / p.bk;
+  const long kbeg = (long)sl * p.slice_len;
+  const long kend = kbeg + p.slice_len < nk ? kbeg + p.slice_len : nk;
+  long m0, n0;
+  gemm256_tile_origin(p, p.n_full + ti, m0, n0);
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (kend > kbeg) {
+    if (F8) gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, kbeg, kend, acc);
+    else gemm256_pp_buf_loop<T>(p, smem, reinterpret_cast<const T*>(p.a), reinterpret_cast<const T*>(p.w), m0, n0, kbeg, kend, acc);
+  }
+  // slot layout: [wave][block = (i, j, g)][lane] x 16 bytes
+  const size_t slot_floats = (size_t)G2_BM * G2_BN;
+  const size_t my_off = ((size_t)wv * 32 * 64 + lane) * 4;
+  float* mine = p.part + (size_t)piece * slot_floats + my_off;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+        agent_store16(mine + (size_t)((i * 2 + j) * 4 + g) * 256, v);
+      }
+  agent_drain();
+  __syncthreads();
+  if (tid == 0) last_flag = agent_ticket(p.tickets + ti) + 1 == p.slices;
+  __syncthreads();
+  if (!last_flag) return;
+  if (tid == 0) { agent_acquire(); agent_store(p.tickets + ti, 0u); }      // zero again for the next launch (a launch boundary away)
+  __syncthreads();
+  const float* base = p.part + (size_t)ti * slot_floats + my_off;
+  const size_t slice_stride = (size_t)rem * slot_floats;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 own = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        const float* q = base + (size_t)((i * 2 + j) * 4 + g) * 256;
+        for (unsigned s2 = 0; s2 < p.slices; ++s2) {
+          const f32x4 v = s2 == sl ? own : *reinterpret_cast<const f32x4*>(q + (size_t)s2 * slice_stride);
+          sum += v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] = sum[e];
+      }
+  __syncthreads();
+  gemm256_epilogue<T, ACT>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
+}
+
 static int gemm_num_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -785,22 +864,87 @@ static void launch_gemm256_tiles(const GemmParams& p, dim3 grid, void* stream) {
 // measured on MI355X (tools/bench_kernels.py, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the 3/3/2/0
 // piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
 // specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
+static thread_local int g_last_split[3] = {0, 0, 0};           // whole tiles, K slices, tail pieces of this thread's last 256-tile launch
+void gemm_last_split(int* out) { out[0] = g_last_split[0]; out[1] = g_last_split[1]; out[2] = g_last_split[2]; }
+
+constexpr long G2_TICKET_BYTES = 4096;                                                   // 1024 tickets at the end of the workspace
+constexpr long G2_MAX_PIECES = ((long)MTX_GEMM_WORKSPACE_BYTES - G2_TICKET_BYTES) / ((long)G2_BM * G2_BN * 4);
+
+// K slices for `r` tiles of `nk` iterations on `cus` CUs: minimise rounds x (slice length + a few iterations of prologue / partial /
+// ticket per piece); returns 0 when no slicing beats `limit` (the cost of the alternative)
+static unsigned gemm256_choose_slices(unsigned r, long nk, unsigned cus, long limit, long* cost_out) {
+  unsigned best = 0; long best_cost = limit;
+  for (unsigned s = 2; s <= 16; ++s) {
+    if ((long)r * s > G2_MAX_PIECES) break;
+    const long len = (nk + s - 1) / s;
+    if (len < 4) break;
+    const long used = (nk + len - 1) / len;                  // slices that are not empty
+    if (used != (long)s) continue;
+    const long rounds = ((long)r * s + cus - 1) / cus;
+    const long cost = rounds * (len + 3) + (long)s;          // + the last arriver's reads
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  if (cost_out) *cost_out = best_cost;
+  return best;
+}
+
 template <typename T, bool F8>
-static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit) {
+static void launch_gemm256_slices(const GemmParams& p, unsigned pieces, void* stream) {
+#define MTX_G256S(ACTV) MTX_LAUNCH((gemm256_slice_kernel<T, F8, ACTV>), dim3(pieces), dim3(512), 0, stream, p)
+  switch (p.act) {
+    case MTX_ACT_NONE: MTX_G256S(MTX_ACT_NONE); break;
+    case MTX_ACT_SILU: MTX_G256S(MTX_ACT_SILU); break;
+    case MTX_ACT_GELU_TANH: MTX_G256S(MTX_ACT_GELU_TANH); break;
+    default: MTX_G256S(-1); break;
+  }
+#undef MTX_G256S
+}
+
+// measured on MI355X (tools/bench_kernels.py, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the 3/3/2/0
+// piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
+// specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
+template <typename T, bool F8>
+static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit, bool old_tail) {
   GemmParams p = p0;
-  // stream-K tail when the last wave of tiles would fill less than ~70 % of the chip
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
   const long nk = p.k / p.bk;
-  const bool tail = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles > cus && rem > 0 && rem * 10 < cus * 7 && nk >= (force ? 4 : (F8 ? 32 : 64)) && !nosplit;
-  // few tiles but a long K (FLUX text-stream ff2: 24 tiles x 192 iterations): stream-K over the whole problem
-  const bool allk = p.part != nullptr && cus <= 320 && grid.y == 1 && tiles * 2 <= cus && nk >= (F8 ? 64 : 128) && !nosplit;
-  if (allk) { p.n_full = 0; p.units = cus; }
-  else if (tail) { p.n_full = tiles - rem; p.units = cus; grid.x = p.n_full; }
-  if (!allk) launch_gemm256_tiles<T, F8>(p, grid, stream);
-  if (tail || allk) {
-    MTX_LAUNCH((gemm256_tail_kernel<T, F8>), dim3(p.units), dim3(512), 0, stream, p);
-    MTX_LAUNCH((gemm256_merge_kernel<T>), dim3((tiles - p.n_full) * 8), dim3(256), 0, stream, p);
+  const bool can = p.part != nullptr && cus <= 320 && grid.y == 1 && !nosplit;
+  if (old_tail) {          // round 3's stream-K tail + merge launch, kept for the same-process A/B of tools/bench_kernels.py
+    const bool tail = can && tiles > cus && rem > 0 && rem * 10 < cus * 7 && nk >= (force ? 4 : (F8 ? 32 : 64));
+    const bool allk = can && tiles * 2 <= cus && nk >= (F8 ? 64 : 128);
+    if (allk) { p.n_full = 0; p.units = cus; }
+    else if (tail) { p.n_full = tiles - rem; p.units = cus; grid.x = p.n_full; }
+    if (!allk) launch_gemm256_tiles<T, F8>(p, grid, stream);
+    if (tail || allk) {
+      MTX_LAUNCH((gemm256_tail_kernel<T, F8>), dim3(p.units), dim3(512), 0, stream, p);
+      MTX_LAUNCH((gemm256_merge_kernel<T>), dim3((tiles - p.n_full) * 8), dim3(256), 0, stream, p);
+    }
+    return;
   }
+  // left-over tiles of the last wave: K slices when they finish clearly before a whole extra tile time would
+  if (can && tiles > cus && rem > 0 && nk >= (force ? 4 : (F8 ? 32 : 64))) {
+    const unsigned s = gemm256_choose_slices(rem, nk, cus, nk * 8 / 10, nullptr);
+    if (s) {
+      p.n_full = tiles - rem; grid.x = p.n_full;
+      launch_gemm256_tiles<T, F8>(p, grid, stream);
+      p.slices = s; p.slice_len = (unsigned)((nk + s - 1) / s);
+      launch_gemm256_slices<T, F8>(p, rem * s, stream);
+      g_last_split[0] = (int)p.n_full; g_last_split[1] = (int)s; g_last_split[2] = (int)(rem * s);
+      return;
+    }
+  }
+  // few tiles but a long K (FLUX text-stream ff2: 24 tiles x 192 iterations): slices over the whole problem
+  if (can && tiles * 2 <= cus && nk >= (F8 ? 64 : 128)) {
+    const unsigned s = gemm256_choose_slices(tiles, nk, cus, nk * 7 / 10, nullptr);
+    if (s) {
+      p.n_full = 0; p.slices = s; p.slice_len = (unsigned)((nk + s - 1) / s);
+      launch_gemm256_slices<T, F8>(p, tiles * s, stream);
+      g_last_split[0] = 0; g_last_split[1] = (int)s; g_last_split[2] = (int)(tiles * s);
+      return;
+    }
+  }
+  launch_gemm256_tiles<T, F8>(p, grid, stream);
+  g_last_split[0] = (int)tiles; g_last_split[1] = 1; g_last_split[2] = 0;
 }
 
 int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
@@ -821,8 +965,9 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.gate_rows_per = a->gate_rows_per > 0 ? a->gate_rows_per : 1;
   p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;
-  p.n_full = 0; p.units = 0;
+  p.n_full = 0; p.units = 0; p.slices = 1; p.slice_len = 0;
   p.part = (a->workspace && a->workspace_bytes >= (int64_t)MTX_GEMM_WORKSPACE_BYTES) ? reinterpret_cast<float*>(a->workspace) : nullptr;
+  p.tickets = p.part ? reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a->workspace) + MTX_GEMM_WORKSPACE_BYTES - G2_TICKET_BYTES) : nullptr;
   p.a_scale = reinterpret_cast<const unsigned*>(a->a_scale); p.w_scale = reinterpret_cast<const unsigned*>(a->w_scale);
   p.lds_a = a->lds_a; p.lds_w = a->lds_w;
   p.glu_q = nullptr; p.glu_scale = nullptr; p.glu_ldq = p.glu_lds = p.glu_col0 = 0;
@@ -830,7 +975,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;
-  const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0;
+  const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0, old_tail = (a->flags & MTX_GEMM_OLD_TAIL) != 0;
   // large, aligned problems: the 256 x 256 LDS-DMA kernel (needs whole K tiles and 16-byte rows everywhere)
   const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;
   const bool vec = a->n % 8 == 0 && a->ldc % 8 == 0 && (!a->res || a->ldres % 8 == 0) && (!a->gate || a->ldgate % 8 == 0) && a->c_bstride % 8 == 0;
@@ -855,7 +1000,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
       else MTX_LAUNCH((gemm256_f8_glu_kernel<_Float16>), g2, dim3(512), 0, stream, p);
       return MTX_OK;
     }
-    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, true>(p, g2, stream, force, nosplit); else launch_gemm256<_Float16, true>(p, g2, stream, force, nosplit);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, true>(p, g2, stream, force, nosplit, old_tail); else launch_gemm256<_Float16, true>(p, g2, stream, force, nosplit, old_tail);
     return MTX_OK;
   }
   // with the descriptor-DMA loop the 256-tile kernel wins from ~24 tiles up even though most CUs idle (512x9216x3072: 55 vs 68 us,
@@ -870,7 +1015,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
     p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
     p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
     dim3 g2(p.tiles_m * p.tiles_n, (unsigned)batch);
-    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, false>(p, g2, stream, force, nosplit); else launch_gemm256<_Float16, false>(p, g2, stream, force, nosplit);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, false>(p, g2, stream, force, nosplit, old_tail); else launch_gemm256<_Float16, false>(p, g2, stream, force, nosplit, old_tail);
     return MTX_OK;
   }
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);

@@ -295,6 +295,20 @@ __device__ __forceinline__ void agent_store(unsigned* word, unsigned v) {
   __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+// 16 bytes per lane, write-through like agent_store (global_store_dwordx4 ... sc1).  The compiler does not count this store: the caller
+// drains it with an explicit `s_waitcnt vmcnt(0)` (agent_drain) before the ticket.
+__device__ __forceinline__ void agent_store16(float* p, f32x4 v) {
+#ifdef MTX_EMU
+  *reinterpret_cast<f32x4*>(p) = v;
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+__device__ __forceinline__ void agent_drain() {
+#ifndef MTX_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 __device__ __forceinline__ void agent_store(float* word, float v) { agent_store(reinterpret_cast<unsigned*>(word), __builtin_bit_cast(unsigned, v)); }
 __device__ __forceinline__ unsigned agent_ticket(unsigned* counter) {          // returns the value before the increment
 #ifdef MTX_EMU

@@ -56,6 +56,7 @@ class MtxLibrary:
         d.mtx_host_png_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
         d.mtx_host_png_encode.restype = C.c_int64
         d.mtx_conv2d_tiles.argtypes = [C.POINTER(abi.ConvArgs)]
+        d.mtx_gemm_last_split.argtypes = [C.POINTER(C.c_int)] * 3
         d.mtx_plan_create.argtypes = [C.POINTER(abi.Op), C.c_int, C.POINTER(C.c_void_p)]
         d.mtx_plan_run.argtypes = [C.c_void_p, C.c_void_p]
         d.mtx_plan_run_graph.argtypes = [C.c_void_p, C.c_void_p]
@@ -86,6 +87,12 @@ class MtxLibrary:
     def check(self, rc: int, what: str = "") -> None:
         if rc != 0:
             raise ModelError(f"{what or 'libmtx_hip'} failed ({rc}): {self.last_error()}")
+
+    def gemm_last_split(self):
+        """(whole tiles, K slices, tail pieces) of this thread's last 256-tile GEMM launch (mtx_gemm_last_split)"""
+        v = [C.c_int(0) for _ in range(3)]
+        self._dll.mtx_gemm_last_split(*[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
 
     def init(self, device_ordinal: int = 0) -> None:
         self.check(self._dll.mtx_init(int(device_ordinal)), "mtx_init")

@@ -314,12 +314,12 @@ class PlanBuilder:
         g.gate_rows_per = gate_rows_per
         g.act, g.act_param, g.alpha = act, 0.0, alpha
         g.dtype, g.out_dtype = self.dtype, (abi.F32 if out_f32 else self.dtype)
-        if ((m >= 2048 and n >= 1024 and k >= 512) or (m >= 256 and k >= 8192)) and batch == 1 and not out_f32:
+        if ((m >= 2048 and n >= 1024 and k >= 512) or (m >= 256 and k >= 8192) or (flags & abi.GEMM_FORCE_TILE256)) and batch == 1 and not out_f32:
             # large problems: one shared scratch per plan for the stream-K tail of the 256-tile kernel (ops of a plan run in order)
             # (side-lane ops run beside main-lane ops: they get a scratch of their own)
             ws_name = "_gemm_ws_side" if self._side else "_gemm_ws"
             if getattr(self, ws_name, None) is None:
-                setattr(self, ws_name, self.buf((abi.GEMM_WORKSPACE_BYTES,), torch.uint8))
+                setattr(self, ws_name, self.buf((abi.GEMM_WORKSPACE_BYTES,), torch.uint8, zero=True))      # the tickets in its last 4 KiB start at zero
             g.workspace, g.workspace_bytes = getattr(self, ws_name).data_ptr(), abi.GEMM_WORKSPACE_BYTES
         self._add(abi.OP_GEMM, g, label)
         return out

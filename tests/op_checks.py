@@ -103,8 +103,10 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
 
 
 def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=False, with_gate=False,
-               out_f32=False, batch=1, alpha=1.0, seed=0, flags=0, runs=1):
-    """runs > 1: the same plan is run again over a poisoned output — a stream-K launch must not depend on what an earlier launch left in its scratch"""
+               out_f32=False, batch=1, alpha=1.0, seed=0, flags=0, runs=1, expect_split=None):
+    """runs > 1: the same plan is run again over a poisoned output — a K-slice launch must not depend on what an earlier launch left in its
+    scratch (and must leave its tickets at zero).  expect_split = (whole tiles, K slices, tail pieces) the launch must report
+    (mtx_gemm_last_split): the test shape really went through the path it is meant to cover."""
     g = torch.Generator().manual_seed(seed)
     dev, td = _dev(lib), TD[dtype]
     a = torch.randn(batch, m, k, generator=g).to(td)
@@ -134,6 +136,8 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
                   gate=pb.const(gate) if gate is not None else None, gate_rows_per=rows_per,
                   alpha=alpha, batch=batch, a_bs=m * k, w_bs=n * k, c_bs=m * n, out_f32=out_f32, flags=flags)
     plan = _run(pb)
+    if expect_split is not None:
+        assert lib.gemm_last_split() == tuple(expect_split), f"launch split {lib.gemm_last_split()} != {tuple(expect_split)}"
     err = _relerr(out.cpu().view(batch, m, n), ref)
     assert err < TOL[dtype], f"gemm mismatch rel err {err}"
     first = out.clone()

@@ -33,7 +33,7 @@ def calibrate_logits(model, ref, target_std=5.0):
     return gain
 
 
-def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, logit_tol=0.08, mask_tol=0.01, calibrated=False):
+def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, logit_tol=0.08, mask_tol=0.01, calibrated=False, **hip_kw):
     model, cfg = sr.make_model(size, seed)
     page = make_page(h, w, seed)
     rng = np.random.default_rng(seed + 5)
@@ -61,7 +61,7 @@ def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, l
             ref = sr.run(model, page, boxes)
         finally:
             md._dynamic_multimask_via_stability = orig
-    hipm = Sam2Hip(model.state_dict(), cfg, device=device, lib=lib)
+    hipm = Sam2Hip(model.state_dict(), cfg, device=device, lib=lib, **hip_kw)
     masks, low, iou, sel = hipm.segment(page, boxes, return_logits=True)
     if calibrated:
         thresh = md.dynamic_multimask_stability_thresh

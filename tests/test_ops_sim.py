@@ -156,18 +156,24 @@ def test_flux_prep_kernels(emu_lib):
     oc.check_softmax_transpose(emu_lib, abi.F16, rows=70, cols=136)
 
 
-def test_gemm_stream_k_tail(emu_lib):
-    """tiles % CUs != 0 (the simulator reports 3 CUs): the left-over tiles go through the stream-K tail + merge kernels; a second and
-    third run of the same plan must reproduce the first bit for bit"""
+def test_gemm_k_slice_tail(emu_lib):
+    """tiles % CUs != 0 (the simulator reports 3 CUs): the left-over tile is cut into K slices whose last arriver sums the partials in
+    slice order and runs the epilogue (gemm256_slice_kernel); a second and third run of the same plan must reproduce the first bit for
+    bit (tickets back at zero, no dependence on which piece came last)"""
     f = abi.GEMM_FORCE_TILE256
-    # 2048 x 1024 -> 8 x 4 = 32 tiles, 32 % 3 = 2 left over, K = 512 -> 8 iterations per tile dealt to 3 units
-    oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f, runs=3)
-    oc.check_gemm(emu_lib, abi.F16, m=2048, n=1032, k=576, with_bias=False, flags=f, runs=2)
+    # 1024 x 256 -> 4 tiles, 4 % 3 = 1 left over, K = 2048 -> 32 iterations in 3 slices of 11 / 11 / 10
+    oc.check_gemm(emu_lib, abi.BF16, m=1024, n=256, k=2048, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f, runs=3, expect_split=(3, 3, 3))
+    # ragged M and N on the left-over tile (7 tiles on 3 CUs), f16
+    oc.check_gemm(emu_lib, abi.F16, m=1700, n=200, k=1536, with_bias=False, flags=f, runs=2, expect_split=(6, 3, 3))
+    # short K: slicing does not pay, the left-over tiles run whole
+    oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, flags=f, expect_split=(32, 1, 0))
+    # round 3's stream-K tail + merge launch (kept for the A/B) still computes the same product
+    oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f | abi.GEMM_OLD_TAIL, runs=2)
 
 
-def test_gemm_stream_k_whole_problem(emu_lib):
-    """few tiles, long K: every tile's K range is dealt across the units (no full-tile launch at all)"""
-    oc.check_gemm(emu_lib, abi.BF16, m=256, n=200, k=8192, with_res=True, with_gate=True, runs=2)
+def test_gemm_k_slices_whole_problem(emu_lib):
+    """few tiles, long K: every tile's K range is cut into slices (no full-tile launch at all)"""
+    oc.check_gemm(emu_lib, abi.BF16, m=256, n=200, k=8192, with_res=True, with_gate=True, runs=2, expect_split=(0, 3, 3))
 
 
 @pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])

@@ -32,7 +32,7 @@ def attn(T, heads=24, d=128, iters=10):
     print(f"attn T={T} heads={heads}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
-def gemm(M, N, K, iters=20, f8=False, pad=0):
+def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0):
     """pad > 0: rows of A and W are `pad` elements apart more than K (leading-dimension padding, an address-interleave probe)"""
     pb = PlanBuilder(lib, dev, abi.BF16)
     a = pb.buf((M, K + pad), torch.bfloat16); a.normal_()
@@ -43,11 +43,13 @@ def gemm(M, N, K, iters=20, f8=False, pad=0):
         wq, wsc, lw = q.quantize(w, N, K)
         q.build().run(); torch.cuda.synchronize()
         pb.keep += [aq, asc, wq, wsc]
-        pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0))
+        pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0), flags=flags)
     else:
-        pb.gemm(a, w, M, N, K, lda=K + pad, ldw=K + pad)
+        pb.gemm(a, w, M, N, K, lda=K + pad, ldw=K + pad, flags=flags)
     ms = _time(pb.build(), iters)
-    print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}{f' ld+{pad}' if pad else ''}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+    split = lib.gemm_last_split()
+    tag = " [r03 stream-K tail + merge]" if flags & abi.GEMM_OLD_TAIL else (" [whole tiles only]" if flags & abi.GEMM_NO_SPLIT else f" [whole tiles, K slices, pieces = {split}]")
+    print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}{f' ld+{pad}' if pad else ''}{tag}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
 def quant(rows, K, iters=20):
@@ -81,7 +83,8 @@ if __name__ == "__main__":
             conv(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "gemmp":
             gemm(int(args[1]), int(args[2]), int(args[3]), pad=int(args[4])); args = args[5:]
-        elif args[0] in ("gemm", "gemm8"):
-            gemm(int(args[1]), int(args[2]), int(args[3]), f8=args[0] == "gemm8"); args = args[4:]
+        elif args[0] in ("gemm", "gemm8", "gemmo", "gemm8o", "gemmn", "gemm8n"):      # ...o: round 3's tail (A/B), ...n: no split at all
+            fl = abi.GEMM_OLD_TAIL if args[0].endswith("o") else (abi.GEMM_NO_SPLIT if args[0].endswith("n") else 0)
+            gemm(int(args[1]), int(args[2]), int(args[3]), f8=args[0].startswith("gemm8"), flags=fl); args = args[4:]
         else:
             raise SystemExit(f"unknown benchmark {args[0]}")
