@@ -169,12 +169,12 @@ class ModelManager:
             self.model_paths = {
                 ModelType.UPSCALE: model_dir / "upscale" / "2x-AnimeSharpV4_RCAN.safetensors",
                 ModelType.UPSCALE_LITE: model_dir / "upscale" / "2x-AnimeSharpV4_Fast_RCAN_PU.safetensors",
-                ModelType.YOLO_SPEECH_BUBBLE: model_dir / "yolo" / "yolov8m_seg-speech-bubble.safetensors",
-                ModelType.YOLO_SPEECH_BUBBLE_2: model_dir / "yolo" / "manga109-segmentation-bubble.safetensors",
+                ModelType.YOLO_SPEECH_BUBBLE: model_dir / "yolo" / "yolov8m_seg-speech-bubble.pt",            # the reference's own file names (:119-132);
+                ModelType.YOLO_SPEECH_BUBBLE_2: model_dir / "yolo" / "manga109-segmentation-bubble.pt",       # a `.safetensors` sibling is read as well
                 ModelType.SAM2: model_dir / "sam" / "sam2.1-hiera-large",
                 ModelType.RTDETR_CONJOINED_BUBBLE: model_dir / "rtdetr" / "comic-text-and-bubble-detector",
-                ModelType.YOLO_OSBTEXT: model_dir / "yolo" / "animetext_yolov12x.safetensors",
-                ModelType.YOLO_PANEL: model_dir / "yolo" / "manga109_panel_yolo11l.safetensors",
+                ModelType.YOLO_OSBTEXT: model_dir / "yolo" / "animetext_yolov12x.pt",
+                ModelType.YOLO_PANEL: model_dir / "yolo" / "manga109_v2023.12.07_l_yolov11.pt",
                 ModelType.FLUX_KONTEXT_SDNQ_PIPELINE: model_dir / "flux" / "kontext",
                 ModelType.FLUX_KLEIN_4B_PIPELINE: model_dir / "flux" / "klein-4b",
                 ModelType.FLUX_KLEIN_9B_PIPELINE: model_dir / "flux" / "klein-9b",
@@ -238,16 +238,25 @@ class ModelManager:
         rank0 = not _dist_on() or dist.get_rank() == 0
         sd, error, metadata = None, None, {}
         if rank0:
-            if not path.exists():
+            # detector checkpoints: the ultralytics `.pt` the reference downloads (read without ultralytics and without executing the
+            # pickle: core/ml/ultralytics_pt.py) or its safetensors export (tools/export_ultralytics_state_dict.py), whichever is staged
+            found = next((c for c in (path, path.with_suffix(".safetensors"), path.with_suffix(".pt")) if c.exists()), None)
+            if found is None:
                 error = f"checkpoint not found: {path} (stage it under ./models; this build never downloads)"
             else:
                 try:
-                    from safetensors import safe_open
-                    with safe_open(str(path), framework="pt", device="cpu") as f:
-                        sd = {k: f.get_tensor(k) for k in f.keys()}
-                        metadata = dict(f.metadata() or {})
+                    with open(found, "rb") as fh:
+                        magic = fh.read(2)
+                    if magic == b"PK":                      # torch's zip container
+                        from .ultralytics_pt import read_ultralytics_pt
+                        sd, metadata = read_ultralytics_pt(found)
+                    else:
+                        from safetensors import safe_open
+                        with safe_open(str(found), framework="pt", device="cpu") as f:
+                            sd = {k: f.get_tensor(k) for k in f.keys()}
+                            metadata = dict(f.metadata() or {})
                 except Exception as e:                      # truncated / foreign file
-                    error = f"cannot read {path}: {e}"
+                    error = f"cannot read {found}: {e}"
         broadcast_status(error)
         if _dist_on():
             meta = [{k: (tuple(v.shape), v.dtype) for k, v in sd.items()}, metadata] if rank0 else [None, None]
@@ -257,7 +266,7 @@ class ModelManager:
         return sd, metadata
 
     def _detector_from_state_dict(self, sd: dict, default_names: Optional[dict] = None, metadata: Optional[dict] = None):
-        """ultralytics detector checkpoint (exported with tools/export_ultralytics_state_dict.py) -> the graph of its family: YOLOv8-seg
+        """ultralytics detector state dict (from the `.pt` itself or its safetensors export) -> the graph of its family: YOLOv8-seg
         (`YoloSegHip`) or YOLO11 / YOLO11-seg / YOLO12 (`Yolo11Hip`), told apart by the blocks the state dict holds.  Class names come
         from the `names` entry of the checkpoint's own header `metadata` (what ultralytics keeps in the .pt)."""
         import ast
@@ -313,8 +322,8 @@ class ModelManager:
 
     def load_yolo_speech_bubble(self, model_path: Optional[str] = None, verbose: bool = False):
         """YOLO-seg bubble detector as a libmtx_hip graph with the ultralytics call shape
-        (reference :711-743; same `model_path` meaning, see `_resolve_speech_bubble_model`).  The checkpoint is the ultralytics state
-        dict exported to safetensors (tools/export_ultralytics_state_dict.py, run once where ultralytics is installed)."""
+        (reference :711-743; same `model_path` meaning, see `_resolve_speech_bubble_model`).  The checkpoint is the reference's own
+        ultralytics `.pt` (read pickle-free, core/ml/ultralytics_pt.py) or its safetensors export (tools/export_ultralytics_state_dict.py)."""
         with self._lock:
             mt, path = self._resolve_speech_bubble_model(model_path)
             if self.is_loaded(mt):
