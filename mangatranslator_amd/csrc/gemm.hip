@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void gemm256_merge_kernel(GemmParams p) {
 // XCD a run of neighbouring tiles of ONE slice, which walk K in step and share their A / W panels through that XCD's L2 like the
 // whole-tile kernel's workgroups do.  A piece publishes its fp32 partial write-through (sc1) in the lane-contiguous order of its
 // accumulators (1 KB per wave store), drains, and draws a ticket of its tile; the piece that draws the last one acquires, adds the
-// tile's partials IN SLICE ORDER (its own from registers: the sum does not depend on who came last) and runs the whole-tile epilogue.
+// tile's partials IN SLICE ORDER (the sum does not depend on who came last) and runs the whole-tile epilogue.
 // No merge launch; tickets return to zero.
 template <typename T, bool F8, int ACT>
 __global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
@@ -813,24 +813,31 @@ __global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
   if (!last_flag) return;
   if (tid == 0) { agent_acquire(); agent_store(p.tickets + ti, 0u); }      // zero again for the next launch (a launch boundary away)
   __syncthreads();
+  // sum of the tile's partials in slice order — ALL of them from memory, this piece's own included (it was just published; the
+  // accumulators are dead from here on, which leaves the registers for 16 blocks x 16 bytes per lane in flight per slice: the first
+  // version kept its own piece in registers and fetched block by block, 32 dependent round trips, ~60 us per fix-up on hardware)
   const float* base = p.part + (size_t)ti * slot_floats + my_off;
   const size_t slice_stride = (size_t)rem * slot_floats;
+  constexpr int CH = 16;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int c0 = 0; c0 < 32; c0 += CH) {
+    f32x4 run[CH];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int b = 0; b < CH; ++b) run[b] = *reinterpret_cast<const f32x4*>(base + (size_t)(c0 + b) * 256);
+    for (unsigned s2 = 1; s2 < p.slices; ++s2) {
+      f32x4 v[CH];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 own = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        const float* q = base + (size_t)((i * 2 + j) * 4 + g) * 256;
-        for (unsigned s2 = 0; s2 < p.slices; ++s2) {
-          const f32x4 v = s2 == sl ? own : *reinterpret_cast<const f32x4*>(q + (size_t)s2 * slice_stride);
-          sum += v;
-        }
+      for (int b = 0; b < CH; ++b) v[b] = *reinterpret_cast<const f32x4*>(base + (size_t)s2 * slice_stride + (size_t)(c0 + b) * 256);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] = sum[e];
-      }
+      for (int b = 0; b < CH; ++b) run[b] += v[b];
+    }
+#pragma unroll
+    for (int b = 0; b < CH; ++b) {
+      const int blk = c0 + b, i = blk >> 3, j = (blk >> 2) & 1, g = blk & 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] = run[b][e];
+    }
+  }
   __syncthreads();
   gemm256_epilogue<T, ACT>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
 }
@@ -881,7 +888,7 @@ static unsigned gemm256_choose_slices(unsigned r, long nk, unsigned cus, long li
     const long used = (nk + len - 1) / len;                  // slices that are not empty
     if (used != (long)s) continue;
     const long rounds = ((long)r * s + cus - 1) / cus;
-    const long cost = rounds * (len + 3) + (long)s;          // + the last arriver's reads
+    const long cost = rounds * (len + 6) + 2 * (long)s + 3;  // per piece: pipeline fill + publishing the partial; once: the last arriver's s reads + epilogue
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
   if (cost_out) *cost_out = best_cost;
@@ -904,7 +911,7 @@ static void launch_gemm256_slices(const GemmParams& p, unsigned pieces, void* st
 // piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
 // specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
 template <typename T, bool F8>
-static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit, bool old_tail) {
+static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit, bool old_tail, unsigned forced_slices) {
   GemmParams p = p0;
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
   const long nk = p.k / p.bk;
@@ -923,7 +930,8 @@ static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool f
   }
   // left-over tiles of the last wave: K slices when they finish clearly before a whole extra tile time would
   if (can && tiles > cus && rem > 0 && nk >= (force ? 4 : (F8 ? 32 : 64))) {
-    const unsigned s = gemm256_choose_slices(rem, nk, cus, nk * 8 / 10, nullptr);
+    unsigned s = gemm256_choose_slices(rem, nk, cus, nk * 8 / 10, nullptr);
+    if (forced_slices >= 2 && (long)rem * forced_slices <= G2_MAX_PIECES && (long)forced_slices * 2 <= nk) s = forced_slices;
     if (s) {
       p.n_full = tiles - rem; grid.x = p.n_full;
       launch_gemm256_tiles<T, F8>(p, grid, stream);
@@ -935,7 +943,8 @@ static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool f
   }
   // few tiles but a long K (FLUX text-stream ff2: 24 tiles x 192 iterations): slices over the whole problem
   if (can && tiles * 2 <= cus && nk >= (F8 ? 64 : 128)) {
-    const unsigned s = gemm256_choose_slices(tiles, nk, cus, nk * 7 / 10, nullptr);
+    unsigned s = gemm256_choose_slices(tiles, nk, cus, nk * 7 / 10, nullptr);
+    if (forced_slices >= 2 && (long)tiles * forced_slices <= G2_MAX_PIECES && (long)forced_slices * 2 <= nk) s = forced_slices;
     if (s) {
       p.n_full = 0; p.slices = s; p.slice_len = (unsigned)((nk + s - 1) / s);
       launch_gemm256_slices<T, F8>(p, tiles * s, stream);
@@ -976,6 +985,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;
   const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0, old_tail = (a->flags & MTX_GEMM_OLD_TAIL) != 0;
+  const unsigned forced_slices = ((unsigned)a->flags >> 8) & 0xffu;
   // large, aligned problems: the 256 x 256 LDS-DMA kernel (needs whole K tiles and 16-byte rows everywhere)
   const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;
   const bool vec = a->n % 8 == 0 && a->ldc % 8 == 0 && (!a->res || a->ldres % 8 == 0) && (!a->gate || a->ldgate % 8 == 0) && a->c_bstride % 8 == 0;
@@ -1000,7 +1010,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
       else MTX_LAUNCH((gemm256_f8_glu_kernel<_Float16>), g2, dim3(512), 0, stream, p);
       return MTX_OK;
     }
-    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, true>(p, g2, stream, force, nosplit, old_tail); else launch_gemm256<_Float16, true>(p, g2, stream, force, nosplit, old_tail);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, true>(p, g2, stream, force, nosplit, old_tail, forced_slices); else launch_gemm256<_Float16, true>(p, g2, stream, force, nosplit, old_tail, forced_slices);
     return MTX_OK;
   }
   // with the descriptor-DMA loop the 256-tile kernel wins from ~24 tiles up even though most CUs idle (512x9216x3072: 55 vs 68 us,
@@ -1015,7 +1025,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
     p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
     p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
     dim3 g2(p.tiles_m * p.tiles_n, (unsigned)batch);
-    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, false>(p, g2, stream, force, nosplit, old_tail); else launch_gemm256<_Float16, false>(p, g2, stream, force, nosplit, old_tail);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, false>(p, g2, stream, force, nosplit, old_tail, forced_slices); else launch_gemm256<_Float16, false>(p, g2, stream, force, nosplit, old_tail, forced_slices);
     return MTX_OK;
   }
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);

@@ -102,6 +102,71 @@ def test_sdnq_shards_through_the_flux_provider(tmp_path):
         _ShardedProvider(folder, dict(shapes, **{"blk.lin.weight": (64, 100)}), torch.device("cpu"))("blk.lin.weight")
 
 
+def _np_pack_nibbles(q: np.ndarray) -> np.ndarray:
+    """independent of core/ml/sdnq.py: two 4-bit values per byte, the EARLIER value in the low nibble (sdnq's packed_int layout)"""
+    flat = q.reshape(-1).astype(np.uint8)
+    if flat.size % 2:
+        flat = np.concatenate([flat, np.zeros(1, np.uint8)])
+    return (flat[0::2] | (flat[1::2] << 4)).astype(np.uint8)
+
+
+def test_kontext_uint4_svd_r32_folder(tmp_path):
+    """A transformer folder laid out like `Disty0/FLUX.1-Kontext-dev-SDNQ-uint4-svd-r32` (reference model_manager.py:231-233): diffusers'
+    FluxTransformer2DModel parameter names, every block linear stored as `<base>.weight` (uint8, two nibbles per byte) + `.scale` +
+    `.zero_point` + `.svd_up` / `.svd_down` of rank 32, embedders / norms / biases in bf16, `quantization_config` in config.json.  The
+    writer is numpy code that shares nothing with the reader; the provider must hand out every parameter of `dit_param_shapes` in its
+    logical shape, equal (to bf16 rounding) to the dequantisation computed here in float64."""
+    from mangatranslator_amd.core.ml import flux as fx
+    from mangatranslator_amd.core.ml.model_manager import _ShardedProvider
+    cfg = dict(d=128, heads=2, layers=1, single_layers=1, in_channels=64, joint_dim=96, pooled_dim=48, axes_dim=(16, 24, 24))
+    shapes = fx.dit_param_shapes(cfg)
+    rng = np.random.default_rng(7)
+    group, rank = 32, 32
+    sd, expect = {}, {}
+    packed_bases = []
+    for name, shp in shapes.items():
+        w = rng.standard_normal(shp).astype(np.float32) * 0.05
+        base = name[:-len(".weight")] if name.endswith(".weight") else None
+        is_block_linear = base is not None and len(shp) == 2 and ("transformer_blocks." in name) and ".norm" not in name
+        if not is_block_linear:
+            t = torch.from_numpy(w).to(torch.bfloat16)
+            sd[name], expect[name] = t, t.float().numpy().astype(np.float64)
+            continue
+        n, k = shp
+        u, sv, vh = np.linalg.svd(w.astype(np.float64), full_matrices=False)
+        up = torch.from_numpy((u[:, :rank] * sv[:rank]).astype(np.float32)).to(torch.bfloat16)
+        down = torch.from_numpy(vh[:rank].astype(np.float32)).to(torch.bfloat16)
+        resid = w.astype(np.float64) - up.float().numpy().astype(np.float64) @ down.float().numpy().astype(np.float64)
+        g = resid.reshape(n, k // group, group)
+        zp = torch.from_numpy(g.min(-1).astype(np.float32)).to(torch.bfloat16)
+        sc = torch.from_numpy(np.maximum((g.max(-1) - g.min(-1)) / 15.0, 1e-8).astype(np.float32)).to(torch.bfloat16)
+        zp64, sc64 = zp.float().numpy().astype(np.float64), sc.float().numpy().astype(np.float64)
+        q = np.clip(np.rint((g - zp64[..., None]) / sc64[..., None]), 0, 15).astype(np.uint8)
+        sd[base + ".weight"] = torch.from_numpy(_np_pack_nibbles(q)).reshape(n, k // 2)
+        sd[base + ".scale"], sd[base + ".zero_point"] = sc.reshape(n, k // group, 1), zp.reshape(n, k // group, 1)
+        sd[base + ".svd_up"], sd[base + ".svd_down"] = up, down
+        expect[name] = (q.astype(np.float64) * sc64[..., None] + zp64[..., None]).reshape(n, k) + up.float().numpy().astype(np.float64) @ down.float().numpy().astype(np.float64)
+        packed_bases.append(base)
+    assert len(packed_bases) == 17 and "transformer_blocks.0.attn.to_q" in packed_bases and "single_transformer_blocks.0.proj_out" in packed_bases
+    folder = tmp_path / "transformer"
+    folder.mkdir()
+    keys = sorted(sd)
+    save_file({k: sd[k].contiguous() for k in keys[::2]}, str(folder / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[1::2]}, str(folder / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    (folder / "config.json").write_text(json.dumps({"_class_name": "FluxTransformer2DModel", "quantization_config": {
+        "quant_method": "sdnq", "weights_dtype": "uint4", "group_size": group, "use_svd": True, "svd_rank": rank, "use_quantized_matmul": True,
+        "modules_to_not_convert": ["x_embedder", "context_embedder", "proj_out", "time_text_embed", "norm_out"]}}))
+    prov = _ShardedProvider(folder, shapes, torch.device("cpu"))
+    for name, shp in shapes.items():
+        got = prov(name)
+        assert tuple(got.shape) == tuple(shp) and got.dtype == torch.bfloat16, name
+        want = torch.from_numpy(expect[name].astype(np.float32)).to(torch.bfloat16)
+        assert torch.equal(got, want) or (got.float() - want.float()).abs().max() <= 2.0 ** -8 * want.float().abs().max(), name
+    # the packed weights really are within 4-bit + rank-32 error of what was quantised (the writer is not vacuous)
+    w_q = prov("transformer_blocks.0.attn.to_q.weight").float()
+    assert w_q.abs().max() > 0.05
+
+
 def test_rcan_hyper_parameters_come_from_the_file_header(tmp_path):
     """the "PU" (pixel-unshuffle) fast variant and the plain one, from the safetensors header alone"""
     from oracle import rcan_ref

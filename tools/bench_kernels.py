@@ -83,8 +83,12 @@ if __name__ == "__main__":
             conv(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "gemmp":
             gemm(int(args[1]), int(args[2]), int(args[3]), pad=int(args[4])); args = args[5:]
-        elif args[0] in ("gemm", "gemm8", "gemmo", "gemm8o", "gemmn", "gemm8n"):      # ...o: round 3's tail (A/B), ...n: no split at all
-            fl = abi.GEMM_OLD_TAIL if args[0].endswith("o") else (abi.GEMM_NO_SPLIT if args[0].endswith("n") else 0)
+        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmo", "gemm8o", "gemmn", "gemm8n", "gemms", "gemm8s"):
+            # ...o: round 3's tail (A/B), ...n: no split at all, ...sN: exactly N K slices (e.g. gemms4, gemm8s2)
+            name = args[0].rstrip("0123456789")
+            fl = abi.GEMM_OLD_TAIL if name.endswith("o") else (abi.GEMM_NO_SPLIT if name.endswith("n") else 0)
+            if name.endswith("s"):
+                fl = int(args[0][len(name):]) << 8
             gemm(int(args[1]), int(args[2]), int(args[3]), f8=args[0].startswith("gemm8"), flags=fl); args = args[4:]
         else:
             raise SystemExit(f"unknown benchmark {args[0]}")
