@@ -303,6 +303,7 @@ def main():
     sam = None
     if "segment" in want:
         from mangatranslator_amd.core.ml.sam2 import Sam2Hip
+        from mangatranslator_amd.hip.abi import F16 as abi_f16
         from oracle.sam2_ref import make_config, make_model
         if first:
             m, sam_cfg = make_model("hiera_large", seed=11)     # facebook/sam2.1-hiera-large geometry, seeded weights
@@ -316,7 +317,7 @@ def main():
             sam_sd = {k: torch.empty(s) for k, s in shapes.items()}
         if world > 1:
             sam_sd = broadcast_state_dict(sam_sd, rank, world, device)
-        sam = Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph)
+        sam = Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph, dtype=abi_f16)        # f16 storage: what ModelManager.load_sam2 serves (bf16 only when a checkpoint leaves the f16 range)
         del sam_sd
     inpainter, flux = None, None
     klein = args.inpainter.startswith("klein")

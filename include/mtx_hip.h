@@ -125,7 +125,6 @@ typedef struct mtx_gemm_args {
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
 #define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the K-slice tail */
 #define MTX_GEMM_SLICES(n) ((n) << 8) /* tuning: cut the left-over tiles into exactly n K slices (2..255) instead of the launcher's choice */
-#define MTX_GEMM_OLD_TAIL 4        /* round 3's stream-K tail + merge launch instead of the K-slice tail (A/B only; goes when the A/B is settled) */
 #define MTX_GEMM_WORKSPACE_BYTES (2 * 320 * 256 * 256 * 4)
 
 /* softmax(scale * Q K^T) V, non-causal, one launch for [batch, heads].

@@ -136,6 +136,9 @@ class _PredMasks:
         return [self._m.bool()[:, None]]
 
 
+SAM_F16_PROBE_TOLERANCE = 0.08       # bf16's own error at Hiera-L is ~0.024 of the logit range (profiles/r04_sam_dtype_probe.json)
+
+
 class _Sam2ModelShim:
     def __init__(self, hip_model, dtype):
         self.hip, self.dtype = hip_model, dtype
@@ -430,7 +433,19 @@ class ModelManager:
             from transformers import Sam2Config
             config = Sam2Config.from_pretrained(str(root))
             sd = self._read_safetensors(weights)
-            hip = Sam2Hip(sd, config, device=self.device)
+            # f16 storage (8x smaller logit error than bf16 against the fp32 reference: the `> 0` masks are what the page flow keeps)
+            # unless the checkpoint leaves the f16 range: then the two models disagree grossly on the load-time probe and bf16 — the
+            # reference's own GPU dtype — is kept
+            from ...hip import abi
+            hip = Sam2Hip(sd, config, device=self.device, dtype=abi.BF16)
+            hip16 = Sam2Hip(sd, config, device=self.device, dtype=abi.F16)
+            ref, got = hip.probe_logits(), hip16.probe_logits()
+            gap = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item() if torch.isfinite(got).all() else float("inf")
+            if gap < SAM_F16_PROBE_TOLERANCE:
+                hip = hip16
+            else:
+                log_message(f"SAM 2.1: f16 storage disagrees with bf16 on the probe page ({gap:.2f} of the logit range): using bf16", always_print=True)
+            del hip16
             self.models[ModelType.SAM2] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
             log_message("SAM 2.1 model loaded.", verbose=verbose)
             return self.models[ModelType.SAM2]

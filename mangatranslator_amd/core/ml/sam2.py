@@ -530,5 +530,21 @@ class Sam2Hip:
         finally:
             self._lane.busy.release()
 
+    @torch.no_grad()
+    def probe_logits(self, size: int = 256) -> torch.Tensor:
+        """low-resolution logits [2, hl, hl] (fp32, host) of two boxes on one synthetic page (white paper, black strokes, a noise band).
+        `ModelManager.load_sam2` compares the f16 model's with the bf16 model's: f16 storage has 3 more mantissa bits (mask mismatch
+        against the fp32 reference 1.7e-4 instead of 1.55e-3 at Hiera-L, profiles/r04_sam_dtype_probe.json) but a 65504 ceiling at which
+        this library's conversions SATURATE (csrc/mtx_device.h from_f32<_Float16>) — an overflow therefore shows as a gross disagreement
+        with the bf16 model, not as NaN; it comes from a few weight-driven channels and shows on any input."""
+        rng = np.random.default_rng(0)
+        page = np.full((size, size, 3), 255, np.uint8)
+        page[size // 4: size // 4 + 3, :] = 0
+        page[:, size // 3: size // 3 + 2] = 0
+        page[size // 2: size // 2 + size // 8] = rng.integers(0, 256, (size // 8, size, 3), dtype=np.uint8)
+        boxes = np.array([[size * 0.1, size * 0.1, size * 0.6, size * 0.7], [0, 0, size - 1, size - 1]], np.float32)
+        _, low, _, _ = self.segment(page, boxes, return_logits=True)
+        return low.float().cpu()
+
     def plans(self, n, h, w):
         return self._pre_plan(h, w), self._encoder(), self._decoder(n), self._post_plan(n, h, w)

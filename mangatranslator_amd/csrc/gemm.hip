@@ -23,8 +23,8 @@ struct GemmParams {
   int gate_rows_per, act; float act_param, alpha;
   int out_f32;
   unsigned tiles_m, tiles_n;
-  // stream-K tail: tiles [n_full, tiles) are cut into `units` equal runs of K iterations; fp32 partials in `part`
-  unsigned n_full, units; float* part;
+  // whole tiles [0, n_full) go to the tile kernel, tiles [n_full, tiles) to the K-slice tail; fp32 partials in `part`
+  unsigned n_full; float* part;
   // K-slice tail (round 4): tiles [n_full, tiles) x `slices` equal K ranges of `slice_len` iterations; piece (slice j, tail tile t) keeps
   // its fp32 partial in slot j * rem + t of `part`; `tickets[t]` counts the finished slices of tile t (zero between launches)
   unsigned slices, slice_len; unsigned* tickets;
@@ -287,7 +287,7 @@ __device__ __forceinline__ void gemm256_tile_origin(const GemmParams& p, unsigne
 #endif
 
 // The ping-pong K loop with descriptor DMA over iterations [kbeg, kend) of one 256 x 256 tile (used by the full-tile kernel and by
-// the stream-K tail): barrier timeline B0, B1, ...: group 0 (waves 0-3) runs  L(k) B C(k) B  per k-step, group 1 the same one
+// the K-slice tail): barrier timeline B0, B1, ...: group 0 (waves 0-3) runs  L(k) B C(k) B  per k-step, group 1 the same one
 // barrier later, so one group's load segment (fragment reads + DMA issue) coincides with the other's 8 MFMAs.
 //   * DMA: per piece a loop-invariant 32-bit lane offset into a buffer descriptor over the valid bytes of A / W (rows past M / N
 //     are zero-filled by the range check), the K position as the wave-uniform soffset, the LDS base (M0) from scalar arithmetic:
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // the launch covers tiles [0, gridDim.x) of the grouped order (all of them, or the whole waves when the rest goes
-  // to the stream-K tail kernel)
+  // to the K-slice tail kernel)
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   long m0, n0;
   gemm256_tile_origin(p, lin, m0, n0);
@@ -660,115 +660,19 @@ __global__ __launch_bounds__(512) void gemm256_f8_glu_kernel(GemmParams p) {
 }
 
 
-// ---- stream-K tail ------------------------------------------------------------------------------------------
-// With one 256 x 256 tile per CU at a time, `rem = tiles % CUs` left-over tiles keep rem CUs busy for a whole tile
-// time while the others idle (FLUX proj_out: 408 tiles on 256 CUs = 1.59 waves billed as 2).  The left-over tiles'
-// K iterations are instead dealt out evenly: unit u takes iterations [u*I/units, (u+1)*I/units) of the rem * nk
-// iterations, i.e. the end of one tile and possibly the start of the next, and leaves an fp32 partial per piece
-// (slot 2u, 2u+1); the merge kernel adds a tile's pieces in K order and applies the usual epilogue.
-template <typename T, bool F8>
-__global__ __launch_bounds__(512) void gemm256_tail_kernel(GemmParams p) {
-  typedef typename Traits<T>::v8 v8;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int wm = wv >> 2, wn = wv & 3;
-  const long nk = p.k / p.bk;
-  const unsigned tiles = p.tiles_m * p.tiles_n, rem = tiles - p.n_full;
-  const long I = (long)rem * nk;
-  const unsigned u = blockIdx.x;
-  const long it0 = u * I / p.units, it1 = (u + 1) * I / p.units;
-  const T* A = reinterpret_cast<const T*>(p.a);
-  const T* W = reinterpret_cast<const T*>(p.w);
-  int arow[4], wrow[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) arow[i] = wm * 128 + i * 32 + l31;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) wrow[j] = G2_BM + wn * 64 + j * 32 + l31;
-
-  for (int seg = 0; seg < 2; ++seg) {
-    const long t0 = it0 / nk;                                   // tail tile of the first piece
-    const long kbeg = seg == 0 ? it0 - t0 * nk : 0;
-    const long kend = seg == 0 ? (it1 < (t0 + 1) * nk ? it1 - t0 * nk : nk) : it1 - (t0 + 1) * nk;
-    if (kend <= kbeg) continue;                                 // (wave-uniform)
-    long m0, n0;
-    gemm256_tile_origin(p, (unsigned)(p.n_full + t0 + seg), m0, n0);
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    __syncthreads();                                            // the previous piece is done with the LDS stages
-    if (F8) gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, kbeg, kend, acc);
-    else gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, kbeg, kend, acc);
-    // fp32 partial of this piece: [256 m][256 n], a lane stores 4 consecutive n
-    float* P = p.part + (size_t)(2 * u + seg) * G2_BM * G2_BN;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int m = wm * 128 + i * 32 + l31, n = wn * 64 + j * 32 + g * 8 + hi * 4;
-          f32x4 v = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
-          *reinterpret_cast<f32x4*>(P + (size_t)m * G2_BN + n) = v;
-        }
-  }
-}
-
-// one workgroup per (tail tile, 32-row band): sum the pieces in K order, epilogue, 16-byte stores
-template <typename T>
-__global__ __launch_bounds__(256) void gemm256_merge_kernel(GemmParams p) {
-  const long nk = p.k / p.bk;
-  const unsigned tiles = p.tiles_m * p.tiles_n, rem = tiles - p.n_full;
-  const long I = (long)rem * nk;
-  const unsigned ti = blockIdx.x / 8, band = blockIdx.x % 8;
-  long m0, n0;
-  gemm256_tile_origin(p, p.n_full + ti, m0, n0);
-  // units whose run intersects iterations [ti*nk, (ti+1)*nk)
-  long u_lo = (long)ti * nk * p.units / I; if (u_lo > 0) --u_lo;
-  long u_hi = ((long)(ti + 1) * nk * p.units + I - 1) / I + 1; if (u_hi > p.units) u_hi = p.units;
-  T* Cp = reinterpret_cast<T*>(p.c);
-  const T* G = reinterpret_cast<const T*>(p.gate);
-  const T* R = reinterpret_cast<const T*>(p.res);
-  for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
-    const int row = band * 32 + idx / 32, ch = idx % 32;
-    const long m = m0 + row, n = n0 + ch * 8;
-    if (m >= p.m || n >= p.n) continue;
-    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long u = u_lo; u < u_hi; ++u) {
-      const long it0 = u * I / p.units, it1 = (u + 1) * I / p.units;
-      const long t0 = it0 / nk;
-      int seg = -1;
-      if (t0 == ti && it1 > it0) seg = 0;
-      else if (t0 + 1 == ti && it1 > (t0 + 1) * nk) seg = 1;
-      if (seg < 0) continue;
-      const float* P = p.part + ((size_t)(2 * u + seg) * G2_BM + row) * G2_BN + ch * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] += P[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = apply_act(f[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f), p.act, p.act_param);
-    if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + (size_t)(m / p.gate_rows_per) * p.ldgate + n), g8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
-    if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)m * p.ldres + n), r8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] += r8[e]; }
-    *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = pack8<T>(f);
-  }
-}
 // ---- K-slice tail with a last-arriver fix-up (round 4) ---------------------------------------------------------------------
-// The stream-K tail above deals out the left-over tiles' iterations evenly, so no two of its units ever read the same operand rows at the
-// same time: 2.45 GB fetched per 8812 x 3072 x 15360 launch (PMC, profiles/r03_pmc_traffic.json) at 9 TB/s — the tail ran at the fabric's
-// limit, not the matrix pipe's (MFMA busy 0.36) — and a second launch (merge) summed the pieces.  Here every left-over tile is cut at
-// the SAME K positions into `slices` pieces; piece p = (slice p / rem, tile p % rem), and the XCD-contiguous workgroup order gives an
-// XCD a run of neighbouring tiles of ONE slice, which walk K in step and share their A / W panels through that XCD's L2 like the
-// whole-tile kernel's workgroups do.  A piece publishes its fp32 partial write-through (sc1) in the lane-contiguous order of its
-// accumulators (1 KB per wave store), drains, and draws a ticket of its tile; the piece that draws the last one acquires, adds the
-// tile's partials IN SLICE ORDER (the sum does not depend on who came last) and runs the whole-tile epilogue.
-// No merge launch; tickets return to zero.
+// With one 256 x 256 tile per CU at a time, `rem = tiles % CUs` left-over tiles keep rem CUs busy for a whole tile time while the
+// others idle (FLUX proj_out: 420 tiles on 256 CUs = 1.64 waves billed as 2).  Rounds 2-3 dealt the left-over tiles' iterations out
+// evenly (stream-K) and summed the pieces in a second launch: no two units ever read the same operand rows at the same time — 2.45 GB
+// fetched per 8812 x 3072 x 15360 launch at 9 TB/s (PMC, profiles/r03_pmc_traffic.json), the tail ran at the fabric's limit, not the
+// matrix pipe's (MFMA busy 0.36) — and the whole construction was SLOWER than not splitting at all (0.768 vs 0.725 ms, same process).
+// Here every left-over tile is cut at the SAME K positions into `slices` pieces; piece p = (slice p / rem, tile p % rem), and the
+// XCD-contiguous workgroup order gives an XCD a run of neighbouring tiles of ONE slice, which walk K in step and share their A / W
+// panels through that XCD's L2 like the whole-tile kernel's workgroups do.  A piece publishes its fp32 partial write-through (sc1) in
+// the lane-contiguous order of its accumulators (1 KB per wave store), drains, and draws a ticket of its tile; the piece that draws the
+// last one acquires, adds the tile's partials IN SLICE ORDER (the sum does not depend on who came last) and runs the whole-tile
+// epilogue.  No merge launch; tickets return to zero.  Measured (same process, profiles/r04_visit_c_slice_sweep.log): 8812x3072x15360
+// 0.700 ms (stream-K + merge 0.768, unsplit 0.725), 8300x3072x12288 0.533 (0.572 / 0.561), 512x3072x12288 0.068 (0.081 / 0.198).
 template <typename T, bool F8, int ACT>
 __global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
@@ -877,21 +781,24 @@ void gemm_last_split(int* out) { out[0] = g_last_split[0]; out[1] = g_last_split
 constexpr long G2_TICKET_BYTES = 4096;                                                   // 1024 tickets at the end of the workspace
 constexpr long G2_MAX_PIECES = ((long)MTX_GEMM_WORKSPACE_BYTES - G2_TICKET_BYTES) / ((long)G2_BM * G2_BN * 4);
 
-// K slices for `r` tiles of `nk` iterations on `cus` CUs: minimise rounds x (slice length + a few iterations of prologue / partial /
-// ticket per piece); returns 0 when no slicing beats `limit` (the cost of the alternative)
-static unsigned gemm256_choose_slices(unsigned r, long nk, unsigned cus, long limit, long* cost_out) {
-  unsigned best = 0; long best_cost = limit;
+// K slices for `r` tiles of `nk` iterations on `cus` CUs, in units of one K iteration of the main loop (~1.5 us bf16, ~1.4 us fp8).
+// Calibrated on MI355X with forced slice counts (tools/bench_kernels.py gemmsN, profiles/r04_visit_c_slice_sweep.log): a round of pieces
+// costs its iterations + ~6 (pipeline fill, publishing the partial, ticket); the partials' write + read-back costs ~0.07 per piece
+// (512 KB of traffic each); the last arriver's epilogue and its serial reads ~14 + 0.4 s^2.  Measured / modelled tails: 8812x3072x15360
+// s = 3: 223 / 224 iterations (s = 2: 281 / 291; one more whole wave: 240); 8300x3072x12288 s = 3: 173 / 187, s = 4: 224 / 221 (whole
+// wave: 192); 512x3072x12288 over s = 2, 3, 4, 6, 8, 10: 120, 88, 75, 66, 71, 80 / 121, 93, 81, 77, 83, 97 (unsplit: 192).
+// Returns 0 when no slicing beats `limit` (the cost of the alternative).
+static unsigned gemm256_choose_slices(unsigned r, long nk, unsigned cus, double limit) {
+  unsigned best = 0; double best_cost = limit;
   for (unsigned s = 2; s <= 16; ++s) {
     if ((long)r * s > G2_MAX_PIECES) break;
     const long len = (nk + s - 1) / s;
     if (len < 4) break;
-    const long used = (nk + len - 1) / len;                  // slices that are not empty
-    if (used != (long)s) continue;
+    if ((nk + len - 1) / len != (long)s) continue;           // a slice would be empty
     const long rounds = ((long)r * s + cus - 1) / cus;
-    const long cost = rounds * (len + 6) + 2 * (long)s + 3;  // per piece: pipeline fill + publishing the partial; once: the last arriver's s reads + epilogue
+    const double cost = (double)rounds * (double)(len + 6) + 0.07 * (double)r * s + 14.0 + 0.4 * (double)s * s;
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
-  if (cost_out) *cost_out = best_cost;
   return best;
 }
 
@@ -911,26 +818,14 @@ static void launch_gemm256_slices(const GemmParams& p, unsigned pieces, void* st
 // piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
 // specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
 template <typename T, bool F8>
-static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit, bool old_tail, unsigned forced_slices) {
+static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit, unsigned forced_slices) {
   GemmParams p = p0;
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
   const long nk = p.k / p.bk;
   const bool can = p.part != nullptr && cus <= 320 && grid.y == 1 && !nosplit;
-  if (old_tail) {          // round 3's stream-K tail + merge launch, kept for the same-process A/B of tools/bench_kernels.py
-    const bool tail = can && tiles > cus && rem > 0 && rem * 10 < cus * 7 && nk >= (force ? 4 : (F8 ? 32 : 64));
-    const bool allk = can && tiles * 2 <= cus && nk >= (F8 ? 64 : 128);
-    if (allk) { p.n_full = 0; p.units = cus; }
-    else if (tail) { p.n_full = tiles - rem; p.units = cus; grid.x = p.n_full; }
-    if (!allk) launch_gemm256_tiles<T, F8>(p, grid, stream);
-    if (tail || allk) {
-      MTX_LAUNCH((gemm256_tail_kernel<T, F8>), dim3(p.units), dim3(512), 0, stream, p);
-      MTX_LAUNCH((gemm256_merge_kernel<T>), dim3((tiles - p.n_full) * 8), dim3(256), 0, stream, p);
-    }
-    return;
-  }
   // left-over tiles of the last wave: K slices when they finish clearly before a whole extra tile time would
   if (can && tiles > cus && rem > 0 && nk >= (force ? 4 : (F8 ? 32 : 64))) {
-    unsigned s = gemm256_choose_slices(rem, nk, cus, nk * 8 / 10, nullptr);
+    unsigned s = gemm256_choose_slices(rem, nk, cus, 0.97 * (double)nk);
     if (forced_slices >= 2 && (long)rem * forced_slices <= G2_MAX_PIECES && (long)forced_slices * 2 <= nk) s = forced_slices;
     if (s) {
       p.n_full = tiles - rem; grid.x = p.n_full;
@@ -943,7 +838,7 @@ static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool f
   }
   // few tiles but a long K (FLUX text-stream ff2: 24 tiles x 192 iterations): slices over the whole problem
   if (can && tiles * 2 <= cus && nk >= (F8 ? 64 : 128)) {
-    unsigned s = gemm256_choose_slices(tiles, nk, cus, nk * 7 / 10, nullptr);
+    unsigned s = gemm256_choose_slices(tiles, nk, cus, 0.9 * (double)nk);
     if (forced_slices >= 2 && (long)tiles * forced_slices <= G2_MAX_PIECES && (long)forced_slices * 2 <= nk) s = forced_slices;
     if (s) {
       p.n_full = 0; p.slices = s; p.slice_len = (unsigned)((nk + s - 1) / s);
@@ -974,7 +869,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.gate_rows_per = a->gate_rows_per > 0 ? a->gate_rows_per : 1;
   p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;
-  p.n_full = 0; p.units = 0; p.slices = 1; p.slice_len = 0;
+  p.n_full = 0; p.slices = 1; p.slice_len = 0;
   p.part = (a->workspace && a->workspace_bytes >= (int64_t)MTX_GEMM_WORKSPACE_BYTES) ? reinterpret_cast<float*>(a->workspace) : nullptr;
   p.tickets = p.part ? reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a->workspace) + MTX_GEMM_WORKSPACE_BYTES - G2_TICKET_BYTES) : nullptr;
   p.a_scale = reinterpret_cast<const unsigned*>(a->a_scale); p.w_scale = reinterpret_cast<const unsigned*>(a->w_scale);
@@ -984,7 +879,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;
-  const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0, old_tail = (a->flags & MTX_GEMM_OLD_TAIL) != 0;
+  const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0;
   const unsigned forced_slices = ((unsigned)a->flags >> 8) & 0xffu;
   // large, aligned problems: the 256 x 256 LDS-DMA kernel (needs whole K tiles and 16-byte rows everywhere)
   const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;
@@ -1010,7 +905,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
       else MTX_LAUNCH((gemm256_f8_glu_kernel<_Float16>), g2, dim3(512), 0, stream, p);
       return MTX_OK;
     }
-    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, true>(p, g2, stream, force, nosplit, old_tail, forced_slices); else launch_gemm256<_Float16, true>(p, g2, stream, force, nosplit, old_tail, forced_slices);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, true>(p, g2, stream, force, nosplit, forced_slices); else launch_gemm256<_Float16, true>(p, g2, stream, force, nosplit, forced_slices);
     return MTX_OK;
   }
   // with the descriptor-DMA loop the 256-tile kernel wins from ~24 tiles up even though most CUs idle (512x9216x3072: 55 vs 68 us,
@@ -1025,7 +920,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
     p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
     p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
     dim3 g2(p.tiles_m * p.tiles_n, (unsigned)batch);
-    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, false>(p, g2, stream, force, nosplit, old_tail, forced_slices); else launch_gemm256<_Float16, false>(p, g2, stream, force, nosplit, old_tail, forced_slices);
+    if (a->dtype == MTX_BF16) launch_gemm256<__bf16, false>(p, g2, stream, force, nosplit, forced_slices); else launch_gemm256<_Float16, false>(p, g2, stream, force, nosplit, forced_slices);
     return MTX_OK;
   }
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);

@@ -315,7 +315,7 @@ class PlanBuilder:
         g.act, g.act_param, g.alpha = act, 0.0, alpha
         g.dtype, g.out_dtype = self.dtype, (abi.F32 if out_f32 else self.dtype)
         if ((m >= 2048 and n >= 1024 and k >= 512) or (m >= 256 and k >= 8192) or (flags & abi.GEMM_FORCE_TILE256)) and batch == 1 and not out_f32:
-            # large problems: one shared scratch per plan for the stream-K tail of the 256-tile kernel (ops of a plan run in order)
+            # large problems: one shared scratch per plan for the K-slice tail of the 256-tile kernel (ops of a plan run in order)
             # (side-lane ops run beside main-lane ops: they get a scratch of their own)
             ws_name = "_gemm_ws_side" if self._side else "_gemm_ws"
             if getattr(self, ws_name, None) is None:

@@ -566,7 +566,7 @@ def check_gemm_f8_glu(lib, dtype, m, col0, hid, k, seed=0, row_off=0, q_col_off=
             c = pb.gemm(aq, wq, m, n, k, out=pb.buf((m, n), TD[dtype], zero=True) if col0 else None, f8=(asc, lds_a, wsc, lds_w, 0, 0),
                         flags=abi.GEMM_FORCE_TILE256, glu=(q8, sc, QW, lds, col0, row_off, q_col_off))
         else:
-            # NO_SPLIT: the gated kernel computes whole tiles; the stream-K tail FORCE_TILE256 would otherwise give this reference on a 256-CU
+            # NO_SPLIT: the gated kernel computes whole tiles; the K-slice tail FORCE_TILE256 would otherwise give this reference on a 256-CU
             # chip (8512 x 27648: 88 left-over tiles) sums K in slabs, i.e. in another fp32 order — found on hardware, round 4's first visit
             c = pb.gemm(aq, wq, m, n, k, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=abi.GEMM_FORCE_TILE256 | abi.GEMM_NO_SPLIT)
             pb.quantize(c, m, hid, ldx=n, x_off=col0, q=q8, scale=sc, row_off=row_off, lds=lds, ldq=QW, q_col_off=q_col_off,

@@ -33,7 +33,7 @@ def calibrate_logits(model, ref, target_std=5.0):
     return gain
 
 
-def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, logit_tol=0.08, mask_tol=0.01, calibrated=False, **hip_kw):
+def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, logit_tol=0.08, mask_tol=0.01, calibrated=False, abs_tol=1.0, rms_tol=0.2, **hip_kw):
     model, cfg = sr.make_model(size, seed)
     page = make_page(h, w, seed)
     rng = np.random.default_rng(seed + 5)
@@ -109,12 +109,11 @@ def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, l
         # logit units (rms far below), hence no page pixel whose fp32 logit is farther than abs_tol from 0 may differ — and the pixels a
         # trained model leaves that close to the threshold are the one-pixel rims of its masks
         d = (low.float().cpu() - low_ref).abs()
-        abs_tol = 1.0
         rim = up_ref.abs() <= abs_tol
         stats.update(logit_gain=gain, logit_std=low_ref.std().item(), boxes_compared=n_cmp, stability_scores=[round(v, 4) for v in cap["stab"].tolist()], logit_abs_err_rms=d.pow(2).mean().sqrt().item(),
                      logit_abs_err_p999=d.flatten().kthvalue(max(1, int(0.999 * d.numel()))).values.item(),
                      pixels_within_1_logit_frac=float(rim.float().mean().item()), wrong_beyond_1_logit=int((diff & ~rim).sum().item()))
         assert delta < abs_tol, f"low-resolution logit error {delta:.3f} logit units at std 5"
-        assert stats["logit_abs_err_rms"] < 0.2, stats["logit_abs_err_rms"]          # measured 0.138 (Hiera-L, 48 bf16 blocks): 2.8 % of the logit spread
+        assert stats["logit_abs_err_rms"] < rms_tol, stats["logit_abs_err_rms"]      # measured at Hiera-L, logit std 11.2: 0.138 with bf16 storage, 0.017 with f16
         assert stats["wrong_beyond_1_logit"] == 0
     return err, mism

@@ -156,7 +156,6 @@ def test_gemm_k_slice_tail(hip_lib):
     oc.check_gemm(hip_lib, abi.BF16, m=8624, n=3072, k=15360, act=abi.ACT_NONE, with_res=True, with_gate=True, runs=3, expect_split=(256, "sliced", None))   # left-over tiles only
     oc.check_gemm(hip_lib, abi.BF16, m=8812, n=3072, k=15360, with_res=True, with_gate=True, runs=2, expect_split=(256, "sliced", None))
     oc.check_gemm(hip_lib, abi.F16, m=8112, n=3072, k=12288, runs=2, expect_split=(256, "sliced", None))
-    oc.check_gemm(hip_lib, abi.BF16, m=8624, n=3072, k=15360, with_res=True, with_gate=True, flags=abi.GEMM_OLD_TAIL)                # round 3's form (A/B only)
 
 
 @pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])

@@ -20,3 +20,43 @@ def test_sam2_tiny(emu_lib):
 
 def test_sam2_tiny_one_box_landscape(emu_lib):
     sc.check_sam2(emu_lib, "cpu", "tiny_test", h=120, w=260, n_boxes=1, seed=3)
+
+
+def test_sam2_tiny_f16_storage(emu_lib):
+    """f16 storage (what `ModelManager.load_sam2` tries first): same graph, 3 more mantissa bits"""
+    from mangatranslator_amd.hip import abi
+    err, mism = sc.check_sam2(emu_lib, "cpu", "tiny_test", h=300, w=200, n_boxes=3, seed=0, dtype=abi.F16)
+    assert err < 0.01
+
+
+def test_manager_loads_sam_in_f16_and_falls_back_to_bf16(emu_lib, tmp_path, monkeypatch):
+    """reference model_manager.py:982-1010: (processor, model).  The loader takes f16 storage when the f16 and bf16 models agree on the
+    load-time probe, bf16 otherwise (a checkpoint with an activation beyond 65504 saturates in f16 and must not be served that way)."""
+    import torch
+    from safetensors.torch import save_file
+    import mangatranslator_amd.hip.lib as libmod
+    from mangatranslator_amd.core.ml import model_manager as mm
+    from mangatranslator_amd.hip import abi
+    from oracle import sam2_ref as sr
+    monkeypatch.setattr(libmod, "_lib", emu_lib)
+    monkeypatch.setattr(mm, "_model_manager", None)
+    monkeypatch.setattr(mm.ModelManager, "_instance", None)
+    m = mm.get_model_manager()
+    try:
+        root = tmp_path / "sam"
+        m.model_paths[mm.ModelType.SAM2] = root
+        model, cfg = sr.make_model("tiny_test", 0)
+        cfg.save_pretrained(str(root))
+        sd = {k: v.contiguous() for k, v in model.state_dict().items()}
+        save_file(sd, str(root / "model.safetensors"))
+        proc, shim = m.load_sam2()
+        assert shim.hip.dtype == abi.F16
+        m.unload_model(mm.ModelType.SAM2)
+        # blow up one MLP of the trunk: its hidden activations leave the f16 range
+        key = next(k for k in sd if "backbone" in k and "mlp" in k and k.endswith("proj_in.weight"))
+        sd[key] = sd[key] * 3.0e5
+        save_file(sd, str(root / "model.safetensors"))
+        proc, shim = m.load_sam2()
+        assert shim.hip.dtype == abi.BF16
+    finally:
+        monkeypatch.setattr(mm.ModelManager, "_instance", None)

@@ -48,7 +48,7 @@ def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0):
         pb.gemm(a, w, M, N, K, lda=K + pad, ldw=K + pad, flags=flags)
     ms = _time(pb.build(), iters)
     split = lib.gemm_last_split()
-    tag = " [r03 stream-K tail + merge]" if flags & abi.GEMM_OLD_TAIL else (" [whole tiles only]" if flags & abi.GEMM_NO_SPLIT else f" [whole tiles, K slices, pieces = {split}]")
+    tag = " [whole tiles only]" if flags & abi.GEMM_NO_SPLIT else f" [whole tiles, K slices, pieces = {split}]"
     print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}{f' ld+{pad}' if pad else ''}{tag}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
@@ -83,10 +83,10 @@ if __name__ == "__main__":
             conv(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "gemmp":
             gemm(int(args[1]), int(args[2]), int(args[3]), pad=int(args[4])); args = args[5:]
-        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmo", "gemm8o", "gemmn", "gemm8n", "gemms", "gemm8s"):
-            # ...o: round 3's tail (A/B), ...n: no split at all, ...sN: exactly N K slices (e.g. gemms4, gemm8s2)
+        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmn", "gemm8n", "gemms", "gemm8s"):
+            # ...n: no split at all, ...sN: exactly N K slices (e.g. gemms4, gemm8s2)
             name = args[0].rstrip("0123456789")
-            fl = abi.GEMM_OLD_TAIL if name.endswith("o") else (abi.GEMM_NO_SPLIT if name.endswith("n") else 0)
+            fl = abi.GEMM_NO_SPLIT if name.endswith("n") else 0
             if name.endswith("s"):
                 fl = int(args[0][len(name):]) << 8
             gemm(int(args[1]), int(args[2]), int(args[3]), f8=args[0].startswith("gemm8"), flags=fl); args = args[4:]
