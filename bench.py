@@ -98,10 +98,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-traffic", action="store_true",
-                    help="fill roofline.traffic: re-run THIS command (same configuration, one page) twice under `rocprofv3 --pmc FETCH_SIZE` / "
-                         "`--pmc WRITE_SIZE` with --kernel-trace (separate passes, counters only) and average the dominant kernel group's bytes per "
-                         "launch — fabric-side bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  Adds two model set-ups to the run.")
+    ap.add_argument("--with-traffic", action="store_true", help=argparse.SUPPRESS)       # (round 3's opt-in; the counter child now runs by default)
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the counter child that fills roofline.traffic: after the timed region rank 0 (at --gpus 1) re-executes this command's inpaint "
+                         "(or upscale) stage under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two passes, --kernel-trace only) on a DiT cut to "
+                         "2 + 4 blocks (same kernels, shapes and launch mix: bytes per launch do not depend on depth) with one denoising step, ~60 s")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--batch-io", type=int, default=0,
                     help="after the timed region: N pages through `batch_process_images` WITH image I/O — PNG files decoded from disk, uploaded, "
@@ -248,7 +249,7 @@ def main():
     upscaler, rcan_sd, rcan_cfg = None, None, None
     if "upscale" in want:
         from mangatranslator_amd.core.ml.rcan import RCANUpscaler
-        from oracle.rcan_ref import make_state_dict   # synthetic checkpoint generator (no real weights offline)
+        from mangatranslator_amd.utils.synthetic_checkpoints import rcan_state_dict as make_state_dict   # seeded stand-in checkpoint (no real weights offline)
         if args.upscale_model == "model_lite":   # assumed Fast_RCAN_PU shape; real hyper-parameters come from the file
             rcan_cfg = dict(n_feats=64, n_resgroups=4, n_resblocks=8, unshuffle=2)
         else:                                    # canonical RCAN: 10 groups x 20 RCAB x 64 feats
@@ -261,29 +262,22 @@ def main():
     aux_detectors = []
     if "detect" in want:
         from mangatranslator_amd.core.ml.yolo import YoloSegHip
-        from oracle.yolo_ref import make_model as make_yolo       # seeded YOLOv8m-seg (the reference's yolo_1 geometry)
-        ynet = make_yolo("m", 1, seed=3 if first else 0)
-        with torch.no_grad():      # tame the random head so NMS sees a realistic number of candidates
-            for l in range(3):
-                ynet.model[22].cv3[l][2].weight.mul_(0.05); ynet.model[22].cv3[l][2].bias.fill_(-1.0)
-                ynet.model[22].cv2[l][2].weight.mul_(0.1)
-        ysd = ynet.state_dict()
+        from mangatranslator_amd.utils import synthetic_checkpoints as synth
+        # seeded YOLOv8m-seg (the reference's yolo_1 geometry) from its parameter inventory; the random head is tamed so NMS sees a
+        # realistic number of candidates
+        v8_shapes, v8_head = synth.yolov8_seg_shapes("m", 1)
+        ysd = synth.seeded_detector(v8_shapes, v8_head, seed=3 if first else 0, class_bias=-1.0, class_gain=0.05, box_gain=0.1)
         if world > 1:
             ysd = broadcast_state_dict(ysd, rank, world, device)
         yolo = YoloSegHip(ysd, device=device, lib=lib, graph=graph)
         if args.bubble_detector == "yolo_2" or not args.no_aux_detectors:
             from mangatranslator_amd.core.ml.yolo11 import Yolo11Hip
-            from oracle import yolo11_ref as y11
 
             def seeded_y11(family, scale, seg, seed):
-                """seeded network of the published architecture, head tamed like the YOLOv8 one above"""
-                n_ = y11.make_model(family, scale, 1, seg, seed=seed if first else 0)
-                with torch.no_grad():
-                    hd = n_.model[-1]
-                    for l in range(3):
-                        hd.cv3[l][2].weight.mul_(0.05); hd.cv3[l][2].bias.fill_(-2.0)       # scores ~ 0.12: below every threshold used here
-                        hd.cv2[l][2].weight.mul_(0.1)
-                sd_ = n_.state_dict()
+                """seeded network of the published architecture (parameter inventory), head tamed like the YOLOv8 one above: scores ~ 0.12,
+                below every threshold used here"""
+                shapes_, head_ = synth.yolo11_shapes(family, scale, 1, seg)
+                sd_ = synth.seeded_detector(shapes_, head_, seed=seed if first else 0, class_bias=-2.0, class_gain=0.05, box_gain=0.1)
                 if world > 1:
                     sd_ = broadcast_state_dict(sd_, rank, world, device)
                 return Yolo11Hip(sd_, device=device, lib=lib, graph=graph)
@@ -293,28 +287,21 @@ def main():
                 aux_detectors = [("panel", seeded_y11("11", "l", False, 17), 0.25), ("osb_text", seeded_y11("12", "x", False, 19), 0.4)]
         # secondary detector of the same stage: RT-DETR-v2 R50 @640 (reference detection.py:1401-1407, on by default)
         from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
-        from oracle.rtdetr_ref import make_model as make_rtdetr
-        rnet, rcfg = make_rtdetr("r50", seed=5 if first else 0)
-        rsd = rnet.state_dict()
+        rcfg = synth.rtdetr_r50_config()
+        rsd = synth.rtdetr_state_dict(rcfg, seed=5 if first else 0)
         if world > 1:
-            rsd = broadcast_state_dict({k: v for k, v in rsd.items() if v.is_floating_point()}, rank, world, device)
+            rsd = broadcast_state_dict(rsd, rank, world, device)
         rtdetr = RTDetrHip(rsd, rcfg, device=device, lib=lib, graph=graph, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
-        del rnet
     sam = None
     if "segment" in want:
         from mangatranslator_amd.core.ml.sam2 import Sam2Hip
         from mangatranslator_amd.hip.abi import F16 as abi_f16
-        from oracle.sam2_ref import make_config, make_model
+        from mangatranslator_amd.utils import synthetic_checkpoints as synth_sam
+        sam_cfg = synth_sam.sam2_hiera_large_config()           # facebook/sam2.1-hiera-large geometry, seeded weights
         if first:
-            m, sam_cfg = make_model("hiera_large", seed=11)     # facebook/sam2.1-hiera-large geometry, seeded weights
-            sam_sd = {k: v for k, v in m.state_dict().items()}
-            del m
+            sam_sd = synth_sam.sam2_state_dict(sam_cfg, seed=11)
         else:
-            from transformers import Sam2Model
-            sam_cfg = make_config("hiera_large")
-            with torch.device("meta"):
-                shapes = {k: v.shape for k, v in Sam2Model(sam_cfg).state_dict().items()}
-            sam_sd = {k: torch.empty(s) for k, s in shapes.items()}
+            sam_sd = {k: torch.empty(shp) for k, shp in synth_sam.sam2_shapes(sam_cfg).items()}
         if world > 1:
             sam_sd = broadcast_state_dict(sam_sd, rank, world, device)
         sam = Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph, dtype=abi_f16)        # f16 storage: what ModelManager.load_sam2 serves (bf16 only when a checkpoint leaves the f16 range)
@@ -330,6 +317,8 @@ def main():
             from mangatranslator_amd.core.ml import flux as fx
             from mangatranslator_amd.core.ml import flux2 as f2
             dcfg = f2.KLEIN_9B_DIT_CFG if args.inpainter == "klein_9b" else f2.KLEIN_4B_DIT_CFG
+            if args.traffic_child:      # counter pass: same kernels, shapes and double : single launch mix on a fraction of the depth
+                dcfg = dict(dcfg, layers=max(1, dcfg["layers"] // 5), single_layers=max(1, dcfg["single_layers"] // 5))
             dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8, fused_quant=not args.no_fused_quant, glu_epilogue=not args.no_glu_epilogue, attn_q8=not args.no_glu_epilogue)
             vae = f2.Flux2VAEHip(fx.synthetic_provider(f2.vae_param_shapes(f2.KLEIN_VAE_CFG), device, 22, broadcast=world > 1), f2.KLEIN_VAE_CFG, device, lib=lib)
             flux = f2.Flux2KleinHip(dit, vae, graph=graph)
@@ -340,7 +329,10 @@ def main():
             from mangatranslator_amd.core.image.inpainting import FluxKontextInpainter
             from mangatranslator_amd.core.ml import flux as fx
             # 11.9 B-parameter MMDiT + 84 M-parameter VAE, bf16, seeded on rank 0's GPU and broadcast tensor by tensor
-            dit = fx.FluxDiTHip(fx.synthetic_provider(fx.dit_param_shapes(fx.KONTEXT_DIT_CFG), device, 21, broadcast=world > 1), fx.KONTEXT_DIT_CFG, device, lib=lib,
+            kcfg = fx.KONTEXT_DIT_CFG
+            if args.traffic_child:      # counter pass: 2 + 4 of the 19 + 38 blocks (the same 1 : 2 launch mix; bytes per launch do not depend on depth)
+                kcfg = dict(kcfg, layers=2, single_layers=4)
+            dit = fx.FluxDiTHip(fx.synthetic_provider(fx.dit_param_shapes(kcfg), device, 21, broadcast=world > 1), kcfg, device, lib=lib,
                                 text_stream_on_side_lane=not args.no_lanes)
             vae = fx.FluxVAEHip(fx.synthetic_provider(fx.vae_param_shapes(fx.KONTEXT_VAE_CFG), device, 22, broadcast=world > 1), fx.KONTEXT_VAE_CFG, device, lib=lib)
             flux = fx.FluxKontextHip(dit, vae, graph=graph)
@@ -487,7 +479,12 @@ def main():
             outs["inpaint"], _ = otp.finish_outside_text_work(work_) if work_ is not None else (page_pil[k], [])
             tl = lap("inpaint_finish", tl)
         if upscaler is not None:
-            outs["upscale"] = upscaler.upscale_u8(pages[k])
+            # chained like the page flow (core/pipeline.py process_page_vision): the upscaler takes the page the inpaint stage produced
+            # (a host image, as the operator API hands it over: one more upload), not the original
+            src = pages[k]
+            if inpainter is not None and outs.get("inpaint") is not None:
+                src = torch.from_numpy(np.asarray(outs["inpaint"] if outs["inpaint"].mode == "RGB" else outs["inpaint"].convert("RGB"))).to(device)
+            outs["upscale"] = upscaler.upscale_u8(src)
             tl = lap("upscale", tl)
         if clean_args is not None:
             dm_, bbs_ = clean_args[k]
@@ -769,7 +766,7 @@ def main():
                 result["roofline_upscale_conv"] = conv_roof
             else:
                 result["roofline"] = conv_roof
-        if args.with_traffic and not args.traffic_child and world == 1 and "roofline" in result:
+        if not args.no_traffic and not args.traffic_child and world == 1 and "roofline" in result:
             result["roofline"]["traffic"], result["roofline"]["traffic_detail"] = measure_traffic(result["roofline"]["kernel"])
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is a single-GPU-run item (rank 0 at N = 1 only)
             result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"), flux.transformer.cfg if (klein and flux is not None) else None)
@@ -792,7 +789,7 @@ def measure_traffic(kernel_desc: str):
     if shutil.which("rocprofv3") is None:
         return None, {"error": "rocprofv3 not on PATH"}
     want = "attn_mma32" if kernel_desc.startswith("attn") else ("conv3x3_c64" if kernel_desc.startswith("conv") else "gemm256")
-    base = [a_ for a_ in sys.argv[1:] if a_ not in ("--with-traffic",)]
+    base = [a_ for a_ in sys.argv[1:] if a_ not in ("--with-traffic", "--no-traffic")]
     for flag in ("--steps", "--warmup", "--stages", "--inpaint-steps", "--batch-io"):
         if flag in base:
             i_ = base.index(flag)
@@ -811,11 +808,11 @@ def measure_traffic(kernel_desc: str):
             proc = subprocess.Popen(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--"] + child,
                                     cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
             try:
-                _, err_ = proc.communicate(timeout=300)
+                _, err_ = proc.communicate(timeout=150)
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, signal.SIGKILL)          # the profiler AND the bench process under it (its own process group)
                 proc.communicate()
-                return None, {"error": f"{counter} pass did not finish in 300 s"}
+                return None, {"error": f"{counter} pass did not finish in 150 s"}
             r = types_.SimpleNamespace(returncode=proc.returncode, stderr=err_)
             files = glob.glob(tmp + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:

@@ -24,7 +24,7 @@ from PIL import Image
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, AsyncLane, PlanBuilder, PlanCache
+from ...hip.plan import Act, AsyncLane, LaneTicket, PlanBuilder, PlanCache, result_tensors
 from ...utils.exceptions import ModelError
 
 
@@ -351,7 +351,7 @@ class RTDetrHip:
         with self._lane.busy:
             with self._lane.enter():
                 out = self._enqueue(img_u8)
-            self._lane.hand_over()
+            self._lane.hand_over(*result_tensors(out))
             return out
 
     def _enqueue(self, img_u8: np.ndarray):
@@ -389,7 +389,7 @@ class RTDetrHip:
         ow, oh = pil.size
         size = int(imgsz) if imgsz is not None else 640
         img = np.asarray(pil.resize((size, size), resample=Image.Resampling.BILINEAR))        # RTDetrImageProcessor: resize + 1/255
-        self._lane.busy.acquire()
+        self._lane.acquire()
         try:
             with self._lane.enter():
                 logits, boxes = self._enqueue(img)
@@ -403,9 +403,9 @@ class RTDetrHip:
                 xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1) * scale
                 keep = top_s > float(conf)
         except BaseException:
-            self._lane.busy.release()
+            self._lane.release()
             raise
-        return dict(xyxy=xyxy, top_s=top_s, labels=labels, keep=keep, hw=(oh, ow))
+        return LaneTicket(self._lane, xyxy=xyxy, top_s=top_s, labels=labels, keep=keep, hw=(oh, ow))
 
     @torch.no_grad()
     def collect(self, t):
@@ -414,10 +414,10 @@ class RTDetrHip:
                 keep = t["keep"]
                 res = [SimpleNamespace(boxes=_Boxes(t["xyxy"][keep].float(), t["top_s"][keep].float(), t["labels"][keep].float()), names=self.names,
                                        orig_shape=t["hw"], masks=None)]
-            self._lane.hand_over()
+            self._lane.hand_over(*result_tensors(res))
             return res
         finally:
-            self._lane.busy.release()
+            t.close() if isinstance(t, LaneTicket) else self._lane.release()
 
 
 class _Boxes:

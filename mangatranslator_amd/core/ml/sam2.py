@@ -33,7 +33,7 @@ import torch.nn.functional as F
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, AsyncLane, PlanBuilder, PlanCache
+from ...hip.plan import Act, AsyncLane, LaneTicket, PlanBuilder, PlanCache, result_tensors
 from ...utils.exceptions import ModelError
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -474,8 +474,9 @@ class Sam2Hip:
         1.6 TFLOP encoder runs beside them.  The ticket goes to `segment(..., ticket=)`; the model is busy until then."""
         page = torch.as_tensor(page_u8)
         h, w = int(page.shape[0]), int(page.shape[1])
-        self._lane.busy.acquire()
+        self._lane.acquire()
         try:
+            self._lane.adopt(page)
             with self._lane.enter():
                 pre = self._pre_plan(h, w)
                 enc = self._encoder()
@@ -483,28 +484,31 @@ class Sam2Hip:
                 pre.run()
                 enc.run(graph=self._graph)
         except BaseException:
-            self._lane.busy.release()
+            self._lane.release()
             raise
-        return dict(hw=(h, w), page=page)
+        return LaneTicket(self._lane, hw=(h, w), page=page)
 
     def segment(self, page_u8, boxes_xyxy, return_logits: bool = False, ticket=None):
         """page uint8 [H,W,3] (numpy or tensor) + boxes [N,4] in page pixels -> uint8 masks [N,H,W] (0/1)
         on the device.  One encoder pass per page, all boxes decoded together (as the reference does).  `ticket`: the page was
-        already encoded by `submit_image` (same page object)."""
+        already encoded by `submit_image` (same page object); the ticket is closed here (a dropped ticket frees the model by itself)."""
         boxes = np.asarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
         n = boxes.shape[0]
         page = torch.as_tensor(page_u8)
         h, w = int(page.shape[0]), int(page.shape[1])
+        close = (lambda: ticket.close()) if isinstance(ticket, LaneTicket) else self._lane.release
         if ticket is not None and ticket["hw"] != (h, w):
-            self._lane.busy.release()
+            close()
             raise ModelError("SAM ticket belongs to a page of another size")
         if n == 0:
             if ticket is not None:
-                self._lane.busy.release()
+                close()
             return torch.zeros((0, h, w), dtype=torch.uint8, device=self.device)
         if ticket is None:
-            self._lane.busy.acquire()
+            self._lane.acquire()
         try:
+            if ticket is None:
+                self._lane.adopt(page)
             with self._lane.enter() if ticket is None else self._lane.resume():
                 pre = self._pre_plan(h, w)
                 enc = self._encoder()
@@ -525,10 +529,10 @@ class Sam2Hip:
                     lg = dec.logits.view(n, dec.hl, dec.hl, 4)
                     low = lg[torch.arange(n, device=self.device), :, :, sel].clone()
                     out = (masks, low, dec.iou.clone(), dec.sel.clone())
-            self._lane.hand_over()
+            self._lane.hand_over(*result_tensors(out))
             return out
         finally:
-            self._lane.busy.release()
+            close()
 
     @torch.no_grad()
     def probe_logits(self, size: int = 256) -> torch.Tensor:

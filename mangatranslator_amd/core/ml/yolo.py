@@ -26,7 +26,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import AsyncLane, PlanBuilder, PlanCache
+from ...hip.plan import AsyncLane, LaneTicket, PlanBuilder, PlanCache, result_tensors
 from ...utils.exceptions import ModelError
 
 
@@ -243,8 +243,10 @@ class YoloSegHip:
         h0, w0 = int(img.shape[0]), int(img.shape[1])
         lp = letterbox_params(h0, w0, imgsz)
         key = (h0, w0, imgsz)
-        self._lane.busy.acquire()
+        self._lane.acquire()
         try:
+            if on_device:
+                self._lane.adopt(image_bgr)
             with self._lane.enter():
                 if key not in self._plans:
                     plan = self._build(lp)
@@ -259,9 +261,9 @@ class YoloSegHip:
                 pp.run()
                 plan.run(graph=self._graph)
         except BaseException:
-            self._lane.busy.release()
+            self._lane.release()
             raise
-        return dict(plan=plan, lp=lp, hw=(h0, w0), conf=conf, iou=iou, max_det=max_det)
+        return LaneTicket(self._lane, plan=plan, lp=lp, hw=(h0, w0), conf=conf, iou=iou, max_det=max_det)
 
     @torch.no_grad()
     def collect(self, ticket):
@@ -269,10 +271,10 @@ class YoloSegHip:
         try:
             with self._lane.resume():
                 res = self._finish(**ticket)
-            self._lane.hand_over()
+            self._lane.hand_over(*result_tensors(res))
             return res
         finally:
-            self._lane.busy.release()
+            ticket.close() if isinstance(ticket, LaneTicket) else self._lane.release()
 
     def _finish(self, plan, lp, hw, conf, iou, max_det):
         h0, w0 = hw

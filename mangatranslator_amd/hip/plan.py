@@ -621,7 +621,74 @@ class AsyncLane:
         """context for the collect half (reads the results on the lane's stream)"""
         return torch.cuda.stream(self.stream) if self.on else contextlib.nullcontext()
 
-    def hand_over(self):
-        """the caller's stream may touch what the lane produced"""
+    def adopt(self, *tensors):
+        """device tensors the CALLER allocated and the lane's kernels read (a page uploaded once for several detectors): the allocator
+        must not hand their blocks out again while the lane still reads them, whatever the caller does with them after `submit`"""
         if self.on:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            for t in tensors:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self.stream)
+
+    def hand_over(self, *tensors):
+        """the caller's stream may touch what the lane produced; `tensors` = results allocated on the lane's stream that leave with the
+        caller (their blocks return to the lane's pool when the caller drops them: recorded on the caller's stream so that the lane does
+        not reuse them under kernels of the caller that still read them — ADVICE r03)"""
+        if self.on:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.stream)
+            for t in tensors:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+
+    def acquire(self):
+        self.busy.acquire()
+
+    def release(self):
+        """idempotent: a ticket may be closed by `collect` and again by its finaliser"""
+        try:
+            self.busy.release()
+        except RuntimeError:
+            pass
+
+
+def result_tensors(obj, _depth=0):
+    """the CUDA tensors reachable from a result object (lists / tuples / dicts / namespaces / small result classes, three levels deep):
+    what `AsyncLane.hand_over` records on the consumer's stream"""
+    if torch.is_tensor(obj):
+        return [obj] if obj.is_cuda else []
+    if _depth >= 3 or obj is None or isinstance(obj, (str, bytes, int, float, bool)):
+        return []
+    if isinstance(obj, dict):
+        items = obj.values()
+    elif isinstance(obj, (list, tuple)):
+        items = obj
+    elif hasattr(obj, "__dict__"):
+        items = vars(obj).values()
+    else:
+        return []
+    out = []
+    for v in items:
+        out += result_tensors(v, _depth + 1)
+    return out
+
+
+class LaneTicket(dict):
+    """What a model's `submit` returns: the arguments of its `collect` half, plus the duty to free the model's lane.  `collect` closes it;
+    a ticket that is DROPPED (an exception between submit and collect in the caller) releases the lane when it is garbage-collected, so a
+    failed page cannot leave a model busy for good.  The lane's stream is in order, so a later submit that reuses the
+    model's buffers still runs behind whatever the dropped ticket had queued."""
+
+    def __init__(self, lane: "AsyncLane", **fields):
+        super().__init__(**fields)
+        self._lane, self._open = lane, True
+
+    def close(self):
+        if self._open:
+            self._open = False
+            self._lane.release()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 — interpreter shutdown
+            pass
