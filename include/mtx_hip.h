@@ -382,7 +382,7 @@ typedef struct mtx_tail_args {
   const void* src; void* dst;
   int32_t out_h, out_w, c;
   int64_t ld_src, ld_dst;
-  const int32_t* bounds; const int32_t* coeff; int32_t ksize, axis, src_row0;                 /* RESAMPLE */
+  const int32_t* bounds; const int32_t* coeff; int32_t ksize, axis, src_row0, coeff_bits;     /* RESAMPLE (coeff_bits: fractional bits of the taps, 0 = Pillow's 22) */
   const float* alpha; int64_t ld_alpha; int32_t x, y, page_c, src_c;                           /* COMPOSITE (ld_alpha in floats; c = channels blended, src_c = bytes per patch pixel, 0 = c) */
   const int32_t* gamma_tab; const int32_t* cbrt_tab; const int32_t* lab_coef; int32_t cbrt_n; /* LAB_* */
   const uint8_t* mask; int64_t ld_mask; const void* other; int64_t ld_other;

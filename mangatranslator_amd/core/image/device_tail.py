@@ -93,6 +93,40 @@ def pil_resample_tables(in_size: int, out_size: int, filter_name: str = "lanczos
     return bounds, taps, ksize
 
 
+def aten_aa_bilinear_tables(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int, int]:
+    """(bounds int32 [out, 2], taps int32 [out, ksize], ksize, fractional bits) of one axis of
+    `torch.nn.functional.interpolate(uint8 image, mode="bilinear", antialias=True, align_corners=False)` — the ATen CPU kernel
+    torchvision's `resize` runs on uint8 images, hence what HF's Sam2ImageProcessorFast does to the page the reference hands it
+    (core/image/detection.py:494-495).  Triangle filter widened by the down-scale factor, window bounds by C truncation, taps
+    normalised in floating point, then 16-bit fixed point with as many fractional bits as keep the largest tap below 2^15; a pass
+    accumulates from 2^(bits-1), shifts and clips, horizontal pass first with a uint8 intermediate.  PINNED: this restatement is
+    compared bit for bit with the installed torch kernel over 60 size pairs incl. 1536x1024 -> 1024x1024 (tests/test_sam_preprocess.py)."""
+    scale = float(in_size) / float(out_size)
+    support = scale if scale >= 1.0 else 1.0
+    invscale = 1.0 / scale if scale >= 1.0 else 1.0
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    w = np.zeros((out_size, ksize), np.float64)
+    for i in range(out_size):
+        center = scale * (i + 0.5)
+        xmin = max(int(center - support + 0.5), 0)
+        xsize = min(int(center + support + 0.5), in_size) - xmin
+        k = [max(0.0, 1.0 - abs((j + xmin - center + 0.5) * invscale)) for j in range(xsize)]
+        total = 0.0
+        for v in k:
+            total += v
+        if total != 0.0:
+            k = [v / total for v in k]
+        bounds[i] = (xmin, xsize)
+        w[i, :xsize] = k
+    wmax = float(w.max())
+    bits = 0
+    while bits < 22 and int(0.5 + wmax * (1 << (bits + 1))) < (1 << 15):
+        bits += 1
+    taps = np.where(w < 0, (-0.5 + w * (1 << bits)), (0.5 + w * (1 << bits))).astype(np.int64).astype(np.int32)
+    return bounds, taps, ksize, bits
+
+
 class DeviceTail:
     def __init__(self, lib, device):
         from .color import _CBRT32, _COEF32, _GAMMA32

@@ -429,7 +429,26 @@ class Sam2Hip:
             enc = self._encoder()
             pb = PlanBuilder(self.lib, self.device, self.dtype)
             page = pb.buf((h, w, 3), torch.uint8)
-            pb.preprocess(page, enc.img, h, w, IMAGENET_MEAN, IMAGENET_STD)
+            # Sam2ImageProcessorFast resizes the uint8 page with torchvision's antialiased bilinear `resize`, i.e. ATen's fixed-point
+            # uint8 kernel (horizontal pass, uint8 intermediate, vertical pass), then rescales and normalises in fp32: the two passes run
+            # with ATen's own taps (core/image/device_tail.py aten_aa_bilinear_tables, pinned against the installed torch), the
+            # normalisation in the preprocess kernel at identity size
+            from ..image.device_tail import aten_aa_bilinear_tables
+            S = enc.img.h
+            cur, cur_h, cur_w = page, h, w
+            if w != enc.img.w:
+                b, t, k, bits = aten_aa_bilinear_tables(w, enc.img.w)
+                tmp = pb.buf((h, enc.img.w, 3), torch.uint8)
+                pb.resample_u8(cur, tmp, h, enc.img.w, 3, cur_w * 3, enc.img.w * 3, pb.const(torch.from_numpy(b.reshape(-1))), pb.const(torch.from_numpy(t.reshape(-1))),
+                               k, 0, bits, label="pre.resize_h")
+                cur, cur_w = tmp, enc.img.w
+            if h != S:
+                b, t, k, bits = aten_aa_bilinear_tables(h, S)
+                tmp = pb.buf((S, cur_w, 3), torch.uint8)
+                pb.resample_u8(cur, tmp, S, cur_w, 3, cur_w * 3, cur_w * 3, pb.const(torch.from_numpy(b.reshape(-1))), pb.const(torch.from_numpy(t.reshape(-1))),
+                               k, 1, bits, label="pre.resize_v")
+                cur, cur_h = tmp, S
+            pb.preprocess(cur, enc.img, S, enc.img.w, IMAGENET_MEAN, IMAGENET_STD, label="pre.normalise")
             plan = pb.build()
             plan.page = page
             self._pre[(h, w)] = plan

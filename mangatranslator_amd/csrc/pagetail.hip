@@ -18,7 +18,9 @@
 
 namespace mtx {
 
-// ---- Pillow resample, one axis ---------------------------------------------------------------------------------------------
+// ---- Pillow resample, one axis (coeff_bits = 0 / 22).  The same arithmetic with 16-bit taps of `coeff_bits` fractional bits is ATen's
+// uint8 antialiased resize (aten/src/ATen/native/cpu/UpSampleKernelAVXAntialias.h), i.e. torchvision's `resize(antialias=True)` of a
+// uint8 image — what HF's Sam2ImageProcessorFast runs on the page (core/image/device_tail.py aten_aa_bilinear_tables) ------------------
 // axis 0 (horizontal): dst[y][xx][c] = clip8((2^21 + sum_k src[y + row0][xmin(xx) + k][c] * coeff[xx][k]) >> 22)
 // axis 1 (vertical):   dst[yy][x][c] = clip8((2^21 + sum_k src[ymin(yy) + k][x][c] * coeff[yy][k]) >> 22)
 __global__ __launch_bounds__(256) void tail_resample_kernel(mtx_tail_args p) {
@@ -30,7 +32,8 @@ __global__ __launch_bounds__(256) void tail_resample_kernel(mtx_tail_args p) {
     const int o = p.axis == 0 ? ox : oy;
     const int lo = p.bounds[2 * o], n = p.bounds[2 * o + 1];
     const int* k = p.coeff + (long)o * p.ksize;
-    int acc[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+    const int bits = p.coeff_bits > 0 ? p.coeff_bits : 22, half = 1 << (bits - 1);
+    int acc[4] = {half, half, half, half};
     for (int t = 0; t < n; ++t) {
       const uint8_t* px = p.axis == 0 ? S + ((long)(oy + p.src_row0) * p.ld_src + (long)(lo + t) * p.c)
                                       : S + ((long)(lo + t) * p.ld_src + (long)ox * p.c);
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void tail_resample_kernel(mtx_tail_args p) {
     }
     uint8_t* out = D + ((long)oy * p.ld_dst + (long)ox * p.c);
     for (int c = 0; c < p.c; ++c) {
-      const int v = acc[c] >> 22;
+      const int v = acc[c] >> bits;
       out[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
     }
   }

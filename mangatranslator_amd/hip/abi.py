@@ -145,7 +145,7 @@ QUANT_PLAIN, QUANT_SWIGLU = 0, 1
 
 class TailArgs(C.Structure):
     _fields_ = [("kind", i32), ("src", vp), ("dst", vp), ("out_h", i32), ("out_w", i32), ("c", i32), ("ld_src", i64), ("ld_dst", i64),
-                ("bounds", vp), ("coeff", vp), ("ksize", i32), ("axis", i32), ("src_row0", i32),
+                ("bounds", vp), ("coeff", vp), ("ksize", i32), ("axis", i32), ("src_row0", i32), ("coeff_bits", i32),
                 ("alpha", vp), ("ld_alpha", i64), ("x", i32), ("y", i32), ("page_c", i32), ("src_c", i32),
                 ("gamma_tab", vp), ("cbrt_tab", vp), ("lab_coef", vp), ("cbrt_n", i32),
                 ("mask", vp), ("ld_mask", i64), ("other", vp), ("ld_other", i64), ("sums", vp), ("params", vp)]

@@ -479,6 +479,15 @@ class PlanBuilder:
         self._add(abi.OP_PREPROC, a, label)
         return dst
 
+    def resample_u8(self, src_u8, dst_u8, out_h, out_w, c, ld_src, ld_dst, bounds_i32, taps_i32, ksize, axis, coeff_bits=0, src_row0=0, label="resample"):
+        """one axis of a fixed-point 8-bit resampling pass (mtx_tail_args, MTX_TAIL_RESAMPLE): Pillow's (coeff_bits 0 = 22) or ATen's"""
+        a = abi.TailArgs()
+        a.kind, a.src, a.dst = abi.TAIL_RESAMPLE, _ptr(src_u8), _ptr(dst_u8)
+        a.out_h, a.out_w, a.c, a.ld_src, a.ld_dst = out_h, out_w, c, ld_src, ld_dst
+        a.bounds, a.coeff, a.ksize, a.axis, a.src_row0, a.coeff_bits = _ptr(bounds_i32), _ptr(taps_i32), ksize, axis, src_row0, coeff_bits
+        self._add(abi.OP_TAIL, a, label)
+        return dst_u8
+
     def letterbox(self, src_u8, dst: "Act", h, w, new_h, new_w, pad_top, pad_left, pad_value=114.0, label="letterbox"):
         a = abi.PreprocArgs()
         a.src, a.dst = _ptr(src_u8), dst.ptr

@@ -74,9 +74,11 @@ def make_model(size: str = "tiny_test", seed: int = 0):
 def preprocess(page_u8: np.ndarray, boxes_xyxy: np.ndarray, size: int):
     """uint8 HWC page + [N,4] boxes in page pixels -> pixel_values [1,3,S,S] fp32, input_boxes [1,N,4]."""
     h, w, _ = page_u8.shape
-    x = torch.from_numpy(page_u8).permute(2, 0, 1)[None].float()
+    # Sam2ImageProcessorFast -> torchvision resize(antialias=True) on the uint8 tensor -> ATen's native uint8 kernel (taken on every
+    # AVX2 host; torch's own kernel is called here, so this step IS the upstream arithmetic, not a restatement of it)
+    x = torch.from_numpy(np.ascontiguousarray(page_u8)).permute(2, 0, 1)[None]
     x = F.interpolate(x, (size, size), mode="bilinear", antialias=True, align_corners=False)
-    x = x.round().clamp(0, 255) / 255.0
+    x = x.float() / 255.0
     mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
     b = torch.as_tensor(boxes_xyxy, dtype=torch.float32).clone().reshape(-1, 2, 2)
