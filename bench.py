@@ -112,6 +112,10 @@ def parse():
     ap.add_argument("--no-glu-epilogue", action="store_true",
                     help="FLUX.2-Klein fp8 path, for A/Bs: separate SwiGLU / attention-output quantiser launches instead of the epilogue fusions "
                          "(mtx_gemm_args.glu_*, mtx_attn_args.q8) that are the default since round 4")
+    ap.add_argument("--front-replicas", type=int, default=None,
+                    help="instances of the detect-stage models (detectors + SAM) per rank; with N > 1 the front halves of N pages run at once, "
+                         "each on its own instance (a model's plan has one set of buffers).  Default: 2 for the stage sets without diffusion / "
+                         "upscaling (BASELINE configs 1 and 2: the 640-pixel graphs of ONE page do not fill 256 CUs), else 1")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--time-ops", default="auto", choices=["auto", "difference", "stamp"],
                     help="in-context kernel timing of the roofline objects: hipGraph with minus hipGraph without the ops (HIP events), "
@@ -259,7 +263,8 @@ def main():
             rcan_sd = broadcast_state_dict(rcan_sd, rank, world, device)
         upscaler = RCANUpscaler(rcan_sd, device=device, lib=lib, graph=graph)
     yolo = rtdetr = None
-    aux_detectors = []
+    aux_detectors, make_aux = [], []
+    make_yolo = make_rtdetr = make_sam = None
     if "detect" in want:
         from mangatranslator_amd.core.ml.yolo import YoloSegHip
         from mangatranslator_amd.utils import synthetic_checkpoints as synth
@@ -269,7 +274,8 @@ def main():
         ysd = synth.seeded_detector(v8_shapes, v8_head, seed=3 if first else 0, class_bias=-1.0, class_gain=0.05, box_gain=0.1)
         if world > 1:
             ysd = broadcast_state_dict(ysd, rank, world, device)
-        yolo = YoloSegHip(ysd, device=device, lib=lib, graph=graph)
+        make_yolo = lambda: YoloSegHip(ysd, device=device, lib=lib, graph=graph)
+        yolo = make_yolo()
         if args.bubble_detector == "yolo_2" or not args.no_aux_detectors:
             from mangatranslator_amd.core.ml.yolo11 import Yolo11Hip
 
@@ -280,18 +286,21 @@ def main():
                 sd_ = synth.seeded_detector(shapes_, head_, seed=seed if first else 0, class_bias=-2.0, class_gain=0.05, box_gain=0.1)
                 if world > 1:
                     sd_ = broadcast_state_dict(sd_, rank, world, device)
-                return Yolo11Hip(sd_, device=device, lib=lib, graph=graph)
+                return lambda: Yolo11Hip(sd_, device=device, lib=lib, graph=graph)
             if args.bubble_detector == "yolo_2":
-                yolo = seeded_y11("11", "m", True, 13)          # manga109-segmentation-bubble: a YOLO11-seg (its scale is not stated upstream: m assumed)
+                make_yolo = seeded_y11("11", "m", True, 13)     # manga109-segmentation-bubble: a YOLO11-seg (its scale is not stated upstream: m assumed)
+                yolo = make_yolo()
             if not args.no_aux_detectors:
-                aux_detectors = [("panel", seeded_y11("11", "l", False, 17), 0.25), ("osb_text", seeded_y11("12", "x", False, 19), 0.4)]
+                make_aux = [("panel", seeded_y11("11", "l", False, 17), 0.25), ("osb_text", seeded_y11("12", "x", False, 19), 0.4)]
+                aux_detectors = [(n_, mk_(), c_) for n_, mk_, c_ in make_aux]
         # secondary detector of the same stage: RT-DETR-v2 R50 @640 (reference detection.py:1401-1407, on by default)
         from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
         rcfg = synth.rtdetr_r50_config()
         rsd = synth.rtdetr_state_dict(rcfg, seed=5 if first else 0)
         if world > 1:
             rsd = broadcast_state_dict(rsd, rank, world, device)
-        rtdetr = RTDetrHip(rsd, rcfg, device=device, lib=lib, graph=graph, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
+        make_rtdetr = lambda: RTDetrHip(rsd, rcfg, device=device, lib=lib, graph=graph, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
+        rtdetr = make_rtdetr()
     sam = None
     if "segment" in want:
         from mangatranslator_amd.core.ml.sam2 import Sam2Hip
@@ -304,8 +313,8 @@ def main():
             sam_sd = {k: torch.empty(shp) for k, shp in synth_sam.sam2_shapes(sam_cfg).items()}
         if world > 1:
             sam_sd = broadcast_state_dict(sam_sd, rank, world, device)
-        sam = Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph, dtype=abi_f16)        # f16 storage: what ModelManager.load_sam2 serves (bf16 only when a checkpoint leaves the f16 range)
-        del sam_sd
+        make_sam = lambda: Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph, dtype=abi_f16)        # f16 storage: what ModelManager.load_sam2 serves (bf16 only when a checkpoint leaves the f16 range)
+        sam = make_sam()
     inpainter, flux = None, None
     klein = args.inpainter.startswith("klein")
     if "inpaint" in want:
@@ -405,6 +414,16 @@ def main():
                 bm.append((((xx - cx) / a_) ** 2 + ((yy - cy) / b_) ** 2 <= 1.0).astype(np.uint8) * 255)
             clean_args.append((torch.from_numpy(np.stack(bm)).to(device), [tuple(int(v) for v in b_) for b_ in page_boxes[k_]]))
 
+    # ---- instances of the front half's models: page i uses set i % N, so N pages' detect stages can be in flight at once --------------
+    n_front = args.front_replicas
+    if n_front is None:
+        n_front = 2 if (yolo is not None and inpainter is None and upscaler is None and not args.no_overlap and not args.serial_detectors) else 1
+    n_front = max(1, n_front)
+    front_sets = [dict(yolo=yolo, aux=aux_detectors, rtdetr=rtdetr, sam=sam)]
+    for _ in range(1, n_front):
+        front_sets.append(dict(yolo=make_yolo() if make_yolo else None, aux=[(n_, mk_(), c_) for n_, mk_, c_ in make_aux],
+                               rtdetr=make_rtdetr() if make_rtdetr else None, sam=make_sam() if make_sam else None))
+
     stage_wall = {}
 
     def lap(name, t_prev):      # only when a stage-by-stage wall-clock breakdown is being taken (one extra page after the timed region)
@@ -426,6 +445,8 @@ def main():
     def stage_a(i):
         """front half of page i: the stages whose host share is large (NMS, prompt handling, OSB region logic)"""
         k = i % pool
+        fs = front_sets[i % n_front]
+        yolo, aux_detectors, rtdetr, sam = fs["yolo"], fs["aux"], fs["rtdetr"], fs["sam"]
         stage_memo.reset()        # the operators remember results per (pixels, settings); the pool repeats pages, and no step may be served from memory
         tl = time.perf_counter()
         work_ = None
@@ -472,7 +493,7 @@ def main():
         k = i % pool
         tl = time.perf_counter()
         if seg_in_b:
-            outs["segment"] = sam.segment(pages[k], page_boxes[k], ticket=work_[1])
+            outs["segment"] = front_sets[i % n_front]["sam"].segment(pages[k], page_boxes[k], ticket=work_[1])
             tl = lap("segment", tl)
             return
         if inpainter is not None:
@@ -504,13 +525,16 @@ def main():
             for i in range(n):
                 step(i)
             return
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=1) as ex:
-            fut = ex.submit(stage_a, 0)
+        with ThreadPoolExecutor(max_workers=n_front) as ex:
+            futs = deque(ex.submit(stage_a, j) for j in range(min(n_front, n)))      # n_front front halves in flight, each on its own model instances
+            nxt = len(futs)
             for i in range(n):
-                work_ = fut.result()
-                if i + 1 < n:
-                    fut = ex.submit(stage_a, i + 1)
+                work_ = futs.popleft().result()
+                if nxt < n:
+                    futs.append(ex.submit(stage_a, nxt))
+                    nxt += 1
                 stage_b(i, work_)
 
     def barrier():
@@ -519,7 +543,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(pool):            # set-up, like model loading: every page of the pool once, so each stage's plans / hipGraphs for the
+    setup_pages = max(pool, n_front)
+    for k in range(setup_pages):            # set-up, like model loading: every page of the pool once (on every model instance), so each stage's plans / hipGraphs for the
         step(k)                      # shapes it will meet (the FLUX crop resolution depends on where the text block sits) exist
     run_steps(args.warmup)
     barrier()
@@ -528,7 +553,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if flux is not None:          # every page sent its R regions through FLUX (none classified as solid, none dropped)
-        want_calls = (pool + args.warmup + args.steps) * args.regions
+        want_calls = (setup_pages + args.warmup + args.steps) * args.regions
         assert flux.calls == want_calls, f"expected {want_calls} FLUX calls, saw {flux.calls}"
         assert flux.completed == want_calls, f"{want_calls - flux.completed} of {want_calls} FLUX calls raised (the OSB stage turns those into flat fills)"
     if rank == 0:               # informational: wall clock of each stage of one more page, synchronised stage by stage
@@ -624,6 +649,7 @@ def main():
                    "inpainter": inp_desc,
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
                    "detector_calls": ("one after the other" if args.serial_detectors else "submitted together, one HIP stream per model, collected afterwards") if yolo is not None else None,
+                   "front_replicas": n_front,
                    "stage_wall_ms_one_page": {k_: round(v_, 2) for k_, v_ in stage_wall.items()},
                    "page_pipeline": ("two pages in flight: detectors (+ SAM encoder) of page i+1 on a worker thread beside the SAM mask decoder of page i" if seg_in_b else
                                      "two pages in flight: detect / segment / OSB prepare of page i+1 on a worker thread beside inpaint / upscale / clean of page i"
