@@ -137,7 +137,7 @@ class StandInPipeline:
         return types.SimpleNamespace(images=[Image.fromarray(u8.cpu().numpy())])
 
 
-def check_klein_operator(lib, page_hw=(300, 400), mask_box=(120, 150, 200, 260), page_mode="RGB"):
+def check_klein_operator(lib, page_hw=(300, 400), mask_box=(120, 150, 200, 260), page_mode="RGB", translucent=False):
     """`FluxKleinInpainter.inpaint_mask` with its image arithmetic on the device against the SAME operator on the host path (PIL / numpy):
     same stand-in pipeline, same seed.  Pixels outside the crop identical; inside within one level (the float Lab -> RGB leg); the
     remembered patch likewise; both LANCZOS passes (crop -> ~1 MP inference size and back), the luminance match and the composite run."""
@@ -151,6 +151,8 @@ def check_klein_operator(lib, page_hw=(300, 400), mask_box=(120, 150, 200, 260),
     page = np.clip(np.stack([140 + 70 * np.sin(xx / 13.0), 130 + 60 * np.cos(yy / 9.0), 120 + 50 * np.sin((xx + 2 * yy) / 17.0)], -1) + rng.normal(0, 5, (H, W, 3)), 0, 255).astype(np.uint8)
     if page_mode == "RGBA":
         page = np.concatenate([page, np.full((H, W, 1), 255, np.uint8)], -1)
+        if translucent:          # Pillow resizes RGBA on premultiplied colours: the device path must step aside for such a crop
+            page[mask_box[0] - 10: mask_box[0] + 30, mask_box[1]: mask_box[1] + 50, 3] = 90
     mask = np.zeros((H, W), bool)
     y0, x0, y1, x1 = mask_box
     mask[y0:y1, x0:x1] = True
@@ -173,6 +175,9 @@ def check_klein_operator(lib, page_hw=(300, 400), mask_box=(120, 150, 200, 260),
         outs.append(np.asarray(res))
         pipes.append(pipe)
         x, y, w, h, _, _ = inp.region_for_mask(mask)
+    if translucent:
+        assert pipes[0].calls[0][0] == "pil" and np.array_equal(outs[0], outs[1]), "a translucent crop must take the host path, byte for byte"
+        return 0.0, pipes[0].calls[0][1]
     assert pipes[0].calls[0][0] == "pt" and pipes[1].calls[0][0] == "pil" and pipes[0].calls[0][1] == pipes[1].calls[0][1]
     a, b = outs
     d = np.abs(a.astype(int) - b.astype(int))

@@ -69,6 +69,19 @@ def test_klein_operator_on_the_device_tail(emu_lib):
     frac, inf = dc.check_klein_operator(emu_lib)
     assert frac < 0.05 and inf[0] * inf[1] > 900_000            # the crop went up to ~1 MP and back
     dc.check_klein_operator(emu_lib, page_hw=(200, 260), mask_box=(60, 70, 110, 150), page_mode="RGBA")
+    dc.check_klein_operator(emu_lib, page_hw=(200, 260), mask_box=(60, 70, 110, 150), page_mode="RGBA", translucent=True)
+
+
+def test_unload_drops_the_device_tail():
+    """`unload_models()` left `_tail` behind, and the next call used a pipeline that was None"""
+    import types
+    from mangatranslator_amd.core.image import inpainting as ip
+    for cls, unload in ((ip.FluxKontextInpainter, "unload_flux_kontext_sdnq_models"), (ip.FluxKleinInpainter, "unload_flux_klein_models")):
+        inp = cls.__new__(cls)
+        inp.manager = types.SimpleNamespace(**{unload: lambda *a, **k: None})
+        inp.pipeline, inp._prompt_embeds, inp._tail = object(), object(), object()
+        inp.unload_models()
+        assert inp.pipeline is None and inp._tail is None
 
 
 def test_kontext_operator_on_the_device_tail(emu_lib):
