@@ -29,7 +29,9 @@ def _early_hw_queues(argv):
     """ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4); streams that share a queue run their work one
     after the other.  A page's detect stage keeps five model streams busy at once (hip/plan.py AsyncLane: four detectors + the SAM encoder),
     so with four queues two of its graphs always wait for each other: measured on an MI355X (profiles/r03_hw_queues_ab.log), BASELINE
-    config 2 29.1 -> 31.4 pages/s and config 1 46.5 -> 49.2 with eight queues.  The same setting LOSES where the back half of the page
+    config 2 29.1 -> 31.4 pages/s and config 1 46.5 -> 49.2 with eight queues; with the detect stages of TWO pages in flight on two sets of
+    model instances (round 4, profiles/r04_visit_e_front_replicas.log) eight queues LOSE (config 2: 28.1) and sixteen win (33.2; config 1:
+    51.3 -> 56.7).  More queues LOSE where the back half of the page
     pipeline saturates the chip with big kernels (config 5, two pages in flight: 1.20 -> 1.10 pages/s on boxes of the same clock class —
     detector kernels that truly run beside the 256-workgroup GEMM / conv waves cost those waves a second round), so it is chosen here only
     for the stage sets without diffusion / upscaling, and reported in the line (config.hw_queues).  It has to be in the environment
@@ -45,7 +47,7 @@ def _early_hw_queues(argv):
     if stages in (None, "all"):
         stages = {"1": "detect,clean", "2": "detect,segment"}.get(opt("--config", "4"), "detect,segment,inpaint,upscale")
     if not ({"inpaint", "upscale"} & {x.strip() for x in stages.split(",")}):
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # round 4: two pages' detect stages in flight (--front-replicas 2) = ten model streams
 
 
 _early_hw_queues(sys.argv[1:])

@@ -57,12 +57,12 @@ def test_two_ranks_on_one_device():
 
 
 def test_hardware_queue_choice(monkeypatch):
-    """bench.py asks ROCm for eight hardware queues only for the stage sets without diffusion / upscaling (measured: helps the detect
+    """bench.py asks ROCm for sixteen hardware queues only for the stage sets without diffusion / upscaling (measured: helps the detect
     stage's five model streams, costs config 5 — DESIGN.md §6), before torch is imported, and never overrides the caller's value"""
     sys.path.insert(0, str(ROOT))
     import importlib
     bench = importlib.import_module("bench")
-    for argv, want in ((["--config", "2"], "8"), (["--config=1", "--steps", "3"], "8"), (["--stages", "detect"], "8"), ([], None), (["--config", "5"], None),
+    for argv, want in ((["--config", "2"], "16"), (["--config=1", "--steps", "3"], "16"), (["--stages", "detect"], "16"), ([], None), (["--config", "5"], None),
                        (["--config", "3"], None), (["--stages", "upscale"], None), (["--gpus", "8", "--steps", "5", "--warmup", "2"], None)):
         monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
         bench._early_hw_queues(argv)

@@ -32,6 +32,52 @@ def attn(T, heads=24, d=128, iters=10):
     print(f"attn T={T} heads={heads}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
+def attn_q8(T, heads=24, d=128, iters=10, fused=True):
+    """FLUX.2 form: the rows leave as the MX fp8 operand of the next linear (fused: mtx_attn_args.q8; else attention + quantiser launch)"""
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    D = heads * d
+    qkv = pb.buf((T, 3 * D), torch.bfloat16); qkv.normal_()
+    qkv[:, :D] *= d ** -0.5 * 1.4426950408889634
+    lds = (T + 63) // 64 * 64
+    q8 = pb.buf((T, D), torch.uint8, zero=True)
+    sc = pb.buf((D // 128, lds), torch.int32, zero=True)
+    strides = ((0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d))
+    if fused:
+        pb.attention(qkv, qkv, qkv, None, 1, heads, T, T, d, *strides, d ** -0.5, k_off=D, v_off=2 * D, q_prescaled=True, q8=(q8, sc, D, lds, 0))
+    else:
+        o = pb.buf((T, D), torch.bfloat16)
+        pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, *strides, d ** -0.5, k_off=D, v_off=2 * D, q_prescaled=True)
+        pb.quantize(o, T, D, q=q8, scale=sc, lds=lds, ldq=D)
+    ms = _time(pb.build(), iters)
+    print(f"attn -> MX fp8 T={T} heads={heads} [{'fused epilogue' if fused else 'attention + quantiser launch'}]: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
+
+
+def gemm8_glu(M, hid, K, col0=0, iters=20, fused=True):
+    """FLUX.2 MLP-in: fp8 GEMM [M, col0 + 2 hid] whose gated half leaves as silu(a) * b in MX fp8 (fused: mtx_gemm_args.glu_*; else GEMM + SwiGLU quantiser)"""
+    from mangatranslator_amd.hip.plan import glu_interleave
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    N = col0 + 2 * hid
+    a = pb.buf((M, K), torch.bfloat16); a.normal_()
+    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5)
+    if fused:
+        w.copy_(w[glu_interleave(col0, hid).to(dev)].clone())
+    q = PlanBuilder(lib, dev, abi.BF16)
+    aq, asc, la = q.quantize(a, M, K)
+    wq, wsc, lw = q.quantize(w, N, K)
+    q.build().run(); torch.cuda.synchronize()
+    pb.keep += [aq, asc, wq, wsc]
+    lds = (M + 63) // 64 * 64
+    q8 = pb.buf((M, hid), torch.uint8, zero=True)
+    sc = pb.buf((hid // 128, lds), torch.int32, zero=True)
+    if fused:
+        pb.gemm(aq, wq, M, N, K, out=pb.buf((M, N), torch.bfloat16) if col0 else None, f8=(asc, la, wsc, lw, 0, 0), glu=(q8, sc, hid, lds, col0, 0, 0))
+    else:
+        c = pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0))
+        pb.quantize(c, M, hid, ldx=N, x_off=col0, q=q8, scale=sc, lds=lds, ldq=hid, swiglu_b=c, b_off=col0 + hid, ldb=N)
+    ms = _time(pb.build(), iters)
+    print(f"gemm8 + SwiGLU -> MX fp8 M={M} N={N} K={K} [{'gated epilogue' if fused else 'GEMM + SwiGLU quantiser launch'}]: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
+
+
 def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0):
     """pad > 0: rows of A and W are `pad` elements apart more than K (leading-dimension padding, an address-interleave probe)"""
     pb = PlanBuilder(lib, dev, abi.BF16)
@@ -77,6 +123,10 @@ if __name__ == "__main__":
     while args:
         if args[0] == "attn":
             attn(int(args[1])); args = args[2:]
+        elif args[0] in ("attnq", "attnqs"):          # attention with MX fp8 output: fused epilogue / separate quantiser
+            attn_q8(int(args[1]), fused=args[0] == "attnq"); args = args[2:]
+        elif args[0] in ("glu", "glus"):              # glu M hid K col0
+            gemm8_glu(int(args[1]), int(args[2]), int(args[3]), int(args[4]), fused=args[0] == "glu"); args = args[5:]
         elif args[0] == "quant":
             quant(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "conv":
