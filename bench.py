@@ -582,7 +582,7 @@ def main():
         barrier()
         io_threads = args.io_threads or max(2, min(8, (os.cpu_count() or 8) // max(1, world) // 4))
 
-        def process_image(page, path):
+        def io_front(page, path):
             i = int(path.stem.split("_")[1])
             k = i % pool
             rgb = page.convert("RGB")
@@ -590,23 +590,31 @@ def main():
             pages[k].copy_(torch.from_numpy(arr))          # the decoded page replaces the resident one: upload inside the harness's clock
             page_bgr[k] = np.ascontiguousarray(arr[..., ::-1])
             page_pil[k] = rgb
-            step(i)
+            return i, page, stage_a(i)
+
+        def io_back(state):
+            i, page, work_ = state
+            stage_b(i, work_)
             if "upscale" in outs:
                 return Image.fromarray(outs["upscale"].cpu().numpy())
             if "inpaint" in outs:
                 return outs["inpaint"]
             return page
 
+        # two pages in flight inside the harness too (core/pipeline.py, round 4) when the plain line runs that way and the pool has a slot per page in flight
+        io_pipelined = overlap and pool >= 2 and not seg_in_b
+        io_kw = dict(process_front=io_front, process_back=io_back) if io_pipelined else dict(process_image=lambda page, path: io_back(io_front(page, path)))
+
         io_cfg = _t.SimpleNamespace(verbose=False, output=_t.SimpleNamespace(output_format="png", jpeg_quality=95, png_compression=2))
         h0, c0 = UnifiedCache.hash_seconds, UnifiedCache.hash_calls
         barrier()
         t_io = time.perf_counter()
-        res_io = batch_process_images(tmp / "in", io_cfg, tmp / "out", process_image=process_image, io_threads=io_threads)
+        res_io = batch_process_images(tmp / "in", io_cfg, tmp / "out", io_threads=io_threads, **io_kw)
         barrier()
         dt_io = time.perf_counter() - t_io
         io_ = res_io.get("io", {})
         out_bytes = sum(f.stat().st_size for f in (tmp / "out").glob("*.png")) if rank == 0 else 0
-        batch_io = {"pages": n_io, "wall_s": round(dt_io, 3), "pages_per_s_with_io": n_io / dt_io, "succeeded": res_io["success_count"], "failed": res_io["error_count"],
+        batch_io = {"pages": n_io, "wall_s": round(dt_io, 3), "pages_per_s_with_io": n_io / dt_io, "pages_in_flight": io_.get("pages_in_flight", 1), "succeeded": res_io["success_count"], "failed": res_io["error_count"],
                     "io_threads_per_rank": io_threads, "decode_ms_per_page": round(io_.get("decode_ms_per_page", 0.0), 2),
                     "encode_ms_per_page": round(io_.get("encode_ms_per_page", 0.0), 2), "process_ms_per_page": round(io_.get("process_ms_per_page", 0.0), 2),
                     "hash_ms_per_page": round(1e3 * (UnifiedCache.hash_seconds - h0) / max(1, args.batch_io), 2), "hash_calls_per_page": (UnifiedCache.hash_calls - c0) / max(1, args.batch_io),

@@ -122,7 +122,8 @@ def load_page(img_path: Path, output_format: str):
 
 
 def batch_process_images(input_dir, config, output_dir=None, preserve_structure: bool = False,
-                         process_image: Optional[Callable] = None, io_threads: int = 2) -> Dict:
+                         process_image: Optional[Callable] = None, io_threads: int = 2,
+                         process_front: Optional[Callable] = None, process_back: Optional[Callable] = None) -> Dict:
     """The vision half of `batch_translate_images` (core/pipeline.py:2481-2733) on one GPU or page-sharded over the ranks of the
     initialised process group: same page list and order, same output naming (`_resolve_output_path`), same results dict
     (`success_count`, `error_count`, `errors` keyed by the display path, `failed_image_paths` absolute, `failed_paths_file`), a bad
@@ -130,8 +131,16 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
     Host codec work is kept off the GPU's critical path: `io_threads` workers decode the next pages while the current one is on the
     GPU and `io_threads` more encode / write finished pages behind it (PIL releases the GIL in its codecs); at most 2 x io_threads
     finished pages wait for an encoder (back-pressure on the page loop).  `results["io"]` accounts for the host side: decode / encode /
-    process seconds, the waits, the deepest save queue."""
+    process seconds, the waits, the deepest save queue.
+    **Two pages in flight** (round 4): with `process_front(page, path) -> state` and `process_back(state) -> PIL.Image` instead of
+    `process_image`, page i + 1's front half (detect / segment / OSB prepare: host-heavy, small GPU graphs on the models' own streams) runs
+    on a worker thread beside page i's back half (diffusion, upscaling, cleaning: GPU-bound) — `process_page_vision_front` /
+    `process_page_vision_back` below are that pair.  Pages still complete, are saved and are reported in batch order; a page whose front
+    or back half raises is recorded as failed exactly like a failing `process_image`, and the pages around it are not affected."""
     from .image.image_utils import save_image_with_compression
+    if (process_front is None) != (process_back is None):
+        raise ValueError("process_front and process_back come as a pair")
+    pipelined = process_front is not None
     import torch.distributed as dist
     empty = {"success_count": 0, "error_count": 0, "errors": {}, "failed_image_paths": []}
     input_dir = Path(input_dir)
@@ -161,7 +170,7 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
             local["failed_image_paths"].append(str(img_path))
 
     io = {"decode_s": 0.0, "encode_s": 0.0, "gpu_wait_for_decode_s": 0.0, "wait_for_save_slot_s": 0.0, "process_s": 0.0, "pages": 0,
-          "max_pending_saves": 0}
+          "max_pending_saves": 0, "front_s": 0.0, "back_s": 0.0, "pages_in_flight": 2 if pipelined else 1}
     io_lock = threading.Lock()
 
     def timed(key, fn, *a):
@@ -180,12 +189,25 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
         except Exception as e:      # noqa: BLE001
             fail(img_path, error_key, e)
 
+    def front_task(i):
+        """decoded page i through the front half (worker thread); what it returns or raises belongs to page i"""
+        t = time.perf_counter()
+        page = decodes.pop(i).result()
+        t1 = time.perf_counter()
+        state = process_front(page, mine[i])
+        with io_lock:
+            io["gpu_wait_for_decode_s"] += t1 - t
+            io["front_s"] += time.perf_counter() - t1
+        return state
+
     # decoders and encoders do not share a queue: the next page's decode must never wait behind the finished pages' (much slower) PNG encodes
-    with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool, ThreadPoolExecutor(max_workers=max(1, io_threads)) as enc_pool:
+    with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool, ThreadPoolExecutor(max_workers=max(1, io_threads)) as enc_pool, \
+            ThreadPoolExecutor(max_workers=1) as front_pool:
         ahead = max(1, io_threads)
         max_pending = 2 * max(1, io_threads)       # finished pages waiting for a codec thread: a 4096x6144 RGBA page is 100 MB, and PNG
         decodes = {i: pool.submit(timed, "decode_s", load_page, mine[i], fmt) for i in range(min(ahead, len(mine)))}      # encoding is slower than the GPU
         saves = deque()
+        fronts = {0: front_pool.submit(front_task, 0)} if pipelined and mine else {}
         for i, img_path in enumerate(mine):
             if i + ahead < len(mine):
                 decodes[i + ahead] = pool.submit(timed, "decode_s", load_page, mine[i + ahead], fmt)
@@ -194,13 +216,24 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
                 out_path, display, error_key = _resolve_output_path(img_path, input_dir, output_dir, config, preserve_structure)
                 log_message(f"Processing {rank + i * world + 1}/{len(files)}: {display}", always_print=True)
                 t = time.perf_counter()
-                page = decodes.pop(i).result()
-                t1 = time.perf_counter()
-                result = process_image(page, img_path) if process_image is not None else page
-                t2 = time.perf_counter()
+                if pipelined:
+                    fut = fronts.pop(i)
+                    if i + 1 < len(mine):          # the next page's front half starts before this page's back half
+                        fronts[i + 1] = front_pool.submit(front_task, i + 1)
+                    state = fut.result()
+                    t1 = time.perf_counter()
+                    result = process_back(state)
+                    t2 = time.perf_counter()
+                    io["back_s"] += t2 - t1
+                    t1 = t                          # process_s = this page's share of the page loop (waiting for its front half + its back half)
+                else:
+                    page = decodes.pop(i).result()
+                    t1 = time.perf_counter()
+                    result = process_image(page, img_path) if process_image is not None else page
+                    t2 = time.perf_counter()
+                    io["gpu_wait_for_decode_s"] += t1 - t
                 while len(saves) >= max_pending:      # back-pressure: the page loop waits for the oldest save instead of queueing pages without bound
                     settle(saves.popleft())
-                io["gpu_wait_for_decode_s"] += t1 - t
                 io["process_s"] += t2 - t1
                 io["wait_for_save_slot_s"] += time.perf_counter() - t2
                 io["pages"] += 1
@@ -209,6 +242,8 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
                 io["max_pending_saves"] = max(io["max_pending_saves"], len(saves))
             except Exception as e:      # noqa: BLE001 — a bad page must not stop the batch
                 decodes.pop(i, None)
+                if pipelined and i + 1 < len(mine) and i + 1 not in fronts:      # this page failed before the next front half was queued
+                    fronts[i + 1] = front_pool.submit(front_task, i + 1)
                 fail(img_path, error_key, e)
         while saves:
             settle(saves.popleft())
@@ -264,26 +299,33 @@ def process_page_vision(page, config, image_path="page.png", image_format: Optio
     Stage failures degrade exactly as there: detection errors -> no bubbles (:804-807), cleaning errors -> the uncleaned page
     (:94-123), OSB errors -> the page as it was.  Panel detection (`use_panel_sorting`): `detect_panels` on the YOLO11-L graph (core/ml/yolo11.py); a failing loader or
     model leaves panels = None, the reference's own failure path.
-    Returns `(page_out, info)` with the detections, the per-bubble cleaning records and the processing scale."""
+    Returns `(page_out, info)` with the detections, the per-bubble cleaning records and the processing scale.
+    = `process_page_vision_back(process_page_vision_front(...))`: the two halves exist so that a batch can keep two pages in flight
+    (`batch_process_images(process_front=, process_back=)`)."""
+    return process_page_vision_back(process_page_vision_front(page, config, image_path, image_format, verbose))
+
+
+def process_page_vision_front(page, config, image_path="page.png", image_format: Optional[str] = None, verbose: bool = False) -> Dict:
+    """Front half of a page: target mode, optional initial upscale, stage-memo page switch, bubble detection (+ SAM masks), panels, and the
+    OSB stage's PREPARE part (outside-text detection, masks, region grouping, the FLUX / flat-fill decision) — the stages whose host share is
+    large and whose GPU work is small graphs on the models' own streams.  Returns the state `process_page_vision_back` finishes."""
     import math
-    import numpy as np
-    from PIL import Image
     from .caching import get_cache
-    from .image.cleaning import clean_speech_bubbles
     from .image.detection import detect_panels, detect_speech_bubbles
     from .image.image_utils import upscale_image
-    from .outside_text_processor import process_outside_text
-    from ..utils.exceptions import CleaningError
+    from .outside_text_processor import prepare_outside_text_work
     target_mode = page.mode if page.mode in ("RGB", "RGBA") else "RGBA"
     if page.mode != target_mode:
         page = page.convert(target_mode)
     info = {"bubbles": [], "text_free_boxes": [], "cleaned": [], "processing_scale": 1.0}
+    state = {"config": config, "image_path": image_path, "verbose": verbose, "target_mode": target_mode, "info": info, "done": None, "work": None, "osb_error": None}
     page, info["pre_upscale_factor"] = apply_pre_upscale_if_needed(page, config, verbose)      # :718-720, before anything looks at the page
     if getattr(config, "upscaling_only", False):
         out = page
         if config.output.upscale_final_image:
             out = upscale_image(out, config.output.image_upscale_factor, model_type=config.output.image_upscale_model, verbose=verbose)
-        return (out if out.mode == target_mode else out.convert(target_mode)), info
+        state["done"] = out if out.mode == target_mode else out.convert(target_mode)
+        return state
     scale = math.sqrt(page.width * page.height / 1_000_000) if config.preprocessing.auto_scale else 1.0          # :765-771
     info["processing_scale"] = scale
     get_cache().set_current_image(page, verbose)       # :774 — a new page drops what the stage memo holds for the previous one
@@ -309,7 +351,32 @@ def process_page_vision(page, config, image_path="page.png", image_format: Optio
             log_message(f"Panel detection failed: {e}. Using global sorting.", always_print=True)
             panels = None
     info["panels"] = panels
-    page, _osb = process_outside_text(page, config, image_path, image_format, verbose, bubble_data=bubbles, text_free_boxes=text_free, panels=panels)
+    try:
+        state["work"] = prepare_outside_text_work(page, config, image_path, image_format, verbose=verbose, bubble_data=bubbles,
+                                                  text_free_boxes=text_free, panels=panels)
+    except Exception as e:      # noqa: BLE001 — raised again where `process_outside_text` would have raised it: in the back half
+        state["osb_error"] = e
+    state.update(page=page, scale=scale)
+    return state
+
+
+def process_page_vision_back(state: Dict):
+    """Back half of a page: the OSB stage's FINISH part (FLUX waves / flat fills), bubble cleaning, optional final upscale, target mode —
+    the GPU-bound stages.  Returns `(page_out, info)` like `process_page_vision`."""
+    import numpy as np
+    from PIL import Image
+    from .image.cleaning import clean_speech_bubbles
+    from .image.image_utils import upscale_image
+    from .outside_text_processor import finish_outside_text_work
+    from ..utils.exceptions import CleaningError
+    info, config, verbose, target_mode = state["info"], state["config"], state["verbose"], state["target_mode"]
+    if state["done"] is not None:
+        return state["done"], info
+    if state["osb_error"] is not None:
+        raise state["osb_error"]
+    page, scale, det, bubbles = state["page"], state["scale"], config.detection, info["bubbles"]
+    if state["work"] is not None:
+        page, _osb = finish_outside_text_work(state["work"])
     if bubbles:
         cl = config.cleaning
         try:

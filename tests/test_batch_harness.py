@@ -156,3 +156,57 @@ def test_save_queue_is_bounded_and_io_is_accounted(tmp_path, monkeypatch):
     assert sorted(p.name for p in odir.iterdir()) == [f"p{i:02d}_translated.png" for i in range(14)]
     for i in (0, 13):                                                                  # decoded pixels survive the writer
         assert Image.open(odir / f"p{i:02d}_translated.png").convert("RGB").getpixel((3, 3)) == (i, 2 * i, 3 * i)
+
+
+def test_two_pages_in_flight_give_the_sequential_results(tmp_path):
+    """`batch_process_images(process_front=, process_back=)` (round 4): page i + 1's front half runs on a worker thread while page i's back
+    half runs on the caller's; the saved files, their order in the results and the failed pages equal those of the sequential
+    `process_image = back(front(.))` run — incl. a page whose FRONT half raises and one whose BACK half raises — and the overlap is real
+    (a back half sees the next page's front half already started)."""
+    import threading
+    import time
+    from mangatranslator_amd.core.pipeline import batch_process_images
+    root = tmp_path / "in"
+    root.mkdir()
+    n = 7
+    for i in range(n):
+        Image.new("RGB", (16, 12), (10 * i, 20, 30)).save(root / f"p{i:02d}.png")
+    started, overlapped = {}, []
+    lock = threading.Lock()
+
+    def front(page, path):
+        i = int(path.stem[1:])
+        with lock:
+            started[i] = True
+        if i == 2:
+            raise RuntimeError("front of page 2")
+        time.sleep(0.02)
+        return {"i": i, "page": page, "thread": threading.get_ident()}
+
+    def back(state):
+        i = state["i"]
+        time.sleep(0.05)
+        with lock:
+            overlapped.append(bool(started.get(i + 1)) or i + 1 >= n)
+        if i == 4:
+            raise ValueError("back of page 4")
+        out = state["page"].copy()
+        out.putpixel((0, 0), (i, i, i))
+        return out
+
+    pipelined = batch_process_images(root, _cfg("png"), tmp_path / "out_p", process_front=front, process_back=back, io_threads=2)
+    main = threading.get_ident()
+    sequential = batch_process_images(root, _cfg("png"), tmp_path / "out_s", process_image=lambda page, path: back(front(page, path)), io_threads=2)
+    for k in ("success_count", "error_count", "errors"):
+        assert pipelined[k] == sequential[k], k
+    assert pipelined["success_count"] == n - 2 and set(pipelined["errors"]) == {"p02.png", "p04.png"}
+    assert [Path(p).name for p in pipelined["failed_image_paths"]] == ["p02.png", "p04.png"]
+    names = sorted(f.name for f in (tmp_path / "out_p").glob("*.png"))
+    assert names == sorted(f.name for f in (tmp_path / "out_s").glob("*.png")) and len(names) == n - 2
+    for name in names:
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "out_p" / name)), np.asarray(Image.open(tmp_path / "out_s" / name)))
+    assert sum(overlapped[: n - 2]) >= n - 3                      # (first run only) nearly every back half ran beside the next front half
+    assert pipelined["io"]["pages_in_flight"] == 2 and sequential["io"]["pages_in_flight"] == 1
+    with pytest.raises(ValueError):
+        batch_process_images(root, _cfg("png"), tmp_path / "o", process_front=front)
+    assert main == threading.get_ident()

@@ -35,8 +35,13 @@ def calls(monkeypatch):
         log.append(("detect", kw["image_override"].mode, kw["seg_model"], kw["osb_enabled"], kw["bubble_detector_model"]))
         return bubbles, [[5.0, 5.0, 9.0, 9.0]]
 
-    def osb(page, config, image_path, image_format, verbose, bubble_data=None, text_free_boxes=None, panels=None):
+    # the OSB stage in its two halves (prepare in the page's front half, finish in its back half: core/pipeline.py)
+    def osb_prepare(page, config, image_path, image_format, verbose=False, bubble_data=None, text_free_boxes=None, panels=None):
         log.append(("osb", len(bubble_data), text_free_boxes, panels))
+        return ("work", page)
+
+    def osb_finish(work):
+        page = work[1]
         out = page.copy(); out.putpixel((0, 0), (1, 2, 3, 255) if page.mode == "RGBA" else (1, 2, 3))
         return out, []
 
@@ -52,7 +57,8 @@ def calls(monkeypatch):
         return image.resize((int(image.width * factor), int(image.height * factor))).convert("RGB")
 
     monkeypatch.setattr(detection, "detect_speech_bubbles", detect)
-    monkeypatch.setattr(otp, "process_outside_text", osb)
+    monkeypatch.setattr(otp, "prepare_outside_text_work", osb_prepare)
+    monkeypatch.setattr(otp, "finish_outside_text_work", osb_finish)
     monkeypatch.setattr(cleaning, "clean_speech_bubbles", clean)
     monkeypatch.setattr(image_utils, "upscale_image", upscale)
     return log
@@ -114,7 +120,8 @@ def test_panels_reach_the_osb_stage(calls, monkeypatch):
     calls.clear()
     monkeypatch.undo()                                   # the product operator: no panel model in this build -> ModelError -> None
     monkeypatch.setattr(detection, "detect_speech_bubbles", lambda *a, **k: ([], []))
-    monkeypatch.setattr(otp, "process_outside_text", lambda page, *a, panels="unset", **k: (calls.append(("osb", panels)), (page, []))[1])
+    monkeypatch.setattr(otp, "prepare_outside_text_work", lambda page, *a, panels="unset", **k: (calls.append(("osb", panels)), ("work", page))[1])
+    monkeypatch.setattr(otp, "finish_outside_text_work", lambda work: (work[1], []))
     monkeypatch.setattr(image_utils, "upscale_image", lambda image, *a, **k: image)
     _, info = pipeline.process_page_vision(page, cfg)
     assert calls == [("osb", None)] and info["panels"] is None
@@ -141,7 +148,7 @@ def test_initial_upscale_rule(calls, monkeypatch):
     log = []
     monkeypatch.setattr(image_utils, "upscale_image", lambda image, factor, model_type="model", verbose=False: (log.append(("up", factor, model_type)), image.resize((int(image.width * factor), int(image.height * factor))))[1])
     monkeypatch.setattr(detection, "detect_speech_bubbles", lambda *a, **k: (log.append(("detect", k["image_override"].size)), ([], []))[1])
-    monkeypatch.setattr(otp, "process_outside_text", lambda page, *a, **k: (page, []))
+    monkeypatch.setattr(otp, "prepare_outside_text_work", lambda page, *a, **k: None)
     cfg = _config()
     cfg.preprocessing = T(auto_scale=True, enabled=True, factor=2.0)
     cfg.output.upscale_final_image = False
