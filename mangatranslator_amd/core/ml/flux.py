@@ -32,7 +32,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder, PlanCache, back_half_priority
+from ...hip.plan import Act, PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 
@@ -136,7 +136,6 @@ class FluxDiTHip:
     def _build_mod_plan(self):
         D, W = self.cfg["d"], self.W
         pb = PlanBuilder(self.lib, self.device, self.dtype)
-        pb.priority = back_half_priority()
         tin = pb.buf((2, 256), self.tdt)                     # sinusoids of timestep*1000 and guidance*1000
         pooled = pb.buf((1, self.cfg["pooled_dim"]), self.tdt)
         embs = []
@@ -179,7 +178,6 @@ class FluxDiTHip:
         t_img = t_noise * (1 + n_ref)
         T = t_txt + t_img
         pb = PlanBuilder(self.lib, self.device, self.dtype, lanes=self.side_lane)
-        pb.priority = back_half_priority()
         lat = pb.buf((t_img, cfg["in_channels"]), self.tdt)       # [noise tokens ; reference tokens]
         ctx_in = pb.buf((t_txt, cfg["joint_dim"]), self.tdt)      # prompt embeddings
         mod = pb.buf((self.n_vec, D), self.tdt)
@@ -356,7 +354,6 @@ class FluxVAEHip:
         if key not in self._plans:
             ch = self.cfg["ch"]
             pb = PlanBuilder(self.lib, self.device, self.dtype)
-            pb.priority = back_half_priority()
             src = pb.buf((1, h, w, 3), torch.uint8)
             x0 = pb.act(1, h, w, 8)
             pb.image_convert(abi.IMG_HWC_U8_TO_NHWC, src, x0.t, 1, h, w, 8, mul=2.0, add=(-1.0, -1.0, -1.0), label="vae.in")
@@ -380,7 +377,6 @@ class FluxVAEHip:
         if key not in self._plans:
             rc = list(reversed(self.cfg["ch"]))
             pb = PlanBuilder(self.lib, self.device, self.dtype)
-            pb.priority = back_half_priority()
             z = pb.act(1, h8, w8, self.cfg.get("latent", 16))
             x = self._conv(pb, self._conv(pb, z, "post_quant_conv"), "decoder.conv_in") if self.cfg.get("quant_conv") else self._conv(pb, z, "decoder.conv_in")
             x = self._mid(pb, x, "decoder.mid_block")

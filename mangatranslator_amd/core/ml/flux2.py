@@ -29,7 +29,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder, PlanCache, glu_interleave, back_half_priority
+from ...hip.plan import Act, PlanBuilder, PlanCache, glu_interleave
 from ...utils.exceptions import ModelError
 from .flux import FluxVAEHip, _rows, rope_table, sinusoid, synthetic_provider  # noqa: F401  (re-exported for callers)
 
@@ -151,7 +151,6 @@ class Flux2DiTHip:
             w16 = w16[glu_interleave(glu_col0, self.hid).to(w16.device)].contiguous()
         n, k = w16.shape
         pb = PlanBuilder(self.lib, self.device, self.dtype)
-        pb.priority = back_half_priority()
         q, scale, lds = pb.quantize(w16, n, k)
         pb.build().run()
         if self.device.type == "cuda":
@@ -162,7 +161,6 @@ class Flux2DiTHip:
     def _build_mod_plan(self):
         D, W = self.cfg["d"], self.W
         pb = PlanBuilder(self.lib, self.device, self.dtype)
-        pb.priority = back_half_priority()
         tin = pb.buf((2, 256), self.tdt)                     # sinusoids of timestep * 1000 (and guidance * 1000)
         a = lambda t: Act(t.view(1, 1, 1, D), 1, 1, 1, D)
         temb = None
@@ -200,7 +198,6 @@ class Flux2DiTHip:
         T = t_txt + t_img
         FW = 3 * D + 2 * hid                                     # width of the single blocks' fused projection
         pb = PlanBuilder(self.lib, self.device, self.dtype)
-        pb.priority = back_half_priority()
         lat = pb.buf((t_img, cfg["in_channels"]), self.tdt)       # [noise tokens ; reference tokens]
         ctx_in = pb.buf((t_txt, cfg["joint_dim"]), self.tdt)      # prompt embeddings
         mod = pb.buf((self.n_vec, D), self.tdt)

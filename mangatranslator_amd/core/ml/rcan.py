@@ -26,7 +26,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import PlanBuilder, PlanCache, back_half_priority
+from ...hip.plan import PlanBuilder, PlanCache
 from ...utils.exceptions import ModelError
 
 
@@ -181,7 +181,6 @@ class RCANUpscaler:
         if h % u or w % u:
             raise ModelError(f"RCAN(PU): plans are built on sizes divisible by {u} (callers pad: see _padded)")
         pb = PlanBuilder(self.lib, self.device, self.dtype)
-        pb.priority = back_half_priority()
         C_ = hp["n_feats"]
         x_in = pb.buf((n, 3, h, w), torch.float32)
         cin_pad = (3 * u * u + 7) // 8 * 8

@@ -13,7 +13,10 @@ namespace mtx {
 
 constexpr int NORM_MAXCH = 12;   // chunks of 8 per lane -> C <= 6144
 
-template <typename T>
+// NCH = 16-byte chunks per lane the row needs (C <= 512 NCH): the row lives in NCH x 8 registers between the passes, and the kernel is
+// latency-bound (one wave per row: a load, two wave reductions, a store) — with the width a template parameter a 3072-wide row takes 48
+// value registers instead of the 96 the widest row needs, twice the waves fit a SIMD and twice the bytes are in flight (round 4).
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -21,10 +24,10 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
   const long nch = p.c / 8;
   const T* X = reinterpret_cast<const T*>(p.x) + row * p.ldx;
   T* Y = reinterpret_cast<T*>(p.y) + row * p.ldy;
-  float v[NORM_MAXCH][8];
+  float v[NCH][8];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NORM_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const long ch = lane + (long)i * 64;
     if (ch < nch) {
       unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), v[i]);
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
   if (p.kind == 0) { s = wave_sum(s); mean = s / (float)p.c; }
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < NORM_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const long ch = lane + (long)i * 64;
     if (ch < nch) {
 #pragma unroll
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
   const T* MH = reinterpret_cast<const T*>(p.mod_shift);
   const long mrow = p.rows_per > 0 ? row / p.rows_per : 0;
 #pragma unroll
-  for (int i = 0; i < NORM_MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const long ch = lane + (long)i * 64;
     if (ch < nch) {
       float o[8];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
     unsigned char* Q = reinterpret_cast<unsigned char*>(p.q) + row * p.ldq;
     unsigned* S = reinterpret_cast<unsigned*>(p.q_scale);
 #pragma unroll
-    for (int i = 0; i < NORM_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const long ch = lane + (long)i * 64;
       if ((long)i * 64 < nch) {                     // wave-uniform
         float f[8];
@@ -109,9 +112,15 @@ int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
   if (a->kind != 0 && a->kind != 1) { *err = "norm: kind must be 0 (LayerNorm) or 1 (RMSNorm)"; return MTX_ERR_INVALID; }
   if (a->rows < 1) return MTX_OK;
   const unsigned blocks = (unsigned)((a->rows + 3) / 4);
-  if (a->dtype == MTX_BF16) MTX_LAUNCH((norm_kernel<__bf16>), dim3(blocks), dim3(256), 0, stream, *a);
-  else if (a->dtype == MTX_F16) MTX_LAUNCH((norm_kernel<_Float16>), dim3(blocks), dim3(256), 0, stream, *a);
-  else { *err = "norm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+  if (a->dtype != MTX_BF16 && a->dtype != MTX_F16) { *err = "norm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+  const long per_lane = (a->c / 8 + 63) / 64;
+#define MTX_NORM(N) do { if (a->dtype == MTX_BF16) MTX_LAUNCH((norm_kernel<__bf16, N>), dim3(blocks), dim3(256), 0, stream, *a); \
+                         else MTX_LAUNCH((norm_kernel<_Float16, N>), dim3(blocks), dim3(256), 0, stream, *a); } while (0)
+  if (per_lane <= 2) MTX_NORM(2);
+  else if (per_lane <= 4) MTX_NORM(4);
+  else if (per_lane <= 6) MTX_NORM(6);
+  else MTX_NORM(NORM_MAXCH);
+#undef MTX_NORM
   return MTX_OK;
 }
 

@@ -59,7 +59,6 @@ class Plan:
         self._h = C.c_void_p(handle)
         self._keep = keep
         self.n_ops = n_ops
-        self.priority = 0                  # of the plan-owned replay stream: 0 = normal, -1 = high (torch / HIP convention)
 
     def _stream(self, stream):
         if stream is not None:
@@ -79,7 +78,7 @@ class Plan:
             return
         cur = torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=cur.device, priority=self.priority)
+            self._side = torch.cuda.Stream(device=cur.device)
         self._side.wait_stream(cur)
         self.lib.check(self.lib.mtx_plan_run_graph(self._h, C.c_void_p(self._side.cuda_stream)), "mtx_plan_run_graph")
         cur.wait_stream(self._side)
@@ -186,7 +185,6 @@ class PlanBuilder:
         self._side, self._join_next = False, False
         self.labels: List[str] = []
         self.keep: list = []
-        self.priority = 0                       # handed to the Plan (its replay stream's priority)
 
     # ---- memory ---------------------------------------------------------------------------
     def hold(self, t):
@@ -582,17 +580,8 @@ class PlanBuilder:
         self.lib.check(self.lib.mtx_plan_create(arr, n, C.byref(handle)), "mtx_plan_create")
         plan = Plan(self.lib, handle.value, list(self.keep), n)
         plan.labels = list(self.labels)
-        plan.priority = self.priority
         plan.ops = list(self.ops)          # the recorded argument blocks (benchmarks group launches by kernel and shape)
         return plan
-
-
-def back_half_priority() -> int:
-    """replay-stream priority of the page's back-half graphs (diffusion, VAE, RCAN).  EXPERIMENT of round 4 (MTX_BACK_PRIORITY=1): high
-    priority for the chip-filling graphs so that the front half's small detector graphs of the NEXT page fill gaps instead of taking CUs from
-    a 256-workgroup wave."""
-    import os
-    return -1 if os.environ.get("MTX_BACK_PRIORITY") == "1" else 0
 
 
 def glu_interleave(col0: int, hid: int) -> torch.Tensor:

@@ -118,7 +118,7 @@ def test_kontext_uint4_svd_r32_folder(tmp_path):
     logical shape, equal (to bf16 rounding) to the dequantisation computed here in float64."""
     from mangatranslator_amd.core.ml import flux as fx
     from mangatranslator_amd.core.ml.model_manager import _ShardedProvider
-    cfg = dict(d=128, heads=2, layers=1, single_layers=1, in_channels=64, joint_dim=96, pooled_dim=48, axes_dim=(16, 24, 24))
+    cfg = dict(d=64, heads=2, layers=1, single_layers=1, in_channels=64, joint_dim=96, pooled_dim=48, axes_dim=(8, 12, 12))
     shapes = fx.dit_param_shapes(cfg)
     rng = np.random.default_rng(7)
     group, rank = 32, 32

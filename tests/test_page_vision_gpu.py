@@ -81,11 +81,11 @@ def test_page_through_all_stages(hip_lib, monkeypatch):
     # the OSB text boxes come from the generator (the OSB text network is not built: the manager's loader raises and the
     # detector falls back to text_free boxes, which here are appended to what the secondary detector reports)
     from mangatranslator_amd.core import outside_text_processor as otp
-    real = otp.process_outside_text
+    real = otp.prepare_outside_text_work          # the OSB stage's prepare half (the page's front half calls it: core/pipeline.py)
 
-    def osb_with_ground_truth(p, c, path, fmt, verbose, bubble_data=None, text_free_boxes=None, panels=None):
-        return real(p, c, path, fmt, verbose, bubble_data=bubble_data, text_free_boxes=list(text_free_boxes or []) + [[x0 + 5.0, y0 + 5.0, x1 - 5.0, y1 - 5.0]], panels=panels)
-    monkeypatch.setattr(otp, "process_outside_text", osb_with_ground_truth)
+    def prepare_with_ground_truth(p, c, path, fmt, verbose=False, bubble_data=None, text_free_boxes=None, panels=None):
+        return real(p, c, path, fmt, verbose=verbose, bubble_data=bubble_data, text_free_boxes=list(text_free_boxes or []) + [[x0 + 5.0, y0 + 5.0, x1 - 5.0, y1 - 5.0]], panels=panels)
+    monkeypatch.setattr(otp, "prepare_outside_text_work", prepare_with_ground_truth)
 
     out, info = pipeline.process_page_vision(page, cfg)
     assert out.mode == "RGBA" and out.size == (2 * W, 2 * H)
