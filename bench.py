@@ -621,7 +621,8 @@ def main():
                     "gpu_wait_for_decode_ms_per_page": round(1e3 * io_.get("gpu_wait_for_decode_s", 0.0) / max(1, n_io), 2),
                     "wait_for_save_slot_ms_per_page": round(1e3 * io_.get("wait_for_save_slot_s", 0.0) / max(1, n_io), 2), "max_pending_saves": io_.get("max_pending_saves"),
                     "input": f"{n_io} PNG files ({W_}x{H_}, compress_level 1)", "output": f"PNG, native writer (csrc/host_png.cpp: reductions + per-row filters + {io_threads and 8}-stripe parallel deflate, zlib level 6; oxipng absent), {out_bytes / max(1, n_io) / 1e6:.2f} MB per page",
-                    "note": "pages go through the stages one at a time here (process_image is called per page by the harness; no two-pages-in-flight overlap)"}
+                    "note": ("two pages in flight inside the harness (core/pipeline.py batch_process_images(process_front=, process_back=))" if io_pipelined else
+                             "pages go through the stages one at a time here (both halves of this stage set are front halves: nothing to overlap)")}
         if rank == 0:
             shutil.rmtree(tmp, ignore_errors=True)
     if dist is not None:
