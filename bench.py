@@ -118,9 +118,6 @@ def parse():
                     help="instances of the detect-stage models (detectors + SAM) per rank; with N > 1 the front halves of N pages run at once, "
                          "each on its own instance (a model's plan has one set of buffers).  Default: 2 for the stage sets without diffusion / "
                          "upscaling (BASELINE configs 1 and 2: the 640-pixel graphs of ONE page do not fill 256 CUs), else 1")
-    ap.add_argument("--no-merge-text", action="store_true",
-                    help="FLUX.1 double-stream blocks, for A/Bs: the text stream's linears as separate launches on the plan's side lane (rounds 2-3) "
-                         "instead of inside the image stream's launches (row-split operands, mtx_gemm_args.alt_*: the default since round 4)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--time-ops", default="auto", choices=["auto", "difference", "stamp"],
                     help="in-context kernel timing of the roofline objects: hipGraph with minus hipGraph without the ops (HIP events), "
@@ -347,7 +344,7 @@ def main():
             if args.traffic_child:      # counter pass: 2 + 4 of the 19 + 38 blocks (the same 1 : 2 launch mix; bytes per launch do not depend on depth)
                 kcfg = dict(kcfg, layers=2, single_layers=4)
             dit = fx.FluxDiTHip(fx.synthetic_provider(fx.dit_param_shapes(kcfg), device, 21, broadcast=world > 1), kcfg, device, lib=lib,
-                                text_stream_on_side_lane=not args.no_lanes, merge_text_stream=not args.no_merge_text)
+                                text_stream_on_side_lane=not args.no_lanes)
             vae = fx.FluxVAEHip(fx.synthetic_provider(fx.vae_param_shapes(fx.KONTEXT_VAE_CFG), device, 22, broadcast=world > 1), fx.KONTEXT_VAE_CFG, device, lib=lib)
             flux = fx.FluxKontextHip(dit, vae, graph=graph)
             g = torch.Generator().manual_seed(23)     # cached T5 / CLIP embeddings of "Remove all text." (random stand-ins)

@@ -36,7 +36,7 @@ extern "C" {
 #define MTX_API
 #endif
 
-#define MTX_ABI_VERSION 6
+#define MTX_ABI_VERSION 5
 
 typedef enum mtx_status {
   MTX_OK = 0,
@@ -121,12 +121,6 @@ typedef struct mtx_gemm_args {
    * act on the launch, glu_q 16-byte aligned with glu_ldq % 16 == 0.  NULL glu_q = off.  (Built and checked on the CPU simulator in
    * round 3; not yet run on hardware — FLUX.2 graphs do not use it by default.) */
   void* glu_q; void* glu_scale; int64_t glu_ldq, glu_lds, glu_col0;
-  /* Row-split second operand set (16-bit path, 256-tile kernel): rows [0, alt_rows) of the launch multiply alt_w [N, K] (same ldw) and take
-   * alt_bias / alt_gate (ONE gate row for all of them), rows from alt_rows on multiply w and take bias / gate (gate row (m - alt_rows) /
-   * gate_rows_per).  alt_rows % 256 == 0.  FLUX's double-stream blocks: the text stream (512 rows in front) and the image stream share every
-   * linear's shape but not its weights (diffusers FluxTransformerBlock behind core/image/inpainting.py:877-887) — one launch instead of two,
-   * the text rows' two tile rows riding in the image launch's last partial wave.  0 = off. */
-  int64_t alt_rows; const void* alt_w; const float* alt_bias; const void* alt_gate;
 } mtx_gemm_args;
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
 #define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the K-slice tail */

@@ -78,14 +78,10 @@ def image_ids(h2, w2, first) -> np.ndarray:
 
 
 class FluxDiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None, text_stream_on_side_lane: bool = True, merge_text_stream: bool = True):
+    def __init__(self, provider, cfg: dict, device, lib=None, text_stream_on_side_lane: bool = True):
         """provider(name) -> tensor with diffusers' FluxTransformer2DModel parameter of that name.
         text_stream_on_side_lane: run the double-stream blocks' text ops beside the image ops (plan lanes); False keeps one lane"""
         self.side_lane = text_stream_on_side_lane
-        # merge_text_stream (round 4): the double-stream blocks' four text-stream linears ride INSIDE the image stream's launches (row-split
-        # operands, mtx_gemm_args.alt_*: the 512 text rows are two tile rows in front of the image rows) instead of running as 76 small
-        # launches per step on the side lane; needs the text length to be a multiple of the 256-row tile, else the side-lane form is built
-        self.merge_text = merge_text_stream
         self.lib = lib if lib is not None else get_library()
         self.device = torch.device(device)
         self.dtype, self.tdt = abi.BF16, torch.bfloat16
@@ -223,27 +219,9 @@ class FluxDiTHip:
         # Double-stream blocks: the text stream's ops (512 rows: GEMMs of 24 - 96 tiles that cannot fill the chip, 4 % of a step when run in
         # line) go to the plan's SIDE lane and run beside the image stream's ops; the lanes meet at the joint attention and at the next block.
         # The two streams touch disjoint row ranges of every shared buffer.
-        merged = self.merge_text and t_txt % 256 == 0 and t_txt > 0
         for i, B in enumerate(self.blocks):
             b0 = i * 12
             tag = f"dbl{i}"
-            if merged:
-                # one launch per linear over ALL rows: rows [0, t_txt) multiply the text stream's weights (alt operand set)
-                adaln(0, t_txt, b0 + 6, b0 + 7, tag + ".norm1_ctx")
-                adaln(t_txt, T, b0 + 0, b0 + 1, tag + ".norm1")
-                pb.gemm(nrm, B["qkv"][0], T, 3 * D, D, bias=B["qkv"][1], out=qkv, alt=(t_txt, B["cqkv"][0], B["cqkv"][1], None), label=tag + ".qkv")
-                rope(qkv, 0, t_txt, B["cnqk"], 3 * D, tag + ".rope_qk_ctx")
-                rope(qkv, t_txt, T, B["nqk"], 3 * D, tag + ".rope_qk")
-                attention(o, D, tag + ".attn")
-                pb.gemm(o, B["out"][0], T, D, D, bias=B["out"][1], gate=mod[b0 + 2], gate_rows_per=t_img, res=x, out=x,
-                        alt=(t_txt, B["cout"][0], B["cout"][1], mod[b0 + 8]), label=tag + ".to_out")
-                adaln(0, t_txt, b0 + 9, b0 + 10, tag + ".norm2_ctx")
-                adaln(t_txt, T, b0 + 3, b0 + 4, tag + ".norm2")
-                pb.gemm(nrm, B["ff1"][0], T, 4 * D, D, bias=B["ff1"][1], act=abi.ACT_GELU_TANH, out=hid,
-                        alt=(t_txt, B["cff1"][0], B["cff1"][1], None), label=tag + ".ff1")
-                pb.gemm(hid, B["ff2"][0], T, D, 4 * D, bias=B["ff2"][1], gate=mod[b0 + 5], gate_rows_per=t_img, res=x, out=x,
-                        alt=(t_txt, B["cff2"][0], B["cff2"][1], mod[b0 + 11]), label=tag + ".ff2")
-                continue
             with pb.side():
                 adaln(0, t_txt, b0 + 6, b0 + 7, tag + ".norm1_ctx")
                 pb.gemm(nrm, B["cqkv"][0], t_txt, 3 * D, D, bias=B["cqkv"][1], out=qkv, label=tag + ".qkv_ctx")

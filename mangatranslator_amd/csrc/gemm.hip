@@ -33,8 +33,6 @@ struct GemmParams {
   int bk;           // K elements per LDS stage row: 64 (16-bit operands) or 128 (fp8); a row is 128 bytes either way
   // SwiGLU + MX-fp8 epilogue of the fp8 kernel (mtx_gemm_args.glu_*): columns >= glu_col0 are [32 a | 32 b] spans
   unsigned char* glu_q; unsigned* glu_scale; long glu_ldq, glu_lds, glu_col0;
-  // row-split second operand set (mtx_gemm_args.alt_*): rows [0, alt_rows) — whole 256-row tiles — multiply alt_w and take alt_bias / alt_gate
-  long alt_rows; const unsigned char* alt_w; const float* alt_bias; const unsigned char* alt_gate;
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -216,17 +214,10 @@ constexpr int G2_STAGE = (G2_BM + G2_BN) * 128;      // 64 KB
 
 // Epilogue of the 256-tile kernels, run by the 8 MFMA waves (wv = 0..7).
 // acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
-// ALT: the tile's rows may belong to the launch's second operand set (rows below p.alt_rows: FLUX's text stream, which shares every linear's
-// shape with the image stream but not its weights) — bias and gate are then the alternates; the gate row index counts from the set's first row
-template <typename T, int ACT, bool ALT = false>
+template <typename T, int ACT>
 __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], unsigned char* smem, T* Cp,
                                                  long m0, long n0, long bz, int wv, int lane) {
   typedef typename Traits<T>::v4 v4;
-  const bool alt = ALT && m0 < p.alt_rows;
-  const float* e_bias = alt ? p.alt_bias : p.bias;
-  const unsigned char* e_gate = alt ? p.alt_gate : p.gate;
-  const long e_row0 = ALT ? (alt ? 0 : p.alt_rows) : 0;
-  const long e_rows_per = alt ? p.alt_rows : (long)p.gate_rows_per;
   const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 2, wn = wv & 3;
   unsigned char* outs = smem + wv * 16384;          // [128 rows m][8 chunks of 16 B], chunk ^= (row & 7)
 #pragma unroll
@@ -238,7 +229,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&a
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long n = n0 + wn * 64 + nl + r;
-        b[r] = (e_bias != nullptr && n < p.n) ? e_bias[n] : 0.f;
+        b[r] = (p.bias != nullptr && n < p.n) ? p.bias[n] : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -255,7 +246,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&a
 #else
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-  const T* G = reinterpret_cast<const T*>(e_gate);
+  const T* G = reinterpret_cast<const T*>(p.gate);
   const T* R = reinterpret_cast<const T*>(p.res);
   const int oc = lane & 7;
 #pragma unroll 4
@@ -267,7 +258,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&a
     if (G != nullptr || R != nullptr) {
       float f[8];
       unpack8<T>(raw, f);
-      if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + (size_t)((m - e_row0) / e_rows_per) * p.ldgate + n), g8);
+      if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + (size_t)(m / p.gate_rows_per) * p.ldgate + n), g8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
       if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)bz * p.res_bs + (size_t)m * p.ldres + n), r8);
@@ -397,7 +388,7 @@ __device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigne
 }
 
 // 256-tile kernel over whole tiles: the K loop above, then the epilogue.
-template <typename T, int ACT, bool ALT = false>
+template <typename T, int ACT>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -408,7 +399,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   gemm256_tile_origin(p, lin, m0, n0);
   const long bz = blockIdx.y;
   const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
-  const T* W = reinterpret_cast<const T*>((ALT && m0 < p.alt_rows) ? p.alt_w : p.w) + (size_t)bz * p.w_bs;
+  const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
   T* Cp = reinterpret_cast<T*>(p.c) + (size_t)bz * p.c_bs;
   f32x16 acc[4][2];
 #pragma unroll
@@ -419,7 +410,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, 0, p.k / G2_BK, acc);
   __syncthreads();
-  gemm256_epilogue<T, ACT, ALT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
+  gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
 }
 
 // =====================================================================================================
@@ -682,7 +673,7 @@ __global__ __launch_bounds__(512) void gemm256_f8_glu_kernel(GemmParams p) {
 // last one acquires, adds the tile's partials IN SLICE ORDER (the sum does not depend on who came last) and runs the whole-tile
 // epilogue.  No merge launch; tickets return to zero.  Measured (same process, profiles/r04_visit_c_slice_sweep.log): 8812x3072x15360
 // 0.700 ms (stream-K + merge 0.768, unsplit 0.725), 8300x3072x12288 0.533 (0.572 / 0.561), 512x3072x12288 0.068 (0.081 / 0.198).
-template <typename T, bool F8, int ACT, bool ALT = false>
+template <typename T, bool F8, int ACT>
 __global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
   __shared__ int last_flag;
@@ -704,7 +695,7 @@ __global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (kend > kbeg) {
     if (F8) gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, kbeg, kend, acc);
-    else gemm256_pp_buf_loop<T>(p, smem, reinterpret_cast<const T*>(p.a), reinterpret_cast<const T*>((ALT && m0 < p.alt_rows) ? p.alt_w : p.w), m0, n0, kbeg, kend, acc);
+    else gemm256_pp_buf_loop<T>(p, smem, reinterpret_cast<const T*>(p.a), reinterpret_cast<const T*>(p.w), m0, n0, kbeg, kend, acc);
   }
   // slot layout: [wave][block = (i, j, g)][lane] x 16 bytes
   const size_t slot_floats = (size_t)G2_BM * G2_BN;
@@ -752,7 +743,7 @@ __global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
     }
   }
   __syncthreads();
-  gemm256_epilogue<T, ACT, ALT>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
+  gemm256_epilogue<T, ACT>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
 }
 
 static int gemm_num_cus() {
@@ -771,7 +762,6 @@ static int gemm_num_cus() {
 template <typename T, bool F8>
 static void launch_gemm256_tiles(const GemmParams& p, dim3 grid, void* stream) {
 #define MTX_G256(ACTV) do { if (F8) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); \
-                            else if (p.alt_rows > 0) MTX_LAUNCH((gemm256_kernel<T, ACTV, true>), grid, dim3(512), 0, stream, p); \
                             else MTX_LAUNCH((gemm256_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); } while (0)
   switch (p.act) {
     case MTX_ACT_NONE: MTX_G256(MTX_ACT_NONE); break;
@@ -814,8 +804,7 @@ static unsigned gemm256_choose_slices(unsigned r, long nk, unsigned cus, double 
 
 template <typename T, bool F8>
 static void launch_gemm256_slices(const GemmParams& p, unsigned pieces, void* stream) {
-#define MTX_G256S(ACTV) do { if (!F8 && p.alt_rows > 0) MTX_LAUNCH((gemm256_slice_kernel<T, F8, ACTV, true>), dim3(pieces), dim3(512), 0, stream, p); \
-                             else MTX_LAUNCH((gemm256_slice_kernel<T, F8, ACTV>), dim3(pieces), dim3(512), 0, stream, p); } while (0)
+#define MTX_G256S(ACTV) MTX_LAUNCH((gemm256_slice_kernel<T, F8, ACTV>), dim3(pieces), dim3(512), 0, stream, p)
   switch (p.act) {
     case MTX_ACT_NONE: MTX_G256S(MTX_ACT_NONE); break;
     case MTX_ACT_SILU: MTX_G256S(MTX_ACT_SILU); break;
@@ -886,19 +875,11 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.a_scale = reinterpret_cast<const unsigned*>(a->a_scale); p.w_scale = reinterpret_cast<const unsigned*>(a->w_scale);
   p.lds_a = a->lds_a; p.lds_w = a->lds_w;
   p.glu_q = nullptr; p.glu_scale = nullptr; p.glu_ldq = p.glu_lds = p.glu_col0 = 0;
-  p.alt_rows = 0; p.alt_w = nullptr; p.alt_bias = nullptr; p.alt_gate = nullptr;
-  if (a->alt_rows > 0) {
-    if (f8 || !a->alt_w || a->alt_rows % G2_BM || a->alt_rows >= a->m || (a->batch > 1) || (a->gate != nullptr) != (a->alt_gate != nullptr) || (a->bias != nullptr) != (a->alt_bias != nullptr)) {
-      *err = "gemm (row-split operands): 16-bit path, batch 1, alt_rows a multiple of 256 below m, alt_w given, alt_bias / alt_gate present exactly when bias / gate are";
-      return MTX_ERR_INVALID;
-    }
-    p.alt_rows = a->alt_rows; p.alt_w = (const unsigned char*)a->alt_w; p.alt_bias = a->alt_bias; p.alt_gate = (const unsigned char*)a->alt_gate;
-  }
   p.bk = f8 ? 128 : G2_BK;
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;
-  const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0 || p.alt_rows > 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0;      // row-split operands exist on the 256-tile kernel only
+  const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0;
   const unsigned forced_slices = ((unsigned)a->flags >> 8) & 0xffu;
   // large, aligned problems: the 256 x 256 LDS-DMA kernel (needs whole K tiles and 16-byte rows everywhere)
   const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;
@@ -942,7 +923,6 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
     if (a->dtype == MTX_BF16) launch_gemm256<__bf16, false>(p, g2, stream, force, nosplit, forced_slices); else launch_gemm256<_Float16, false>(p, g2, stream, force, nosplit, forced_slices);
     return MTX_OK;
   }
-  if (p.alt_rows > 0) { *err = "gemm (row-split operands): the problem does not qualify for the 256-tile kernel (K % 64, 16-byte rows, tile count)"; return MTX_ERR_INVALID; }
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
   if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm_kernel<__bf16>), grid, dim3(256), 0, stream, p);
   else if (a->dtype == MTX_F16) MTX_LAUNCH((gemm_kernel<_Float16>), grid, dim3(256), 0, stream, p);

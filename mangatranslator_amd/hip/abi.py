@@ -2,7 +2,7 @@
 mtx_abi_sizeof() when the library is opened)."""
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 5
 
 # enums
 BF16, F16, F32, U8, I32, F8 = 0, 1, 2, 3, 4, 5
@@ -36,8 +36,7 @@ class GemmArgs(C.Structure):
                 ("act", i32), ("act_param", f32), ("alpha", f32),
                 ("dtype", i32), ("out_dtype", i32), ("workspace", vp), ("workspace_bytes", i64),
                 ("a_scale", vp), ("w_scale", vp), ("lds_a", i64), ("lds_w", i64), ("in_dtype", i32), ("flags", i32),
-                ("glu_q", vp), ("glu_scale", vp), ("glu_ldq", i64), ("glu_lds", i64), ("glu_col0", i64),
-                ("alt_rows", i64), ("alt_w", vp), ("alt_bias", vp), ("alt_gate", vp)]
+                ("glu_q", vp), ("glu_scale", vp), ("glu_ldq", i64), ("glu_lds", i64), ("glu_col0", i64)]
 
 
 GEMM_FORCE_TILE256, GEMM_NO_SPLIT = 1, 2

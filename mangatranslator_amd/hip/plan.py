@@ -283,7 +283,7 @@ class PlanBuilder:
     def gemm(self, a_t, w_t, m, n, k, lda=None, ldw=None, out=None, ldc=None, bias=None, act=abi.ACT_NONE,
              res=None, ldres=None, gate=None, ldgate=None, gate_rows_per=1, alpha=1.0, batch=1,
              a_bs=0, w_bs=0, c_bs=0, res_bs=0, out_f32=False, a_off=0, w_off=0, c_off=0, res_off=0,
-             label="gemm", f8=None, flags=0, glu=None, alt=None):
+             label="gemm", f8=None, flags=0, glu=None):
         """f8 = (a_scale, lds_a, w_scale, lds_w, a_scale_off, w_scale_off): a_t / w_t are e4m3 byte matrices from `quantize` (offsets in
         bytes), the epilogue operands and the output stay in the builder's 16-bit type (include/mtx_hip.h, in_dtype == MTX_F8).
         glu = (q, scale, ldq, lds, col0, row_off, q_col_off): the columns from col0 on are [32 a | 32 b] spans (`glu_interleave` order of
@@ -291,9 +291,6 @@ class PlanBuilder:
         (mtx_gemm_args.glu_*); with col0 == 0 no 16-bit output exists at all"""
         g = abi.GemmArgs()
         g.flags = flags
-        if alt is not None:      # (rows, w, bias, gate): rows [0, rows) of the launch use this second operand set (mtx_gemm_args.alt_*)
-            arows, aw, ab, ag = alt
-            g.alt_rows, g.alt_w, g.alt_bias, g.alt_gate = arows, _ptr(aw), _ptr(ab), _ptr(ag)
         if glu is not None:
             gq, gsc, gldq, glds, gcol0, grow, gqcol = glu
             assert f8 is not None and gqcol % 128 == 0 and gcol0 % 256 == 0

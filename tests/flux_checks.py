@@ -30,13 +30,13 @@ def models(seed=0, **kw):
     return t, v
 
 
-def hip_models(t, v, lib, device, **dit_kw):
+def hip_models(t, v, lib, device):
     tsd, vsd = t.state_dict(), v.state_dict()
     c = t.cfg
     dcfg = dict(d=c["d"], heads=c["heads"], layers=c["layers"], single_layers=c["single_layers"], in_channels=c["in_channels"],
                 joint_dim=c["joint_dim"], pooled_dim=c["pooled_dim"], axes_dim=tuple(c["axes_dim"]))
     vcfg = dict(ch=tuple(v.cfg["ch"]), groups=v.cfg["groups"], scaling_factor=v.cfg["scaling_factor"], shift_factor=v.cfg["shift_factor"])
-    dit = fx.FluxDiTHip(lambda n: tsd[n], dcfg, device, lib=lib, **dit_kw)
+    dit = fx.FluxDiTHip(lambda n: tsd[n], dcfg, device, lib=lib)
     vae = fx.FluxVAEHip(lambda n: vsd[n], vcfg, device, lib=lib)
     return dit, vae
 
@@ -50,9 +50,9 @@ def inputs(t, h, w, t_txt, seed=1):
     return img, pe, pooled, noise
 
 
-def check_dit_step(lib, device, h2=4, w2=6, t_txt=16, tol=3e-2, dit_kw=None, **kw):
+def check_dit_step(lib, device, h2=4, w2=6, t_txt=16, tol=3e-2, **kw):
     t, v = models(**kw)
-    dit, _ = hip_models(t, v, lib, device, **(dit_kw or {}))
+    dit, _ = hip_models(t, v, lib, device)
     g = torch.Generator().manual_seed(3)
     tn = h2 * w2
     lat = torch.randn(2 * tn, 64, generator=g).to(torch.bfloat16).float()

@@ -103,7 +103,7 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
 
 
 def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=False, with_gate=False,
-               out_f32=False, batch=1, alpha=1.0, seed=0, flags=0, runs=1, expect_split=None, alt_rows=0):
+               out_f32=False, batch=1, alpha=1.0, seed=0, flags=0, runs=1, expect_split=None):
     """runs > 1: the same plan is run again over a poisoned output — a K-slice launch must not depend on what an earlier launch left in its
     scratch (and must leave its tickets at zero).  expect_split = (whole tiles, K slices, tail pieces) the launch must report
     (mtx_gemm_last_split): the test shape really went through the path it is meant to cover."""
@@ -115,27 +115,17 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
     ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float()) * alpha
     if b is not None:
         ref = ref + b
-    w2 = b2 = None
-    if alt_rows:         # row-split second operand set (mtx_gemm_args.alt_*): rows below alt_rows multiply other weights, take another bias / gate row
-        assert batch == 1
-        w2 = (torch.randn(n, k, generator=g) / math.sqrt(k)).to(td)
-        b2 = torch.randn(n, generator=g) if with_bias else None
-        ref[0, :alt_rows] = a[0, :alt_rows].float() @ w2.float().t() * alpha + (b2 if b2 is not None else 0.0)
     if act == abi.ACT_GELU:
         ref = F.gelu(ref)
     elif act == abi.ACT_GELU_TANH:
         ref = F.gelu(ref, approximate="tanh")
     elif act == abi.ACT_SILU:
         ref = F.silu(ref)
-    gate = res = gate2 = None
-    rows_per = max((m - alt_rows) // 2, 1)
+    gate = res = None
+    rows_per = max(m // 2, 1)
     if with_gate:
-        gate = torch.randn((m - alt_rows + rows_per - 1) // rows_per, n, generator=g).to(td)
-        full = gate.float().repeat_interleave(rows_per, dim=0)[:m - alt_rows]
-        if alt_rows:
-            gate2 = torch.randn(1, n, generator=g).to(td)
-            full = torch.cat([gate2.float().expand(alt_rows, n), full])
-        ref = ref * full
+        gate = torch.randn((m + rows_per - 1) // rows_per, n, generator=g).to(td)
+        ref = ref * gate.float().repeat_interleave(rows_per, dim=0)[:m]
     if with_res:
         res = torch.randn(batch, m, n, generator=g).to(td)
         ref = ref + res.float()
@@ -144,8 +134,7 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
     out = pb.gemm(at, wt, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
                   res=pb.const(res) if res is not None else None,
                   gate=pb.const(gate) if gate is not None else None, gate_rows_per=rows_per,
-                  alpha=alpha, batch=batch, a_bs=m * k, w_bs=n * k, c_bs=m * n, out_f32=out_f32, flags=flags,
-                  alt=(alt_rows, pb.const(w2), pb.const(b2) if b2 is not None else None, pb.const(gate2) if gate2 is not None else None) if alt_rows else None)
+                  alpha=alpha, batch=batch, a_bs=m * k, w_bs=n * k, c_bs=m * n, out_f32=out_f32, flags=flags)
     plan = _run(pb)
     if expect_split is not None:
         got = lib.gemm_last_split()           # None in expect_split = any value; "sliced" = at least two K slices

@@ -158,14 +158,6 @@ def test_gemm_k_slice_tail(hip_lib):
     oc.check_gemm(hip_lib, abi.F16, m=8112, n=3072, k=12288, runs=2, expect_split=(256, "sliced", None))
 
 
-def test_gemm_row_split_operands(hip_lib):
-    """mtx_gemm_args.alt_* at FLUX.1's double-block shapes: 512 text rows in front of 8300 image rows, own weights / bias / gate row"""
-    oc.check_gemm(hip_lib, abi.BF16, m=8812, n=3072, k=3072, with_res=True, with_gate=True, alt_rows=512)                                   # to_out
-    oc.check_gemm(hip_lib, abi.BF16, m=8812, n=9216, k=3072, alt_rows=512)                                                                  # qkv
-    oc.check_gemm(hip_lib, abi.BF16, m=8812, n=12288, k=3072, act=abi.ACT_GELU_TANH, alt_rows=512)                                          # ff1
-    oc.check_gemm(hip_lib, abi.BF16, m=8812, n=3072, k=12288, with_res=True, with_gate=True, alt_rows=512, runs=2, expect_split=(256, "sliced", None))   # ff2: K-slice tail
-
-
 @pytest.mark.parametrize("dtype", [abi.BF16, abi.F16])
 def test_rcab_tail_pool_before_conv(hip_lib, dtype):
     """RCAN's RCAB tail: channel attention from the sums of conv2's INPUT, conv2 writing x + s * conv2(t) (interior and border tiles)"""

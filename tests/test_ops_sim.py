@@ -169,17 +169,6 @@ def test_gemm_k_slice_tail(emu_lib):
     oc.check_gemm(emu_lib, abi.BF16, m=2048, n=1024, k=512, flags=f, expect_split=(32, 1, 0))
 
 
-def test_gemm_row_split_operands(emu_lib):
-    """mtx_gemm_args.alt_*: the first 256 / 512 rows of a launch multiply a second weight matrix and take their own bias and gate row (FLUX's
-    text stream inside the image stream's launch) — whole tiles, and through the K-slice tail (the left-over tile may be an alt tile or not)"""
-    f = abi.GEMM_FORCE_TILE256
-    oc.check_gemm(emu_lib, abi.BF16, m=900, n=320, k=192, act=abi.ACT_GELU_TANH, with_res=True, with_gate=True, flags=f, alt_rows=256)
-    oc.check_gemm(emu_lib, abi.F16, m=1100, n=256, k=128, with_bias=False, flags=f, alt_rows=512)
-    oc.check_gemm(emu_lib, abi.BF16, m=1024, n=256, k=4096, with_res=True, with_gate=True, flags=f, runs=2, alt_rows=256, expect_split=(3, "sliced", None))
-    with pytest.raises(Exception):
-        oc.check_gemm(emu_lib, abi.BF16, m=900, n=320, k=192, flags=f, alt_rows=100)      # not a whole tile row
-
-
 def test_gemm_k_slices_whole_problem(emu_lib):
     """few tiles, long K: every tile's K range is cut into slices (no full-tile launch at all)"""
     oc.check_gemm(emu_lib, abi.BF16, m=256, n=200, k=8192, with_res=True, with_gate=True, runs=2, expect_split=(0, "sliced", None))
