@@ -16,6 +16,7 @@ Everything is uint8 HWC torch tensors on the model's device; PyTorch is the allo
 that have no device tail use the host functions of `inpainting.py` (the reference's own arithmetic) as before."""
 import ctypes as C
 import math
+import threading
 from functools import lru_cache
 from typing import Tuple
 
@@ -127,6 +128,22 @@ def aten_aa_bilinear_tables(in_size: int, out_size: int) -> Tuple[np.ndarray, np
     return bounds, taps, ksize, bits
 
 
+_TAILS = {}
+_TAILS_LOCK = threading.Lock()
+
+
+def get_device_tail(lib, device) -> "DeviceTail":
+    """the process-wide DeviceTail of (library, device).  The inpainters are built per page by the OSB stage (like the reference's), and a
+    DeviceTail of their own meant rebuilding Pillow's tap tables — 13 000 `math.sin` calls per axis in Python — three times per page:
+    ≈ 50 ms of a 760 ms config-5 page spent on the host with the GPU idle (round 4, host profile of `bench.py --config 5 --stages inpaint`)."""
+    key = (id(lib), str(torch.device(device)))
+    with _TAILS_LOCK:
+        t = _TAILS.get(key)
+        if t is None:
+            t = _TAILS[key] = DeviceTail(lib, device)
+        return t
+
+
 class DeviceTail:
     def __init__(self, lib, device):
         from .color import _CBRT32, _COEF32, _GAMMA32
@@ -135,6 +152,7 @@ class DeviceTail:
         self._cbrt = torch.from_numpy(_CBRT32.astype(np.int32)).to(self.device)
         self._coef = torch.from_numpy(_COEF32.astype(np.int32).reshape(-1)).to(self.device)
         self._tables = {}
+        self._tables_lock = threading.Lock()
         self._ramps = {}
 
     # ---- plumbing ----------------------------------------------------------------------------------------------------------
@@ -148,12 +166,14 @@ class DeviceTail:
 
     def _dev_tables(self, in_size, out_size, filt):
         key = (in_size, out_size, filt)
-        if key not in self._tables:
-            b, t, k = pil_resample_tables(in_size, out_size, filt)
-            if len(self._tables) > 64:
-                self._tables.clear()
-            self._tables[key] = (torch.from_numpy(b).to(self.device), torch.from_numpy(t).to(self.device), k, int(b[0, 0]), int(b[-1, 0] + b[-1, 1]))
-        return self._tables[key]
+        with self._tables_lock:
+            hit = self._tables.get(key)
+            if hit is None:
+                b, t, k = pil_resample_tables(in_size, out_size, filt)
+                if len(self._tables) > 256:
+                    self._tables.clear()
+                hit = self._tables[key] = (torch.from_numpy(b).to(self.device), torch.from_numpy(t).to(self.device), k, int(b[0, 0]), int(b[-1, 0] + b[-1, 1]))
+        return hit
 
     @staticmethod
     def _u8(img) -> torch.Tensor:

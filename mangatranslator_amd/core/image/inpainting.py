@@ -327,8 +327,8 @@ class FluxKontextInpainter:
         lib = getattr(getattr(pipe, "transformer", None), "lib", None)
         if pipe is None or lib is None or not hasattr(pipe, "device"):
             return None
-        from .device_tail import DeviceTail
-        self._tail = DeviceTail(lib, pipe.device)
+        from .device_tail import get_device_tail
+        self._tail = get_device_tail(lib, pipe.device)
         return self._tail
 
     def _memo_key(self, crop, mask_crop, seed, bbox, padding, blur, ocr_params, strict_mask_clipping, composite_clip_bbox):
@@ -657,8 +657,8 @@ class FluxKleinInpainter:
         lib = getattr(getattr(pipe, "transformer", None), "lib", None)
         if pipe is None or lib is None or not hasattr(pipe, "device"):
             return None
-        from .device_tail import DeviceTail
-        self._tail = DeviceTail(lib, pipe.device)
+        from .device_tail import get_device_tail
+        self._tail = get_device_tail(lib, pipe.device)
         return self._tail
 
     def _inpaint_on_device(self, tail, image_pil, crop, mask_crop, feather, x, y, w, h, seed, verbose):
