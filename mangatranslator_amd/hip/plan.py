@@ -185,6 +185,7 @@ class PlanBuilder:
         self._side, self._join_next = False, False
         self.labels: List[str] = []
         self.keep: list = []
+        self.conv1x1_as_gemm = True             # 1x1 convolutions of >= 1024 pixels go to the GEMM kernels (round 4: detector graphs -15 %); False = the conv kernel, for A/Bs
 
     # ---- memory ---------------------------------------------------------------------------
     def hold(self, t):
@@ -249,6 +250,16 @@ class PlanBuilder:
                 out = self.act(x.n, ho * pixel_shuffle, wo * pixel_shuffle, cout // (pixel_shuffle ** 2))
             else:
                 out = self.act(x.n, ho, wo, cout)
+        if (self.conv1x1_as_gemm and ksize == 1 and stride == 1 and not pixel_shuffle and chan_sum is None and not res_broadcast and valid_hw is None
+                and out_scale is None and not act_after_res and res_scale == 1.0 and pad_mode == 0 and act_param == 0.0 and x.c % 8 == 0 and cout % 8 == 0
+                and x.n * x.h * x.w >= 1024):
+            # a 1x1 convolution over NHWC pixels IS a GEMM of the pixel rows ([n h w, ld] with K = Cin) against the packed filter [Cout, Cin]: the
+            # MFMA GEMM kernels (fused bias / act / residual, output into a channel slice through ldc) serve it 2-3x faster than the halo-tile
+            # conv kernel at detector shapes — YOLO11m-seg @1600 7.16 -> 6.10 ms, YOLO12x @640 10.6 -> 8.8 ms, config 2 34.0 -> 35.7 pages/s on
+            # one box (profiles/r04_visit_n_conv1x1_as_gemm_ab.log); parity tests unchanged
+            self.gemm(x, w_packed, x.n * x.h * x.w, cout, x.c, lda=x.ld, ldw=int(w_packed.shape[-1]), out=out, ldc=out.ld, bias=bias, act=act,
+                      res=res, ldres=(res.ld if res is not None else None), label=label)
+            return out
         a = abi.ConvArgs()
         a.x, a.w, a.bias = x.ptr, _ptr(w_packed), _ptr(bias)
         a.res = res.ptr if res is not None else None
