@@ -98,10 +98,17 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
 
   const size_t img_off = (size_t)img * p.h * p.w_in;
 
-  for (int kc0 = 0; kc0 < p.cin; kc0 += 64) {
-    __syncthreads();   // previous slice's fragment reads are done
-    // ---- stage the input halo slice: [HALO_PIX] x 64 channels, zero outside the image -----
-    for (int idx = tid; idx < C::HALO_PIX * 8; idx += 256) {
+  // Software pipeline (round 4): the halo slice and the filter rows used to be fetched global -> register -> LDS right where they were
+  // needed — per 64-channel slice four exposed memory round trips against ~2.4 us of MFMAs.  Now every fetch is ISSUED one phase early
+  // into registers (next filter row / next slice's halo + first row, before the current row's MFMAs) and only STORED to LDS where the
+  // old code fetched: same LDS image, same barriers, the latencies run under the matrix work.
+  constexpr int HN = (C::HALO_PIX * 8 + 255) / 256;     // 16-byte halo chunks per thread and slice
+  constexpr int WN = (C::WT_ROWS * 8 + 255) / 256;      // 16-byte filter chunks per thread and row
+  u32x4 hreg[HN], wreg[WN];
+  auto load_halo = [&](int kc0) {
+#pragma unroll
+    for (int it = 0; it < HN; ++it) {
+      const int idx = tid + it * 256;
       const int c = idx & 7;
       const int hp = idx >> 3;
       const int hy = hp / C::HW_;
@@ -109,34 +116,71 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
       const int gy = iy0 + hy, gx = ix0 + hx;
       const int ch = kc0 + c * 8;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_in && ch < p.cin) {
+      if (idx < C::HALO_PIX * 8 && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_in && ch < p.cin) {
         const size_t off = ((img_off + (size_t)gy * p.w_in + gx) * (size_t)p.ldx + ch) * sizeof(T);
         v = *reinterpret_cast<const u32x4*>(p.x + off);
       }
-      const int lp = C::lds_pix(hy, hx);
-      *reinterpret_cast<u32x4*>(halo + lp * 128 + ((c ^ (lp & 7)) << 4)) = v;
+      hreg[it] = v;
     }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int it = 0; it < HN; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < C::HALO_PIX * 8) {
+        const int c = idx & 7;
+        const int hp = idx >> 3;
+        const int hy = hp / C::HW_;
+        const int hx = hp - hy * C::HW_;
+        const int lp = C::lds_pix(hy, hx);
+        *reinterpret_cast<u32x4*>(halo + lp * 128 + ((c ^ (lp & 7)) << 4)) = hreg[it];
+      }
+    }
+  };
+  auto load_w = [&](int kc0, int ky) {
+#pragma unroll
+    for (int it = 0; it < WN; ++it) {
+      const int idx = tid + it * 256;
+      const int c = idx & 7;
+      const int row = idx >> 3;
+      const int kx = row / C::BN;
+      const int co = row - kx * C::BN;
+      const int gco = n0 + co;
+      const int ch = kc0 + c * 8;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (idx < C::WT_ROWS * 8 && gco < p.cout && ch < p.cin) {
+        const size_t off = (((size_t)gco * (KS * KS) + ky * KS + kx) * (size_t)p.cin + ch) * sizeof(T);
+        v = *reinterpret_cast<const u32x4*>(p.w + off);
+      }
+      wreg[it] = v;
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int it = 0; it < WN; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < C::WT_ROWS * 8) {
+        const int c = idx & 7;
+        const int row = idx >> 3;
+        const int co = row % C::BN;
+        *reinterpret_cast<u32x4*>(wts + row * 128 + ((c ^ (co & 7)) << 4)) = wreg[it];
+      }
+    }
+  };
+  load_w(0, 0);
+  for (int kc0 = 0; kc0 < p.cin; kc0 += 64) {
+    __syncthreads();   // previous slice's fragment reads are done
+    load_halo(kc0);
+    store_halo();      // this slice's halo: [HALO_PIX] x 64 channels, zero outside the image
     const int rem = p.cin - kc0;
     const int nks = rem >= 64 ? 2 : (rem + 31) / 32;
 
     for (int ky = 0; ky < KS; ++ky) {
       if (ky > 0) __syncthreads();   // previous filter row's fragment reads are done
-      // ---- stage one filter row: [KS taps][64 couts] x 64 channels -------------------------
-      for (int idx = tid; idx < C::WT_ROWS * 8; idx += 256) {
-        const int c = idx & 7;
-        const int row = idx >> 3;
-        const int kx = row / C::BN;
-        const int co = row - kx * C::BN;
-        const int gco = n0 + co;
-        const int ch = kc0 + c * 8;
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (gco < p.cout && ch < p.cin) {
-          const size_t off = (((size_t)gco * (KS * KS) + ky * KS + kx) * (size_t)p.cin + ch) * sizeof(T);
-          v = *reinterpret_cast<const u32x4*>(p.w + off);
-        }
-        *reinterpret_cast<u32x4*>(wts + row * 128 + ((c ^ (co & 7)) << 4)) = v;
-      }
+      store_w();                     // one filter row: [KS taps][64 couts] x 64 channels
       __syncthreads();
+      if (ky + 1 < KS) load_w(kc0, ky + 1);
+      else if (kc0 + 64 < p.cin) load_w(kc0 + 64, 0);
 
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
