@@ -104,36 +104,39 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
   // old code fetched: same LDS image, same barriers, the latencies run under the matrix work.
   constexpr int HN = (C::HALO_PIX * 8 + 255) / 256;     // 16-byte halo chunks per thread and slice
   constexpr int WN = (C::WT_ROWS * 8 + 255) / 256;      // 16-byte filter chunks per thread and row
-  u32x4 hreg[HN], wreg[WN];
-  auto load_halo = [&](int kc0) {
+  constexpr int HB = HN;                                // halo chunks in flight per batch: all of a slice (the stride-2 tile is LDS-limited to one workgroup per CU either way)
+  u32x4 wreg[WN];
+  auto stage_halo = [&](int kc0) {
 #pragma unroll
-    for (int it = 0; it < HN; ++it) {
-      const int idx = tid + it * 256;
-      const int c = idx & 7;
-      const int hp = idx >> 3;
-      const int hy = hp / C::HW_;
-      const int hx = hp - hy * C::HW_;
-      const int gy = iy0 + hy, gx = ix0 + hx;
-      const int ch = kc0 + c * 8;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (idx < C::HALO_PIX * 8 && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_in && ch < p.cin) {
-        const size_t off = ((img_off + (size_t)gy * p.w_in + gx) * (size_t)p.ldx + ch) * sizeof(T);
-        v = *reinterpret_cast<const u32x4*>(p.x + off);
-      }
-      hreg[it] = v;
-    }
-  };
-  auto store_halo = [&]() {
+    for (int b0 = 0; b0 < HN; b0 += HB) {
+      u32x4 hreg[HB];
 #pragma unroll
-    for (int it = 0; it < HN; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < C::HALO_PIX * 8) {
+      for (int j = 0; j < HB; ++j) {
+        const int idx = tid + (b0 + j) * 256;
         const int c = idx & 7;
         const int hp = idx >> 3;
         const int hy = hp / C::HW_;
         const int hx = hp - hy * C::HW_;
-        const int lp = C::lds_pix(hy, hx);
-        *reinterpret_cast<u32x4*>(halo + lp * 128 + ((c ^ (lp & 7)) << 4)) = hreg[it];
+        const int gy = iy0 + hy, gx = ix0 + hx;
+        const int ch = kc0 + c * 8;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (b0 + j < HN && idx < C::HALO_PIX * 8 && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_in && ch < p.cin) {
+          const size_t off = ((img_off + (size_t)gy * p.w_in + gx) * (size_t)p.ldx + ch) * sizeof(T);
+          v = *reinterpret_cast<const u32x4*>(p.x + off);
+        }
+        hreg[j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const int idx = tid + (b0 + j) * 256;
+        if (b0 + j < HN && idx < C::HALO_PIX * 8) {
+          const int c = idx & 7;
+          const int hp = idx >> 3;
+          const int hy = hp / C::HW_;
+          const int hx = hp - hy * C::HW_;
+          const int lp = C::lds_pix(hy, hx);
+          *reinterpret_cast<u32x4*>(halo + lp * 128 + ((c ^ (lp & 7)) << 4)) = hreg[j];
+        }
       }
     }
   };
@@ -170,8 +173,7 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_kernel(ConvParams p) {
   load_w(0, 0);
   for (int kc0 = 0; kc0 < p.cin; kc0 += 64) {
     __syncthreads();   // previous slice's fragment reads are done
-    load_halo(kc0);
-    store_halo();      // this slice's halo: [HALO_PIX] x 64 channels, zero outside the image
+    stage_halo(kc0);   // this slice's halo: [HALO_PIX] x 64 channels, zero outside the image
     const int rem = p.cin - kc0;
     const int nks = rem >= 64 ? 2 : (rem + 31) / 32;
 
