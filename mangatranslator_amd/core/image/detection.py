@@ -287,7 +287,10 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
         if remembered is not None:
             log_message("Using cached SAM masks", verbose=verbose)
             return remembered, text_free_boxes
-        processor, sam = manager.load_sam2(verbose=verbose)
+        if seg_model == "sam3":                 # reference :1661-1666; the loader raises here (SAM 3 is not built) and the page keeps its YOLO masks
+            processor, sam = manager.load_sam3(token=osb_text_hf_token, verbose=verbose)
+        else:
+            processor, sam = manager.load_sam2(verbose=verbose)
         prompts, owners = [], []
         for idx in simple_indices:
             prompts.append(primary_boxes[idx]); owners.append(idx)
@@ -314,7 +317,7 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
         cache.set_sam_masks(sam_key, detections)
         return detections, text_free_boxes
     except Exception as e:
-        log_message(f"SAM 2.1 segmentation failed: {e}. Falling back to YOLO segmentation masks.", always_print=True)
+        log_message(f"{'SAM 3' if seg_model == 'sam3' else 'SAM 2.1'} segmentation failed: {e}. Falling back to YOLO segmentation masks.", always_print=True)
         for sg in synthetic_groups:
             sg["parent_mask"] = None
         return assemble(None), text_free_boxes

@@ -24,7 +24,7 @@ import torch
 
 from ...utils.exceptions import ModelError
 from ...utils.logging import log_message
-from ..device import empty_cache, get_best_device, get_best_dtype
+from ..device import empty_cache, get_best_device, get_best_dtype, get_device_info
 
 
 class ModelType(Enum):
@@ -41,6 +41,13 @@ class ModelType(Enum):
     FLUX_KLEIN_4B_PIPELINE = "flux_klein_4b_pipeline"
     MANGA_OCR = "manga_ocr"
     PADDLE_OCR_VL = "paddle_ocr_vl"
+    # members the reference's callers name (:31-54) whose backends are not this build's: the slots exist so `is_loaded` / `unload_model` on
+    # them behave (never loaded), the nunchaku trio aliases the one native Kontext pipeline (`load_flux_models` below)
+    SAM3 = "sam3"
+    FLUX_TRANSFORMER = "flux_transformer"
+    FLUX_TEXT_ENCODER = "flux_text_encoder"
+    FLUX_PIPELINE = "flux_pipeline"
+    SDCPP_SERVER = "sdcpp_server"
 
 
 def _dist_on() -> bool:
@@ -222,6 +229,45 @@ class ModelManager:
 
     def unload_flux_kontext_sdnq_models(self, verbose: bool = False):
         self.unload_model(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE, verbose=verbose)
+
+    # the nunchaku / sd.cpp backend names of the reference's Kontext inpainter (core/image/inpainting.py:172-222, model_manager.py:1076-1174,
+    # :1436-1452): there is ONE Kontext implementation here, so they resolve to it instead of raising AttributeError under a caller that
+    # was configured for another backend
+    def set_flux_residual_diff_threshold(self, threshold: float):
+        """reference :1076-1082 — stored clamped to [0, 1] like there; the first-block cache it tunes is a nunchaku approximation that skips
+        denoising work, which this build never does (every step runs every block)"""
+        self.flux_residual_diff_threshold = max(0.0, min(1.0, float(threshold)))
+
+    def load_flux_models(self, verbose: bool = False):
+        """-> (transformer, text_encoder, pipeline) like reference :1084-1174; the native pipeline owns its transformer and works from exported
+        prompt embeddings, so the first two are None — what the reference's own SDNQ branch leaves them at (inpainting.py:186-187)"""
+        return None, None, self.load_flux_kontext_sdnq(verbose=verbose)
+
+    def unload_flux_kontext_models(self, verbose: bool = False):
+        self.unload_flux_kontext_sdnq_models(verbose=verbose)
+
+    def shutdown_sdcpp_server(self, name: Optional[str] = None, verbose: bool = False):
+        """no stable-diffusion.cpp server exists in this build; unload paths of the reference call this unconditionally (:1449, :1480)"""
+
+    def shutdown_sdcpp_servers(self, verbose: bool = False):
+        pass
+
+    def load_sam3(self, token: Optional[str] = None, verbose: bool = False):
+        """SAM 3 (`facebook/sam3`, gated; reference :1012-1046) is outside SURVEY §8 — fail the way a missing checkpoint does, so
+        `detect_speech_bubbles(seg_model="sam3")` degrades through its ModelError path instead of an AttributeError"""
+        raise ModelError("SAM 3 is not built in this package (SURVEY §8 a3 covers SAM 2.1); use seg_model='sam2'")
+
+    def get_memory_stats(self):
+        """reference :1495-1497"""
+        return get_device_info(self.device)
+
+    def print_memory_stats(self):
+        """reference :1499-1510 (which indexes `stats["memory"]` and so raises KeyError on a GPU; this one prints)"""
+        stats = self.get_memory_stats()
+        if stats.get("memory") == "N/A":
+            log_message(f"Device: {stats['device']}", always_print=True)
+        else:
+            log_message(f"GPU Memory - Allocated: {stats['allocated_gb']} GB, Reserved: {stats['reserved_gb']} GB", always_print=True)
 
     def unload_flux_klein_models(self, verbose: bool = False):
         """reference :1462-1480"""

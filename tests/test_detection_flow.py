@@ -116,3 +116,28 @@ def test_no_secondary_model_falls_back(monkeypatch, emu_lib):
     img = Image.fromarray(np.zeros((H, W, 3), np.uint8))
     dets, tf = detection.detect_speech_bubbles(Path("p.png"), image_override=img)
     assert len(dets) == 2 and tf == [] and all(d["sam_mask"].shape == (H, W) for d in dets)       # rect masks from the boxes
+
+
+def test_sam3_request_keeps_yolo_masks(monkeypatch, emu_lib):
+    """seg_model="sam3" asks the manager for SAM 3 (reference :1661-1666), never silently for SAM 2.1; this build's loader refuses and the
+    page keeps its YOLO / rectangle masks, the reference's own path when the gated checkpoint cannot be loaded"""
+    from mangatranslator_amd.utils.exceptions import ModelError
+    inp = GOLD["inputs"]
+    H, W = inp["H"], inp["W"]
+    pm = _Model(types.SimpleNamespace(boxes=_Boxes(inp["primary"][:2], inp["pconf"][:2], [0, 0]), masks=None, orig_shape=(H, W)), {0: "speech_bubble"})
+    asked = []
+
+    def boom(*a, **k):
+        raise RuntimeError("not staged")
+
+    def sam3(token=None, verbose=False):
+        asked.append(token)
+        raise ModelError("SAM 3 is not built")
+
+    def sam2(*a, **k):
+        raise AssertionError("SAM 2.1 must not stand in for SAM 3")
+    mgr = types.SimpleNamespace(load_yolo_speech_bubble=lambda *a, **k: pm, load_rtdetr_conjoined_bubble=boom, load_sam2=sam2, load_sam3=sam3, device="cpu")
+    monkeypatch.setattr(detection, "get_model_manager", lambda: mgr)
+    img = Image.fromarray(np.full((H, W, 3), 7, np.uint8))
+    dets, _ = detection.detect_speech_bubbles(Path("p3.png"), image_override=img, seg_model="sam3", osb_text_hf_token="tok")
+    assert asked == ["tok"] and len(dets) == 2 and all(d["sam_mask"].shape == (H, W) for d in dets)

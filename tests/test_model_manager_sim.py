@@ -37,6 +37,26 @@ def test_singleton_and_missing_checkpoint(manager):
     assert manager.load_flux_kontext_sdnq() is None      # nothing staged: inpainter skips, as the reference does
 
 
+def test_other_backend_names_resolve_to_the_native_pipeline(manager):
+    """callers configured for the reference's nunchaku / sd.cpp Kontext backends and for SAM 3 (inpainting.py:172-222, detection.py:1661-1666)
+    meet methods, not AttributeErrors: the nunchaku trio is the one native pipeline, SAM 3 refuses with ModelError"""
+    from mangatranslator_amd.core.ml.model_manager import ModelType
+    from mangatranslator_amd.utils.exceptions import ModelError
+    manager.set_flux_residual_diff_threshold(1.7)
+    assert manager.flux_residual_diff_threshold == 1.0
+    assert manager.load_flux_models() == (None, None, None)            # nothing staged: same "no pipeline" answer as the SDNQ loader
+    manager.unload_flux_kontext_models(); manager.shutdown_sdcpp_server("flux_kontext"); manager.shutdown_sdcpp_servers()
+    with pytest.raises(ModelError):
+        manager.load_sam3(token="x")
+    for name in ("SAM3", "FLUX_TRANSFORMER", "FLUX_TEXT_ENCODER", "FLUX_PIPELINE", "SDCPP_SERVER"):
+        assert not manager.is_loaded(ModelType[name])
+    stats = manager.get_memory_stats()
+    assert stats == {"device": "cpu", "memory": "N/A"}
+    manager.print_memory_stats()
+    from mangatranslator_amd.core.device import is_gpu_available
+    assert is_gpu_available() is torch.cuda.is_available()
+
+
 def test_load_upscale_and_unload(manager):
     sd = make_state_dict(n_feats=32, n_resgroups=1, n_resblocks=1, seed=3)
     p = manager.model_paths[list(manager.model_paths)[0]]
