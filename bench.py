@@ -444,10 +444,17 @@ def main():
     seg_in_b = (yolo is not None and sam is not None and inpainter is None and upscaler is None and clean_args is None
                 and not args.no_overlap and not args.serial_detectors)
 
+    import threading as _threading
+    harness_slot = _threading.local()       # set by the batch harness (front_context): the instance set this thread's front half holds
+
+    def front_set_of(i):
+        slot = getattr(harness_slot, "slot", None)
+        return slot if slot is not None else i % n_front
+
     def stage_a(i):
         """front half of page i: the stages whose host share is large (NMS, prompt handling, OSB region logic)"""
         k = i % pool
-        fs = front_sets[i % n_front]
+        fs = front_sets[front_set_of(i)]
         yolo, aux_detectors, rtdetr, sam = fs["yolo"], fs["aux"], fs["rtdetr"], fs["sam"]
         stage_memo.reset()        # the operators remember results per (pixels, settings); the pool repeats pages, and no step may be served from memory
         tl = time.perf_counter()
@@ -495,7 +502,7 @@ def main():
         k = i % pool
         tl = time.perf_counter()
         if seg_in_b:
-            outs["segment"] = front_sets[i % n_front]["sam"].segment(pages[k], page_boxes[k], ticket=work_[1])
+            outs["segment"] = front_sets[front_set_of(i)]["sam"].segment(pages[k], page_boxes[k], ticket=work_[1])
             tl = lap("segment", tl)
             return
         if inpainter is not None:
@@ -592,9 +599,15 @@ def main():
             page_pil[k] = rgb
             return i, page, stage_a(i)
 
+        def io_front_whole(page, path):          # detect + segment only: the product's front half holds both stages (core/pipeline.py
+            i, page, work_ = io_front(page, path)       # process_page_vision_front), pages overlap through front_workers instead
+            stage_b(i, work_)
+            return i, page, None
+
         def io_back(state):
             i, page, work_ = state
-            stage_b(i, work_)
+            if not seg_in_b:
+                stage_b(i, work_)
             if "upscale" in outs:
                 return Image.fromarray(outs["upscale"].cpu().numpy())
             if "inpaint" in outs:
@@ -602,8 +615,19 @@ def main():
             return page
 
         # two pages in flight inside the harness too (core/pipeline.py, round 4) when the plain line runs that way and the pool has a slot per page in flight
-        io_pipelined = overlap and pool >= 2 and not seg_in_b
-        io_kw = dict(process_front=io_front, process_back=io_back) if io_pipelined else dict(process_image=lambda page, path: io_back(io_front(page, path)))
+        import contextlib
+
+        @contextlib.contextmanager
+        def io_slot(slot):
+            harness_slot.slot = slot
+            try:
+                yield
+            finally:
+                harness_slot.slot = None
+
+        io_pipelined = overlap and pool >= 2
+        io_kw = (dict(process_front=io_front_whole if seg_in_b else io_front, process_back=io_back, front_workers=n_front, front_context=io_slot) if io_pipelined
+                 else dict(process_image=lambda page, path: io_back((io_front_whole if seg_in_b else io_front)(page, path))))
 
         io_cfg = _t.SimpleNamespace(verbose=False, output=_t.SimpleNamespace(output_format="png", jpeg_quality=95, png_compression=2))
         h0, c0 = UnifiedCache.hash_seconds, UnifiedCache.hash_calls
@@ -621,8 +645,9 @@ def main():
                     "gpu_wait_for_decode_ms_per_page": round(1e3 * io_.get("gpu_wait_for_decode_s", 0.0) / max(1, n_io), 2),
                     "wait_for_save_slot_ms_per_page": round(1e3 * io_.get("wait_for_save_slot_s", 0.0) / max(1, n_io), 2), "max_pending_saves": io_.get("max_pending_saves"),
                     "input": f"{n_io} PNG files ({W_}x{H_}, compress_level 1)", "output": f"PNG, native writer (csrc/host_png.cpp: reductions + per-row filters + {io_threads and 8}-stripe parallel deflate, zlib level 6; oxipng absent), {out_bytes / max(1, n_io) / 1e6:.2f} MB per page",
-                    "note": ("two pages in flight inside the harness (core/pipeline.py batch_process_images(process_front=, process_back=))" if io_pipelined else
-                             "pages go through the stages one at a time here (both halves of this stage set are front halves: nothing to overlap)")}
+                    "front_workers": n_front if io_pipelined else 1,
+                    "note": (f"{io_.get('pages_in_flight', 2)} pages in flight inside the harness (core/pipeline.py batch_process_images(process_front=, process_back=, "
+                             f"front_workers={n_front}))" if io_pipelined else "pages go through the stages one at a time here")}
         if rank == 0:
             shutil.rmtree(tmp, ignore_errors=True)
     if dist is not None:

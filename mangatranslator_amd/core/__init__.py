@@ -14,8 +14,8 @@ from .image.image_utils import cv2_to_pil, pil_to_cv2, save_image_with_compressi
 from .image.inpainting import FluxKleinInpainter, FluxKontextInpainter  # noqa: F401
 from .image.ocr_detection import OutsideTextDetector  # noqa: F401
 from .ml.model_manager import ModelManager, get_model_manager  # noqa: F401
-from .pipeline import batch_process_images, process_page_vision  # noqa: F401
+from .pipeline import batch_process_images, batch_vision_images, process_page_vision  # noqa: F401
 
 __all__ = ["__version__", "__version_info__", "get_cache", "UnifiedCache", "detect_speech_bubbles", "clean_speech_bubbles", "pil_to_cv2",
            "cv2_to_pil", "save_image_with_compression", "get_model_manager", "ModelManager", "OutsideTextDetector", "FluxKontextInpainter",
-           "FluxKleinInpainter", "process_page_vision", "batch_process_images"]
+           "FluxKleinInpainter", "process_page_vision", "batch_process_images", "batch_vision_images"]

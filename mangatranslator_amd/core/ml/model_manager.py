@@ -192,11 +192,43 @@ class ModelManager:
             self.hf_token = None
             self.flux_hf_token = None
             self.flux_inference_lock = threading.Lock()
+            self._tls = threading.local()           # .replica: which instance set of the front-half models this thread is served from
             self._initialized = True
             log_message(f"Model Manager initialized on device: {self.device}", always_print=True)
 
+    # ---- front-half replicas (round 4) ----------------------------------------------------------------
+    # A model's plan owns ONE set of activation buffers and one stream, so two pages cannot be inside the same detector or SAM instance at
+    # once.  `with manager.front_replica(i):` makes the loaders of the front-half models (FRONT_MODEL_TYPES: the four detectors and SAM)
+    # hand this thread instance set i — built on first use from the same checkpoint files, < 2 GB of HBM per set — so that
+    # `batch_process_images(front_workers=N)` can run N pages' detect stages at once (core/pipeline.py; what `bench.py --front-replicas`
+    # measures: config 2 33 -> 37 pages/s with sixteen hardware queues).  Set 0 is the plain slot the reference's callers know; every other
+    # model type ignores the setting.
+    FRONT_MODEL_TYPES = frozenset({ModelType.YOLO_SPEECH_BUBBLE, ModelType.YOLO_SPEECH_BUBBLE_2, ModelType.RTDETR_CONJOINED_BUBBLE,
+                                   ModelType.YOLO_OSBTEXT, ModelType.YOLO_PANEL, ModelType.SAM2})
+
+    def front_replica(self, index: int):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            before = getattr(self._tls, "replica", 0)
+            self._tls.replica = max(0, int(index))
+            try:
+                yield self
+            finally:
+                self._tls.replica = before
+        return scope()
+
+    def current_front_replica(self) -> int:
+        return getattr(self._tls, "replica", 0)
+
+    def _slot(self, model_type: ModelType):
+        """key of `self.models` this thread's loader call uses"""
+        r = self.current_front_replica()
+        return (model_type, r) if r and model_type in self.FRONT_MODEL_TYPES else model_type
+
     # ---- bookkeeping -------------------------------------------------------------------------------
-    def is_loaded(self, model_type: ModelType) -> bool:
+    def is_loaded(self, model_type) -> bool:
         with self._lock:
             return self.models.get(model_type) is not None
 
@@ -211,10 +243,13 @@ class ModelManager:
 
     def unload_model(self, model_type: ModelType, force_gc: bool = True, verbose: bool = False):
         with self._lock:
-            if not self.is_loaded(model_type):
+            replicas = [k for k in self.models if isinstance(k, tuple) and k[0] == model_type]      # its front-half replicas go with it
+            if not self.is_loaded(model_type) and not replicas:
                 return
             log_message(f"Unloading {model_type.value}...", verbose=verbose)
             self.models[model_type] = None
+            for key in replicas:
+                del self.models[key]
             if force_gc:
                 empty_cache(self.device)
 
@@ -275,16 +310,19 @@ class ModelManager:
         self.unload_model(ModelType.FLUX_KLEIN_4B_PIPELINE, force_gc=True, verbose=verbose)
 
     # ---- loaders -----------------------------------------------------------------------------------
-    def _read_safetensors(self, path: Path) -> dict:
+    def _read_safetensors(self, path: Path, local: bool = False) -> dict:
         """the tensors of a checkpoint (see `_read_safetensors_with_metadata`)"""
-        return self._read_safetensors_with_metadata(path)[0]
+        return self._read_safetensors_with_metadata(path, local)[0]
 
-    def _read_safetensors_with_metadata(self, path: Path):
+    def _read_safetensors_with_metadata(self, path: Path, local: bool = False):
         """(tensors, header metadata): rank 0 reads, then (with several ranks) a status broadcast, a shape / dtype / metadata broadcast
         and one flat broadcast per dtype; a missing or unreadable file raises ModelError on EVERY rank.  The metadata travels WITH the
-        state dict it describes — nothing is remembered on the manager between reads."""
+        state dict it describes — nothing is remembered on the manager between reads.
+        `local`: this rank reads for itself and no collective is issued — front-half replicas (`front_replica`) are built lazily from
+        worker threads, where the ranks' calls cannot be kept in one order; their checkpoint has been read once through the collective
+        path already (set 0), the ranks of a node share the filesystem."""
         import torch.distributed as dist
-        rank0 = not _dist_on() or dist.get_rank() == 0
+        rank0 = local or not _dist_on() or dist.get_rank() == 0
         sd, error, metadata = None, None, {}
         if rank0:
             # detector checkpoints: the ultralytics `.pt` the reference downloads (read without ultralytics and without executing the
@@ -306,6 +344,10 @@ class ModelManager:
                             metadata = dict(f.metadata() or {})
                 except Exception as e:                      # truncated / foreign file
                     error = f"cannot read {found}: {e}"
+        if local:
+            if error:
+                raise ModelError(error)
+            return sd, metadata
         broadcast_status(error)
         if _dist_on():
             meta = [{k: (tuple(v.shape), v.dtype) for k, v in sd.items()}, metadata] if rank0 else [None, None]
@@ -375,11 +417,12 @@ class ModelManager:
         ultralytics `.pt` (read pickle-free, core/ml/ultralytics_pt.py) or its safetensors export (tools/export_ultralytics_state_dict.py)."""
         with self._lock:
             mt, path = self._resolve_speech_bubble_model(model_path)
-            if self.is_loaded(mt):
-                return self.models[mt]
-            sd, md = self._read_safetensors_with_metadata(path)
+            slot = self._slot(mt)
+            if self.is_loaded(slot):
+                return self.models[slot]
+            sd, md = self._read_safetensors_with_metadata(path, local=slot is not mt)
             model = self._detector_from_state_dict(sd, {0: "speech_bubble"}, md)        # yolo_1 is a YOLOv8m-seg, the default yolo_2 a YOLO11-seg
-            self.models[mt] = model
+            self.models[slot] = model
             log_message(f"YOLO bubble detector loaded ({mt.value}).", verbose=verbose)
             return model
 
@@ -388,7 +431,10 @@ class ModelManager:
         log_message("Unloading all models...", verbose=verbose)
         with self._lock:
             for model_type in list(self.models):
-                self.models[model_type] = None
+                if isinstance(model_type, tuple):
+                    del self.models[model_type]
+                else:
+                    self.models[model_type] = None
         self.clear_cache()
         log_message("All models unloaded.", verbose=verbose)
 
@@ -398,16 +444,17 @@ class ModelManager:
         `detect_outside_text` falls back to the secondary detector's text_free boxes (ocr_detection.py:447-468) and
         `detect_speech_bubbles` skips OSB text verification (detection.py:196-198)."""
         with self._lock:
-            if self.is_loaded(ModelType.YOLO_OSBTEXT):
-                return self.models[ModelType.YOLO_OSBTEXT]
+            slot = self._slot(ModelType.YOLO_OSBTEXT)
+            if self.is_loaded(slot):
+                return self.models[slot]
             try:
-                sd, md = self._read_safetensors_with_metadata(self.model_paths[ModelType.YOLO_OSBTEXT])
+                sd, md = self._read_safetensors_with_metadata(self.model_paths[ModelType.YOLO_OSBTEXT], local=slot is not ModelType.YOLO_OSBTEXT)
                 model = self._detector_from_state_dict(sd, {0: "text"}, md)
             except ModelError:
                 raise
             except Exception as e:
                 raise ModelError(f"Failed to load OSB Text model: {e}") from e
-            self.models[ModelType.YOLO_OSBTEXT] = model
+            self.models[slot] = model
             log_message("OSB text detector loaded.", verbose=verbose)
             return model
 
@@ -415,16 +462,17 @@ class ModelManager:
         """Panel detector (YOLO11-L, reference :810-838) as a libmtx_hip graph (core/ml/yolo11.py); ModelError when the checkpoint is not
         staged, which `detect_panels` passes on and the page flow turns into "Panel detection failed ... Using global sorting"."""
         with self._lock:
-            if self.is_loaded(ModelType.YOLO_PANEL):
-                return self.models[ModelType.YOLO_PANEL]
+            slot = self._slot(ModelType.YOLO_PANEL)
+            if self.is_loaded(slot):
+                return self.models[slot]
             try:
-                sd, md = self._read_safetensors_with_metadata(self.model_paths[ModelType.YOLO_PANEL])
+                sd, md = self._read_safetensors_with_metadata(self.model_paths[ModelType.YOLO_PANEL], local=slot is not ModelType.YOLO_PANEL)
                 model = self._detector_from_state_dict(sd, {0: "frame"}, md)
             except ModelError:
                 raise
             except Exception as e:
                 raise ModelError(f"Failed to load panel detection model: {e}") from e
-            self.models[ModelType.YOLO_PANEL] = model
+            self.models[slot] = model
             log_message("Panel detector loaded.", verbose=verbose)
             return model
 
@@ -449,36 +497,45 @@ class ModelManager:
         (reference :745-778; core/ml/rtdetr_adapter.py).  Expects the HF repo layout (config.json + model.safetensors)."""
         mt = ModelType.RTDETR_CONJOINED_BUBBLE
         with self._lock:
-            if self.is_loaded(mt):
-                return self.models[mt]
+            slot = self._slot(mt)
+            if self.is_loaded(slot):
+                return self.models[slot]
             from .rtdetr import RTDetrHip
             root = self.model_paths[mt]
-            self._staged(root / "config.json", "RT-DETR config")
+            if slot is mt:
+                self._staged(root / "config.json", "RT-DETR config")
             try:
                 from transformers import RTDetrV2Config
                 config = RTDetrV2Config.from_pretrained(str(root))
-                sd = self._read_safetensors(root / "model.safetensors")
+                sd = self._read_safetensors(root / "model.safetensors", local=slot is not mt)
                 model = RTDetrHip(sd, config, device=self.device, names=getattr(config, "id2label", None))
             except ModelError:
                 raise
             except Exception as e:
                 raise ModelError(f"Failed to load RT-DETR conjoined model: {e}") from e
-            self.models[mt] = model
+            self.models[slot] = model
             log_message("RT-DETR conjoined bubble model loaded.", verbose=verbose)
             return model
 
     def load_sam2(self, verbose: bool = False):
         """-> (processor, model) like the reference (:982-1010), backed by the HIP graph."""
         with self._lock:
-            if self.is_loaded(ModelType.SAM2):
-                return self.models[ModelType.SAM2]
+            slot = self._slot(ModelType.SAM2)
+            if self.is_loaded(slot):
+                return self.models[slot]
             from .sam2 import Sam2Hip
             root = self.model_paths[ModelType.SAM2]
             weights, cfg = root / "model.safetensors", root / "config.json"
-            self._staged(cfg, "SAM-2.1 config")
+            if slot is ModelType.SAM2:
+                self._staged(cfg, "SAM-2.1 config")
             from transformers import Sam2Config
             config = Sam2Config.from_pretrained(str(root))
-            sd = self._read_safetensors(weights)
+            sd = self._read_safetensors(weights, local=slot is not ModelType.SAM2)
+            if slot is not ModelType.SAM2 and self.is_loaded(ModelType.SAM2):
+                # a replica takes the storage type set 0 settled on (its probe compared the two): one more model, no second probe
+                hip = Sam2Hip(sd, config, device=self.device, dtype=self.models[ModelType.SAM2][1].hip.dtype)
+                self.models[slot] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
+                return self.models[slot]
             # f16 storage (8x smaller logit error than bf16 against the fp32 reference: the `> 0` masks are what the page flow keeps)
             # unless the checkpoint leaves the f16 range: then the two models disagree grossly on the load-time probe and bf16 — the
             # reference's own GPU dtype — is kept
@@ -492,9 +549,9 @@ class ModelManager:
             else:
                 log_message(f"SAM 2.1: f16 storage disagrees with bf16 on the probe page ({gap:.2f} of the logit range): using bf16", always_print=True)
             del hip16
-            self.models[ModelType.SAM2] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
+            self.models[slot] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
             log_message("SAM 2.1 model loaded.", verbose=verbose)
-            return self.models[ModelType.SAM2]
+            return self.models[slot]
 
     def load_flux_kontext_sdnq(self, low_vram: bool = False, verbose: bool = False):
         """FLUX.1-Kontext as libmtx_hip graphs behind the diffusers call shape (reference :1176-1252).

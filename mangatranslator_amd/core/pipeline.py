@@ -123,7 +123,8 @@ def load_page(img_path: Path, output_format: str):
 
 def batch_process_images(input_dir, config, output_dir=None, preserve_structure: bool = False,
                          process_image: Optional[Callable] = None, io_threads: int = 2,
-                         process_front: Optional[Callable] = None, process_back: Optional[Callable] = None) -> Dict:
+                         process_front: Optional[Callable] = None, process_back: Optional[Callable] = None,
+                         front_workers: int = 1, front_context: Optional[Callable] = None) -> Dict:
     """The vision half of `batch_translate_images` (core/pipeline.py:2481-2733) on one GPU or page-sharded over the ranks of the
     initialised process group: same page list and order, same output naming (`_resolve_output_path`), same results dict
     (`success_count`, `error_count`, `errors` keyed by the display path, `failed_image_paths` absolute, `failed_paths_file`), a bad
@@ -136,11 +137,23 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
     `process_image`, page i + 1's front half (detect / segment / OSB prepare: host-heavy, small GPU graphs on the models' own streams) runs
     on a worker thread beside page i's back half (diffusion, upscaling, cleaning: GPU-bound) — `process_page_vision_front` /
     `process_page_vision_back` below are that pair.  Pages still complete, are saved and are reported in batch order; a page whose front
-    or back half raises is recorded as failed exactly like a failing `process_image`, and the pages around it are not affected."""
+    or back half raises is recorded as failed exactly like a failing `process_image`, and the pages around it are not affected.
+    **`front_workers` = N > 1**: N front halves run at once (pages i + 1 .. i + N beside page i's back half), each holding one of N
+    slots for its duration; `front_context(slot)` is entered around the front half — by default `ModelManager.front_replica(slot)`, which
+    serves the detectors and SAM from instance set `slot` (a model instance holds one page at a time).  Pays off for stage sets whose back
+    half is short (detect / clean only: the 640-pixel detector graphs do not fill the chip) and needs `GPU_MAX_HW_QUEUES=16` in the
+    environment — two pages' model streams on ROCm's default four hardware queues run slower than one page."""
     from .image.image_utils import save_image_with_compression
     if (process_front is None) != (process_back is None):
         raise ValueError("process_front and process_back come as a pair")
     pipelined = process_front is not None
+    front_workers = max(1, int(front_workers)) if pipelined else 1
+    if front_workers > 1 and front_context is None:
+        from .ml.model_manager import get_model_manager
+        front_context = get_model_manager().front_replica
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+            log_message("front_workers > 1 without GPU_MAX_HW_QUEUES=16 in the environment: two pages' model streams will share the "
+                        "runtime's default hardware queues (expect no gain)", always_print=True)
     import torch.distributed as dist
     empty = {"success_count": 0, "error_count": 0, "errors": {}, "failed_image_paths": []}
     input_dir = Path(input_dir)
@@ -170,7 +183,7 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
             local["failed_image_paths"].append(str(img_path))
 
     io = {"decode_s": 0.0, "encode_s": 0.0, "gpu_wait_for_decode_s": 0.0, "wait_for_save_slot_s": 0.0, "process_s": 0.0, "pages": 0,
-          "max_pending_saves": 0, "front_s": 0.0, "back_s": 0.0, "pages_in_flight": 2 if pipelined else 1}
+          "max_pending_saves": 0, "front_s": 0.0, "back_s": 0.0, "pages_in_flight": 1 + front_workers if pipelined else 1}
     io_lock = threading.Lock()
 
     def timed(key, fn, *a):
@@ -189,25 +202,47 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
         except Exception as e:      # noqa: BLE001
             fail(img_path, error_key, e)
 
+    import contextlib
+    import queue
+    free_slots = queue.SimpleQueue()               # a front half holds one slot (= one instance set of the front-half models) while it runs
+    for slot in range(front_workers):
+        free_slots.put(slot)
+
     def front_task(i):
         """decoded page i through the front half (worker thread); what it returns or raises belongs to page i"""
         t = time.perf_counter()
         page = decodes.pop(i).result()
         t1 = time.perf_counter()
-        state = process_front(page, mine[i])
+        slot = free_slots.get()
+        try:
+            with (front_context(slot) if front_context is not None else contextlib.nullcontext()):
+                state = process_front(page, mine[i])
+        finally:
+            free_slots.put(slot)
         with io_lock:
             io["gpu_wait_for_decode_s"] += t1 - t
             io["front_s"] += time.perf_counter() - t1
         return state
 
+    queued_fronts = 0
+
+    def queue_fronts(upto):
+        """front halves of the pages below `upto` are queued (each exactly once, in page order)"""
+        nonlocal queued_fronts
+        while queued_fronts < min(upto, len(mine)):
+            fronts[queued_fronts] = front_pool.submit(front_task, queued_fronts)
+            queued_fronts += 1
+
     # decoders and encoders do not share a queue: the next page's decode must never wait behind the finished pages' (much slower) PNG encodes
     with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool, ThreadPoolExecutor(max_workers=max(1, io_threads)) as enc_pool, \
-            ThreadPoolExecutor(max_workers=1) as front_pool:
-        ahead = max(1, io_threads)
+            ThreadPoolExecutor(max_workers=front_workers) as front_pool:
+        ahead = max(1, io_threads, front_workers)
         max_pending = 2 * max(1, io_threads)       # finished pages waiting for a codec thread: a 4096x6144 RGBA page is 100 MB, and PNG
         decodes = {i: pool.submit(timed, "decode_s", load_page, mine[i], fmt) for i in range(min(ahead, len(mine)))}      # encoding is slower than the GPU
         saves = deque()
-        fronts = {0: front_pool.submit(front_task, 0)} if pipelined and mine else {}
+        fronts = {}
+        if pipelined:
+            queue_fronts(front_workers)
         for i, img_path in enumerate(mine):
             if i + ahead < len(mine):
                 decodes[i + ahead] = pool.submit(timed, "decode_s", load_page, mine[i + ahead], fmt)
@@ -217,10 +252,8 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
                 log_message(f"Processing {rank + i * world + 1}/{len(files)}: {display}", always_print=True)
                 t = time.perf_counter()
                 if pipelined:
-                    fut = fronts.pop(i)
-                    if i + 1 < len(mine):          # the next page's front half starts before this page's back half
-                        fronts[i + 1] = front_pool.submit(front_task, i + 1)
-                    state = fut.result()
+                    queue_fronts(i + 1 + front_workers)      # the next pages' front halves start before this page's back half
+                    state = fronts.pop(i).result()
                     t1 = time.perf_counter()
                     result = process_back(state)
                     t2 = time.perf_counter()
@@ -242,8 +275,9 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
                 io["max_pending_saves"] = max(io["max_pending_saves"], len(saves))
             except Exception as e:      # noqa: BLE001 — a bad page must not stop the batch
                 decodes.pop(i, None)
-                if pipelined and i + 1 < len(mine) and i + 1 not in fronts:      # this page failed before the next front half was queued
-                    fronts[i + 1] = front_pool.submit(front_task, i + 1)
+                if pipelined:                       # this page may have failed before the next front halves were queued
+                    fronts.pop(i, None)
+                    queue_fronts(i + 1 + front_workers)
                 fail(img_path, error_key, e)
         while saves:
             settle(saves.popleft())
@@ -397,3 +431,39 @@ def process_page_vision_back(state: Dict):
         if page.mode != target_mode:
             page = page.convert(target_mode)
     return page, info
+
+
+_PIL_FORMAT_BY_SUFFIX = {".png": "PNG", ".jpg": "JPEG", ".jpeg": "JPEG", ".webp": "WEBP", ".bmp": "BMP", ".tif": "TIFF", ".tiff": "TIFF", ".gif": "GIF"}
+
+
+def default_front_workers(config) -> int:
+    """front halves a batch keeps in flight beside the running back half: 2 for configurations whose back half is short — no FLUX inpainting
+    of outside text, no final upscale: then the page's time is its detect stage, whose graphs do not fill the chip (two pages' detect stages
+    at once: config 2 33 -> 37 pages/s) — and only when the process was started with `GPU_MAX_HW_QUEUES` >= 16 (on the
+    runtime's default four queues two pages' ten model streams run SLOWER than one page's five); 1 otherwise"""
+    osb = getattr(config, "outside_text", None)
+    heavy_back = bool(getattr(osb, "enabled", False)) or bool(getattr(getattr(config, "output", None), "upscale_final_image", False))
+    try:
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+    except ValueError:
+        queues = 4
+    return 1 if heavy_back or queues < 16 else 2
+
+
+def batch_vision_images(input_dir, config, output_dir=None, preserve_structure: bool = False, io_threads: int = 2,
+                        front_workers: Optional[int] = None) -> Dict:
+    """The page stack of this package behind the batch harness — what the reference's `batch_translate_images` does with
+    `cleaning_only` pages (core/pipeline.py:2481-2733 around `translate_and_render`, :638-1000): every image of `input_dir` through
+    `process_page_vision`, page i + 1's front half (and, with `front_workers` > 1, the following pages' on further instance sets of the
+    detectors and SAM) beside page i's back half; same files, order and results dict as the sequential loop."""
+    verbose = bool(getattr(config, "verbose", False))
+
+    def front(page, path):
+        return process_page_vision_front(page, config, path, _PIL_FORMAT_BY_SUFFIX.get(Path(path).suffix.lower()), verbose)
+
+    def back(state):
+        return process_page_vision_back(state)[0]
+
+    n = default_front_workers(config) if front_workers is None else max(1, int(front_workers))
+    return batch_process_images(input_dir, config, output_dir, preserve_structure, io_threads=io_threads, process_front=front, process_back=back,
+                                front_workers=n)

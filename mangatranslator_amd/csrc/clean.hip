@@ -176,7 +176,7 @@ int clean_launch(const mtx_clean_args* a, void* stream, const char** err) {
 #ifdef MTX_EMU
   memset(a->stats, 0, (size_t)a->n * 260 * sizeof(int));
 #else
-  if (hipMemsetAsync(a->stats, 0, (size_t)a->n * 260 * sizeof(int), (hipStream_t)stream) != hipSuccess) { *err = "bubble_clean: memset failed"; return MTX_ERR_HIP; }
+  zero_words_async(a->stats, (size_t)a->n * 260 * sizeof(int), stream);        // a kernel, not a memset node (mtx_device.h)
 #endif
   const dim3 grid((unsigned)((a->max_pixels + 255) / 256), (unsigned)a->n), small((unsigned)((a->n + 63) / 64));
   MTX_LAUNCH(clean_morph_kernel, grid, dim3(256), 0, stream, *a);

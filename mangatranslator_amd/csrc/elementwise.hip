@@ -838,7 +838,7 @@ __global__ __launch_bounds__(64) void mask_pick_kernel(mtx_mask_select_args p) {
 int mask_select_launch(const mtx_mask_select_args* a, void* stream, const char** err) {
   if (!a->logits || !a->iou || !a->counts || !a->sel) { *err = "mask_select: null operand"; return MTX_ERR_INVALID; }
   if (a->n < 1 || a->pix < 1) return MTX_OK;
-  if (hipMemsetAsync(a->counts, 0, (size_t)a->n * 2 * sizeof(int), (hipStream_t)stream) != hipSuccess) { *err = "mask_select: memset failed"; return MTX_ERR_HIP; }
+  zero_words_async(a->counts, (size_t)a->n * 2 * sizeof(int), stream);        // a kernel, not a memset node (mtx_device.h)
   long bx = (a->pix + 255) / 256; if (bx > 64) bx = 64;
   MTX_LAUNCH(mask_count_kernel, dim3((unsigned)bx, (unsigned)a->n), dim3(256), 0, stream, *a);
   MTX_LAUNCH(mask_pick_kernel, dim3((unsigned)((a->n + 63) / 64)), dim3(64), 0, stream, *a);

@@ -407,4 +407,19 @@ __device__ __forceinline__ void buf_load16_lds(const BufView& b, unsigned voff, 
 #endif
 }
 
+// Zero fill as a KERNEL.  Launchers that need a cleared accumulator in front of an atomics pass (mask_select's pixel counts, GroupNorm's
+// channel sums, the cleaning statistics) used hipMemsetAsync; captured into a hipGraph that became a memset node, and on ROCm 7.2 / gfx950
+// replays of the SAM decoder graph left counts of a 184-byte fill (23 boxes x 2 ints — not a multiple of 16 bytes) uncleared now and then:
+// the stability-based mask choice of a box changed between identical calls (round 4, tools/diag_sam_repeat.py; eager launches and a
+// 224-byte fill were stable).  A kernel node has no such special cases.
+static __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* p, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0u;
+}
+static inline void zero_words_async(void* p, size_t bytes, void* stream) {      // bytes: a multiple of 4
+  const long n = (long)(bytes / 4);
+  if (n <= 0) return;
+  long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  MTX_LAUNCH(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<unsigned*>(p), n);
+}
+
 }  // namespace mtx

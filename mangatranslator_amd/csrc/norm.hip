@@ -211,7 +211,7 @@ int groupnorm_launch(const mtx_groupnorm_args* a, void* stream, const char** err
     *err = "groupnorm: C/8 must divide 256 and groups must divide C"; return MTX_ERR_INVALID;
   }
   if (a->n < 1 || a->hw < 1) return MTX_OK;
-  if (hipMemsetAsync(a->workspace, 0, (size_t)a->n * a->c * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) { *err = "groupnorm: memset failed"; return MTX_ERR_HIP; }
+  zero_words_async(a->workspace, (size_t)a->n * a->c * 2 * sizeof(float), stream);        // a kernel, not a memset node (mtx_device.h)
   const int ppb = 1024;
   dim3 g1((unsigned)((a->hw + ppb - 1) / ppb), (unsigned)a->n);
   long tot = a->n * a->hw * C8;

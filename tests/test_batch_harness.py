@@ -210,3 +210,69 @@ def test_two_pages_in_flight_give_the_sequential_results(tmp_path):
     with pytest.raises(ValueError):
         batch_process_images(root, _cfg("png"), tmp_path / "o", process_front=front)
     assert main == threading.get_ident()
+
+
+def test_several_front_halves_in_flight(tmp_path):
+    """`front_workers=3`: up to three front halves run at once, each inside `front_context(slot)` with a slot no other running front half
+    holds; files, order, failures equal the sequential run's; with slow front halves the wall clock shows the overlap"""
+    import contextlib
+    import threading
+    import time
+    from mangatranslator_amd.core.pipeline import batch_process_images
+    root = tmp_path / "in"
+    root.mkdir()
+    n = 10
+    for i in range(n):
+        Image.new("RGB", (16, 12), (10 * i, 20, 30)).save(root / f"p{i:02d}.png")
+    lock = threading.Lock()
+    tls = threading.local()
+    held, peak, slots_seen, clashes = set(), [0], set(), []
+
+    @contextlib.contextmanager
+    def ctx(slot):
+        with lock:
+            if slot in held:
+                clashes.append(slot)
+            held.add(slot)
+            slots_seen.add(slot)
+            peak[0] = max(peak[0], len(held))
+        tls.slot = slot
+        try:
+            yield
+        finally:
+            tls.slot = None
+            with lock:
+                held.discard(slot)
+
+    def front(page, path):
+        i = int(path.stem[1:])
+        assert getattr(tls, "slot", None) is not None          # the front half runs INSIDE its context, on the thread that entered it
+        time.sleep(0.06)
+        if i == 3:
+            raise RuntimeError("front of page 3")
+        return {"i": i, "page": page}
+
+    def back(state):
+        i = state["i"]
+        if i == 6:
+            raise ValueError("back of page 6")
+        out = state["page"].copy()
+        out.putpixel((0, 0), (i, i, i))
+        return out
+
+    t0 = time.perf_counter()
+    res = batch_process_images(root, _cfg("png"), tmp_path / "out_p", process_front=front, process_back=back, io_threads=2, front_workers=3,
+                               front_context=ctx)
+    wall = time.perf_counter() - t0
+    seq = batch_process_images(root, _cfg("png"), tmp_path / "out_s", io_threads=2,
+                               process_image=lambda page, path: back({"i": int(path.stem[1:]), "page": page}) if int(path.stem[1:]) != 3 else (_ for _ in ()).throw(RuntimeError("front of page 3")))
+    for k in ("success_count", "error_count", "errors"):
+        assert res[k] == seq[k], k
+    assert [Path(p).name for p in res["failed_image_paths"]] == ["p03.png", "p06.png"]
+    names = sorted(f.name for f in (tmp_path / "out_p").glob("*.png"))
+    assert names == sorted(f.name for f in (tmp_path / "out_s").glob("*.png")) and len(names) == n - 2
+    for name in names:
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "out_p" / name)), np.asarray(Image.open(tmp_path / "out_s" / name)))
+    assert not clashes and slots_seen == {0, 1, 2} and peak[0] == 3
+    assert res["io"]["pages_in_flight"] == 4
+    assert wall < 0.06 * n * 0.75                                 # ten 60 ms front halves one at a time would take 0.6 s

@@ -176,3 +176,46 @@ def test_load_yolo11_family_detectors(manager):
     assert res.masks is None and len(res.boxes) == 5 and res.boxes.xyxy.shape == (5, 4)
     res = bubble(page, conf=0.0, imgsz=64, max_det=3)[0]
     assert len(res.masks) == 3 and tuple(res.masks.data.shape[1:]) == (96, 64)
+
+
+def test_front_replicas_are_separate_instances_of_the_same_checkpoint(manager):
+    """`with manager.front_replica(i)`: the front-half loaders (detectors, SAM) hand the thread instance set i — another model object built
+    from the same file, same outputs — while every other model type, and every other thread, keeps the plain slot; unloading a type takes
+    its replicas with it (core/pipeline.py batch_process_images(front_workers=N) is the caller)"""
+    import threading
+    from oracle import yolo11_ref as y11
+    from oracle.rcan_ref import make_state_dict
+    from mangatranslator_amd.core.ml.model_manager import ModelType
+    names = {0: "body", 1: "frame"}
+    net = y11.make_model("11", "n", len(names), False, seed=1)
+    path = manager.model_paths[ModelType.YOLO_PANEL]
+    path.parent.mkdir(parents=True, exist_ok=True)
+    save_file({k: v.contiguous() for k, v in net.state_dict().items()}, str(path), metadata={"names": repr(names)})
+    up = manager.model_paths[ModelType.UPSCALE]
+    up.parent.mkdir(parents=True, exist_ok=True)
+    save_file(make_state_dict(n_feats=32, n_resgroups=1, n_resblocks=1, seed=3), str(up))
+    panel0 = manager.load_yolo_panel()
+    with manager.front_replica(1):
+        assert manager.current_front_replica() == 1
+        panel1 = manager.load_yolo_panel()
+        assert manager.load_yolo_panel() is panel1 and panel1 is not panel0
+        assert manager.load_upscale() is manager.load_upscale()                     # not a front-half model: one instance for every thread
+        rcan = manager.load_upscale()
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(manager.load_yolo_panel()))    # the setting is the calling thread's only
+        th.start(); th.join()
+        assert seen == [panel0]
+        with manager.front_replica(0):
+            assert manager.load_yolo_panel() is panel0
+        assert manager.current_front_replica() == 1
+    assert manager.current_front_replica() == 0 and manager.load_yolo_panel() is panel0 and manager.load_upscale() is rcan
+    assert (ModelType.YOLO_PANEL, 1) in manager.models and (ModelType.UPSCALE, 1) not in manager.models
+    page = (np.random.default_rng(0).random((96, 64, 3)) * 255).astype(np.uint8)
+    r0, r1 = panel0(page, conf=0.0, imgsz=64, max_det=5)[0], panel1(page, conf=0.0, imgsz=64, max_det=5)[0]
+    assert torch.equal(r0.boxes.xyxy.cpu(), r1.boxes.xyxy.cpu()) and torch.equal(r0.boxes.conf.cpu(), r1.boxes.conf.cpu())
+    manager.unload_model(ModelType.YOLO_PANEL)
+    assert not manager.is_loaded(ModelType.YOLO_PANEL) and (ModelType.YOLO_PANEL, 1) not in manager.models
+    with manager.front_replica(1):
+        assert manager.load_yolo_panel() is not panel1                               # rebuilt on demand
+    manager.unload_all()
+    assert all(not isinstance(k, tuple) for k in manager.models)

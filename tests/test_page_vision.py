@@ -155,3 +155,31 @@ def test_initial_upscale_rule(calls, monkeypatch):
     out, info = pipeline.process_page_vision(Image.new("RGB", (50, 60)), cfg)
     assert log == [("up", 2.0, "model_lite"), ("detect", (100, 120))] and out.size == (100, 120)
     assert info["pre_upscale_factor"] == 2.0 and info["processing_scale"] == pytest.approx(math.sqrt(100 * 120 / 1e6))
+
+
+def test_batch_vision_images_equals_page_by_page(calls, tmp_path, monkeypatch):
+    """`batch_vision_images`: the folder through the front / back halves inside the harness — files, order and pixels of
+    `process_page_vision` page by page; front_workers chosen from the configuration (short back half + sixteen hardware queues -> 2)"""
+    root = tmp_path / "in"
+    root.mkdir()
+    for i in range(5):
+        Image.new("RGB", (50, 60), (200 + i, 250, 250)).save(root / f"p{i}.png")
+    cfg = _config(verbose=False, output=types.SimpleNamespace(upscale_final_image=True, image_upscale_factor=2.0, image_upscale_model="model_lite",
+                                                             output_format="png", jpeg_quality=95, png_compression=2))
+    cfg.detection.use_panel_sorting = False
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert pipeline.default_front_workers(cfg) == 1                      # FLUX / upscale in the back half
+    light = _config(outside_text=types.SimpleNamespace(enabled=False, huggingface_token=""),
+                    output=types.SimpleNamespace(upscale_final_image=False))
+    assert pipeline.default_front_workers(light) == 1                    # runtime default of four hardware queues
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert pipeline.default_front_workers(light) == 2 and pipeline.default_front_workers(cfg) == 1
+    res = pipeline.batch_vision_images(root, cfg, tmp_path / "out", io_threads=2, front_workers=2)
+    assert res["success_count"] == 5 and res["error_count"] == 0 and res["io"]["pages_in_flight"] == 3
+    assert [c[0] for c in calls].count("detect") == 5 and [c[0] for c in calls].count("upscale") == 5
+    formats = {c[1] for c in calls if c[0] == "detect"}
+    assert formats == {"RGBA"}                                           # png output: pages are converted up front (load_page)
+    for i in range(5):
+        want, _ = pipeline.process_page_vision(Image.open(root / f"p{i}.png").convert("RGBA"), cfg, root / f"p{i}.png")
+        got = Image.open(tmp_path / "out" / f"p{i}_translated.png").convert("RGBA")
+        assert got.size == (100, 120) and np.array_equal(np.asarray(got), np.asarray(want))

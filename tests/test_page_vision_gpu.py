@@ -105,3 +105,70 @@ def test_page_through_all_stages(hip_lib, monkeypatch):
     assert len(dets) >= 1 and all(d["sam_mask"].shape == (H, W) for d in dets)
     cleaned, cinfo = cleaning.clean_speech_bubbles(page, None, pre_computed_detections=dets, device=dev, processing_scale=info["processing_scale"])
     assert cleaned.shape == (H, W, 4) and isinstance(cinfo, list)
+
+
+def test_batch_with_two_front_halves_in_flight(hip_lib, monkeypatch, tmp_path):
+    """`batch_vision_images(front_workers=2)` on the HIP path: two pages' detect stages (YOLO-seg, RT-DETR-v2, SAM-2.1) run at once on two
+    instance sets served by `ModelManager.front_replica`, cleaning follows in the back half; the written pages equal those of the
+    one-front-half run byte for byte"""
+    from oracle import rtdetr_ref, sam2_ref, yolo_ref
+    from mangatranslator_amd.core import pipeline
+    from mangatranslator_amd.core.ml import model_manager as mm
+    from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
+    from mangatranslator_amd.core.ml.sam2 import Sam2Hip
+    from mangatranslator_amd.core.ml.yolo import YoloSegHip
+    from mangatranslator_amd.utils.synthetic_pages import make_page
+    dev = torch.device("cuda:0")
+    mgr = mm.get_model_manager()
+    monkeypatch.setattr(mgr, "device", dev)
+    ynet = yolo_ref.make_model("n", 1, seed=3)
+    with torch.no_grad():
+        for l in range(3):
+            ynet.model[22].cv3[l][2].weight.mul_(0.05); ynet.model[22].cv3[l][2].bias.fill_(-1.0)
+            ynet.model[22].cv2[l][2].weight.mul_(0.1)
+    rmodel, rcfg = rtdetr_ref.make_model("tiny_test", seed=5)
+    smodel, scfg = sam2_ref.make_model("tiny_test", seed=2)
+    sets = []
+    for r in range(2):
+        yolo = YoloSegHip(ynet.state_dict(), device=dev, lib=hip_lib, names={0: "speech_bubble"})
+        rtdetr = RTDetrHip(rmodel.state_dict(), rcfg, device=dev, lib=hip_lib, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
+        sam = Sam2Hip(smodel.state_dict(), scfg, device=dev, lib=hip_lib)
+        sets.append((yolo, rtdetr, sam))
+        for mt, obj in [(mm.ModelType.YOLO_SPEECH_BUBBLE, yolo), (mm.ModelType.RTDETR_CONJOINED_BUBBLE, rtdetr),
+                        (mm.ModelType.SAM2, (mm._Sam2ProcessorShim(), mm._Sam2ModelShim(sam, torch.bfloat16)))]:
+            monkeypatch.setitem(mgr.models, mt if r == 0 else (mt, r), obj)
+    W, H = 512, 768
+    root = tmp_path / "in"
+    root.mkdir()
+    n = 6
+    for i in range(n):
+        pg, _boxes, _regions = make_page(20 + i, W, H, bubbles=8, osb_regions=0)
+        Image.fromarray(pg).save(root / f"p{i}.png")
+        if i == 0:
+            sets[0][0](np.ascontiguousarray(pg[..., ::-1]), conf=0.0, imgsz=640, max_det=1)
+            plan0, _ = next(iter(sets[0][0]._plans.values()))
+            sc = plan0.decoded[:, 4].float().sort(descending=True).values
+            conf = float(sc[min(12, len(sc) - 1)])
+    cfg = _config(conf, None)
+    cfg.outside_text.enabled = False
+    cfg.output = types.SimpleNamespace(upscale_final_image=False, image_upscale_factor=1.0, image_upscale_model="model_lite", output_format="png",
+                                       jpeg_quality=95, png_compression=2)
+    cfg.verbose = False
+    used = {0: 0, 1: 0}
+    real_front = pipeline.process_page_vision_front
+
+    def counting_front(*a, **k):
+        used[mgr.current_front_replica()] += 1
+        return real_front(*a, **k)
+    monkeypatch.setattr(pipeline, "process_page_vision_front", counting_front)
+    two = pipeline.batch_vision_images(root, cfg, tmp_path / "two", front_workers=2)
+    assert two["success_count"] == n and two["io"]["pages_in_flight"] == 3 and used[0] > 0 and used[1] > 0
+    one = pipeline.batch_vision_images(root, cfg, tmp_path / "one", front_workers=1)
+    assert one["success_count"] == n
+    changed = 0
+    for i in range(n):
+        a = np.asarray(Image.open(tmp_path / "two" / f"p{i}_translated.png").convert("RGBA"))
+        b = np.asarray(Image.open(tmp_path / "one" / f"p{i}_translated.png").convert("RGBA"))
+        assert np.array_equal(a, b), i
+        changed += int(not np.array_equal(a[..., :3], np.asarray(Image.open(root / f"p{i}.png").convert("RGB"))))
+    assert changed >= 1, "cleaning changed at least one page (the calibrated threshold lets detections through)"

@@ -50,3 +50,31 @@ def test_sam2_hiera_large_calibrated_logits_bf16(hip_lib):
     from mangatranslator_amd.hip import abi
     err, mism = sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=1536, w=1024, n_boxes=8, seed=2, logit_tol=0.06, mask_tol=0.01, calibrated=True, dtype=abi.BF16)
     record("sam2.hiera_large.1024x1536.calibrated.bf16", boxes=8, **sc.stats)
+
+
+def test_sam2_repeated_calls_are_bit_identical(hip_lib):
+    """the same page and boxes through one model again and again (hipGraph replays after the first call): logits, the stability-based mask
+    choice and the masks never change.  23 boxes on purpose: the pixel counters of the mask choice are then 184 bytes, the size at which a
+    captured hipMemsetAsync left counts uncleared on some replays (round 4: the choice of a box flipped between identical calls; the
+    counters are now cleared by a kernel, csrc/mtx_device.h zero_words_async)"""
+    import numpy as np
+    import torch
+    from oracle import sam2_ref
+    from mangatranslator_amd.core.ml.sam2 import Sam2Hip
+    from mangatranslator_amd.utils.synthetic_pages import make_page
+    dev = torch.device("cuda:0")
+    smodel, scfg = sam2_ref.make_model("tiny_test", seed=2)
+    sam = Sam2Hip(smodel.state_dict(), scfg, device=dev, lib=hip_lib)
+    pg, _b, _r = make_page(23, 512, 768, bubbles=8, osb_regions=0)
+    for nb in (23, 28, 7, 23):
+        r = np.random.default_rng(nb)
+        bx = np.stack([r.integers(0, 300, nb), r.integers(0, 500, nb)], 1).astype(np.float32)
+        bx = np.concatenate([bx, bx + np.stack([25 + (np.arange(nb) % 5) * 30, 32 + (np.arange(nb) % 7) * 20], 1)], 1).astype(np.float32)
+        first = None
+        for rep in range(8):
+            masks, low, iou, sel = sam.segment(pg, bx, return_logits=True)
+            got = [t.cpu() for t in (masks, low, iou, sel)]
+            if first is None:
+                first = got
+            for a, b, name in zip(first, got, ("masks", "logits", "iou", "choice")):
+                assert torch.equal(a, b), (nb, rep, name)

@@ -44,6 +44,11 @@ rest)
     echo "== config 5"; timeout 600 python bench.py --config 5 --steps 8 --warmup 2 --no-traffic > gpurun_out/bench_c5.out 2> gpurun_out/bench_c5.err; line gpurun_out/bench_c5.out gpurun_out/r04_bench_config5.json
     echo "== upscale only"; timeout 300 python bench.py --stages upscale --steps 10 --warmup 3 --no-cpu-baseline --no-traffic > gpurun_out/bench_up.out 2>/dev/null; line gpurun_out/bench_up.out gpurun_out/r04_bench_upscale_only.json
   } > gpurun_out/r04_end_rest.log 2>&1; cat gpurun_out/r04_end_rest.log ;;
+io_detect)
+  { echo "== product harness with two front halves in flight (GPU test)"; timeout 600 python -m pytest tests/test_page_vision_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -5
+    for c in 2 1; do echo "== batch harness with image I/O: config $c, 64 pages, front_workers = front replicas"
+      timeout 600 python bench.py --config $c --steps 30 --warmup 3 --batch-io 64 --no-cpu-baseline --no-traffic > gpurun_out/bench_io$c.out 2> gpurun_out/bench_io$c.err; line gpurun_out/bench_io$c.out gpurun_out/r04_bench_config${c}_batch_io64.json; tail -2 gpurun_out/bench_io$c.err; done
+  } > gpurun_out/r04_end_io_detect.log 2>&1; cat gpurun_out/r04_end_io_detect.log ;;
 io)
   { echo "== batch harness with image I/O: config 2, 64 pages"; timeout 1200 python bench.py --config 2 --steps 10 --warmup 3 --batch-io 64 --no-cpu-baseline --no-traffic > gpurun_out/bench_io2.out 2> gpurun_out/bench_io2.err; line gpurun_out/bench_io2.out gpurun_out/r04_bench_config2_batch_io64.json
     echo "== batch harness with image I/O: config 5, 16 pages"; timeout 1800 python bench.py --config 5 --steps 4 --warmup 2 --batch-io 16 --no-cpu-baseline --no-traffic > gpurun_out/bench_io5.out 2> gpurun_out/bench_io5.err; line gpurun_out/bench_io5.out gpurun_out/r04_bench_config5_batch_io16.json
