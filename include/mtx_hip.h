@@ -36,7 +36,7 @@ extern "C" {
 #define MTX_API
 #endif
 
-#define MTX_ABI_VERSION 5
+#define MTX_ABI_VERSION 6
 
 typedef enum mtx_status {
   MTX_OK = 0,
@@ -168,9 +168,13 @@ typedef struct mtx_norm_args {
   void* q; void* q_scale; int64_t ldq, lds_q;
 } mtx_norm_args;
 
-/* GroupNorm over NHWC [N, HW, C] with G groups, optional fused SiLU. */
+/* GroupNorm over NHWC [N, HW, C] with G groups, optional fused SiLU.  `workspace`: MTX_GROUPNORM_WS_FLOATS(n, hw, c, groups) floats
+ * ([N][G] {mean, rstd} + per-block per-channel partial sums, added in a fixed order: identical calls give identical bytes); its content on
+ * entry does not matter (ABI 6; up to ABI 5: N*C*2 + N*G*2 floats accumulated by atomics). */
+#define MTX_GN_PIX_PER_BLOCK 1024
+#define MTX_GROUPNORM_WS_FLOATS(n, hw, c, g) ((n) * (g) * 2 + (n) * (((hw) + MTX_GN_PIX_PER_BLOCK - 1) / MTX_GN_PIX_PER_BLOCK) * (c) * 2)
 typedef struct mtx_groupnorm_args {
-  const void* x; void* y; const float* gamma; const float* beta; float* workspace; /* fp32 [N*C*2 + N*G*2] */
+  const void* x; void* y; const float* gamma; const float* beta; float* workspace;
   int64_t n, hw, c, groups; float eps; int32_t act; int32_t dtype;
 } mtx_groupnorm_args;
 

@@ -125,7 +125,11 @@ int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
 }
 
 // ---- GroupNorm -----------------------------------------------------------------------------------
-// workspace layout (fp32): [N][C][2] per-channel {sum, sumsq}  followed by  [N][G][2] {mean, rstd}
+// workspace layout (fp32, MTX_GROUPNORM_WS_FLOATS): [N][G][2] {mean, rstd}  followed by  [N][BX][C][2] per-block per-channel {sum, sumsq},
+// BX = ceil(HW / MTX_GN_PIX_PER_BLOCK).  Round 4: the per-channel sums used to be accumulated with fp32 atomicAdd from every block — the
+// order of those additions, hence the last bits of mean / rstd and of every VAE output, changed from run to run.  Now each block stores
+// its partial sums and one workgroup per (image, group) adds them in a fixed order (double accumulators): identical calls give identical
+// bytes (tests/test_determinism_gpu.py), and nothing has to be cleared first.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(mtx_groupnorm_args p, int pix_per_block) {
   __shared__ float red[256 * 16];
@@ -149,32 +153,46 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(mtx_groupnorm_args p, int
   for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s[e]; red[tid * 16 + 8 + e] = ss[e]; }
   __syncthreads();
   if (sub == 0) {
-    float* ws = p.workspace + (n * p.c + col * 8) * 2;
+    float* part = p.workspace + p.n * p.groups * 2 + ((n * gridDim.x + blockIdx.x) * p.c + col * 8) * 2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float a = 0.f, b = 0.f;
       for (int k = 0; k < nsub; ++k) { a += red[(k * C8 + col) * 16 + e]; b += red[(k * C8 + col) * 16 + 8 + e]; }
-      atomicAdd(ws + e * 2, a);
-      atomicAdd(ws + e * 2 + 1, b);
+      part[e * 2] = a;
+      part[e * 2 + 1] = b;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(mtx_groupnorm_args p) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= p.n * p.groups) return;
-  const long n = idx / p.groups, g = idx % p.groups;
+// one workgroup per (image, group): thread t adds the (block, channel) pairs t, t + 256, ... of the group, then a fixed binary tree over the
+// 256 threads — the same order on every run
+__global__ __launch_bounds__(256) void gn_finalize_kernel(mtx_groupnorm_args p, int nblocks) {
+  __shared__ double rs[256], rq[256];
+  const long n = blockIdx.x / p.groups, g = blockIdx.x % p.groups;
   const long cg = p.c / p.groups;
-  const float* ws = p.workspace + (n * p.c + g * cg) * 2;
-  float s = 0.f, ss = 0.f;
-  for (long c = 0; c < cg; ++c) { s += ws[c * 2]; ss += ws[c * 2 + 1]; }
-  const float cnt = (float)(cg * p.hw);
-  const float mean = s / cnt;
-  float var = ss / cnt - mean * mean;
-  if (var < 0.f) var = 0.f;
-  float* out = p.workspace + p.n * p.c * 2 + idx * 2;
-  out[0] = mean;
-  out[1] = 1.0f / sqrtf(var + p.eps);
+  const float* part = p.workspace + p.n * p.groups * 2 + n * (long)nblocks * p.c * 2;
+  double s = 0.0, ss = 0.0;
+  const long pairs = (long)nblocks * cg;
+  for (long i = threadIdx.x; i < pairs; i += 256) {
+    const long b = i / cg, c = g * cg + i % cg;
+    s += (double)part[(b * p.c + c) * 2];
+    ss += (double)part[(b * p.c + c) * 2 + 1];
+  }
+  rs[threadIdx.x] = s; rq[threadIdx.x] = ss;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { rs[threadIdx.x] += rs[threadIdx.x + w]; rq[threadIdx.x] += rq[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double cnt = (double)(cg * p.hw);
+    const double mean = rs[0] / cnt;
+    double var = rq[0] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float* out = p.workspace + (n * p.groups + g) * 2;
+    out[0] = (float)mean;
+    out[1] = 1.0f / sqrtf((float)var + p.eps);
+  }
 }
 
 template <typename T>
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(mtx_groupnorm_args p) {
   const long C8 = p.c / 8;
   const long total = p.n * p.hw * C8;
   const long cg = p.c / p.groups;
-  const float* st = p.workspace + p.n * p.c * 2;
+  const float* st = p.workspace;
   const T* X = reinterpret_cast<const T*>(p.x);
   T* Y = reinterpret_cast<T*>(p.y);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -211,18 +229,18 @@ int groupnorm_launch(const mtx_groupnorm_args* a, void* stream, const char** err
     *err = "groupnorm: C/8 must divide 256 and groups must divide C"; return MTX_ERR_INVALID;
   }
   if (a->n < 1 || a->hw < 1) return MTX_OK;
-  zero_words_async(a->workspace, (size_t)a->n * a->c * 2 * sizeof(float), stream);        // a kernel, not a memset node (mtx_device.h)
-  const int ppb = 1024;
-  dim3 g1((unsigned)((a->hw + ppb - 1) / ppb), (unsigned)a->n);
+  const int ppb = MTX_GN_PIX_PER_BLOCK;
+  const int nb = (int)((a->hw + ppb - 1) / ppb);
+  dim3 g1((unsigned)nb, (unsigned)a->n);
   long tot = a->n * a->hw * C8;
   long blocks = (tot + 255) / 256; if (blocks > 8192) blocks = 8192;
   if (a->dtype == MTX_BF16) {
     MTX_LAUNCH((gn_stats_kernel<__bf16>), g1, dim3(256), 0, stream, *a, ppb);
-    MTX_LAUNCH(gn_finalize_kernel, dim3((unsigned)((a->n * a->groups + 255) / 256)), dim3(256), 0, stream, *a);
+    MTX_LAUNCH(gn_finalize_kernel, dim3((unsigned)(a->n * a->groups)), dim3(256), 0, stream, *a, nb);
     MTX_LAUNCH((gn_apply_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
   } else if (a->dtype == MTX_F16) {
     MTX_LAUNCH((gn_stats_kernel<_Float16>), g1, dim3(256), 0, stream, *a, ppb);
-    MTX_LAUNCH(gn_finalize_kernel, dim3((unsigned)((a->n * a->groups + 255) / 256)), dim3(256), 0, stream, *a);
+    MTX_LAUNCH(gn_finalize_kernel, dim3((unsigned)(a->n * a->groups)), dim3(256), 0, stream, *a, nb);
     MTX_LAUNCH((gn_apply_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, stream, *a);
   } else { *err = "groupnorm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
   return MTX_OK;

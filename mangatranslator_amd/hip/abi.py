@@ -2,7 +2,7 @@
 mtx_abi_sizeof() when the library is opened)."""
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # enums
 BF16, F16, F32, U8, I32, F8 = 0, 1, 2, 3, 4, 5
@@ -14,6 +14,13 @@ IMG_NCHW_F32_TO_NHWC, IMG_NHWC_TO_NCHW_F32, IMG_NHWC_TO_HWC_U8, IMG_HWC_U8_TO_NH
  OP_MEMSET, OP_MASK_SELECT, OP_PREPROC, OP_YOLO_DECODE, OP_DETR, OP_QUANT, OP_TAIL) = range(1, 17)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+GN_PIX_PER_BLOCK = 1024
+
+
+def groupnorm_ws_floats(n: int, hw: int, c: int, groups: int) -> int:
+    """MTX_GROUPNORM_WS_FLOATS of include/mtx_hip.h"""
+    return n * groups * 2 + n * ((hw + GN_PIX_PER_BLOCK - 1) // GN_PIX_PER_BLOCK) * c * 2
 
 
 class ConvArgs(C.Structure):

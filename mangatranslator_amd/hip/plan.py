@@ -380,7 +380,7 @@ class PlanBuilder:
         assert x.c == x.ld and x.c0 == 0, "groupnorm needs a dense NHWC tensor"
         if out is None:
             out = self.act(x.n, x.h, x.w, x.c)
-        ws = self.buf((x.n * x.c * 2 + x.n * groups * 2,), torch.float32)
+        ws = self.buf((abi.groupnorm_ws_floats(x.n, x.h * x.w, x.c, groups),), torch.float32)
         a = abi.GroupNormArgs()
         a.x, a.y, a.gamma, a.beta, a.workspace = x.ptr, out.ptr, _ptr(gamma), _ptr(beta), _ptr(ws)
         a.n, a.hw, a.c, a.groups = x.n, x.h * x.w, x.c, groups
