@@ -11,6 +11,7 @@ import torch
 
 from mangatranslator_amd.core.ml import flux2 as f2
 from oracle import flux2_ref as fr
+from flux_checks import assert_repeats as fc_assert_repeats
 
 PSNR_MIN_DB = 40.0
 
@@ -77,6 +78,7 @@ def check_dit_step(lib, device, h2=4, w2=6, rh2=None, rw2=None, t_txt=16, tol=3e
     e = rel(vel, ref)
     print(f"FLUX.2 DiT step ({t.cfg['layers']}+{t.cfg['single_layers']} blocks, d={t.cfg['d']}, T={plan.T}, fp8={bool(fp8)}): velocity rel err {e:.4f}")
     assert e < (fp8_tol if fp8 else tol)
+    fc_assert_repeats(plan, device)
     return e
 
 

@@ -69,7 +69,21 @@ def check_dit_step(lib, device, h2=4, w2=6, t_txt=16, tol=3e-2, **kw):
     e = rel(plan.vel, ref)
     print(f"DiT step ({t.cfg['layers']}+{t.cfg['single_layers']} blocks, T={plan.T}): velocity rel err {e:.4f}")
     assert e < tol
+    assert_repeats(plan, device)
     return e
+
+
+def assert_repeats(plan, device, runs=3):
+    """the step again — eagerly and as hipGraph replays, the pipelines' form — over the same inputs: the velocity's bytes do not change
+    (side lane joins, K-slice tickets and partials, key-split merges: nothing may depend on what the previous run left behind)"""
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+    sync()
+    first = plan.vel.clone()
+    for i in range(runs):
+        plan.vel.fill_(float("nan"))
+        plan.run(graph=i > 0)
+        sync()
+        assert torch.equal(plan.vel, first), f"run {i + 2} of the same step differs from the first"
 
 
 def check_vae(lib, device, h=64, w=96, tol=3e-2, **kw):
