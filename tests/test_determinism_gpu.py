@@ -136,3 +136,60 @@ def test_rcan_repeats(hip_lib):
             out = m.upscale_u8(page.to(DEV)).cpu()
             first = [out] if first is None else first
             _same(first, [out], "RCAN")
+
+
+def test_bench_geometry_repeats(hip_lib):
+    """the networks at the sizes the pages use (the big-tile GEMMs with their K-slice tail behind the 1x1 convolutions and SAM's linears,
+    the pipelined conv kernel at thousands of tiles, RCAN at page size): seeded weights of the published architectures, a 1024 x 1536
+    page, every result compared over three calls — first eager, then hipGraph replays"""
+    from mangatranslator_amd.core.ml.rcan import RCANUpscaler
+    from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
+    from mangatranslator_amd.core.ml.sam2 import Sam2Hip
+    from mangatranslator_amd.core.ml.yolo import YoloSegHip
+    from mangatranslator_amd.core.ml.yolo11 import Yolo11Hip
+    from mangatranslator_amd.utils import synthetic_checkpoints as synth
+    from mangatranslator_amd.utils.synthetic_pages import make_page
+    dev = torch.device(DEV)
+    pg, boxes, _ = make_page(5, 1024, 1536, bubbles=8, osb_regions=0)
+    bgr = np.ascontiguousarray(pg[..., ::-1])
+
+    def detector_outputs(res):
+        got = [res.boxes.xyxy.cpu(), res.boxes.conf.cpu(), res.boxes.cls.cpu()]
+        if getattr(res, "masks", None) is not None:
+            got.append(res.masks.data.cpu())
+        return got
+
+    v8_shapes, v8_head = synth.yolov8_seg_shapes("m", 1)
+    nets = [("yolov8m-seg @1600", lambda: YoloSegHip(synth.seeded_detector(v8_shapes, v8_head, seed=3, class_bias=-1.0, class_gain=0.05, box_gain=0.1), device=dev, lib=hip_lib),
+             dict(conf=0.0, imgsz=1600, max_det=50))]
+    for tag, fam, scale, seg, seed, imgsz in (("yolo11m-seg @1600", "11", "m", True, 13, 1600), ("yolo11l @640", "11", "l", False, 17, 640), ("yolo12x @640", "12", "x", False, 19, 640)):
+        shapes_, head_ = synth.yolo11_shapes(fam, scale, 1, seg)
+        sd_ = synth.seeded_detector(shapes_, head_, seed=seed, class_bias=-2.0, class_gain=0.05, box_gain=0.1)
+        nets.append((tag, (lambda sd=sd_: Yolo11Hip(sd, device=dev, lib=hip_lib)), dict(conf=0.0, imgsz=imgsz, max_det=50)))
+    rcfg = synth.rtdetr_r50_config()
+    rsd = synth.rtdetr_state_dict(rcfg, seed=5)
+    nets.append(("rtdetr-r50 @640", lambda: RTDetrHip(rsd, rcfg, device=dev, lib=hip_lib), dict(conf=0.0, imgsz=640)))
+    for tag, make, kw in nets:
+        model = make()
+        first = None
+        for _ in range(3):
+            got = detector_outputs(model(bgr, **kw)[0])
+            first = got if first is None else first
+            _same(first, got, tag)
+        del model
+    sam_cfg = synth.sam2_hiera_large_config()
+    sam = Sam2Hip(synth.sam2_state_dict(sam_cfg, seed=11), sam_cfg, device=dev, lib=hip_lib, dtype=abi.F16)
+    first = None
+    for _ in range(3):
+        masks, low, iou, sel = sam.segment(pg, np.asarray(boxes, np.float32), return_logits=True)
+        got = [t.cpu() for t in (masks, low, iou, sel)]
+        first = got if first is None else first
+        _same(first, got, "sam2.1 hiera-L")
+    del sam
+    rcan = RCANUpscaler(synth.rcan_state_dict(seed=7, n_feats=64, n_resgroups=10, n_resblocks=20, unshuffle=1), device=dev, lib=hip_lib)
+    page = torch.from_numpy(pg).to(dev)
+    first = None
+    for _ in range(3):
+        out = rcan.upscale_u8(page).cpu()
+        first = [out] if first is None else first
+        _same(first, [out], "rcan 10x20 @1024x1536")
