@@ -77,8 +77,9 @@ static int run_op(const mtx_op& op, void* stream) {
     case MTX_OP_QUANT: rc = quant_launch(&op.u.quant, stream, &err); break;
     case MTX_OP_TAIL: rc = tail_launch(&op.u.tail, stream, &err); break;
     case MTX_OP_MEMSET:
-      if (hipMemsetAsync(op.u.ms.ptr, op.u.ms.value, (size_t)op.u.ms.bytes, (hipStream_t)stream) != hipSuccess) { rc = MTX_ERR_HIP; err = "memset failed"; }
-      else rc = MTX_OK;
+      if (op.u.ms.bytes < 0 || (!op.u.ms.ptr && op.u.ms.bytes > 0)) { rc = MTX_ERR_INVALID; err = "memset: null pointer or negative size"; break; }
+      fill_bytes_async(op.u.ms.ptr, op.u.ms.value, (size_t)op.u.ms.bytes, stream);        // a kernel: a captured hipMemsetAsync (memset node) did not always clear (mtx_device.h)
+      rc = MTX_OK;
       break;
     default: rc = MTX_ERR_INVALID; err = "unknown op kind"; break;
   }

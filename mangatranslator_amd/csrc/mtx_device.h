@@ -415,6 +415,26 @@ __device__ __forceinline__ void buf_load16_lds(const BufView& b, unsigned voff, 
 static __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* p, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0u;
 }
+// byte fill of any length (MTX_OP_MEMSET): 4-byte stores over the aligned middle, single bytes at the ragged ends
+static __global__ __launch_bounds__(256) void fill_bytes_kernel(unsigned char* p, long bytes, unsigned char v) {
+  const long head = (4 - (long)(reinterpret_cast<unsigned long long>(p) & 3)) & 3;          // bytes before the first aligned word
+  const long lead = head < bytes ? head : bytes;
+  const long words = (bytes - lead) / 4;
+  const unsigned pattern = 0x01010101u * v;
+  unsigned* w = reinterpret_cast<unsigned*>(p + lead);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long)gridDim.x * 256) w[i] = pattern;
+  if (blockIdx.x == 0 && threadIdx.x < 8) {
+    const long t = threadIdx.x;
+    if (t < lead) p[t] = v;                                                             // up to 3 leading bytes
+    const long tail0 = lead + words * 4;
+    if (t >= 4 && tail0 + (t - 4) < bytes) p[tail0 + (t - 4)] = v;                          // up to 3 trailing bytes
+  }
+}
+static inline void fill_bytes_async(void* p, int value, size_t bytes, void* stream) {
+  if (bytes == 0) return;
+  long blocks = ((long)(bytes / 4) + 255) / 256; if (blocks < 1) blocks = 1; if (blocks > 2048) blocks = 2048;
+  MTX_LAUNCH(fill_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<unsigned char*>(p), (long)bytes, (unsigned char)value);
+}
 static inline void zero_words_async(void* p, size_t bytes, void* stream) {      // bytes: a multiple of 4
   const long n = (long)(bytes / 4);
   if (n <= 0) return;

@@ -644,3 +644,25 @@ def check_rcab_tail(lib, dtype, n=2, h=37, w=29, c=64, cr=4, canvas=None, seed=0
     if canvas:
         assert float(out[:, h:].abs().max()) == 0.0 and float(out[:, :, w:].abs().max()) == 0.0      # beyond the image: zeros
     return e_s, err
+
+
+def check_memset(lib):
+    """MTX_OP_MEMSET as a plan op (a fill kernel, not hipMemsetAsync): every byte of ragged ranges at ragged offsets takes the value, the
+    bytes around them keep theirs, also on a second run"""
+    dev = _dev(lib)
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    cases = [(0, 184, 0), (3, 1, 7), (5, 2, 255), (1, 1027, 9), (2, 4, 1), (6, 4099, 0), (0, 0, 5)]
+    bufs = []
+    for off, n, v in cases:
+        t = pb.buf((n + 16,), torch.uint8)
+        t.fill_(0x5A)
+        pb.memset(t[off:off + n], v)
+        bufs.append(t)
+    plan = _run(pb)
+    for rep in range(2):
+        for (off, n, v), t in zip(cases, bufs):
+            h = t.cpu()
+            assert (h[off:off + n] == v).all() and (h[:off] == 0x5A).all() and (h[off + n:] == 0x5A).all(), (off, n, v, rep)
+            t[off:off + n] = 0x33
+        plan.run()
+        _sync(lib)

@@ -192,3 +192,7 @@ def test_gemm_f8_glu_epilogue(hip_lib, cfg):
 def test_attention_mx_fp8_output(hip_lib, cfg):
     """attn_mma32_q8_kernel / attn_merge_q8_kernel: bytes and scale words equal attention -> mtx_quantize_mx."""
     oc.check_attention_q8(hip_lib, abi.BF16, **cfg)
+
+
+def test_memset_op(hip_lib):
+    oc.check_memset(hip_lib)

@@ -195,3 +195,7 @@ def test_producers_write_their_fp8_twins(emu_lib):
     """adaLN norm and SwiGLU quantise their own output for the fp8 linears: bit-identical to producer + mtx_quantize_mx"""
     oc.check_fused_quantisers(emu_lib, abi.BF16, rows=37, c=256, hid=128)
     oc.check_fused_quantisers(emu_lib, abi.F16, rows=70, c=1152, hid=384, seed=1)
+
+
+def test_memset_op(emu_lib):
+    oc.check_memset(emu_lib)
