@@ -46,6 +46,10 @@ typedef enum mtx_status {
   MTX_ERR_STATE = -4
 } mtx_status;
 
+/* MTX_F32 as the `dtype` of mtx_gemm / mtx_attention / mtx_norm / mtx_elementwise (late round 4): every operand and the result are fp32 and
+ * the arithmetic runs on the vector ALUs (csrc/f32ops.hip) — GEMM with bias / act / res / strided batches (no gate, glu or fp8 operands),
+ * attention with head dim 8 / 16 / 32 / 64, LayerNorm (+ act), element-wise ADD / MUL / ACT / COPY / ROW_GATHER / SHUFFLE2_ADD / CVT_F32.
+ * Small problems only: SAM-2.1's mask decoder under Sam2Hip(precision="high").  Simulator-verified; not yet run on hardware. */
 typedef enum mtx_dtype { MTX_BF16 = 0, MTX_F16 = 1, MTX_F32 = 2, MTX_U8 = 3, MTX_I32 = 4,
                          MTX_F8 = 5 /* OCP e4m3fn bytes with MX block scales, see mtx_quant_args */ } mtx_dtype;
 
@@ -118,8 +122,8 @@ typedef struct mtx_gemm_args {
    *   h = round_T(silu(round_T(a)) * round_T(b))  (what MTX_QUANT_SWIGLU computes from the 16-bit projection),  span u -> the 32
    *   bytes glu_q[m * glu_ldq + 32 u ..] and byte (u & 3) of the scale word glu_scale[(u >> 2) * glu_lds + m].
    * Columns below glu_col0 take the usual epilogue into c.  glu_col0 % 256 == 0, (n - glu_col0) % 256 == 0, no bias / gate / res /
-   * act on the launch, glu_q 16-byte aligned with glu_ldq % 16 == 0.  NULL glu_q = off.  (Built and checked on the CPU simulator in
-   * round 3; not yet run on hardware — FLUX.2 graphs do not use it by default.) */
+   * act on the launch, glu_q 16-byte aligned with glu_ldq % 16 == 0.  NULL glu_q = off.  (Hardware-verified in round 4 — tests/test_ops_gpu.py::test_gemm_f8_glu_epilogue —
+   * and the default of the FLUX.2 graphs since.) */
   void* glu_q; void* glu_scale; int64_t glu_ldq, glu_lds, glu_col0;
 } mtx_gemm_args;
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
@@ -143,8 +147,8 @@ typedef struct mtx_attn_args {
   int32_t flags;                 /* MTX_ATTN_* bits */
   /* MX fp8 output (long-sequence kernel only: d = 128, sq >= 1024, sk >= 256, batch 1): the rows leave as the e4m3 operand of the next
    * linear — q8[row * ldq8 + head * 128 + ..] and one scale word per head and row, q8_scale[head * lds_q8 + row] — exactly what
-   * mtx_quantize_mx makes of the 16-bit output (rounded to `dtype` first); `o` may then be NULL.  (Built and checked on the CPU simulator
-   * in round 3; not yet run on hardware — FLUX.2 graphs do not use it by default.) */
+   * mtx_quantize_mx makes of the 16-bit output (rounded to `dtype` first); `o` may then be NULL.  (Hardware-verified in round 4 —
+   * tests/test_ops_gpu.py::test_attention_mx_fp8_output — and the default of the FLUX.2 graphs since.) */
   void* q8; void* q8_scale; int64_t ldq8, lds_q8;
 } mtx_attn_args;
 /* q already carries scale * log2(e) (folded into the producer, e.g. the pre-scaled rotary table of MTX_EW_QK_NORM_ROPE): `scale`
@@ -200,6 +204,10 @@ typedef enum mtx_ew_kind {
                              s = weights T [k*k][C] (tap-major), b = fp32 bias [C] (may be null) — YOLO11 head / C2PSA and YOLO12 area-attention
                              positional convs (ultralytics DWConv, Conv(g = c)) */
   MTX_EW_SWIGLU = 14,     /* y = silu(a) * b   (FLUX.2 feed-forward: a, b = the two column halves of linear_in's output) */
+  MTX_EW_SHUFFLE2_ADD = 16, /* fp32 only: a [n, h, w, 4c] holds per input pixel the four output pixels' c channels (column (dy * 2 + dx) * c + ch: a
+                               ConvTranspose2d(k = 2, s = 2) done as a GEMM); y[n, 2h + dy, 2w + dx, ch] = a[...] + b[(n), 2h + dy, 2w + dx, ch] with b
+                               optional and lds = its per-sample stride (0 = one image for every n) — SAM's mask upscaling                        */
+  MTX_EW_CVT_F32 = 17,    /* fp32 only: y = (float) a, a of the 16-bit type i0 (MTX_F16 / MTX_BF16)                                              */
   MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
                              i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then
                              rotary on interleaved pairs with b = fp32 [rows][d] cos|sin table laid out as

@@ -193,6 +193,9 @@ class ModelManager:
             self.flux_hf_token = None
             self.flux_inference_lock = threading.Lock()
             self._tls = threading.local()           # .replica: which instance set of the front-half models this thread is served from
+            # "fast": SAM-2.1 as measured all round (16-bit storage).  "high": hi + lo weight pairs in the trunk / neck and an fp32 mask
+            # decoder (core/ml/sam2.py; simulator-verified, first hardware run pending — not the default)
+            self.sam_precision = "fast"
             self._initialized = True
             log_message(f"Model Manager initialized on device: {self.device}", always_print=True)
 
@@ -533,7 +536,8 @@ class ModelManager:
             sd = self._read_safetensors(weights, local=slot is not ModelType.SAM2)
             if slot is not ModelType.SAM2 and self.is_loaded(ModelType.SAM2):
                 # a replica takes the storage type set 0 settled on (its probe compared the two): one more model, no second probe
-                hip = Sam2Hip(sd, config, device=self.device, dtype=self.models[ModelType.SAM2][1].hip.dtype)
+                first = self.models[ModelType.SAM2][1].hip
+                hip = Sam2Hip(sd, config, device=self.device, dtype=first.dtype, precision="high" if first.high else "fast")
                 self.models[slot] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
                 return self.models[slot]
             # f16 storage (8x smaller logit error than bf16 against the fp32 reference: the `> 0` masks are what the page flow keeps)
@@ -549,6 +553,8 @@ class ModelManager:
             else:
                 log_message(f"SAM 2.1: f16 storage disagrees with bf16 on the probe page ({gap:.2f} of the logit range): using bf16", always_print=True)
             del hip16
+            if getattr(self, "sam_precision", "fast") == "high":
+                hip = Sam2Hip(sd, config, device=self.device, dtype=hip.dtype, precision="high")
             self.models[slot] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
             log_message("SAM 2.1 model loaded.", verbose=verbose)
             return self.models[slot]

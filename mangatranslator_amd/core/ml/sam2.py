@@ -77,7 +77,15 @@ def window_order(hs: int, ws_: int, win: int) -> np.ndarray:
 
 
 class Sam2Hip:
-    def __init__(self, state_dict: dict, config, device="cuda", lib=None, graph: bool = True, dtype: int = abi.BF16):
+    def __init__(self, state_dict: dict, config, device="cuda", lib=None, graph: bool = True, dtype: int = abi.BF16, precision: str = "fast"):
+        """precision = "high" (round 4, built for VERDICT r03 #2; simulator-verified, NOT yet run on hardware, not the default anywhere):
+        the trunk's and the neck's weights as hi + lo pairs of the storage type — W = W_hi + W_lo, one GEMM over K' = 2K with the operand
+        [x | x] against [W_hi | W_lo], fp32 accumulation: the weights' rounding, the largest term of the error budget, goes
+        away at twice the trunk's matrix work and no kernel change — and the prompt encoder / two-way transformer / mask head in fp32
+        (csrc/f32ops.hip)."""
+        if precision not in ("fast", "high"):
+            raise ModelError("SAM-2: precision must be 'fast' or 'high'")
+        self.high = precision == "high"
         self.lib = lib if lib is not None else get_library()
         self.device = torch.device(device)
         self.hp = hiera_hparams(config)
@@ -85,6 +93,8 @@ class Sam2Hip:
             raise ModelError("SAM-2: storage dtype must be bf16 or f16")
         self.dtype = dtype
         self.tdt = torch.bfloat16 if dtype == abi.BF16 else torch.float16
+        # the prompt encoder / two-way transformer / mask head: the storage type, or fp32 operands and arithmetic under precision "high"
+        self.ddtype, self.ddt = (abi.F32, torch.float32) if self.high else (self.dtype, self.tdt)
         self._graph = graph and not self.lib.is_simulator
         self._lane = AsyncLane(self.device, self.lib.is_simulator)
         self._enc = None
@@ -100,6 +110,18 @@ class Sam2Hip:
     def _c(self, t, dtype=None):
         return t.to(device=self.device, dtype=dtype if dtype is not None else self.tdt).contiguous()
 
+    def _cd(self, t):
+        """a matrix of the mask decoder in ITS operand type"""
+        return self._c(t, self.ddt)
+
+    def _cw(self, w):
+        """matrix [N, K] of a trunk / neck linear in the storage type; precision "high": [N, 2K] = [W_hi | W_lo]"""
+        if not self.high:
+            return self._c(w)
+        hi = w.to(self.tdt)
+        lo = (w - hi.float()).to(self.tdt)
+        return self._c(torch.cat([hi, lo], dim=1))
+
     def _pack(self, sd):
         hp, W = self.hp, {}
         S = hp["image_size"]
@@ -110,7 +132,7 @@ class Sam2Hip:
         wpe = sd[bbp + "patch_embed.projection.weight"]                      # [C0,3,7,7]
         wk = torch.zeros(C0, 49, 8)
         wk[:, :, :3] = wpe.permute(0, 2, 3, 1).reshape(C0, 49, 3)
-        W["pe_w"] = self._c(wk.reshape(C0, 392))
+        W["pe_w"] = self._cw(wk.reshape(C0, 392))
         W["pe_b"] = self._c(sd[bbp + "patch_embed.projection.bias"], torch.float32)
         # position table (hf:638-644), stored in the first stage's window-major order
         pos = F.interpolate(sd[bbp + "pos_embed"], size=(g0, g0), mode="bicubic")
@@ -136,9 +158,10 @@ class Sam2Hip:
                 for nm in ("layer_norm1", "layer_norm2"):
                     blk[nm] = (self._c(sd[p + nm + ".weight"], torch.float32), self._c(sd[p + nm + ".bias"], torch.float32))
                 for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.proj_in"), ("fc2", "mlp.proj_out")):
-                    blk[nm] = (self._c(sd[p + key + ".weight"]), self._c(sd[p + key + ".bias"], torch.float32))
+                    blk[nm] = (self._cw(sd[p + key + ".weight"]), self._c(sd[p + key + ".bias"], torch.float32))
+                    blk[nm + "_n"] = sd[p + key + ".weight"].shape[0]
                 if dim != dim_out:
-                    blk["skip"] = (self._c(sd[p + "proj.weight"]), self._c(sd[p + "proj.bias"], torch.float32))
+                    blk["skip"] = (self._cw(sd[p + "proj.weight"]), self._c(sd[p + "proj.bias"], torch.float32))
                 self.blocks.append(blk)
                 total += 1
         # neck (hf:216-265): convs[n-i] serves level i; levels 0/1 are folded with conv_s0/conv_s1
@@ -149,14 +172,14 @@ class Sam2Hip:
             lat[i] = (sd[f"vision_encoder.neck.convs.{n - i}.weight"].reshape(D, -1), sd[f"vision_encoder.neck.convs.{n - i}.bias"])
         ws0, bs0 = sd["mask_decoder.conv_s0.weight"].reshape(-1, D), sd["mask_decoder.conv_s0.bias"]
         ws1, bs1 = sd["mask_decoder.conv_s1.weight"].reshape(-1, D), sd["mask_decoder.conv_s1.bias"]
-        W["neck0"] = (self._c(ws0 @ lat[0][0]), self._c(ws0 @ lat[0][1] + bs0, torch.float32))
-        W["neck1"] = (self._c(ws1 @ lat[1][0]), self._c(ws1 @ lat[1][1] + bs1, torch.float32))
+        W["neck0"] = (self._cw(ws0 @ lat[0][0]), self._c(ws0 @ lat[0][1] + bs0, torch.float32))
+        W["neck1"] = (self._cw(ws1 @ lat[1][0]), self._c(ws1 @ lat[1][1] + bs1, torch.float32))
         fold = sd["no_memory_embedding"].reshape(-1) + sd["prompt_encoder.no_mask_embed.weight"].reshape(-1)
         if 2 in hp["top_down"]:
-            W["neck2"] = (self._c(lat[2][0]), self._c(lat[2][1] + fold, torch.float32))
-            W["neck3"] = (self._c(lat[3][0]), self._c(lat[3][1], torch.float32))
+            W["neck2"] = (self._cw(lat[2][0]), self._c(lat[2][1] + fold, torch.float32))
+            W["neck3"] = (self._cw(lat[3][0]), self._c(lat[3][1], torch.float32))
         else:
-            W["neck2"] = (self._c(lat[2][0]), self._c(lat[2][1] + fold, torch.float32))
+            W["neck2"] = (self._cw(lat[2][0]), self._c(lat[2][1] + fold, torch.float32))
             W["neck3"] = None
         # dense image positional encoding (hf:1341-1353) and prompt tables
         ge = S // hp["patch"]
@@ -175,12 +198,12 @@ class Sam2Hip:
         md = "mask_decoder.transformer."
 
         def lin(key):
-            return (self._c(sd[key + ".weight"]), self._c(sd[key + ".bias"], torch.float32))
+            return (self._cd(sd[key + ".weight"]), self._c(sd[key + ".bias"], torch.float32))
 
         def attn(prefix, pe_side):
             a = {k: lin(f"{prefix}.{k}_proj") for k in ("q", "k", "v", "o")}
             if pe_side:   # projection of the dense PE, added as a batch-broadcast residual
-                a["pe"] = self._c(img_pe @ sd[f"{prefix}.{pe_side}_proj.weight"].t())
+                a["pe"] = self._cd(img_pe @ sd[f"{prefix}.{pe_side}_proj.weight"].t())
             return a
 
         self.dec_layers = []
@@ -200,7 +223,7 @@ class Sam2Hip:
         for nm in ("upscale_conv1", "upscale_conv2"):
             wt = sd[f"mask_decoder.{nm}.weight"]
             ci, co = wt.shape[:2]
-            W[nm] = (self._c(wt.permute(2, 3, 1, 0).reshape(4 * co, 1, ci)), self._c(sd[f"mask_decoder.{nm}.bias"].repeat(4), torch.float32))
+            W[nm] = (self._cd(wt.permute(2, 3, 1, 0).reshape(4 * co, 1, ci)), self._c(sd[f"mask_decoder.{nm}.bias"].repeat(4), torch.float32))
         W["up_ln"] = (self._c(sd["mask_decoder.upscale_layer_norm.weight"], torch.float32), self._c(sd["mask_decoder.upscale_layer_norm.bias"], torch.float32))
         W["hyper"] = [[lin(f"mask_decoder.output_hypernetworks_mlps.{i}.proj_in"), lin(f"mask_decoder.output_hypernetworks_mlps.{i}.layers.0"),
                        lin(f"mask_decoder.output_hypernetworks_mlps.{i}.proj_out")] for i in range(4)]
@@ -229,10 +252,24 @@ class Sam2Hip:
         C0 = hp["embed"][0]
         win0 = hp["windows"][0]
         T = g * g
-        cols = pb.buf((T, 392), self.tdt)
+        # precision "high": every linear's operand is a [rows, 2K] buffer — the producer fills columns [0, K), `dup` copies them to
+        # [K, 2K) — against the [W_hi | W_lo] matrix; "fast": kk(K) = K and `dup` is nothing, the op list is what it always was
+        hi = self.high
+
+        def kk(k):
+            return 2 * k if hi else k
+
+        def dup(buf, rows, k, label):
+            if hi:
+                v = buf.view(1, 1, rows, 2 * k)
+                pb.ew(abi.EW_COPY, Act(v, 1, 1, rows, k, 0), out=Act(v, 1, 1, rows, k, k), label=label + ".dup")
+            return buf
+
+        cols = pb.buf((T, kk(392)), self.tdt)
         order0 = pb.hold(torch.from_numpy(window_order(g, g, win0).astype(np.int32)).to(self.device))
-        pb.im2col(img, cols, 7, 4, 392, row_map=order0, label="patch_im2col")
-        x = pb.gemm(cols, W["pe_w"], T, C0, 392, bias=W["pe_b"], res=W["pos"], label="patch_embed")
+        pb.im2col(img, cols, 7, 4, kk(392), row_map=order0, label="patch_im2col")
+        dup(cols, T, 392, "patch_im2col")
+        x = pb.gemm(cols, W["pe_w"], T, C0, kk(392), bias=W["pe_b"], res=W["pos"], label="patch_embed")
         layout, hs = win0, g
         eps = hp["ln_eps"]
         feats = {}
@@ -246,8 +283,9 @@ class Sam2Hip:
                 m = pb.hold(self._gather_map(hs, hs, layout, win))
                 x = pb.row_gather(x, pb.buf((T, dim), self.tdt), m, T, dim, label=tag + ".relayout")
                 layout = win
-            ln1 = pb.norm(x, pb.buf((T, dim), self.tdt), T, dim, gamma=blk["layer_norm1"][0], beta=blk["layer_norm1"][1], eps=eps, label=tag + ".ln1")
-            qkv = pb.gemm(ln1, blk["qkv"][0], T, 3 * dout, dim, bias=blk["qkv"][1], label=tag + ".qkv")
+            ln1 = pb.norm(x, pb.buf((T, kk(dim)), self.tdt), T, dim, ldy=kk(dim), gamma=blk["layer_norm1"][0], beta=blk["layer_norm1"][1], eps=eps, label=tag + ".ln1")
+            dup(ln1, T, dim, tag + ".ln1")
+            qkv = pb.gemm(ln1, blk["qkv"][0], T, 3 * dout, kk(dim), bias=blk["qkv"][1], label=tag + ".qkv")
             wtok = win * win if win else T
             nwin = T // wtok
             if dim != dout and not blk["pool"]:
@@ -255,7 +293,7 @@ class Sam2Hip:
             if blk["pool"]:
                 if not win:
                     raise ModelError("SAM-2: q-pooling inside a global-attention block is not supported")
-                res_full = pb.gemm(ln1, blk["skip"][0], T, dout, dim, bias=blk["skip"][1], label=tag + ".skip")
+                res_full = pb.gemm(ln1, blk["skip"][0], T, dout, kk(dim), bias=blk["skip"][1], label=tag + ".skip")
                 res = pb.ew(abi.EW_MAXPOOL, Act(res_full.view(nwin, win, win, dout), nwin, win, win, dout), i0=2, i1=2, label=tag + ".skip_pool")
                 qv = Act(qkv.view(nwin, win, win, 3 * dout), nwin, win, win, dout, 0)
                 qp = pb.ew(abi.EW_MAXPOOL, qv, i0=2, i1=2, label=tag + ".q_pool")
@@ -266,15 +304,19 @@ class Sam2Hip:
                 Tq, sq = T, wtok
                 q_t, q_str = qkv, (wtok * 3 * dout, 3 * dout, d)
                 res_t = x
-            o = pb.buf((Tq, dout), self.tdt)
+            o = pb.buf((Tq, kk(dout)), self.tdt)
             kv_str = (wtok * 3 * dout, 3 * dout, d)
-            pb.attention(q_t, qkv, qkv, o, nwin, heads, sq, wtok, d, q_str, kv_str, kv_str, (sq * dout, dout, d),
+            pb.attention(q_t, qkv, qkv, o, nwin, heads, sq, wtok, d, q_str, kv_str, kv_str, (sq * kk(dout), kk(dout), d),
                          1.0 / math.sqrt(d), k_off=dout, v_off=2 * dout, label=tag + ".attn")
-            x1 = pb.gemm(o, blk["proj"][0], Tq, dout, dout, bias=blk["proj"][1], res=res_t, label=tag + ".proj")
-            ln2 = pb.norm(x1, pb.buf((Tq, dout), self.tdt), Tq, dout, gamma=blk["layer_norm2"][0], beta=blk["layer_norm2"][1], eps=eps, label=tag + ".ln2")
-            hdim = blk["fc1"][0].shape[0]
-            h = pb.gemm(ln2, blk["fc1"][0], Tq, hdim, dout, bias=blk["fc1"][1], act=abi.ACT_GELU, label=tag + ".fc1")
-            x = pb.gemm(h, blk["fc2"][0], Tq, dout, hdim, bias=blk["fc2"][1], res=x1, label=tag + ".fc2")
+            dup(o, Tq, dout, tag + ".attn")
+            x1 = pb.gemm(o, blk["proj"][0], Tq, dout, kk(dout), bias=blk["proj"][1], res=res_t, label=tag + ".proj")
+            ln2 = pb.norm(x1, pb.buf((Tq, kk(dout)), self.tdt), Tq, dout, ldy=kk(dout), gamma=blk["layer_norm2"][0], beta=blk["layer_norm2"][1], eps=eps, label=tag + ".ln2")
+            dup(ln2, Tq, dout, tag + ".ln2")
+            hdim = blk["fc1_n"]
+            h = pb.gemm(ln2, blk["fc1"][0], Tq, hdim, kk(dout), bias=blk["fc1"][1], act=abi.ACT_GELU,
+                        out=pb.buf((Tq, 2 * hdim), self.tdt) if hi else None, ldc=kk(hdim), label=tag + ".fc1")
+            dup(h, Tq, hdim, tag + ".fc1")
+            x = pb.gemm(h, blk["fc2"][0], Tq, dout, kk(hdim), bias=blk["fc2"][1], res=x1, label=tag + ".fc2")
             if blk["pool"]:
                 T, hs, layout = Tq, hs // 2, win // 2
             if blk["stage_end"]:
@@ -285,14 +327,20 @@ class Sam2Hip:
 
         def lateral(level, wb, cout):
             xt, Tn, hn, lay, cin = feats[level]
-            y = pb.gemm(xt, wb[0], Tn, cout, cin, bias=wb[1], label=f"neck{level}")
+            if hi:                  # the stage output is a dense [Tn, cin] stream (residual, next block's input): copied twice into the wide operand
+                wide = pb.buf((Tn, 2 * cin), self.tdt)
+                src_v, wide_v = Act(xt.view(1, 1, Tn, cin), 1, 1, Tn, cin), wide.view(1, 1, Tn, 2 * cin)
+                pb.ew(abi.EW_COPY, src_v, out=Act(wide_v, 1, 1, Tn, cin, 0), label=f"neck{level}.wide0")
+                pb.ew(abi.EW_COPY, src_v, out=Act(wide_v, 1, 1, Tn, cin, cin), label=f"neck{level}.wide1")
+                xt = wide
+            y = pb.gemm(xt, wb[0], Tn, cout, kk(cin), bias=wb[1], label=f"neck{level}")
             m = pb.hold(self._gather_map(hn, hn, lay, 0))
             r = pb.act(1, hn, hn, cout)
             pb.row_gather(y, r.t, m, Tn, cout, label=f"neck{level}.to_raster")
             return r
 
         c0 = W["neck0"][0].shape[0]
-        c1 = W["neck1"][0].shape[0]
+        c1 = W["neck1"][0].shape[0]        # (row counts: unaffected by the [hi | lo] column layout)
         feat_s0 = lateral(0, W["neck0"], c0)
         feat_s1 = lateral(1, W["neck1"], c1)
         lat2 = lateral(2, W["neck2"], D)
@@ -319,7 +367,7 @@ class Sam2Hip:
         else:
             k = pb.gemm(k_in, A["k"][0], n * sk, internal, D, bias=A["k"][1], label=tag + ".k")
         v = pb.gemm(v_in, A["v"][0], n * sk, internal, D, bias=A["v"][1], label=tag + ".v")
-        o = pb.buf((n * sq, internal), self.tdt)
+        o = pb.buf((n * sq, internal), self.ddt)
         pb.attention(q, k, v, o, n, heads, sq, sk, d, (sq * internal, internal, d), (sk * internal, internal, d),
                      (sk * internal, internal, d), (sq * internal, internal, d), 1.0 / math.sqrt(d), label=tag + ".attn")
         return o
@@ -327,19 +375,31 @@ class Sam2Hip:
     def _build_decoder(self, n):
         hp, W = self.hp, self.W
         enc = self._encoder()
-        pb = PlanBuilder(self.lib, self.device, self.dtype)
+        pb = PlanBuilder(self.lib, self.device, self.ddtype)
         D = hp["dec_dim"]
         ge = hp["image_size"] // hp["patch"]
         P = ge * ge
         NT = 9
         inner = D // hp["dec_down"]
-        tok0 = pb.buf((n * NT, D), self.tdt)                 # point embeddings (input, also the query PE)
+        tok0 = pb.buf((n * NT, D), self.ddt)                 # point embeddings (input, also the query PE)
         bidx = pb.hold((torch.arange(n * P, dtype=torch.int32) % P).to(self.device))
-        keys = pb.row_gather(enc.src.t, pb.buf((n * P, D), self.tdt), bidx, n * P, D, label="dec.keys_bcast")
+        src, feat_s0, feat_s1 = enc.src, enc.feat_s0, enc.feat_s1
+        if self.high:                                        # the encoder's three outputs (16-bit) enter the fp32 plan through one conversion each
+            src, feat_s0, feat_s1 = (pb.cvt_f32(t, self.dtype, label=f"dec.{nm}_f32") for t, nm in ((src, "src"), (feat_s0, "feat_s0"), (feat_s1, "feat_s1")))
+        keys = pb.row_gather(src.t, pb.buf((n * P, D), self.ddt), bidx, n * P, D, label="dec.keys_bcast")
         queries = tok0
 
         def ln(x, rows, wb, label):
-            return pb.norm(x, pb.buf((rows, D), self.tdt), rows, D, gamma=wb[0], beta=wb[1], eps=1e-5, label=label)
+            return pb.norm(x, pb.buf((rows, D), self.ddt), rows, D, gamma=wb[0], beta=wb[1], eps=1e-5, label=label)
+
+        def up(x, wb, cout, skip, label):
+            """ConvTranspose2d(k=2, s=2) + the skip feature: the conv kernel's pixel-shuffle store in the 16-bit plans, a GEMM over the
+            pixels and a shuffle-add map in the fp32 plan"""
+            if not self.high:
+                return pb.conv2d(x, wb[0], wb[1], 4 * cout, ksize=1, pixel_shuffle=2, res=skip, res_broadcast=True, label=label)
+            rows = x.n * x.h * x.w
+            cols = pb.gemm(x.t, wb[0], rows, 4 * cout, x.c, bias=wb[1], label=label + ".gemm")
+            return pb.shuffle2_add(cols, x.n, x.h, x.w, cout, skip=skip, label=label)
 
         def add_pe(x, label):
             xa = Act(x.view(1, 1, n * NT, D), 1, 1, n * NT, D)
@@ -354,7 +414,7 @@ class Sam2Hip:
                 qin = add_pe(queries, tag + ".sa_pe")
             qk = pb.gemm(qin, sa["qk"][0], n * NT, 2 * D, D, bias=sa["qk"][1], label=tag + ".sa_qk")
             v = pb.gemm(queries, sa["v"][0], n * NT, D, D, bias=sa["v"][1], label=tag + ".sa_v")
-            o = pb.buf((n * NT, D), self.tdt)
+            o = pb.buf((n * NT, D), self.ddt)
             dh = D // hp["dec_heads"]
             pb.attention(qk, qk, v, o, n, hp["dec_heads"], NT, NT, dh, (NT * 2 * D, 2 * D, dh), (NT * 2 * D, 2 * D, dh),
                          (NT * D, D, dh), (NT * D, D, dh), 1.0 / math.sqrt(dh), k_off=D, label=tag + ".sa_attn")
@@ -382,18 +442,16 @@ class Sam2Hip:
         # ---- upscaling (hf:1203-1209) ----------------------------------------------------------------
         ka = Act(keys.view(n, ge, ge, D), n, ge, ge, D)
         c1 = W["upscale_conv1"][0].shape[0] // 4
-        up1 = pb.conv2d(ka, W["upscale_conv1"][0], W["upscale_conv1"][1], 4 * c1, ksize=1, pixel_shuffle=2,
-                        res=enc.feat_s1, res_broadcast=True, label="dec.up1")
+        up1 = up(ka, W["upscale_conv1"], c1, feat_s1, "dec.up1")
         rows1 = n * up1.h * up1.w
-        up1n = pb.norm(up1.t, pb.buf((rows1, c1), self.tdt), rows1, c1, gamma=W["up_ln"][0], beta=W["up_ln"][1], eps=1e-6,
+        up1n = pb.norm(up1.t, pb.buf((rows1, c1), self.ddt), rows1, c1, gamma=W["up_ln"][0], beta=W["up_ln"][1], eps=1e-6,
                        act=abi.ACT_GELU, label="dec.up_ln_gelu")
         c2 = W["upscale_conv2"][0].shape[0] // 4
-        up2 = pb.conv2d(Act(up1n.view(n, up1.h, up1.w, c1), n, up1.h, up1.w, c1), W["upscale_conv2"][0], W["upscale_conv2"][1],
-                        4 * c2, ksize=1, pixel_shuffle=2, res=enc.feat_s0, res_broadcast=True, label="dec.up2")
+        up2 = up(Act(up1n.view(n, up1.h, up1.w, c1), n, up1.h, up1.w, c1), W["upscale_conv2"], c2, feat_s0, "dec.up2")
         up2a = pb.ew(abi.EW_ACT, up2, act=abi.ACT_GELU, label="dec.up2_gelu")
         hl = up2.h
         # ---- hypernetwork MLPs + IoU head on single token rows -------------------------------------------
-        hyper = pb.buf((n, 4, c2), self.tdt)
+        hyper = pb.buf((n, 4, c2), self.ddt)
         for i in range(4):
             (w1, b1), (w2, b2), (w3, b3) = W["hyper"][i]
             t = pb.gemm(queries, w1, n, D, D, lda=NT * D, a_off=(2 + i) * D, bias=b1, act=abi.ACT_RELU, label=f"dec.hyper{i}.0")
@@ -535,7 +593,7 @@ class Sam2Hip:
                 post = self._post_plan(n, h, w)
                 if ticket is None:
                     pre.page.copy_(page.to(self.device))
-                dec.tok0.copy_(torch.from_numpy(self.embed_boxes(boxes, h, w).reshape(n * 9, -1)).to(self.device, self.tdt))
+                dec.tok0.copy_(torch.from_numpy(self.embed_boxes(boxes, h, w).reshape(n * 9, -1)).to(self.device, self.ddt))
                 if ticket is None:
                     pre.run()
                     enc.run(graph=self._graph)

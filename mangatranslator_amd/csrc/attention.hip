@@ -568,7 +568,9 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
   return MTX_OK;
 }
 
+int attn_f32_launch(const mtx_attn_args* a, void* stream, const char** err);      // f32ops.hip
 int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
+  if (a->dtype == MTX_F32) return attn_f32_launch(a, stream, err);
   if (!a->q || !a->k || !a->v || (!a->o && !a->q8)) { *err = "attention: null operand"; return MTX_ERR_INVALID; }
   if (a->q8 != nullptr && (!a->q8_scale || a->batch != 1 || a->d != 128 || a->sq < 1024 || a->sk < 256 || a->ldq8 % 16 || ((size_t)a->q8 & 15) || a->lds_q8 < a->sq)) {
     *err = "attention (MX fp8 output): long-sequence kernel only (d = 128, sq >= 1024, sk >= 256, batch 1), ldq8 % 16 == 0, lds_q8 >= sq"; return MTX_ERR_INVALID; }

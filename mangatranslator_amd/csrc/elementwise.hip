@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(mtx_ew_args p) {
   }
 }
 
+int ew_f32_launch(const mtx_ew_args* a, void* stream, const char** err);      // f32ops.hip
 int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
+  if (a->dtype == MTX_F32) return ew_f32_launch(a, stream, err);
   if (a->kind == MTX_EW_SOFTMAX_ROWS) {
     if (!a->a || !a->y || a->c % 8 || a->lda % 8 || a->ldy % 8) { *err = "softmax_rows: bad layout"; return MTX_ERR_INVALID; }
     const long rows = a->n * a->h * a->w;

@@ -851,9 +851,11 @@ static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool f
   g_last_split[0] = (int)tiles; g_last_split[1] = 1; g_last_split[2] = 0;
 }
 
+int gemm_f32_launch(const mtx_gemm_args* a, void* stream, const char** err);      // f32ops.hip
 int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (!a->a || !a->w || !a->c) { *err = "gemm: null operand"; return MTX_ERR_INVALID; }
   if (a->m < 1 || a->n < 1 || a->k < 1) { *err = "gemm: empty problem"; return MTX_ERR_INVALID; }
+  if (a->dtype == MTX_F32) return gemm_f32_launch(a, stream, err);      // fp32 operands: the vector-ALU path (SAM's high-precision mask decoder)
   const bool f8 = a->in_dtype == MTX_F8;
   if (a->glu_q != nullptr && !f8) { *err = "gemm: the SwiGLU epilogue exists on the fp8 kernel only"; return MTX_ERR_INVALID; }
   if (a->in_dtype != 0 && !f8 && a->in_dtype != a->dtype) { *err = "gemm: in_dtype must be 0, dtype or MTX_F8"; return MTX_ERR_INVALID; }

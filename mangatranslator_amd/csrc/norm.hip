@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
   }
 }
 
+int norm_f32_launch(const mtx_norm_args* a, void* stream, const char** err);      // f32ops.hip
 int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
+  if (a->dtype == MTX_F32) return norm_f32_launch(a, stream, err);
   if (!a->x || (!a->y && !a->q)) { *err = "norm: null operand"; return MTX_ERR_INVALID; }
   if (a->q && (!a->q_scale || a->c % 128 || a->ldq % 8 || a->lds_q < a->rows)) { *err = "norm (fp8 twin): needs q_scale, C % 128 == 0, ldq % 8 == 0, lds_q >= rows"; return MTX_ERR_INVALID; }
   if (a->c % 8 || a->ldx % 8 || a->ldy % 8 || a->c > NORM_MAXCH * 64 * 8 || a->c < 8) { *err = "norm: C must be a multiple of 8, <= 6144"; return MTX_ERR_INVALID; }

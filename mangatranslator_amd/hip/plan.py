@@ -465,6 +465,33 @@ class PlanBuilder:
         self._add(abi.OP_EW, e, label)
         return dst
 
+    # ---- fp32 plans only (csrc/f32ops.hip) -----------------------------------------------------------------------------------------
+    def cvt_f32(self, x: Act, src_dtype: int, label="cvt_f32") -> Act:
+        """fp32 copy of a 16-bit activation (`src_dtype` = its abi dtype)"""
+        assert self.dtype == abi.F32
+        out = self.act(x.n, x.h, x.w, x.c)
+        e = abi.EwArgs()
+        e.a, e.b, e.s, e.y = x.ptr, None, None, out.ptr
+        e.n, e.h, e.w, e.c = x.n, x.h, x.w, x.c
+        e.lda, e.ldb, e.ldy, e.lds = x.ld, 0, out.ld, 0
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_CVT_F32, 0, 0.0, src_dtype, 0, abi.F32
+        self._add(abi.OP_EW, e, label)
+        return out
+
+    def shuffle2_add(self, cols, n, h, w, c, skip: Optional[Act] = None, skip_broadcast: bool = True, label="shuffle2_add") -> Act:
+        """`cols` [n*h*w, 4c]: the four output pixels of every input pixel side by side (a ConvTranspose2d(k=2, s=2) computed as a GEMM) ->
+        [n, 2h, 2w, c] plus an optional skip feature at output resolution (one image for every n when `skip_broadcast`)"""
+        assert self.dtype == abi.F32
+        out = self.act(n, 2 * h, 2 * w, c)
+        e = abi.EwArgs()
+        e.a, e.b, e.s, e.y = _ptr(cols), (skip.ptr if skip is not None else None), None, out.ptr
+        e.n, e.h, e.w, e.c = n, h, w, c
+        e.lda, e.ldb, e.ldy = 4 * c, (skip.ld if skip is not None else 0), out.ld
+        e.lds = 0 if (skip is None or skip_broadcast) else 4 * h * w * skip.ld
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_SHUFFLE2_ADD, 0, 0.0, 0, 0, abi.F32
+        self._add(abi.OP_EW, e, label)
+        return out
+
     def im2col(self, x: Act, dst, k, stride, ldy, row_map=None, label="im2col"):
         e = abi.EwArgs()
         e.a, e.b, e.s, e.y = x.ptr, None, _ptr(row_map), _ptr(dst)

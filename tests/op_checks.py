@@ -666,3 +666,117 @@ def check_memset(lib):
             t[off:off + n] = 0x33
         plan.run()
         _sync(lib)
+
+
+# ---- fp32 plans (csrc/f32ops.hip: SAM's high-precision mask decoder) ------------------------------------------------------------------------
+def check_f32_ops(lib, seed=0):
+    """every op of the fp32 path against torch fp32 on the same values: GEMM (ragged sizes, bias, activation, residual broadcast over a
+    batch, operand offsets and strides, strided batches), attention (strided q / k / v slices of fused projections, few and many keys),
+    LayerNorm (+ GELU), and the element-wise kinds incl. the ConvTranspose pixel shuffle and the 16-bit -> fp32 conversion"""
+    g = torch.Generator().manual_seed(seed)
+    dev = _dev(lib)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    pb = PlanBuilder(lib, dev, abi.F32)
+    checks = []
+    # GEMM 1: ragged, bias + GELU + residual
+    m, n, k = 203, 77, 50
+    a, w, b, r = rnd(m, k), rnd(n, k) / math.sqrt(k), rnd(n), rnd(m, n)
+    out = pb.gemm(pb.const(a), pb.const(w), m, n, k, bias=pb.const(b), act=abi.ACT_GELU, res=pb.const(r))
+    checks.append(("gemm gelu+res", out, F.gelu(a @ w.t() + b) + r))
+    # GEMM 2: batch with a residual shared by every batch (res_bs = 0), alpha
+    bt, m, n, k = 3, 40, 24, 32
+    a, w, r = rnd(bt, m, k), rnd(n, k), rnd(m, n)
+    out = pb.gemm(pb.const(a), pb.const(w), m, n, k, res=pb.const(r), batch=bt, a_bs=m * k, c_bs=m * n, res_bs=0, alpha=0.5)
+    checks.append(("gemm batch shared res", out, 0.5 * torch.einsum("bmk,nk->bmn", a, w) + r))
+    # GEMM 3: rows picked out of a wider matrix (lda, a_off), output into a column slice (ldc, c_off), relu; strided weight batches
+    rows, NT, D, c2 = 5, 9, 16, 8
+    q = rnd(rows * NT, D)
+    w1, b1 = rnd(D, D) / 4, rnd(D)
+    t = pb.gemm(pb.const(q), pb.const(w1), rows, D, D, lda=NT * D, a_off=2 * D, bias=pb.const(b1), act=abi.ACT_RELU)
+    checks.append(("gemm token rows", t, F.relu(q.view(rows, NT, D)[:, 2] @ w1.t() + b1)))
+    hyper = pb.buf((rows, 4, c2), torch.float32, zero=True)
+    w3 = rnd(c2, D)
+    pb.gemm(t, pb.const(w3), rows, c2, D, out=hyper, ldc=4 * c2, c_off=1 * c2)
+    up = rnd(rows, 30, c2)
+    hyp = rnd(rows, 4, c2)
+    masks = pb.gemm(pb.const(up), pb.const(hyp), 30, 4, c2, batch=rows, a_bs=30 * c2, w_bs=4 * c2, c_bs=30 * 4, out_f32=True)
+    checks.append(("gemm per-box weights", masks, torch.einsum("bpc,bkc->bpk", up, hyp)))
+    # attention: q / k from one fused projection (k_off), 70 keys (two key rounds of a wave) and 3 keys
+    for nb, heads, sq, sk, d in ((2, 4, 5, 70, 16), (1, 2, 130, 3, 32), (1, 1, 2, 64, 8)):
+        Dm = heads * d
+        qk, v = rnd(nb * max(sq, sk), 2 * Dm), rnd(nb * sk, Dm)
+        o = pb.buf((nb * sq, Dm), torch.float32, zero=True)
+        L = max(sq, sk)
+        qkT = pb.const(qk)
+        pb.attention(qkT, qkT, pb.const(v), o, nb, heads, sq, sk, d, (L * 2 * Dm, 2 * Dm, d), (L * 2 * Dm, 2 * Dm, d),
+                     (sk * Dm, Dm, d), (sq * Dm, Dm, d), 1.0 / math.sqrt(d), k_off=Dm)
+        qq = qk.view(nb, L, 2, heads, d)[:, :sq, 0].transpose(1, 2)
+        kk_ = qk.view(nb, L, 2, heads, d)[:, :sk, 1].transpose(1, 2)
+        vv = v.view(nb, sk, heads, d).transpose(1, 2)
+        checks.append((f"attention {sq}x{sk} d{d}", o, F.scaled_dot_product_attention(qq, kk_, vv).transpose(1, 2).reshape(nb * sq, Dm)))
+    # LayerNorm (+ GELU), row stride wider than C
+    rows, c = 37, 200
+    x, gm, bt_ = rnd(rows, 256) * 3 + 1, rnd(c), rnd(c)
+    y = pb.norm(pb.const(x), pb.buf((rows, c), torch.float32), rows, c, ldx=256, gamma=pb.const(gm), beta=pb.const(bt_), eps=1e-5, act=abi.ACT_GELU)
+    checks.append(("layernorm gelu", y, F.gelu(F.layer_norm(x[:, :c], (c,), gm, bt_, 1e-5))))
+    # element-wise kinds
+    n_, h_, w_, c_ = 2, 3, 5, 8
+    xa, xb = rnd(n_, h_, w_, c_), rnd(n_, h_, w_, c_)
+    A, B = Act(pb.const(xa), n_, h_, w_, c_), Act(pb.const(xb), n_, h_, w_, c_)
+    checks.append(("add", pb.ew(abi.EW_ADD, A, b=B).t, xa + xb))
+    checks.append(("gelu", pb.ew(abi.EW_ACT, A, act=abi.ACT_GELU).t, F.gelu(xa)))
+    idx = torch.tensor([4, 0, 3, 3, 1], dtype=torch.int32)
+    src = rnd(6, 16)
+    checks.append(("row gather", pb.row_gather(pb.const(src), pb.buf((5, 16), torch.float32), pb.hold(idx.to(dev)), 5, 16), src[idx.long()]))
+    cols = rnd(n_, h_, w_, 4 * c_)
+    skip = rnd(1, 2 * h_, 2 * w_, c_)
+    want = cols.view(n_, h_, w_, 2, 2, c_).permute(0, 1, 3, 2, 4, 5).reshape(n_, 2 * h_, 2 * w_, c_) + skip
+    outS = pb.act(n_, 2 * h_, 2 * w_, c_)
+    e = abi.EwArgs()
+    colsT = pb.const(cols)
+    skipT = pb.const(skip)
+    e.a, e.b, e.s, e.y = colsT.data_ptr(), skipT.data_ptr(), None, outS.ptr
+    e.n, e.h, e.w, e.c = n_, h_, w_, c_
+    e.lda, e.ldb, e.ldy, e.lds = 4 * c_, c_, c_, 0
+    e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_SHUFFLE2_ADD, 0, 0.0, 0, 0, abi.F32
+    pb._add(abi.OP_EW, e, "shuffle2_add")
+    checks.append(("pixel shuffle + broadcast skip", outS.t, want))
+    for src_dt, code in ((torch.float16, abi.F16), (torch.bfloat16, abi.BF16)):
+        x16 = rnd(1, 2, 3, 16).to(src_dt)
+        y32 = pb.act(1, 2, 3, 16)
+        e = abi.EwArgs()
+        x16d = pb.const(x16)
+        e.a, e.b, e.s, e.y = x16d.data_ptr(), None, None, y32.ptr
+        e.n, e.h, e.w, e.c = 1, 2, 3, 16
+        e.lda, e.ldb, e.ldy, e.lds = 16, 0, 16, 0
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_CVT_F32, 0, 0.0, code, 0, abi.F32
+        pb._add(abi.OP_EW, e, "cvt")
+        checks.append((f"cvt {src_dt}", y32.t, x16.float()))
+    _run(pb)
+    worst = 0.0
+    for name, got, want in checks:
+        got, want = got.float().cpu().reshape(want.shape), want.float()
+        err = ((got - want).abs().max() / want.abs().max().clamp_min(1e-6)).item()
+        assert err < 2e-5, f"fp32 op '{name}': rel err {err}"
+        worst = max(worst, err)
+    return worst
+
+
+def check_hi_lo_weights(lib, dtype=abi.F16, m=300, n=96, k=144, seed=0):
+    """`Sam2Hip(precision="high")`'s weight trick at op level: W = W_hi + W_lo in the storage type, one GEMM over K' = 2K of [x | x] against
+    [W_hi | W_lo] with fp32 accumulation and fp32 output — against x @ W^T in float64 the error falls from the weights' rounding (2^-12
+    relative per weight) to fp32 accumulation noise"""
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    x = torch.randn(m, k, generator=g).to(td)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    ref = (x.double() @ w.double().t()).float()
+    w_hi = w.to(td)
+    w_lo = (w - w_hi.float()).to(td)
+    pb = PlanBuilder(lib, dev, dtype)
+    fast = pb.gemm(pb.const(x), pb.const(w_hi), m, n, k, out_f32=True)
+    high = pb.gemm(pb.const(torch.cat([x, x], 1)), pb.const(torch.cat([w_hi, w_lo], 1)), m, n, 2 * k, out_f32=True)
+    _run(pb)
+    e_fast, e_high = _relerr(fast.cpu(), ref), _relerr(high.cpu(), ref)
+    assert e_high < e_fast / 50 and e_high < 2e-6, (e_fast, e_high)
+    return e_fast, e_high

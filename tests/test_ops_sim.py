@@ -199,3 +199,12 @@ def test_producers_write_their_fp8_twins(emu_lib):
 
 def test_memset_op(emu_lib):
     oc.check_memset(emu_lib)
+
+
+def test_f32_ops(emu_lib):
+    assert oc.check_f32_ops(emu_lib) < 2e-5
+
+
+def test_hi_lo_weight_pairs(emu_lib):
+    e_fast, e_high = oc.check_hi_lo_weights(emu_lib)
+    assert e_fast > 1e-5            # the weights' rounding is what the fast form is left with

@@ -29,6 +29,19 @@ def test_sam2_tiny_f16_storage(emu_lib):
     assert err < 0.01
 
 
+def test_sam2_tiny_high_precision(emu_lib):
+    """precision "high": trunk / neck linears with hi + lo weight pairs (one GEMM over [x | x] x [W_hi | W_lo]), prompt encoder, two-way
+    transformer and mask head as fp32 plans (csrc/f32ops.hip): same masks, and the logit error against the fp32 oracle drops by more
+    than half on the same page and boxes (at Hiera-L depth the weights' rounding is a larger share of the total: DESIGN.md §3)"""
+    from mangatranslator_amd.hip import abi
+    sc.check_sam2(emu_lib, "cpu", "tiny_test", h=300, w=200, n_boxes=3, seed=0, dtype=abi.F16, calibrated=True)
+    fast = sc.stats["logit_abs_err_rms"]
+    sc.check_sam2(emu_lib, "cpu", "tiny_test", h=300, w=200, n_boxes=3, seed=0, dtype=abi.F16, calibrated=True, precision="high")
+    high = sc.stats["logit_abs_err_rms"]
+    assert high < 0.5 * fast, (fast, high)                     # logit units at std 5.9: rms 0.0117 -> 0.0041, page mask mismatch 6.8e-4 -> 2.7e-4
+    assert sc.stats["decided_pixels_wrong"] == 0 and sc.stats["wrong_beyond_1_logit"] == 0
+
+
 def test_manager_loads_sam_in_f16_and_falls_back_to_bf16(emu_lib, tmp_path, monkeypatch):
     """reference model_manager.py:982-1010: (processor, model).  The loader takes f16 storage when the f16 and bf16 models agree on the
     load-time probe, bf16 otherwise (a checkpoint with an activation beyond 65504 saturates in f16 and must not be served that way)."""
@@ -50,8 +63,15 @@ def test_manager_loads_sam_in_f16_and_falls_back_to_bf16(emu_lib, tmp_path, monk
         sd = {k: v.contiguous() for k, v in model.state_dict().items()}
         save_file(sd, str(root / "model.safetensors"))
         proc, shim = m.load_sam2()
-        assert shim.hip.dtype == abi.F16
+        assert shim.hip.dtype == abi.F16 and not shim.hip.high
         m.unload_model(mm.ModelType.SAM2)
+        m.sam_precision = "high"                                   # hi + lo trunk weights, fp32 mask decoder, on the storage type the probe settled on
+        proc, shim = m.load_sam2()
+        assert shim.hip.dtype == abi.F16 and shim.hip.high and shim.hip.ddtype == abi.F32
+        with m.front_replica(1):
+            assert m.load_sam2()[1].hip.high                         # a replica follows set 0
+        m.unload_model(mm.ModelType.SAM2)
+        m.sam_precision = "fast"
         # blow up one MLP of the trunk: its hidden activations leave the f16 range
         key = next(k for k in sd if "backbone" in k and "mlp" in k and k.endswith("proj_in.weight"))
         sd[key] = sd[key] * 3.0e5

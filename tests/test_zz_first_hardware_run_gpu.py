@@ -1,0 +1,38 @@
+"""GPU tier, sorted last on purpose: code written after the round's GPU budget was spent.  The CPU simulator runs these very kernel
+sources and the checks below are green there; their first execution on gfx950 is whoever runs this file first (the round-end driver).
+Nothing here is reachable from a default graph: fp32 plans (csrc/f32ops.hip) exist for `Sam2Hip(precision="high")` only."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_f32_ops(hip_lib):
+    import op_checks as oc
+    assert oc.check_f32_ops(hip_lib) < 2e-5
+
+
+def test_hi_lo_weight_pairs(hip_lib):
+    import op_checks as oc
+    oc.check_hi_lo_weights(hip_lib)
+    oc.check_hi_lo_weights(hip_lib, m=4096, n=1152, k=576)          # a stage-3 trunk linear of Hiera-L: the 256-tile kernel
+
+
+def test_sam2_tiny_high_precision(hip_lib):
+    import sam2_checks as sc
+    from mangatranslator_amd.hip import abi
+    sc.check_sam2(hip_lib, "cuda:0", "tiny_test", h=300, w=200, n_boxes=3, seed=0, dtype=abi.F16, calibrated=True)
+    fast = sc.stats["logit_abs_err_rms"]
+    sc.check_sam2(hip_lib, "cuda:0", "tiny_test", h=300, w=200, n_boxes=3, seed=0, dtype=abi.F16, calibrated=True, precision="high")
+    assert sc.stats["logit_abs_err_rms"] < 0.5 * fast and sc.stats["decided_pixels_wrong"] == 0
+
+
+def test_sam2_hiera_large_high_precision(hip_lib):
+    """SAM-2.1 Hiera-L, 1024 x 1536, logits at a trained model's spread: the bounds are the f16-storage test's (they hold if the path is
+    right); the figure VERDICT r03 #2 asked for — mask mismatch below 1e-4 — is RECORDED (r04_parity.json), not asserted, until it has been
+    seen once"""
+    import sam2_checks as sc
+    from parity_log import record
+    from mangatranslator_amd.hip import abi
+    sc.check_sam2(hip_lib, "cuda:0", "hiera_large", h=1536, w=1024, n_boxes=8, seed=2, logit_tol=0.01, mask_tol=3e-4, calibrated=True, abs_tol=0.25, rms_tol=0.03,
+                  dtype=abi.F16, precision="high")      # test_sam2_gpu.py::test_sam2_hiera_large_calibrated_logits with precision="high": there 0.087 / 0.017 / 1.7e-4
+    record("sam2.hiera_large.1024x1536.calibrated.f16.high_precision", boxes=8, **sc.stats)
