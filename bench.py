@@ -101,6 +101,9 @@ def parse():
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-traffic", action="store_true", help=argparse.SUPPRESS)       # (round 3's opt-in; the counter child now runs by default)
+    ap.add_argument("--sam-precision", choices=("fast", "high"), default="fast",
+                    help="SAM-2.1 arithmetic: fast = 16-bit storage as measured all round; high = hi + lo trunk weights and an fp32 mask decoder "
+                         "(core/ml/sam2.py; for the A/B of the segment stage's time once it has run on hardware)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the counter child that fills roofline.traffic: after the timed region rank 0 (at --gpus 1) re-executes this command's inpaint "
                          "(or upscale) stage under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two passes, --kernel-trace only) on a DiT cut to "
@@ -315,7 +318,7 @@ def main():
             sam_sd = {k: torch.empty(shp) for k, shp in synth_sam.sam2_shapes(sam_cfg).items()}
         if world > 1:
             sam_sd = broadcast_state_dict(sam_sd, rank, world, device)
-        make_sam = lambda: Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph, dtype=abi_f16)        # f16 storage: what ModelManager.load_sam2 serves (bf16 only when a checkpoint leaves the f16 range)
+        make_sam = lambda: Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph, dtype=abi_f16, precision=args.sam_precision)        # f16 storage: what ModelManager.load_sam2 serves (bf16 only when a checkpoint leaves the f16 range)
         sam = make_sam()
     inpainter, flux = None, None
     klein = args.inpainter.startswith("klein")

@@ -48,7 +48,8 @@ typedef enum mtx_status {
 
 /* MTX_F32 as the `dtype` of mtx_gemm / mtx_attention / mtx_norm / mtx_elementwise (late round 4): every operand and the result are fp32 and
  * the arithmetic runs on the vector ALUs (csrc/f32ops.hip) — GEMM with bias / act / res / strided batches (no gate, glu or fp8 operands),
- * attention with head dim 8 / 16 / 32 / 64, LayerNorm (+ act), element-wise ADD / MUL / ACT / COPY / ROW_GATHER / SHUFFLE2_ADD / CVT_F32.
+ * attention with head dim 8 / 16 / 32 / 64, LayerNorm (+ act), element-wise ADD / MUL / ACT / COPY / ROW_GATHER / SHUFFLE2_ADD / CVT_F32 /
+ * CVT_16 (fp32 -> 16-bit, the bridge back into a 16-bit GEMM).
  * Small problems only: SAM-2.1's mask decoder under Sam2Hip(precision="high").  Simulator-verified; not yet run on hardware. */
 typedef enum mtx_dtype { MTX_BF16 = 0, MTX_F16 = 1, MTX_F32 = 2, MTX_U8 = 3, MTX_I32 = 4,
                          MTX_F8 = 5 /* OCP e4m3fn bytes with MX block scales, see mtx_quant_args */ } mtx_dtype;
@@ -208,6 +209,7 @@ typedef enum mtx_ew_kind {
                                ConvTranspose2d(k = 2, s = 2) done as a GEMM); y[n, 2h + dy, 2w + dx, ch] = a[...] + b[(n), 2h + dy, 2w + dx, ch] with b
                                optional and lds = its per-sample stride (0 = one image for every n) — SAM's mask upscaling                        */
   MTX_EW_CVT_F32 = 17,    /* fp32 only: y = (float) a, a of the 16-bit type i0 (MTX_F16 / MTX_BF16)                                              */
+  MTX_EW_CVT_16 = 18,     /* fp32 only: y = a rounded to the 16-bit type i0, written i1 (1..4) times side by side: y[px][j * c + ch]             */
   MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
                              i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then
                              rotary on interleaved pairs with b = fp32 [rows][d] cos|sin table laid out as

@@ -229,6 +229,21 @@ __global__ __launch_bounds__(256) void cvt_f32_kernel(mtx_ew_args p) {
   }
 }
 
+// fp32 -> 16-bit storage (i0 = the destination's mtx_dtype), i1 copies side by side: y[px][j * c + ch] for j < i1 — the [x | x] operand of a
+// linear whose weights are [W_hi | W_lo] pairs, written by the conversion itself
+template <typename T>
+__global__ __launch_bounds__(256) void cvt_16_kernel(mtx_ew_args p) {
+  const long pixels = p.n * p.h * p.w, total = pixels * p.c;
+  const float* A = reinterpret_cast<const float*>(p.a);
+  T* Y = reinterpret_cast<T*>(p.y);
+  const int copies = p.i1 < 1 ? 1 : p.i1;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long c = idx % p.c, px = idx / p.c;
+    const T v = from_f32<T>(A[px * p.lda + c]);
+    for (int j = 0; j < copies; ++j) Y[px * p.ldy + j * p.c + c] = v;
+  }
+}
+
 int ew_f32_launch(const mtx_ew_args* a, void* stream, const char** err) {
   if (!a->a || !a->y) { *err = "elementwise f32: null operand"; return MTX_ERR_INVALID; }
   const long total = a->n * a->h * a->w * a->c;
@@ -247,6 +262,12 @@ int ew_f32_launch(const mtx_ew_args* a, void* stream, const char** err) {
       if (a->i0 == MTX_F16) MTX_LAUNCH(cvt_f32_kernel<_Float16>, grid, dim3(256), 0, stream, *a);
       else if (a->i0 == MTX_BF16) MTX_LAUNCH(cvt_f32_kernel<__bf16>, grid, dim3(256), 0, stream, *a);
       else { *err = "elementwise f32: CVT source must be f16 or bf16"; return MTX_ERR_INVALID; }
+      return MTX_OK;
+    case MTX_EW_CVT_16:
+      if (a->i1 > 4 || a->ldy < (a->i1 < 1 ? 1 : a->i1) * a->c) { *err = "elementwise f32: CVT_16 writes at most four copies and needs ldy >= copies * c"; return MTX_ERR_INVALID; }
+      if (a->i0 == MTX_F16) MTX_LAUNCH(cvt_16_kernel<_Float16>, grid, dim3(256), 0, stream, *a);
+      else if (a->i0 == MTX_BF16) MTX_LAUNCH(cvt_16_kernel<__bf16>, grid, dim3(256), 0, stream, *a);
+      else { *err = "elementwise f32: CVT_16 destination must be f16 or bf16"; return MTX_ERR_INVALID; }
       return MTX_OK;
     default: *err = "elementwise f32: op kind is not part of the fp32 path"; return MTX_ERR_UNSUPPORTED;
   }

@@ -360,7 +360,7 @@ class PlanBuilder:
 
     def norm(self, x, y, rows, c, ldx=None, ldy=None, gamma=None, beta=None, eps=1e-6, kind=0,
              mod_scale=None, mod_shift=None, rows_per=0, ldmod=0, x_off=0, y_off=0, act=abi.ACT_NONE,
-             label="norm", q8=None, q_row_off=0, lds_q=0):
+             label="norm", q8=None, q_row_off=0, lds_q=0, dtype=None):
         """q8 = (q bytes [R, c], scale plane [c / 128, lds_q]): also (or, with y None, only) the MX fp8 twin of the result, rows landing
         at q_row_off (include/mtx_hip.h mtx_norm_args.q)"""
         a = abi.NormArgs()
@@ -372,7 +372,7 @@ class PlanBuilder:
         a.mod_scale, a.mod_shift = _ptr(mod_scale), _ptr(mod_shift)
         a.rows, a.c, a.ldx, a.ldy = rows, c, (ldx or c), (ldy or c)
         a.rows_per, a.ldmod = rows_per, ldmod
-        a.eps, a.kind, a.dtype, a.act = eps, kind, self.dtype, act
+        a.eps, a.kind, a.dtype, a.act = eps, kind, (self.dtype if dtype is None else dtype), act      # dtype = abi.F32: an fp32 op inside a 16-bit plan
         self._add(abi.OP_NORM, a, label)
         return y
 
@@ -389,7 +389,7 @@ class PlanBuilder:
         return out
 
     def ew(self, kind, a_: Act, b: Optional[Act] = None, s=None, out: Optional[Act] = None, lds=0,
-           act=abi.ACT_NONE, act_param=0.0, i0=0, i1=0, label="ew") -> Act:
+           act=abi.ACT_NONE, act_param=0.0, i0=0, i1=0, label="ew", dtype=None) -> Act:
         if out is None:
             if kind == abi.EW_UPSAMPLE2X:
                 out = self.act(a_.n, a_.h * 2, a_.w * 2, a_.c)
@@ -404,7 +404,7 @@ class PlanBuilder:
         e.a, e.b, e.s, e.y = a_.ptr, (b.ptr if b is not None else None), _ptr(s), out.ptr
         e.n, e.h, e.w, e.c = a_.n, a_.h, a_.w, a_.c
         e.lda, e.ldb, e.ldy, e.lds = a_.ld, (b.ld if b is not None else 0), out.ld, lds
-        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = kind, act, act_param, i0, i1, self.dtype
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = kind, act, act_param, i0, i1, (self.dtype if dtype is None else dtype)
         self._add(abi.OP_EW, e, label)
         return out
 
@@ -455,21 +455,31 @@ class PlanBuilder:
         self._add(abi.OP_IMG, a, label)
         return dst
 
-    def row_gather(self, src, dst, index_i32, rows, c, lda=None, ldy=None, label="row_gather"):
+    def row_gather(self, src, dst, index_i32, rows, c, lda=None, ldy=None, label="row_gather", dtype=None):
         """dst[r, :c] = src[index[r], :c]  (token re-ordering between window layouts)"""
         e = abi.EwArgs()
         e.a, e.b, e.s, e.y = _ptr(src), None, _ptr(index_i32), _ptr(dst)
         e.n, e.h, e.w, e.c = 1, 1, rows, c
         e.lda, e.ldb, e.ldy, e.lds = (lda or c), 0, (ldy or c), 0
-        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_ROW_GATHER, 0, 0.0, 0, 0, self.dtype
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_ROW_GATHER, 0, 0.0, 0, 0, (self.dtype if dtype is None else dtype)
         self._add(abi.OP_EW, e, label)
         return dst
 
-    # ---- fp32 plans only (csrc/f32ops.hip) -----------------------------------------------------------------------------------------
+    # ---- fp32 ops (csrc/f32ops.hip) --------------------------------------------------------------------------------------------------
+    def cvt16(self, src_f32, dst16, rows, c, copies=1, lda=None, label="cvt16"):
+        """dst16 [rows, >= copies * c] (this builder's 16-bit type) <- src_f32 [rows, c] rounded, written `copies` times side by side"""
+        assert self.dtype in (abi.F16, abi.BF16) and src_f32.dtype == torch.float32 and dst16.dtype == self.tdtype
+        e = abi.EwArgs()
+        e.a, e.b, e.s, e.y = _ptr(src_f32), None, None, _ptr(dst16)
+        e.n, e.h, e.w, e.c = 1, 1, rows, c
+        e.lda, e.ldb, e.ldy, e.lds = (lda or c), 0, dst16.shape[-1], 0
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_CVT_16, 0, 0.0, self.dtype, copies, abi.F32
+        self._add(abi.OP_EW, e, label)
+        return dst16
+
     def cvt_f32(self, x: Act, src_dtype: int, label="cvt_f32") -> Act:
         """fp32 copy of a 16-bit activation (`src_dtype` = its abi dtype)"""
-        assert self.dtype == abi.F32
-        out = self.act(x.n, x.h, x.w, x.c)
+        out = self.act(x.n, x.h, x.w, x.c) if self.dtype == abi.F32 else Act(self.buf((x.n, x.h, x.w, x.c), torch.float32), x.n, x.h, x.w, x.c)
         e = abi.EwArgs()
         e.a, e.b, e.s, e.y = x.ptr, None, None, out.ptr
         e.n, e.h, e.w, e.c = x.n, x.h, x.w, x.c

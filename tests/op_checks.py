@@ -752,6 +752,18 @@ def check_f32_ops(lib, seed=0):
         e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_CVT_F32, 0, 0.0, code, 0, abi.F32
         pb._add(abi.OP_EW, e, "cvt")
         checks.append((f"cvt {src_dt}", y32.t, x16.float()))
+    # fp32 ops inside a 16-bit plan: LayerNorm on an fp32 stream, its result rounded into both halves of a wide 16-bit operand
+    pb16 = PlanBuilder(lib, dev, abi.F16)
+    x32 = rnd(21, 40)
+    y32 = pb16.norm(pb16.const(x32), pb16.buf((21, 40), torch.float32), 21, 40, eps=1e-6, dtype=abi.F32)
+    wide = pb16.cvt16(y32, pb16.buf((21, 80), torch.float16), 21, 40, copies=2)
+    s32 = pb16.buf((21, 40), torch.float32)
+    pb16.ew(abi.EW_ADD, Act(y32.view(1, 1, 21, 40), 1, 1, 21, 40), b=Act(pb16.const(x32).view(1, 1, 21, 40), 1, 1, 21, 40), out=Act(s32.view(1, 1, 21, 40), 1, 1, 21, 40), dtype=abi.F32)
+    _run(pb16)
+    want_ln = F.layer_norm(x32, (40,), eps=1e-6)
+    assert torch.equal(wide.cpu()[:, :40], wide.cpu()[:, 40:]) and torch.equal(wide.cpu()[:, :40], y32.cpu().to(torch.float16))
+    checks.append(("layernorm fp32 in a 16-bit plan", y32, want_ln))
+    checks.append(("fp32 add in a 16-bit plan", s32, want_ln + x32))
     _run(pb)
     worst = 0.0
     for name, got, want in checks:

@@ -1,5 +1,6 @@
 """SAM-2.1 Hiera-L at 1024x1536 with trained-model logit spread: logit error and mask mismatch of the HIP path against the fp32 oracle for
-bf16 and f16 storage (round 4: which precision the `> 0` masks need; tests/sam2_checks.py does the comparison).
+bf16 and f16 storage, each also with precision "high" (round 4: which precision the `> 0` masks need; tests/sam2_checks.py does the comparison;
+the timing of the segment stage with precision "high" is `bench.py --config 2 --sam-precision high`).
     python tools/sam_dtype_probe.py [out.json]"""
 import json
 import sys
@@ -20,9 +21,8 @@ def main():
     lib = get_library()
     lib.init(0)
     out = {}
-    variants = [("bf16", dict(dtype=abi.BF16)), ("f16", dict(dtype=abi.F16))]
-    if "--f32-tail" in sys.argv:
-        variants += [("bf16+f32tail", dict(dtype=abi.BF16, f32_tail=True)), ("f16+f32tail", dict(dtype=abi.F16, f32_tail=True))]
+    variants = [("bf16", dict(dtype=abi.BF16)), ("f16", dict(dtype=abi.F16)),
+                ("f16 high", dict(dtype=abi.F16, precision="high")), ("bf16 high", dict(dtype=abi.BF16, precision="high"))]      # hi + lo trunk weights, fp32 mask decoder
     for name, kw in variants:
         t = time.perf_counter()
         try:
