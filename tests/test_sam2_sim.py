@@ -54,6 +54,9 @@ def test_manager_loads_sam_in_f16_and_falls_back_to_bf16(emu_lib, tmp_path, monk
     monkeypatch.setattr(libmod, "_lib", emu_lib)
     monkeypatch.setattr(mm, "_model_manager", None)
     monkeypatch.setattr(mm.ModelManager, "_instance", None)
+    from mangatranslator_amd.core.ml.sam2 import Sam2Hip
+    probe = Sam2Hip.probe_logits
+    monkeypatch.setattr(Sam2Hip, "probe_logits", lambda self, size=96: probe(self, size))      # a smaller probe page: the simulator's time
     m = mm.get_model_manager()
     try:
         root = tmp_path / "sam"
