@@ -2,7 +2,8 @@
 //
 // A tiny SIMT simulator that lets the gfx950 kernel sources under mangatranslator_amd/csrc be
 // compiled for the host (clang++ -x c++ -DMTX_EMU) and executed on the CPU: every HIP thread is
-// a ucontext fiber, a workgroup is a round-robin scheduler over its fibers, __syncthreads() and
+// a fiber (own stack, a hand-written register switch on x86-64 — glibc's swapcontext costs two
+// signal-mask system calls per switch — ucontext elsewhere), a workgroup is a round-robin scheduler over its fibers, __syncthreads() and
 // the wave-level primitives (MFMA, shuffles) are rendezvous points.  It exists so the index
 // arithmetic of the kernels (LDS swizzles, halo tiles, MFMA fragment maps, epilogues) can be
 // checked in the CPU-only test tier (`pytest -m "not gpu"`), where no MI355X is present.
@@ -11,7 +12,9 @@
 // libmtx_hip.so and raises ModelError when that is missing; the simulator library
 // (tests/emu/libmtx_emu.so) is opened by tests alone, through an explicit test-only entry point.
 #pragma once
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -46,8 +49,17 @@ constexpr int kWave = 64;
 constexpr int kMaxThreads = 1024;
 constexpr size_t kStack = 96 * 1024;
 
+#if defined(__x86_64__)
+struct Ctx { void* sp = nullptr; };                 // everything else of a suspended fiber lives on its stack
+extern "C" void emu_switch(Ctx* from, Ctx* to);     // emu_hip.cpp: callee-saved registers + control words, no signal mask
+inline void ctx_switch(Ctx& from, Ctx& to) { emu_switch(&from, &to); }
+#else
+typedef ucontext_t Ctx;
+inline void ctx_switch(Ctx& from, Ctx& to) { swapcontext(&from, &to); }
+#endif
+
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   dim3 tid;
   int lin = 0;
   bool done = false;
@@ -67,7 +79,7 @@ struct Block {
   int cur = 0;
   int bar_count = 0;
   unsigned bar_gen = 0;
-  ucontext_t main_ctx;
+  Ctx main_ctx;
   std::vector<Fiber> fibers;
   std::vector<WaveState> waves;
   char* dyn_smem = nullptr;
@@ -76,7 +88,7 @@ struct Block {
 
 extern thread_local Block* B;
 
-inline void yield() { swapcontext(&B->fibers[B->cur].ctx, &B->main_ctx); }
+inline void yield() { ctx_switch(B->fibers[B->cur].ctx, B->main_ctx); }
 
 inline void syncthreads() {
   unsigned g = B->bar_gen;
