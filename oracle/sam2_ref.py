@@ -33,6 +33,13 @@ def make_config(size: str = "tiny_test"):
                                 window_positional_embedding_background_size=[7, 7])
         vc = Sam2VisionConfig(backbone_config=bb, backbone_channel_list=[1152, 576, 288, 144])
         return Sam2Config(vision_config=vc)
+    if size == "large_dims_test":  # Hiera-L's channel widths, head counts (head dim 72) and windows on a 256x256 input with [1, 1, 2, 1] blocks:
+        bb = Sam2HieraDetConfig(hidden_size=144, num_attention_heads=2, image_size=[256, 256], blocks_per_stage=[1, 1, 2, 1],      # the real GEMM K / N sizes and
+                                embed_dim_per_stage=[144, 288, 576, 1152], num_attention_heads_per_stage=[2, 4, 8, 16],           # strides at a size the simulator runs
+                                window_size_per_stage=[8, 4, 16, 8], global_attention_blocks=[3],
+                                window_positional_embedding_background_size=[7, 7])
+        vc = Sam2VisionConfig(backbone_config=bb, backbone_channel_list=[1152, 576, 288, 144], backbone_feature_sizes=[[64, 64], [32, 32], [16, 16]])
+        return Sam2Config(vision_config=vc, prompt_encoder_config=Sam2PromptEncoderConfig(image_size=256), mask_decoder_config=Sam2MaskDecoderConfig())
     if size == "tiny_test":        # 256x256 input, every block flavour present (window / q-pool / global)
         bb = Sam2HieraDetConfig(hidden_size=16, num_attention_heads=1, image_size=[256, 256], blocks_per_stage=[1, 2, 3, 2],
                                 embed_dim_per_stage=[16, 32, 64, 128], num_attention_heads_per_stage=[1, 2, 4, 8],

@@ -53,6 +53,17 @@ def test_sam2_small_high_precision(emu_lib):
     assert sc.stats["decided_pixels_wrong"] == 0 and sc.stats["wrong_beyond_1_logit"] == 0
 
 
+def test_sam2_hiera_large_dims_high_precision(emu_lib):
+    """Hiera-L's own channel widths (144 / 288 / 576 / 1152), head dim 72, windows and decoder on a 256-pixel input with [1, 1, 2, 1] blocks:
+    the GEMM shapes (K' = 288 ... 9216), operand strides and attention head size of the real model, at a size the simulator runs"""
+    from mangatranslator_amd.hip import abi
+    sc.check_sam2(emu_lib, "cpu", "large_dims_test", h=300, w=200, n_boxes=3, seed=0, dtype=abi.F16, calibrated=True)
+    fast = sc.stats["logit_abs_err_rms"]
+    sc.check_sam2(emu_lib, "cpu", "large_dims_test", h=300, w=200, n_boxes=3, seed=0, dtype=abi.F16, calibrated=True, precision="high")
+    assert sc.stats["logit_abs_err_rms"] < 0.5 * fast, (fast, sc.stats["logit_abs_err_rms"])
+    assert sc.stats["decided_pixels_wrong"] == 0 and sc.stats["wrong_beyond_1_logit"] == 0
+
+
 def test_manager_loads_sam_in_f16_and_falls_back_to_bf16(emu_lib, tmp_path, monkeypatch):
     """reference model_manager.py:982-1010: (processor, model).  The loader takes f16 storage when the f16 and bf16 models agree on the
     load-time probe, bf16 otherwise (a checkpoint with an activation beyond 65504 saturates in f16 and must not be served that way)."""
