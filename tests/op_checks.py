@@ -787,8 +787,11 @@ def check_hi_lo_weights(lib, dtype=abi.F16, m=300, n=96, k=144, seed=0):
     w_lo = (w - w_hi.float()).to(td)
     pb = PlanBuilder(lib, dev, dtype)
     fast = pb.gemm(pb.const(x), pb.const(w_hi), m, n, k, out_f32=True)
-    high = pb.gemm(pb.const(torch.cat([x, x], 1)), pb.const(torch.cat([w_hi, w_lo], 1)), m, n, 2 * k, out_f32=True)
+    xx, ww = pb.const(torch.cat([x, x], 1)), pb.const(torch.cat([w_hi, w_lo], 1))
+    high = pb.gemm(xx, ww, m, n, 2 * k, out_f32=True)
+    high16 = pb.gemm(xx, ww, m, n, 2 * k)                 # 16-bit output: the form the qkv / fc1 linears use (large shapes: the 256-tile kernel)
     _run(pb)
     e_fast, e_high = _relerr(fast.cpu(), ref), _relerr(high.cpu(), ref)
     assert e_high < e_fast / 50 and e_high < 2e-6, (e_fast, e_high)
+    assert _relerr(high16.cpu(), ref) < TOL[dtype]
     return e_fast, e_high

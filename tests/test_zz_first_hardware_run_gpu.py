@@ -14,7 +14,7 @@ def test_f32_ops(hip_lib):
 def test_hi_lo_weight_pairs(hip_lib):
     import op_checks as oc
     oc.check_hi_lo_weights(hip_lib)
-    oc.check_hi_lo_weights(hip_lib, m=4096, n=1152, k=576)          # a stage-3 trunk linear of Hiera-L: the 256-tile kernel
+    oc.check_hi_lo_weights(hip_lib, m=4096, n=2304, k=576)          # Hiera-L stage 3, fc1: the 256-tile kernel takes the 16-bit-output form (K' = 1152)
 
 
 def test_sam2_tiny_high_precision(hip_lib):
