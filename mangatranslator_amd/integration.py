@@ -17,9 +17,30 @@ HOT_PATH_MODULES = ("device", "caching", "batch_coordinator", "ml.model_manager"
                     "image.inpainting", "image.cleaning", "outside_text_processor")
 
 
-def install(include_caching: bool = True, share_utils: bool = True) -> list:
+def set_hardware_queues(n: int = 16) -> bool:
+    """`GPU_MAX_HW_QUEUES=n` for this process — ROCm multiplexes a process's HIP streams onto that many hardware queues (default 4) and reads
+    the variable when the HIP runtime is LOADED, i.e. at `import torch`: too late from inside a library that imports torch, in time from
+    here (this module imports nothing heavy).  Sixteen is what a service that mostly detects / segments / cleans wants (every model owns a
+    stream; two pages' detect stages in flight = ten streams: config 2 33 -> 37 pages/s); diffusion-bound services keep the
+    default (config 5 measured slower with more).  A value already in the environment is left alone.  -> True when the setting will
+    take effect, False (with a message) when torch is already loaded."""
+    import os
+    if os.environ.get("GPU_MAX_HW_QUEUES"):
+        return True
+    if "torch" in sys.modules:
+        print(f"mangatranslator_amd: GPU_MAX_HW_QUEUES={n} requested after torch was imported — the HIP runtime has read its settings already; "
+              "export it in the environment (or call install() / set_hardware_queues() before importing torch)", file=sys.stderr)
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return True
+
+
+def install(include_caching: bool = True, share_utils: bool = True, hardware_queues: "int | None" = None) -> list:
     """-> the list of `core.*` module names now served by this package.  `include_caching=False` keeps the reference's own stage memo
-    (needed when its translation / manga-ocr key builders are in use: this build restates the vision-side keys only)."""
+    (needed when its translation / manga-ocr key builders are in use: this build restates the vision-side keys only).
+    `hardware_queues=16`: see `set_hardware_queues` (detect / segment / clean services; makes `batch_vision_images` pick two front workers)."""
+    if hardware_queues is not None:
+        set_hardware_queues(hardware_queues)
     if "core" in sys.modules and getattr(sys.modules["core"], "__file__", None):
         raise RuntimeError("mangatranslator_amd.integration.install() must run before the reference's `core` package is imported")
     if share_utils:

@@ -80,3 +80,24 @@ def test_centroid_expansion_box():
     two[10:50, 10:70] = 255; two[10:50, 90:150] = 255; two[27:33, 70:90] = 255
     (_, _, w2, _), (cx2, _) = calculate_centroid_expansion_box(two, padding_pixels=4.0)
     assert (cx2 < 70 or cx2 > 90) and w2 > 20
+
+
+def test_hardware_queue_setting_needs_to_come_before_torch():
+    """`integration.set_hardware_queues` / `install(hardware_queues=)`: in time in a fresh interpreter (the module imports nothing heavy), refused
+    with a message once torch is loaded, and never over an explicit environment setting"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    code = ("import sys, os; sys.path.insert(0, %r); import mangatranslator_amd.integration as a; "
+            "print(a.set_hardware_queues(16), os.environ.get('GPU_MAX_HW_QUEUES'), 'torch' in sys.modules); "
+            "import torch; os.environ.pop('GPU_MAX_HW_QUEUES'); print(a.set_hardware_queues(16), os.environ.get('GPU_MAX_HW_QUEUES'))") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "True 16 False" and lines[1] == "False None" and "after torch was imported" in r.stderr
+    r = subprocess.run([sys.executable, "-c", "import sys, os; sys.path.insert(0, %r); import mangatranslator_amd.integration as a; print(a.set_hardware_queues(16), os.environ['GPU_MAX_HW_QUEUES'])" % root],
+                       capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="8"), timeout=300)
+    assert r.stdout.strip() == "True 8"
