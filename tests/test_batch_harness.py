@@ -276,3 +276,47 @@ def test_several_front_halves_in_flight(tmp_path):
     assert not clashes and slots_seen == {0, 1, 2} and peak[0] == 3
     assert res["io"]["pages_in_flight"] == 4
     assert wall < 0.06 * n * 1.5, wall                            # (loose: `peak` above is the proof of overlap; ten 60 ms front halves one at a time take 0.6 s before any I/O)
+
+
+@pytest.mark.parametrize("workers", [1, 2, 4])
+def test_harness_under_random_delays_and_failures(tmp_path, workers):
+    """seeded stress: front / back halves with random durations, random failures in either half and io_threads 1..3 — whatever the
+    interleaving, success / error counts, the failed list IN BATCH ORDER and every written page equal the sequential run's"""
+    import random
+    import time
+    from mangatranslator_amd.core.pipeline import batch_process_images
+    root = tmp_path / "in"
+    root.mkdir()
+    n = 17
+    for i in range(n):
+        Image.new("RGB", (10, 6), (i, 255 - i, 7)).save(root / f"q{i:02d}.png")
+    for seed in range(4):
+        rng = random.Random(1000 * workers + seed)
+        plan = {i: (rng.random() * 0.012, rng.random() * 0.012, rng.random() < 0.15, rng.random() < 0.15) for i in range(n)}
+
+        def front(page, path):
+            i = int(path.stem[1:])
+            time.sleep(plan[i][0])
+            if plan[i][2]:
+                raise RuntimeError(f"front {i}")
+            return i, page
+
+        def back(state):
+            i, page = state
+            time.sleep(plan[i][1])
+            if plan[i][3]:
+                raise ValueError(f"back {i}")
+            out = page.copy()
+            out.putpixel((1, 1), (i, seed, workers))
+            return out
+
+        tag = f"{workers}_{seed}"
+        got = batch_process_images(root, _cfg("png"), tmp_path / f"p{tag}", process_front=front, process_back=back, io_threads=1 + seed % 3, front_workers=workers,
+                                   front_context=None if workers == 1 else (lambda slot: __import__("contextlib").nullcontext()))
+        want = batch_process_images(root, _cfg("png"), tmp_path / f"s{tag}", process_image=lambda page, path: back(front(page, path)), io_threads=2)
+        for k in ("success_count", "error_count", "errors", "failed_image_paths"):
+            assert got[k] == want[k], (tag, k)
+        names = sorted(f.name for f in (tmp_path / f"p{tag}").glob("*.png"))
+        assert names == sorted(f.name for f in (tmp_path / f"s{tag}").glob("*.png")) and len(names) == got["success_count"]
+        for name in names:
+            assert np.array_equal(np.asarray(Image.open(tmp_path / f"p{tag}" / name)), np.asarray(Image.open(tmp_path / f"s{tag}" / name))), (tag, name)
