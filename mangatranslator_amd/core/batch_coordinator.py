@@ -6,7 +6,6 @@ and results (`BatchRequestCoordinator.slot/run/map_ordered`, `bboxes_overlap`, `
 """
 import threading
 from concurrent.futures import ThreadPoolExecutor
-from contextlib import contextmanager
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple, TypeVar
 
 import numpy as np
@@ -18,49 +17,99 @@ R = TypeVar("R")
 BBox = Tuple[int, int, int, int]
 
 
+class _SlotBudget:
+    """A counted budget of request slots with an owner set: a thread that already owns a slot is let through
+    again without taking a second one.  One condition variable guards the free count and the owner set, so
+    ownership and the count can never disagree (the reference keeps a semaphore plus a thread-local flag)."""
+
+    def __init__(self, capacity: int):
+        self.capacity = capacity
+        self._free = capacity
+        self._owners = set()
+        self._cv = threading.Condition()
+
+    def owned_by_caller(self) -> bool:
+        with self._cv:
+            return threading.get_ident() in self._owners
+
+    def take(self) -> bool:
+        """True when this call took a slot (and must give it back), False when the thread already owned one."""
+        me = threading.get_ident()
+        with self._cv:
+            if me in self._owners:
+                return False
+            while self._free == 0:
+                self._cv.wait()
+            self._free -= 1
+            self._owners.add(me)
+            return True
+
+    def give_back(self) -> None:
+        with self._cv:
+            self._owners.discard(threading.get_ident())
+            self._free += 1
+            self._cv.notify()
+
+
+class _HeldSlot:
+    """Context manager of one `slot()` entry: cancellation is looked at before waiting and again once the slot is held."""
+
+    def __init__(self, owner: "BatchRequestCoordinator"):
+        self._owner = owner
+        self._took = False
+
+    def __enter__(self):
+        budget = self._owner._budget
+        if not budget.owned_by_caller():
+            self._owner._stop_if_cancelled()
+            self._took = budget.take()
+            if self._took:
+                try:
+                    self._owner._stop_if_cancelled()
+                except BaseException:
+                    budget.give_back()
+                    self._took = False
+                    raise
+        return None
+
+    def __exit__(self, *exc):
+        if self._took:
+            self._took = False
+            self._owner._budget.give_back()
+        return False
+
+
 class BatchRequestCoordinator:
-    """At most `max_requests` jobs hold a slot at once; a thread already inside a slot re-enters freely."""
+    """Operator surface of the reference's class (core/batch_coordinator.py:18-75): at most `max_requests` jobs hold a
+    slot at once, a thread inside a slot re-enters freely, `map_ordered` returns results in input order."""
 
     def __init__(self, max_requests: int, cancellation_manager=None):
         self.max_requests = max(1, int(max_requests or 1))
-        self._slots = threading.BoundedSemaphore(self.max_requests)
+        self._budget = _SlotBudget(self.max_requests)
         self._cancel = cancellation_manager
-        self._tls = threading.local()
 
-    def _raise_if_cancelled(self):
-        if self._cancel is not None and self._cancel.is_cancelled():
+    def _stop_if_cancelled(self) -> None:
+        manager = self._cancel
+        if manager is not None and manager.is_cancelled():
             raise CancellationError("Batch process cancelled by user.")
 
     def in_slot(self) -> bool:
-        return getattr(self._tls, "depth", 0) > 0
+        return self._budget.owned_by_caller()
 
-    @contextmanager
-    def slot(self):
-        if self.in_slot():
-            yield
-            return
-        self._raise_if_cancelled()
-        self._slots.acquire()
-        self._tls.depth = 1
-        try:
-            self._raise_if_cancelled()
-            yield
-        finally:
-            self._tls.depth = 0
-            self._slots.release()
+    def slot(self) -> _HeldSlot:
+        return _HeldSlot(self)
 
     def run(self, fn: Callable[..., R], *args, **kwargs) -> R:
-        with self.slot():
+        with _HeldSlot(self):
             return fn(*args, **kwargs)
 
     def map_ordered(self, jobs: Sequence[Callable[[], R]]) -> List[R]:
-        if not jobs:
-            return []
-        if len(jobs) == 1:
-            return [self.run(jobs[0])]
-        with ThreadPoolExecutor(max_workers=min(len(jobs), self.max_requests)) as pool:
-            futures = [pool.submit(self.run, job) for job in jobs]
-            return [f.result() for f in futures]
+        jobs = list(jobs)
+        width = min(len(jobs), self.max_requests)
+        if width <= 1:                                  # nothing to overlap: stay on the caller's thread
+            return [self.run(job) for job in jobs]
+        with ThreadPoolExecutor(max_workers=width, thread_name_prefix="batch-request") as pool:
+            return list(pool.map(self.run, jobs))
 
 
 def bboxes_overlap(first: BBox, second: BBox) -> bool:
