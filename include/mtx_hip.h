@@ -36,7 +36,7 @@ extern "C" {
 #define MTX_API
 #endif
 
-#define MTX_ABI_VERSION 6
+#define MTX_ABI_VERSION 7
 
 typedef enum mtx_status {
   MTX_OK = 0,
@@ -50,7 +50,7 @@ typedef enum mtx_status {
  * the arithmetic runs on the vector ALUs (csrc/f32ops.hip) — GEMM with bias / act / res / strided batches (no gate, glu or fp8 operands),
  * attention with head dim 8 / 16 / 32 / 64, LayerNorm (+ act), element-wise ADD / MUL / ACT / COPY / ROW_GATHER / SHUFFLE2_ADD / CVT_F32 /
  * CVT_16 (fp32 -> 16-bit, the bridge back into a 16-bit GEMM).
- * Small problems only: SAM-2.1's mask decoder under Sam2Hip(precision="high").  Simulator-verified; not yet run on hardware. */
+ * Small problems only: SAM-2.1's mask decoder under Sam2Hip(precision="high") (hardware-verified in round 5: profiles/r05_parity.json). */
 typedef enum mtx_dtype { MTX_BF16 = 0, MTX_F16 = 1, MTX_F32 = 2, MTX_U8 = 3, MTX_I32 = 4,
                          MTX_F8 = 5 /* OCP e4m3fn bytes with MX block scales, see mtx_quant_args */ } mtx_dtype;
 
@@ -156,6 +156,11 @@ typedef struct mtx_attn_args {
  * is ignored, scores are used as base-2 logits as they come out of the matrix pipe.  The long-sequence kernel then seeds its score
  * accumulators with minus the running maximum and needs no per-score multiply-add. */
 #define MTX_ATTN_Q_PRESCALED 1
+/* bits 8..12 of `flags`: schedule of the long-sequence kernel (pre-scaled q, 16-bit output only; ignored elsewhere).  0 = the default.
+ * s > 0 selects attn_x_kernel<s - 1> (csrc/attention.hip): K / V by LDS-DMA, + 1 = half-tile stagger of the two wave groups,
+ * + 2 = row sums on the matrix pipe (bf16), + 4 = 16-byte row stores, + 8 = K / V staged through registers like the default kernel
+ * instead of LDS-DMA.  Same results up to the summation order of the row sums. */
+#define MTX_ATTN_SCHEDULE_SHIFT 8
 #define MTX_ATTN_WORKSPACE_BYTES (256 * (256 * 128 * 4 + 256 * 2 * 4))
 
 /* row-wise normalisation over the last dim C of [rows, C] (row stride ld):
@@ -210,6 +215,10 @@ typedef enum mtx_ew_kind {
                                optional and lds = its per-sample stride (0 = one image for every n) — SAM's mask upscaling                        */
   MTX_EW_CVT_F32 = 17,    /* fp32 only: y = (float) a, a of the 16-bit type i0 (MTX_F16 / MTX_BF16)                                              */
   MTX_EW_CVT_16 = 18,     /* fp32 only: y = a rounded to the 16-bit type i0, written i1 (1..4) times side by side: y[px][j * c + ch]             */
+  MTX_EW_SUB = 19,        /* y = a - b                                                                                                             */
+  MTX_EW_RESIDUAL_DIST = 20, /* first-block cache probe: r = a - b rounded to the 16-bit type, prev = s (same layout, row stride lds); y = fp32
+                                [2 * MTX_RESDIST_PARTS]: y[2 g] = part g of sum |prev - r|, y[2 g + 1] = part g of sum |prev| (fixed summation order; the
+                                caller adds the parts in index order)                                                                          */
   MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
                              i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then
                              rotary on interleaved pairs with b = fp32 [rows][d] cos|sin table laid out as
@@ -218,6 +227,8 @@ typedef enum mtx_ew_kind {
                              < i1 (the q slice) read their table at b + ldb floats instead — a copy pre-multiplied by
                              the attention scale * log2(e), see MTX_ATTN_Q_PRESCALED                    */
 } mtx_ew_kind;
+
+#define MTX_RESDIST_PARTS 256
 
 typedef struct mtx_ew_args {
   const void* a; const void* b; const void* s; void* y;

@@ -132,11 +132,11 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
         unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = f[e] / (1.f + __expf(-f[e])) * g[e];
-      } else if (kind == MTX_EW_ADD || kind == MTX_EW_MUL) {
+      } else if (kind == MTX_EW_ADD || kind == MTX_EW_MUL || kind == MTX_EW_SUB) {
         float g[8];
         unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = kind == MTX_EW_ADD ? f[e] + g[e] : f[e] * g[e];
+        for (int e = 0; e < 8; ++e) f[e] = kind == MTX_EW_ADD ? f[e] + g[e] : kind == MTX_EW_SUB ? f[e] - g[e] : f[e] * g[e];
       } else if (kind == MTX_EW_GATE_RES) {
         float g[8], s8[8];
         unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), g);
@@ -150,6 +150,43 @@ __global__ __launch_bounds__(256) void ew_kernel(mtx_ew_args p) {
       }
     }
     *reinterpret_cast<u32x4*>(Y + pix * p.ldy + c) = pack8<T>(f);
+  }
+}
+
+// ---- MTX_EW_RESIDUAL_DIST: the probe of the first-block cache (reference core/ml/model_manager.py:1159-1162, nunchaku's
+// apply_cache_on_pipe: "is this step's first-block residual close to the last computed step's?") --------------------------------------
+// r = a - b rounded to T (the residual as a 16-bit tensor), prev = s.  Workgroup g of MTX_RESDIST_PARTS leaves y[2 g] = sum |prev - r| and
+// y[2 g + 1] = sum |prev| over its grid-strided share, accumulated in a fixed order (lane-local, wave tree, waves in order): the caller adds
+// the parts in index order, so the decision does not depend on scheduling.  No atomics, no clearing pass.
+template <typename T>
+__global__ __launch_bounds__(256) void residual_dist_kernel(mtx_ew_args p) {
+  __shared__ float red[2][4];
+  const long C8 = p.c / 8, total = p.n * p.h * p.w * C8;
+  const T* A = reinterpret_cast<const T*>(p.a);
+  const T* Bp = reinterpret_cast<const T*>(p.b);
+  const T* Sp = reinterpret_cast<const T*>(p.s);
+  float d = 0.f, m = 0.f;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long c = (idx % C8) * 8, pix = idx / C8;
+    float fa[8], fb[8], fs[8];
+    unpack8<T>(*reinterpret_cast<const u32x4*>(A + pix * p.lda + c), fa);
+    unpack8<T>(*reinterpret_cast<const u32x4*>(Bp + pix * p.ldb + c), fb);
+    unpack8<T>(*reinterpret_cast<const u32x4*>(Sp + pix * p.lds + c), fs);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float r = to_f32(from_f32<T>(fa[e] - fb[e]));
+      d += fabsf(fs[e] - r);
+      m += fabsf(fs[e]);
+    }
+  }
+  d = wave_sum(d); m = wave_sum(m);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = d; red[1][wv] = m; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* Y = reinterpret_cast<float*>(p.y);
+    Y[2 * blockIdx.x] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    Y[2 * blockIdx.x + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
   }
 }
 
@@ -283,6 +320,13 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
     else { *err = "softmax_rows: dtype"; return MTX_ERR_INVALID; }
     return MTX_OK;
   }
+  if (a->kind == MTX_EW_RESIDUAL_DIST) {
+    if (!a->a || !a->b || !a->s || !a->y || a->c % 8 || a->lda % 8 || a->ldb % 8 || a->lds % 8) { *err = "residual_dist: needs a, b, s (16-bit, strides % 8 == 0) and y (fp32 [2 * MTX_RESDIST_PARTS])"; return MTX_ERR_INVALID; }
+    if (a->dtype == MTX_BF16) MTX_LAUNCH((residual_dist_kernel<__bf16>), dim3(MTX_RESDIST_PARTS), dim3(256), 0, stream, *a);
+    else if (a->dtype == MTX_F16) MTX_LAUNCH((residual_dist_kernel<_Float16>), dim3(MTX_RESDIST_PARTS), dim3(256), 0, stream, *a);
+    else { *err = "residual_dist: dtype"; return MTX_ERR_INVALID; }
+    return MTX_OK;
+  }
   if (a->kind == MTX_EW_TRANSPOSE) {
     if (!a->a || !a->y) { *err = "transpose: null operand"; return MTX_ERR_INVALID; }
     const long rows = a->h * a->w;
@@ -308,7 +352,7 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
   }
   if (!a->a || !a->y) { *err = "elementwise: null operand"; return MTX_ERR_INVALID; }
   if (a->c % 8 || a->lda % 8 || a->ldy % 8 || (a->b && a->ldb % 8 && a->kind != MTX_EW_DWCONV)) { *err = "elementwise: C and pixel strides must be multiples of 8"; return MTX_ERR_INVALID; }
-  if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_ADD || a->kind == MTX_EW_MUL || a->kind == MTX_EW_GATE_RES || a->kind == MTX_EW_SWIGLU) && !a->b) { *err = "elementwise: missing operand b"; return MTX_ERR_INVALID; }
+  if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_ADD || a->kind == MTX_EW_MUL || a->kind == MTX_EW_SUB || a->kind == MTX_EW_GATE_RES || a->kind == MTX_EW_SWIGLU) && !a->b) { *err = "elementwise: missing operand b"; return MTX_ERR_INVALID; }
   if ((a->kind == MTX_EW_SCALE_RES || a->kind == MTX_EW_GATE_RES) && !a->s) { *err = "elementwise: missing operand s"; return MTX_ERR_INVALID; }
   if (a->kind == MTX_EW_MAXPOOL && (a->i0 < 1 || a->i1 < 1)) { *err = "elementwise: maxpool needs kernel/stride"; return MTX_ERR_INVALID; }
   if (a->kind == MTX_EW_DWCONV && (!a->s || (a->i0 & 1) == 0 || a->i0 < 1 || a->i0 > 7)) { *err = "elementwise: dwconv needs weights in s and an odd kernel <= 7"; return MTX_ERR_INVALID; }

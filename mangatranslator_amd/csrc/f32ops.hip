@@ -3,8 +3,8 @@
 // accurate expf / erff.  Round 4, for `Sam2Hip(precision="high")` (reference core/image/detection.py:494-510: the `> 0` masks are what the
 // page flow keeps; DESIGN.md §3's error budget: with 16-bit storage the mask decoder contributes 0.0067 + 0.0053 of 0.0130 logit units).
 // These are small problems — 28 GFLOP per page at eight boxes against the trunk's 1.6 TFLOP — so the kernels are written to be obviously
-// right: an LDS-tiled FMA GEMM, a wave-per-query attention, a wave-per-row LayerNorm, element-wise maps.  SIMULATOR-VERIFIED ONLY: the
-// round's GPU budget was spent when they were written; nothing in the default graphs reaches them.
+// right: an LDS-tiled FMA GEMM, a wave-per-query attention, a wave-per-row LayerNorm, element-wise maps.  First hardware run: round 5
+// (tests/test_ops_gpu.py::test_f32_ops, profiles/r05_visit_a_sam_high_first_run.log).
 #include "mtx_device.h"
 #include <math.h>
 

@@ -2,7 +2,7 @@
 mtx_abi_sizeof() when the library is opened)."""
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # enums
 BF16, F16, F32, U8, I32, F8 = 0, 1, 2, 3, 4, 5
@@ -10,6 +10,8 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_SIGMOID, ACT_LEAKY = 
 (EW_SCALE_RES, EW_ADD, EW_MUL, EW_ACT, EW_UPSAMPLE2X, EW_MAXPOOL, EW_COPY, EW_GATE_RES,
  EW_ROW_GATHER, EW_IM2COL, EW_SOFTMAX_ROWS, EW_TRANSPOSE, EW_QK_NORM_ROPE, EW_AVGPOOL2, EW_SWIGLU, EW_DWCONV) = range(16)
 EW_SHUFFLE2_ADD, EW_CVT_F32, EW_CVT_16 = 16, 17, 18            # fp32 ops only (csrc/f32ops.hip)
+EW_SUB, EW_RESIDUAL_DIST = 19, 20                              # y = a - b; the first-block cache probe (include/mtx_hip.h)
+RESDIST_PARTS = 256
 IMG_NCHW_F32_TO_NHWC, IMG_NHWC_TO_NCHW_F32, IMG_NHWC_TO_HWC_U8, IMG_HWC_U8_TO_NHWC = range(4)
 (OP_CONV2D, OP_GEMM, OP_ATTN, OP_NORM, OP_GROUPNORM, OP_EW, OP_CA, OP_IMG, OP_RESIZE_THRESH,
  OP_MEMSET, OP_MASK_SELECT, OP_PREPROC, OP_YOLO_DECODE, OP_DETR, OP_QUANT, OP_TAIL) = range(1, 17)
@@ -61,6 +63,7 @@ class AttnArgs(C.Structure):
 
 
 ATTN_Q_PRESCALED = 1
+ATTN_SCHEDULE_SHIFT = 8      # bits 8..12 of AttnArgs.flags: schedule of the long-sequence kernel (include/mtx_hip.h)
 ATTN_WORKSPACE_BYTES = 256 * (256 * 128 * 4 + 256 * 2 * 4)
 
 

@@ -336,11 +336,11 @@ class PlanBuilder:
         return out
 
     def attention(self, q, k, v, o, batch, heads, sq, sk, d, q_str, k_str, v_str, o_str, scale,
-                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False, q8=None):
+                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False, q8=None, schedule=0):
         """q8 = (q bytes [sq, ldq], scale plane [ldq / 128, lds], ldq, lds, byte column offset): the rows leave as the MX fp8 operand of the
         next linear instead of (o None) or beside 16-bit values — long-sequence kernel only (mtx_attn_args.q8)"""
         a = abi.AttnArgs()
-        a.flags = abi.ATTN_Q_PRESCALED if q_prescaled else 0
+        a.flags = (abi.ATTN_Q_PRESCALED if q_prescaled else 0) | (int(schedule) << abi.ATTN_SCHEDULE_SHIFT)
         a.q, a.k, a.v, a.o = _ptr(q, q_off), _ptr(k, k_off), _ptr(v, v_off), (_ptr(o, o_off) if o is not None else None)
         if q8 is not None:
             q8q, q8s, ldq, lds8, col = q8

@@ -173,7 +173,7 @@ def check_gemm_huge_rows(lib, dtype, m, n, k, seed=0):
         assert err < TOL[dtype], f"gemm rows {rows} mismatch rel err {err}"
 
 
-def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, prescaled=False):
+def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, prescaled=False, schedule=0, late_keys=None):
     """prescaled: q carries scale * log2(e) before its rounding to the storage type (MTX_ATTN_Q_PRESCALED): the reference is the
     base-2 softmax of q k^T, i.e. SDPA with scale = ln 2 on the very same rounded q"""
     g = torch.Generator().manual_seed(seed)
@@ -181,7 +181,10 @@ def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, presc
     scale = 1.0 / math.sqrt(d)
     q = torch.randn(batch, sq, heads, d, generator=g) * qmul              # qmul > 1: peaked rows, exercises max refreshes
     q = (q * (scale * 1.4426950408889634)).to(td) if prescaled else q.to(td)
-    k = torch.randn(batch, sk, heads, d, generator=g).to(td)
+    k = torch.randn(batch, sk, heads, d, generator=g)
+    if late_keys is not None:                                              # (first key, factor): keys from there on score far above everything before them
+        k[:, late_keys[0]:] *= late_keys[1]
+    k = k.to(td)
     v = torch.randn(batch, sk, heads, d, generator=g).to(td)
     ref = F.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2),
                                          v.float().transpose(1, 2), scale=math.log(2.0) if prescaled else scale).transpose(1, 2)
@@ -190,10 +193,10 @@ def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, presc
     o = pb.buf((batch, sq, heads, d), td, zero=True)
     pb.attention(qt, kt, vt, o, batch, heads, sq, sk, d,
                  (sq * heads * d, heads * d, d), (sk * heads * d, heads * d, d),
-                 (sk * heads * d, heads * d, d), (sq * heads * d, heads * d, d), scale, q_prescaled=prescaled)
+                 (sk * heads * d, heads * d, d), (sq * heads * d, heads * d, d), scale, q_prescaled=prescaled, schedule=schedule)
     _run(pb)
     err = _relerr(o.cpu(), ref)
-    assert err < TOL[dtype] * 1.5, f"attention mismatch rel err {err}"
+    assert err < TOL[dtype] * 1.5, f"attention mismatch rel err {err} (schedule {schedule})"
     return err
 
 

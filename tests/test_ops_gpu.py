@@ -137,6 +137,16 @@ def test_attention_prescaled_q(hip_lib):
     oc.check_attention(hip_lib, abi.BF16, batch=2, heads=2, sq=300, sk=200, d=64, prescaled=True)
 
 
+@pytest.mark.parametrize("schedule", [1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 15, 16])
+def test_attention_alternative_schedules(hip_lib, schedule):
+    """mtx_attn_args.flags schedule bits (round 5; tests/test_ops_sim.py has the same cases on the simulator): the FLUX shape through the
+    key-split tail, a ragged shape with peaked rows, and scores that outgrow a maximum taken once (matrix-pipe row sums: the block is redone)"""
+    oc.check_attention(hip_lib, abi.BF16, batch=1, heads=3, sq=2100, sk=2100, d=128, qmul=4.0, prescaled=True, schedule=schedule)
+    oc.check_attention(hip_lib, abi.BF16, batch=1, heads=24, sq=8652, sk=8652, d=128, prescaled=True, schedule=schedule)
+    oc.check_attention(hip_lib, abi.BF16, batch=1, heads=2, sq=1100, sk=449, d=128, qmul=40.0, prescaled=True, schedule=schedule)
+    oc.check_attention(hip_lib, abi.BF16, batch=1, heads=2, sq=1024, sk=320, d=128, qmul=8.0, prescaled=True, schedule=schedule, late_keys=(200, 12.0))
+
+
 def test_flux_prep_kernels(hip_lib):
     oc.check_qk_norm_rope(hip_lib, abi.BF16, rows=1000, heads=24, d=128)
     oc.check_qk_norm_rope(hip_lib, abi.BF16, rows=1000, heads=24, d=128, q_fold=0.1275)

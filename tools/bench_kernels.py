@@ -20,16 +20,18 @@ def _time(plan, iters):
     return min(plan.time(iters) for _ in range(3))
 
 
-def attn(T, heads=24, d=128, iters=10):
+def attn(T, heads=24, d=128, iters=10, schedule=0):
+    """schedule > 0: attn_x_kernel<schedule - 1> (mtx_attn_args.flags bits 8..11): 1 = K / V by LDS-DMA, + 1 stagger, + 2 matrix-pipe row sums, + 4 wide stores"""
     pb = PlanBuilder(lib, dev, abi.BF16)
     D = heads * d
     qkv = pb.buf((T, 3 * D), torch.bfloat16); qkv.normal_()
     o = pb.buf((T, D), torch.bfloat16)
     qkv[:, :D] *= d ** -0.5 * 1.4426950408889634         # the FLUX graphs' form: q pre-multiplied by scale * log2(e)
     pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D,
-                 q_prescaled=True)
+                 q_prescaled=True, schedule=schedule)
     ms = _time(pb.build(), iters)
-    print(f"attn T={T} heads={heads}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
+    print(f"attn T={T} heads={heads} schedule={schedule}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
+    return ms
 
 
 def attn_q8(T, heads=24, d=128, iters=10, fused=True):
@@ -123,6 +125,15 @@ if __name__ == "__main__":
     while args:
         if args[0] == "attn":
             attn(int(args[1])); args = args[2:]
+        elif args[0] == "attnx":                       # attnx T s1,s2,...  REPS: the listed schedules in turn, REPS rounds in one process
+            T, scheds, reps = int(args[1]), [int(v) for v in args[2].split(",")], int(args[3])
+            best = {}
+            for _ in range(reps):
+                for sc in scheds:
+                    ms = attn(T, schedule=sc)
+                    best[sc] = min(best.get(sc, 1e9), ms)
+            print("attnx best of", reps, {sc: round(v, 4) for sc, v in best.items()}, flush=True)
+            args = args[4:]
         elif args[0] in ("attnq", "attnqs"):          # attention with MX fp8 output: fused epilogue / separate quantiser
             attn_q8(int(args[1]), fused=args[0] == "attnq"); args = args[2:]
         elif args[0] in ("glu", "glus"):              # glu M hid K col0
