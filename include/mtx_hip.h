@@ -159,7 +159,9 @@ typedef struct mtx_attn_args {
 /* bits 8..12 of `flags`: schedule of the long-sequence kernel (pre-scaled q, 16-bit output only; ignored elsewhere).  0 = the default.
  * s > 0 selects attn_x_kernel<s - 1> (csrc/attention.hip): K / V by LDS-DMA, + 1 = half-tile stagger of the two wave groups,
  * + 2 = row sums on the matrix pipe (bf16), + 4 = 16-byte row stores, + 8 = K / V staged through registers like the default kernel
- * instead of LDS-DMA.  Same results up to the summation order of the row sums. */
+ * instead of LDS-DMA (bf16 only).  17 = the default kernel with 16-byte row stores (what 0 selects when the output rows are 16-byte aligned),
+ * 18 = 17 + matrix-pipe row sums, 31 = the default kernel with its round-4 8-byte stores.  Same results up to the summation order of the row sums.
+ * Tuning / measurement switches: tools/bench_kernels.py attnx, profiles/r05_visit_*attention*.log. */
 #define MTX_ATTN_SCHEDULE_SHIFT 8
 #define MTX_ATTN_WORKSPACE_BYTES (256 * (256 * 128 * 4 + 256 * 2 * 4))
 

@@ -440,8 +440,91 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
         oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
       }
 }
+// a and b of lanes l / l ^ 32: afterwards the lower lane holds (its a, the upper lane's a), the upper lane (the lower lane's b, its b)
+__device__ __forceinline__ void half_pair_exchange(uint32_t& a, uint32_t& b) {
+#ifdef MTX_EMU
+  const uint32_t pa = __shfl_xor(a, 32, 64), pb = __shfl_xor(b, 32, 64);
+  if (emu::lane_id() >> 5) a = pb; else b = pa;
+#else
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+#endif
+}
+
+// Tile step with the row sums on the matrix pipe (round 5): attn_bias_tile's NOMAX form without its 32 v_add per tile — an all-ones A
+// fragment against the P^T operand the P V product reads anyway puts the row sum into every row of `lacc` (one more 32x32x16 MFMA per 16
+// keys: + 12.5 % matrix work for - 1/3 of the loop's vector instructions).  The running maximum is the FIRST tile's; nothing on the hot
+// path looks at the probabilities' size (bf16 keeps fp32's exponent range and its relative precision), the caller checks the finished row
+// sums and redoes the block with the classic form when they left the safe range.  bf16 only (f16 probabilities would saturate unseen).
+template <typename T, int DP, int STAGE, bool RAGGED>
+__device__ __forceinline__ void attn_bias_tile_ms(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32], f32x16& lacc,
+                                                  float& M, f32x16& minit, bool& first,
+                                                  const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
+  const unsigned char* Vs = Ks + TILE_B;
+  f32x16 sacc[2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
+      if (ks == 0) Mma32Pinned<T>::set_from(sacc[kb], kf, qf[ks], minit);
+      else sacc[kb] = Mma32<T>::mfma(kf, qf[ks], sacc[kb]);
+    }
+  if (RAGGED) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) sacc[kb][r] = -1.0e30f;
+  }
+  if (__builtin_expect(first, 0)) {            // (wave-uniform) M <- the first tile's maximum; O^T and the sums are still zero
+    float tmax = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
+    tmax = half_max(tmax);
+    M += tmax;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] -= tmax;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) minit[r] = -M;
+    first = false;
+  }
+  v8 pb[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pb[kb][r >> 3][r & 7] = from_f32<T>(fast_exp2(sacc[kb][r]));
+  v8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = from_f32<T>(1.0f);
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
+        const v4 lo = lds_read_tr16<T>(a);
+        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+        v8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
+        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
+      }
+      lacc = Mma32<T>::mfma(ones, pb[kb][s2], lacc);
+    }
+}
+
 #define ATTN_MMA32_NAME attn_mma32_kernel
 #define ATTN_MMA32_Q8 0
+#define ATTN_MMA32_WIDE 0
+#define ATTN_MMA32_MATSUM 0
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
 #undef ATTN_MMA32_Q8
@@ -449,6 +532,20 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
 #define ATTN_MMA32_Q8 1
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_Q8
+#undef ATTN_MMA32_WIDE
+#define ATTN_MMA32_Q8 0
+#define ATTN_MMA32_WIDE 1
+#define ATTN_MMA32_NAME attn_mma32_w_kernel
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_MATSUM
+#define ATTN_MMA32_MATSUM 1
+#define ATTN_MMA32_NAME attn_mma32_ms_kernel
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_MATSUM
+#undef ATTN_MMA32_WIDE
 #undef ATTN_MMA32_Q8
 
 // =====================================================================================================
@@ -493,17 +590,6 @@ __device__ __forceinline__ int xor_here(int base) {
   int r;
   asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "v"(base), "v"(C));
   return r;
-#endif
-}
-
-// a and b of lanes l / l ^ 32: afterwards the lower lane holds (its a, the upper lane's a), the upper lane (the lower lane's b, its b)
-__device__ __forceinline__ void half_pair_exchange(uint32_t& a, uint32_t& b) {
-#ifdef MTX_EMU
-  const uint32_t pa = __shfl_xor(a, 32, 64), pb = __shfl_xor(b, 32, 64);
-  if (emu::lane_id() >> 5) a = pb; else b = pa;
-#else
-  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  a = r[0]; b = r[1];
 #endif
 }
 
@@ -1002,22 +1088,41 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
       if (p.split > 1) MTX_LAUNCH((attn_merge_q8_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
       return MTX_OK;
     }
-    if (p.schedule > 0 && p.prescaled) {
-      int var = p.schedule - 1;
-      const bool aligned16 = p.o_ss % 8 == 0 && p.o_hs % 8 == 0 && p.o_bs % 8 == 0 && ((size_t)p.o & 15) == 0;
-      if (!aligned16) var &= ~AX_WIDE;
-      if (!std::is_same<T, __bf16>::value) var &= ~AX_MATSUM;          // f16 probabilities saturate: a stale maximum would go unnoticed
+    // Measured in one process on MI355X at T = 8812, 24 heads (round 5, profiles/r05_visit_b / _c / _d_attention_*.log; default 0.827-0.835 ms):
+    //   16-byte row stores on this kernel (schedule 17)  0.832 vs 0.835 ms (+0.3 %, four rounds of four)      -> the default from here on;
+    //   matrix-pipe row sums on this kernel (18)          0.890 (-6.7 %: 22 % fewer vector instructions, 12.5 % more MFMAs; the kernel is
+    //                                                     bound by its LDS-read -> MFMA dependency chains, not by vector issue slots);
+    //   attn_x_kernel (schedules 1..16: the same loop rebuilt with the transport / schedule as template switches)
+    //     K / V by LDS-DMA  0.967 (-17 %: four 1 KB pieces per wave and tile cost more issue time than 8 loads + 8 ds_write_b128);
+    //     half-tile stagger of the two wave groups  0.966 with LDS-DMA (no change), 1.222 with register staging;
+    //     register staging  0.983; + matrix-pipe sums 0.903; + 16-byte stores 0.970; both 0.894.
+    // schedule 31 = this kernel with its round-4 epilogue (8-byte stores).
+    const bool wide_ok = p.o_ss % 8 == 0 && p.o_hs % 8 == 0 && p.o_bs % 8 == 0 && ((size_t)p.o & 15) == 0;
+    bool launched = false;
+    if ((p.schedule == 0 || p.schedule == 17 || p.schedule == 18) && p.prescaled && wide_ok) {
+      if constexpr (std::is_same<T, __bf16>::value) {
+        if (p.schedule == 18) { MTX_LAUNCH((attn_mma32_ms_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true; }
+      }
+      if (!launched) { MTX_LAUNCH((attn_mma32_w_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true; }
+    } else if (p.schedule > 0 && p.schedule <= 16 && p.prescaled) {
+      if constexpr (std::is_same<T, __bf16>::value) {      // (f16 probabilities saturate: matrix-pipe sums would not notice a stale maximum; the measurement kernels are bf16)
+        int var = p.schedule - 1;
+        if (!wide_ok) var &= ~AX_WIDE;
 #define MTX_AX(V) case V: MTX_LAUNCH((attn_x_kernel<T, 128, V>), dim3(g), dim3(512), 0, stream, p); break
 #ifdef AX_ONLY
-      switch (var) { MTX_AX(AX_ONLY); default: return MTX_ERR_INVALID; }
+        switch (var) { MTX_AX(AX_ONLY); default: return MTX_ERR_INVALID; }
 #else
-      switch (var) { MTX_AX(0); MTX_AX(1); MTX_AX(2); MTX_AX(3); MTX_AX(4); MTX_AX(5); MTX_AX(6); MTX_AX(7);
-                     MTX_AX(8); MTX_AX(9); MTX_AX(10); MTX_AX(11); MTX_AX(12); MTX_AX(13); MTX_AX(14); MTX_AX(15); default: return MTX_ERR_INVALID; }
+        switch (var) { MTX_AX(0); MTX_AX(1); MTX_AX(2); MTX_AX(3); MTX_AX(4); MTX_AX(5); MTX_AX(6); MTX_AX(7);
+                       MTX_AX(8); MTX_AX(9); MTX_AX(10); MTX_AX(11); MTX_AX(12); MTX_AX(13); MTX_AX(14); MTX_AX(15); default: return MTX_ERR_INVALID; }
 #endif
 #undef MTX_AX
+        launched = true;
+      }
     }
-    else if (p.prescaled) MTX_LAUNCH((attn_mma32_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
-    else MTX_LAUNCH((attn_mma32_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
+    if (!launched) {
+      if (p.prescaled) MTX_LAUNCH((attn_mma32_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+      else MTX_LAUNCH((attn_mma32_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
+    }
     if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
     return MTX_OK;
   }

@@ -408,6 +408,20 @@ class PlanBuilder:
         self._add(abi.OP_EW, e, label)
         return out
 
+    def residual_dist(self, after, before, prev, rows, c, parts=None, after_off=0, before_off=0, ld=None, label="residual_dist"):
+        """first-block cache probe (include/mtx_hip.h MTX_EW_RESIDUAL_DIST): r = after - before (rounded to the storage type) against `prev`;
+        -> fp32 [RESDIST_PARTS, 2]: per part (sum |prev - r|, sum |prev|); `residual_distance(parts)` adds them in index order"""
+        if parts is None:
+            parts = self.buf((abi.RESDIST_PARTS, 2), torch.float32, zero=True)
+        e = abi.EwArgs()
+        e.a, e.b, e.s, e.y = _ptr(after, after_off), _ptr(before, before_off), _ptr(prev), parts.data_ptr()
+        e.n, e.h, e.w, e.c = 1, 1, rows, c
+        e.lda = e.ldb = (ld or c)
+        e.lds, e.ldy = c, 2
+        e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_RESIDUAL_DIST, 0, 0.0, 0, 0, self.dtype
+        self._add(abi.OP_EW, e, label)
+        return parts
+
     def dwconv(self, x: Act, w_taps, bias, ksize: int, act=abi.ACT_NONE, out: Optional[Act] = None, label="dwconv") -> Act:
         """depthwise k x k, stride 1 (include/mtx_hip.h MTX_EW_DWCONV): w_taps T [k*k, C], bias fp32 [C] or None"""
         if out is None:
@@ -630,6 +644,14 @@ class PlanBuilder:
         plan.labels = list(self.labels)
         plan.ops = list(self.ops)          # the recorded argument blocks (benchmarks group launches by kernel and shape)
         return plan
+
+
+def residual_distance(parts: torch.Tensor) -> float:
+    """mean |prev - r| / mean |prev| from the parts a `residual_dist` op left (added in index order, in double: the same bytes give the same
+    verdict on every run); inf when `prev` is all zero"""
+    p = parts.detach().to("cpu", torch.float64)
+    d, m = float(p[:, 0].sum()), float(p[:, 1].sum())
+    return d / m if m > 0.0 else float("inf")
 
 
 def glu_interleave(col0: int, hid: int) -> torch.Tensor:

@@ -289,6 +289,30 @@ def check_groupnorm(lib, dtype, n, h, w, c, groups, silu=True, seed=0):
     return err
 
 
+def check_residual_dist(lib, dtype, rows=700, c=3072, seed=0, ld_extra=0):
+    """MTX_EW_RESIDUAL_DIST (first-block cache probe) and MTX_EW_SUB against torch on the same rounded operands; the probe twice: identical parts"""
+    from mangatranslator_amd.hip.plan import residual_distance
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    ld = c + ld_extra
+    before = torch.randn(rows, ld, generator=g).to(td)
+    after = (before.float() + 0.3 * torch.randn(rows, ld, generator=g)).to(td)
+    prev = ((after.float() - before.float())[:, :c] + 0.05 * torch.randn(rows, c, generator=g)).to(td)
+    r = (after.float() - before.float()).to(td).float()[:, :c]
+    want = ((prev.float() - r).abs().sum() / prev.float().abs().sum()).item()
+    pb = PlanBuilder(lib, dev, dtype)
+    a_t, b_t, p_t = pb.const(after), pb.const(before), pb.const(prev)
+    parts = pb.residual_dist(a_t, b_t, p_t, rows, c, ld=ld)
+    parts2 = pb.residual_dist(a_t, b_t, p_t, rows, c, ld=ld)
+    diff = pb.ew(abi.EW_SUB, Act(a_t.view(1, 1, rows, ld), 1, 1, rows, c), b=Act(b_t.view(1, 1, rows, ld), 1, 1, rows, c), label="sub")
+    _run(pb)
+    got = residual_distance(parts)
+    assert abs(got - want) < 1e-4 * max(want, 1e-6) + 1e-6, (got, want)
+    assert torch.equal(parts.cpu(), parts2.cpu())
+    assert torch.equal(diff.t.reshape(rows, c).cpu().float(), r)
+    return got
+
+
 def check_ew(lib, dtype, seed=0):
     g = torch.Generator().manual_seed(seed)
     dev, td = _dev(lib), TD[dtype]
