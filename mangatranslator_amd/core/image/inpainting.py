@@ -180,8 +180,13 @@ class FluxKontextInpainter:
     def load_models(self):
         if self.pipeline is not None:
             return
-        # every backend name maps onto the one MI355X-native FLUX graph
+        # every backend name maps onto the one MI355X-native FLUX graph; what the reference's backends differ in on this path is the
+        # first-block cache: its nunchaku loader wraps the pipeline in apply_cache_on_pipe(residual_diff_threshold=) (model_manager.py:1159-1162,
+        # inpainting.py:203), its SDNQ and sd.cpp loaders run every block of every step
         self.pipeline = self.manager.load_flux_kontext_sdnq(low_vram=self.low_vram, verbose=True)
+        if self.pipeline is not None:
+            self.manager.set_flux_residual_diff_threshold(self.residual_diff_threshold)
+            self.pipeline.residual_diff_threshold = self.manager.flux_residual_diff_threshold if self.backend == "nunchaku" else 0.0
 
     def unload_models(self):
         self.pipeline = None

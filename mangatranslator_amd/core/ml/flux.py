@@ -32,7 +32,7 @@ import torch
 
 from ...hip import abi
 from ...hip.lib import get_library
-from ...hip.plan import Act, PlanBuilder, PlanCache
+from ...hip.plan import Act, PlanBuilder, PlanCache, residual_distance
 from ...utils.exceptions import ModelError
 
 
@@ -171,13 +171,18 @@ class FluxDiTHip:
         return self._mod_cache[key]
 
     # ---- one denoising step as a plan ----------------------------------------------------------------------
-    def _build(self, t_txt, h2, w2, n_ref):
+    def _build(self, t_txt, h2, w2, n_ref, cached: bool = False):
+        """One denoising step.  cached=False: ONE plan (what every round measured).  cached=True (first-block cache, reference
+        core/ml/model_manager.py:1159-1162): the same ops as three plans over shared buffers — `head` (embedders, double block 0, the
+        residual-distance probe), `body` (this step's first residual kept, blocks 1.., the whole-stack residual kept, output layers) and
+        `skip` (cached whole-stack residual added, output layers) — so that the host can choose between `body` and `skip` after `head`."""
         cfg, W = self.cfg, self.W
         D, H, hd = cfg["d"], cfg["heads"], self.hd
         t_noise = h2 * w2
         t_img = t_noise * (1 + n_ref)
         T = t_txt + t_img
-        pb = PlanBuilder(self.lib, self.device, self.dtype, lanes=self.side_lane)
+        new_pb = lambda: PlanBuilder(self.lib, self.device, self.dtype, lanes=self.side_lane)
+        pb = new_pb()
         lat = pb.buf((t_img, cfg["in_channels"]), self.tdt)       # [noise tokens ; reference tokens]
         ctx_in = pb.buf((t_txt, cfg["joint_dim"]), self.tdt)      # prompt embeddings
         mod = pb.buf((self.n_vec, D), self.tdt)
@@ -194,15 +199,18 @@ class FluxDiTHip:
         o = pb.buf((T, D), self.tdt)
         hid = pb.buf((T, 4 * D), self.tdt)
         cat = pb.buf((T, 5 * D), self.tdt)
-        pb.gemm(ctx_in, W["context_embedder"][0], t_txt, D, cfg["joint_dim"], bias=W["context_embedder"][1], out=x, label="context_embedder")
-        pb.gemm(lat, W["x_embedder"][0], t_img, D, cfg["in_channels"], bias=W["x_embedder"][1], out=x, c_off=t_txt * D, label="x_embedder")
+        vel = pb.buf((t_noise, cfg["in_channels"]), torch.float32)
         m_ = lambda idx: (mod, idx * D)       # (tensor, element offset) of one modulation row
 
-        def adaln(r0, r1, shift_i, scale_i, label):
+        def embed(pb):
+            pb.gemm(ctx_in, W["context_embedder"][0], t_txt, D, cfg["joint_dim"], bias=W["context_embedder"][1], out=x, label="context_embedder")
+            pb.gemm(lat, W["x_embedder"][0], t_img, D, cfg["in_channels"], bias=W["x_embedder"][1], out=x, c_off=t_txt * D, label="x_embedder")
+
+        def adaln(pb, r0, r1, shift_i, scale_i, label):
             pb.norm(x, nrm, r1 - r0, D, eps=1e-6, kind=0, mod_scale=mod[scale_i], mod_shift=mod[shift_i], rows_per=r1 - r0, ldmod=D,
                     x_off=r0 * D, y_off=r0 * D, label=label)
 
-        def rope(buf, r0, r1, gamma_qk, ld, label):
+        def rope(pb, buf, r0, r1, gamma_qk, ld, label):
             """per-head RMSNorm + RoPE over the q AND k column slices (2D columns) of rows [r0, r1) in one launch"""
             v = _rows(buf, r0, r1, 0, 2 * D)
             e = abi.EwArgs()
@@ -212,60 +220,107 @@ class FluxDiTHip:
             e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 0, 1e-6, hd, H, self.dtype
             pb._add(abi.OP_EW, e, label)
 
-        def attention(out_t, out_ld, label):
+        def attention(pb, out_t, out_ld, label):
             pb.attention(qkv, qkv, qkv, out_t, 1, H, T, T, hd, (0, 3 * D, hd), (0, 3 * D, hd), (0, 3 * D, hd), (0, out_ld, hd),
                          1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True)
 
         # Double-stream blocks: the text stream's ops (512 rows: GEMMs of 24 - 96 tiles that cannot fill the chip, 4 % of a step when run in
         # line) go to the plan's SIDE lane and run beside the image stream's ops; the lanes meet at the joint attention and at the next block.
         # The two streams touch disjoint row ranges of every shared buffer.
-        for i, B in enumerate(self.blocks):
+        def double_block(pb, i, B):
             b0 = i * 12
             tag = f"dbl{i}"
             with pb.side():
-                adaln(0, t_txt, b0 + 6, b0 + 7, tag + ".norm1_ctx")
+                adaln(pb, 0, t_txt, b0 + 6, b0 + 7, tag + ".norm1_ctx")
                 pb.gemm(nrm, B["cqkv"][0], t_txt, 3 * D, D, bias=B["cqkv"][1], out=qkv, label=tag + ".qkv_ctx")
-                rope(qkv, 0, t_txt, B["cnqk"], 3 * D, tag + ".rope_qk_ctx")
-            adaln(t_txt, T, b0 + 0, b0 + 1, tag + ".norm1")
+                rope(pb, qkv, 0, t_txt, B["cnqk"], 3 * D, tag + ".rope_qk_ctx")
+            adaln(pb, t_txt, T, b0 + 0, b0 + 1, tag + ".norm1")
             pb.gemm(nrm, B["qkv"][0], t_img, 3 * D, D, bias=B["qkv"][1], out=qkv, a_off=t_txt * D, c_off=t_txt * 3 * D, label=tag + ".qkv")
-            rope(qkv, t_txt, T, B["nqk"], 3 * D, tag + ".rope_qk")
+            rope(pb, qkv, t_txt, T, B["nqk"], 3 * D, tag + ".rope_qk")
             pb.join()
-            attention(o, D, tag + ".attn")
+            attention(pb, o, D, tag + ".attn")
             with pb.side():
                 pb.gemm(o, B["cout"][0], t_txt, D, D, bias=B["cout"][1], gate=mod[b0 + 8], gate_rows_per=t_txt, res=x, out=x, label=tag + ".to_add_out")
-                adaln(0, t_txt, b0 + 9, b0 + 10, tag + ".norm2_ctx")
+                adaln(pb, 0, t_txt, b0 + 9, b0 + 10, tag + ".norm2_ctx")
                 pb.gemm(nrm, B["cff1"][0], t_txt, 4 * D, D, bias=B["cff1"][1], act=abi.ACT_GELU_TANH, out=hid, label=tag + ".ff1_ctx")
                 pb.gemm(hid, B["cff2"][0], t_txt, D, 4 * D, bias=B["cff2"][1], gate=mod[b0 + 11], gate_rows_per=t_txt, res=x, out=x, label=tag + ".ff2_ctx")
             pb.gemm(o, B["out"][0], t_img, D, D, bias=B["out"][1], gate=mod[b0 + 2], gate_rows_per=t_img, res=x, out=x,
                     a_off=t_txt * D, c_off=t_txt * D, res_off=t_txt * D, label=tag + ".to_out")
-            adaln(t_txt, T, b0 + 3, b0 + 4, tag + ".norm2")
+            adaln(pb, t_txt, T, b0 + 3, b0 + 4, tag + ".norm2")
             pb.gemm(nrm, B["ff1"][0], t_img, 4 * D, D, bias=B["ff1"][1], act=abi.ACT_GELU_TANH, out=hid, a_off=t_txt * D, c_off=t_txt * 4 * D, label=tag + ".ff1")
             pb.gemm(hid, B["ff2"][0], t_img, D, 4 * D, bias=B["ff2"][1], gate=mod[b0 + 5], gate_rows_per=t_img, res=x, out=x,
                     a_off=t_txt * 4 * D, c_off=t_txt * D, res_off=t_txt * D, label=tag + ".ff2")
-        pb.join()                 # the single-stream blocks read every row
+
         s0 = cfg["layers"] * 12
-        for i, S in enumerate(self.singles):
+
+        def single_block(pb, i, S):
             b0 = s0 + i * 3
             tag = f"sgl{i}"
-            adaln(0, T, b0 + 0, b0 + 1, tag + ".norm")
+            adaln(pb, 0, T, b0 + 0, b0 + 1, tag + ".norm")
             pb.gemm(nrm, S["qkv"][0], T, 3 * D, D, bias=S["qkv"][1], out=qkv, label=tag + ".qkv")
             pb.gemm(nrm, S["mlp"][0], T, 4 * D, D, bias=S["mlp"][1], act=abi.ACT_GELU_TANH, out=cat, ldc=5 * D, c_off=D, label=tag + ".proj_mlp")
-            rope(qkv, 0, T, S["nqk"], 3 * D, tag + ".rope_qk")
-            attention(cat, 5 * D, tag + ".attn")
+            rope(pb, qkv, 0, T, S["nqk"], 3 * D, tag + ".rope_qk")
+            attention(pb, cat, 5 * D, tag + ".attn")
             pb.gemm(cat, S["out"][0], T, D, 5 * D, bias=S["out"][1], gate=mod[b0 + 2], gate_rows_per=T, res=x, out=x, label=tag + ".proj_out")
-        f0 = s0 + cfg["single_layers"] * 3
-        pb.norm(x, nrm, t_noise, D, eps=1e-6, kind=0, mod_scale=mod[f0], mod_shift=mod[f0 + 1], rows_per=t_noise, ldmod=D,
-                x_off=t_txt * D, y_off=t_txt * D, label="norm_out")
-        vel = pb.gemm(nrm, W["proj_out"][0], t_noise, cfg["in_channels"], D, bias=W["proj_out"][1], a_off=t_txt * D, out_f32=True, label="proj_out")
-        plan = pb.build()
-        plan.lat, plan.ctx_in, plan.mod, plan.vel, plan.x = lat, ctx_in, mod, vel, x
-        plan.t_noise, plan.t_img, plan.T = t_noise, t_img, T
-        return plan
 
-    def plan_for(self, t_txt, h2, w2, n_ref=1):
-        key = (t_txt, h2, w2, n_ref)
+        f0 = s0 + cfg["single_layers"] * 3
+
+        def output_layers(pb):
+            pb.norm(x, nrm, t_noise, D, eps=1e-6, kind=0, mod_scale=mod[f0], mod_shift=mod[f0 + 1], rows_per=t_noise, ldmod=D,
+                    x_off=t_txt * D, y_off=t_txt * D, label="norm_out")
+            pb.gemm(nrm, W["proj_out"][0], t_noise, cfg["in_channels"], D, bias=W["proj_out"][1], a_off=t_txt * D, out=vel, out_f32=True, label="proj_out")
+
+        def finish(plan):
+            plan.lat, plan.ctx_in, plan.mod, plan.vel, plan.x = lat, ctx_in, mod, vel, x
+            plan.t_noise, plan.t_img, plan.T = t_noise, t_img, T
+            return plan
+
+        if not cached:
+            embed(pb)
+            for i, B in enumerate(self.blocks):
+                double_block(pb, i, B)
+            pb.join()                 # the single-stream blocks read every row
+            for i, S in enumerate(self.singles):
+                single_block(pb, i, S)
+            output_layers(pb)
+            return finish(pb.build())
+
+        # ---- first-block cache: three plans over the buffers above ------------------------------------------------------------------
+        rows2d = lambda t, r0, r1: _rows(t, r0, r1)
+        x0 = pb.buf((t_img, D), self.tdt)              # image stream before block 0
+        first_prev = pb.buf((t_img, D), self.tdt, zero=True)      # first-block residual of the last COMPUTED step
+        x1 = pb.buf((T, D), self.tdt)                  # both streams after block 0
+        whole = pb.buf((T, D), self.tdt, zero=True)    # whole-stack residual of the last computed step (x after the last block - x1)
+        embed(pb)
+        pb.ew(abi.EW_COPY, rows2d(x, t_txt, T), out=rows2d(x0, 0, t_img), label="cache.keep_x0")
+        double_block(pb, 0, self.blocks[0])
+        pb.join()
+        parts = pb.residual_dist(x, x0, first_prev, t_img, D, after_off=t_txt * D, label="cache.probe")
+        head = finish(pb.build())
+        pb_b = new_pb()
+        pb_b.ew(abi.EW_SUB, rows2d(x, t_txt, T), b=rows2d(x0, 0, t_img), out=rows2d(first_prev, 0, t_img), label="cache.keep_first_residual")
+        pb_b.ew(abi.EW_COPY, rows2d(x, 0, T), out=rows2d(x1, 0, T), label="cache.keep_x1")
+        for i, B in enumerate(self.blocks[1:], start=1):
+            double_block(pb_b, i, B)
+        pb_b.join()
+        for i, S in enumerate(self.singles):
+            single_block(pb_b, i, S)
+        pb_b.ew(abi.EW_SUB, rows2d(x, 0, T), b=rows2d(x1, 0, T), out=rows2d(whole, 0, T), label="cache.keep_whole_residual")
+        output_layers(pb_b)
+        body = finish(pb_b.build())
+        pb_c = new_pb()
+        pb_c.ew(abi.EW_ADD, rows2d(x, 0, T), b=rows2d(whole, 0, T), out=rows2d(x, 0, T), label="cache.apply_whole_residual")
+        output_layers(pb_c)
+        skip = finish(pb_c.build())
+        head.body, head.skip, head.parts = body, skip, parts
+        head.cache_buffers = (x0, first_prev, x1, whole)
+        return head
+
+    def plan_for(self, t_txt, h2, w2, n_ref=1, cached: bool = False):
+        """cached: the three-plan form of the first-block cache (`.body`, `.skip`, `.parts` hang off the returned head plan)"""
+        key = (t_txt, h2, w2, n_ref) + (("cached",) if cached else ())
         if key not in self._plans:
-            self._plans[key] = self._build(t_txt, h2, w2, n_ref)
+            self._plans[key] = self._build(t_txt, h2, w2, n_ref, cached)
         return self._plans[key]
 
     def flops_per_step(self, t_txt, h2, w2, n_ref=1):
@@ -406,6 +461,13 @@ class FluxKontextHip:
         self._embeds = None
         self.calls = 0                # pipeline invocations (benchmarks assert the expected number of FLUX regions ran)
         self.completed = 0            # ... that returned an image (a call that raised is caught by the OSB stage and becomes a flat fill)
+        # First-block cache (reference core/ml/model_manager.py:1159-1162: nunchaku's apply_cache_on_pipe(pipeline, residual_diff_threshold=)).
+        # 0 = off: every step runs every block through the one-plan graph (byte-identical to the builds before round 5).  > 0: after double
+        # block 0 the image stream's residual is compared with the last computed step's (mean |difference| / mean |previous|); below the
+        # threshold the other 56 blocks are skipped and the cached whole-stack residual is added.  `FluxKontextInpainter` sets it for
+        # backend "nunchaku" only, like the reference.  Parity with nunchaku's implementation is UNPINNED (the wheel is not installable here).
+        self.residual_diff_threshold = 0.0
+        self.cache_stats = {"steps": 0, "skipped": 0}      # over the pipeline's lifetime; `last["skipped_steps"]` holds the last call's count
 
     def set_prompt_embeds(self, prompt_embeds: torch.Tensor, pooled: torch.Tensor):
         """T5 / CLIP embeddings of the (fixed) prompt — computed once per process by the caller."""
@@ -446,23 +508,33 @@ class FluxKontextHip:
                 latents = torch.randn((1, 16, h8, w8), generator=generator, dtype=torch.float32,
                                       device=generator.device if generator is not None else "cpu")
             lat = pack(latents.to(self.device, torch.float32))
-            plan = dit.plan_for(pe.shape[0], h2, w2, 1)
+            threshold = float(kw.get("residual_diff_threshold", self.residual_diff_threshold) or 0.0)
+            plan = dit.plan_for(pe.shape[0], h2, w2, 1, cached=threshold > 0.0)
             plan.ctx_in.copy_(pe.to(self.device, dit.tdt))
             plan.lat[plan.t_noise:].copy_(pack(ref).to(dit.tdt))
             sig = flow_sigmas(num_inference_steps, h2 * w2)
             pooled_dev = pooled.to(self.device, dit.tdt)
             pooled_key = hash(pooled_dev.float().cpu().numpy().tobytes())
+            have_cache, skipped = False, []               # the cache lives for ONE call, like the reference's cache context
             for i in range(num_inference_steps):
                 plan.mod.copy_(dit.modulation(float(sig[i]), float(guidance_scale), pooled_dev, pooled_key))
                 plan.lat[: plan.t_noise].copy_(lat.to(dit.tdt))
                 plan.run(graph=self._graph)
+                if threshold > 0.0:
+                    # `plan` was the head (embedders, block 0, probe): the one host decision of the step
+                    use = have_cache and residual_distance(plan.parts) < threshold
+                    (plan.skip if use else plan.body).run(graph=self._graph)
+                    have_cache = True
+                    skipped.append(bool(use))
                 lat = lat + (float(sig[i + 1]) - float(sig[i])) * plan.vel
+            self.cache_stats["steps"] += num_inference_steps
+            self.cache_stats["skipped"] += sum(skipped)
             z = lat.view(1, h2, w2, 16, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(1, 16, h8, w8) / vc["scaling_factor"] + vc["shift_factor"]
             dec = vae.decoder_plan(h8, w8)
             dec.z.t.copy_(z.permute(0, 2, 3, 1).to(dit.tdt))
             dec.run(graph=self._graph)
             out = dec.out[0].clamp(0, 1).clone()
-            self.last = dict(latents=lat, sigmas=sig)
+            self.last = dict(latents=lat, sigmas=sig, skipped_steps=sum(skipped), skipped=skipped)
         self.completed += 1
         return SimpleNamespace(images=[out])
 

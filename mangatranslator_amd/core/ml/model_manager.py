@@ -272,8 +272,9 @@ class ModelManager:
     # :1436-1452): there is ONE Kontext implementation here, so they resolve to it instead of raising AttributeError under a caller that
     # was configured for another backend
     def set_flux_residual_diff_threshold(self, threshold: float):
-        """reference :1076-1082 — stored clamped to [0, 1] like there; the first-block cache it tunes is a nunchaku approximation that skips
-        denoising work, which this build never does (every step runs every block)"""
+        """reference :1076-1082 — stored clamped to [0, 1] like there.  `FluxKontextInpainter.load_models` hands it to the pipeline
+        (`FluxKontextHip.residual_diff_threshold`) for backend "nunchaku" — the reference applies its first-block cache in that loader only
+        (:1159-1162) — and 0 (every step runs every block) for "sdnq" / "sdcpp"."""
         self.flux_residual_diff_threshold = max(0.0, min(1.0, float(threshold)))
 
     def load_flux_models(self, verbose: bool = False):

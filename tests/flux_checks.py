@@ -206,3 +206,46 @@ def check_full_depth_step(lib, device, h2=24, w2=32, t_txt=512, tol=3e-2, seed=4
     print(f"full-depth DiT step (19 + 38 blocks, d = 3072, T = {plan.T}): velocity rel err {e:.4f}, cosine {cosine:.6f}")
     assert e < tol
     return e, cosine
+
+
+def check_first_block_cache(lib, device, h=64, w=96, t_txt=16, steps=4, **kw):
+    """The first-block cache behind `residual_diff_threshold` (reference core/ml/model_manager.py:1159-1162; nunchaku's algorithm, unpinned):
+      * threshold 0 is the one-plan graph: the image the pipeline made before the knob existed, byte for byte;
+      * a threshold nothing passes runs head + body every step: the same ops in three plans — still the same bytes;
+      * the skip path on a step whose inputs equal the computed step's reproduces that step's velocity up to the 16-bit rounding of the
+        two residuals (x1 + (x_out - x1));
+      * a threshold everything passes computes step 0 and skips every later one."""
+    t, v = models(**kw)
+    dit, vae = hip_models(t, v, lib, device)
+    img, pe, pooled, noise = inputs(t, h, w, t_txt)
+    pipe = fx.FluxKontextHip(dit, vae)
+    call = lambda **k: pipe(image=img, width=w, height=h, num_inference_steps=steps, guidance_scale=2.5, prompt_embeds=pe[None],
+                            pooled_prompt_embeds=pooled[None], latents=noise, **k).images[0].clone()
+    base = call()
+    assert pipe.last["skipped_steps"] == 0
+    never = call(residual_diff_threshold=1e-12)
+    assert pipe.last["skipped_steps"] == 0 and torch.equal(never, base), "head + body differs from the one-plan step"
+    # the skip path against the body path on identical step inputs
+    h2, w2 = h // 16, w // 16
+    plan = dit.plan_for(t_txt, h2, w2, 1, cached=True)
+    g = torch.Generator().manual_seed(7)
+    plan.ctx_in.copy_(pe.to(device, torch.bfloat16))
+    plan.lat.copy_(torch.randn(2 * h2 * w2, 64, generator=g).to(device, torch.bfloat16))
+    plan.mod.copy_(dit.modulation(0.6, 2.5, pooled.to(device, torch.bfloat16)))
+    plan.run(); plan.body.run()
+    computed = plan.vel.clone()
+    plan.run()
+    from mangatranslator_amd.hip.plan import residual_distance
+    d = residual_distance(plan.parts)
+    assert d == 0.0, f"the same step again: first-block residual distance {d}"
+    plan.skip.run()
+    e = rel(plan.vel, computed)
+    print(f"first-block cache: skip path vs computed step on equal inputs: velocity rel err {e:.2e}")
+    assert e < 2e-2
+    always = call(residual_diff_threshold=1e9)
+    assert pipe.last["skipped_steps"] == steps - 1 and pipe.last["skipped"][0] is False
+    assert torch.isfinite(always).all()
+    some = call(residual_diff_threshold=0.5)
+    print(f"first-block cache: threshold 0.5 skipped {pipe.last['skipped_steps']} of {steps} steps; image PSNR vs full compute "
+          f"{-10 * math.log10(max(((some.float() - base.float()) ** 2).mean().item(), 1e-12)):.1f} dB")
+    return e

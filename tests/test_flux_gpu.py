@@ -31,3 +31,10 @@ def test_full_depth_kontext_step(hip_lib):
     """57 blocks at d = 3072, T = 2 048: one step of the real geometry against a single fp32 pass of the oracle (streamed block by block)"""
     e, c = fc.check_full_depth_step(hip_lib, "cuda:0")
     record("flux1.full_depth_step.19+38.d3072.T2048", velocity_rel_err=e, cosine=c)
+
+
+def test_first_block_cache(hip_lib):
+    """`residual_diff_threshold` (reference core/ml/model_manager.py:1159-1162): off and never-passing thresholds give the one-plan step's bytes
+    (hipGraph replays of head + body), the skip path reproduces a computed step on equal inputs, an always-passing threshold skips every
+    step after the first.  Parity with nunchaku's implementation itself is unpinned (the wheel cannot be installed here)."""
+    record("flux1.first_block_cache.mid.bf16", skip_vs_computed_velocity_rel_err=fc.check_first_block_cache(hip_lib, "cuda:0", h=128, w=192, t_txt=32, steps=4, **MID))

@@ -12,3 +12,9 @@ def test_vae(emu_lib):
 
 def test_kontext_loop(emu_lib):
     fc.check_kontext(emu_lib, "cpu", h=32, w=48, t_txt=8, steps=2)
+
+
+def test_first_block_cache(emu_lib):
+    """`residual_diff_threshold` (the reference's nunchaku first-block cache): off == the one-plan step, never-passing == the same bytes through
+    head + body, the skip path reproduces a computed step on equal inputs, always-passing skips every step after the first"""
+    fc.check_first_block_cache(emu_lib, "cpu", h=32, w=48, t_txt=8, steps=3)

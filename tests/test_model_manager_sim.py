@@ -103,6 +103,13 @@ def test_load_flux_kontext_and_inpaint(manager):
     assert out.size == page.size and (a != b).any()
     far = np.ones((96, 128), bool); far[10:70, 10:118] = False
     assert (a[far] == b[far]).all()           # pixels far from the mask are untouched by the composite
+    assert pipe.residual_diff_threshold == 0.0                     # backend "sdnq": every step runs every block, as in the reference's SDNQ loader
+    # the reference's nunchaku backend wraps the pipeline in the first-block cache (model_manager.py:1159-1162): same route here
+    cached = FluxKontextInpainter(num_inference_steps=3, backend="nunchaku", residual_diff_threshold=0.4)
+    cached.PREFERED_KONTEXT_RESOLUTIONS = [(48, 32), (32, 48), (32, 32)]
+    out2 = cached.inpaint_mask(page, mask, seed=1)
+    assert pipe.residual_diff_threshold == 0.4 and manager.flux_residual_diff_threshold == 0.4
+    assert out2.size == page.size and len(pipe.last["skipped"]) == 3 and pipe.last["skipped"][0] is False
     manager.unload_flux_kontext_sdnq_models()
     assert not manager.is_loaded(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE)
 
