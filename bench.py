@@ -122,6 +122,14 @@ def parse():
                          "each on its own instance (a model's plan has one set of buffers).  Default: 2 for the stage sets without diffusion / "
                          "upscaling (BASELINE configs 1 and 2: the 640-pixel graphs of ONE page do not fill 256 CUs), else 1")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kontext-backend", default="sdnq", choices=["sdnq", "nunchaku", "sdcpp"],
+                    help="the reference's Kontext backend name the OSB stage is configured with: sdnq (default; every step runs every block — the headline) "
+                         "or nunchaku, whose loader wraps the pipeline in the first-block cache (reference model_manager.py:1159-1162) with --residual-diff-threshold")
+    ap.add_argument("--residual-diff-threshold", type=float, default=0.15, help="first-block cache threshold (reference core/config.py:150), used with --kontext-backend nunchaku")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default command only (config 4, one GPU): skip the child runs that put BASELINE configs 5 and 2 and the first-block-cache figure "
+                         "under `extra` of the same JSON line (after the timed region; ~2 minutes)")
+    ap.add_argument("--extra-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--time-ops", default="auto", choices=["auto", "difference", "stamp"],
                     help="in-context kernel timing of the roofline objects: hipGraph with minus hipGraph without the ops (HIP events), "
                          "or device wall-clock stamps around the ops inside one graph (mtx_plan_time_ops, MTX_TIME_OPS=stamp); auto = "
@@ -364,10 +372,10 @@ def main():
             detection=_types.SimpleNamespace(conjoined_confidence=0.35, bubble_detector_model="yolo_2"),
             outside_text=_types.SimpleNamespace(      # the reference's OutsideTextConfig defaults (core/config.py:126-173), Kontext selected
                 enabled=True, enable_page_number_filtering=False, min_area_ignore_ratio=0.0, seed=1, huggingface_token="",
-                inpainting_method=method, flux_backend="sdnq", flux_low_vram=False, flux_num_inference_steps=args.inpaint_steps,
+                inpainting_method=method, flux_backend=args.kontext_backend, flux_low_vram=False, flux_num_inference_steps=args.inpaint_steps,
                 flux_luminance_correction=True, flux_upscale_small_crops=True, flux_sdcpp_cache_mode="none", flux_sdcpp_diffusion_quant="",
                 flux_sdcpp_text_encoder_quant="",
-                flux_group_regions=False, flux_residual_diff_threshold=0.15, osb_confidence=0.5, osb_text_free_only=False,
+                flux_group_regions=False, flux_residual_diff_threshold=args.residual_diff_threshold, osb_confidence=0.5, osb_text_free_only=False,
                 bbox_expansion_percent_width=0.1, bbox_expansion_percent_height=0.1, osb_render_expansion_narrow_multiplier=1.0,
                 osb_render_expansion_tiny_multiplier=1.0, osb_render_expansion_aspect_ratio_threshold=0.4,
                 osb_render_expansion_area_ratio_threshold=0.005, text_box_proximity_ratio=0.02))
@@ -393,7 +401,7 @@ def main():
         page_text_boxes.append([[x0 + 10.0, y0 + 10.0, x1 - 10.0, y1 - 10.0] for (x0, y0, x1, y1) in regions])
     torch.cuda.synchronize()
 
-    outs = {}
+    page_outs = {}           # page index -> that page's stage results: two front halves may be in flight, nothing is shared between pages
     page_bgr = [pg.flip(-1).contiguous().cpu().numpy() for pg in pages]   # the detector's input is BGR (cv2 layout)
     yolo_conf = 0.6
     if yolo is not None:     # untimed calibration: seeded weights have arbitrary scores; let ~3x boxes anchors pass
@@ -457,6 +465,7 @@ def main():
     def stage_a(i):
         """front half of page i: the stages whose host share is large (NMS, prompt handling, OSB region logic)"""
         k = i % pool
+        outs = page_outs.setdefault(i, {})
         fs = front_sets[front_set_of(i)]
         yolo, aux_detectors, rtdetr, sam = fs["yolo"], fs["aux"], fs["rtdetr"], fs["sam"]
         stage_memo.reset()        # the operators remember results per (pixels, settings); the pool repeats pages, and no step may be served from memory
@@ -501,13 +510,14 @@ def main():
         return work_
 
     def stage_b(i, work_):
-        """back half of page i: GPU-bound"""
+        """back half of page i: GPU-bound; returns the page's stage results"""
         k = i % pool
+        outs = page_outs.pop(i, None) or {}
         tl = time.perf_counter()
         if seg_in_b:
             outs["segment"] = front_sets[front_set_of(i)]["sam"].segment(pages[k], page_boxes[k], ticket=work_[1])
             tl = lap("segment", tl)
-            return
+            return outs
         if inpainter is not None:
             outs["inpaint"], _ = otp.finish_outside_text_work(work_) if work_ is not None else (page_pil[k], [])
             tl = lap("inpaint_finish", tl)
@@ -523,9 +533,10 @@ def main():
             dm_, bbs_ = clean_args[k]
             outs["clean"] = cl.process_bubbles(page_bgr[k], dm_, bbs_, 200, False, shrink_, **ckw)
             tl = lap("clean", tl)
+        return outs
 
     def step(i):
-        stage_b(i, stage_a(i))
+        return stage_b(i, stage_a(i))
 
     overlap = not args.no_overlap and (yolo is not None or sam is not None) and (inpainter is not None or upscaler is not None or clean_args is not None)
     overlap = overlap or seg_in_b
@@ -609,8 +620,7 @@ def main():
 
         def io_back(state):
             i, page, work_ = state
-            if not seg_in_b:
-                stage_b(i, work_)
+            outs = stage_b(i, work_) if not seg_in_b else {}
             if "upscale" in outs:
                 return Image.fromarray(outs["upscale"].cpu().numpy())
             if "inpaint" in outs:
@@ -701,6 +711,14 @@ def main():
     cfg = result["config"]
     if batch_io is not None:
         cfg["batch_io"] = batch_io
+    if flux is not None and not klein:
+        st_ = getattr(flux, "cache_stats", {"steps": 0, "skipped": 0})
+        on_ = args.kontext_backend == "nunchaku" and args.residual_diff_threshold > 0
+        cfg["first_block_cache"] = ({"state": f"on (backend nunchaku, residual_diff_threshold {args.residual_diff_threshold}; reference model_manager.py:1159-1162)",
+                                     "denoising_steps": st_["steps"], "steps_skipped": st_["skipped"],
+                                     "steps_skipped_per_page": st_["skipped"] / max(1, flux.calls) * args.regions,
+                                     "note": "seeded random weights: how often the probe passes says nothing about a trained model; parity with nunchaku unpinned"} if on_
+                                    else {"state": f"off (backend {args.kontext_backend}: every step runs every block)", "steps_skipped": st_["skipped"]})
 
     if rank == 0:
         # ---- per-stage GPU time (HIP events on the launch stream), outside the timed region ---------------
@@ -833,12 +851,57 @@ def main():
                 result["roofline"] = conv_roof
         if not args.no_traffic and not args.traffic_child and world == 1 and "roofline" in result:
             result["roofline"]["traffic"], result["roofline"]["traffic_detail"] = measure_traffic(result["roofline"]["kernel"])
+        if (world == 1 and headline and not args.no_extra and not args.extra_child and not args.traffic_child
+                and args.kontext_backend == "sdnq" and args.sam_precision == "fast"):
+            result["extra"] = run_extra_children()
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is a single-GPU-run item (rank 0 at N = 1 only)
             result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"), flux.transformer.cfg if (klein and flux is not None) else None)
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_extra_children():
+    """The other BASELINE configurations under the driver's clock: after the timed region of the default command, this very
+    script is run again as child processes — the GPU is idle by then; each child loads its own models, times its own region with the same
+    barrier discipline and prints its own JSON line, of which the figures are kept:
+      config5  6 pages at 2048x3072, FLUX.2-Klein-4B with MX-fp8 block linears, 8 steps, + 2x upscale (BASELINE configs[4]; the reference's DEFAULT inpainter)
+      config2  64 pages, detect + segment only (BASELINE configs[1]), two front halves in flight on sixteen hardware queues
+      first_block_cache  3 pages of config 3 with the OSB stage configured for the reference's nunchaku backend (first-block cache on)"""
+    import subprocess
+    me = [sys.executable, str(Path(__file__).resolve()), "--no-cpu-baseline", "--no-traffic", "--extra-child"]
+    jobs = {"config5": ["--config", "5", "--steps", "6", "--warmup", "1"],
+            "config2": ["--config", "2", "--steps", "64", "--warmup", "4"],
+            "first_block_cache": ["--config", "3", "--steps", "3", "--warmup", "1", "--kontext-backend", "nunchaku"]}
+    out = {}
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}          # each child picks its own queue count (see _early_hw_queues)
+    for name, extra_args in jobs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(me + extra_args, capture_output=True, text=True, timeout=420, env=env)
+            line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
+            if r.returncode != 0 or line is None:
+                out[name] = {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+                continue
+            d = json.loads(line)
+            c = d.get("config", {})
+            keep = {"command": "python bench.py " + " ".join(extra_args), "metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+                    "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "workload": c.get("workload"), "wall_s_incl_model_setup": round(time.perf_counter() - t0, 1)}
+            for k in ("roofline", "roofline_attention", "roofline_gemm_fp8", "roofline_gemm_bf16", "roofline_upscale_conv"):
+                if k in d:
+                    keep[k] = {kk: vv for kk, vv in d[k].items() if kk not in ("traffic_detail", "per_conv")}
+            for k in ("stage_wall_ms_one_page", "front_replicas", "hw_queues", "segment_ms", "detect_net_ms", "upscale_ms", "first_block_cache", "inpainter"):
+                if k in c:
+                    keep[k] = c[k]
+            if "inpaint" in c:
+                keep["inpaint"] = {kk: c["inpaint"][kk] for kk in ("resolution", "tokens", "dit_step_ms", "dit_tflops", "vae_encode_ms", "vae_decode_ms") if kk in c["inpaint"]}
+            out[name] = keep
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "did not finish in 420 s"}
+        except Exception as e:      # noqa: BLE001 — an extra must never cost the headline line
+            out[name] = {"error": str(e)[:300]}
+    return out
 
 
 def measure_traffic(kernel_desc: str):

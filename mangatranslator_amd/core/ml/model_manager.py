@@ -193,9 +193,17 @@ class ModelManager:
             self.flux_hf_token = None
             self.flux_inference_lock = threading.Lock()
             self._tls = threading.local()           # .replica: which instance set of the front-half models this thread is served from
-            # "fast": SAM-2.1 as measured all round (16-bit storage).  "high": hi + lo weight pairs in the trunk / neck and an fp32 mask
-            # decoder (core/ml/sam2.py; simulator-verified, first hardware run pending — not the default)
-            self.sam_precision = "fast"
+            # SAM-2.1 arithmetic.  "high" (the default): hi + lo weight pairs in the trunk / neck, fp32 residual stream and an fp32 mask decoder
+            # (core/ml/sam2.py) — 5.1e-5 of a page's mask pixels differ from the fp32 reference after `> 0` (the reference keeps exactly
+            # those masks, detection.py:494-510), for + 11.6 ms of GPU time per page: under 1 % of any page that is inpainted or upscaled.
+            # "fast": 16-bit storage throughout (1.8e-4 of the pixels; encoder + decoder 13.0 instead of 24.6 ms) — what
+            # `core.pipeline.batch_vision_images` selects for batches with neither inpainting nor upscaling behind the masks (detect +
+            # segment at 37.9 instead of 27.6 pages/s, profiles/r05_bench_config2_sam_*.json), and what a caller sets here before `load_sam2`.
+            self.sam_precision = "high"
+            # storage type of SAM's 16-bit tensors: "auto" = f16 when the f16 and bf16 models agree on the load-time probe page (f16's logit
+            # error is 8x smaller; this library's f16 conversions SATURATE at 65504, so an activation overflow on a page unlike the probe
+            # would degrade masks without a NaN — ADVICE r04), "bf16" = the reference's own GPU dtype, no probe, "f16" = no probe either
+            self.sam_storage = "auto"
             self._initialized = True
             log_message(f"Model Manager initialized on device: {self.device}", always_print=True)
 
@@ -208,6 +216,68 @@ class ModelManager:
     # model type ignores the setting.
     FRONT_MODEL_TYPES = frozenset({ModelType.YOLO_SPEECH_BUBBLE, ModelType.YOLO_SPEECH_BUBBLE_2, ModelType.RTDETR_CONJOINED_BUBBLE,
                                    ModelType.YOLO_OSBTEXT, ModelType.YOLO_PANEL, ModelType.SAM2})
+
+    # checkpoint file names earlier builds of this package staged for a slot whose default name has since become the reference's own
+    # (a staging directory that still holds the old panel export must keep working, not fall back to "global sorting")
+    LEGACY_CHECKPOINT_NAMES = {"manga109_v2023.12.07_l_yolov11.pt": ("manga109_panel_yolo11l.safetensors", "manga109_panel_yolo11l.pt")}
+
+    def thread_local_reads(self):
+        """`with manager.thread_local_reads():` — loader calls of THIS thread read their checkpoints themselves and issue no collective.
+        For worker threads of a page-sharded batch (core/pipeline.py front halves): the ranks' threads cannot be kept in one order, and a
+        status / tensor broadcast entered in different orders on different ranks hangs or cross-wires.  The models a batch
+        needs are loaded through the collective path on the main thread first (`preload_for_config`); what a worker still loads lazily
+        afterwards (a replica set, a model the preload could not know about) comes from the filesystem the ranks of a node share."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            before = getattr(self._tls, "local_reads", False)
+            self._tls.local_reads = True
+            try:
+                yield self
+            finally:
+                self._tls.local_reads = before
+        return scope()
+
+    def _local_reads(self) -> bool:
+        return bool(getattr(self._tls, "local_reads", False))
+
+    def preload_for_config(self, config, verbose: bool = False) -> dict:
+        """Every model the page flow of `config` will ask for, loaded NOW, on the calling (main) thread, in one fixed order — so that in a
+        multi-rank batch all collective loads happen before any worker thread exists and in the same order on every rank.  A model that
+        cannot be loaded is reported and skipped (every rank sees the same verdict: the loaders share their status first); the page flow
+        meets the same error later on its own failure path.  Returns {model name: "loaded" | error text}."""
+        det = getattr(config, "detection", None)
+        osb = getattr(config, "outside_text", None)
+        out_cfg = getattr(config, "output", None)
+        pre = getattr(config, "preprocessing", None)
+        g = lambda o, n, d=None: getattr(o, n, d) if o is not None else d
+        jobs = [("bubble detector", lambda: self.load_yolo_speech_bubble(getattr(config, "yolo_model_path", None) or g(det, "bubble_detector_model"), verbose=verbose))]
+        if g(det, "conjoined_detection", True) or g(osb, "enabled", False):
+            jobs.append(("RT-DETR secondary detector", lambda: self.load_rtdetr_conjoined_bubble(verbose=verbose)))
+        if g(det, "seg_model", "sam2") == "sam2":
+            jobs.append(("SAM 2.1", lambda: self.load_sam2(verbose=verbose)))
+        if g(osb, "enabled", False) or g(det, "use_osb_text_verification", False):
+            jobs.append(("outside-text detector", lambda: self.load_yolo_osbtext(token=g(osb, "huggingface_token", None), verbose=verbose)))
+        if g(det, "use_panel_sorting", False):
+            jobs.append(("panel detector", lambda: self.load_yolo_panel(verbose=verbose)))
+        if g(out_cfg, "upscale_final_image", False) or g(pre, "enabled", False):
+            lite = g(out_cfg, "image_upscale_model", "model_lite") == "model_lite"
+            jobs.append(("upscaler", (lambda: self.load_upscale_lite(verbose=verbose)) if lite else (lambda: self.load_upscale(verbose=verbose))))
+        if g(osb, "enabled", False):
+            method = g(osb, "inpainting_method", "flux_klein_4b")
+            if method == "flux_kontext":
+                jobs.append(("FLUX.1 Kontext", lambda: self.load_flux_kontext_sdnq(verbose=verbose)))
+            elif method in ("flux_klein_4b", "flux_klein_9b"):
+                jobs.append((f"FLUX.2 Klein {method[-2:].upper()}", (lambda: self.load_flux_klein_9b(verbose=verbose)) if method.endswith("9b") else (lambda: self.load_flux_klein_4b(verbose=verbose))))
+        report = {}
+        for name, load in jobs:
+            try:
+                report[name] = "loaded" if load() is not None else "not staged"
+            except Exception as e:      # noqa: BLE001 — the page flow has its own failure path for every one of these
+                report[name] = f"{type(e).__name__}: {e}"
+                log_message(f"preload: {name}: {e}", always_print=True)
+        return report
 
     def front_replica(self, index: int):
         import contextlib
@@ -326,12 +396,17 @@ class ModelManager:
         worker threads, where the ranks' calls cannot be kept in one order; their checkpoint has been read once through the collective
         path already (set 0), the ranks of a node share the filesystem."""
         import torch.distributed as dist
+        local = local or self._local_reads()
         rank0 = local or not _dist_on() or dist.get_rank() == 0
         sd, error, metadata = None, None, {}
         if rank0:
             # detector checkpoints: the ultralytics `.pt` the reference downloads (read without ultralytics and without executing the
-            # pickle: core/ml/ultralytics_pt.py) or its safetensors export (tools/export_ultralytics_state_dict.py), whichever is staged
-            found = next((c for c in (path, path.with_suffix(".safetensors"), path.with_suffix(".pt")) if c.exists()), None)
+            # pickle: core/ml/ultralytics_pt.py) or its safetensors export (tools/export_ultralytics_state_dict.py), whichever is staged;
+            # then the names earlier builds staged for the slot
+            candidates = [path, path.with_suffix(".safetensors"), path.with_suffix(".pt")] + [path.with_name(n) for n in self.LEGACY_CHECKPOINT_NAMES.get(path.name, ())]
+            found = next((c for c in candidates if c.exists()), None)
+            if found is not None and found.name in self.LEGACY_CHECKPOINT_NAMES.get(path.name, ()):
+                log_message(f"{path.name} is not staged; reading the earlier export {found.name} from the same directory", always_print=True)
             if found is None:
                 error = f"checkpoint not found: {path} (stage it under ./models; this build never downloads)"
             else:
@@ -382,8 +457,13 @@ class ModelManager:
     def _staged(self, path: Path, what: str) -> None:
         """filesystem check done by rank 0 only, verdict shared: every rank raises or none does"""
         import torch.distributed as dist
+        missing = f"{what} not found: {path} (stage it under ./models; this build never downloads)"
+        if self._local_reads():              # a worker thread of a page-sharded batch: no collective (see `thread_local_reads`)
+            if not path.exists():
+                raise ModelError(missing)
+            return
         rank0 = not _dist_on() or dist.get_rank() == 0
-        broadcast_status(f"{what} not found: {path} (stage it under ./models; this build never downloads)" if rank0 and not path.exists() else None)
+        broadcast_status(missing if rank0 and not path.exists() else None)
 
     def _load_rcan(self, model_type: ModelType, verbose: bool):
         with self._lock:
@@ -526,7 +606,10 @@ class ModelManager:
         with self._lock:
             slot = self._slot(ModelType.SAM2)
             if self.is_loaded(slot):
-                return self.models[slot]
+                loaded = self.models[slot][1].hip
+                if slot is not ModelType.SAM2 or ("high" if loaded.high else "fast") == getattr(self, "sam_precision", "high"):
+                    return self.models[slot]
+                self.unload_model(ModelType.SAM2, force_gc=False, verbose=verbose)      # `sam_precision` changed since the load: build the other arithmetic
             from .sam2 import Sam2Hip
             root = self.model_paths[ModelType.SAM2]
             weights, cfg = root / "model.safetensors", root / "config.json"
@@ -535,6 +618,9 @@ class ModelManager:
             from transformers import Sam2Config
             config = Sam2Config.from_pretrained(str(root))
             sd = self._read_safetensors(weights, local=slot is not ModelType.SAM2)
+            want = getattr(self, "sam_precision", "high")
+            if want not in ("fast", "high"):
+                raise ModelError(f"ModelManager.sam_precision must be 'fast' or 'high', not {want!r}")
             if slot is not ModelType.SAM2 and self.is_loaded(ModelType.SAM2):
                 # a replica takes the storage type set 0 settled on (its probe compared the two): one more model, no second probe
                 first = self.models[ModelType.SAM2][1].hip
@@ -545,19 +631,25 @@ class ModelManager:
             # unless the checkpoint leaves the f16 range: then the two models disagree grossly on the load-time probe and bf16 — the
             # reference's own GPU dtype — is kept
             from ...hip import abi
-            hip = Sam2Hip(sd, config, device=self.device, dtype=abi.BF16)
-            hip16 = Sam2Hip(sd, config, device=self.device, dtype=abi.F16)
-            ref, got = hip.probe_logits(), hip16.probe_logits()
-            gap = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item() if torch.isfinite(got).all() else float("inf")
-            if gap < SAM_F16_PROBE_TOLERANCE:
-                hip = hip16
+            storage = getattr(self, "sam_storage", "auto")
+            if storage not in ("auto", "bf16", "f16"):
+                raise ModelError(f"ModelManager.sam_storage must be 'auto', 'bf16' or 'f16', not {storage!r}")
+            if storage == "auto":
+                hip = Sam2Hip(sd, config, device=self.device, dtype=abi.BF16)
+                hip16 = Sam2Hip(sd, config, device=self.device, dtype=abi.F16)
+                ref, got = hip.probe_logits(), hip16.probe_logits()
+                gap = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item() if torch.isfinite(got).all() else float("inf")
+                if gap < SAM_F16_PROBE_TOLERANCE:
+                    hip, why = hip16, f"f16 and bf16 agree on the probe page within {gap:.3f} of the logit range"
+                else:
+                    why = f"f16 disagrees with bf16 on the probe page by {gap:.2f} of the logit range"
+                del hip16
             else:
-                log_message(f"SAM 2.1: f16 storage disagrees with bf16 on the probe page ({gap:.2f} of the logit range): using bf16", always_print=True)
-            del hip16
-            if getattr(self, "sam_precision", "fast") == "high":
+                hip, why = Sam2Hip(sd, config, device=self.device, dtype=abi.F16 if storage == "f16" else abi.BF16), "ModelManager.sam_storage"
+            if want == "high":
                 hip = Sam2Hip(sd, config, device=self.device, dtype=hip.dtype, precision="high")
             self.models[slot] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
-            log_message("SAM 2.1 model loaded.", verbose=verbose)
+            log_message(f"SAM 2.1 model loaded: {'f16' if hip.dtype == abi.F16 else 'bf16'} storage ({why}), precision {want!r}.", always_print=True)
             return self.models[slot]
 
     def load_flux_kontext_sdnq(self, low_vram: bool = False, verbose: bool = False):

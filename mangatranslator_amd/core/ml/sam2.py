@@ -78,7 +78,10 @@ def window_order(hs: int, ws_: int, win: int) -> np.ndarray:
 
 class Sam2Hip:
     def __init__(self, state_dict: dict, config, device="cuda", lib=None, graph: bool = True, dtype: int = abi.BF16, precision: str = "fast"):
-        """precision = "high" (round 4, built for VERDICT r03 #2; simulator-verified, NOT yet run on hardware, not the default anywhere):
+        """precision = "high" (what `ModelManager` serves unless a detect / segment-only batch asks for "fast"; measured on MI355X in round 5,
+        Hiera-L at 1024x1536, logits at a trained model's spread, against the fp32 reference: mask pixels that differ after `> 0` 5.1e-5 against
+        1.8e-4 for "fast", logit rms error 0.0051 against 0.016, no pixel wrong outside the error band; encoder 20.1 ms against 11.4, mask
+        decoder at 8 boxes 4.5 against 1.6 — profiles/r05_parity.json, r05_sam_dtype_probe.json, r05_bench_config2_sam_*.json):
         the trunk's and the neck's weights as hi + lo pairs of the storage type — W = W_hi + W_lo, one GEMM over K' = 2K with the operand
         [x | x] against [W_hi | W_lo], fp32 accumulation: the weights' rounding, the largest term of the error budget, goes
         away at twice the trunk's matrix work and no kernel change — and the prompt encoder / two-way transformer / mask head in fp32

@@ -124,7 +124,8 @@ def load_page(img_path: Path, output_format: str):
 def batch_process_images(input_dir, config, output_dir=None, preserve_structure: bool = False,
                          process_image: Optional[Callable] = None, io_threads: int = 2,
                          process_front: Optional[Callable] = None, process_back: Optional[Callable] = None,
-                         front_workers: int = 1, front_context: Optional[Callable] = None) -> Dict:
+                         front_workers: int = 1, front_context: Optional[Callable] = None,
+                         preload: Optional[Callable] = None) -> Dict:
     """The vision half of `batch_translate_images` (core/pipeline.py:2481-2733) on one GPU or page-sharded over the ranks of the
     initialised process group: same page list and order, same output naming (`_resolve_output_path`), same results dict
     (`success_count`, `error_count`, `errors` keyed by the display path, `failed_image_paths` absolute, `failed_paths_file`), a bad
@@ -142,7 +143,10 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
     slots for its duration; `front_context(slot)` is entered around the front half — by default `ModelManager.front_replica(slot)`, which
     serves the detectors and SAM from instance set `slot` (a model instance holds one page at a time).  Pays off for stage sets whose back
     half is short (detect / clean only: the 640-pixel detector graphs do not fill the chip) and needs `GPU_MAX_HW_QUEUES=16` in the
-    environment — two pages' model streams on ROCm's default four hardware queues run slower than one page."""
+    environment — two pages' model streams on ROCm's default four hardware queues run slower than one page.
+    **Worker threads and the process group** (ADVICE r04): `preload()` is called once on the calling thread before the first front half
+    starts — the place to load every model through the rank-collective path (`ModelManager.preload_for_config`) — and every front half runs
+    with the calling thread's current device (the HIP device is per thread and defaults to 0; ranks > 0 work on cuda:LOCAL_RANK)."""
     from .image.image_utils import save_image_with_compression
     if (process_front is None) != (process_back is None):
         raise ValueError("process_front and process_back come as a pair")
@@ -204,6 +208,18 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
 
     import contextlib
     import queue
+    if preload is not None and pipelined:
+        try:
+            preload()
+        except Exception as e:      # noqa: BLE001 — pages meet the same error on their own failure paths
+            log_message(f"Model preload failed: {e}", always_print=True)
+    main_device = None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            main_device = torch.cuda.current_device()
+    except Exception:      # noqa: BLE001
+        main_device = None
     free_slots = queue.SimpleQueue()               # a front half holds one slot (= one instance set of the front-half models) while it runs
     for slot in range(front_workers):
         free_slots.put(slot)
@@ -211,6 +227,9 @@ def batch_process_images(input_dir, config, output_dir=None, preserve_structure:
     def front_task(i):
         """decoded page i through the front half (worker thread); what it returns or raises belongs to page i"""
         t = time.perf_counter()
+        if main_device is not None:
+            import torch
+            torch.cuda.set_device(main_device)     # per thread: without it `torch.cuda.current_stream()` and hipSetDevice-scoped calls of this thread mean device 0
         page = decodes.pop(i).result()
         t1 = time.perf_counter()
         slot = free_slots.get()
@@ -436,6 +455,18 @@ def process_page_vision_back(state: Dict):
 _PIL_FORMAT_BY_SUFFIX = {".png": "PNG", ".jpg": "JPEG", ".jpeg": "JPEG", ".webp": "WEBP", ".bmp": "BMP", ".tif": "TIFF", ".tiff": "TIFF", ".gif": "GIF"}
 
 
+def resolve_sam_precision(config) -> str:
+    """SAM-2.1 arithmetic of a batch: what `config.detection.sam_precision` pins ("fast" / "high"), otherwise "high" whenever the masks feed
+    inpainting or upscaling (+ 11.6 ms of GPU time on a page that takes hundreds: 5.1e-5 of the mask pixels differ from the fp32 reference
+    instead of 1.8e-4) and "fast" for detect / segment / clean-only batches (37.9 against 27.6 pages/s, profiles/r05_bench_config2_sam_*.json)"""
+    pinned = getattr(getattr(config, "detection", None), "sam_precision", None)
+    if pinned in ("fast", "high"):
+        return pinned
+    osb = getattr(config, "outside_text", None)
+    heavy_back = bool(getattr(osb, "enabled", False)) or bool(getattr(getattr(config, "output", None), "upscale_final_image", False))
+    return "high" if heavy_back else "fast"
+
+
 def default_front_workers(config) -> int:
     """front halves a batch keeps in flight beside the running back half: 2 for configurations whose back half is short — no FLUX inpainting
     of outside text, no final upscale: then the page's time is its detect stage, whose graphs do not fill the chip (two pages' detect stages
@@ -457,13 +488,18 @@ def batch_vision_images(input_dir, config, output_dir=None, preserve_structure: 
     `process_page_vision`, page i + 1's front half (and, with `front_workers` > 1, the following pages' on further instance sets of the
     detectors and SAM) beside page i's back half; same files, order and results dict as the sequential loop."""
     verbose = bool(getattr(config, "verbose", False))
+    from .ml.model_manager import get_model_manager
+    manager = get_model_manager()
+    manager.sam_precision = resolve_sam_precision(config)
 
     def front(page, path):
-        return process_page_vision_front(page, config, path, _PIL_FORMAT_BY_SUFFIX.get(Path(path).suffix.lower()), verbose)
+        # worker thread: whatever it still has to load lazily is read locally — collectives belong to the main thread (preload below)
+        with manager.thread_local_reads():
+            return process_page_vision_front(page, config, path, _PIL_FORMAT_BY_SUFFIX.get(Path(path).suffix.lower()), verbose)
 
     def back(state):
         return process_page_vision_back(state)[0]
 
     n = default_front_workers(config) if front_workers is None else max(1, int(front_workers))
     return batch_process_images(input_dir, config, output_dir, preserve_structure, io_threads=io_threads, process_front=front, process_back=back,
-                                front_workers=n)
+                                front_workers=n, preload=lambda: manager.preload_for_config(config, verbose))

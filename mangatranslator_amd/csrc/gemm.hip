@@ -13,6 +13,8 @@
 #include "mtx_device.h"
 #include <type_traits>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_set>
 
 namespace mtx {
 
@@ -802,8 +804,21 @@ static unsigned gemm256_choose_slices(unsigned r, long nk, unsigned cus, double 
   return best;
 }
 
+// The K-slice tail counts arrivals in `tickets` and relies on finding zeros (the last arriver of a tile puts its ticket back to zero).  A
+// workspace the library has not seen before is cleared here, in front of its first slice launch on that stream — callers that allocate the
+// workspace themselves (hipMalloc does not clear) no longer have to know (include/mtx_hip.h still asks for a zeroed workspace:
+// an address that is freed and handed out again with other contents is not seen as new).
+static void gemm256_tickets_ready(unsigned* tickets, void* stream) {
+  static std::mutex mu;
+  static std::unordered_set<const void*> seen;
+  bool fresh;
+  { std::lock_guard<std::mutex> lock(mu); fresh = seen.insert(tickets).second; }
+  if (fresh) zero_words_async(tickets, (size_t)G2_TICKET_BYTES, stream);
+}
+
 template <typename T, bool F8>
 static void launch_gemm256_slices(const GemmParams& p, unsigned pieces, void* stream) {
+  gemm256_tickets_ready(p.tickets, stream);
 #define MTX_G256S(ACTV) MTX_LAUNCH((gemm256_slice_kernel<T, F8, ACTV>), dim3(pieces), dim3(512), 0, stream, p)
   switch (p.act) {
     case MTX_ACT_NONE: MTX_G256S(MTX_ACT_NONE); break;

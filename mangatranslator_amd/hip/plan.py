@@ -719,8 +719,15 @@ class AsyncLane:
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(cur)
 
+    ACQUIRE_TIMEOUT_S = 120.0      # far beyond any graph of this package; a wait this long is a ticket that was never closed
+
     def acquire(self):
-        self.busy.acquire()
+        """waits for the model's previous ticket to be closed.  A ticket kept alive by a traceback / frame / reference cycle, or a caller that
+        re-submits to the same model inside the `except` of a failed collect, never releases the lane by itself (the finaliser only runs when
+        the ticket is collected): instead of hanging the thread for good, say so"""
+        if not self.busy.acquire(timeout=self.ACQUIRE_TIMEOUT_S):
+            raise RuntimeError(f"model lane busy for {self.ACQUIRE_TIMEOUT_S:.0f} s: a ticket of an earlier submit() was neither collected nor closed "
+                               "(close tickets in try / finally, or use `with ticket:`)")
 
     def release(self):
         """idempotent: a ticket may be closed by `collect` and again by its finaliser"""
@@ -765,6 +772,13 @@ class LaneTicket(dict):
         if self._open:
             self._open = False
             self._lane.release()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):          # `with model.submit(...) as ticket:` — the lane is free again however the block ends
+        self.close()
+        return False
 
     def __del__(self):
         try:

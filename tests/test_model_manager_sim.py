@@ -226,3 +226,62 @@ def test_front_replicas_are_separate_instances_of_the_same_checkpoint(manager):
         assert manager.load_yolo_panel() is not panel1                               # rebuilt on demand
     manager.unload_all()
     assert all(not isinstance(k, tuple) for k in manager.models)
+
+
+def test_preload_order_worker_thread_reads_and_legacy_names(manager, monkeypatch):
+    """(1) `preload_for_config` asks the loaders in one fixed order whatever fails on the way; (2) inside `thread_local_reads` a
+    loader reads its checkpoint itself — no status / tensor broadcast, even with a process group up (the order of worker threads' calls is
+    not the same on every rank); (3) a staging directory that still holds the panel detector under its earlier export name is read."""
+    import types
+    from mangatranslator_amd.core.ml import model_manager as mm
+    from mangatranslator_amd.utils.exceptions import ModelError
+    calls = []
+
+    def fake(name, fail=False):
+        def load(*a, **k):
+            calls.append(name)
+            if fail:
+                raise ModelError(name + " not staged")
+            return object()
+        return load
+    for attr, fail in (("load_yolo_speech_bubble", False), ("load_rtdetr_conjoined_bubble", True), ("load_sam2", False), ("load_yolo_osbtext", True),
+                       ("load_yolo_panel", False), ("load_upscale", False), ("load_flux_klein_4b", False)):
+        monkeypatch.setattr(manager, attr, fake(attr, fail))
+    cfg = types.SimpleNamespace(
+        yolo_model_path=None, detection=types.SimpleNamespace(bubble_detector_model="yolo_2", conjoined_detection=True, seg_model="sam2", use_osb_text_verification=False, use_panel_sorting=True),
+        outside_text=types.SimpleNamespace(enabled=True, huggingface_token="", inpainting_method="flux_klein_4b"),
+        output=types.SimpleNamespace(upscale_final_image=True, image_upscale_model="model"), preprocessing=types.SimpleNamespace(enabled=False))
+    report = manager.preload_for_config(cfg)
+    assert calls == ["load_yolo_speech_bubble", "load_rtdetr_conjoined_bubble", "load_sam2", "load_yolo_osbtext", "load_yolo_panel", "load_upscale", "load_flux_klein_4b"]
+    assert report["SAM 2.1"] == "loaded" and report["RT-DETR secondary detector"].startswith("ModelError")
+    monkeypatch.undo()
+
+    # (2) + (3): the panel detector's earlier export, read from a worker-thread scope while "a process group is up"
+    from mangatranslator_amd.core.ml import model_manager as mm2
+    path = manager.model_paths[mm2.ModelType.YOLO_PANEL]
+    path.parent.mkdir(parents=True, exist_ok=True)
+    save_file({"w": torch.arange(6.0).reshape(2, 3)}, str(path.with_name("manga109_panel_yolo11l.safetensors")), metadata={"names": "{0: 'frame'}"})
+    monkeypatch.setattr(mm2, "_dist_on", lambda: True)
+
+    def no_collective(*a, **k):
+        raise AssertionError("a collective was issued from a worker-thread scope")
+    monkeypatch.setattr(mm2, "broadcast_status", no_collective)
+    monkeypatch.setattr(mm2, "broadcast_state_dict", no_collective)
+    with manager.thread_local_reads():
+        sd, md = manager._read_safetensors_with_metadata(path)
+        with pytest.raises(ModelError):
+            manager._staged(path.with_name("absent.json"), "config")
+    assert torch.equal(sd["w"], torch.arange(6.0).reshape(2, 3)) and md["names"] == "{0: 'frame'}"
+
+
+def test_sam_precision_of_a_batch():
+    """`resolve_sam_precision`: "high" when inpainting or upscaling follows the masks, "fast" for detect / segment / clean batches, a pin wins"""
+    import types
+    from mangatranslator_amd.core.pipeline import resolve_sam_precision
+    ns = types.SimpleNamespace
+    cfg = lambda osb, up, pin=None: ns(detection=ns(sam_precision=pin), outside_text=ns(enabled=osb), output=ns(upscale_final_image=up))
+    assert resolve_sam_precision(cfg(False, False)) == "fast"
+    assert resolve_sam_precision(cfg(True, False)) == "high"
+    assert resolve_sam_precision(cfg(False, True)) == "high"
+    assert resolve_sam_precision(cfg(False, False, "high")) == "high"
+    assert resolve_sam_precision(cfg(True, True, "fast")) == "fast"

@@ -87,16 +87,20 @@ def test_manager_loads_sam_in_f16_and_falls_back_to_bf16(emu_lib, tmp_path, monk
         cfg.save_pretrained(str(root))
         sd = {k: v.contiguous() for k, v in model.state_dict().items()}
         save_file(sd, str(root / "model.safetensors"))
-        proc, shim = m.load_sam2()
-        assert shim.hip.dtype == abi.F16 and not shim.hip.high
-        m.unload_model(mm.ModelType.SAM2)
-        m.sam_precision = "high"                                   # hi + lo trunk weights, fp32 mask decoder, on the storage type the probe settled on
-        proc, shim = m.load_sam2()
+        assert m.sam_precision == "high" and m.sam_storage == "auto"          # the defaults (round 5: "high" measured on hardware)
+        proc, shim = m.load_sam2()                                  # hi + lo trunk weights, fp32 mask decoder, on the storage type the probe settled on
         assert shim.hip.dtype == abi.F16 and shim.hip.high and shim.hip.ddtype == abi.F32
         with m.front_replica(1):
             assert m.load_sam2()[1].hip.high                         # a replica follows set 0
+        m.sam_precision = "fast"                                    # changed after the load: the next call builds the other arithmetic
+        proc, shim = m.load_sam2()
+        assert shim.hip.dtype == abi.F16 and not shim.hip.high
+        assert m.load_sam2()[1] is shim
         m.unload_model(mm.ModelType.SAM2)
-        m.sam_precision = "fast"
+        m.sam_storage = "bf16"                                      # the reference's own GPU dtype, no probe
+        assert m.load_sam2()[1].hip.dtype == abi.BF16
+        m.unload_model(mm.ModelType.SAM2)
+        m.sam_storage = "auto"
         # blow up one MLP of the trunk: its hidden activations leave the f16 range
         key = next(k for k in sd if "backbone" in k and "mlp" in k and k.endswith("proj_in.weight"))
         sd[key] = sd[key] * 3.0e5
