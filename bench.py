@@ -101,9 +101,10 @@ def parse():
     ap.add_argument("--upscale-model", default="model", choices=["model", "model_lite"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-traffic", action="store_true", help=argparse.SUPPRESS)       # (round 3's opt-in; the counter child now runs by default)
-    ap.add_argument("--sam-precision", choices=("fast", "high"), default="fast",
-                    help="SAM-2.1 arithmetic: fast = 16-bit storage as measured all round; high = hi + lo trunk weights and an fp32 mask decoder "
-                         "(core/ml/sam2.py; for the A/B of the segment stage's time once it has run on hardware)")
+    ap.add_argument("--sam-precision", choices=("fast", "high"), default=None,
+                    help="SAM-2.1 arithmetic: high = hi + lo trunk weights, fp32 residual stream and an fp32 mask decoder (core/ml/sam2.py); fast = 16-bit "
+                         "storage throughout.  Default: the product's rule (core/pipeline.py resolve_sam_precision) — high when inpainting or upscaling "
+                         "follows the masks (configs 3, 4, 5), fast for detect / segment / clean-only stage sets (configs 1, 2)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the counter child that fills roofline.traffic: after the timed region rank 0 (at --gpus 1) re-executes this command's inpaint "
                          "(or upscale) stage under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two passes, --kernel-trace only) on a DiT cut to "
@@ -146,6 +147,9 @@ def parse():
         a.inpainter = "klein_4b" if a.config == 5 else "kontext"
     if a.inpaint_steps is None:
         a.inpaint_steps = 20 if a.inpainter == "kontext" else 8
+    a.sam_precision_rule = a.sam_precision is None
+    if a.sam_precision is None:
+        a.sam_precision = "high" if {"inpaint", "upscale"} & {x.strip() for x in a.stages.split(",")} else "fast"
     return a
 
 
@@ -236,11 +240,17 @@ def main():
     # Counted on the cores this process may actually run on (a container's affinity mask, not the machine's core count: setting the
     # latter on a 32-core slice of a 256-core host made every small torch op 40 ms — measured, r03 visit E), and capped: the host ops
     # here are small, more than 16 threads each only adds fork / join time.
+    # With several ranks each one first moves to the CPUs of its GPU's NUMA node (its share of them when GPUs share a node):
+    # core/device.py pin_host_threads_to_gpu — worker threads and codec pools started later inherit the mask.
+    placement = {"pinned": False, "reason": "one rank"}
+    if world > 1 and os.environ.get("MTX_BENCH_ONE_DEVICE") != "1":
+        from mangatranslator_amd.core.device import pin_host_threads_to_gpu
+        placement = pin_host_threads_to_gpu(local_rank, n_devices=torch.cuda.device_count())
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 8
-    host_threads = max(1, min(16, usable // world, torch.get_num_threads()))
+    host_threads = max(1, min(16, usable if placement.get("pinned") else usable // world, torch.get_num_threads()))
     torch.set_num_threads(host_threads)
     dist = None
     if world > 1:
@@ -694,7 +704,8 @@ def main():
                    "detector": (("YOLO11m-seg (yolo_2, the reference's default)" if args.bubble_detector == "yolo_2" else "YOLOv8m-seg (yolo_1)")
                                 + " @imgsz 1600 + RT-DETR-v2 R50 @640 (secondary)"
                                 + (" + YOLO11-L panel detector @640 + YOLO12x outside-text detector @640" if aux_detectors else "") + ", seeded random weights") if yolo is not None else None,
-                   "segmenter": "SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights" if sam is not None else None,
+                   "segmenter": (f"SAM-2.1 Hiera-L (HF Sam2Model layout), seeded random weights, precision {args.sam_precision!r}"
+                                 + (" (the product's rule for this stage set)" if args.sam_precision_rule else " (--sam-precision)")) if sam is not None else None,
                    "inpainter": inp_desc,
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
                    "detector_calls": ("one after the other" if args.serial_detectors else "submitted together, one HIP stream per model, collected afterwards") if yolo is not None else None,
@@ -704,7 +715,7 @@ def main():
                                      "two pages in flight: detect / segment / OSB prepare of page i+1 on a worker thread beside inpaint / upscale / clean of page i"
                                      if overlap else "stages strictly in order, one page at a time"),
                    "parallelism": f"page-sharded x{world}, weights broadcast once over RCCL",
-                   "host_threads_per_rank": host_threads, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                   "host_threads_per_rank": host_threads, "host_placement": placement, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                    "launch": {"world_size_seen_by_collectives": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                               "self_launched": os.environ.get("MTX_BENCH_SELF_LAUNCHED") == "1", "model_setup_and_weight_broadcast_s": round(load_s, 2)}},
     }
@@ -852,7 +863,7 @@ def main():
         if not args.no_traffic and not args.traffic_child and world == 1 and "roofline" in result:
             result["roofline"]["traffic"], result["roofline"]["traffic_detail"] = measure_traffic(result["roofline"]["kernel"])
         if (world == 1 and headline and not args.no_extra and not args.extra_child and not args.traffic_child
-                and args.kontext_backend == "sdnq" and args.sam_precision == "fast"):
+                and args.kontext_backend == "sdnq" and args.sam_precision_rule):
             result["extra"] = run_extra_children()
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is a single-GPU-run item (rank 0 at N = 1 only)
             result["cpu_baseline"] = cpu_baseline(stages, rcan_sd, W_, H_, args, cfg.get("inpaint"), flux.transformer.cfg if (klein and flux is not None) else None)

@@ -42,3 +42,87 @@ def get_device_info(device: Optional[torch.device] = None) -> dict:
 def is_gpu_available() -> bool:
     """reference core/device.py:169-191 (one backend here: ROCm behind torch.cuda)"""
     return torch.cuda.is_available()
+
+
+# ---- host placement for N ranks on one node (no counterpart in the reference, which runs one process) ------------------------------------
+def _parse_cpulist(text: str) -> list:
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_pci_addresses(sys_root: str = "/sys") -> list:
+    """PCI addresses of the AMD GPUs / accelerators of this host in bus order — the order HIP numbers them in when HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES do not remap (display controller 0x03xx or processing accelerator 0x12xx, vendor 0x1002)"""
+    from pathlib import Path
+    out = []
+    base = Path(sys_root) / "bus" / "pci" / "devices"
+    if not base.is_dir():
+        return out
+    for d in sorted(base.iterdir()):
+        try:
+            if (d / "vendor").read_text().strip().lower() != "0x1002":
+                continue
+            cls = (d / "class").read_text().strip().lower()
+            if cls.startswith("0x03") or cls.startswith("0x12"):
+                out.append(d.name)
+        except OSError:
+            continue
+    return out
+
+
+def gpu_local_cpus(device_index: int, n_devices: Optional[int] = None, sys_root: str = "/sys") -> Optional[list]:
+    """The CPUs this rank should run its host threads on: those of the NUMA node its GPU hangs off (`local_cpulist` of the GPU's PCI
+    function), intersected with the CPUs the process may use, and — when several of the node's GPUs share that NUMA node — this GPU's
+    equal share of them (GPUs in bus order).  None when the topology cannot be read (containers without /sys PCI entries) or says nothing
+    (one NUMA node, numa_node = -1): the caller then leaves the affinity alone."""
+    from pathlib import Path
+    addrs = gpu_pci_addresses(sys_root)
+    if torch.cuda.is_available() and sys_root == "/sys":
+        try:                                           # the runtime's own answer for this index, when it exposes it
+            pr = torch.cuda.get_device_properties(device_index)
+            if hasattr(pr, "pci_bus_id") and hasattr(pr, "pci_device_id"):
+                want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+                if want in addrs:
+                    device_index = addrs.index(want)
+        except Exception:      # noqa: BLE001
+            pass
+    if n_devices is not None and len(addrs) > n_devices:
+        addrs = addrs[:n_devices]
+    if not (0 <= device_index < len(addrs)):
+        return None
+    base = Path(sys_root) / "bus" / "pci" / "devices"
+    try:
+        lists = [tuple(_parse_cpulist((base / a / "local_cpulist").read_text())) for a in addrs]
+    except (OSError, ValueError):
+        return None
+    mine = lists[device_index]
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    cpus = [c for c in mine if c in allowed]
+    if not cpus or (len(addrs) <= 1 and len(cpus) == len(allowed)):      # nothing usable, or one GPU whose node is the whole mask
+        return None
+    sharers = [i for i, l in enumerate(lists) if l == mine]
+    k, n = sharers.index(device_index), len(sharers)
+    share = cpus[k * len(cpus) // n:(k + 1) * len(cpus) // n]
+    return share or None
+
+
+def pin_host_threads_to_gpu(device_index: int, n_devices: Optional[int] = None, sys_root: str = "/sys") -> dict:
+    """`os.sched_setaffinity` of the calling thread (threads started afterwards inherit it) to `gpu_local_cpus`: a page's host work — NMS, mask
+    logic, PNG codecs, the launches themselves — then runs on the socket its GPU is attached to instead of wherever the scheduler put the
+    rank.  At configs 1 / 2 speeds (tens of pages per second and GPU) eight ranks are host-bound.  -> what was done."""
+    cpus = gpu_local_cpus(device_index, n_devices, sys_root)
+    if not cpus:
+        return {"pinned": False, "reason": "no usable PCI / NUMA topology for this GPU"}
+    try:
+        os.sched_setaffinity(0, cpus)
+    except (AttributeError, OSError) as e:
+        return {"pinned": False, "reason": str(e)}
+    return {"pinned": True, "cpus": len(cpus), "first": cpus[0], "last": cpus[-1]}

@@ -615,31 +615,73 @@ def vae_param_shapes(cfg: dict) -> dict:
     return s
 
 
+BROADCAST_BUCKET_BYTES = 1 << 30
+
+
+def broadcast_in_buckets(entries, make, device, src: int = 0, bucket_bytes: int = None) -> dict:
+    """Start-up weight broadcast of a model that is built tensor by tensor: `entries` = [(name, shape, dtype)] in an order every rank
+    agrees on; rank `src` fills each tensor through `make(name, out_view)`; the tensors travel in flat per-dtype buckets of at most
+    `bucket_bytes` — FLUX.1-Kontext's 24 GB are ~25 collectives instead of ~1 000 per-tensor ones (xGMI rings are per-link bound: few
+    large transfers) — and every rank gets name -> view into its bucket (the views keep their bucket alive).
+    gloo (CPU dry runs) stages the buckets through host memory."""
+    import torch.distributed as dist
+    bucket_bytes = bucket_bytes or BROADCAST_BUCKET_BYTES
+    rank = dist.get_rank()
+    nccl = dist.get_backend() == "nccl"
+    out, groups = {}, {}
+    for name, shape, dt in entries:
+        groups.setdefault(dt, []).append((name, tuple(shape)))
+    for dt, items in groups.items():
+        esz = torch.empty((), dtype=dt).element_size()
+        start = 0
+        while start < len(items):
+            end, n = start, 0
+            while end < len(items) and (end == start or (n + int(np.prod(items[end][1]))) * esz <= bucket_bytes):
+                n += int(np.prod(items[end][1]))
+                end += 1
+            flat = torch.empty(n, dtype=dt, device=device)
+            views, off = [], 0
+            for name, shape in items[start:end]:
+                k = int(np.prod(shape))
+                views.append((name, flat[off:off + k].view(shape)))
+                off += k
+            if rank == src:
+                for name, v in views:
+                    make(name, v)
+            if nccl:
+                dist.broadcast(flat, src=src)
+            else:
+                h = flat.cpu()
+                dist.broadcast(h, src=src)
+                flat.copy_(h)
+            out.update(views)
+            start = end
+    return out
+
+
 def synthetic_provider(shapes: dict, device, seed: int, broadcast: bool = False):
     """Seeded random-init parameters generated on `device` one tensor at a time (benchmarks: there is no
-    checkpoint on the box).  With `broadcast`, rank 0's tensors are sent to every rank over RCCL — the
-    start-up weight broadcast of the page-sharded deployment."""
+    checkpoint on the box).  With `broadcast` and more than one rank, rank 0 generates every tensor up front (in the order of `shapes`)
+    and the set travels in flat buckets (`broadcast_in_buckets`) — the start-up weight broadcast of the page-sharded deployment."""
     gen = torch.Generator(device=device).manual_seed(seed)
 
-    def get(name):
+    def dtype_of(name):
+        return torch.bfloat16 if len(shapes[name]) >= 2 else torch.float32
+
+    def fresh(name):
         shp = shapes[name]
         if len(shp) >= 2:
             fan = int(np.prod(shp[1:]))
-            t = torch.randn(shp, device=device, generator=gen, dtype=torch.float32).mul_(1.0 / math.sqrt(fan)).to(torch.bfloat16)
-        elif name.endswith("running_var"):
-            t = 0.5 + 1.5 * torch.rand(shp, device=device, generator=gen)
-        elif "norm" in name and name.endswith("weight"):
-            t = 1.0 + 0.1 * torch.randn(shp, device=device, generator=gen)
-        else:
-            t = 0.02 * torch.randn(shp, device=device, generator=gen)
-        if broadcast:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                if dist.get_backend() == "nccl":
-                    dist.broadcast(t, src=0)
-                else:                                  # gloo dry runs: host staging
-                    h = t.cpu()
-                    dist.broadcast(h, src=0)
-                    t = h.to(device)
-        return t
-    return get
+            return torch.randn(shp, device=device, generator=gen, dtype=torch.float32).mul_(1.0 / math.sqrt(fan)).to(torch.bfloat16)
+        if name.endswith("running_var"):
+            return 0.5 + 1.5 * torch.rand(shp, device=device, generator=gen)
+        if "norm" in name and name.endswith("weight"):
+            return 1.0 + 0.1 * torch.randn(shp, device=device, generator=gen)
+        return 0.02 * torch.randn(shp, device=device, generator=gen)
+
+    if broadcast:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            ready = broadcast_in_buckets([(n, shapes[n], dtype_of(n)) for n in shapes], lambda n, v: v.copy_(fresh(n)), device)
+            return lambda name: ready[name]
+    return fresh

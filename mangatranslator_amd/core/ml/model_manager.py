@@ -768,7 +768,7 @@ class ModelManager:
 
 class _ShardedProvider:
     """name -> tensor over the *.safetensors shards of one diffusers sub-folder.  Rank 0 reads; with more
-    than one rank every tensor is handed to the others by an RCCL broadcast (start-up only).  What rank 0 finds wrong (no shards,
+    than one rank the tensors are handed to the others in flat RCCL broadcasts of up to 1 GiB (start-up only).  What rank 0 finds wrong (no shards,
     missing or mis-shaped parameters) is shared through `broadcast_status` first, so every rank raises the same ModelError."""
 
     def __init__(self, folder: Path, shapes: dict, device, keep_dtype=()):
@@ -806,20 +806,26 @@ class _ShardedProvider:
                 except Exception as e:
                     error = f"cannot read the shards under {folder}: {e}"
         broadcast_status(error)
+        self._ready = None
+        if self.multi:
+            # several ranks: the whole sub-folder travels now, in flat buckets of <= 1 GiB per dtype (24 GB of Kontext weights: ~25
+            # broadcasts; tensor by tensor it was ~1 000) — the model's constructor then picks views out of the buckets
+            from .flux import broadcast_in_buckets
+            self._ready = broadcast_in_buckets([(n, shapes[n], self._dtype_of(n)) for n in sorted(shapes)],
+                                               lambda n, v: v.copy_(self._read(n, v.dtype)), self.device)
+
+    def _dtype_of(self, name: str):
+        return torch.float32 if self.keep_dtype and name.startswith(self.keep_dtype) else torch.bfloat16
+
+    def _read(self, name: str, dt) -> torch.Tensor:
+        if self.sdnq is not None and self.sdnq.is_packed(name):
+            return self.sdnq.get(name, self.shapes[name]).to(self.device, dt)
+        return self.where[name].get_tensor(name).to(self.device, dt, copy=True)   # never a view of the shard's mapping (it goes away with the handle)
 
     def __call__(self, name: str) -> torch.Tensor:
-        dt = torch.float32 if name.startswith(self.keep_dtype) and self.keep_dtype else torch.bfloat16
-        if self.rank0:
-            if self.sdnq is not None and self.sdnq.is_packed(name):
-                t = self.sdnq.get(name, self.shapes[name]).to(self.device, dt)
-            else:
-                t = self.where[name].get_tensor(name).to(self.device, dt, copy=True)   # never a view of the shard's mapping (it goes away with the handle)
-        else:
-            t = torch.empty(self.shapes[name], dtype=dt, device=self.device)
-        if self.multi:
-            import torch.distributed as dist
-            dist.broadcast(t, src=0)
-        return t
+        if self._ready is not None:
+            return self._ready[name]
+        return self._read(name, self._dtype_of(name))
 
 
 _model_manager = None

@@ -35,6 +35,18 @@ def set_hardware_queues(n: int = 16) -> bool:
     return True
 
 
+def pin_rank_to_gpu_cpus() -> dict:
+    """For services that run one process per GPU (LOCAL_RANK set by the launcher): this process's host threads move to the CPUs of the NUMA
+    node its GPU is attached to — its share of them when several GPUs hang off one node (core/device.py pin_host_threads_to_gpu).  Call
+    it after install() and before the page loop starts its thread pools; a single process on a one-GPU host is left alone."""
+    import os
+    import torch
+    from .core.device import pin_host_threads_to_gpu
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        return {"pinned": False, "reason": "one GPU"}
+    return pin_host_threads_to_gpu(int(os.environ.get("LOCAL_RANK", "0")), n_devices=torch.cuda.device_count())
+
+
 def install(include_caching: bool = True, share_utils: bool = True, hardware_queues: "int | None" = None) -> list:
     """-> the list of `core.*` module names now served by this package.  `include_caching=False` keeps the reference's own stage memo
     (needed when its translation / manga-ocr key builders are in use: this build restates the vision-side keys only).

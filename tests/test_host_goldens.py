@@ -145,3 +145,29 @@ def test_page_sharding_partitions_every_page_once():
     merged = pl.merge_batch_results([{"success_count": 2, "error_count": 1, "errors": {"a": "x"}, "failed_image_paths": ["p10.png"]},
                                      {"success_count": 3, "error_count": 0, "errors": {}, "failed_image_paths": ["p2.png"]}])
     assert merged["success_count"] == 5 and merged["failed_image_paths"] == ["p2.png", "p10.png"]
+
+
+def test_gpu_numa_placement(tmp_path, monkeypatch):
+    """core/device.py gpu_local_cpus on a made-up /sys: eight accelerators, four per NUMA node — every rank gets a quarter of its node's
+    CPUs, nothing outside the process's affinity mask, and None when the tree is absent (containers)"""
+    import os
+    from mangatranslator_amd.core import device as dv
+    root = tmp_path / "sys"
+    for i in range(8):
+        d = root / "bus" / "pci" / "devices" / f"0000:{0x05 + 0x10 * i:02x}:00.0"
+        d.mkdir(parents=True)
+        (d / "vendor").write_text("0x1002\n"); (d / "class").write_text("0x120000\n")
+        (d / "local_cpulist").write_text("0-15,64-79\n" if i < 4 else "16-31,80-95\n")
+    nic = root / "bus" / "pci" / "devices" / "0000:01:00.0"
+    nic.mkdir(parents=True); (nic / "vendor").write_text("0x15b3\n"); (nic / "class").write_text("0x020000\n")
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)), raising=False)
+    monkeypatch.setattr(dv.torch.cuda, "is_available", lambda: False)
+    assert len(dv.gpu_pci_addresses(str(root))) == 8
+    shares = [dv.gpu_local_cpus(i, 8, str(root)) for i in range(8)]
+    assert shares[0] == list(range(0, 8)) and shares[1] == list(range(8, 16)) and shares[2] == list(range(64, 72)) and shares[3] == list(range(72, 80))
+    assert shares[4] == list(range(16, 24)) and shares[7] == list(range(88, 96))
+    assert not set(shares[0]) & set(shares[1]) and all(len(s) == 8 for s in shares)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(0, 8)) | set(range(16, 20)), raising=False)
+    assert dv.gpu_local_cpus(0, 8, str(root)) == [0, 1] and dv.gpu_local_cpus(5, 8, str(root)) == [17]
+    assert dv.gpu_local_cpus(0, 8, str(tmp_path / "nowhere")) is None and dv.gpu_local_cpus(9, 8, str(root)) is None
+    assert dv.pin_host_threads_to_gpu(0, 8, str(tmp_path / "nowhere"))["pinned"] is False

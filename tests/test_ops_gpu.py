@@ -147,6 +147,17 @@ def test_attention_alternative_schedules(hip_lib, schedule):
     oc.check_attention(hip_lib, abi.BF16, batch=1, heads=2, sq=1024, sk=320, d=128, qmul=8.0, prescaled=True, schedule=schedule, late_keys=(200, 12.0))
 
 
+def test_f32_ops(hip_lib):
+    """MTX_F32 instantiations of gemm / attention / norm / element-wise (csrc/f32ops.hip: SAM's fp32 mask decoder under precision "high")"""
+    assert oc.check_f32_ops(hip_lib) < 2e-5
+
+
+def test_hi_lo_weight_pairs(hip_lib):
+    """W = W_hi + W_lo as ONE GEMM over K' = 2K ([x | x] against [W_hi | W_lo], fp32 accumulation): SAM's trunk under precision 'high'"""
+    oc.check_hi_lo_weights(hip_lib)
+    oc.check_hi_lo_weights(hip_lib, m=4096, n=2304, k=576)          # Hiera-L stage 3, fc1: the 256-tile kernel takes the 16-bit-output form (K' = 1152)
+
+
 def test_first_block_cache_probe(hip_lib):
     """MTX_EW_RESIDUAL_DIST + MTX_EW_SUB at the Kontext image stream's size: the distance torch computes on the same rounded operands, the same
     parts from two launches (no atomics: the cache decision cannot depend on scheduling)"""

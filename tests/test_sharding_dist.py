@@ -41,6 +41,20 @@ def _worker(rank, world, port, out_dir):
     ref = fx.synthetic_provider(shapes, "cpu", seed=7, broadcast=False)
     assert all(torch.equal(mine[k], ref(k)) for k in shapes), "per-tensor broadcast mismatch"
 
+    # 2b. the same set in buckets: several tensors per collective, a tensor larger than the bucket alone in its own, both dtypes
+    import mangatranslator_amd.core.ml.flux as fxm
+    calls = []
+    real_bcast = dist.broadcast
+    dist.broadcast = lambda t, src=0: (calls.append(t.numel()), real_bcast(t, src=src))[1]
+    try:
+        big = {"w0": (40, 16), "w1": (8, 16), "w2": (8, 16), "b0": (40,), "b1": (8,), "w3": (8, 16)}
+        got = fxm.broadcast_in_buckets([(n, s, torch.bfloat16 if len(s) == 2 else torch.float32) for n, s in big.items()],
+                                       lambda n, v: v.copy_(torch.full(v.shape, float(len(n) + sum(map(ord, n)) % 7 + (0 if rank == 0 else 100)))), "cpu", bucket_bytes=600)
+    finally:
+        dist.broadcast = real_bcast
+    assert calls == [640, 256, 128, 48], calls                      # bf16: 1280 B alone, 2 x 256 B together (a third would pass 600 B), the last alone; fp32: one bucket
+    assert all(float(got[n].float().max()) == float(len(n) + sum(map(ord, n)) % 7) and tuple(got[n].shape) == s for n, s in big.items())
+
     # 3. sharded batch loop + gather
     pages = [f"ch2/010.jpg", "ch2/001.jpg", "ch10/001.jpg", "P1.png", "p10.png", "p2.png", "bad_3.png"]
     mine_pages = shard_pages(pages, rank, world)
