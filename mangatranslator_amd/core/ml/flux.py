@@ -475,7 +475,9 @@ class FluxKontextHip:
 
     def encode_prompt(self, prompt=None, prompt_2=None, device=None, **kw):
         if self._embeds is None:
-            raise ModelError("FLUX text encoders are not part of the MI355X hot path: export them once with `python tools/export_prompt_embeds.py kontext <pipeline snapshot>` (writes prompt_embeds.safetensors next to the transformer) or hand them to set_prompt_embeds()")
+            raise ModelError("no prompt embeddings: the loader encodes the fixed prompt once when the snapshot's text_encoder/, text_encoder_2/, tokenizer/, tokenizer_2/ "
+                             "folders are staged next to transformer/ (core/ml/prompt_embeds.py); otherwise run `python tools/export_prompt_embeds.py kontext <pipeline "
+                             "snapshot>` (writes prompt_embeds.safetensors) or hand the tensors to set_prompt_embeds()")
         return self._embeds[0][None], self._embeds[1][None], None
 
     @torch.no_grad()

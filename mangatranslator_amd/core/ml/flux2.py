@@ -384,7 +384,9 @@ class Flux2KleinHip:
 
     def encode_prompt(self, prompt=None, device=None, **kw):
         if self._embeds is None:
-            raise ModelError("FLUX.2 text encoder (Qwen3) is not part of the MI355X hot path: export them once with `python tools/export_prompt_embeds.py klein <pipeline snapshot>` (writes prompt_embeds.safetensors next to the transformer) or hand them to set_prompt_embeds()")
+            raise ModelError("no prompt embeddings: the loader encodes the fixed prompt once when the snapshot's text_encoder/ and tokenizer/ folders are staged next to "
+                             "transformer/ (core/ml/prompt_embeds.py); otherwise run `python tools/export_prompt_embeds.py klein <pipeline snapshot>` (writes "
+                             "prompt_embeds.safetensors) or hand the tensor to set_prompt_embeds()")
         n = self._embeds.shape[0]
         text_ids = torch.zeros(1, n, 4)
         text_ids[0, :, 3] = torch.arange(n)

@@ -435,6 +435,20 @@ class ModelManager:
             sd = broadcast_state_dict(sd, template=meta[0])
         return sd, metadata
 
+    def _prompt_embeds_ready(self, root: Path, pipeline: str) -> bool:
+        """rank 0's verdict, shared: `root / prompt_embeds.safetensors` exists — after encoding the fixed prompt ONCE from the snapshot's
+        staged text encoder(s) if the file was absent (core/ml/prompt_embeds.py: the reference's first-use encode, inpainting.py:846-873 /
+        :1110-1124, moved to load time; the encoders are dropped again)"""
+        import torch.distributed as dist
+        rank0 = not _dist_on() or dist.get_rank() == 0 or self._local_reads()
+        have = [False]
+        if rank0:
+            from .prompt_embeds import ensure_prompt_embeds
+            have = [bool(ensure_prompt_embeds(root, pipeline, device=self.device, log=lambda msg: log_message(msg, always_print=True)))]
+        if _dist_on() and not self._local_reads():
+            dist.broadcast_object_list(have, src=0)
+        return bool(have[0])
+
     def _detector_from_state_dict(self, sd: dict, default_names: Optional[dict] = None, metadata: Optional[dict] = None):
         """ultralytics detector state dict (from the `.pt` itself or its safetensors export) -> the graph of its family: YOLOv8-seg
         (`YoloSegHip`) or YOLO11 / YOLO11-seg / YOLO12 (`Yolo11Hip`), told apart by the blocks the state dict holds.  Class names come
@@ -686,7 +700,7 @@ class ModelManager:
             vae = FluxVAEHip(_ShardedProvider(root / "vae", vae_param_shapes(vcfg), self.device), vcfg, self.device)
             pipe = FluxKontextHip(dit, vae)
             emb = root / "prompt_embeds.safetensors"
-            if emb.exists():
+            if self._prompt_embeds_ready(root, "kontext"):
                 e = self._read_safetensors(emb)
                 pipe.set_prompt_embeds(e["prompt_embeds"], e["pooled_prompt_embeds"])
             self.models[mt] = pipe
@@ -750,10 +764,7 @@ class ModelManager:
                 raise ModelError(f"Failed to load Flux.2 Klein {variant.upper()} model: {e}") from e
             pipe = flux2.Flux2KleinHip(dit, vae)
             emb = root / "prompt_embeds.safetensors"
-            have = [bool(rank0 and emb.exists())]
-            if _dist_on():
-                dist.broadcast_object_list(have, src=0)
-            if have[0]:
+            if self._prompt_embeds_ready(root, "klein"):
                 pipe.set_prompt_embeds(self._read_safetensors(emb)["prompt_embeds"])
             self.models[model_type] = pipe
             log_message(f"Flux.2 Klein {variant.upper()} model loaded successfully (libmtx_hip graphs, {'fp8 + ' if self.flux_klein_fp8 else ''}bf16).", verbose=verbose)

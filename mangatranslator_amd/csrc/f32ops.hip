@@ -87,6 +87,86 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(mtx_gemm_args p) {
   }
 }
 
+// ---- the same GEMM on the matrix pipe: v_mfma_f32_32x32x2_f32 — fp32 operands, fp32 products and sums (exact fp32, no TF32 on gfx950), at
+// the vector ALUs' peak rate but without their LDS-operand traffic (MI355X_MICROARCH.md: 155 TFLOP/s measured).  Round 5: with precision
+// "high" SAM's mask decoder spends its time in the image-side projections (8 boxes x 4 096 tokens x 256 -> 128 / 256: 28 GFLOP per
+// page) and ran 4.5 ms against 1.6 ms in 16-bit storage (profiles/r05_bench_config2_sam_high.json).
+// 128 x 64 tile, 4 waves in a 2 x 2 grid of 64 x 32 wave tiles (two 32 x 32 accumulator blocks each); the k-major LDS images of the FMA
+// kernel; lane (l31, hi) feeds A[row l31][k = hi] and B[k = hi][column l31] of a k pair, and holds C rows (r & 3) + 8 (r >> 2) + 4 hi of
+// column l31 — so a wave's stores are 128-byte row segments.
+__device__ __forceinline__ f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+#ifdef MTX_EMU
+  return emu_mfma_32x32x2_f32(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mtx_gemm_args p) {
+  __shared__ float As[F_TK][F_TM + 4];
+  __shared__ float Ws[F_TK][F_TN + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wm = wv >> 1, wn = wv & 1;
+  const long m0 = (long)blockIdx.y * F_TM, n0 = (long)blockIdx.x * F_TN, z = blockIdx.z;
+  const float* A = reinterpret_cast<const float*>(p.a) + z * p.a_bstride;
+  const float* W = reinterpret_cast<const float*>(p.w) + z * p.w_bstride;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (long k0 = 0; k0 < p.k; k0 += F_TK) {
+    {
+      const long r = m0 + (tid >> 1);
+      const int kq = (tid & 1) * 8;
+      const bool row_ok = r < p.m;
+      if (row_ok && k0 + kq + 8 <= p.k && ((p.lda | (k0 + kq)) & 3) == 0 && ((size_t)(A + r * p.lda + k0 + kq) & 15) == 0) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(A + r * p.lda + k0 + kq), v1 = *reinterpret_cast<const f32x4*>(A + r * p.lda + k0 + kq + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { As[kq + i][tid >> 1] = v0[i]; As[kq + 4 + i][tid >> 1] = v1[i]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const long k = k0 + kq + i;
+          As[kq + i][tid >> 1] = (row_ok && k < p.k) ? A[r * p.lda + k] : 0.f;
+        }
+      }
+      const long c = n0 + (tid >> 2);
+      const int kw = (tid & 3) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long k = k0 + kw + i;
+        Ws[kw + i][tid >> 2] = (c < p.n && k < p.k) ? W[c * p.ldw + k] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < F_TK; kk += 2) {
+      const float b = Ws[kk + hi][wn * 32 + l31];
+      const float a0 = As[kk + hi][wm * 64 + l31], a1 = As[kk + hi][wm * 64 + 32 + l31];
+      acc[0] = mfma_f32_32x32x2(a0, b, acc[0]);
+      acc[1] = mfma_f32_32x32x2(a1, b, acc[1]);
+    }
+    __syncthreads();
+  }
+  float* Cz = reinterpret_cast<float*>(p.c) + z * p.c_bstride;
+  const float* R = p.res ? reinterpret_cast<const float*>(p.res) + z * p.res_bstride : nullptr;
+  const long c = n0 + wn * 32 + l31;
+  if (c >= p.n) return;
+  const float bias = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (row >= p.m) continue;
+      float v = acc[i][r] * p.alpha + bias;
+      v = act_f32(v, p.act, p.act_param);
+      if (R) v += R[row * p.ldres + c];
+      Cz[row * p.ldc + c] = v;
+    }
+}
+
 int gemm_f32_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (!a->a || !a->w || !a->c) { *err = "gemm f32: null operand"; return MTX_ERR_INVALID; }
   if (a->gate || a->glu_q || a->in_dtype == MTX_F8 || (a->out_dtype != MTX_F32 && a->out_dtype != a->dtype)) {
@@ -96,7 +176,10 @@ int gemm_f32_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (a->batch > 65535) { *err = "gemm f32: batch > 65535"; return MTX_ERR_INVALID; }
   dim3 grid((unsigned)((a->n + F_TN - 1) / F_TN), (unsigned)((a->m + F_TM - 1) / F_TM), (unsigned)a->batch);
   if (grid.y > 65535) { *err = "gemm f32: more than 65535 row tiles"; return MTX_ERR_INVALID; }
-  MTX_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, stream, *a);
+  // from a few row tiles up the matrix pipe wins; the token-side GEMMs (72 rows) stay on the vector ALUs (MTX_GEMM_FORCE_TILE256 forces the
+  // matrix kernel: tests)
+  if (a->m >= 256 || (a->flags & MTX_GEMM_FORCE_TILE256)) MTX_LAUNCH(gemm_f32_mfma_kernel, grid, dim3(256), 0, stream, *a);
+  else MTX_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, stream, *a);
   return MTX_OK;
 }
 

@@ -226,6 +226,30 @@ inline emu_f32x16 emu_mfma_32x32x16(V8 a, V8 b, emu_f32x16 c) {
   emu::wave_sync();
   return d;
 }
+// v_mfma_f32_32x32x2_f32: D = A(32x2) * B(2x32) + C, fp32 throughout; lane l holds A[l & 31][l >> 5] and B[l >> 5][l & 31]; C / D as the
+// other 32x32 forms (column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5))
+inline emu_f32x16 emu_mfma_32x32x2_f32(float a, float b, emu_f32x16 c) {
+  emu::WaveState& w = emu::wave();
+  int l = emu::lane_id();
+  memcpy(w.xa[l], &a, 4);
+  memcpy(w.xb[l], &b, 4);
+  emu::wave_sync();
+  emu_f32x16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float s = d[r];
+    for (int k = 0; k < 2; ++k) {
+      float pa, pb;
+      memcpy(&pa, w.xa[k * 32 + row], 4);
+      memcpy(&pb, w.xb[k * 32 + col], 4);
+      s = fmaf(pa, pb, s);
+    }
+    d[r] = s;
+  }
+  emu::wave_sync();
+  return d;
+}
 // ---- OCP fp8 e4m3fn (bias 7, no inf, 0x7f = NaN, max 448) --------------------------------------------------
 inline float emu_e4m3_to_f32(unsigned char b) {
   const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;

@@ -715,6 +715,19 @@ def check_f32_ops(lib, seed=0):
     a, w, r = rnd(bt, m, k), rnd(n, k), rnd(m, n)
     out = pb.gemm(pb.const(a), pb.const(w), m, n, k, res=pb.const(r), batch=bt, a_bs=m * k, c_bs=m * n, res_bs=0, alpha=0.5)
     checks.append(("gemm batch shared res", out, 0.5 * torch.einsum("bmk,nk->bmn", a, w) + r))
+    # GEMM 2b: from 256 rows up the fp32 GEMM runs on the matrix pipe (v_mfma_f32_32x32x2_f32): ragged in every dimension, an unaligned lda
+    # (scalar loads) and an aligned one (16-byte loads), bias + activation + residual, batches, and the forced form on a small problem
+    for m, n, k, ld_extra in ((300, 70, 50, 1), (513, 129, 256, 0)):
+        a, w, b, r = rnd(m, k + ld_extra), rnd(n, k) / math.sqrt(k), rnd(n), rnd(m, n)
+        out = pb.gemm(pb.const(a), pb.const(w), m, n, k, lda=k + ld_extra, bias=pb.const(b), act=abi.ACT_GELU, res=pb.const(r))
+        checks.append((f"gemm (matrix pipe) {m}x{n}x{k}", out, F.gelu(a[:, :k] @ w.t() + b) + r))
+    bt, m, n, k = 2, 260, 33, 18
+    a, w = rnd(bt, m, k), rnd(bt, n, k)
+    out = pb.gemm(pb.const(a), pb.const(w), m, n, k, batch=bt, a_bs=m * k, w_bs=n * k, c_bs=m * n, alpha=0.25)
+    checks.append(("gemm (matrix pipe) batch", out, 0.25 * torch.einsum("bmk,bnk->bmn", a, w)))
+    a, w = rnd(40, 24), rnd(9, 24)
+    out = pb.gemm(pb.const(a), pb.const(w), 40, 9, 24, flags=abi.GEMM_FORCE_TILE256)
+    checks.append(("gemm (matrix pipe, forced) 40x9x24", out, a @ w.t()))
     # GEMM 3: rows picked out of a wider matrix (lda, a_off), output into a column slice (ldc, c_off), relu; strided weight batches
     rows, NT, D, c2 = 5, 9, 16, 8
     q = rnd(rows * NT, D)

@@ -285,3 +285,49 @@ def test_sam_precision_of_a_batch():
     assert resolve_sam_precision(cfg(False, True)) == "high"
     assert resolve_sam_precision(cfg(False, False, "high")) == "high"
     assert resolve_sam_precision(cfg(True, True, "fast")) == "fast"
+
+
+def test_prompt_is_encoded_at_load_time_when_the_encoders_are_staged(manager, tmp_path):
+    """reference core/image/inpainting.py:846-873: the fixed prompt is encoded on first use and kept.  Here: `prompt_embeds.safetensors` absent,
+    text_encoder/ (CLIP), text_encoder_2/ (T5), tokenizer/, tokenizer_2/ staged next to transformer/ -> the loader encodes "Remove all text."
+    once through `transformers`, writes the file, and the pipeline has its embeddings; a second load reads the file (the encoders may be gone)"""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import CLIPTextConfig, CLIPTextModel, PreTrainedTokenizerFast, T5Config, T5EncoderModel
+    from mangatranslator_amd.core.ml.model_manager import ModelType
+    from mangatranslator_amd.core.ml.prompt_embeds import ensure_prompt_embeds
+    t, v = fc.models(seed=5)
+    c = t.cfg
+    root = manager.model_paths[ModelType.FLUX_KONTEXT_SDNQ_PIPELINE]
+    (root / "transformer").mkdir(parents=True); (root / "vae").mkdir()
+    save_file({k: x.to(torch.bfloat16).contiguous() for k, x in t.state_dict().items()}, str(root / "transformer" / "diffusion_pytorch_model.safetensors"))
+    save_file({k: x.contiguous() for k, x in v.state_dict().items()}, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+    (root / "transformer" / "config.json").write_text(json.dumps(dict(
+        num_attention_heads=c["heads"], attention_head_dim=c["d"] // c["heads"], num_layers=c["layers"], num_single_layers=c["single_layers"],
+        in_channels=64, joint_attention_dim=c["joint_dim"], pooled_projection_dim=c["pooled_dim"], axes_dims_rope=list(c["axes_dim"]))))
+    (root / "vae" / "config.json").write_text(json.dumps(dict(block_out_channels=list(v.cfg["ch"]), norm_num_groups=v.cfg["groups"],
+                                                            scaling_factor=v.cfg["scaling_factor"], shift_factor=v.cfg["shift_factor"])))
+    pipe = manager.load_flux_kontext_sdnq()
+    assert pipe._embeds is None                                   # nothing to encode with: the inpainter would report the missing embeddings
+    manager.unload_flux_kontext_sdnq_models()
+    # tiny stand-ins of the snapshot's encoders, written with transformers' own save_pretrained
+    words = ["<pad>", "</s>", "<unk>", "remove", "all", "text", ".", "<s>"]
+    for name in ("tokenizer", "tokenizer_2"):
+        tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+        tk.pre_tokenizer = pre_tokenizers.Whitespace()
+        PreTrainedTokenizerFast(tokenizer_object=tk, pad_token="<pad>", eos_token="</s>", unk_token="<unk>", bos_token="<s>", model_max_length=77).save_pretrained(str(root / name))
+    torch.manual_seed(0)
+    CLIPTextModel(CLIPTextConfig(vocab_size=len(words), hidden_size=c["pooled_dim"], intermediate_size=32, num_hidden_layers=1, num_attention_heads=2,
+                                 max_position_embeddings=77, eos_token_id=1, pad_token_id=0, bos_token_id=7)).save_pretrained(str(root / "text_encoder"))
+    T5EncoderModel(T5Config(vocab_size=len(words), d_model=c["joint_dim"], d_kv=8, d_ff=32, num_layers=1, num_heads=2, pad_token_id=0, eos_token_id=1,
+                            decoder_start_token_id=0)).save_pretrained(str(root / "text_encoder_2"))
+    pipe = manager.load_flux_kontext_sdnq()
+    assert (root / "prompt_embeds.safetensors").exists()
+    seq, pooled = pipe._embeds
+    assert tuple(seq.shape) == (512, c["joint_dim"]) and tuple(pooled.shape) == (c["pooled_dim"],) and torch.isfinite(seq.float()).all() and seq.float().abs().sum() > 0
+    manager.unload_flux_kontext_sdnq_models()
+    import shutil
+    for name in ("text_encoder", "text_encoder_2", "tokenizer", "tokenizer_2"):
+        shutil.rmtree(root / name)
+    again = manager.load_flux_kontext_sdnq()._embeds
+    assert torch.equal(again[0], seq) and torch.equal(again[1], pooled)
+    assert ensure_prompt_embeds(tmp_path / "nothing-here", "kontext") is False

@@ -144,12 +144,14 @@ if __name__ == "__main__":
             conv(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "gemmp":
             gemm(int(args[1]), int(args[2]), int(args[3]), pad=int(args[4])); args = args[5:]
-        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmn", "gemm8n", "gemms", "gemm8s"):
+        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmn", "gemm8n", "gemms", "gemm8s", "gemmfs", "gemm8fs"):
             # ...n: no split at all, ...sN: exactly N K slices (e.g. gemms4, gemm8s2)
             name = args[0].rstrip("0123456789")
             fl = abi.GEMM_NO_SPLIT if name.endswith("n") else 0
             if name.endswith("s"):
                 fl = int(args[0][len(name):]) << 8
+            if name.endswith("fs"):                    # gemmfsN: N slices also where the launcher would not slice (K shorter than 64 iterations)
+                fl |= abi.GEMM_FORCE_TILE256
             gemm(int(args[1]), int(args[2]), int(args[3]), f8=args[0].startswith("gemm8"), flags=fl); args = args[4:]
         else:
             raise SystemExit(f"unknown benchmark {args[0]}")
