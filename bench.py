@@ -233,6 +233,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if os.environ.get("MTX_BENCH_ONE_DEVICE") == "1":     # dry run of the N > 1 code path on a one-GPU box (with --backend gloo)
         local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"                     # ... for everything that derives its device from it (ModelManager: core/device.py)
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     # host hygiene for N ranks on one node: every rank runs a stage-A worker thread plus numpy / PIL / torch-CPU work (NMS, EDT feather,
