@@ -129,6 +129,7 @@ typedef struct mtx_gemm_args {
 } mtx_gemm_args;
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
 #define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the K-slice tail */
+#define MTX_GEMM_F8_WIDE 4         /* fp8 whole-tile kernel: one segment per k-step (8 MFMAs, half the barriers) — a measurement switch, see csrc/gemm.hip */
 #define MTX_GEMM_SLICES(n) ((n) << 8) /* tuning: cut the left-over tiles into exactly n K slices (2..255) instead of the launcher's choice */
 #define MTX_GEMM_WORKSPACE_BYTES (2 * 320 * 256 * 256 * 4)
 
@@ -156,12 +157,12 @@ typedef struct mtx_attn_args {
  * is ignored, scores are used as base-2 logits as they come out of the matrix pipe.  The long-sequence kernel then seeds its score
  * accumulators with minus the running maximum and needs no per-score multiply-add. */
 #define MTX_ATTN_Q_PRESCALED 1
-/* bits 8..12 of `flags`: schedule of the long-sequence kernel (pre-scaled q, 16-bit output only; ignored elsewhere).  0 = the default.
- * s > 0 selects attn_x_kernel<s - 1> (csrc/attention.hip): K / V by LDS-DMA, + 1 = half-tile stagger of the two wave groups,
- * + 2 = row sums on the matrix pipe (bf16), + 4 = 16-byte row stores, + 8 = K / V staged through registers like the default kernel
- * instead of LDS-DMA (bf16 only).  17 = the default kernel with 16-byte row stores (what 0 selects when the output rows are 16-byte aligned),
- * 18 = 17 + matrix-pipe row sums, 31 = the default kernel with its round-4 8-byte stores.  Same results up to the summation order of the row sums.
- * Tuning / measurement switches: tools/bench_kernels.py attnx, profiles/r05_visit_*attention*.log. */
+/* bits 8..14 of `flags`: schedule of the long-sequence kernel (pre-scaled q, 16-bit output only; ignored elsewhere).  0 = the default.
+ * s in 1..64 selects attn_x_kernel<s - 1> (csrc/attention.hip, bf16; a measured subset is instantiated): K / V by LDS-DMA, + 1 = half-tile stagger
+ * of the two wave groups, + 2 = row sums on the matrix pipe, + 4 = 16-byte row stores, + 8 = K / V staged through registers like the default
+ * kernel, + 16 = fragment reads four steps ahead of the MFMAs.  68 = the tuned kernel with 16-byte row stores and fragment reads four steps ahead
+ * (what 0 selects when the output rows are 16-byte aligned), 65 = 16-byte stores only, 66 = 65 + matrix-pipe row sums, 67 = the round-4 kernel.  Same results up to the
+ * summation order of the row sums.  Tuning / measurement switches: tools/bench_kernels.py attnx, profiles/r05_visit_*attention*.log. */
 #define MTX_ATTN_SCHEDULE_SHIFT 8
 #define MTX_ATTN_WORKSPACE_BYTES (256 * (256 * 128 * 4 + 256 * 2 * 4))
 

@@ -331,7 +331,14 @@ __device__ __forceinline__ void attn_mma32_tile(unsigned char* smem, const typen
 // largest partial row sum a stale maximum may produce before the exact path is taken: the probabilities must stay finite in T
 template <typename T> struct AttnSumLimit { static constexpr float v = 1.0e12f; };       // bf16: fp32 exponent range, 2^40
 template <> struct AttnSumLimit<_Float16> { static constexpr float v = 3.0e4f; };        // f16: max 65504
-template <typename T, int DP, int STAGE, bool RAGGED, bool NOMAX = false>
+#ifdef MTX_EMU
+#define MTX_SCHED_GROUP(mask, n) ((void)0)
+#else
+#define MTX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
+// DEEP (round 5, schedule 68; measured against the plain form in one process): the K fragments of four k-steps and the V^T fragments of four
+// MFMAs are in flight ahead of the matrix pipe, the order pinned with sched_group_barrier (0x100 = LDS reads, 0x008 = MFMA)
+template <typename T, int DP, int STAGE, bool RAGGED, bool NOMAX = false, bool DEEP = false>
 __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
                                                float& M, float& lsum, f32x16& minit, bool& first,
                                                const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
@@ -341,6 +348,22 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
   const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
   const unsigned char* Vs = Ks + TILE_B;
   f32x16 sacc[2];
+  if constexpr (DEEP) {
+    static_assert(KS == 8, "pipeline written for eight k-steps");
+    v8 kfd[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) kfd[ks][kb] = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sacc[kb] = Mma32<T>::mfma(kfd[ks][kb], qf[ks], ks == 0 ? minit : sacc[kb]);
+    MTX_SCHED_GROUP(0x100, 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { MTX_SCHED_GROUP(0x008, 2); MTX_SCHED_GROUP(0x100, 2); }
+    MTX_SCHED_GROUP(0x008, 8);
+  } else {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -349,6 +372,7 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
       if (ks == 0) Mma32Pinned<T>::set_from(sacc[kb], kf, qf[ks], minit);
       else sacc[kb] = Mma32<T>::mfma(kf, qf[ks], sacc[kb]);
     }
+  }
   if (RAGGED) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -424,6 +448,28 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
       first = false;
     }
     lsum += tsum;
+  }
+  if constexpr (DEEP) {
+    v8 vfd[4][DB];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* a = Vs + vaddr[d] + ((g >> 1) * 32 + (g & 1) * 16) * ROWB;
+        const v4 lo = lds_read_tr16<T>(a);
+        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+        vfd[g][d][0] = lo[0]; vfd[g][d][1] = lo[1]; vfd[g][d][2] = lo[2]; vfd[g][d][3] = lo[3];
+        vfd[g][d][4] = hv[0]; vfd[g][d][5] = hv[1]; vfd[g][d][6] = hv[2]; vfd[g][d][7] = hv[3];
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) oacc[d] = Mma32<T>::mfma(vfd[g][d], pb[g >> 1][g & 1], oacc[d]);
+    MTX_SCHED_GROUP(0x100, 8);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { MTX_SCHED_GROUP(0x008, 1); MTX_SCHED_GROUP(0x100, 2); }
+    MTX_SCHED_GROUP(0x008, 4);
+    return;
   }
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
@@ -532,6 +578,11 @@ __device__ __forceinline__ void attn_bias_tile_ms(unsigned char* smem, const typ
 #define ATTN_MMA32_Q8 1
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
+#define ATTN_MMA32_DEEP 1
+#define ATTN_MMA32_NAME attn_mma32_q8d_kernel
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_DEEP
 #undef ATTN_MMA32_Q8
 #undef ATTN_MMA32_WIDE
 #define ATTN_MMA32_Q8 0
@@ -539,6 +590,11 @@ __device__ __forceinline__ void attn_bias_tile_ms(unsigned char* smem, const typ
 #define ATTN_MMA32_NAME attn_mma32_w_kernel
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
+#define ATTN_MMA32_DEEP 1
+#define ATTN_MMA32_NAME attn_mma32_d_kernel
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_DEEP
 #undef ATTN_MMA32_MATSUM
 #define ATTN_MMA32_MATSUM 1
 #define ATTN_MMA32_NAME attn_mma32_ms_kernel
@@ -565,12 +621,12 @@ __device__ __forceinline__ void attn_bias_tile_ms(unsigned char* smem, const typ
 //     before that); bf16 only;
 //   * AX_WIDE: the 16-bit rows leave as 8 x 16-byte stores per lane (lanes l and l ^ 32 trade two dwords by v_permlane32_swap)
 //     instead of 16 x 8-byte stores.
-constexpr int AX_STAGGER = 1, AX_MATSUM = 2, AX_WIDE = 4, AX_STAGED = 8;
+constexpr int AX_STAGGER = 1, AX_MATSUM = 2, AX_WIDE = 4, AX_STAGED = 8, AX_DEEP = 16;
 
 #ifdef MTX_EMU
 #define AX_BAR(N) __syncthreads()
 #else
-#define AX_BAR(N) do { asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define AX_BAR(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)      /* fenced on both sides: MFMAs are not memory operations and would drift across the asm */
 #endif
 
 #ifdef MTX_EMU
@@ -593,12 +649,45 @@ __device__ __forceinline__ int xor_here(int base) {
 #endif
 }
 
-template <typename T, int DP, int STAGE>
+#ifdef MTX_EMU
+#define AX_GROUP(mask, n) ((void)0)
+#else
+#define AX_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
+constexpr int AX_SG_MFMA = 0x008, AX_SG_DS_READ = 0x100;
+
+template <typename T, int DP, int STAGE, bool DEEP = false>
 __device__ __forceinline__ void attn_x_scores(const unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&sacc)[2],
                                               const f32x16& minit, const int kaddr0) {
   typedef typename Traits<T>::v8 v8;
   constexpr int KS = DP / 16, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
   const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
+  if constexpr (DEEP) {
+    // AX_DEEP: the K fragments of four k-steps (eight 16-byte reads) are in flight before the first MFMA and stay four steps ahead, so the
+    // 16 MFMAs of a tile issue back to back (512 cycles) instead of each pair waiting one LDS round trip (two reads in flight: ~1 500
+    // cycles when the wave has the SIMD's matrix pipe to itself, which is what the staggered schedule gives it).  The order is pinned
+    // with sched_group_barrier; the seed MFMAs are builtins here (the scheduler cannot classify inline asm).
+    static_assert(KS == 8, "pipeline written for eight k-steps");
+    v8 kf[KS][2];
+    int ka[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      ka[ks] = ks == 0 ? kaddr0 : ks == 1 ? xor_here<1 << 5>(kaddr0) : ks == 2 ? xor_here<2 << 5>(kaddr0) : ks == 3 ? xor_here<3 << 5>(kaddr0) :
+               ks == 4 ? xor_here<4 << 5>(kaddr0) : ks == 5 ? xor_here<5 << 5>(kaddr0) : ks == 6 ? xor_here<6 << 5>(kaddr0) : xor_here<7 << 5>(kaddr0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) kf[ks][kb] = *reinterpret_cast<const v8*>(Ks + ka[ks] + kb * 32 * ROWB);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sacc[kb] = Mma32<T>::mfma(kf[ks][kb], qf[ks], ks == 0 ? minit : sacc[kb]);
+    AX_GROUP(AX_SG_DS_READ, 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { AX_GROUP(AX_SG_MFMA, 2); AX_GROUP(AX_SG_DS_READ, 2); }
+    AX_GROUP(AX_SG_MFMA, 8);
+    return;
+  }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const int ka = ks == 0 ? kaddr0 : ks == 1 ? xor_here<1 << 5>(kaddr0) : ks == 2 ? xor_here<2 << 5>(kaddr0) : ks == 3 ? xor_here<3 << 5>(kaddr0) :
@@ -615,7 +704,7 @@ __device__ __forceinline__ void attn_x_scores(const unsigned char* smem, const t
 // softmax of the S^T accumulators (seeded with minus the running maximum M, log2 units) and O^T += V^T P^T.
 // !MATSUM: attn_bias_tile's NOMAX form (partial row sums flag a stale maximum).  MATSUM && !EXACT: maximum on the first tile only, sums on
 // the matrix pipe (lacc: every row of the block is the row sum).  MATSUM && EXACT: maximum every tile, refreshed when it grew by > 2^8.
-template <typename T, int DP, int STAGE, bool RAGGED, bool MATSUM, bool EXACT>
+template <typename T, int DP, int STAGE, bool RAGGED, bool MATSUM, bool EXACT, bool DEEP = false>
 __device__ __forceinline__ void attn_x_softmax_pv(const unsigned char* smem, f32x16 (&sacc)[2], f32x16 (&oacc)[DP / 32], f32x16& lacc,
                                                   float& M, float& lsum, f32x16& minit, bool& first,
                                                   const int vaddr0, const long kvalid, const int hi) {
@@ -706,6 +795,32 @@ __device__ __forceinline__ void attn_x_softmax_pv(const unsigned char* smem, f32
   v8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = from_f32<T>(1.0f);
+  if constexpr (DEEP && !MATSUM) {
+    // AX_DEEP: the V^T fragments of four MFMAs (eight transpose reads) ahead of the matrix pipe; same order of the 16 MFMAs as below
+    int va[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) va[d] = d == 0 ? vaddr0 : d == 1 ? xor_here<1 << 6>(vaddr0) : d == 2 ? xor_here<2 << 6>(vaddr0) : xor_here<3 << 6>(vaddr0);
+    v8 vf[4][DB];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* a = Vs + va[d] + ((g >> 1) * 32 + (g & 1) * 16) * ROWB;
+        const v4 lo = lds_read_tr16<T>(a);
+        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+        vf[g][d][0] = lo[0]; vf[g][d][1] = lo[1]; vf[g][d][2] = lo[2]; vf[g][d][3] = lo[3];
+        vf[g][d][4] = hv[0]; vf[g][d][5] = hv[1]; vf[g][d][6] = hv[2]; vf[g][d][7] = hv[3];
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) oacc[d] = Mma32<T>::mfma(vf[g][d], pb[g >> 1][g & 1], oacc[d]);
+    AX_GROUP(AX_SG_DS_READ, 8);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { AX_GROUP(AX_SG_MFMA, 1); AX_GROUP(AX_SG_DS_READ, 2); }
+    AX_GROUP(AX_SG_MFMA, 4);
+    return;
+  }
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -727,7 +842,7 @@ __device__ __forceinline__ void attn_x_softmax_pv(const unsigned char* smem, f32
 
 template <typename T, int DP, int VAR>
 __global__ __launch_bounds__(512) void attn_x_kernel(AttnParams p) {
-  constexpr bool STAGGER = (VAR & AX_STAGGER) != 0, MATSUM = (VAR & AX_MATSUM) != 0, WIDE = (VAR & AX_WIDE) != 0, STAGED = (VAR & AX_STAGED) != 0;
+  constexpr bool STAGGER = (VAR & AX_STAGGER) != 0, MATSUM = (VAR & AX_MATSUM) != 0, WIDE = (VAR & AX_WIDE) != 0, STAGED = (VAR & AX_STAGED) != 0, DEEP = (VAR & AX_DEEP) != 0;
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
   constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
@@ -842,11 +957,20 @@ __global__ __launch_bounds__(512) void attn_x_kernel(AttnParams p) {
   // transport hooks of the tile loop.  One barrier per tile: `tile_begin(next stage)` ... `tile_end(next stage)`; staggered: phase A
   // (`a_begin` ... `a_end`) and phase B (`b_begin` ... `b_end`) of the same tile
   auto tile_begin = [&](int st) { if (STAGED) load_tile(); else { dma_k(st); dma_v(st); } };
-  auto tile_end = [&](int st) { if (STAGED) { store_tile(st); MTX_LDS_BARRIER(); } else AX_BAR(0); };
+  auto lds_bar = [&]() {
+#ifndef MTX_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    MTX_LDS_BARRIER();
+#ifndef MTX_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  };
+  auto tile_end = [&](int st) { if (STAGED) { store_tile(st); lds_bar(); } else AX_BAR(0); };
   auto a_begin = [&](int st) { if (STAGED) load_tile(); else dma_k(st); };
-  auto a_end = [&]() { if (STAGED) MTX_LDS_BARRIER(); else AX_BAR(2); };
+  auto a_end = [&]() { if (STAGED) lds_bar(); else AX_BAR(2); };
   auto b_begin = [&](int st) { if (!STAGED) dma_v(st); };
-  auto b_end = [&](int st) { if (STAGED) { store_tile(st); MTX_LDS_BARRIER(); } else AX_BAR(2); };
+  auto b_end = [&](int st) { if (STAGED) { store_tile(st); lds_bar(); } else AX_BAR(2); };
 
   f32x16 oacc[DB], lacc, minit, sacc[2];
   float M, lsum;
@@ -864,8 +988,8 @@ __global__ __launch_bounds__(512) void attn_x_kernel(AttnParams p) {
     AX_PIN(minit);
     M = 0.f; lsum = 0.f; first = true;
     first_tile_offsets();
-#define AX_S(ST) attn_x_scores<T, DP, ST>(smem, qf, sacc, minit, kaddr0)
-#define AX_PV(ST, RAG, KV) attn_x_softmax_pv<T, DP, ST, RAG, MATSUM, EXACT>(smem, sacc, oacc, lacc, M, lsum, minit, first, vaddr0, KV, hi)
+#define AX_S(ST) attn_x_scores<T, DP, ST, DEEP>(smem, qf, sacc, minit, kaddr0)
+#define AX_PV(ST, RAG, KV) attn_x_softmax_pv<T, DP, ST, RAG, MATSUM, EXACT, DEEP>(smem, sacc, oacc, lacc, M, lsum, minit, first, vaddr0, KV, hi)
 #define AX_PV_LAST(ST) do { if (kv_last < AB_KV) AX_PV(ST, true, kv_last); else AX_PV(ST, false, AB_KV); } while (0)
     if (STAGED) { tile_next = (unsigned)t_begin; load_tile(); store_tile(0); }
     else { dma_k(0); dma_v(0); MTX_WAIT_VMEM(); }
@@ -1083,28 +1207,35 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     // schedules tried against this one and dropped (DESIGN.md §9 keeps the numbers): half-tile staggered wave groups, fragment reads
     // pinned 2-4 k-steps ahead, an S^T-pipelined LDS-DMA ring, 4 waves x 64 rows, two 128-query workgroups per CU — all equal or slower
     if (p.q8 != nullptr) {
-      if (p.prescaled) MTX_LAUNCH((attn_mma32_q8_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+      // (pre-scaled q: fragment reads four steps ahead since round 5, identical bytes; schedule 67 = the round-4 loop, for A/Bs)
+      if (p.prescaled && p.schedule != 67) MTX_LAUNCH((attn_mma32_q8d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+      else if (p.prescaled) MTX_LAUNCH((attn_mma32_q8_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
       else MTX_LAUNCH((attn_mma32_q8_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
       if (p.split > 1) MTX_LAUNCH((attn_merge_q8_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
       return MTX_OK;
     }
     // Measured in one process on MI355X at T = 8812, 24 heads (round 5, profiles/r05_visit_b / _c / _d_attention_*.log; default 0.827-0.835 ms):
-    //   16-byte row stores on this kernel (schedule 17)  0.832 vs 0.835 ms (+0.3 %, four rounds of four)      -> the default from here on;
-    //   matrix-pipe row sums on this kernel (18)          0.890 (-6.7 %: 22 % fewer vector instructions, 12.5 % more MFMAs; the kernel is
+    //   16-byte row stores on this kernel (schedule 65)  0.832 vs 0.835 ms (+0.3 %, four rounds of four)      -> the default from here on;
+    //   matrix-pipe row sums on this kernel (66)          0.890 (-6.7 %: 22 % fewer vector instructions, 12.5 % more MFMAs; the kernel is
     //                                                     bound by its LDS-read -> MFMA dependency chains, not by vector issue slots);
-    //   attn_x_kernel (schedules 1..16: the same loop rebuilt with the transport / schedule as template switches)
+    //   attn_x_kernel (schedules 1..64: the same loop rebuilt with the transport / schedule as template switches)
     //     K / V by LDS-DMA  0.967 (-17 %: four 1 KB pieces per wave and tile cost more issue time than 8 loads + 8 ds_write_b128);
     //     half-tile stagger of the two wave groups  0.966 with LDS-DMA (no change), 1.222 with register staging;
     //     register staging  0.983; + matrix-pipe sums 0.903; + 16-byte stores 0.970; both 0.894.
-    // schedule 31 = this kernel with its round-4 epilogue (8-byte stores).
+    //   fragment reads four steps ahead of the MFMAs, order pinned with sched_group_barrier (68): +9 % on attn_x (0.905 vs 0.984 / 0.991), on this kernel
+    //     0.802 vs 0.814 ms (+1.5 %; T = 13 312 +2.5 %, T = 4 096 +1.3 %; four rounds, profiles/r05_visit_j_*.log), identical bytes -> the default, also for the
+    //     MX-fp8-output form.  With the stagger it loses (1.069 / 1.087).
+    // schedule 67 = this kernel with its round-4 loop and epilogue (8-byte stores), 65 = 16-byte stores only.
     const bool wide_ok = p.o_ss % 8 == 0 && p.o_hs % 8 == 0 && p.o_bs % 8 == 0 && ((size_t)p.o & 15) == 0;
     bool launched = false;
-    if ((p.schedule == 0 || p.schedule == 17 || p.schedule == 18) && p.prescaled && wide_ok) {
+    if ((p.schedule == 0 || p.schedule == 68) && p.prescaled && wide_ok) {      // the default since round 5: 16-byte stores + fragment reads four steps ahead
+      MTX_LAUNCH((attn_mma32_d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true;
+    } else if ((p.schedule == 65 || p.schedule == 66) && p.prescaled && wide_ok) {
       if constexpr (std::is_same<T, __bf16>::value) {
-        if (p.schedule == 18) { MTX_LAUNCH((attn_mma32_ms_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true; }
+        if (p.schedule == 66) { MTX_LAUNCH((attn_mma32_ms_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true; }
       }
       if (!launched) { MTX_LAUNCH((attn_mma32_w_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true; }
-    } else if (p.schedule > 0 && p.schedule <= 16 && p.prescaled) {
+    } else if (p.schedule > 0 && p.schedule <= 64 && p.prescaled) {
       if constexpr (std::is_same<T, __bf16>::value) {      // (f16 probabilities saturate: matrix-pipe sums would not notice a stale maximum; the measurement kernels are bf16)
         int var = p.schedule - 1;
         if (!wide_ok) var &= ~AX_WIDE;
@@ -1113,7 +1244,9 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
         switch (var) { MTX_AX(AX_ONLY); default: return MTX_ERR_INVALID; }
 #else
         switch (var) { MTX_AX(0); MTX_AX(1); MTX_AX(2); MTX_AX(3); MTX_AX(4); MTX_AX(5); MTX_AX(6); MTX_AX(7);
-                       MTX_AX(8); MTX_AX(9); MTX_AX(10); MTX_AX(11); MTX_AX(12); MTX_AX(13); MTX_AX(14); MTX_AX(15); default: return MTX_ERR_INVALID; }
+                       MTX_AX(8); MTX_AX(9); MTX_AX(10); MTX_AX(11); MTX_AX(12); MTX_AX(13); MTX_AX(14); MTX_AX(15);
+                       MTX_AX(16); MTX_AX(17); MTX_AX(20); MTX_AX(21); MTX_AX(24); MTX_AX(25); MTX_AX(28); MTX_AX(29);      // + AX_DEEP (no matrix-pipe sums)
+                       default: return MTX_ERR_INVALID; }
 #endif
 #undef MTX_AX
         launched = true;
@@ -1151,7 +1284,7 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   p.q_bs = a->q_bs; p.q_ss = a->q_ss; p.q_hs = a->q_hs; p.k_bs = a->k_bs; p.k_ss = a->k_ss; p.k_hs = a->k_hs;
   p.v_bs = a->v_bs; p.v_ss = a->v_ss; p.v_hs = a->v_hs; p.o_bs = a->o_bs; p.o_ss = a->o_ss; p.o_hs = a->o_hs;
   p.prescaled = (a->flags & MTX_ATTN_Q_PRESCALED) ? 1 : 0;
-  p.schedule = (a->flags >> MTX_ATTN_SCHEDULE_SHIFT) & 31;
+  p.schedule = (a->flags >> MTX_ATTN_SCHEDULE_SHIFT) & 127;
   p.scale_log2 = p.prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
   p.n_full = 0; p.split = 1; p.part_o = nullptr; p.part_ml = nullptr;

@@ -443,6 +443,10 @@ __device__ __forceinline__ void mfma_mx_f8(f32x16& c, i32x8 a, i32x8 b, unsigned
 #endif
 }
 
+// WIDE (round 5, measured against the form above in one process): a segment is a whole k-step — all six fragments read, then eight MFMAs
+// (512 cycles of the pipe) — so a K tile has two segments and four barriers instead of four and eight, and a load segment has 512 cycles
+// of the other group's matrix work to hide four DMA pieces and twelve fragment reads behind.  Same accumulation order per accumulator.
+template <bool WIDE>
 __device__ __forceinline__ void gemm256_f8_loop(const GemmParams& p, unsigned char* smem, const unsigned char* A, const unsigned char* W,
                                                 long m0, long n0, long kbeg, long kend, f32x16 (&acc)[4][2]) {
   constexpr int BK = 128;
@@ -512,6 +516,53 @@ __device__ __forceinline__ void gemm256_f8_loop(const GemmParams& p, unsigned ch
 #pragma unroll
     for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(sw[j]));
 #endif
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        i32x8 wfw[2], afw[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + waddr[S][ks][0] + j * 4096);
+          const u32x4 hi4 = *reinterpret_cast<const u32x4*>(smem + waddr[S][ks][1] + j * 4096);
+          wfw[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + aaddr[S][ks][0] + i * 4096);
+          const u32x4 hi4 = *reinterpret_cast<const u32x4*>(smem + aaddr[S][ks][1] + i * 4096);
+          afw[i] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+        }
+        if (more && ks == 0) load_scales(kt + 1);
+        if (more) {
+          const long k0 = (kt + 1) * BK;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) piece(ks * 4 + i, 1 - S, k0);
+        }
+#ifndef MTX_EMU
+        if (ks == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        if (ks == 1 && grp == 1) MTX_WAIT_VMEM();
+        G2_BAR();
+#ifndef MTX_EMU
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (ks == 0) mfma_mx_f8<0>(acc[i][j], wfw[j], afw[i], sw[j], sa[i]); else mfma_mx_f8<2>(acc[i][j], wfw[j], afw[i], sw[j], sa[i]);
+          }
+#ifndef MTX_EMU
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (ks == 1 && grp == 0) MTX_WAIT_VMEM();
+        G2_BAR();
+      }
+      return;
+    }
     i32x8 wf[2];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -576,7 +627,7 @@ __device__ __forceinline__ void gemm256_f8_loop(const GemmParams& p, unsigned ch
   if (grp == 0) G2_BAR();
 }
 
-template <typename T, int ACT>
+template <typename T, int ACT, bool WIDE = false>
 __global__ __launch_bounds__(512) void gemm256_f8_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -590,7 +641,7 @@ __global__ __launch_bounds__(512) void gemm256_f8_kernel(GemmParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
+  gemm256_f8_loop<WIDE>(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
   __syncthreads();
   gemm256_epilogue<T, ACT>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
 }
@@ -615,7 +666,7 @@ __global__ __launch_bounds__(512) void gemm256_f8_glu_kernel(GemmParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
+  gemm256_f8_loop<false>(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
   __syncthreads();
   if (n0 < p.glu_col0) {                                  // (workgroup-uniform: glu_col0 is a multiple of the tile width)
     gemm256_epilogue<T, MTX_ACT_NONE>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
@@ -696,7 +747,7 @@ __global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (kend > kbeg) {
-    if (F8) gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, kbeg, kend, acc);
+    if (F8) gemm256_f8_loop<false>(p, smem, p.a, p.w, m0, n0, kbeg, kend, acc);
     else gemm256_pp_buf_loop<T>(p, smem, reinterpret_cast<const T*>(p.a), reinterpret_cast<const T*>(p.w), m0, n0, kbeg, kend, acc);
   }
   // slot layout: [wave][block = (i, j, g)][lane] x 16 bytes
@@ -761,9 +812,11 @@ static int gemm_num_cus() {
   return cus;
 }
 
+static thread_local bool g_f8_wide = false;      // MTX_GEMM_F8_WIDE of the launch being issued (a measurement switch)
 template <typename T, bool F8>
 static void launch_gemm256_tiles(const GemmParams& p, dim3 grid, void* stream) {
-#define MTX_G256(ACTV) do { if (F8) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); \
+#define MTX_G256(ACTV) do { if (F8 && g_f8_wide) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV, true>), grid, dim3(512), 0, stream, p); \
+                            else if (F8) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV, false>), grid, dim3(512), 0, stream, p); \
                             else MTX_LAUNCH((gemm256_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); } while (0)
   switch (p.act) {
     case MTX_ACT_NONE: MTX_G256(MTX_ACT_NONE); break;
@@ -897,6 +950,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;
   const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0;
+  g_f8_wide = (a->flags & MTX_GEMM_F8_WIDE) != 0;
   const unsigned forced_slices = ((unsigned)a->flags >> 8) & 0xffu;
   // large, aligned problems: the 256 x 256 LDS-DMA kernel (needs whole K tiles and 16-byte rows everywhere)
   const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;

@@ -49,7 +49,7 @@ class GemmArgs(C.Structure):
                 ("glu_q", vp), ("glu_scale", vp), ("glu_ldq", i64), ("glu_lds", i64), ("glu_col0", i64)]
 
 
-GEMM_FORCE_TILE256, GEMM_NO_SPLIT = 1, 2
+GEMM_FORCE_TILE256, GEMM_NO_SPLIT, GEMM_F8_WIDE = 1, 2, 4
 GEMM_WORKSPACE_BYTES = 2 * 320 * 256 * 256 * 4
 
 
@@ -63,7 +63,7 @@ class AttnArgs(C.Structure):
 
 
 ATTN_Q_PRESCALED = 1
-ATTN_SCHEDULE_SHIFT = 8      # bits 8..12 of AttnArgs.flags: schedule of the long-sequence kernel (include/mtx_hip.h)
+ATTN_SCHEDULE_SHIFT = 8      # bits 8..14 of AttnArgs.flags: schedule of the long-sequence kernel (include/mtx_hip.h)
 ATTN_WORKSPACE_BYTES = 256 * (256 * 128 * 4 + 256 * 2 * 4)
 
 

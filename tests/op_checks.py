@@ -563,9 +563,17 @@ def check_gemm_f8(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_re
     out = pb.gemm(aq, wq, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
                   res=pb.const(res) if res is not None else None, gate=pb.const(gate) if gate is not None else None,
                   gate_rows_per=rows_per, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=flags)
+    # the one-segment-per-k-step form of the whole-tile kernel (MTX_GEMM_F8_WIDE, round 5): same accumulation order, identical bytes
+    wide = pb.gemm(aq, wq, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
+                   res=pb.const(res) if res is not None else None, gate=pb.const(gate) if gate is not None else None,
+                   gate_rows_per=rows_per, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=flags | abi.GEMM_F8_WIDE | abi.GEMM_NO_SPLIT)
+    plain = pb.gemm(aq, wq, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
+                    res=pb.const(res) if res is not None else None, gate=pb.const(gate) if gate is not None else None,
+                    gate_rows_per=rows_per, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=flags | abi.GEMM_NO_SPLIT)
     _run(pb)
     err = _relerr(out.cpu().view(m, n), ref)
     assert err < TOL[dtype], f"fp8 gemm mismatch rel err {err}"
+    assert torch.equal(wide.cpu(), plain.cpu()), "fp8 gemm: wide segments differ from the four-segment loop"
     return err, qerr
 
 

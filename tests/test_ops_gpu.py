@@ -137,7 +137,7 @@ def test_attention_prescaled_q(hip_lib):
     oc.check_attention(hip_lib, abi.BF16, batch=2, heads=2, sq=300, sk=200, d=64, prescaled=True)
 
 
-@pytest.mark.parametrize("schedule", [2, 3, 9, 10, 11, 15, 17, 18, 31])
+@pytest.mark.parametrize("schedule", [2, 3, 9, 10, 11, 15, 17, 18, 25, 26, 30, 65, 66, 67, 68])
 def test_attention_alternative_schedules(hip_lib, schedule):
     """mtx_attn_args.flags schedule bits (round 5; tests/test_ops_sim.py has the same cases on the simulator): the FLUX shape through the
     key-split tail, a ragged shape with peaked rows, and scores that outgrow a maximum taken once (matrix-pipe row sums: the block is redone)"""

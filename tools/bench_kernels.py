@@ -34,7 +34,7 @@ def attn(T, heads=24, d=128, iters=10, schedule=0):
     return ms
 
 
-def attn_q8(T, heads=24, d=128, iters=10, fused=True):
+def attn_q8(T, heads=24, d=128, iters=10, fused=True, schedule=0):
     """FLUX.2 form: the rows leave as the MX fp8 operand of the next linear (fused: mtx_attn_args.q8; else attention + quantiser launch)"""
     pb = PlanBuilder(lib, dev, abi.BF16)
     D = heads * d
@@ -45,13 +45,13 @@ def attn_q8(T, heads=24, d=128, iters=10, fused=True):
     sc = pb.buf((D // 128, lds), torch.int32, zero=True)
     strides = ((0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d))
     if fused:
-        pb.attention(qkv, qkv, qkv, None, 1, heads, T, T, d, *strides, d ** -0.5, k_off=D, v_off=2 * D, q_prescaled=True, q8=(q8, sc, D, lds, 0))
+        pb.attention(qkv, qkv, qkv, None, 1, heads, T, T, d, *strides, d ** -0.5, k_off=D, v_off=2 * D, q_prescaled=True, q8=(q8, sc, D, lds, 0), schedule=schedule)
     else:
         o = pb.buf((T, D), torch.bfloat16)
         pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, *strides, d ** -0.5, k_off=D, v_off=2 * D, q_prescaled=True)
         pb.quantize(o, T, D, q=q8, scale=sc, lds=lds, ldq=D)
     ms = _time(pb.build(), iters)
-    print(f"attn -> MX fp8 T={T} heads={heads} [{'fused epilogue' if fused else 'attention + quantiser launch'}]: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
+    print(f"attn -> MX fp8 T={T} heads={heads} schedule={schedule} [{'fused epilogue' if fused else 'attention + quantiser launch'}]: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
 def gemm8_glu(M, hid, K, col0=0, iters=20, fused=True):
@@ -97,6 +97,8 @@ def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0):
     ms = _time(pb.build(), iters)
     split = lib.gemm_last_split()
     tag = " [whole tiles only]" if flags & abi.GEMM_NO_SPLIT else f" [whole tiles, K slices, pieces = {split}]"
+    if flags & abi.GEMM_F8_WIDE:
+        tag += " [wide segments]"
     print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}{f' ld+{pad}' if pad else ''}{tag}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
@@ -134,8 +136,8 @@ if __name__ == "__main__":
                     best[sc] = min(best.get(sc, 1e9), ms)
             print("attnx best of", reps, {sc: round(v, 4) for sc, v in best.items()}, flush=True)
             args = args[4:]
-        elif args[0] in ("attnq", "attnqs"):          # attention with MX fp8 output: fused epilogue / separate quantiser
-            attn_q8(int(args[1]), fused=args[0] == "attnq"); args = args[2:]
+        elif args[0] in ("attnq", "attnqs", "attnq67"):          # attention with MX fp8 output: fused epilogue / separate quantiser / the round-4 loop
+            attn_q8(int(args[1]), fused=args[0] != "attnqs", schedule=67 if args[0] == "attnq67" else 0); args = args[2:]
         elif args[0] in ("glu", "glus"):              # glu M hid K col0
             gemm8_glu(int(args[1]), int(args[2]), int(args[3]), int(args[4]), fused=args[0] == "glu"); args = args[5:]
         elif args[0] == "quant":
@@ -144,7 +146,7 @@ if __name__ == "__main__":
             conv(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "gemmp":
             gemm(int(args[1]), int(args[2]), int(args[3]), pad=int(args[4])); args = args[5:]
-        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmn", "gemm8n", "gemms", "gemm8s", "gemmfs", "gemm8fs"):
+        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmn", "gemm8n", "gemms", "gemm8s", "gemmfs", "gemm8fs", "gemm8w"):
             # ...n: no split at all, ...sN: exactly N K slices (e.g. gemms4, gemm8s2)
             name = args[0].rstrip("0123456789")
             fl = abi.GEMM_NO_SPLIT if name.endswith("n") else 0
@@ -152,6 +154,8 @@ if __name__ == "__main__":
                 fl = int(args[0][len(name):]) << 8
             if name.endswith("fs"):                    # gemmfsN: N slices also where the launcher would not slice (K shorter than 64 iterations)
                 fl |= abi.GEMM_FORCE_TILE256
+            if name.endswith("w"):                     # gemm8w: fp8 whole-tile kernel with one segment per k-step (MTX_GEMM_F8_WIDE)
+                fl |= abi.GEMM_F8_WIDE
             gemm(int(args[1]), int(args[2]), int(args[3]), f8=args[0].startswith("gemm8"), flags=fl); args = args[4:]
         else:
             raise SystemExit(f"unknown benchmark {args[0]}")
