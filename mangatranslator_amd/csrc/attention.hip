@@ -1225,6 +1225,9 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     //   fragment reads four steps ahead of the MFMAs, order pinned with sched_group_barrier (68): +9 % on attn_x (0.905 vs 0.984 / 0.991), on this kernel
     //     0.802 vs 0.814 ms (+1.5 %; T = 13 312 +2.5 %, T = 4 096 +1.3 %; four rounds, profiles/r05_visit_j_*.log), identical bytes -> the default, also for the
     //     MX-fp8-output form.  With the stagger it loses (1.069 / 1.087).
+    //   softmax of a tile's second 32 keys placed in the issue gaps of the P V MFMAs of its first 32 (half-tile checks of the row sums, order pinned):
+    //     2.05 ms — it does not fit the 256 registers of two waves per SIMD next to the prefetched fragments; the q fragments spill into the S^T MFMA
+    //     chain (profiles/r05_visit_k_*.log).  Removed again.
     // schedule 67 = this kernel with its round-4 loop and epilogue (8-byte stores), 65 = 16-byte stores only.
     const bool wide_ok = p.o_ss % 8 == 0 && p.o_hs % 8 == 0 && p.o_bs % 8 == 0 && ((size_t)p.o & 15) == 0;
     bool launched = false;
