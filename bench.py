@@ -878,12 +878,12 @@ def run_extra_children():
     """The other BASELINE configurations under the driver's clock: after the timed region of the default command, this very
     script is run again as child processes — the GPU is idle by then; each child loads its own models, times its own region with the same
     barrier discipline and prints its own JSON line, of which the figures are kept:
-      config5  6 pages at 2048x3072, FLUX.2-Klein-4B with MX-fp8 block linears, 8 steps, + 2x upscale (BASELINE configs[4]; the reference's DEFAULT inpainter)
+      config5  8 pages at 2048x3072, FLUX.2-Klein-4B with MX-fp8 block linears, 8 steps, + 2x upscale (BASELINE configs[4]; the reference's DEFAULT inpainter)
       config2  64 pages, detect + segment only (BASELINE configs[1]), two front halves in flight on sixteen hardware queues
       first_block_cache  3 pages of config 3 with the OSB stage configured for the reference's nunchaku backend (first-block cache on)"""
     import subprocess
     me = [sys.executable, str(Path(__file__).resolve()), "--no-cpu-baseline", "--no-traffic", "--extra-child"]
-    jobs = {"config5": ["--config", "5", "--steps", "6", "--warmup", "1"],
+    jobs = {"config5": ["--config", "5", "--steps", "8", "--warmup", "2"],
             "config2": ["--config", "2", "--steps", "64", "--warmup", "4"],
             "first_block_cache": ["--config", "3", "--steps", "3", "--warmup", "1", "--kontext-backend", "nunchaku"]}
     out = {}
