@@ -338,7 +338,7 @@ template <> struct AttnSumLimit<_Float16> { static constexpr float v = 3.0e4f; }
 #endif
 // DEEP (round 5, schedule 68; measured against the plain form in one process): the K fragments of four k-steps and the V^T fragments of four
 // MFMAs are in flight ahead of the matrix pipe, the order pinned with sched_group_barrier (0x100 = LDS reads, 0x008 = MFMA)
-template <typename T, int DP, int STAGE, bool RAGGED, bool NOMAX = false, bool DEEP = false>
+template <typename T, int DP, int STAGE, bool RAGGED, bool NOMAX = false, int DEEP = 0>      // DEEP = 0, or K k-steps ahead | V MFMAs ahead << 4
 __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32],
                                                float& M, float& lsum, f32x16& minit, bool& first,
                                                const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
@@ -359,10 +359,12 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) sacc[kb] = Mma32<T>::mfma(kfd[ks][kb], qf[ks], ks == 0 ? minit : sacc[kb]);
-    MTX_SCHED_GROUP(0x100, 8);
+    constexpr int KD = DEEP & 15;                // k-steps (read pairs) in flight ahead of the matrix pipe
+    static_assert(KD >= 1 && KD <= KS, "K prefetch depth");
+    MTX_SCHED_GROUP(0x100, 2 * KD);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { MTX_SCHED_GROUP(0x008, 2); MTX_SCHED_GROUP(0x100, 2); }
-    MTX_SCHED_GROUP(0x008, 8);
+    for (int i = 0; i < KS - KD; ++i) { MTX_SCHED_GROUP(0x008, 2); MTX_SCHED_GROUP(0x100, 2); }
+    MTX_SCHED_GROUP(0x008, 2 * KD);
   } else {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -465,10 +467,12 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int d = 0; d < DB; ++d) oacc[d] = Mma32<T>::mfma(vfd[g][d], pb[g >> 1][g & 1], oacc[d]);
-    MTX_SCHED_GROUP(0x100, 8);
+    constexpr int VD = DEEP >> 4;                // MFMAs whose fragments (two transpose reads each) are in flight ahead of the matrix pipe
+    static_assert(VD >= 1 && VD <= 16, "V prefetch depth");
+    MTX_SCHED_GROUP(0x100, 2 * VD);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { MTX_SCHED_GROUP(0x008, 1); MTX_SCHED_GROUP(0x100, 2); }
-    MTX_SCHED_GROUP(0x008, 4);
+    for (int i = 0; i < 16 - VD; ++i) { MTX_SCHED_GROUP(0x008, 1); MTX_SCHED_GROUP(0x100, 2); }
+    MTX_SCHED_GROUP(0x008, VD);
     return;
   }
 #pragma unroll
@@ -578,7 +582,7 @@ __device__ __forceinline__ void attn_bias_tile_ms(unsigned char* smem, const typ
 #define ATTN_MMA32_Q8 1
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
-#define ATTN_MMA32_DEEP 1
+#define ATTN_MMA32_DEEP 0x44
 #define ATTN_MMA32_NAME attn_mma32_q8d_kernel
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
@@ -590,7 +594,7 @@ __device__ __forceinline__ void attn_bias_tile_ms(unsigned char* smem, const typ
 #define ATTN_MMA32_NAME attn_mma32_w_kernel
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
-#define ATTN_MMA32_DEEP 1
+#define ATTN_MMA32_DEEP 0x44
 #define ATTN_MMA32_NAME attn_mma32_d_kernel
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
@@ -1225,6 +1229,7 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     //   fragment reads four steps ahead of the MFMAs, order pinned with sched_group_barrier (68): +9 % on attn_x (0.905 vs 0.984 / 0.991), on this kernel
     //     0.802 vs 0.814 ms (+1.5 %; T = 13 312 +2.5 %, T = 4 096 +1.3 %; four rounds, profiles/r05_visit_j_*.log), identical bytes -> the default, also for the
     //     MX-fp8-output form.  With the stagger it loses (1.069 / 1.087).
+    //     Other depths (K k-steps | V MFMAs ahead: 3 | 4, 6 | 4, 4 | 6, 4 | 8, 4 | 2) all land within 0.8 % of 4 | 4 (0.812 ... 0.819 ms, profiles/r05_visit_l_*.log).
     //   softmax of a tile's second 32 keys placed in the issue gaps of the P V MFMAs of its first 32 (half-tile checks of the row sums, order pinned):
     //     2.05 ms — it does not fit the 256 registers of two waves per SIMD next to the prefetched fragments; the q fragments spill into the S^T MFMA
     //     chain (profiles/r05_visit_k_*.log).  Removed again.
