@@ -682,7 +682,7 @@ __global__ __launch_bounds__(512) void gemm256_f8_glu_kernel(GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float a = to_f32(from_f32<T>(acc[i][0][e] * p.alpha)), b = to_f32(from_f32<T>(acc[i][1][e] * p.alpha));
-      h[e] = to_f32(from_f32<T>(a / (1.f + __expf(-a)) * b));
+      h[e] = to_f32(from_f32<T>(div_by_1p(a, 1.f + __expf(-a)) * b));
       const float v = fabsf(h[e]);
       amax = v > amax ? v : amax;
     }

@@ -176,6 +176,18 @@ template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) {
   return (_Float16)v;
 }
 
+// x / d where d = 1 + e^t >= 1 (SiLU, sigmoid, tanh-GELU as v * sigmoid(2u)): one v_rcp_f32 (1 ulp) and a multiply instead of the IEEE division
+// sequence the compiler emits for `/` (two v_div_scale, v_rcp, four FMAs, v_div_fmas, v_div_fixup: 10 instructions per element — 1 300 per wave in
+// the epilogue of a 256 x 256 GELU tile).  The result is rounded to a 16-bit type next, 2^13 times coarser than the difference.  d = inf gives 0 either
+// way.  (Round 5; -DMTX_EXACT_DIV builds the previous form for A/Bs; the fp32 path of csrc/f32ops.hip keeps exact division.)
+__device__ __forceinline__ float div_by_1p(float x, float d) {
+#if defined(MTX_EMU) || defined(MTX_EXACT_DIV)
+  return x / d;
+#else
+  return x * __builtin_amdgcn_rcpf(d);
+#endif
+}
+
 // compile-time activation (hot epilogues): ACT < 0 falls back to the runtime switch
 template <int ACT>
 __device__ __forceinline__ float apply_act_t(float v, int act, float p);
@@ -183,13 +195,13 @@ __device__ __forceinline__ float apply_act_t(float v, int act, float p);
 __device__ __forceinline__ float apply_act(float v, int act, float p) {
   switch (act) {
     case MTX_ACT_RELU: return v > 0.f ? v : 0.f;
-    case MTX_ACT_SILU: return v / (1.f + __expf(-v));
+    case MTX_ACT_SILU: return div_by_1p(v, 1.f + __expf(-v));
     case MTX_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     case MTX_ACT_GELU_TANH: {
       float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
       return 0.5f * v * (1.f + tanhf(u));
     }
-    case MTX_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case MTX_ACT_SIGMOID: return div_by_1p(1.f, 1.f + __expf(-v));
     case MTX_ACT_LEAKY: return v > 0.f ? v : v * p;
     default: return v;
   }
@@ -199,10 +211,10 @@ template <int ACT>
 __device__ __forceinline__ float apply_act_t(float v, int act, float p) {
   if (ACT == MTX_ACT_NONE) return v;
   if (ACT == MTX_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (ACT == MTX_ACT_SILU) return v / (1.f + __expf(-v));
+  if (ACT == MTX_ACT_SILU) return div_by_1p(v, 1.f + __expf(-v));
   if (ACT == MTX_ACT_GELU_TANH) {       // 0.5 v (1 + tanh u) == v * sigmoid(2u): one exp, one divide
     const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-    return v / (1.f + __expf(-2.f * u));
+    return div_by_1p(v, 1.f + __expf(-2.f * u));
   }
   return apply_act(v, act, p);
 }

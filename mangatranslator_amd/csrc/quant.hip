@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(mtx_quant_args p) {
       float g[8];
       unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.b) + row * p.ldb + c8 * 8), g);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(f[e] / (1.f + __expf(-f[e])) * g[e]));
+      for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(div_by_1p(f[e], 1.f + __expf(-f[e])) * g[e]));
       if (p.y != nullptr && valid) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.y) + row * p.ldy + c8 * 8) = pack8<T>(f);
     }
     unsigned w0, w1, word;

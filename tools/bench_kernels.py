@@ -80,7 +80,7 @@ def gemm8_glu(M, hid, K, col0=0, iters=20, fused=True):
     print(f"gemm8 + SwiGLU -> MX fp8 M={M} N={N} K={K} [{'gated epilogue' if fused else 'GEMM + SwiGLU quantiser launch'}]: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
-def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0):
+def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0, act=0):
     """pad > 0: rows of A and W are `pad` elements apart more than K (leading-dimension padding, an address-interleave probe)"""
     pb = PlanBuilder(lib, dev, abi.BF16)
     a = pb.buf((M, K + pad), torch.bfloat16); a.normal_()
@@ -93,12 +93,14 @@ def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0):
         pb.keep += [aq, asc, wq, wsc]
         pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0), flags=flags)
     else:
-        pb.gemm(a, w, M, N, K, lda=K + pad, ldw=K + pad, flags=flags)
+        pb.gemm(a, w, M, N, K, lda=K + pad, ldw=K + pad, flags=flags, act=act, bias=(pb.buf((N,), torch.float32, zero=True) if act else None))
     ms = _time(pb.build(), iters)
     split = lib.gemm_last_split()
     tag = " [whole tiles only]" if flags & abi.GEMM_NO_SPLIT else f" [whole tiles, K slices, pieces = {split}]"
     if flags & abi.GEMM_F8_WIDE:
         tag += " [wide segments]"
+    if act:
+        tag += " [bias + tanh-GELU epilogue]"
     print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}{f' ld+{pad}' if pad else ''}{tag}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
@@ -144,6 +146,8 @@ if __name__ == "__main__":
             quant(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "conv":
             conv(int(args[1]), int(args[2])); args = args[3:]
+        elif args[0] == "gemmg":                       # bf16 GEMM with the bias + tanh-GELU epilogue (FLUX ff1 / proj_mlp)
+            gemm(int(args[1]), int(args[2]), int(args[3]), act=abi.ACT_GELU_TANH); args = args[4:]
         elif args[0] == "gemmp":
             gemm(int(args[1]), int(args[2]), int(args[3]), pad=int(args[4])); args = args[5:]
         elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmn", "gemm8n", "gemms", "gemm8s", "gemmfs", "gemm8fs", "gemm8w"):
