@@ -437,7 +437,7 @@ __device__ __forceinline__ void ca_mlp(const mtx_ca_args& p, int n, const float*
   for (int c = tid; c < p.c; c += 1024) {
     float s = p.b2 ? p.b2[c] : 0.f;
     for (int r = 0; r < p.cr; ++r) s += p.w2[c * p.cr + r] * hid[r];
-    p.s[(size_t)n * p.c + c] = div_by_1p(1.f, 1.f + __expf(-s));
+    p.s[(size_t)n * p.c + c] = 1.f / (1.f + __expf(-s));
   }
 }
 
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(1024) void ca_split_kernel(mtx_ca_args p) {
   if (tid < p.c) {
     float s = b2v;
     for (int r = 0; r < p.cr; ++r) s += red[tid * p.cr + r];
-    p.s[(size_t)n * p.c + tid] = div_by_1p(1.f, 1.f + __expf(-s));
+    p.s[(size_t)n * p.c + tid] = 1.f / (1.f + __expf(-s));
   }
 }
 
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(mtx_yolo_decode_args p
   float* o = p.out + (size_t)a * (4 + p.nc + p.nm);
   o[0] = (ax - d4[0]) * st; o[1] = (ay - d4[1]) * st; o[2] = (ax + d4[2]) * st; o[3] = (ay + d4[3]) * st;
   const T* cls = src + (p.cls_off > 0 ? p.cls_off : 4 * p.reg_max);
-  for (int c = 0; c < p.nc; ++c) o[4 + c] = div_by_1p(1.f, 1.f + __expf(-to_f32(cls[c])));
+  for (int c = 0; c < p.nc; ++c) o[4 + c] = 1.f / (1.f + __expf(-to_f32(cls[c])));
   const T* mc = p.mc_off > 0 ? src + p.mc_off : cls + p.nc;
   for (int c = 0; c < p.nm; ++c) o[4 + p.nc + c] = to_f32(mc[c]);
 }

@@ -176,15 +176,22 @@ template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) {
   return (_Float16)v;
 }
 
-// x / d where d = 1 + e^t >= 1 (SiLU, sigmoid, tanh-GELU as v * sigmoid(2u)): one v_rcp_f32 (1 ulp) and a multiply instead of the IEEE division
-// sequence the compiler emits for `/` (two v_div_scale, v_rcp, four FMAs, v_div_fmas, v_div_fixup: 10 instructions per element — 1 300 per wave in
-// the epilogue of a 256 x 256 GELU tile).  The result is rounded to a 16-bit type next, 2^13 times coarser than the difference.  d = inf gives 0 either
-// way.  (Round 5; -DMTX_EXACT_DIV builds the previous form for A/Bs; the fp32 path of csrc/f32ops.hip keeps exact division.)
+// x / d where d = 1 + e^t >= 1: one v_rcp_f32 (1 ulp) and a multiply instead of the IEEE division sequence the compiler emits for `/` (two
+// v_div_scale, v_rcp, four FMAs, v_div_fmas, v_div_fixup: 10 instructions per element — 1 300 per wave in the epilogue of a 256 x 256 GELU tile).
+// Used where it was measured to pay and the parity tests hold: the tanh-GELU epilogue (v * sigmoid(2u)) and the SwiGLU sites of the FLUX graphs
+// (bf16; profiles/r05_visit_m_*.log: GELU GEMMs -4.3 ... -4.9 %).  NOT used for SiLU / sigmoid: the f16 detector graphs go through those, and
+// YOLO11-L's decoded-box error doubled with the bare reciprocal (0.061 -> 0.138 of a DFL bin at stride 32, YOLO12x + 28 %, same visit, same sources built
+// both ways): a 1-ulp error that leans one way is a bias, and a bias of 6e-8 per activation summed over a K = 4 608 convolution is 3e-4 — the size of an
+// f16 rounding step.  The Newton step removes the lean for the FLUX sites; the detector sites keep exact division.  d = inf gives 0 either way.
+// (-DMTX_EXACT_DIV builds the previous form everywhere, for A/Bs; the fp32 path of csrc/f32ops.hip keeps exact division.)
 __device__ __forceinline__ float div_by_1p(float x, float d) {
 #if defined(MTX_EMU) || defined(MTX_EXACT_DIV)
   return x / d;
 #else
-  return x * __builtin_amdgcn_rcpf(d);
+  d = fminf(d, 3.0e38f);                                      // e^t may have overflowed: inf * 0 in the Newton step would be NaN where x / inf is 0
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);      // one Newton step: the 1-ulp result of v_rcp_f32 errs to one side, and a one-sided error
+  return x * r;                                                // adds up coherently over the thousands of products of the next reduction (see below)
 #endif
 }
 
@@ -195,13 +202,13 @@ __device__ __forceinline__ float apply_act_t(float v, int act, float p);
 __device__ __forceinline__ float apply_act(float v, int act, float p) {
   switch (act) {
     case MTX_ACT_RELU: return v > 0.f ? v : 0.f;
-    case MTX_ACT_SILU: return div_by_1p(v, 1.f + __expf(-v));
+    case MTX_ACT_SILU: return v / (1.f + __expf(-v));
     case MTX_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     case MTX_ACT_GELU_TANH: {
       float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
       return 0.5f * v * (1.f + tanhf(u));
     }
-    case MTX_ACT_SIGMOID: return div_by_1p(1.f, 1.f + __expf(-v));
+    case MTX_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
     case MTX_ACT_LEAKY: return v > 0.f ? v : v * p;
     default: return v;
   }
@@ -211,7 +218,7 @@ template <int ACT>
 __device__ __forceinline__ float apply_act_t(float v, int act, float p) {
   if (ACT == MTX_ACT_NONE) return v;
   if (ACT == MTX_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (ACT == MTX_ACT_SILU) return div_by_1p(v, 1.f + __expf(-v));
+  if (ACT == MTX_ACT_SILU) return v / (1.f + __expf(-v));
   if (ACT == MTX_ACT_GELU_TANH) {       // 0.5 v (1 + tanh u) == v * sigmoid(2u): one exp, one divide
     const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
     return div_by_1p(v, 1.f + __expf(-2.f * u));

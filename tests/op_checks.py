@@ -529,6 +529,24 @@ def check_fused_quantisers(lib, dtype, rows, c, hid, seed=0):
     assert q1.any() and qs1.any()
 
 
+def check_gemm_act_extremes(lib, dtype):
+    """tanh-GELU / SiLU epilogues far outside the usual range: pre-activations of -600 .. +600 (e^t overflows fp32 on one side): finite, the
+    limits of the functions (0 and v), never NaN — the reciprocal form of the division (csrc/mtx_device.h div_by_1p) must survive d = inf"""
+    dev, td = _dev(lib), TD[dtype]
+    m, n, k = 256, 256, 64
+    a = torch.linspace(-9.5, 9.5, m)[:, None].repeat(1, k).to(td)
+    w = torch.ones(n, k).to(td)
+    ref_v = a.float() @ w.float().t()                       # rows of constant value -608 .. 608
+    for act, fn in ((abi.ACT_GELU_TANH, lambda v: F.gelu(v, approximate="tanh")), (abi.ACT_SILU, F.silu)):
+        pb = PlanBuilder(lib, dev, dtype)
+        out = pb.gemm(pb.const(a), pb.const(w), m, n, k, act=act, flags=abi.GEMM_FORCE_TILE256)
+        _run(pb)
+        got = out.cpu().float().view(m, n)
+        assert torch.isfinite(got).all(), f"act {act}: non-finite values"
+        want = fn(ref_v).to(td).float()
+        assert (got - want).abs().max() <= 4.0 * torch.finfo(td).eps * want.abs().max(), (act, (got - want).abs().max().item())
+
+
 def check_gemm_f8(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=False, with_gate=False, seed=0, flags=0,
                   spread=1.0):
     """C = epilogue(dequant(Aq) dequant(Wq)^T): the kernel against an fp32 product of the SAME quantised operands (so the check is

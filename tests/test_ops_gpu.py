@@ -158,6 +158,11 @@ def test_hi_lo_weight_pairs(hip_lib):
     oc.check_hi_lo_weights(hip_lib, m=4096, n=2304, k=576)          # Hiera-L stage 3, fc1: the 256-tile kernel takes the 16-bit-output form (K' = 1152)
 
 
+def test_activation_epilogues_at_extreme_values(hip_lib):
+    oc.check_gemm_act_extremes(hip_lib, abi.BF16)
+    oc.check_gemm_act_extremes(hip_lib, abi.F16)
+
+
 def test_first_block_cache_probe(hip_lib):
     """MTX_EW_RESIDUAL_DIST + MTX_EW_SUB at the Kontext image stream's size: the distance torch computes on the same rounded operands, the same
     parts from two launches (no atomics: the cache decision cannot depend on scheduling)"""

@@ -118,6 +118,11 @@ def test_attention_alternative_schedules(emu_lib, schedule):
         oc.check_attention(emu_lib, abi.F16, batch=1, heads=1, sq=1024, sk=449, d=128, qmul=40.0, prescaled=True, schedule=schedule)
 
 
+def test_activation_epilogues_at_extreme_values(emu_lib):
+    oc.check_gemm_act_extremes(emu_lib, abi.BF16)
+    oc.check_gemm_act_extremes(emu_lib, abi.F16)
+
+
 def test_first_block_cache_probe(emu_lib):
     """MTX_EW_RESIDUAL_DIST + MTX_EW_SUB (the first-block cache of the Kontext path, reference core/ml/model_manager.py:1159-1162)"""
     oc.check_residual_dist(emu_lib, abi.BF16, rows=70, c=3072)

@@ -15,12 +15,12 @@ def test_yolo11n_and_12n_small(hip_lib):
 
 def test_yolo11l_panel_detector_geometry(hip_lib):
     be, ce = yc.check(hip_lib, "cuda:0", "11", "l", False, h=1536, w=1024, imgsz=640, seed=5, nc=4, n_det=20)
-    record("yolo11.l.detect.1024x1536.imgsz640", box_err_px=be, class_abs_err=ce)
+    record("yolo11.l.detect.1024x1536.imgsz640", class_abs_err=ce, **yc.stats)
 
 
 def test_yolo12x_osb_text_detector_geometry(hip_lib):
     be, ce = yc.check(hip_lib, "cuda:0", "12", "x", False, h=1536, w=1024, imgsz=640, seed=6, n_det=20)
-    record("yolo12.x.detect.1024x1536.imgsz640", box_err_px=be, class_abs_err=ce)
+    record("yolo12.x.detect.1024x1536.imgsz640", class_abs_err=ce, **yc.stats)
 
 
 def test_yolo11m_seg_bubble_detector_geometry(hip_lib):
