@@ -60,11 +60,17 @@ class Plan:
         self._keep = keep
         self.n_ops = n_ops
 
+    def _dev(self):
+        """the plan's own device (the HIP device is per thread and defaults to 0 — a worker thread of rank k must not launch this
+        plan on device 0's stream); None = the thread's current device (plans built before `device` existed, CPU simulator)"""
+        d = getattr(self, "device", None)
+        return d if d is not None and getattr(d, "type", None) == "cuda" else None
+
     def _stream(self, stream):
         if stream is not None:
             return C.c_void_p(stream)
         if torch.cuda.is_available() and not self.lib.is_simulator:
-            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            return C.c_void_p(torch.cuda.current_stream(self._dev()).cuda_stream)
         return C.c_void_p(0)
 
     def run(self, stream=None, graph: bool = False) -> None:
@@ -76,7 +82,7 @@ class Plan:
         if stream is not None:
             self.lib.check(self.lib.mtx_plan_run_graph(self._h, C.c_void_p(stream)), "mtx_plan_run_graph")
             return
-        cur = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream(self._dev())
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=cur.device)
         self._side.wait_stream(cur)
@@ -91,7 +97,7 @@ class Plan:
         if graph and stream is None and not self.lib.is_simulator:
             torch.cuda.synchronize()
             if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream()
+                self._side = torch.cuda.Stream(device=self._dev())
             stream = self._side.cuda_stream
         self.lib.check(self.lib.mtx_plan_time(self._h, self._stream(stream), iters, int(graph), C.byref(ms)), "mtx_plan_time")
         return float(ms.value)
@@ -641,6 +647,7 @@ class PlanBuilder:
         handle = C.c_void_p()
         self.lib.check(self.lib.mtx_plan_create(arr, n, C.byref(handle)), "mtx_plan_create")
         plan = Plan(self.lib, handle.value, list(self.keep), n)
+        plan.device = self.device          # where its buffers live: `run` takes streams of THIS device, whatever the calling thread's current device is
         plan.labels = list(self.labels)
         plan.ops = list(self.ops)          # the recorded argument blocks (benchmarks group launches by kernel and shape)
         return plan

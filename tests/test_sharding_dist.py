@@ -55,6 +55,35 @@ def _worker(rank, world, port, out_dir):
     assert calls == [640, 256, 128, 48], calls                      # bf16: 1280 B alone, 2 x 256 B together (a third would pass 600 B), the last alone; fp32: one bucket
     assert all(float(got[n].float().max()) == float(len(n) + sum(map(ord, n)) % 7) and tuple(got[n].shape) == s for n, s in big.items())
 
+    # 2c. worker threads under a process group: the ranks' threads ask the loaders in DIFFERENT orders; inside
+    # `thread_local_reads` every call reads its file itself — no collective, so nothing can hang or cross-wire — while the same calls on
+    # the main thread (one order on every rank) go through the status + tensor broadcasts
+    import threading
+    from safetensors.torch import save_file
+    from mangatranslator_amd.core.ml import model_manager as mm
+    mm.ModelManager._instance = None; mm._model_manager = None
+    man = mm.get_model_manager()
+    files = []
+    for i in range(3):
+        f = Path(out_dir) / f"ckpt{i}.safetensors"
+        if rank == 0:
+            save_file({"w": torch.full((4, 4), float(i))}, str(f))
+        files.append(f)
+    dist.barrier()
+    main_thread = [man._read_safetensors(f)["w"][0, 0].item() for f in files]          # collective path, same order everywhere
+    assert main_thread == [0.0, 1.0, 2.0]
+    got_t = {}
+
+    def worker():
+        order = files if rank == 0 else files[::-1]
+        with man.thread_local_reads():
+            for f in order:
+                got_t[f.name] = man._read_safetensors(f)["w"][0, 0].item()
+    th = threading.Thread(target=worker); th.start(); th.join(timeout=60)
+    assert not th.is_alive(), "a worker-thread load entered a collective"
+    assert got_t == {"ckpt0.safetensors": 0.0, "ckpt1.safetensors": 1.0, "ckpt2.safetensors": 2.0}
+    dist.barrier()
+
     # 3. sharded batch loop + gather
     pages = [f"ch2/010.jpg", "ch2/001.jpg", "ch10/001.jpg", "P1.png", "p10.png", "p2.png", "bad_3.png"]
     mine_pages = shard_pages(pages, rank, world)
