@@ -475,6 +475,13 @@ def main():
 
     def stage_a(i):
         """front half of page i: the stages whose host share is large (NMS, prompt handling, OSB region logic)"""
+        if world > 1:       # may run on a worker thread: an operator that asks the manager for an unstaged optional model must not enter a collective from here
+            from mangatranslator_amd.core.ml.model_manager import get_model_manager as _gmm
+            with _gmm().thread_local_reads():
+                return stage_a_body(i)
+        return stage_a_body(i)
+
+    def stage_a_body(i):
         k = i % pool
         outs = page_outs.setdefault(i, {})
         fs = front_sets[front_set_of(i)]

@@ -204,6 +204,7 @@ class ModelManager:
             # error is 8x smaller; this library's f16 conversions SATURATE at 65504, so an activation overflow on a page unlike the probe
             # would degrade masks without a NaN — ADVICE r04), "bf16" = the reference's own GPU dtype, no probe, "f16" = no probe either
             self.sam_storage = "auto"
+            self._failed_reads = {}                 # checkpoint path -> the error all ranks were told (multi-rank only; see _read_safetensors_with_metadata)
             self._initialized = True
             log_message(f"Model Manager initialized on device: {self.device}", always_print=True)
 
@@ -314,6 +315,11 @@ class ModelManager:
     def clear_cache(self):
         empty_cache(self.device)
 
+    def forget_failed_loads(self):
+        """checkpoints reported missing / unreadable under a process group are remembered (no collective per retry); call this on every rank
+        after staging one of them"""
+        self._failed_reads.clear()
+
     def unload_model(self, model_type: ModelType, force_gc: bool = True, verbose: bool = False):
         with self._lock:
             replicas = [k for k in self.models if isinstance(k, tuple) and k[0] == model_type]      # its front-half replicas go with it
@@ -397,6 +403,13 @@ class ModelManager:
         path already (set 0), the ranks of a node share the filesystem."""
         import torch.distributed as dist
         local = local or self._local_reads()
+        if not local and _dist_on():
+            # a checkpoint every rank was already told is missing / unreadable: say so again without another collective (callers such as the
+            # OSB stage ask for an unstaged optional model on EVERY page; a status broadcast per page and rank is a sync point the page loop
+            # does not need).  Staging the file later takes `forget_failed_loads()`.
+            known = self._failed_reads.get(str(path))
+            if known is not None:
+                raise ModelError(known)
         rank0 = local or not _dist_on() or dist.get_rank() == 0
         sd, error, metadata = None, None, {}
         if rank0:
@@ -427,7 +440,12 @@ class ModelManager:
             if error:
                 raise ModelError(error)
             return sd, metadata
-        broadcast_status(error)
+        try:
+            broadcast_status(error)
+        except ModelError as e:
+            if _dist_on():
+                self._failed_reads[str(path)] = str(e)
+            raise
         if _dist_on():
             meta = [{k: (tuple(v.shape), v.dtype) for k, v in sd.items()}, metadata] if rank0 else [None, None]
             dist.broadcast_object_list(meta, src=0)

@@ -113,3 +113,36 @@ def test_world_size_2_gloo(tmp_path):
     pages = ["ch2/010.jpg", "ch2/001.jpg", "ch10/001.jpg", "P1.png", "p10.png", "p2.png", "bad_3.png"]
     order = shard_pages(pages, 0, 1)
     assert order[0::2] == shard_pages(pages, 0, 2) and order[1::2] == shard_pages(pages, 1, 2)
+
+
+def _worker_failed_read(rank, world, port, out_dir):
+    """a checkpoint that is missing: the first ask is a collective (every rank raises the same ModelError), later asks raise at once —
+    counted by wrapping the status broadcast"""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mangatranslator_amd.core.ml import model_manager as mm
+    from mangatranslator_amd.utils.exceptions import ModelError
+    man = mm.get_model_manager()
+    calls = []
+    real = mm.broadcast_status
+    mm.broadcast_status = lambda err, src=0: (calls.append(1), real(err, src))[1]
+    missing = Path(out_dir) / "absent.safetensors"
+    for _ in range(3):
+        try:
+            man._read_safetensors(missing)
+            raise AssertionError("a missing checkpoint loaded")
+        except ModelError as e:
+            assert "not found" in str(e)
+    assert len(calls) == 1, calls
+    if rank == 0:
+        from safetensors.torch import save_file
+        save_file({"w": torch.ones(2)}, str(missing))
+    dist.barrier()
+    man.forget_failed_loads()
+    assert float(man._read_safetensors(missing)["w"].sum()) == 2.0 and len(calls) == 2
+    dist.destroy_process_group()
+
+
+def test_failed_collective_load_is_remembered(tmp_path):
+    mp.spawn(_worker_failed_read, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
