@@ -54,6 +54,14 @@ io)
     echo "== batch harness with image I/O: config 5, 16 pages"; timeout 1800 python bench.py --config 5 --steps 4 --warmup 2 --batch-io 16 --no-cpu-baseline --no-traffic > gpurun_out/bench_io5.out 2> gpurun_out/bench_io5.err; line gpurun_out/bench_io5.out gpurun_out/r05_bench_config5_batch_io16.json
     tail -3 gpurun_out/bench_io2.err
   } > gpurun_out/r05_end_io.log 2>&1; cat gpurun_out/r05_end_io.log ;;
+config5prof)
+  { echo "== config 5 serial (--no-overlap), under rocprofv3 --kernel-trace --stats"; prof config5 --config 5 --steps 4 --warmup 1 --no-overlap --no-traffic --no-extra
+    python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r05_bench_config5_under_rocprof.json"))
+print(round(d["value"], 4), d["unit"], round(d["ms_per_step"], 1), "ms/page |", {k: round(v["frac"], 3) for k, v in d.items() if k.startswith("roofline")})
+PY
+  } > gpurun_out/r05_end_config5prof.log 2>&1; cat gpurun_out/r05_end_config5prof.log ;;
 pmc)
   { ARGS="gemm 8812 9216 3072 gemm 8812 3072 15360 attn 8812 conv 1536 1024 gemm8 8512 27648 3072 glu 8512 9216 3072 9216"
     rm -rf /tmp/pmc_a; mkdir -p /tmp/pmc_a
