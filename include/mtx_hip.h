@@ -456,6 +456,10 @@ MTX_API int mtx_gemm(const mtx_gemm_args* a, void* stream);
 MTX_API int mtx_gemm_last_split(int* whole_tiles, int* k_slices, int* tail_pieces);
 MTX_API int mtx_attention(const mtx_attn_args* a, void* stream);
 MTX_API int mtx_norm(const mtx_norm_args* a, void* stream);
+/* which row-normalisation kernel THIS THREAD's mtx_norm launches (and plan norm ops issued from it) use: 2 = rows kept packed between the
+ * passes and the adaLN modulation rows requested before the statistics (the default), 1 = packed rows only, 3 = form 2 held to 96 registers,
+ * 0 = the fp32-register form of rounds 1-4, -1 = back to the default (environment MTX_NORM_FORM=0..3 selects a form process-wide).  Both forms give identical bytes; a test / measurement switch. */
+MTX_API int mtx_norm_form(int form);
 MTX_API int mtx_groupnorm(const mtx_groupnorm_args* a, void* stream);
 MTX_API int mtx_elementwise(const mtx_ew_args* a, void* stream);
 MTX_API int mtx_channel_attention(const mtx_ca_args* a, void* stream);

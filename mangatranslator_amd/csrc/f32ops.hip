@@ -115,31 +115,41 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mtx_gemm_args p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  for (long k0 = 0; k0 < p.k; k0 += F_TK) {
-    {
-      const long r = m0 + (tid >> 1);
-      const int kq = (tid & 1) * 8;
-      const bool row_ok = r < p.m;
-      if (row_ok && k0 + kq + 8 <= p.k && ((p.lda | (k0 + kq)) & 3) == 0 && ((size_t)(A + r * p.lda + k0 + kq) & 15) == 0) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(A + r * p.lda + k0 + kq), v1 = *reinterpret_cast<const f32x4*>(A + r * p.lda + k0 + kq + 4);
+  // the next K step's operands are requested into registers before this step's MFMAs and written to LDS after them: with two workgroups per
+  // CU (SAM's 32 768 x 128 projections) the global-load latency was the whole step (round 5, second pass: 50 -> see profiles)
+  const long ar = m0 + (tid >> 1), wc = n0 + (tid >> 2);
+  const int kq = (tid & 1) * 8, kw = (tid & 3) * 4;
+  const bool row_ok = ar < p.m, col_ok = wc < p.n;
+  const float* Arow = A + (row_ok ? ar : 0) * p.lda;
+  const float* Wrow = W + (col_ok ? wc : 0) * p.ldw;
+  const bool a_vec = (p.lda & 3) == 0 && ((size_t)Arow & 15) == 0, w_vec = (p.ldw & 3) == 0 && ((size_t)Wrow & 15) == 0;
+  float ra[8], rw[4];
+  auto fetch = [&](long k0) {
+    if (row_ok && a_vec && k0 + kq + 8 <= p.k) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(Arow + k0 + kq), v1 = *reinterpret_cast<const f32x4*>(Arow + k0 + kq + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { As[kq + i][tid >> 1] = v0[i]; As[kq + 4 + i][tid >> 1] = v1[i]; }
-      } else {
+      for (int i = 0; i < 4; ++i) { ra[i] = v0[i]; ra[4 + i] = v1[i]; }
+    } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const long k = k0 + kq + i;
-          As[kq + i][tid >> 1] = (row_ok && k < p.k) ? A[r * p.lda + k] : 0.f;
-        }
-      }
-      const long c = n0 + (tid >> 2);
-      const int kw = (tid & 3) * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const long k = k0 + kw + i;
-        Ws[kw + i][tid >> 2] = (c < p.n && k < p.k) ? W[c * p.ldw + k] : 0.f;
-      }
+      for (int i = 0; i < 8; ++i) ra[i] = (row_ok && k0 + kq + i < p.k) ? Arow[k0 + kq + i] : 0.f;
     }
+    if (col_ok && w_vec && k0 + kw + 4 <= p.k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Wrow + k0 + kw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rw[i] = v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rw[i] = (col_ok && k0 + kw + i < p.k) ? Wrow[k0 + kw + i] : 0.f;
+    }
+  };
+  fetch(0);
+  for (long k0 = 0; k0 < p.k; k0 += F_TK) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) As[kq + i][tid >> 1] = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Ws[kw + i][tid >> 2] = rw[i];
     __syncthreads();
+    if (k0 + F_TK < p.k) fetch(k0 + F_TK);
 #pragma unroll
     for (int kk = 0; kk < F_TK; kk += 2) {
       const float b = Ws[kk + hi][wn * 32 + l31];
@@ -167,6 +177,43 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mtx_gemm_args p) {
     }
 }
 
+// ---- few rows, long K (the token-side MLP-out of SAM's two-way blocks: 72 x 256 from K = 2 048): the tiled kernels above give that
+// problem four workgroups walking 128 K steps each (0.27 ms per launch on MI355X).  Here a wave owns one output column and SK_R rows:
+// its lanes stride over K in 16-byte pieces (coalesced), each keeps SK_R partial dot products, one wave reduction per row at the end —
+// rows / SK_R x n waves (2 304 for the shape above), A re-read from the L2.
+constexpr int SK_R = 8;
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(mtx_gemm_args p) {
+  const int lane = threadIdx.x & 63;
+  const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6), r0 = (long)blockIdx.y * SK_R, z = blockIdx.z;
+  if (c >= p.n) return;                                                   // wave-uniform
+  const float* A = reinterpret_cast<const float*>(p.a) + z * p.a_bstride;
+  const float* W = reinterpret_cast<const float*>(p.w) + z * p.w_bstride + c * p.ldw;
+  float acc[SK_R];
+#pragma unroll
+  for (int i = 0; i < SK_R; ++i) acc[i] = 0.f;
+  for (long k = (long)lane * 4; k < p.k; k += 256) {                      // K % 4 == 0 (launcher)
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + k);
+#pragma unroll
+    for (int i = 0; i < SK_R; ++i) {
+      const long r = r0 + i < p.m ? r0 + i : p.m - 1;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(A + r * p.lda + k);
+      acc[i] = fmaf(a[0], w[0], fmaf(a[1], w[1], fmaf(a[2], w[2], fmaf(a[3], w[3], acc[i]))));
+    }
+  }
+  float* Cz = reinterpret_cast<float*>(p.c) + z * p.c_bstride;
+  const float* R = p.res ? reinterpret_cast<const float*>(p.res) + z * p.res_bstride : nullptr;
+  const float bias = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < SK_R; ++i) {
+    const float t = wave_sum(acc[i]);
+    if (lane == i && r0 + i < p.m) {
+      float v = act_f32(t * p.alpha + bias, p.act, p.act_param);
+      if (R) v += R[(r0 + i) * p.ldres + c];
+      Cz[(r0 + i) * p.ldc + c] = v;
+    }
+  }
+}
+
 int gemm_f32_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (!a->a || !a->w || !a->c) { *err = "gemm f32: null operand"; return MTX_ERR_INVALID; }
   if (a->gate || a->glu_q || a->in_dtype == MTX_F8 || (a->out_dtype != MTX_F32 && a->out_dtype != a->dtype)) {
@@ -176,6 +223,12 @@ int gemm_f32_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (a->batch > 65535) { *err = "gemm f32: batch > 65535"; return MTX_ERR_INVALID; }
   dim3 grid((unsigned)((a->n + F_TN - 1) / F_TN), (unsigned)((a->m + F_TM - 1) / F_TM), (unsigned)a->batch);
   if (grid.y > 65535) { *err = "gemm f32: more than 65535 row tiles"; return MTX_ERR_INVALID; }
+  if (a->m <= 128 && a->k >= 1024 && a->k % 4 == 0 && a->lda % 4 == 0 && a->ldw % 4 == 0 && a->a_bstride % 4 == 0 && a->w_bstride % 4 == 0 &&
+      (((size_t)a->a | (size_t)a->w) & 15) == 0 && !(a->flags & MTX_GEMM_FORCE_TILE256)) {
+    const dim3 sgrid((unsigned)((a->n + 3) / 4), (unsigned)((a->m + SK_R - 1) / SK_R), (unsigned)a->batch);
+    MTX_LAUNCH(gemm_f32_skinny_kernel, sgrid, dim3(256), 0, stream, *a);
+    return MTX_OK;
+  }
   // from a few row tiles up the matrix pipe wins; the token-side GEMMs (72 rows) stay on the vector ALUs (MTX_GEMM_FORCE_TILE256 forces the
   // matrix kernel: tests)
   if (a->m >= 256 || (a->flags & MTX_GEMM_FORCE_TILE256)) MTX_LAUNCH(gemm_f32_mfma_kernel, grid, dim3(256), 0, stream, *a);
@@ -222,12 +275,55 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(mtx_attn_args p) {
   }
 }
 
+// Few keys, many queries (SAM's image-to-token attention: 4 096 queries per box and head against 9 tokens): with a wave per query only
+// `sk` of the 64 lanes have a key.  Here a LANE owns a query — q and the accumulator in its registers, the keys walked in order with the
+// same running-max update — and the K / V rows, shared by all queries of a (batch, head), are broadcast loads.
+template <int D>
+__global__ __launch_bounds__(256) void attn_f32_rows_kernel(mtx_attn_args p) {
+  const long unit = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = p.batch * p.heads * p.sq;
+  if (unit >= total) return;
+  const long qi = unit % p.sq, h = (unit / p.sq) % p.heads, b = unit / (p.sq * p.heads);
+  const float* Q = reinterpret_cast<const float*>(p.q) + b * p.q_bs + qi * p.q_ss + h * p.q_hs;
+  const float* K = reinterpret_cast<const float*>(p.k) + b * p.k_bs + h * p.k_hs;
+  const float* V = reinterpret_cast<const float*>(p.v) + b * p.v_bs + h * p.v_hs;
+  float q[D], acc[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) { q[c] = Q[c] * p.scale; acc[c] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  for (long j = 0; j < p.sk; ++j) {
+    const float* kj = K + j * p.k_ss;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s = fmaf(q[c], kj[c], s);
+    const float mn = s > m ? s : m;
+    const float corr = expf(m - mn), e = expf(s - mn);          // first key: expf(-inf) = 0
+    l = l * corr + e;
+    const float* vj = V + j * p.v_ss;
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = acc[c] * corr + e * vj[c];
+    m = mn;
+  }
+  float* O = reinterpret_cast<float*>(p.o) + b * p.o_bs + qi * p.o_ss + h * p.o_hs;
+#pragma unroll
+  for (int c = 0; c < D; ++c) O[c] = acc[c] / l;
+}
+
 int attn_f32_launch(const mtx_attn_args* a, void* stream, const char** err) {
   if (!a->q || !a->k || !a->v || !a->o) { *err = "attention f32: null operand"; return MTX_ERR_INVALID; }
   if (a->q8 || (a->flags & MTX_ATTN_Q_PRESCALED)) { *err = "attention f32: fp8 output / pre-scaled q are not part of the fp32 path"; return MTX_ERR_UNSUPPORTED; }
   if (a->sk < 1) { *err = "attention f32: no keys"; return MTX_ERR_INVALID; }
   const long total = a->batch * a->heads * a->sq;
   if (total < 1) return MTX_OK;
+  if (a->sk <= 32 && a->sq >= 64 && a->d <= 32) {          // a lane per query
+    const dim3 rgrid((unsigned)((total + 255) / 256));
+    switch (a->d) {
+      case 8: MTX_LAUNCH(attn_f32_rows_kernel<8>, rgrid, dim3(256), 0, stream, *a); return MTX_OK;
+      case 16: MTX_LAUNCH(attn_f32_rows_kernel<16>, rgrid, dim3(256), 0, stream, *a); return MTX_OK;
+      case 32: MTX_LAUNCH(attn_f32_rows_kernel<32>, rgrid, dim3(256), 0, stream, *a); return MTX_OK;
+      default: break;
+    }
+  }
   const dim3 grid((unsigned)((total + 3) / 4));
   switch (a->d) {
     case 8: MTX_LAUNCH(attn_f32_kernel<8>, grid, dim3(256), 0, stream, *a); break;

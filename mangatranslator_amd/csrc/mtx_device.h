@@ -241,15 +241,68 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
   return __builtin_bit_cast(u32x4, v);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
+// the xor butterfly through the LDS crossbar (ds_bpermute per level): what `wave_sum` was through round 4; kept as the yardstick the
+// register-only form below is held to (norm_kernel, mtx_norm_form(0))
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
+#ifndef MTX_EMU
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+#endif
+// The same butterfly, same level order (32, 16, 8, 4, 2, 1), without LDS traffic: v_permlane32_swap, v_permlane16_swap, then DPP inside the
+// 16-lane rows — row_ror:8 is lane ^ 8; row_ror:4 reads lane (l + 4) % 16, which after the ^ 8 level holds what lane l ^ 4 holds; quad_perm
+// for ^ 2 and ^ 1.  Every level adds the same two numbers as the shuffle form, so the bytes are identical (fp addition commutes).
+__device__ __forceinline__ float wave_sum(float v) {
+#ifdef MTX_EMU
+  return wave_sum_shfl(v);
+#else
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  }
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  }
+  v += dpp_move<0x128>(v);      // row_ror:8
+  v += dpp_move<0x124>(v);      // row_ror:4
+  v += dpp_move<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  v += dpp_move<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  return v;
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
+#ifdef MTX_EMU
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { float o = __shfl_xor(v, m, 64); v = v > o ? v : o; }
   return v;
+#else
+  float o;
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a = __builtin_bit_cast(float, (unsigned)r[0]), b = __builtin_bit_cast(float, (unsigned)r[1]);
+    v = a > b ? a : b;
+  }
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float a = __builtin_bit_cast(float, (unsigned)r[0]), b = __builtin_bit_cast(float, (unsigned)r[1]);
+    v = a > b ? a : b;
+  }
+  o = dpp_move<0x128>(v); v = v > o ? v : o;
+  o = dpp_move<0x124>(v); v = v > o ? v : o;
+  o = dpp_move<0x4E>(v); v = v > o ? v : o;
+  o = dpp_move<0xB1>(v); v = v > o ? v : o;
+  return v;
+#endif
 }
 
 // ---- OCP fp8 e4m3 ------------------------------------------------------------------------------------------

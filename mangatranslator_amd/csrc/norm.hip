@@ -18,6 +18,7 @@ constexpr int NORM_MAXCH = 12;   // chunks of 8 per lane -> C <= 6144
 // value registers instead of the 96 the widest row needs, twice the waves fit a SIMD and twice the bytes are in flight (round 4).
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
+#pragma clang fp contract(off)      // every product and sum rounded on its own: what this kernel's code has always been (packed multiplies, then adds); the packed-row kernel is held to the same bytes
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
     }
   }
   float mean = 0.f;
-  if (p.kind == 0) { s = wave_sum(s); mean = s / (float)p.c; }
+  if (p.kind == 0) { s = wave_sum_shfl(s); mean = s / (float)p.c; }
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
       for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
     }
   }
-  ss = wave_sum(ss);
+  ss = wave_sum_shfl(ss);
   const float rstd = 1.0f / sqrtf(ss / (float)p.c + p.eps);
   const T* MS = reinterpret_cast<const T*>(p.mod_scale);
   const T* MH = reinterpret_cast<const T*>(p.mod_shift);
@@ -104,6 +105,136 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
   }
 }
 
+// Round 5: the same row normalisation with the row kept PACKED between the passes (NCH x 4 registers instead of NCH x 8 fp32 values) and
+// unpacked again where each pass needs it — a 16-bit -> fp32 unpack is one shift / convert per element, and the kernel has nothing but
+// latency to hide: a 3072-wide row drops from 105 to <= 64 VGPRs, 8 waves per SIMD instead of 4, i.e. the whole 8 812-row problem of a FLUX
+// block resident at once and twice the bytes in flight.  The additions run in the same order as in `norm_kernel`, so the bytes are identical
+// (tests compare both).  NORM_PIN keeps the optimiser from carrying the unpacked values across the passes (which would undo the point).
+#ifdef MTX_EMU
+#define NORM_PIN(x) do { } while (0)
+#else
+#define NORM_PIN(x) asm volatile("" : "+v"(x))
+#endif
+// FULL: every lane owns NCH valid chunks (C == 512 NCH), no gamma / beta / activation — the adaLN rows of the FLUX blocks: straight-line
+// code, no per-chunk exec masks, no per-element affine loads.  PRE (with FULL): the modulation rows are requested together with x instead of
+// after the two reductions (their L2 latency leaves the critical path at the price of 8 NCH more registers).
+template <typename T, int NCH, bool FULL, bool PRE, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void norm_packed_kernel(mtx_norm_args p) {
+#pragma clang fp contract(off)      // as in norm_kernel: no fused multiply-adds, so both kernels round alike (hardware visit o: the fused variance differed in the last bit of some rows)
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const long nch = p.c / 8;
+  const T* X = reinterpret_cast<const T*>(p.x) + row * p.ldx;
+  T* Y = reinterpret_cast<T*>(p.y) + row * p.ldy;
+  u32x4 raw[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const long ch = lane + (long)i * 64;
+    raw[i] = (FULL || ch < nch) ? *reinterpret_cast<const u32x4*>(X + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+  }
+  const T* MS = reinterpret_cast<const T*>(p.mod_scale);
+  const T* MH = reinterpret_cast<const T*>(p.mod_shift);
+  const long mrow = p.rows_per > 0 ? row / p.rows_per : 0;
+  u32x4 gs[PRE ? NCH : 1], gh[PRE ? NCH : 1];
+  if (PRE) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const long ch = lane + (long)i * 64;
+      gs[i] = MS ? *reinterpret_cast<const u32x4*>(MS + mrow * p.ldmod + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+      gh[i] = MH ? *reinterpret_cast<const u32x4*>(MH + mrow * p.ldmod + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const long ch = lane + (long)i * 64;
+    if (FULL || ch < nch) {
+      float f[8];
+      unpack8<T>(raw[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[e];
+    }
+  }
+  float mean = 0.f;
+  if (p.kind == 0) { s = wave_sum(s); mean = s / (float)p.c; }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) NORM_PIN(raw[i]);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const long ch = lane + (long)i * 64;
+    if (FULL || ch < nch) {
+      float f[8];
+      unpack8<T>(raw[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; ss += d * d; }
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = 1.0f / sqrtf(ss / (float)p.c + p.eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) NORM_PIN(raw[i]);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const long ch = lane + (long)i * 64;
+    if (FULL || ch < nch) {
+      float f[8], o[8];
+      unpack8<T>(raw[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (f[e] - mean) * rstd;
+        if (!FULL) {
+          if (p.gamma) t *= p.gamma[ch * 8 + e];
+          if (p.beta) t += p.beta[ch * 8 + e];
+        }
+        o[e] = t;
+      }
+      if (MS) { float g[8]; unpack8<T>(PRE ? gs[i] : *reinterpret_cast<const u32x4*>(MS + mrow * p.ldmod + ch * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= (1.f + g[e]); }
+      if (MH) { float g[8]; unpack8<T>(PRE ? gh[i] : *reinterpret_cast<const u32x4*>(MH + mrow * p.ldmod + ch * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += g[e]; }
+      if (!FULL && p.act != MTX_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = apply_act(o[e], p.act, 0.f);
+      }
+      raw[i] = pack8<T>(o);                                   // the result as rounded to T: what y holds and what the quantiser reads
+      if (p.y != nullptr) *reinterpret_cast<u32x4*>(Y + ch * 8) = raw[i];
+    }
+  }
+  if (p.q != nullptr) {
+    unsigned char* Q = reinterpret_cast<unsigned char*>(p.q) + row * p.ldq;
+    unsigned* S = reinterpret_cast<unsigned*>(p.q_scale);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const long ch = lane + (long)i * 64;
+      if (FULL || (long)i * 64 < nch) {             // wave-uniform
+        float f[8];
+        unpack8<T>(raw[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (FULL || ch < nch) ? f[e] : 0.f;
+        unsigned w0, w1, word;
+        mx_quantize_chunk(f, ch, w0, w1, word);
+        if (FULL || ch < nch) {
+          *reinterpret_cast<u32x2*>(Q + ch * 8) = u32x2{w0, w1};
+          if ((ch & 15) == 0) S[(ch >> 4) * p.lds_q + row] = word;
+        }
+      }
+    }
+  }
+}
+
+// which form norm_launch uses (MTX_NORM_FORM / mtx_norm_form: same-process A/Bs and the test that holds all forms to identical bytes)
+static int norm_form() {
+  static int form = -1;
+  if (form < 0) { const char* e = getenv("MTX_NORM_FORM"); form = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 2; }
+  return form;
+}
+static thread_local int g_norm_form_override = -1;
+void norm_set_form(int form) { g_norm_form_override = form; }
+
 int norm_f32_launch(const mtx_norm_args* a, void* stream, const char** err);      // f32ops.hip
 int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
   if (a->dtype == MTX_F32) return norm_f32_launch(a, stream, err);
@@ -116,12 +247,22 @@ int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
   const unsigned blocks = (unsigned)((a->rows + 3) / 4);
   if (a->dtype != MTX_BF16 && a->dtype != MTX_F16) { *err = "norm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
   const long per_lane = (a->c / 8 + 63) / 64;
-#define MTX_NORM(N) do { if (a->dtype == MTX_BF16) MTX_LAUNCH((norm_kernel<__bf16, N>), dim3(blocks), dim3(256), 0, stream, *a); \
-                         else MTX_LAUNCH((norm_kernel<_Float16, N>), dim3(blocks), dim3(256), 0, stream, *a); } while (0)
+  // forms: 0 = fp32-register kernel (rounds 1-4), 1 = packed rows, 2 = packed rows with the modulation requested up front (default), 3 = the
+  // same held to 96 registers (5 waves per SIMD, 20 bytes of scratch).  MI355X, 8 812 x 3 072 bf16 with adaLN modulation, same process
+  // (profiles/r05_visit_o_*.log): 29.7 / 21.6 / 18.8 / 23.1 us; with the MX fp8 twin instead of the 16-bit store 35.6 / 26.3 / 23.4 / 26.4.
+  const int form = g_norm_form_override >= 0 ? g_norm_form_override : norm_form();
+  const bool full = a->c % 512 == 0 && (per_lane == 2 || per_lane == 4 || per_lane == 6 || per_lane == NORM_MAXCH) && !a->gamma && !a->beta && a->act == MTX_ACT_NONE;
+#define MTX_NORM_T(TT, N) do { if (form == 0) MTX_LAUNCH((norm_kernel<TT, N>), dim3(blocks), dim3(256), 0, stream, *a); \
+                               else if (!full) MTX_LAUNCH((norm_packed_kernel<TT, N, false, false>), dim3(blocks), dim3(256), 0, stream, *a); \
+                               else if (form == 2) MTX_LAUNCH((norm_packed_kernel<TT, N, true, true>), dim3(blocks), dim3(256), 0, stream, *a); \
+                               else if (form == 3) MTX_LAUNCH((norm_packed_kernel<TT, N, true, true, (N <= 6 ? 5 : 1)>), dim3(blocks), dim3(256), 0, stream, *a); \
+                               else MTX_LAUNCH((norm_packed_kernel<TT, N, true, false>), dim3(blocks), dim3(256), 0, stream, *a); } while (0)
+#define MTX_NORM(N) do { if (a->dtype == MTX_BF16) MTX_NORM_T(__bf16, N); else MTX_NORM_T(_Float16, N); } while (0)
   if (per_lane <= 2) MTX_NORM(2);
   else if (per_lane <= 4) MTX_NORM(4);
   else if (per_lane <= 6) MTX_NORM(6);
   else MTX_NORM(NORM_MAXCH);
+#undef MTX_NORM_T
 #undef MTX_NORM
   return MTX_OK;
 }

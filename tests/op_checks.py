@@ -264,9 +264,21 @@ def check_norm(lib, dtype, rows, c, kind=0, affine=True, modulate=False, seed=0)
             beta=pb.const(beta) if beta is not None else None, eps=1e-6, kind=kind,
             mod_scale=pb.const(ms) if ms is not None else None, mod_shift=pb.const(mh) if mh is not None else None,
             rows_per=rows_per if modulate else 0, ldmod=c if modulate else 0)
-    _run(pb)
+    plan = _run(pb)
     err = _relerr(y.cpu(), ref)
     assert err < TOL[dtype], f"norm mismatch rel err {err}"
+    # the packed-row kernel (default) and the fp32-register form of rounds 1-4 add in the same order: identical bytes
+    packed = y.clone()
+    try:
+        for form in (0, 1, 3):
+            lib.check(lib.mtx_norm_form(form), "mtx_norm_form")
+            y.zero_()
+            _sync(lib)
+            plan.run()
+            _sync(lib)
+            assert torch.equal(y.view(torch.int16), packed.view(torch.int16)), f"norm: kernel form {form} and the default differ"
+    finally:
+        lib.check(lib.mtx_norm_form(-1), "mtx_norm_form")
     return err
 
 
@@ -520,8 +532,18 @@ def check_fused_quantisers(lib, dtype, rows, c, hid, seed=0):
     sw1 = pb.buf((rows, hid), td)
     pb.quantize(abt, rows, hid, ldx=2 * hid, q=qs1, scale=ss1, row_off=r_off, lds=lds, ldq=2 * hid, q_col_off=hid,
                 swiglu_b=abt, b_off=hid, ldb=2 * hid, y=sw1, ldy=hid)
-    _run(pb)
+    plan = _run(pb)
     assert torch.equal(y1, y2), "16-bit norm output changed"
+    keep = [t.clone() for t in (y1, q1, s1, q1b, s1b)]
+    try:
+        for form in (0, 1, 3):                                      # the other norm kernels: same bytes, 16-bit and fp8 twin
+            lib.check(lib.mtx_norm_form(form), "mtx_norm_form")
+            plan.run()
+            _sync(lib)
+            for t, k, what in zip((y1, q1, s1, q1b, s1b), keep, ("y", "q", "scales", "q (no y)", "scales (no y)")):
+                assert torch.equal(t.view(torch.uint8), k.view(torch.uint8)), f"norm kernel form {form} differs in {what}"
+    finally:
+        lib.check(lib.mtx_norm_form(-1), "mtx_norm_form")
     for a_, b_, what in ((q1, q2, "norm bytes"), (s1, s2, "norm scales"), (q1b, q2, "norm bytes (no 16-bit output)"), (s1b, s2, "norm scales (no 16-bit output)"),
                          (qs1, qs2, "SwiGLU bytes"), (ss1, ss2, "SwiGLU scales")):
         assert torch.equal(a_, b_), f"{what}: {(a_ != b_).sum().item()} differ"
@@ -754,6 +776,11 @@ def check_f32_ops(lib, seed=0):
     a, w = rnd(40, 24), rnd(9, 24)
     out = pb.gemm(pb.const(a), pb.const(w), 40, 9, 24, flags=abi.GEMM_FORCE_TILE256)
     checks.append(("gemm (matrix pipe, forced) 40x9x24", out, a @ w.t()))
+    # GEMM 2c: few rows, long K (SAM's token-side MLP-out): a wave per output column and 8 rows, lanes striding K
+    for m, n, k, bt in ((37, 50, 1024, 1), (72, 19, 2048, 2)):
+        a, w, b, r = rnd(bt, m, k), rnd(n, k) / math.sqrt(k), rnd(n), rnd(bt, m, n)
+        out = pb.gemm(pb.const(a), pb.const(w), m, n, k, bias=pb.const(b), act=abi.ACT_RELU, res=pb.const(r), batch=bt, a_bs=m * k, c_bs=m * n, res_bs=m * n)
+        checks.append((f"gemm (few rows, long K) {bt}x{m}x{n}x{k}", out, F.relu(torch.einsum("bmk,nk->bmn", a, w) + b) + r))
     # GEMM 3: rows picked out of a wider matrix (lda, a_off), output into a column slice (ldc, c_off), relu; strided weight batches
     rows, NT, D, c2 = 5, 9, 16, 8
     q = rnd(rows * NT, D)
@@ -768,7 +795,8 @@ def check_f32_ops(lib, seed=0):
     masks = pb.gemm(pb.const(up), pb.const(hyp), 30, 4, c2, batch=rows, a_bs=30 * c2, w_bs=4 * c2, c_bs=30 * 4, out_f32=True)
     checks.append(("gemm per-box weights", masks, torch.einsum("bpc,bkc->bpk", up, hyp)))
     # attention: q / k from one fused projection (k_off), 70 keys (two key rounds of a wave) and 3 keys
-    for nb, heads, sq, sk, d in ((2, 4, 5, 70, 16), (1, 2, 130, 3, 32), (1, 1, 2, 64, 8)):
+    # (130 x 3 and 300 x 9: many queries against few keys — a lane per query)
+    for nb, heads, sq, sk, d in ((2, 4, 5, 70, 16), (1, 2, 130, 3, 32), (1, 1, 2, 64, 8), (3, 2, 300, 9, 16)):
         Dm = heads * d
         qk, v = rnd(nb * max(sq, sk), 2 * Dm), rnd(nb * sk, Dm)
         o = pb.buf((nb * sq, Dm), torch.float32, zero=True)

@@ -70,6 +70,11 @@ def test_attention_f16(hip_lib):
     dict(rows=9, c=128, kind=1),
     dict(rows=3, c=1152, kind=0),
     dict(rows=8704, c=3072, kind=0, affine=False, modulate=True),
+    dict(rows=611, c=1024, kind=0, affine=False, modulate=True),
+    dict(rows=1030, c=2048, kind=1, affine=False),
+    dict(rows=517, c=6144, kind=0, affine=False, modulate=True),
+    dict(rows=4001, c=1152, kind=0),                                 # affine, ragged chunks, enough elements for a last-bit difference between the kernel forms to show
+    dict(rows=3000, c=1024, kind=1),
 ])
 def test_norm(hip_lib, cfg):
     oc.check_norm(hip_lib, abi.BF16, **cfg)

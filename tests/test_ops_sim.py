@@ -60,6 +60,8 @@ def test_attention_f16(emu_lib):
     dict(rows=5, c=3072, kind=0, affine=False, modulate=True),
     dict(rows=9, c=128, kind=1),
     dict(rows=3, c=1152, kind=0),
+    dict(rows=6, c=1024, kind=0, affine=False, modulate=True),      # whole 512-chunks, no affine: the straight-line kernel
+    dict(rows=5, c=2048, kind=1, affine=False),
 ])
 def test_norm(emu_lib, cfg):
     oc.check_norm(emu_lib, abi.BF16, **cfg)

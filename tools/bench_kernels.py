@@ -124,6 +124,42 @@ def conv(H, W, iters=20):
     print(f"conv3x3 64->64 {W}x{H}: {ms * 1e3:.1f} us  {byts / ms / 1e6:.0f} GB/s  {2 * 9 * 64 * 64 * H * W / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
+def norm(rows, c, reps=3, iters=50, q8=False):
+    """adaLN LayerNorm rows of a FLUX block (no affine, modulation rows per stream) under every mtx_norm_form, REPS rounds in one process;
+    q8: the FLUX.2 form (MX fp8 twin from the registers, no 16-bit store).  Also: all forms give identical bytes on this chip."""
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    x = pb.buf((rows, c), torch.bfloat16); x.normal_()
+    ms_, mh_ = pb.buf((2, c), torch.bfloat16), pb.buf((2, c), torch.bfloat16)
+    ms_.normal_(); mh_.normal_()
+    rows_per = (rows + 1) // 2
+    lds = (rows + 63) // 64 * 64
+    if q8:
+        q, sc = pb.buf((rows, c), torch.uint8, zero=True), pb.buf((c // 128, lds), torch.int32, zero=True)
+        pb.norm(x, None, rows, c, eps=1e-6, kind=0, mod_scale=ms_, mod_shift=mh_, rows_per=rows_per, ldmod=c, q8=(q, sc), lds_q=lds)
+        outs = (q, sc)
+    else:
+        y = pb.buf((rows, c), torch.bfloat16)
+        pb.norm(x, y, rows, c, eps=1e-6, kind=0, mod_scale=ms_, mod_shift=mh_, rows_per=rows_per, ldmod=c)
+        outs = (y,)
+    plan = pb.build()
+    best, ref = {}, None
+    for _ in range(reps):
+        for form in (0, 1, 2, 3):
+            lib.check(lib.mtx_norm_form(form), "mtx_norm_form")
+            for t in outs:
+                t.zero_()
+            t_ms = _time(plan, iters)
+            got = [t.clone() for t in outs]
+            if ref is None:
+                ref = got
+            same = all(torch.equal(a, b) for a, b in zip(got, ref))
+            best[form] = min(best.get(form, 1e9), t_ms)
+            byts = rows * c * (2 + (1 if q8 else 2))
+            print(f"norm {rows}x{c} {'-> MX fp8' if q8 else 'bf16'} form {form}: {t_ms * 1e3:.1f} us  {byts / t_ms / 1e6:.0f} GB/s  bytes equal to form 0: {same}", flush=True)
+    lib.check(lib.mtx_norm_form(-1), "mtx_norm_form")
+    print("norm best of", reps, {f: round(v * 1e3, 1) for f, v in best.items()}, flush=True)
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     while args:
@@ -142,6 +178,8 @@ if __name__ == "__main__":
             attn_q8(int(args[1]), fused=args[0] != "attnqs", schedule=67 if args[0] == "attnq67" else 0); args = args[2:]
         elif args[0] in ("glu", "glus"):              # glu M hid K col0
             gemm8_glu(int(args[1]), int(args[2]), int(args[3]), int(args[4]), fused=args[0] == "glu"); args = args[5:]
+        elif args[0] in ("norm", "normq"):              # norm ROWS C: every norm kernel form in turn
+            norm(int(args[1]), int(args[2]), q8=args[0] == "normq"); args = args[3:]
         elif args[0] == "quant":
             quant(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "conv":
