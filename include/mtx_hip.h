@@ -130,6 +130,7 @@ typedef struct mtx_gemm_args {
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
 #define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the K-slice tail */
 #define MTX_GEMM_F8_WIDE 4         /* fp8 whole-tile kernel: one segment per k-step (8 MFMAs, half the barriers) — a measurement switch, see csrc/gemm.hip */
+#define MTX_GEMM_SERIAL_EPILOGUE 8 /* 256-tile kernels: the epilogue of rounds 1-5a (bias / gate / residual requested one at a time) — identical bytes, a measurement switch */
 #define MTX_GEMM_SLICES(n) ((n) << 8) /* tuning: cut the left-over tiles into exactly n K slices (2..255) instead of the launcher's choice */
 #define MTX_GEMM_WORKSPACE_BYTES (2 * 320 * 256 * 256 * 4)
 

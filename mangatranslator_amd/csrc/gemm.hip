@@ -24,6 +24,7 @@ struct GemmParams {
   long m, n, k, lda, ldw, ldc, ldres, ldgate, a_bs, w_bs, c_bs, res_bs;
   int gate_rows_per, act; float act_param, alpha;
   int out_f32;
+  int serial_epilogue;      // MTX_GEMM_SERIAL_EPILOGUE: the 256-tile kernels' epilogue with its memory requests one at a time (A/B yardstick)
   unsigned tiles_m, tiles_n;
   // whole tiles [0, n_full) go to the tile kernel, tiles [n_full, tiles) to the K-slice tail; fp32 partials in `part`
   unsigned n_full; float* part;
@@ -214,10 +215,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_STAGE = (G2_BM + G2_BN) * 128;      // 64 KB
 
-// Epilogue of the 256-tile kernels, run by the 8 MFMA waves (wv = 0..7).
+// Epilogue of the 256-tile kernels as it was through round 5's first half (MTX_GEMM_SERIAL_EPILOGUE: the yardstick of the batched form below).
 // acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
 template <typename T, int ACT>
-__device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], unsigned char* smem, T* Cp,
+__device__ __forceinline__ void gemm256_epilogue_serial(const GemmParams& p, f32x16 (&acc)[4][2], unsigned char* smem, T* Cp,
                                                  long m0, long n0, long bz, int wv, int lane) {
   typedef typename Traits<T>::v4 v4;
   const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 2, wn = wv & 3;
@@ -269,6 +270,111 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&a
       raw = pack8<T>(f);
     }
     *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = raw;
+  }
+}
+
+// Epilogue of the 256-tile kernels, run by the 8 MFMA waves (wv = 0..7).
+// acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
+// Round 5 (late): memory requests in batches.  Read as ISA, the form above asked for its bias values one dword at a time under per-element
+// exec branches, eight groups each behind an `s_waitcnt vmcnt(0)`, and for the gate and residual chunks of a row inside that row's
+// iteration — gate, wait, residual, wait, store, sixteen times per wave: ~40 dependent memory round trips per tile on a CU that has
+// nothing else resident (one 128 KB workgroup).  Here the bias leaves as eight 16-byte loads in one batch, and — the accumulators being
+// dead once staged — all sixteen gate and residual chunks of a lane are requested (clamped addresses, no branches) before the first is
+// used.  Same arithmetic, same rounding order (the gate product and the residual sum stay two roundings): identical bytes.
+template <typename T, int ACT>
+__device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], unsigned char* smem, T* Cp,
+                                                 long m0, long n0, long bz, int wv, int lane) {
+  if (p.serial_epilogue) { gemm256_epilogue_serial<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane); return; }
+  typedef typename Traits<T>::v4 v4;
+  const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 2, wn = wv & 3;
+  unsigned char* outs = smem + wv * 16384;          // [128 rows m][8 chunks of 16 B], chunk ^= (row & 7)
+  f32x4 bv[2][4];
+  if (p.bias != nullptr && ((size_t)p.bias & 15) == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long n = n0 + wn * 64 + j * 32 + g * 8 + hi * 4;          // N % 8 == 0: four valid values or none
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.bias + (n < p.n ? n : 0));
+        bv[j][g] = n < p.n ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long n = n0 + wn * 64 + j * 32 + g * 8 + hi * 4 + r;
+          bv[j][g][r] = (p.bias != nullptr && n < p.n) ? p.bias[n] : 0.f;
+        }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = j * 32 + g * 8 + hi * 4;         // local n of this lane's 4 values
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + l31;
+        v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act_t<ACT>(acc[i][j][g * 4 + r] * p.alpha + bv[j][g][r], p.act, p.act_param));
+        *reinterpret_cast<v4*>(outs + row * 128 + ((((nl >> 3)) ^ (row & 7)) << 4) + ((nl & 4) << 1)) = o;
+      }
+    }
+  const T* G = reinterpret_cast<const T*>(p.gate);
+  const T* R = reinterpret_cast<const T*>(p.res);
+  const int oc = lane & 7;
+  const long nn = n0 + wn * 64 + oc * 8;
+  const bool n_ok = nn < p.n;
+  const long nc = n_ok ? nn : 0;
+  u32x4 gq[16], rq[16];
+  if (G != nullptr) {
+    // gate row = m / rows_per: one division per wave when a 128-row span crosses at most one boundary (FLUX: rows_per = a stream's length)
+    const unsigned per = (unsigned)p.gate_rows_per, mb = (unsigned)(m0 + wm * 128);
+    const unsigned q0 = mb / per, next = (q0 + 1) * per;
+    const bool one_step = per >= 128;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const long m = m0 + wm * 128 + it * 8 + (lane >> 3);
+      const unsigned mc = (unsigned)(m < p.m ? m : p.m - 1);
+      const unsigned gr = one_step ? q0 + (mc >= next ? 1u : 0u) : mc / per;
+      gq[it] = *reinterpret_cast<const u32x4*>(G + (size_t)gr * p.ldgate + nc);
+    }
+  }
+  if (R != nullptr) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const long m = m0 + wm * 128 + it * 8 + (lane >> 3);
+      const long mc = m < p.m ? m : p.m - 1;
+      rq[it] = *reinterpret_cast<const u32x4*>(R + (size_t)bz * p.res_bs + (size_t)mc * p.ldres + nc);
+    }
+  }
+  // a wave only re-reads its own region: no workgroup barrier needed, just its own LDS writes
+#ifdef MTX_EMU
+  emu::wave_sync();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const long m = m0 + wm * 128 + row;
+    u32x4 raw = *reinterpret_cast<const u32x4*>(outs + row * 128 + ((oc ^ (row & 7)) << 4));
+    if (G != nullptr || R != nullptr) {
+#pragma clang fp contract(off)
+      float f[8];
+      unpack8<T>(raw, f);
+      if (G != nullptr) { float g8[8]; unpack8<T>(gq[it], g8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * g8[e]; }
+      if (R != nullptr) { float r8[8]; unpack8<T>(rq[it], r8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] + r8[e]; }
+      raw = pack8<T>(f);
+    }
+    if (m < p.m && n_ok) *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + nn) = raw;
   }
 }
 
@@ -939,6 +1045,8 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.gate_rows_per = a->gate_rows_per > 0 ? a->gate_rows_per : 1;
   p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;
+  static const bool env_serial = [] { const char* e = getenv("MTX_GEMM_SERIAL_EPILOGUE"); return e && e[0] == '1'; }();      // whole-page A/Bs (tools/gpu_visit_r05_r.sh)
+  p.serial_epilogue = ((a->flags & MTX_GEMM_SERIAL_EPILOGUE) || env_serial) ? 1 : 0;
   p.n_full = 0; p.slices = 1; p.slice_len = 0;
   p.part = (a->workspace && a->workspace_bytes >= (int64_t)MTX_GEMM_WORKSPACE_BYTES) ? reinterpret_cast<float*>(a->workspace) : nullptr;
   p.tickets = p.part ? reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a->workspace) + MTX_GEMM_WORKSPACE_BYTES - G2_TICKET_BYTES) : nullptr;

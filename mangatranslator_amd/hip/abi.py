@@ -49,7 +49,7 @@ class GemmArgs(C.Structure):
                 ("glu_q", vp), ("glu_scale", vp), ("glu_ldq", i64), ("glu_lds", i64), ("glu_col0", i64)]
 
 
-GEMM_FORCE_TILE256, GEMM_NO_SPLIT, GEMM_F8_WIDE = 1, 2, 4
+GEMM_FORCE_TILE256, GEMM_NO_SPLIT, GEMM_F8_WIDE, GEMM_SERIAL_EPILOGUE = 1, 2, 4, 8
 GEMM_WORKSPACE_BYTES = 2 * 320 * 256 * 256 * 4
 
 

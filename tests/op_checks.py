@@ -148,6 +148,15 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
         plan.run()
         _sync(lib)
         assert torch.equal(out, first), "a second run of the same plan differs (stale scratch read, or an order-dependent sum)"
+    if not out_f32:
+        # the 256-tile kernels' epilogue with its bias / gate / residual requests in batches against the one-at-a-time form: identical bytes
+        pb2 = PlanBuilder(lib, dev, dtype)
+        out2 = pb2.gemm(at, wt, m, n, k, bias=pb2.const(b) if b is not None else None, act=act,
+                        res=pb2.const(res) if res is not None else None,
+                        gate=pb2.const(gate) if gate is not None else None, gate_rows_per=rows_per,
+                        alpha=alpha, batch=batch, a_bs=m * k, w_bs=n * k, c_bs=m * n, flags=flags | abi.GEMM_SERIAL_EPILOGUE)
+        _run(pb2)
+        assert torch.equal(out2.view(torch.int16), first.view(torch.int16)), "gemm: the batched and the serial epilogue differ"
     return err
 
 

@@ -104,6 +104,44 @@ def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0, act=0):
     print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}{f' ld+{pad}' if pad else ''}{tag}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
+def gemm_epi(M, N, K, kind, f8=False, reps=3, iters=20):
+    """The 256-tile kernels with the epilogue a FLUX linear really has — kind "b": bias; "g": bias + tanh-GELU; "r": bias + gate + residual
+    (attention / MLP output projections) — with the epilogue's memory requests in batches (default) against one at a time
+    (MTX_GEMM_SERIAL_EPILOGUE), alternating in one process; the outputs must be the same bytes."""
+    outs, best = {}, {}
+    plans = {}
+    for serial in (0, 1):
+        pb = PlanBuilder(lib, dev, abi.BF16)
+        g = torch.Generator(device=dev).manual_seed(5)
+        a = pb.buf((M, K), torch.bfloat16); a.normal_(generator=g)
+        w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5, generator=g)
+        bias = pb.buf((N,), torch.float32); bias.normal_(generator=g)
+        gate = res = None
+        if kind == "r":
+            gate = pb.buf((2, N), torch.bfloat16); gate.normal_(generator=g)
+            res = pb.buf((M, N), torch.bfloat16); res.normal_(generator=g)
+        fl = abi.GEMM_SERIAL_EPILOGUE if serial else 0
+        kw = dict(bias=bias, act=abi.ACT_GELU_TANH if kind == "g" else 0, res=res, gate=gate, gate_rows_per=(M + 1) // 2, flags=fl)
+        if f8:
+            q = PlanBuilder(lib, dev, abi.BF16)
+            aq, asc, la = q.quantize(a, M, K)
+            wq, wsc, lw = q.quantize(w, N, K)
+            q.build().run(); torch.cuda.synchronize()
+            pb.keep += [aq, asc, wq, wsc]
+            outs[serial] = pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0), **kw)
+        else:
+            outs[serial] = pb.gemm(a, w, M, N, K, **kw)
+        plans[serial] = pb.build()
+    for _ in range(reps):
+        for serial in (0, 1):
+            ms = _time(plans[serial], iters)
+            best[serial] = min(best.get(serial, 1e9), ms)
+    same = torch.equal(outs[0], outs[1])
+    what = {"b": "bias", "g": "bias + tanh-GELU", "r": "bias + gate + residual"}[kind]
+    print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K} [{what}]: batched epilogue {best[0]:.3f} ms ({2 * M * N * K / best[0] / 1e9:.0f} TFLOP/s), "
+          f"serial {best[1]:.3f} ms ({2 * M * N * K / best[1] / 1e9:.0f})  {100 * (best[1] / best[0] - 1):+.1f} %  same bytes: {same}", flush=True)
+
+
 def quant(rows, K, iters=20):
     pb = PlanBuilder(lib, dev, abi.BF16)
     a = pb.buf((rows, K), torch.bfloat16); a.normal_()
@@ -184,6 +222,8 @@ if __name__ == "__main__":
             quant(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "conv":
             conv(int(args[1]), int(args[2])); args = args[3:]
+        elif args[0] in ("gemmeb", "gemmeg", "gemmer", "gemm8eb", "gemm8er"):      # gemmeK M N K: epilogue A/B (K = b / g / r), fp8 with gemm8eK
+            gemm_epi(int(args[1]), int(args[2]), int(args[3]), args[0][-1], f8=args[0].startswith("gemm8")); args = args[4:]
         elif args[0] == "gemmg":                       # bf16 GEMM with the bias + tanh-GELU epilogue (FLUX ff1 / proj_mlp)
             gemm(int(args[1]), int(args[2]), int(args[3]), act=abi.ACT_GELU_TANH); args = args[4:]
         elif args[0] == "gemmp":
