@@ -332,7 +332,8 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&a
   u32x4 gq[16], rq[16];
   if (G != nullptr) {
     // gate row = m / rows_per: one division per wave when a 128-row span crosses at most one boundary (FLUX: rows_per = a stream's length)
-    const unsigned per = (unsigned)p.gate_rows_per, mb = (unsigned)(m0 + wm * 128);
+    // (the span's first row clamped like the rows themselves: a wave whose whole span lies beyond M must not compute a gate row past the last one)
+    const unsigned per = (unsigned)p.gate_rows_per, mb = (unsigned)(m0 + wm * 128 < p.m ? m0 + wm * 128 : p.m - 1);
     const unsigned q0 = mb / per, next = (q0 + 1) * per;
     const bool one_step = per >= 128;
 #pragma unroll
