@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256, MINW) void norm_packed_kernel(mtx_norm_args p)
   }
   ss = wave_sum(ss);
   const float rstd = 1.0f / sqrtf(ss / (float)p.c + p.eps);
+  const bool affine_vec = (((size_t)p.gamma | (size_t)p.beta) & 15) == 0;      // fp32 vectors, chunk offsets are multiples of 32 bytes
 #pragma unroll
   for (int i = 0; i < NCH; ++i) NORM_PIN(raw[i]);
 #pragma unroll
@@ -181,12 +182,33 @@ __global__ __launch_bounds__(256, MINW) void norm_packed_kernel(mtx_norm_args p)
     if (FULL || ch < nch) {
       float f[8], o[8];
       unpack8<T>(raw[i], f);
+      // affine parameters of the chunk as one batch of 16-byte loads (element by element each load sat behind its own full wait: sixteen
+      // dependent L2 round trips per chunk in the ISA); same products and sums, so the bytes do not change
+      float ga[8], be[8];
+      if (!FULL) {
+        if (p.gamma != nullptr && affine_vec) {
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + ch * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ga[e] = g0[e]; ga[4 + e] = g1[e]; }
+        } else if (p.gamma != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ga[e] = p.gamma[ch * 8 + e];
+        }
+        if (p.beta != nullptr && affine_vec) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + ch * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { be[e] = b0[e]; be[4 + e] = b1[e]; }
+        } else if (p.beta != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) be[e] = p.beta[ch * 8 + e];
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = (f[e] - mean) * rstd;
         if (!FULL) {
-          if (p.gamma) t *= p.gamma[ch * 8 + e];
-          if (p.beta) t += p.beta[ch * 8 + e];
+          if (p.gamma) t *= ga[e];
+          if (p.beta) t += be[e];
         }
         o[e] = t;
       }
