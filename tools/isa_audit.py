@@ -72,7 +72,7 @@ def audit(asm: Path):
 def demangle(name: str) -> str:
     import shutil
     tool = shutil.which("c++filt")
-    if not tool:
+    if not tool or "DF16" in name:          # binutils' demangler misreads the _Float16 / __bf16 template arguments: keep those mangled
         return name
     return subprocess.run([tool, name], capture_output=True, text=True).stdout.strip() or name
 
