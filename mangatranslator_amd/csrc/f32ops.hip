@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mtx_gemm_args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   // the next K step's operands are requested into registers before this step's MFMAs and written to LDS after them: with two workgroups per
-  // CU (SAM's 32 768 x 128 projections) the global-load latency was the whole step (round 5, second pass: 50 -> see profiles)
+  // CU (SAM's 32 768 x 128 projections) the global-load latency was the whole step (round 5: four such launches 0.20 -> 0.16 ms, profiles/r05_visit_p_*.log)
   const long ar = m0 + (tid >> 1), wc = n0 + (tid >> 2);
   const int kq = (tid & 1) * 8, kw = (tid & 3) * 4;
   const bool row_ok = ar < p.m, col_ok = wc < p.n;
