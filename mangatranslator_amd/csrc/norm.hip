@@ -107,9 +107,9 @@ __global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
 
 // Round 5: the same row normalisation with the row kept PACKED between the passes (NCH x 4 registers instead of NCH x 8 fp32 values) and
 // unpacked again where each pass needs it — a 16-bit -> fp32 unpack is one shift / convert per element, and the kernel has nothing but
-// latency to hide: a 3072-wide row drops from 105 to <= 64 VGPRs, 8 waves per SIMD instead of 4, i.e. the whole 8 812-row problem of a FLUX
-// block resident at once and twice the bytes in flight.  The additions run in the same order as in `norm_kernel`, so the bytes are identical
-// (tests compare both).  NORM_PIN keeps the optimiser from carrying the unpacked values across the passes (which would undo the point).
+// latency to hide: a 3072-wide row takes 74 VGPRs instead of 105 (6 waves per SIMD instead of 4); with the modulation rows requested up
+// front (PRE) 98 — 4 waves again, but every memory request of a row is in flight at once, which is what pays (19.0 against 21.3 us).  The
+// additions and products run in the same order as in `norm_kernel` and nothing is fused, so the bytes are identical (tests compare them).  NORM_PIN keeps the optimiser from carrying the unpacked values across the passes (which would undo the point).
 #ifdef MTX_EMU
 #define NORM_PIN(x) do { } while (0)
 #else
