@@ -36,6 +36,7 @@ struct GemmParams {
   int bk;           // K elements per LDS stage row: 64 (16-bit operands) or 128 (fp8); a row is 128 bytes either way
   // SwiGLU + MX-fp8 epilogue of the fp8 kernel (mtx_gemm_args.glu_*): columns >= glu_col0 are [32 a | 32 b] spans
   unsigned char* glu_q; unsigned* glu_scale; long glu_ldq, glu_lds, glu_col0;
+  unsigned strip_w;         // 256-tile kernels: tile columns per strip of the workgroup -> tile map (gemm256_tile_origin); >= tiles_n: one strip
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
@@ -379,14 +380,23 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&a
   }
 }
 
-// tile `lin` of the grouped order -> its origin: groups of 4 tile rows x all tile columns, column-major inside a group
+// tile `lin` of the grouped order -> its origin.  The tile plane is cut into STRIPS of `strip_w` tile columns; inside a strip the order
+// is groups of 4 tile rows x the strip's columns, column-major inside a group (the 32 workgroups resident on an XCD work on ~8 columns
+// x 4 rows that walk K in step and share 12 panels through that XCD's L2).  The XCD-contiguous workgroup order (xcd_remap) hands each
+// XCD a run of tiles/8 consecutive tiles, i.e. a block of about (tiles/8 / strip_w) rows x strip_w columns: the narrower the strip, the
+// squarer the block and the fewer A / W panels an XCD pulls over the fabric into its own L2 (one strip = rounds 1-5: 4.4 rows x all
+// columns).  strip_w is chosen per launch (gemm256_choose_strip).
 __device__ __forceinline__ void gemm256_tile_origin(const GemmParams& p, unsigned lin, long& m0, long& n0) {
   const unsigned GM = 4;
-  const unsigned per_group = GM * p.tiles_n;
-  const unsigned group = lin / per_group, first_m = group * GM;
+  const unsigned per_strip = p.tiles_m * p.strip_w;
+  const unsigned strip = lin / per_strip, col0 = strip * p.strip_w;
+  const unsigned sw = (p.tiles_n - col0) < p.strip_w ? (p.tiles_n - col0) : p.strip_w;      // the last strip may be narrower
+  const unsigned rest = lin - strip * per_strip;
+  const unsigned per_group = GM * sw;
+  const unsigned group = rest / per_group, first_m = group * GM;
   const unsigned gsz = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
-  m0 = (long)(first_m + (lin % per_group) % gsz) * G2_BM;
-  n0 = (long)((lin % per_group) / gsz) * G2_BN;
+  m0 = (long)(first_m + (rest % per_group) % gsz) * G2_BM;
+  n0 = (long)(col0 + (rest % per_group) / gsz) * G2_BN;
 }
 
 #ifdef MTX_EMU
@@ -992,9 +1002,28 @@ static void launch_gemm256_slices(const GemmParams& p, unsigned pieces, void* st
 // measured on MI355X (tools/bench_kernels.py, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the 3/3/2/0
 // piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
 // specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
+// Strip width of the tile map: the XCD blocks should be as square as the problem allows.  With `xc` strips an XCD's run of tiles/8 tiles
+// covers about tiles_m * xc / 8 rows (rounded up to whole 4-row groups, + one group where the run starts mid-group) of ceil(tiles_n / xc)
+// columns; its fabric traffic is (rows + columns) panels of 256 x K.  MTX_GEMM_STRIPS = 1 / 2 / 4 / 8 forces a count (A/B, tools/bench_kernels.py).
+static unsigned gemm256_choose_strip(unsigned tiles_m, unsigned tiles_n) {
+  const char* e = getenv("MTX_GEMM_STRIPS");            // read per launch: same-process A/Bs switch it between timings
+  const int want = e ? atoi(e) : 0;
+  unsigned best_w = tiles_n; double best = 1e30;
+  for (unsigned xc = 1; xc <= 8; xc *= 2) {
+    const unsigned w = (tiles_n + xc - 1) / xc;
+    if (want > 0 && (unsigned)want != xc) continue;
+    if (w < 4 && xc > 1 && want <= 0) break;                          // fewer than 4 columns per strip: the resident 4 x 8 patch no longer fits a strip
+    const double rows = (double)tiles_m * xc / 8.0;
+    const double cost = (rows < 4 ? 4 : rows) + 4.0 + (double)w;
+    if (cost < best) { best = cost; best_w = w; }
+  }
+  return best_w < 1 ? 1 : best_w;
+}
+
 template <typename T, bool F8>
 static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit, unsigned forced_slices) {
   GemmParams p = p0;
+  p.strip_w = gemm256_choose_strip(p.tiles_m, p.tiles_n);
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
   const long nk = p.k / p.bk;
   const bool can = p.part != nullptr && cus <= 320 && grid.y == 1 && !nosplit;
@@ -1054,6 +1083,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.a_scale = reinterpret_cast<const unsigned*>(a->a_scale); p.w_scale = reinterpret_cast<const unsigned*>(a->w_scale);
   p.lds_a = a->lds_a; p.lds_w = a->lds_w;
   p.glu_q = nullptr; p.glu_scale = nullptr; p.glu_ldq = p.glu_lds = p.glu_col0 = 0;
+  p.strip_w = 0x7fffffffu;
   p.bk = f8 ? 128 : G2_BK;
   p.tiles_m = (unsigned)((a->m + GBM - 1) / GBM);
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
@@ -1081,6 +1111,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
       }
       p.glu_q = reinterpret_cast<unsigned char*>(a->glu_q); p.glu_scale = reinterpret_cast<unsigned*>(a->glu_scale);
       p.glu_ldq = a->glu_ldq; p.glu_lds = a->glu_lds; p.glu_col0 = a->glu_col0;
+      p.strip_w = gemm256_choose_strip(p.tiles_m, p.tiles_n);
       if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm256_f8_glu_kernel<__bf16>), g2, dim3(512), 0, stream, p);
       else MTX_LAUNCH((gemm256_f8_glu_kernel<_Float16>), g2, dim3(512), 0, stream, p);
       return MTX_OK;

@@ -138,6 +138,16 @@ def test_attention_fp8_output(emu_lib):
     oc.check_attention_q8(emu_lib, abi.F16, heads=1, sq=1024, sk=256, prescaled=False, col_off=128, extra_cols=128, seed=1)
 
 
+def test_gemm_256_tile_map_strips(emu_lib, monkeypatch):
+    """round 6: the workgroup -> tile map cut into 1 / 2 / 4 / 8 column strips (gemm256_tile_origin) is a bijection on ragged tile planes —
+    3 x 5 and 5 x 3 tiles of 256 x 256, whole tiles + K-slice tail (3 simulated CUs) — for every forced strip count and the launcher's choice"""
+    f = abi.GEMM_FORCE_TILE256
+    for st in (0, 1, 2, 4, 8):
+        monkeypatch.setenv("MTX_GEMM_STRIPS", str(st))
+        oc.check_gemm(emu_lib, abi.BF16, m=700, n=1200, k=128, with_res=True, flags=f)
+        oc.check_gemm(emu_lib, abi.F16, m=1100, n=600, k=64, act=abi.ACT_SILU, flags=f, seed=st)
+
+
 def test_gemm_256_tile_kernel(emu_lib):
     """the 256 x 256 LDS-DMA kernel (normally used from 24 tiles up) on ragged small problems: ping-pong loop with descriptor-based
     LDS-DMA (range-checked zero fill), pieces spread 3/3/2/0"""

@@ -142,6 +142,40 @@ def gemm_epi(M, N, K, kind, f8=False, reps=3, iters=20):
           f"serial {best[1]:.3f} ms ({2 * M * N * K / best[1] / 1e9:.0f})  {100 * (best[1] / best[0] - 1):+.1f} %  same bytes: {same}", flush=True)
 
 
+def gemm_strips(M, N, K, f8=False, reps=3, iters=20, kind="b"):
+    """Round 6: the workgroup -> tile map of the 256-tile kernels with 1 (rounds 1-5), 2, 4, 8 column strips and the launcher's own choice (0),
+    alternating in one process (the launcher reads MTX_GEMM_STRIPS per launch); the outputs must be the same bytes."""
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = pb.buf((M, K), torch.bfloat16); a.normal_(generator=g)
+    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5, generator=g)
+    bias = pb.buf((N,), torch.float32); bias.normal_(generator=g)
+    kw = dict(bias=bias, act=abi.ACT_GELU_TANH if kind == "g" else 0)
+    if f8:
+        q = PlanBuilder(lib, dev, abi.BF16)
+        aq, asc, la = q.quantize(a, M, K)
+        wq, wsc, lw = q.quantize(w, N, K)
+        q.build().run(); torch.cuda.synchronize()
+        pb.keep += [aq, asc, wq, wsc]
+        out = pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0), **kw)
+    else:
+        out = pb.gemm(a, w, M, N, K, **kw)
+    plan = pb.build()
+    best, ref, same = {}, None, True
+    for _ in range(reps):
+        for st in (1, 2, 4, 8, 0):
+            os.environ["MTX_GEMM_STRIPS"] = str(st)
+            out.zero_()
+            ms = _time(plan, iters)
+            best[st] = min(best.get(st, 1e9), ms)
+            if ref is None:
+                ref = out.clone()
+            same = same and torch.equal(out, ref)
+    os.environ.pop("MTX_GEMM_STRIPS", None)
+    print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K} strips -> ms: " + "  ".join(f"{'auto' if st == 0 else st}: {best[st]:.4f} ({2 * M * N * K / best[st] / 1e9:.0f} TF)" for st in (1, 2, 4, 8, 0))
+          + f"  same bytes: {same}", flush=True)
+
+
 def quant(rows, K, iters=20):
     pb = PlanBuilder(lib, dev, abi.BF16)
     a = pb.buf((rows, K), torch.bfloat16); a.normal_()
@@ -224,6 +258,8 @@ if __name__ == "__main__":
             conv(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] in ("gemmeb", "gemmeg", "gemmer", "gemm8eb", "gemm8er"):      # gemmeK M N K: epilogue A/B (K = b / g / r), fp8 with gemm8eK
             gemm_epi(int(args[1]), int(args[2]), int(args[3]), args[0][-1], f8=args[0].startswith("gemm8")); args = args[4:]
+        elif args[0] in ("gemmst", "gemm8st", "gemmgst"):     # strip-count A/B of the 256-tile kernels' tile map
+            gemm_strips(int(args[1]), int(args[2]), int(args[3]), f8=args[0] == "gemm8st", kind="g" if args[0] == "gemmgst" else "b"); args = args[4:]
         elif args[0] == "gemmg":                       # bf16 GEMM with the bias + tanh-GELU epilogue (FLUX ff1 / proj_mlp)
             gemm(int(args[1]), int(args[2]), int(args[3]), act=abi.ACT_GELU_TANH); args = args[4:]
         elif args[0] == "gemmp":

@@ -8,11 +8,13 @@
 #include <vector>
 using namespace mtx;
 
-template <int ABL> static float run(ConvC64Params p, unsigned grid, int iters) {
+// VAR 0: ReLU (the probe of rounds 2-5), 1: ReLU + fused channel sums (RCAB conv1), 2: out_scale + residual (RCAB conv2)
+template <int ABL, int VAR = 0> static float run(ConvC64Params p, unsigned grid, int iters) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv3x3_c64_kernel<_Float16, ABL, MTX_ACT_RELU, false>), dim3(grid), dim3(512), 0, 0, p);
+  constexpr int ACT = VAR == 2 ? MTX_ACT_NONE : MTX_ACT_RELU;
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv3x3_c64_kernel<_Float16, ABL, ACT, VAR == 1, VAR == 2>), dim3(grid), dim3(512), 0, 0, p);
   hipEventRecord(a, 0);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv3x3_c64_kernel<_Float16, ABL, MTX_ACT_RELU, false>), dim3(grid), dim3(512), 0, 0, p);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv3x3_c64_kernel<_Float16, ABL, ACT, VAR == 1, VAR == 2>), dim3(grid), dim3(512), 0, 0, p);
   hipEventRecord(b, 0); hipEventSynchronize(b);
   float ms = 0; hipEventElapsedTime(&ms, a, b);
   return ms / iters * 1e3f;
@@ -42,7 +44,25 @@ int main(int argc, char** argv) {
   t = run<1>(p, grid, 20); printf("ABL 1 (no MFMA)               %7.1f us\n", t);
   t = run<3>(p, grid, 20); printf("ABL 3 (no halo DMA)           %7.1f us\n", t);
   t = run<4>(p, grid, 20); printf("ABL 4 (no epilogue / stores)  %7.1f us\n", t);
-  t = run<7>(p, grid, 1);
+  // the RCAB pair's own variants (round 6): conv1 = ReLU + channel sums, conv2 = out_scale * conv + residual
+  void *dr, *dsum; float* dsc;
+  hipMalloc(&dr, px * 128); hipMemcpy(dr, hx.data(), px * 128, hipMemcpyHostToDevice);
+  hipMalloc(&dsum, (size_t)grid * 8 * 64 * 4); hipMalloc((void**)&dsc, 256);
+  { std::vector<float> sc(64, 0.5f); hipMemcpy(dsc, sc.data(), 256, hipMemcpyHostToDevice); }
+  ConvC64Params p1 = p; p1.chan_sum = (float*)dsum;
+  ConvC64Params p2 = p; p2.act = MTX_ACT_NONE; p2.res = (const unsigned char*)dr; p2.ldres = 64; p2.res_scale = 1.f; p2.res_bytes = (unsigned)(px * 128); p2.out_scale = dsc;
+  t = run<0, 1>(p1, grid, 20); printf("conv1 form (ReLU + sums)      %7.1f us  %6.0f GB/s\n", t, bytes / t / 1e3);
+  t = run<4, 1>(p1, grid, 20); printf("   no epilogue / stores       %7.1f us\n", t);
+  t = run<1, 1>(p1, grid, 20); printf("   no MFMA                    %7.1f us\n", t);
+  t = run<0, 2>(p2, grid, 20); printf("conv2 form (scale + residual) %7.1f us  %6.0f GB/s\n", t, (bytes + px * 128.0) / t / 1e3);
+  t = run<4, 2>(p2, grid, 20); printf("   no epilogue / stores       %7.1f us\n", t);
+  t = run<1, 2>(p2, grid, 20); printf("   no MFMA                    %7.1f us\n", t);
+  t = run<0>(p, grid, 20); printf("ABL 0 again                   %7.1f us\n", t);
+  for (int var = 0; var < 3; ++var) {
+  hipMemset(dst, 0, 2 * 2 * 64 * 8 * 8);
+  ConvC64Params ps = var == 2 ? p2 : p; ps.chan_sum = (float*)dst;       // the stamps go where the sums would (ABL 7 never flushes sums into it: SUM rows are per wave, the stamp area is separate for var 1 below)
+  if (var == 0) t = run<7, 0>(ps, grid, 1); else if (var == 2) t = run<7, 2>(ps, grid, 1); else continue;
+  printf("---- stamps, variant %d\n", var);
   std::vector<unsigned long long> st(2 * 2 * 64 * 8);
   hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost);
   for (int wg = 0; wg < 2; ++wg)
@@ -55,5 +75,6 @@ int main(int argc, char** argv) {
         printf("  slot %2d  %s  mfma %6lld | dma %6lld epi %6lld wait %6lld | bar %6lld out %6lld\n", s, ((s & 1) == g) ? "MFMA" : "mem ", d(1), d(2), d(3), d(4), d(5), d(6));
       }
     }
+  }
   return 0;
 }
