@@ -701,7 +701,7 @@ def main():
         "metric": "pages/sec (detect+segment+inpaint+upscale) 1024x1536" if headline else f"pages/sec ({stage_names}) {W_}x{H_}",
         "value": pages_per_s, "unit": "pages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": ("fp8 (e4m3, MX block scales) block linears + bf16" if klein and flux is not None and flux.transformer.fp8 else "bf16"),
+        "vs_baseline": None, "dtype": dtype_string(stages, klein and flux is not None and flux.transformer.fp8),
         "data": "synthetic",
         "config": {"workload": f"{W_}x{H_} synthetic pages, BASELINE.json configs[{args.config - 1}] per GPU ({stage_names}): one page per step per GPU, "
                                f"{args.boxes} bubbles" + (f", {args.regions} FLUX region(s) x {args.inpaint_steps} steps" if flux is not None else "")
@@ -789,30 +789,45 @@ def main():
             key, plan = next(iter(flux.transformer._plans.items()))
             t_txt, h2, w2 = key[0], key[1], key[2]
             fl = flux.transformer.flops_per_step(*key[:3]) if not klein else flux.transformer.flops_per_step(*key)
-            plan.time(6, graph=True)              # ~1 s of sustained load first: the chip boosts for the first few steps after an idle phase and
-            step_ms = plan.time(4, graph=True)    # then settles (rocprof: 0.71 ms vs 0.83 ms per attention launch); the steady state is what a page
+            # With the first-block cache on, a step is TWO graphs — the head (embedders, double block 0, the probe) and, when the step is
+            # computed, the body (the other 56 blocks): `plan` is the head and carries the body.  A computed step is what is timed and priced here
+            # (dividing the whole step's flops by the head's time read 23x the chip's peak).
+            parts_ = [plan] + ([plan.body] if hasattr(plan, "body") else [])
+            for p_ in parts_:
+                p_.time(6 if len(parts_) == 1 else 3, graph=True)   # ~1 s of sustained load first: the chip boosts for the first few steps after an idle phase and
+            part_ms = [p_.time(4, graph=True) for p_ in parts_]    # then settles (rocprof: 0.71 ms vs 0.83 ms per attention launch); the steady state is what a page
+            step_ms = sum(part_ms)
             # sees.  Timed as the hipGraph replay the pipeline runs (with the text stream on its side lane), not as eager launches
-            cfg["dit_step_ms_one_lane_eager"] = plan.time(2)
+            cfg["dit_step_ms_one_lane_eager"] = sum(p_.time(2) for p_ in parts_)
             rh2, rw2 = (key[3], key[4]) if klein else (h2, w2)
             cfg["inpaint"] = {"resolution": [w2 * 16, h2 * 16], "tokens": fl["tokens"], "dit_step_ms": step_ms,
                               "dit_tflops": (fl["gemm"] + fl["attention"]) / step_ms / 1e9,
                               "vae_encode_ms": flux.vae.encoder_plan(rh2 * 16, rw2 * 16).time(2), "vae_decode_ms": flux.vae.decoder_plan(h2 * 2, w2 * 2).time(2)}
+            if len(parts_) > 1:
+                cfg["inpaint"]["dit_step_parts_ms"] = {"head (embedders + block 0 + probe)": part_ms[0], "body (56 blocks + projection)": part_ms[1]}
             # ---- in-context time of every MFMA-bound launch of one denoising step, grouped by kernel and problem shape -----------------------
             # (hipGraph replay of the whole step; per group: device wall-clock stamps around its ops, or graph with minus graph without them)
             import ctypes as C_
             from mangatranslator_amd.hip import abi as abi_
             groups = {}
-            for i_, lab in enumerate(plan.labels):
-                op_ = plan.ops[i_] if hasattr(plan, "ops") else None
-                if lab.endswith(".attn"):
-                    groups.setdefault(("attention", fl["tokens"], fl["tokens"], flux.transformer.cfg["d"]), []).append(i_)
-                elif op_ is not None and op_.kind == abi_.OP_GEMM and lab.split(".")[0][:3] in ("sgl", "dbl"):
-                    g_ = op_.u.gemm
-                    groups.setdefault(("gemm_fp8" if g_.in_dtype == abi_.F8 else "gemm_bf16", int(g_.m), int(g_.n), int(g_.k)), []).append(i_)
+            for pi_, p_ in enumerate(parts_):
+                for i_, lab in enumerate(p_.labels):
+                    op_ = p_.ops[i_] if hasattr(p_, "ops") else None
+                    if lab.endswith(".attn"):
+                        groups.setdefault(("attention", fl["tokens"], fl["tokens"], flux.transformer.cfg["d"]), {}).setdefault(pi_, []).append(i_)
+                    elif op_ is not None and op_.kind == abi_.OP_GEMM and lab.split(".")[0][:3] in ("sgl", "dbl"):
+                        g_ = op_.u.gemm
+                        groups.setdefault(("gemm_fp8" if g_.in_dtype == abi_.F8 else "gemm_bf16", int(g_.m), int(g_.n), int(g_.k)), {}).setdefault(pi_, []).append(i_)
             rows, tot = [], {}
-            for (kind_, m_, n_, k_), idx_ in sorted(groups.items(), key=lambda kv: -len(kv[1])):
+            for (kind_, m_, n_, k_), by_part in sorted(groups.items(), key=lambda kv: -sum(len(v_) for v_ in kv[1].values())):
                 flops_ = (4.0 * m_ * n_ * k_) if kind_ == "attention" else (2.0 * m_ * n_ * k_)        # attention: M = N = T, K = d_model: 4 T^2 D
-                ms_, how_, info_ = in_context_ms(plan, idx_, 3, args.time_ops, replay_ms=step_ms)
+                ms_, how_, info_, n_l = 0.0, set(), {}, 0
+                for pi_, idx_ in by_part.items():
+                    m1, h1, i1 = in_context_ms(parts_[pi_], idx_, 3, args.time_ops, replay_ms=part_ms[pi_])
+                    ms_ += m1; how_.add(h1); n_l += len(idx_)
+                    info_ = i1 if len(by_part) == 1 else {**info_, f"part{pi_}": i1}
+                how_ = "+".join(sorted(how_))
+                idx_ = range(n_l)
                 peak_ = FP8_PEAK_TFLOPS if kind_ == "gemm_fp8" else MFMA_PEAK_TFLOPS
                 rows.append({"kernel": kind_, "m": m_, "n": n_, "k": k_, "launches_per_step": len(idx_), "mean_ms": ms_ / len(idx_), "timing": how_,
                              "timing_detail": info_, "tflops": flops_ * len(idx_) / ms_ / 1e9, "frac_of_peak": flops_ * len(idx_) / ms_ / 1e9 / peak_})
@@ -986,6 +1001,23 @@ def measure_traffic(kernel_desc: str):
     detail.update(launches=launches, read_bytes_per_launch=round(rd), write_bytes_per_launch=round(wr),
                   note="fabric-side bytes (Infinity-Cache hits counted), mean over every launch of the group in one page")
     return rd + wr, detail
+
+
+def dtype_string(stages, fp8_linears):
+    """The arithmetic the timed stages compute in, by stage — the storage types narrower than the reference's fp32 are named in the top-level
+    field, not only in `config.dtypes` (VERDICT r05 weak #4): the detectors and the RCAN upscaler store f16 where the reference runs fp32."""
+    parts = []
+    if "inpaint" in stages:
+        parts.append("fp8 (e4m3, MX block scales) block linears + bf16 DiT / VAE" if fp8_linears else "bf16 DiT / VAE")
+    if "detect" in stages:
+        parts.append("f16 detectors")
+    if "segment" in stages:
+        parts.append("bf16 / f16 SAM trunk")
+    if "upscale" in stages:
+        parts.append("f16 upscaler")
+    if "clean" in stages:
+        parts.append("u8 cleaning")
+    return ", ".join(parts) + "; fp32 accumulation throughout"
 
 
 def in_context_ms(plan, idx, iters, mode, replay_ms=None):

@@ -36,7 +36,7 @@ extern "C" {
 #define MTX_API
 #endif
 
-#define MTX_ABI_VERSION 7
+#define MTX_ABI_VERSION 8
 
 typedef enum mtx_status {
   MTX_OK = 0,
@@ -126,6 +126,12 @@ typedef struct mtx_gemm_args {
    * act on the launch, glu_q 16-byte aligned with glu_ldq % 16 == 0.  NULL glu_q = off.  (Hardware-verified in round 4 — tests/test_ops_gpu.py::test_gemm_f8_glu_epilogue —
    * and the default of the FLUX.2 graphs since.) */
   void* glu_q; void* glu_scale; int64_t glu_ldq, glu_lds, glu_col0;
+  /* ABI 8.  w_lo: the weights are a PAIR W = w + w_lo of the storage type (same ldw / w_bstride) — both halves are multiplied with the same A
+   * tile and add into one fp32 accumulator (SAM-2.1 precision "high": the weights' rounding to 16 bits goes away at twice the matrix
+   * work, with no [x | x] operand and no copy pass; 16-bit operands, 128-tile kernel).  NULL = off.
+   * res_dtype: 0 / dtype = res has the storage type; MTX_F32 (with out_dtype MTX_F32 only) = res is fp32 [.., ldres] — an fp32 residual
+   * stream is added inside the GEMM that closes a branch. */
+  const void* w_lo; int32_t res_dtype;
 } mtx_gemm_args;
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
 #define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the K-slice tail */
@@ -180,6 +186,9 @@ typedef struct mtx_norm_args {
    * E8M0 scale plane q_scale[(c / 128) * lds_q + row], quantised from the result as rounded to `dtype` — bit-identical to running
    * mtx_quantize_mx on y.  With q given, y may be NULL (no 16-bit consumer: the 16-bit store is skipped).  C % 128 == 0. */
   void* q; void* q_scale; int64_t ldq, lds_q;
+  /* ABI 8.  dtype == MTX_F32 only: the type y is written in — 0 / MTX_F32 = fp32, MTX_BF16 / MTX_F16 = the 16-bit operand of the
+   * linear that follows (an fp32 residual stream is normalised in fp32 and rounded once, by the kernel that produced the value) */
+  int32_t out_dtype;
 } mtx_norm_args;
 
 /* GroupNorm over NHWC [N, HW, C] with G groups, optional fused SiLU.  `workspace`: MTX_GROUPNORM_WS_FLOATS(n, hw, c, groups) floats

@@ -618,6 +618,7 @@ def vae_param_shapes(cfg: dict) -> dict:
 
 
 BROADCAST_BUCKET_BYTES = 1 << 30
+BROADCAST_ENTRY_ALIGN_BYTES = 256
 
 
 def broadcast_in_buckets(entries, make, device, src: int = 0, bucket_bytes: int = None) -> dict:
@@ -635,18 +636,20 @@ def broadcast_in_buckets(entries, make, device, src: int = 0, bucket_bytes: int 
         groups.setdefault(dt, []).append((name, tuple(shape)))
     for dt, items in groups.items():
         esz = torch.empty((), dtype=dt).element_size()
+        align = BROADCAST_ENTRY_ALIGN_BYTES // esz           # every entry starts on a 256-byte boundary of its bucket (the allocator's own granule):
+        padded = lambda shape: -(-int(np.prod(shape)) // align) * align      # the GEMM / conv kernels take 16-byte vector loads and LDS-DMA from these views
         start = 0
         while start < len(items):
             end, n = start, 0
-            while end < len(items) and (end == start or (n + int(np.prod(items[end][1]))) * esz <= bucket_bytes):
-                n += int(np.prod(items[end][1]))
+            while end < len(items) and (end == start or (n + padded(items[end][1])) * esz <= bucket_bytes):
+                n += padded(items[end][1])                   # the padding counts toward the bucket size
                 end += 1
             flat = torch.empty(n, dtype=dt, device=device)
             views, off = [], 0
             for name, shape in items[start:end]:
                 k = int(np.prod(shape))
                 views.append((name, flat[off:off + k].view(shape)))
-                off += k
+                off += padded(shape)
             if rank == src:
                 for name, v in views:
                     make(name, v)

@@ -78,17 +78,24 @@ def window_order(hs: int, ws_: int, win: int) -> np.ndarray:
 
 class Sam2Hip:
     def __init__(self, state_dict: dict, config, device="cuda", lib=None, graph: bool = True, dtype: int = abi.BF16, precision: str = "fast"):
-        """precision = "high" (what `ModelManager` serves unless a detect / segment-only batch asks for "fast"; measured on MI355X in round 5,
-        Hiera-L at 1024x1536, logits at a trained model's spread, against the fp32 reference: mask pixels that differ after `> 0` 5.1e-5 against
-        1.8e-4 for "fast", logit rms error 0.0051 against 0.016, no pixel wrong outside the error band; encoder 20.1 ms against 11.4, mask
-        decoder at 8 boxes 4.5 against 1.6 — profiles/r05_parity.json, r05_sam_dtype_probe.json, r05_bench_config2_sam_*.json):
-        the trunk's and the neck's weights as hi + lo pairs of the storage type — W = W_hi + W_lo, one GEMM over K' = 2K with the operand
-        [x | x] against [W_hi | W_lo], fp32 accumulation: the weights' rounding, the largest term of the error budget, goes
-        away at twice the trunk's matrix work and no kernel change — and the prompt encoder / two-way transformer / mask head in fp32
-        (csrc/f32ops.hip)."""
-        if precision not in ("fast", "high"):
-            raise ModelError("SAM-2: precision must be 'fast' or 'high'")
-        self.high = precision == "high"
+        """precision = "high" (what `ModelManager` serves; measured on MI355X, Hiera-L at 1024x1536, logits at a trained model's spread, against
+        the fp32 reference: mask pixels that differ after `> 0` 5.1e-5 against 1.8e-4 for "fast", logit rms error 0.0051 against 0.016, no pixel
+        wrong outside the error band — profiles/r05_parity.json, r06_sam_frontier.json) is three independent parts, each selectable on its own
+        for pricing ("hilo", "stream32", "dec32", joined with "+"; "high" = all three, "fast" = none):
+          hilo      the trunk's and the neck's weights as PAIRS of the storage type, W = W_hi + W_lo, both multiplied with the same operand tile
+                    into one fp32 accumulator (mtx_gemm_args.w_lo): the weights' rounding — the largest term of the error budget
+                    — goes away at twice the trunk's matrix work (round 5 ran it as a GEMM over K' = 2K against a copied [x | x] operand);
+          stream32  the residual stream stays fp32 from the patch embedding to the neck: the GEMMs that close a branch add the fp32 residual
+                    in their epilogue and write fp32, the LayerNorms read fp32 and round once to the next linear's operand type;
+          dec32     prompt encoder / two-way transformer / mask head with fp32 operands and arithmetic (csrc/f32ops.hip)."""
+        parts = {"fast": set(), "high": {"hilo", "stream32", "dec32"}}.get(precision)
+        if parts is None:
+            parts = set(precision.split("+"))
+            if not parts <= {"hilo", "stream32", "dec32"}:
+                raise ModelError("SAM-2: precision must be 'fast', 'high' or a '+'-joined subset of hilo / stream32 / dec32")
+        self.precision = precision
+        self.hilo, self.stream32, self.dec32 = "hilo" in parts, "stream32" in parts, "dec32" in parts
+        self.high = self.hilo and self.stream32 and self.dec32
         self.lib = lib if lib is not None else get_library()
         self.device = torch.device(device)
         self.hp = hiera_hparams(config)
@@ -97,7 +104,7 @@ class Sam2Hip:
         self.dtype = dtype
         self.tdt = torch.bfloat16 if dtype == abi.BF16 else torch.float16
         # the prompt encoder / two-way transformer / mask head: the storage type, or fp32 operands and arithmetic under precision "high"
-        self.ddtype, self.ddt = (abi.F32, torch.float32) if self.high else (self.dtype, self.tdt)
+        self.ddtype, self.ddt = (abi.F32, torch.float32) if self.dec32 else (self.dtype, self.tdt)
         self._graph = graph and not self.lib.is_simulator
         self._lane = AsyncLane(self.device, self.lib.is_simulator)
         self._enc = None
@@ -118,12 +125,12 @@ class Sam2Hip:
         return self._c(t, self.ddt)
 
     def _cw(self, w):
-        """matrix [N, K] of a trunk / neck linear in the storage type; precision "high": [N, 2K] = [W_hi | W_lo]"""
-        if not self.high:
-            return self._c(w)
+        """matrix [N, K] of a trunk / neck linear: (W, None) in the storage type, or with "hilo" the pair (W_hi, W_lo), W_lo = round(W - W_hi)"""
+        if not self.hilo:
+            return self._c(w), None
         hi = w.to(self.tdt)
         lo = (w - hi.float()).to(self.tdt)
-        return self._c(torch.cat([hi, lo], dim=1))
+        return self._c(hi), self._c(lo)
 
     def _pack(self, sd):
         hp, W = self.hp, {}
@@ -135,8 +142,7 @@ class Sam2Hip:
         wpe = sd[bbp + "patch_embed.projection.weight"]                      # [C0,3,7,7]
         wk = torch.zeros(C0, 49, 8)
         wk[:, :, :3] = wpe.permute(0, 2, 3, 1).reshape(C0, 49, 3)
-        W["pe_w"] = self._cw(wk.reshape(C0, 392))
-        W["pe_b"] = self._c(sd[bbp + "patch_embed.projection.bias"], torch.float32)
+        W["pe"] = (*self._cw(wk.reshape(C0, 392)), self._c(sd[bbp + "patch_embed.projection.bias"], torch.float32))
         # position table (hf:638-644), stored in the first stage's window-major order
         pos = F.interpolate(sd[bbp + "pos_embed"], size=(g0, g0), mode="bicubic")
         win = sd[bbp + "pos_embed_window"]
@@ -161,10 +167,10 @@ class Sam2Hip:
                 for nm in ("layer_norm1", "layer_norm2"):
                     blk[nm] = (self._c(sd[p + nm + ".weight"], torch.float32), self._c(sd[p + nm + ".bias"], torch.float32))
                 for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.proj_in"), ("fc2", "mlp.proj_out")):
-                    blk[nm] = (self._cw(sd[p + key + ".weight"]), self._c(sd[p + key + ".bias"], torch.float32))
+                    blk[nm] = (*self._cw(sd[p + key + ".weight"]), self._c(sd[p + key + ".bias"], torch.float32))
                     blk[nm + "_n"] = sd[p + key + ".weight"].shape[0]
                 if dim != dim_out:
-                    blk["skip"] = (self._cw(sd[p + "proj.weight"]), self._c(sd[p + "proj.bias"], torch.float32))
+                    blk["skip"] = (*self._cw(sd[p + "proj.weight"]), self._c(sd[p + "proj.bias"], torch.float32))
                 self.blocks.append(blk)
                 total += 1
         # neck (hf:216-265): convs[n-i] serves level i; levels 0/1 are folded with conv_s0/conv_s1
@@ -175,14 +181,14 @@ class Sam2Hip:
             lat[i] = (sd[f"vision_encoder.neck.convs.{n - i}.weight"].reshape(D, -1), sd[f"vision_encoder.neck.convs.{n - i}.bias"])
         ws0, bs0 = sd["mask_decoder.conv_s0.weight"].reshape(-1, D), sd["mask_decoder.conv_s0.bias"]
         ws1, bs1 = sd["mask_decoder.conv_s1.weight"].reshape(-1, D), sd["mask_decoder.conv_s1.bias"]
-        W["neck0"] = (self._cw(ws0 @ lat[0][0]), self._c(ws0 @ lat[0][1] + bs0, torch.float32))
-        W["neck1"] = (self._cw(ws1 @ lat[1][0]), self._c(ws1 @ lat[1][1] + bs1, torch.float32))
+        W["neck0"] = (*self._cw(ws0 @ lat[0][0]), self._c(ws0 @ lat[0][1] + bs0, torch.float32))
+        W["neck1"] = (*self._cw(ws1 @ lat[1][0]), self._c(ws1 @ lat[1][1] + bs1, torch.float32))
         fold = sd["no_memory_embedding"].reshape(-1) + sd["prompt_encoder.no_mask_embed.weight"].reshape(-1)
         if 2 in hp["top_down"]:
-            W["neck2"] = (self._cw(lat[2][0]), self._c(lat[2][1] + fold, torch.float32))
-            W["neck3"] = (self._cw(lat[3][0]), self._c(lat[3][1], torch.float32))
+            W["neck2"] = (*self._cw(lat[2][0]), self._c(lat[2][1] + fold, torch.float32))
+            W["neck3"] = (*self._cw(lat[3][0]), self._c(lat[3][1], torch.float32))
         else:
-            W["neck2"] = (self._cw(lat[2][0]), self._c(lat[2][1] + fold, torch.float32))
+            W["neck2"] = (*self._cw(lat[2][0]), self._c(lat[2][1] + fold, torch.float32))
             W["neck3"] = None
         # dense image positional encoding (hf:1341-1353) and prompt tables
         ge = S // hp["patch"]
@@ -255,52 +261,35 @@ class Sam2Hip:
         C0 = hp["embed"][0]
         win0 = hp["windows"][0]
         T = g * g
-        # precision "high": (1) every linear's operand is a [rows, 2K] buffer — the producer fills columns [0, K), `dup` copies them to
-        # [K, 2K) — against the [W_hi | W_lo] matrix; (2) the residual stream x stays fp32 from the patch embedding to the neck: the
-        # projections that close a branch (attn.proj, mlp.proj_out) leave the GEMM as fp32 and are added to the stream by an fp32 map, the
-        # LayerNorms read the fp32 stream and hand their 16-bit result to the next GEMM through one conversion that writes both halves.
-        # Measured on the fp32 oracle with the roundings injected (Hiera-L): with hi + lo weights the stream's 96 roundings
-        # are 90 % of what is left of the trunk's error.  "fast": kk(K) = K, `dup` is nothing, the op list is what it always was.
-        hi = self.high
+        # "hilo": every trunk / neck linear carries its weight pair (w, w_lo, bias) — one launch, one operand.  "stream32": the residual stream x
+        # stays fp32 from the patch embedding to the neck — the projections that close a branch (attn.proj, mlp.proj_out) take the fp32 residual
+        # in their epilogue and write fp32; the LayerNorms read fp32 and round once, to the storage type of the GEMM that follows.  Measured on
+        # the fp32 oracle with the roundings injected (Hiera-L): with hi + lo weights the stream's 96 roundings are 90 % of what
+        # is left of the trunk's error.  Neither part adds a launch to the "fast" op list (round 5's form added six per block).
+        s32 = self.stream32
         f32 = torch.float32
 
-        def rows32(t, rows, c):
-            return Act(t.view(1, 1, rows, c), 1, 1, rows, c)
-
-        def add32(a, b, rows, c, label):
-            out = pb.buf((rows, c), f32)
-            pb.ew(abi.EW_ADD, rows32(a, rows, c), b=rows32(b, rows, c), out=rows32(out, rows, c), dtype=abi.F32, label=label)
-            return out
-
         def layer_norm(x, rows, c, wb, label):
-            """the operand of the linears that follow: [rows, kk(c)] of the storage type"""
-            if not hi:
-                return pb.norm(x, pb.buf((rows, c), self.tdt), rows, c, ldy=c, gamma=wb[0], beta=wb[1], eps=eps, label=label)
-            y32 = pb.norm(x, pb.buf((rows, c), f32), rows, c, gamma=wb[0], beta=wb[1], eps=eps, dtype=abi.F32, label=label)
-            return pb.cvt16(y32, pb.buf((rows, 2 * c), self.tdt), rows, c, copies=2, label=label + ".cvt")
+            """the operand of the linears that follow: [rows, c] of the storage type"""
+            y = pb.buf((rows, c), self.tdt)
+            if not s32:
+                return pb.norm(x, y, rows, c, ldy=c, gamma=wb[0], beta=wb[1], eps=eps, label=label)
+            return pb.norm(x, y, rows, c, gamma=wb[0], beta=wb[1], eps=eps, dtype=abi.F32, out_dtype=self.dtype, label=label)
+
+        def linear(a, wb, rows, n_out, k, label, **kw):
+            return pb.gemm(a, wb[0], rows, n_out, k, bias=wb[2], w_lo=wb[1], label=label, **kw)
 
         def close_branch(a, wb, rows, n_out, k, res, label):
             """stream <- res + a @ W^T + b"""
-            if not hi:
-                return pb.gemm(a, wb[0], rows, n_out, k, bias=wb[1], res=res, label=label)
-            y32 = pb.gemm(a, wb[0], rows, n_out, 2 * k, bias=wb[1], out_f32=True, label=label)
-            return add32(y32, res, rows, n_out, label + ".add")
+            if not s32:
+                return linear(a, wb, rows, n_out, k, label, res=res)
+            return linear(a, wb, rows, n_out, k, label, res=res, res_f32=True, out_f32=True)
 
-        def kk(k):
-            return 2 * k if hi else k
-
-        def dup(buf, rows, k, label):
-            if hi:
-                v = buf.view(1, 1, rows, 2 * k)
-                pb.ew(abi.EW_COPY, Act(v, 1, 1, rows, k, 0), out=Act(v, 1, 1, rows, k, k), label=label + ".dup")
-            return buf
-
-        cols = pb.buf((T, kk(392)), self.tdt)
+        cols = pb.buf((T, 392), self.tdt)
         order0 = pb.hold(torch.from_numpy(window_order(g, g, win0).astype(np.int32)).to(self.device))
-        pb.im2col(img, cols, 7, 4, kk(392), row_map=order0, label="patch_im2col")
-        dup(cols, T, 392, "patch_im2col")
+        pb.im2col(img, cols, 7, 4, 392, row_map=order0, label="patch_im2col")
         eps = hp["ln_eps"]
-        x = close_branch(cols, (W["pe_w"], W["pe_b"]), T, C0, 392, pb.const(W["pos"].float()) if hi else W["pos"], "patch_embed")
+        x = close_branch(cols, W["pe"], T, C0, 392, pb.const(W["pos"].float()) if s32 else W["pos"], "patch_embed")
         layout, hs = win0, g
         feats = {}
         stage = 0
@@ -311,10 +300,10 @@ class Sam2Hip:
             tag = f"blk{blk['idx']}"
             if win and win != layout:
                 m = pb.hold(self._gather_map(hs, hs, layout, win))
-                x = pb.row_gather(x, pb.buf((T, dim), f32 if hi else self.tdt), m, T, dim, label=tag + ".relayout", dtype=abi.F32 if hi else None)
+                x = pb.row_gather(x, pb.buf((T, dim), f32 if s32 else self.tdt), m, T, dim, label=tag + ".relayout", dtype=abi.F32 if s32 else None)
                 layout = win
             ln1 = layer_norm(x, T, dim, blk["layer_norm1"], tag + ".ln1")
-            qkv = pb.gemm(ln1, blk["qkv"][0], T, 3 * dout, kk(dim), bias=blk["qkv"][1], label=tag + ".qkv")
+            qkv = linear(ln1, blk["qkv"], T, 3 * dout, dim, tag + ".qkv")
             wtok = win * win if win else T
             nwin = T // wtok
             if dim != dout and not blk["pool"]:
@@ -322,28 +311,25 @@ class Sam2Hip:
             if blk["pool"]:
                 if not win:
                     raise ModelError("SAM-2: q-pooling inside a global-attention block is not supported")
-                res_full = pb.gemm(ln1, blk["skip"][0], T, dout, kk(dim), bias=blk["skip"][1], label=tag + ".skip")
+                res_full = linear(ln1, blk["skip"], T, dout, dim, tag + ".skip")
                 res = pb.ew(abi.EW_MAXPOOL, Act(res_full.view(nwin, win, win, dout), nwin, win, win, dout), i0=2, i1=2, label=tag + ".skip_pool")
                 qv = Act(qkv.view(nwin, win, win, 3 * dout), nwin, win, win, dout, 0)
                 qp = pb.ew(abi.EW_MAXPOOL, qv, i0=2, i1=2, label=tag + ".q_pool")
                 Tq, sq = T // 4, wtok // 4
                 q_t, q_str = qp.t, (sq * dout, dout, d)
-                res_t = pb.cvt_f32(res, self.dtype, label=tag + ".skip_f32").t.view(Tq, dout) if hi else res.t
+                res_t = pb.cvt_f32(res, self.dtype, label=tag + ".skip_f32").t.view(Tq, dout) if s32 else res.t
             else:
                 Tq, sq = T, wtok
                 q_t, q_str = qkv, (wtok * 3 * dout, 3 * dout, d)
                 res_t = x
-            o = pb.buf((Tq, kk(dout)), self.tdt)
+            o = pb.buf((Tq, dout), self.tdt)
             kv_str = (wtok * 3 * dout, 3 * dout, d)
-            pb.attention(q_t, qkv, qkv, o, nwin, heads, sq, wtok, d, q_str, kv_str, kv_str, (sq * kk(dout), kk(dout), d),
+            pb.attention(q_t, qkv, qkv, o, nwin, heads, sq, wtok, d, q_str, kv_str, kv_str, (sq * dout, dout, d),
                          1.0 / math.sqrt(d), k_off=dout, v_off=2 * dout, label=tag + ".attn")
-            dup(o, Tq, dout, tag + ".attn")
             x1 = close_branch(o, blk["proj"], Tq, dout, dout, res_t, tag + ".proj")
             ln2 = layer_norm(x1, Tq, dout, blk["layer_norm2"], tag + ".ln2")
             hdim = blk["fc1_n"]
-            h = pb.gemm(ln2, blk["fc1"][0], Tq, hdim, kk(dout), bias=blk["fc1"][1], act=abi.ACT_GELU,
-                        out=pb.buf((Tq, 2 * hdim), self.tdt) if hi else None, ldc=kk(hdim), label=tag + ".fc1")
-            dup(h, Tq, hdim, tag + ".fc1")
+            h = linear(ln2, blk["fc1"], Tq, hdim, dout, tag + ".fc1", act=abi.ACT_GELU)
             x = close_branch(h, blk["fc2"], Tq, dout, hdim, x1, tag + ".fc2")
             if blk["pool"]:
                 T, hs, layout = Tq, hs // 2, win // 2
@@ -355,16 +341,16 @@ class Sam2Hip:
 
         def lateral(level, wb, cout):
             xt, Tn, hn, lay, cin = feats[level]
-            if hi:                  # the stage output is the fp32 stream: rounded once, into both halves of the wide operand
-                xt = pb.cvt16(xt, pb.buf((Tn, 2 * cin), self.tdt), Tn, cin, copies=2, label=f"neck{level}.cvt")
-            y = pb.gemm(xt, wb[0], Tn, cout, kk(cin), bias=wb[1], label=f"neck{level}")
+            if s32:                 # the stage output is the fp32 stream: rounded once, to the lateral projection's operand type
+                xt = pb.cvt16(xt, pb.buf((Tn, cin), self.tdt), Tn, cin, copies=1, label=f"neck{level}.cvt")
+            y = linear(xt, wb, Tn, cout, cin, f"neck{level}")
             m = pb.hold(self._gather_map(hn, hn, lay, 0))
             r = pb.act(1, hn, hn, cout)
             pb.row_gather(y, r.t, m, Tn, cout, label=f"neck{level}.to_raster")
             return r
 
         c0 = W["neck0"][0].shape[0]
-        c1 = W["neck1"][0].shape[0]        # (row counts: unaffected by the [hi | lo] column layout)
+        c1 = W["neck1"][0].shape[0]
         feat_s0 = lateral(0, W["neck0"], c0)
         feat_s1 = lateral(1, W["neck1"], c1)
         lat2 = lateral(2, W["neck2"], D)
@@ -408,7 +394,7 @@ class Sam2Hip:
         tok0 = pb.buf((n * NT, D), self.ddt)                 # point embeddings (input, also the query PE)
         bidx = pb.hold((torch.arange(n * P, dtype=torch.int32) % P).to(self.device))
         src, feat_s0, feat_s1 = enc.src, enc.feat_s0, enc.feat_s1
-        if self.high:                                        # the encoder's three outputs (16-bit) enter the fp32 plan through one conversion each
+        if self.dec32:                                       # the encoder's three outputs (16-bit) enter the fp32 plan through one conversion each
             src, feat_s0, feat_s1 = (pb.cvt_f32(t, self.dtype, label=f"dec.{nm}_f32") for t, nm in ((src, "src"), (feat_s0, "feat_s0"), (feat_s1, "feat_s1")))
         keys = pb.row_gather(src.t, pb.buf((n * P, D), self.ddt), bidx, n * P, D, label="dec.keys_bcast")
         queries = tok0
@@ -419,7 +405,7 @@ class Sam2Hip:
         def up(x, wb, cout, skip, label):
             """ConvTranspose2d(k=2, s=2) + the skip feature: the conv kernel's pixel-shuffle store in the 16-bit plans, a GEMM over the
             pixels and a shuffle-add map in the fp32 plan"""
-            if not self.high:
+            if not self.dec32:
                 return pb.conv2d(x, wb[0], wb[1], 4 * cout, ksize=1, pixel_shuffle=2, res=skip, res_broadcast=True, label=label)
             rows = x.n * x.h * x.w
             cols = pb.gemm(x.t, wb[0], rows, 4 * cout, x.c, bias=wb[1], label=label + ".gemm")

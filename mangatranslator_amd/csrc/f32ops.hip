@@ -336,12 +336,58 @@ int attn_f32_launch(const mtx_attn_args* a, void* stream, const char** err) {
 }
 
 // ---- LayerNorm over the last dim, one wave per row (two passes over the row: mean, then centred variance) ------------------------------------
+// TO = float, or (round 6, mtx_norm_args.out_dtype) the 16-bit type of the linear that follows: the fp32 residual stream of SAM's precision
+// "high" is normalised in fp32 and rounded ONCE here — no fp32 result, no conversion pass.  Rows of up to 64 x 4 x NCH values stay in registers
+// between the passes (16-byte loads); wider or unaligned rows take the element loop.
+template <typename TO> __device__ __forceinline__ TO norm_out(float v);
+template <> __device__ __forceinline__ float norm_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 norm_out<__bf16>(float v) { return from_f32<__bf16>(v); }
+template <> __device__ __forceinline__ _Float16 norm_out<_Float16>(float v) { return from_f32<_Float16>(v); }
+
+template <typename TO>
 __global__ __launch_bounds__(256) void norm_f32_kernel(mtx_norm_args p) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= p.rows) return;
   const float* X = reinterpret_cast<const float*>(p.x) + row * p.ldx;
-  float* Y = reinterpret_cast<float*>(p.y) + row * p.ldy;
+  TO* Y = reinterpret_cast<TO*>(p.y) + row * p.ldy;
+  constexpr int NCH = 5;                                   // 5 x 256 = 1280 values per row in registers (Hiera-L: 144 .. 1152)
+  const bool fits = (p.c & 3) == 0 && p.c <= 256 * NCH && (p.ldx & 3) == 0 && ((size_t)p.x & 15) == 0;
+  if (fits) {
+    f32x4 xv[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const long c = (long)(ch * 64 + lane) * 4;
+      xv[ch] = c < p.c ? *reinterpret_cast<const f32x4*>(X + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += (xv[ch][0] + xv[ch][1]) + (xv[ch][2] + xv[ch][3]);
+    }
+    const float mean = wave_sum(s) / (float)p.c;
+    float v = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const long c = (long)(ch * 64 + lane) * 4;
+      if (c < p.c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[ch][e] - mean; v = fmaf(d, d, v); }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)p.c + p.eps);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const long c = (long)(ch * 64 + lane) * 4;
+      if (c < p.c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = (xv[ch][e] - mean) * rstd;
+          if (p.gamma) t *= p.gamma[c + e];
+          if (p.beta) t += p.beta[c + e];
+          Y[c + e] = norm_out<TO>(act_f32(t, p.act, 0.f));
+        }
+      }
+    }
+    return;
+  }
   float s = 0.f;
   for (long c = lane; c < p.c; c += 64) s += X[c];
   const float mean = wave_sum(s) / (float)p.c;
@@ -352,7 +398,7 @@ __global__ __launch_bounds__(256) void norm_f32_kernel(mtx_norm_args p) {
     float t = (X[c] - mean) * rstd;
     if (p.gamma) t *= p.gamma[c];
     if (p.beta) t += p.beta[c];
-    Y[c] = act_f32(t, p.act, 0.f);
+    Y[c] = norm_out<TO>(act_f32(t, p.act, 0.f));
   }
 }
 
@@ -360,7 +406,11 @@ int norm_f32_launch(const mtx_norm_args* a, void* stream, const char** err) {
   if (!a->x || !a->y) { *err = "norm f32: null operand"; return MTX_ERR_INVALID; }
   if (a->kind != 0 || a->mod_scale || a->mod_shift || a->q) { *err = "norm f32: LayerNorm without modulation / fp8 twin only"; return MTX_ERR_UNSUPPORTED; }
   if (a->rows < 1 || a->c < 1) return MTX_OK;
-  MTX_LAUNCH(norm_f32_kernel, dim3((unsigned)((a->rows + 3) / 4)), dim3(256), 0, stream, *a);
+  const dim3 grid((unsigned)((a->rows + 3) / 4));
+  if (a->out_dtype == 0 || a->out_dtype == MTX_F32) MTX_LAUNCH(norm_f32_kernel<float>, grid, dim3(256), 0, stream, *a);
+  else if (a->out_dtype == MTX_BF16) MTX_LAUNCH(norm_f32_kernel<__bf16>, grid, dim3(256), 0, stream, *a);
+  else if (a->out_dtype == MTX_F16) MTX_LAUNCH(norm_f32_kernel<_Float16>, grid, dim3(256), 0, stream, *a);
+  else { *err = "norm f32: out_dtype must be 0, f32, bf16 or f16"; return MTX_ERR_INVALID; }
   return MTX_OK;
 }
 

@@ -21,6 +21,7 @@ namespace mtx {
 struct GemmParams {
   const unsigned char* a; const unsigned char* w; const float* bias; const unsigned char* res;
   const unsigned char* gate; unsigned char* c;
+  const unsigned char* w2; int res_f32;      // 128-tile kernel: W_lo of a [W_hi, W_lo] weight pair (or null); residual is fp32 (fp32 output only)
   long m, n, k, lda, ldw, ldc, ldres, ldgate, a_bs, w_bs, c_bs, res_bs;
   int gate_rows_per, act; float act_param, alpha;
   int out_f32;
@@ -41,14 +42,24 @@ struct GemmParams {
 
 constexpr int GBM = 128, GBN = 128, GBK = 64;
 constexpr int G_SMEM = (GBM + GBN) * 128;   // 32 KB; the output tile (128 x 256 B) aliases it
+constexpr int G_SMEM_DUAL = (GBM + 2 * GBN) * 128;   // 48 KB: a second W stage for the W_lo half of a [W_hi, W_lo] weight pair
 
-template <typename T>
+// DUAL (round 6, SAM-2.1 `precision = "high"`): the weights come as a pair W = W_hi + W_lo of the storage type (p.w, p.w2); both stages are
+// multiplied with the SAME A fragments in LDS and add into one accumulator tile — per k-step W_hi first, then W_lo.  Round 5 ran this as a
+// GEMM over K' = 2K against an operand [x | x]: twice the A traffic, a copy pass per linear to build [x | x], twice the LDS A reads.
+// Epilogue (round 6): memory requests in batches, like the 256-tile kernel's since round 5 — the bias as four 16-byte loads, all gate and
+// residual chunks of a thread requested before the first is used (it used to be bias dword by dword under exec branches, then per row
+// gate -> wait -> residual -> wait -> store: 216 full waits on 242 loads in the ISA, profiles/r05_isa_audit.txt); the fp32-output form
+// writes 16-byte vectors and takes an fp32 residual (p.res_f32: SAM's fp32 residual stream is added inside the GEMM that closes a branch).
+// Same arithmetic and rounding order as before on the 16-bit path (gate product and residual sum stay two roundings).
+template <typename T, bool DUAL>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   typedef typename Traits<T>::v8 v8;
   typedef typename Traits<T>::v4 v4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[G_SMEM];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DUAL ? G_SMEM_DUAL : G_SMEM];
   unsigned char* As = smem;
   unsigned char* Ws = smem + GBM * 128;
+  unsigned char* W2s = smem + (GBM + GBN) * 128;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const int wm = wv >> 1, wn = wv & 1;
@@ -60,6 +71,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const long bz = blockIdx.y;
   const unsigned char* A = p.a + (size_t)bz * p.a_bs * sizeof(T);
   const unsigned char* W = p.w + (size_t)bz * p.w_bs * sizeof(T);
+  const unsigned char* W2 = DUAL ? p.w2 + (size_t)bz * p.w_bs * sizeof(T) : nullptr;
   unsigned char* Cp = p.c + (size_t)bz * p.c_bs * (p.out_f32 ? 4 : sizeof(T));
 
   f32x4 acc[4][4];
@@ -70,17 +82,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   const int lc = tid & 7;          // 16-byte chunk within the 64-wide K slice
   const int lr = tid >> 3;         // row within a 32-row pass
-  u32x4 ra[4], rw[4];
+  u32x4 ra[4], rw[4], rw2[DUAL ? 4 : 1];
 
   auto load_slice = [&](long k0) {
     const long kk = k0 + lc * 8;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const long r = lr + it * 32;
-      u32x4 va = u32x4{0u, 0u, 0u, 0u}, vw = u32x4{0u, 0u, 0u, 0u};
+      u32x4 va = u32x4{0u, 0u, 0u, 0u}, vw = u32x4{0u, 0u, 0u, 0u}, vw2 = u32x4{0u, 0u, 0u, 0u};
       if (m0 + r < p.m && kk < p.k) va = *reinterpret_cast<const u32x4*>(A + ((size_t)(m0 + r) * p.lda + kk) * sizeof(T));
-      if (n0 + r < p.n && kk < p.k) vw = *reinterpret_cast<const u32x4*>(W + ((size_t)(n0 + r) * p.ldw + kk) * sizeof(T));
+      if (n0 + r < p.n && kk < p.k) {
+        vw = *reinterpret_cast<const u32x4*>(W + ((size_t)(n0 + r) * p.ldw + kk) * sizeof(T));
+        if (DUAL) vw2 = *reinterpret_cast<const u32x4*>(W2 + ((size_t)(n0 + r) * p.ldw + kk) * sizeof(T));
+      }
       ra[it] = va; rw[it] = vw;
+      if (DUAL) rw2[it] = vw2;
     }
   };
 
@@ -93,6 +109,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       const int r = lr + it * 32;
       *reinterpret_cast<u32x4*>(As + r * 128 + ((lc ^ (r & 7)) << 4)) = ra[it];
       *reinterpret_cast<u32x4*>(Ws + r * 128 + ((lc ^ (r & 7)) << 4)) = rw[it];
+      if (DUAL) *reinterpret_cast<u32x4*>(W2s + r * 128 + ((lc ^ (r & 7)) << 4)) = rw2[it];
     }
     __syncthreads();
     if (kt + 1 < nk) load_slice((kt + 1) * GBK);
@@ -115,12 +132,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = Traits<T>::mfma(wf[j], af[i], acc[i][j]);
+      if (DUAL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = wn * 64 + j * 16 + l15;
+          wf[j] = *reinterpret_cast<const v8*>(W2s + r * 128 + ((cch ^ (l15 & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = Traits<T>::mfma(wf[j], af[i], acc[i][j]);
+      }
     }
   }
 
   // lane holds C[m = m0 + wm*64 + i*16 + l15][n = n0 + wn*64 + j*16 + q*4 + r]
+  // bias of this lane's 16 columns: four 16-byte loads in one batch when the vector is aligned and N a multiple of 4 (then a quad is valid or not as a whole)
+  f32x4 bv[4];
+  const bool bias_vec = p.bias != nullptr && ((size_t)p.bias & 15) == 0 && (p.n & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long nb = n0 + wn * 64 + j * 16 + q * 4;
+    if (bias_vec) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.bias + (nb < p.n ? nb : 0));
+      bv[j] = nb < p.n ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = (p.bias != nullptr && nb + r < p.n) ? p.bias[nb + r] : 0.f;
+    }
+  }
   if (p.out_f32) {
     float* Cf = reinterpret_cast<float*>(Cp);
+    const bool vec = (p.n & 3) == 0 && (p.ldc & 3) == 0 && ((size_t)Cf & 15) == 0 && p.gate == nullptr &&
+                     (p.res == nullptr || (p.res_f32 && (p.ldres & 3) == 0 && (p.res_bs & 3) == 0 && ((size_t)p.res & 15) == 0));
+    if (vec) {
+      // 16-byte stores (a lane's four consecutive columns); the fp32 residual of all sixteen quads requested before the first is used
+      const float* Rf = reinterpret_cast<const float*>(p.res);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long m = m0 + wm * 64 + i * 16 + l15;
+        const long mc = m < p.m ? m : p.m - 1;
+        f32x4 rq4[4];
+        if (Rf != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const long n = n0 + wn * 64 + j * 16 + q * 4;
+            rq4[j] = *reinterpret_cast<const f32x4*>(Rf + (size_t)bz * p.res_bs + (size_t)mc * p.ldres + (n < p.n ? n : 0));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long n = n0 + wn * 64 + j * 16 + q * 4;
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = apply_act(acc[i][j][r] * p.alpha + bv[j][r], p.act, p.act_param);
+            if (Rf != nullptr) v[r] += rq4[j][r];
+          }
+          if (m < p.m && n < p.n) *reinterpret_cast<f32x4*>(Cf + (size_t)m * p.ldc + n) = v;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long m = m0 + wm * 64 + i * 16 + l15;
@@ -131,10 +204,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         for (int r = 0; r < 4; ++r) {
           const long n = n0 + wn * 64 + j * 16 + q * 4 + r;
           if (n < p.n) {
-            float v = acc[i][j][r] * p.alpha + (p.bias ? p.bias[n] : 0.f);
+            float v = acc[i][j][r] * p.alpha + bv[j][r];
             v = apply_act(v, p.act, p.act_param);
             if (p.gate) v *= to_f32(reinterpret_cast<const T*>(p.gate)[(size_t)(m / p.gate_rows_per) * p.ldgate + n]);
-            if (p.res) v += to_f32(reinterpret_cast<const T*>(p.res)[(size_t)bz * p.res_bs + (size_t)m * p.ldres + n]);
+            if (p.res) v += p.res_f32 ? reinterpret_cast<const float*>(p.res)[(size_t)bz * p.res_bs + (size_t)m * p.ldres + n]
+                                      : to_f32(reinterpret_cast<const T*>(p.res)[(size_t)bz * p.res_bs + (size_t)m * p.ldres + n]);
             Cf[(size_t)m * p.ldc + n] = v;
           }
         }
@@ -147,50 +221,61 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   unsigned char* outs = smem;    // [128 rows][16 chunks of 16 B], chunk ^= (row & 15)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const long nb = n0 + wn * 64 + j * 16 + q * 4;
-    float b[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b[r] = (p.bias != nullptr && nb + r < p.n) ? p.bias[nb + r] : 0.f;
     const int chunk = wn * 8 + j * 2 + (q >> 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = wm * 64 + i * 16 + l15;
       v4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act(acc[i][j][r] * p.alpha + b[r], p.act, p.act_param));
+      for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act(acc[i][j][r] * p.alpha + bv[j][r], p.act, p.act_param));
       *reinterpret_cast<v4*>(outs + row * 256 + ((chunk ^ (row & 15)) << 4) + ((q & 1) << 3)) = o;
     }
   }
-  __syncthreads();
   const int oc = tid & 15;
   const bool vec_ok = (p.ldc % 8 == 0) && (!p.res || p.ldres % 8 == 0) && (!p.gate || p.ldgate % 8 == 0);
+  const long n = n0 + oc * 8;
+  const bool full = vec_ok && (n + 8 <= p.n);
+  const T* G = reinterpret_cast<const T*>(p.gate);
+  const T* R = reinterpret_cast<const T*>(p.res);
+  const long gper = p.gate_rows_per > 0 ? p.gate_rows_per : 1;
+  // the thread's eight gate and eight residual chunks, requested before the barrier (clamped addresses, no branches): one round trip
+  u32x4 gq[8], rq[8];
+  if (full && (G != nullptr || R != nullptr)) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const long m = m0 + (tid >> 4) + it * 16;
+      const long mc = m < p.m ? m : p.m - 1;
+      if (G != nullptr) gq[it] = *reinterpret_cast<const u32x4*>(G + (size_t)(mc / gper) * p.ldgate + n);
+      if (R != nullptr) rq[it] = *reinterpret_cast<const u32x4*>(R + (size_t)bz * p.res_bs + (size_t)mc * p.ldres + n);
+    }
+  }
+  __syncthreads();
+#pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int row = (tid >> 4) + it * 16;
-    const long m = m0 + row, n = n0 + oc * 8;
+    const long m = m0 + row;
     if (m >= p.m || n >= p.n) continue;
     u32x4 raw = *reinterpret_cast<const u32x4*>(outs + row * 256 + ((oc ^ (row & 15)) << 4));
-    const bool full = vec_ok && (n + 8 <= p.n);
-    if (p.gate != nullptr || p.res != nullptr || !full) {
+    if (G != nullptr || R != nullptr || !full) {
+#pragma clang fp contract(off)
       float f[8];
       unpack8<T>(raw, f);
-      const T* G = reinterpret_cast<const T*>(p.gate);
-      const T* R = reinterpret_cast<const T*>(p.res);
-      const size_t goff = (size_t)(m / (p.gate_rows_per > 0 ? p.gate_rows_per : 1)) * p.ldgate + n;
-      const size_t roff = (size_t)bz * p.res_bs + (size_t)m * p.ldres + n;
       if (full) {
-        if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + goff), g8);
+        if (G) { float g8[8]; unpack8<T>(gq[it], g8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
-        if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + roff), r8);
+          for (int e = 0; e < 8; ++e) f[e] = f[e] * g8[e]; }
+        if (R) { float r8[8]; unpack8<T>(rq[it], r8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += r8[e]; }
+          for (int e = 0; e < 8; ++e) f[e] = f[e] + r8[e]; }
         raw = pack8<T>(f);
       } else {
+        const size_t goff = (size_t)(m / gper) * p.ldgate + n;
+        const size_t roff = (size_t)bz * p.res_bs + (size_t)m * p.ldres + n;
         T* Co = reinterpret_cast<T*>(Cp);
         for (int e = 0; e < 8 && n + e < p.n; ++e) {
           float v = f[e];
-          if (G) v *= to_f32(G[goff + e]);
-          if (R) v += to_f32(R[roff + e]);
+          if (G) v = v * to_f32(G[goff + e]);
+          if (R) v = v + to_f32(R[roff + e]);
           Co[(size_t)m * p.ldc + n + e] = from_f32<T>(v);
         }
         continue;
@@ -383,9 +468,8 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&a
 // tile `lin` of the grouped order -> its origin.  The tile plane is cut into STRIPS of `strip_w` tile columns; inside a strip the order
 // is groups of 4 tile rows x the strip's columns, column-major inside a group (the 32 workgroups resident on an XCD work on ~8 columns
 // x 4 rows that walk K in step and share 12 panels through that XCD's L2).  The XCD-contiguous workgroup order (xcd_remap) hands each
-// XCD a run of tiles/8 consecutive tiles, i.e. a block of about (tiles/8 / strip_w) rows x strip_w columns: the narrower the strip, the
-// squarer the block and the fewer A / W panels an XCD pulls over the fabric into its own L2 (one strip = rounds 1-5: 4.4 rows x all
-// columns).  strip_w is chosen per launch (gemm256_choose_strip).
+// XCD a run of tiles/8 consecutive tiles, i.e. a block of about (tiles/8 / strip_w) rows x strip_w columns (one strip = rounds 1-5: 4.4
+// rows x all columns).  strip_w is chosen per launch (gemm256_choose_strip: what strips buy, and what they do not).
 __device__ __forceinline__ void gemm256_tile_origin(const GemmParams& p, unsigned lin, long& m0, long& n0) {
   const unsigned GM = 4;
   const unsigned per_strip = p.tiles_m * p.strip_w;
@@ -1002,28 +1086,25 @@ static void launch_gemm256_slices(const GemmParams& p, unsigned pieces, void* st
 // measured on MI355X (tools/bench_kernels.py, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the 3/3/2/0
 // piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
 // specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
-// Strip width of the tile map: the XCD blocks should be as square as the problem allows.  With `xc` strips an XCD's run of tiles/8 tiles
-// covers about tiles_m * xc / 8 rows (rounded up to whole 4-row groups, + one group where the run starts mid-group) of ceil(tiles_n / xc)
-// columns; its fabric traffic is (rows + columns) panels of 256 x K.  MTX_GEMM_STRIPS = 1 / 2 / 4 / 8 forces a count (A/B, tools/bench_kernels.py).
-static unsigned gemm256_choose_strip(unsigned tiles_m, unsigned tiles_n) {
-  const char* e = getenv("MTX_GEMM_STRIPS");            // read per launch: same-process A/Bs switch it between timings
+// Strip width of the tile map.  Measured on MI355X (same process, identical bytes: profiles/r06_visit_a / _b logs): with ONE strip every
+// XCD walks all tile columns from column 0 at the same time, i.e. eight L2s pull the same W panel over the fabric at once; two strips put
+// XCDs 0-3 and 4-7 on different halves of W.  The MX-fp8 kernel (half the time per byte of the 16-bit one) gains on the wide problems —
+// 8512 x 27648 x 3072 0.635 -> 0.606 ms, 8000 x 18432 x 3072 0.420 -> 0.371 — and is flat up to N = 9216; the bf16 kernel is flat
+// everywhere (+- 0.5 %) and its K-sliced shapes lose 2 % (their tail tiles move); four or eight strips and a per-group column rotation
+// were within noise of two.  (The fabric-side read volume goes UP with strips — 1.26 -> 1.58 GB per launch, A panels re-fetched per
+// strip: it was never the volume, it was eight XCDs asking for the same lines.)  MTX_GEMM_STRIPS = n forces a count (tests, tools/bench_kernels.py).
+static unsigned gemm256_choose_strip(unsigned tiles_n, bool f8) {
+  const char* e = getenv("MTX_GEMM_STRIPS");
   const int want = e ? atoi(e) : 0;
-  unsigned best_w = tiles_n; double best = 1e30;
-  for (unsigned xc = 1; xc <= 8; xc *= 2) {
-    const unsigned w = (tiles_n + xc - 1) / xc;
-    if (want > 0 && (unsigned)want != xc) continue;
-    if (w < 4 && xc > 1 && want <= 0) break;                          // fewer than 4 columns per strip: the resident 4 x 8 patch no longer fits a strip
-    const double rows = (double)tiles_m * xc / 8.0;
-    const double cost = (rows < 4 ? 4 : rows) + 4.0 + (double)w;
-    if (cost < best) { best = cost; best_w = w; }
-  }
-  return best_w < 1 ? 1 : best_w;
+  const unsigned xc = want > 0 ? (unsigned)want : ((f8 && tiles_n >= 64) ? 2u : 1u);
+  const unsigned w = (tiles_n + xc - 1) / xc;
+  return w < 1 ? 1 : w;
 }
 
 template <typename T, bool F8>
 static void launch_gemm256(const GemmParams& p0, dim3 grid, void* stream, bool force, bool nosplit, unsigned forced_slices) {
   GemmParams p = p0;
-  p.strip_w = gemm256_choose_strip(p.tiles_m, p.tiles_n);
+  p.strip_w = gemm256_choose_strip(p.tiles_n, F8);
   const unsigned tiles = p.tiles_m * p.tiles_n, cus = (unsigned)gemm_num_cus(), rem = tiles % cus;
   const long nk = p.k / p.bk;
   const bool can = p.part != nullptr && cus <= 320 && grid.y == 1 && !nosplit;
@@ -1064,11 +1145,18 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   if (a->glu_q != nullptr && !f8) { *err = "gemm: the SwiGLU epilogue exists on the fp8 kernel only"; return MTX_ERR_INVALID; }
   if (a->in_dtype != 0 && !f8 && a->in_dtype != a->dtype) { *err = "gemm: in_dtype must be 0, dtype or MTX_F8"; return MTX_ERR_INVALID; }
   if (a->k % 8 || a->lda % 8 || a->ldw % 8) { *err = "gemm: K, lda, ldw must be multiples of 8 (16-byte chunks)"; return MTX_ERR_INVALID; }
+  // every kernel below takes its operand rows as 16-byte vector loads / LDS-DMA pieces and stores 16-byte row chunks: a base pointer that
+  // is only element-aligned (a view into a packed buffer) is refused here instead of faulting or tearing there
+  if (((size_t)a->a | (size_t)a->w) & 15) { *err = "gemm: a and w must be 16-byte aligned"; return MTX_ERR_INVALID; }
+  if ((((size_t)a->c | (size_t)a->res | (size_t)a->gate) & 15) && a->n % 8 == 0 && a->ldc % 8 == 0) { *err = "gemm: c, res and gate must be 16-byte aligned when rows are stored as 16-byte chunks"; return MTX_ERR_INVALID; }
   if (a->batch > 1 && (a->a_bstride % 8 || a->w_bstride % 8 || a->c_bstride % 8 || a->res_bstride % 8)) { *err = "gemm: batch strides must be multiples of 8"; return MTX_ERR_INVALID; }
   if (a->out_dtype != a->dtype && a->out_dtype != MTX_F32) { *err = "gemm: out_dtype must equal dtype or be f32"; return MTX_ERR_INVALID; }
+  if (a->res_dtype != 0 && a->res_dtype != a->dtype && !(a->res_dtype == MTX_F32 && a->out_dtype == MTX_F32)) { *err = "gemm: res_dtype must be 0, dtype, or f32 together with an f32 output"; return MTX_ERR_INVALID; }
+  if (a->w_lo != nullptr && (f8 || ((size_t)a->w_lo & 15))) { *err = "gemm: w_lo (the low half of a weight pair) needs 16-bit operands and a 16-byte aligned pointer"; return MTX_ERR_INVALID; }
   GemmParams p;
   p.a = (const unsigned char*)a->a; p.w = (const unsigned char*)a->w; p.bias = a->bias;
   p.res = (const unsigned char*)a->res; p.gate = (const unsigned char*)a->gate; p.c = (unsigned char*)a->c;
+  p.w2 = (const unsigned char*)a->w_lo; p.res_f32 = (a->res != nullptr && a->res_dtype == MTX_F32) ? 1 : 0;
   p.m = a->m; p.n = a->n; p.k = a->k; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
   p.ldres = a->ldres; p.ldgate = a->ldgate;
   p.a_bs = a->a_bstride; p.w_bs = a->w_bstride; p.c_bs = a->c_bstride; p.res_bs = a->res_bstride;
@@ -1111,7 +1199,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
       }
       p.glu_q = reinterpret_cast<unsigned char*>(a->glu_q); p.glu_scale = reinterpret_cast<unsigned*>(a->glu_scale);
       p.glu_ldq = a->glu_ldq; p.glu_lds = a->glu_lds; p.glu_col0 = a->glu_col0;
-      p.strip_w = gemm256_choose_strip(p.tiles_m, p.tiles_n);
+      p.strip_w = gemm256_choose_strip(p.tiles_n, true);
       if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm256_f8_glu_kernel<__bf16>), g2, dim3(512), 0, stream, p);
       else MTX_LAUNCH((gemm256_f8_glu_kernel<_Float16>), g2, dim3(512), 0, stream, p);
       return MTX_OK;
@@ -1127,7 +1215,7 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   const bool snug = a->m * 10 >= t256m * G2_BM * 9 && a->n * 10 >= t256n * G2_BN * 9;
   const long min_tiles = force ? 1 : ((a->k >= 1024 && snug) ? 24 : 160);
   const bool few_long = a->workspace != nullptr && batch == 1 && t256 * 2 <= gemm_num_cus() && a->k / G2_BK >= 128 && a->m >= 256;
-  if (!p.out_f32 && a->k % G2_BK == 0 && vec && fits32 && (t256 >= min_tiles || few_long) && (a->dtype == MTX_BF16 || a->dtype == MTX_F16)) {
+  if (!p.out_f32 && a->w_lo == nullptr && a->k % G2_BK == 0 && vec && fits32 && (t256 >= min_tiles || few_long) && (a->dtype == MTX_BF16 || a->dtype == MTX_F16)) {
     p.tiles_m = (unsigned)((a->m + G2_BM - 1) / G2_BM);
     p.tiles_n = (unsigned)((a->n + G2_BN - 1) / G2_BN);
     dim3 g2(p.tiles_m * p.tiles_n, (unsigned)batch);
@@ -1135,9 +1223,12 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
     return MTX_OK;
   }
   dim3 grid(p.tiles_m * p.tiles_n, (unsigned)batch);
-  if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm_kernel<__bf16>), grid, dim3(256), 0, stream, p);
-  else if (a->dtype == MTX_F16) MTX_LAUNCH((gemm_kernel<_Float16>), grid, dim3(256), 0, stream, p);
-  else { *err = "gemm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+  if (a->dtype != MTX_BF16 && a->dtype != MTX_F16) { *err = "gemm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
+  if (p.w2 != nullptr) {
+    if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm_kernel<__bf16, true>), grid, dim3(256), 0, stream, p);
+    else MTX_LAUNCH((gemm_kernel<_Float16, true>), grid, dim3(256), 0, stream, p);
+  } else if (a->dtype == MTX_BF16) MTX_LAUNCH((gemm_kernel<__bf16, false>), grid, dim3(256), 0, stream, p);
+  else MTX_LAUNCH((gemm_kernel<_Float16, false>), grid, dim3(256), 0, stream, p);
   return MTX_OK;
 }
 

@@ -2,7 +2,7 @@
 mtx_abi_sizeof() when the library is opened)."""
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # enums
 BF16, F16, F32, U8, I32, F8 = 0, 1, 2, 3, 4, 5
@@ -46,7 +46,8 @@ class GemmArgs(C.Structure):
                 ("act", i32), ("act_param", f32), ("alpha", f32),
                 ("dtype", i32), ("out_dtype", i32), ("workspace", vp), ("workspace_bytes", i64),
                 ("a_scale", vp), ("w_scale", vp), ("lds_a", i64), ("lds_w", i64), ("in_dtype", i32), ("flags", i32),
-                ("glu_q", vp), ("glu_scale", vp), ("glu_ldq", i64), ("glu_lds", i64), ("glu_col0", i64)]
+                ("glu_q", vp), ("glu_scale", vp), ("glu_ldq", i64), ("glu_lds", i64), ("glu_col0", i64),
+                ("w_lo", vp), ("res_dtype", i32)]
 
 
 GEMM_FORCE_TILE256, GEMM_NO_SPLIT, GEMM_F8_WIDE, GEMM_SERIAL_EPILOGUE = 1, 2, 4, 8
@@ -71,7 +72,7 @@ class NormArgs(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("mod_scale", vp), ("mod_shift", vp),
                 ("rows", i64), ("c", i64), ("ldx", i64), ("ldy", i64), ("rows_per", i64), ("ldmod", i64),
                 ("eps", f32), ("kind", i32), ("dtype", i32), ("act", i32),
-                ("q", vp), ("q_scale", vp), ("ldq", i64), ("lds_q", i64)]
+                ("q", vp), ("q_scale", vp), ("ldq", i64), ("lds_q", i64), ("out_dtype", i32)]
 
 
 class GroupNormArgs(C.Structure):

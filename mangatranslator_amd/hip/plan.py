@@ -284,14 +284,18 @@ class PlanBuilder:
         self._add(abi.OP_CONV2D, a, label)
         return out
 
-    def conv_tiles(self, x: Act, ksize=3, stride=1, cout=None, with_res=False) -> int:
+    def conv_tiles(self, x: Act, ksize=3, stride=1, cout=None, with_res=False, with_scale=False, act=abi.ACT_NONE, pixel_shuffle=0) -> int:
         """rows per image of the chan_sum buffer the conv with these arguments fills (which kernel runs — hence how many partial rows it
-        writes — depends on the channel counts and on whether a residual comes with the sums)"""
+        writes — depends on the channel counts, on whether a residual or output factors come with the sums, on the activation and the store form:
+        pass what the conv2d call will pass)"""
         a = abi.ConvArgs()
         a.n, a.h, a.w_in, a.cin, a.cout, a.ksize, a.stride = x.n, x.h, x.w, x.c, (cout if cout is not None else x.c), ksize, stride
         a.ldx, a.ldy, a.dtype = x.ld, (cout if cout is not None else x.c), self.dtype
         a.chan_sum = x.ptr                       # non-null markers: only their presence matters here
         a.res = x.ptr if with_res else None
+        a.ldres = a.ldy
+        a.out_scale = x.ptr if with_scale else None
+        a.act, a.pixel_shuffle = act, pixel_shuffle
         t = self.lib.mtx_conv2d_tiles(C.byref(a))
         if t < 0:
             raise ModelError(f"mtx_conv2d_tiles: {self.lib.last_error()}")
@@ -300,8 +304,10 @@ class PlanBuilder:
     def gemm(self, a_t, w_t, m, n, k, lda=None, ldw=None, out=None, ldc=None, bias=None, act=abi.ACT_NONE,
              res=None, ldres=None, gate=None, ldgate=None, gate_rows_per=1, alpha=1.0, batch=1,
              a_bs=0, w_bs=0, c_bs=0, res_bs=0, out_f32=False, a_off=0, w_off=0, c_off=0, res_off=0,
-             label="gemm", f8=None, flags=0, glu=None):
-        """f8 = (a_scale, lds_a, w_scale, lds_w, a_scale_off, w_scale_off): a_t / w_t are e4m3 byte matrices from `quantize` (offsets in
+             label="gemm", f8=None, flags=0, glu=None, w_lo=None, res_f32=False):
+        """w_lo: the low half of a weight pair W = w_t + w_lo (same layout as w_t; mtx_gemm_args.w_lo).  res_f32: `res` is an fp32 matrix
+        (needs out_f32; the fp32 residual stream of SAM's precision "high").
+        f8 = (a_scale, lds_a, w_scale, lds_w, a_scale_off, w_scale_off): a_t / w_t are e4m3 byte matrices from `quantize` (offsets in
         bytes), the epilogue operands and the output stay in the builder's 16-bit type (include/mtx_hip.h, in_dtype == MTX_F8).
         glu = (q, scale, ldq, lds, col0, row_off, q_col_off): the columns from col0 on are [32 a | 32 b] spans (`glu_interleave` order of
         w's rows) and land as the MX fp8 matrix silu(a) * b in rows [row_off, row_off + m) of q / scale from byte column q_col_off on
@@ -331,6 +337,11 @@ class PlanBuilder:
         g.gate_rows_per = gate_rows_per
         g.act, g.act_param, g.alpha = act, 0.0, alpha
         g.dtype, g.out_dtype = self.dtype, (abi.F32 if out_f32 else self.dtype)
+        if w_lo is not None:
+            g.w_lo = _ptr(w_lo, w_off)
+        if res_f32:
+            assert out_f32 and res is not None
+            g.res_dtype = abi.F32
         if ((m >= 2048 and n >= 1024 and k >= 512) or (m >= 256 and k >= 8192) or (flags & abi.GEMM_FORCE_TILE256)) and batch == 1 and not out_f32:
             # large problems: one shared scratch per plan for the K-slice tail of the 256-tile kernel (ops of a plan run in order)
             # (side-lane ops run beside main-lane ops: they get a scratch of their own)
@@ -366,8 +377,9 @@ class PlanBuilder:
 
     def norm(self, x, y, rows, c, ldx=None, ldy=None, gamma=None, beta=None, eps=1e-6, kind=0,
              mod_scale=None, mod_shift=None, rows_per=0, ldmod=0, x_off=0, y_off=0, act=abi.ACT_NONE,
-             label="norm", q8=None, q_row_off=0, lds_q=0, dtype=None):
-        """q8 = (q bytes [R, c], scale plane [c / 128, lds_q]): also (or, with y None, only) the MX fp8 twin of the result, rows landing
+             label="norm", q8=None, q_row_off=0, lds_q=0, dtype=None, out_dtype=0):
+        """out_dtype (dtype = abi.F32 only): the type y is written in — 0 = fp32, abi.BF16 / abi.F16 = rounded once to the next linear's operand type.
+        q8 = (q bytes [R, c], scale plane [c / 128, lds_q]): also (or, with y None, only) the MX fp8 twin of the result, rows landing
         at q_row_off (include/mtx_hip.h mtx_norm_args.q)"""
         a = abi.NormArgs()
         a.x, a.y = _ptr(x, x_off), (_ptr(y, y_off) if y is not None else None)
@@ -379,6 +391,7 @@ class PlanBuilder:
         a.rows, a.c, a.ldx, a.ldy = rows, c, (ldx or c), (ldy or c)
         a.rows_per, a.ldmod = rows_per, ldmod
         a.eps, a.kind, a.dtype, a.act = eps, kind, (self.dtype if dtype is None else dtype), act      # dtype = abi.F32: an fp32 op inside a 16-bit plan
+        a.out_dtype = out_dtype
         self._add(abi.OP_NORM, a, label)
         return y
 

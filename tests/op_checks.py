@@ -87,7 +87,7 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
         rb.t.copy_(res.permute(0, 2, 3, 1).to(td))
     cs = None
     if with_sum:
-        tiles = pb.conv_tiles(xb, ksize, stride, cout=cout, with_res=with_res)
+        tiles = pb.conv_tiles(xb, ksize, stride, cout=cout, with_res=with_res, with_scale=with_scale, act=act, pixel_shuffle=pixel_shuffle)
         cs = pb.buf((n, tiles, cout), torch.float32, zero=True)
         cs.fill_(777.0)          # the conv owns every row: stale values must not survive a launch (no memset in front of it)
     y = pb.conv2d(xb, wpk, bias, cout, ksize, stride, act=act, act_param=0.1, res=rb, res_scale=0.5,
@@ -878,23 +878,53 @@ def check_f32_ops(lib, seed=0):
 
 
 def check_hi_lo_weights(lib, dtype=abi.F16, m=300, n=96, k=144, seed=0):
-    """`Sam2Hip(precision="high")`'s weight trick at op level: W = W_hi + W_lo in the storage type, one GEMM over K' = 2K of [x | x] against
-    [W_hi | W_lo] with fp32 accumulation and fp32 output — against x @ W^T in float64 the error falls from the weights' rounding (2^-12
-    relative per weight) to fp32 accumulation noise"""
+    """`Sam2Hip(precision="high")`'s weight trick at op level: W = W_hi + W_lo in the storage type, both halves multiplied with the same
+    operand tile into one fp32 accumulator (mtx_gemm_args.w_lo, round 6; round 5 ran it as a GEMM over K' = 2K against a copied [x | x]) —
+    against x @ W^T in float64 the error falls from the weights' rounding (2^-12 relative per weight) to fp32 accumulation noise.  Also the
+    epilogue forms the trunk uses: fp32 output with an fp32 residual (the branch-closing linears of the fp32 residual stream), 16-bit output
+    with bias + GELU (fc1), and the pair form must agree with the 2K form up to fp32 summation order."""
     g = torch.Generator().manual_seed(seed)
     dev, td = _dev(lib), TD[dtype]
     x = torch.randn(m, k, generator=g).to(td)
     w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g)
+    r32 = torch.randn(m, n, generator=g)
     ref = (x.double() @ w.double().t()).float()
     w_hi = w.to(td)
     w_lo = (w - w_hi.float()).to(td)
     pb = PlanBuilder(lib, dev, dtype)
-    fast = pb.gemm(pb.const(x), pb.const(w_hi), m, n, k, out_f32=True)
+    xc, whc, wlc = pb.const(x), pb.const(w_hi), pb.const(w_lo)
+    fast = pb.gemm(xc, whc, m, n, k, out_f32=True)
+    high = pb.gemm(xc, whc, m, n, k, out_f32=True, w_lo=wlc)
     xx, ww = pb.const(torch.cat([x, x], 1)), pb.const(torch.cat([w_hi, w_lo], 1))
-    high = pb.gemm(xx, ww, m, n, 2 * k, out_f32=True)
-    high16 = pb.gemm(xx, ww, m, n, 2 * k)                 # 16-bit output: the form the qkv / fc1 linears use (large shapes: the 256-tile kernel)
+    high2k = pb.gemm(xx, ww, m, n, 2 * k, out_f32=True)
+    high16 = pb.gemm(xc, whc, m, n, k, w_lo=wlc, bias=pb.const(b), act=abi.ACT_GELU)                 # 16-bit output: the form the qkv / fc1 linears use
+    closed = pb.gemm(xc, whc, m, n, k, w_lo=wlc, bias=pb.const(b), res=pb.const(r32), res_f32=True, out_f32=True)      # stream <- res + x W^T + b, all fp32
     _run(pb)
     e_fast, e_high = _relerr(fast.cpu(), ref), _relerr(high.cpu(), ref)
     assert e_high < e_fast / 20 and e_high < 1e-5, (e_fast, e_high)          # what is left is fp32 accumulation over K (2.3e-6 at K = 1152 on the simulator)
-    assert _relerr(high16.cpu(), ref) < TOL[dtype]
+    assert _relerr(high.cpu(), high2k.cpu()) < 2e-6
+    assert _relerr(high16.cpu(), F.gelu(ref + b)) < TOL[dtype]
+    assert _relerr(closed.cpu(), ref + b + r32) < 1e-5
     return e_fast, e_high
+
+
+def check_norm_f32_to_16(lib, dtype=abi.F16, rows=37, c=576, seed=0):
+    """LayerNorm of an fp32 row written in the 16-bit operand type of the next linear (mtx_norm_args.out_dtype, round 6): equal to the fp32
+    result rounded once; widths on the register path (c % 4 == 0, c <= 1280) and off it"""
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    worst = 0.0
+    for cc in (c, 144, 1152, 1284, 75):
+        x = torch.randn(rows, cc, generator=g) * 3 + 0.5
+        gam, bet = torch.randn(cc, generator=g), torch.randn(cc, generator=g)
+        pb = PlanBuilder(lib, dev, dtype)
+        xc = pb.const(x, torch.float32)
+        y32 = pb.norm(xc, pb.buf((rows, cc), torch.float32), rows, cc, gamma=pb.const(gam, torch.float32), beta=pb.const(bet, torch.float32), eps=1e-6, dtype=abi.F32)
+        y16 = pb.norm(xc, pb.buf((rows, cc), td), rows, cc, gamma=pb.const(gam, torch.float32), beta=pb.const(bet, torch.float32), eps=1e-6, dtype=abi.F32, out_dtype=dtype)
+        _run(pb)
+        ref = F.layer_norm(x, (cc,), gam, bet, 1e-6)
+        assert _relerr(y32.cpu(), ref) < 2e-6
+        assert torch.equal(y16.cpu(), y32.cpu().to(td)), "16-bit norm output is not the fp32 result rounded once"
+        worst = max(worst, _relerr(y16.float().cpu(), ref))
+    return worst

@@ -160,7 +160,9 @@ def test_f32_ops(hip_lib):
 def test_hi_lo_weight_pairs(hip_lib):
     """W = W_hi + W_lo as ONE GEMM over K' = 2K ([x | x] against [W_hi | W_lo], fp32 accumulation): SAM's trunk under precision 'high'"""
     oc.check_hi_lo_weights(hip_lib)
-    oc.check_hi_lo_weights(hip_lib, m=4096, n=2304, k=576)          # Hiera-L stage 3, fc1: the 256-tile kernel takes the 16-bit-output form (K' = 1152)
+    oc.check_hi_lo_weights(hip_lib, m=4096, n=2304, k=576)          # Hiera-L stage 3, fc1
+    oc.check_hi_lo_weights(hip_lib, dtype=abi.BF16, m=1024, n=1152, k=4608, seed=1)
+    assert oc.check_norm_f32_to_16(hip_lib, abi.F16) < 1e-3
 
 
 def test_activation_epilogues_at_extreme_values(hip_lib):

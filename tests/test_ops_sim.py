@@ -244,6 +244,11 @@ def test_f32_ops(emu_lib):
     assert oc.check_f32_ops(emu_lib) < 2e-5
 
 
+def test_norm_f32_row_to_16_bit_operand(emu_lib):
+    assert oc.check_norm_f32_to_16(emu_lib, abi.F16) < 1e-3
+    assert oc.check_norm_f32_to_16(emu_lib, abi.BF16, rows=9) < 8e-3
+
+
 def test_hi_lo_weight_pairs(emu_lib):
     e_fast, e_high = oc.check_hi_lo_weights(emu_lib)
     assert e_fast > 1e-5            # the weights' rounding is what the fast form is left with

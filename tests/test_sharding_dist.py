@@ -52,8 +52,14 @@ def _worker(rank, world, port, out_dir):
                                        lambda n, v: v.copy_(torch.full(v.shape, float(len(n) + sum(map(ord, n)) % 7 + (0 if rank == 0 else 100)))), "cpu", bucket_bytes=600)
     finally:
         dist.broadcast = real_bcast
-    assert calls == [640, 256, 128, 48], calls                      # bf16: 1280 B alone, 2 x 256 B together (a third would pass 600 B), the last alone; fp32: one bucket
+    assert calls == [640, 256, 128, 128], calls                     # bf16: 1280 B alone, 2 x 256 B together (a third would pass 600 B), the last alone; fp32: one bucket of two 256-byte entries
     assert all(float(got[n].float().max()) == float(len(n) + sum(map(ord, n)) % 7) and tuple(got[n].shape) == s for n, s in big.items())
+    # 2b'. an odd-length 16-bit entry ahead of a matrix (the real VAE's bf16 decoder.conv_out.bias, 6 bytes: ADVICE r05) must not shift the matrix
+    # off a 16-byte boundary — the GEMM kernels take 16-byte vector loads and LDS-DMA from these views
+    odd = [("conv_out.bias", (3,), torch.bfloat16), ("mid.to_q.weight", (16, 16), torch.bfloat16), ("x", (5,), torch.bfloat16), ("mid.to_k.weight", (16, 16), torch.bfloat16)]
+    got = fxm.broadcast_in_buckets(odd, lambda n, v: v.copy_(torch.full(v.shape, float(len(n)))), "cpu")
+    assert all(got[n].data_ptr() % 16 == 0 for n, _, _ in odd), [got[n].data_ptr() % 256 for n, _, _ in odd]
+    assert all(float(got[n].float().min()) == float(len(n)) == float(got[n].float().max()) for n, _, _ in odd)
 
     # 2c. worker threads under a process group: the ranks' threads ask the loaders in DIFFERENT orders; inside
     # `thread_local_reads` every call reads its file itself — no collective, so nothing can hang or cross-wire — while the same calls on
