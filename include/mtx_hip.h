@@ -135,8 +135,6 @@ typedef struct mtx_gemm_args {
 } mtx_gemm_args;
 #define MTX_GEMM_FORCE_TILE256 1   /* use the 256-tile LDS-DMA kernel whatever the tile count (small-shape tests of that kernel) */
 #define MTX_GEMM_NO_SPLIT 2        /* never hand left-over tiles to the K-slice tail */
-#define MTX_GEMM_F8_WIDE 4         /* fp8 whole-tile kernel: one segment per k-step (8 MFMAs, half the barriers) — a measurement switch, see csrc/gemm.hip */
-#define MTX_GEMM_SERIAL_EPILOGUE 8 /* 256-tile kernels: the epilogue of rounds 1-5a (bias / gate / residual requested one at a time) — identical bytes, a measurement switch */
 #define MTX_GEMM_SLICES(n) ((n) << 8) /* tuning: cut the left-over tiles into exactly n K slices (2..255) instead of the launcher's choice */
 #define MTX_GEMM_WORKSPACE_BYTES (2 * 320 * 256 * 256 * 4)
 
@@ -164,13 +162,6 @@ typedef struct mtx_attn_args {
  * is ignored, scores are used as base-2 logits as they come out of the matrix pipe.  The long-sequence kernel then seeds its score
  * accumulators with minus the running maximum and needs no per-score multiply-add. */
 #define MTX_ATTN_Q_PRESCALED 1
-/* bits 8..14 of `flags`: schedule of the long-sequence kernel (pre-scaled q, 16-bit output only; ignored elsewhere).  0 = the default.
- * s in 1..64 selects attn_x_kernel<s - 1> (csrc/attention.hip, bf16; a measured subset is instantiated): K / V by LDS-DMA, + 1 = half-tile stagger
- * of the two wave groups, + 2 = row sums on the matrix pipe, + 4 = 16-byte row stores, + 8 = K / V staged through registers like the default
- * kernel, + 16 = fragment reads four steps ahead of the MFMAs.  68 = the tuned kernel with 16-byte row stores and fragment reads four steps ahead
- * (what 0 selects when the output rows are 16-byte aligned), 65 = 16-byte stores only, 66 = 65 + matrix-pipe row sums, 67 = the round-4 kernel.  Same results up to the
- * summation order of the row sums.  Tuning / measurement switches: tools/bench_kernels.py attnx, profiles/r05_visit_*attention*.log. */
-#define MTX_ATTN_SCHEDULE_SHIFT 8
 #define MTX_ATTN_WORKSPACE_BYTES (256 * (256 * 128 * 4 + 256 * 2 * 4))
 
 /* row-wise normalisation over the last dim C of [rows, C] (row stride ld):
@@ -186,8 +177,9 @@ typedef struct mtx_norm_args {
    * E8M0 scale plane q_scale[(c / 128) * lds_q + row], quantised from the result as rounded to `dtype` — bit-identical to running
    * mtx_quantize_mx on y.  With q given, y may be NULL (no 16-bit consumer: the 16-bit store is skipped).  C % 128 == 0. */
   void* q; void* q_scale; int64_t ldq, lds_q;
-  /* ABI 8.  dtype == MTX_F32 only: the type y is written in — 0 / MTX_F32 = fp32, MTX_BF16 / MTX_F16 = the 16-bit operand of the
-   * linear that follows (an fp32 residual stream is normalised in fp32 and rounded once, by the kernel that produced the value) */
+  /* ABI 8.  dtype == MTX_F32 only (ignored otherwise): the type y is written in — MTX_F32, or MTX_BF16 / MTX_F16 = the 16-bit operand of
+   * the linear that follows (an fp32 residual stream is normalised in fp32 and rounded once, by the kernel that produced the value).
+   * MTX_BF16 is 0: a caller of the fp32 norm must SET this field (MTX_F32 for the round-4 behaviour). */
   int32_t out_dtype;
 } mtx_norm_args;
 
@@ -466,10 +458,6 @@ MTX_API int mtx_gemm(const mtx_gemm_args* a, void* stream);
 MTX_API int mtx_gemm_last_split(int* whole_tiles, int* k_slices, int* tail_pieces);
 MTX_API int mtx_attention(const mtx_attn_args* a, void* stream);
 MTX_API int mtx_norm(const mtx_norm_args* a, void* stream);
-/* which row-normalisation kernel THIS THREAD's mtx_norm launches (and plan norm ops issued from it) use: 2 = rows kept packed between the
- * passes and the adaLN modulation rows requested before the statistics (the default), 1 = packed rows only, 3 = form 2 held to 96 registers,
- * 0 = the fp32-register form of rounds 1-4, -1 = back to the default (environment MTX_NORM_FORM=0..3 selects a form process-wide).  Both forms give identical bytes; a test / measurement switch. */
-MTX_API int mtx_norm_form(int form);
 MTX_API int mtx_groupnorm(const mtx_groupnorm_args* a, void* stream);
 MTX_API int mtx_elementwise(const mtx_ew_args* a, void* stream);
 MTX_API int mtx_channel_attention(const mtx_ca_args* a, void* stream);

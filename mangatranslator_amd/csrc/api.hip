@@ -18,7 +18,6 @@ int gemm_launch(const mtx_gemm_args*, void*, const char**);
 void gemm_last_split(int*);
 int attn_launch(const mtx_attn_args*, void*, const char**);
 int norm_launch(const mtx_norm_args*, void*, const char**);
-void norm_set_form(int);
 int groupnorm_launch(const mtx_groupnorm_args*, void*, const char**);
 int ew_launch(const mtx_ew_args*, void*, const char**);
 int ca_launch(const mtx_ca_args*, void*, const char**);
@@ -237,11 +236,6 @@ MTX_OP_ENTRY(mtx_detr, mtx_detr_args, detr_launch)
 MTX_OP_ENTRY(mtx_quantize_mx, mtx_quant_args, quant_launch)
 MTX_OP_ENTRY(mtx_page_tail, mtx_tail_args, tail_launch)
 
-int mtx_norm_form(int form) {
-  if (form < -1 || form > 3) return fail(MTX_ERR_INVALID, "mtx_norm_form: form must be -1 … 3");
-  norm_set_form(form);
-  return MTX_OK;
-}
 
 int mtx_gemm_last_split(int* whole_tiles, int* k_slices, int* tail_pieces) {
   int v[3];

@@ -30,7 +30,6 @@ struct AttnParams {
   int prescaled;                 // q carries scale * log2(e): scale_log2 == 1
   // MX fp8 output of the long-sequence kernel (mtx_attn_args.q8): bytes [sq][ldq8] (head h at byte column h * d), scale words [heads * d / 128][lds_q8]
   unsigned char* q8; unsigned* q8_scale; long ldq8, lds_q8;
-  int schedule;                  // MTX_ATTN_SCHEDULE bits of the flags: 0 = the default kernel, s > 0 = attn_x_kernel<VAR = s - 1>
 };
 
 constexpr int AT_KV = 64;      // keys per tile
@@ -501,80 +500,9 @@ __device__ __forceinline__ void half_pair_exchange(uint32_t& a, uint32_t& b) {
 #endif
 }
 
-// Tile step with the row sums on the matrix pipe (round 5): attn_bias_tile's NOMAX form without its 32 v_add per tile — an all-ones A
-// fragment against the P^T operand the P V product reads anyway puts the row sum into every row of `lacc` (one more 32x32x16 MFMA per 16
-// keys: + 12.5 % matrix work for - 1/3 of the loop's vector instructions).  The running maximum is the FIRST tile's; nothing on the hot
-// path looks at the probabilities' size (bf16 keeps fp32's exponent range and its relative precision), the caller checks the finished row
-// sums and redoes the block with the classic form when they left the safe range.  bf16 only (f16 probabilities would saturate unseen).
-template <typename T, int DP, int STAGE, bool RAGGED>
-__device__ __forceinline__ void attn_bias_tile_ms(unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&oacc)[DP / 32], f32x16& lacc,
-                                                  float& M, f32x16& minit, bool& first,
-                                                  const int (&kaddr)[DP / 16], const int (&vaddr)[DP / 32], const long kvalid, const int hi) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
-  const unsigned char* Vs = Ks + TILE_B;
-  f32x16 sacc[2];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const v8 kf = *reinterpret_cast<const v8*>(Ks + kaddr[ks] + kb * 32 * ROWB);
-      if (ks == 0) Mma32Pinned<T>::set_from(sacc[kb], kf, qf[ks], minit);
-      else sacc[kb] = Mma32<T>::mfma(kf, qf[ks], sacc[kb]);
-    }
-  if (RAGGED) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) sacc[kb][r] = -1.0e30f;
-  }
-  if (__builtin_expect(first, 0)) {            // (wave-uniform) M <- the first tile's maximum; O^T and the sums are still zero
-    float tmax = fmaxf(sacc[0][0], sacc[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
-    tmax = half_max(tmax);
-    M += tmax;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] -= tmax;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) minit[r] = -M;
-    first = false;
-  }
-  v8 pb[2][2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pb[kb][r >> 3][r & 7] = from_f32<T>(fast_exp2(sacc[kb][r]));
-  v8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = from_f32<T>(1.0f);
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const unsigned char* a = Vs + vaddr[d] + (kb * 32 + s2 * 16) * ROWB;
-        const v4 lo = lds_read_tr16<T>(a);
-        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-        v8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
-        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
-      }
-      lacc = Mma32<T>::mfma(ones, pb[kb][s2], lacc);
-    }
-}
-
 #define ATTN_MMA32_NAME attn_mma32_kernel
 #define ATTN_MMA32_Q8 0
 #define ATTN_MMA32_WIDE 0
-#define ATTN_MMA32_MATSUM 0
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
 #undef ATTN_MMA32_Q8
@@ -586,530 +514,16 @@ __device__ __forceinline__ void attn_bias_tile_ms(unsigned char* smem, const typ
 #define ATTN_MMA32_NAME attn_mma32_q8d_kernel
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
-#undef ATTN_MMA32_DEEP
 #undef ATTN_MMA32_Q8
 #undef ATTN_MMA32_WIDE
 #define ATTN_MMA32_Q8 0
 #define ATTN_MMA32_WIDE 1
-#define ATTN_MMA32_NAME attn_mma32_w_kernel
-#include "attn_mma32_body.inc"
-#undef ATTN_MMA32_NAME
-#define ATTN_MMA32_DEEP 0x44
 #define ATTN_MMA32_NAME attn_mma32_d_kernel
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
 #undef ATTN_MMA32_DEEP
-#undef ATTN_MMA32_MATSUM
-#define ATTN_MMA32_MATSUM 1
-#define ATTN_MMA32_NAME attn_mma32_ms_kernel
-#include "attn_mma32_body.inc"
-#undef ATTN_MMA32_NAME
-#undef ATTN_MMA32_MATSUM
 #undef ATTN_MMA32_WIDE
 #undef ATTN_MMA32_Q8
-
-// =====================================================================================================
-// Round 5: alternative schedules of the long-sequence kernel (mtx_attn_args.flags, MTX_ATTN_SCHEDULE bits), built to be measured
-// against the kernel above in one process (tools/bench_kernels.py attnx).  Same tile shape, fragment layouts, swizzles, key-split tail
-// and partial format; what changes:
-//   * K / V tiles arrive by LDS-DMA (buffer_load ... lds, one 1 KB piece = four 256-byte rows per wave instruction, the swizzle applied
-//     to the lane's SOURCE chunk) instead of global -> registers -> ds_write: no staging registers (44 VGPRs), no LDS write instructions;
-//   * AX_STAGGER: the workgroup's two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run half a tile apart, two barriers per
-//     tile: while one group issues the 16 S^T MFMAs of tile u, the other runs softmax + P V of tile u - 1 — one wave's exponentials under
-//     its SIMD partner's matrix work instead of both waves' softmax at the same time (MI355X_MICROARCH.md "Two waves per SIMD");
-//     K(u + 1) is issued in the first half-tile phase of tile u, V(u + 1) in the second, each landing a full phase later (vmcnt(2)
-//     before every barrier: all but the two pieces issued in the phase that is ending);
-//   * AX_MATSUM: the row sums come from the matrix pipe (an all-ones A fragment: one more 32x32x16 MFMA per 16 keys) instead of 32
-//     v_add per tile; the running maximum is taken on the first tile only and the block is REDONE with the classic online softmax
-//     when a row sum ends up non-finite or above 1e30 (bf16 probabilities keep fp32's exponent range, so a stale maximum costs no precision
-//     before that); bf16 only;
-//   * AX_WIDE: the 16-bit rows leave as 8 x 16-byte stores per lane (lanes l and l ^ 32 trade two dwords by v_permlane32_swap)
-//     instead of 16 x 8-byte stores.
-constexpr int AX_STAGGER = 1, AX_MATSUM = 2, AX_WIDE = 4, AX_STAGED = 8, AX_DEEP = 16;
-
-#ifdef MTX_EMU
-#define AX_BAR(N) __syncthreads()
-#else
-#define AX_BAR(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)      /* fenced on both sides: MFMAs are not memory operations and would drift across the asm */
-#endif
-
-#ifdef MTX_EMU
-#define AX_PIN(x) ((void)0)
-#else
-#define AX_PIN(x) asm volatile("" : "+v"(x))
-#endif
-
-// base ^ C as its own instruction at the point of use (never hoisted, never kept): the fragment addresses of one operand differ by an XOR
-// of a few swizzle bits, and eleven loop-invariant address registers were what this kernel spilled
-template <int C>
-__device__ __forceinline__ int xor_here(int base) {
-  if (C == 0) return base;
-#ifdef MTX_EMU
-  return base ^ C;
-#else
-  int r;
-  asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "v"(base), "v"(C));
-  return r;
-#endif
-}
-
-#ifdef MTX_EMU
-#define AX_GROUP(mask, n) ((void)0)
-#else
-#define AX_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#endif
-constexpr int AX_SG_MFMA = 0x008, AX_SG_DS_READ = 0x100;
-
-template <typename T, int DP, int STAGE, bool DEEP = false>
-__device__ __forceinline__ void attn_x_scores(const unsigned char* smem, const typename Traits<T>::v8 (&qf)[DP / 16], f32x16 (&sacc)[2],
-                                              const f32x16& minit, const int kaddr0) {
-  typedef typename Traits<T>::v8 v8;
-  constexpr int KS = DP / 16, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
-  if constexpr (DEEP) {
-    // AX_DEEP: the K fragments of four k-steps (eight 16-byte reads) are in flight before the first MFMA and stay four steps ahead, so the
-    // 16 MFMAs of a tile issue back to back (512 cycles) instead of each pair waiting one LDS round trip (two reads in flight: ~1 500
-    // cycles when the wave has the SIMD's matrix pipe to itself, which is what the staggered schedule gives it).  The order is pinned
-    // with sched_group_barrier; the seed MFMAs are builtins here (the scheduler cannot classify inline asm).
-    static_assert(KS == 8, "pipeline written for eight k-steps");
-    v8 kf[KS][2];
-    int ka[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      ka[ks] = ks == 0 ? kaddr0 : ks == 1 ? xor_here<1 << 5>(kaddr0) : ks == 2 ? xor_here<2 << 5>(kaddr0) : ks == 3 ? xor_here<3 << 5>(kaddr0) :
-               ks == 4 ? xor_here<4 << 5>(kaddr0) : ks == 5 ? xor_here<5 << 5>(kaddr0) : ks == 6 ? xor_here<6 << 5>(kaddr0) : xor_here<7 << 5>(kaddr0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) kf[ks][kb] = *reinterpret_cast<const v8*>(Ks + ka[ks] + kb * 32 * ROWB);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) sacc[kb] = Mma32<T>::mfma(kf[ks][kb], qf[ks], ks == 0 ? minit : sacc[kb]);
-    AX_GROUP(AX_SG_DS_READ, 8);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { AX_GROUP(AX_SG_MFMA, 2); AX_GROUP(AX_SG_DS_READ, 2); }
-    AX_GROUP(AX_SG_MFMA, 8);
-    return;
-  }
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int ka = ks == 0 ? kaddr0 : ks == 1 ? xor_here<1 << 5>(kaddr0) : ks == 2 ? xor_here<2 << 5>(kaddr0) : ks == 3 ? xor_here<3 << 5>(kaddr0) :
-                   ks == 4 ? xor_here<4 << 5>(kaddr0) : ks == 5 ? xor_here<5 << 5>(kaddr0) : ks == 6 ? xor_here<6 << 5>(kaddr0) : xor_here<7 << 5>(kaddr0);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const v8 kf = *reinterpret_cast<const v8*>(Ks + ka + kb * 32 * ROWB);
-      if (ks == 0) Mma32Pinned<T>::set_from(sacc[kb], kf, qf[ks], minit);
-      else sacc[kb] = Mma32<T>::mfma(kf, qf[ks], sacc[kb]);
-    }
-  }
-}
-
-// softmax of the S^T accumulators (seeded with minus the running maximum M, log2 units) and O^T += V^T P^T.
-// !MATSUM: attn_bias_tile's NOMAX form (partial row sums flag a stale maximum).  MATSUM && !EXACT: maximum on the first tile only, sums on
-// the matrix pipe (lacc: every row of the block is the row sum).  MATSUM && EXACT: maximum every tile, refreshed when it grew by > 2^8.
-template <typename T, int DP, int STAGE, bool RAGGED, bool MATSUM, bool EXACT, bool DEEP = false>
-__device__ __forceinline__ void attn_x_softmax_pv(const unsigned char* smem, f32x16 (&sacc)[2], f32x16 (&oacc)[DP / 32], f32x16& lacc,
-                                                  float& M, float& lsum, f32x16& minit, bool& first,
-                                                  const int vaddr0, const long kvalid, const int hi) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  static_assert(DB == 4, "four 32-row blocks of O^T");
-  const unsigned char* Vs = smem + STAGE * 2 * TILE_B + TILE_B;
-  if (RAGGED) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) sacc[kb][r] = -1.0e30f;
-  }
-  auto row_max = [&]() {
-    float tmax = fmaxf(sacc[0][0], sacc[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
-    return half_max(tmax);
-  };
-  auto refresh = [&](float tmax) {             // M moves to the tile's maximum (first tile) or up by the growth; everything accumulated so far shrinks with it
-    const float delta = first ? tmax : fmaxf(tmax, 0.f);
-    const float alpha = fast_exp2(-delta);
-    M += delta;
-    lsum *= alpha;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-    if (MATSUM) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-    }
-    first = false;
-    return delta;
-  };
-  // the seed tuple follows M as the LAST step of a refresh, after the probabilities have been recomputed: its old registers are then live
-  // through the whole cold path and the new value can only land in them (redefined early, the allocator reused them for the cold path's
-  // temporaries and reconciled the two paths by spilling the tuple on the HOT path: 14 scratch stores + loads per two tiles)
-  auto reseed = [&]() {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) minit[r] = -M;
-    AX_PIN(minit);                             // ONE 16-register value from here on (not 16 scalars gathered in front of every MFMA that reads it)
-  };
-  v8 pb[2][2];
-  if (MATSUM) {
-    if (EXACT || __builtin_expect(first, 0)) {                      // (wave-uniform)
-      const float tmax = row_max();
-      if (__builtin_expect(first || __any(tmax > 8.0f), 0)) {
-        const float delta = refresh(tmax);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
-        reseed();
-      }
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pb[kb][r >> 3][r & 7] = from_f32<T>(fast_exp2(sacc[kb][r]));
-  } else {
-    float tsum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = fast_exp2(sacc[kb][r]);
-        tsum += pv;
-        pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
-      }
-    if (__builtin_expect(first || __any(!(tsum < AttnSumLimit<T>::v)), 0)) {      // cold: the allocator should spill here, not on the hot path
-      const float delta = refresh(row_max());
-      tsum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = fast_exp2(sacc[kb][r] - delta);
-          tsum += pv;
-          pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
-        }
-      reseed();
-    }
-    lsum += tsum;
-  }
-  v8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = from_f32<T>(1.0f);
-  if constexpr (DEEP && !MATSUM) {
-    // AX_DEEP: the V^T fragments of four MFMAs (eight transpose reads) ahead of the matrix pipe; same order of the 16 MFMAs as below
-    int va[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d) va[d] = d == 0 ? vaddr0 : d == 1 ? xor_here<1 << 6>(vaddr0) : d == 2 ? xor_here<2 << 6>(vaddr0) : xor_here<3 << 6>(vaddr0);
-    v8 vf[4][DB];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const unsigned char* a = Vs + va[d] + ((g >> 1) * 32 + (g & 1) * 16) * ROWB;
-        const v4 lo = lds_read_tr16<T>(a);
-        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-        vf[g][d][0] = lo[0]; vf[g][d][1] = lo[1]; vf[g][d][2] = lo[2]; vf[g][d][3] = lo[3];
-        vf[g][d][4] = hv[0]; vf[g][d][5] = hv[1]; vf[g][d][6] = hv[2]; vf[g][d][7] = hv[3];
-      }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int d = 0; d < DB; ++d) oacc[d] = Mma32<T>::mfma(vf[g][d], pb[g >> 1][g & 1], oacc[d]);
-    AX_GROUP(AX_SG_DS_READ, 8);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { AX_GROUP(AX_SG_MFMA, 1); AX_GROUP(AX_SG_DS_READ, 2); }
-    AX_GROUP(AX_SG_MFMA, 4);
-    return;
-  }
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const int va = d == 0 ? vaddr0 : d == 1 ? xor_here<1 << 6>(vaddr0) : d == 2 ? xor_here<2 << 6>(vaddr0) : xor_here<3 << 6>(vaddr0);
-        const unsigned char* a = Vs + va + (kb * 32 + s2 * 16) * ROWB;
-        const v4 lo = lds_read_tr16<T>(a);
-        const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-        v8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hv[0]; vf[5] = hv[1]; vf[6] = hv[2]; vf[7] = hv[3];
-        oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
-      }
-      if (MATSUM) lacc = Mma32<T>::mfma(ones, pb[kb][s2], lacc);
-    }
-}
-
-template <typename T, int DP, int VAR>
-__global__ __launch_bounds__(512) void attn_x_kernel(AttnParams p) {
-  constexpr bool STAGGER = (VAR & AX_STAGGER) != 0, MATSUM = (VAR & AX_MATSUM) != 0, WIDE = (VAR & AX_WIDE) != 0, STAGED = (VAR & AX_STAGED) != 0, DEEP = (VAR & AX_DEEP) != 0;
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int KS = DP / 16, DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
-  static_assert(DP == 128, "swizzles and the DMA piece map are written for 256-byte rows");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B];
-  __shared__ int redo_flag;
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  int wvs = wv;
-#ifndef MTX_EMU
-  wvs = __builtin_amdgcn_readfirstlane(wv);
-#endif
-  unsigned vb, part = 0, nparts = 1;
-  if (blockIdx.x < p.n_full) vb = xcd_remap(blockIdx.x, p.n_full);
-  else { const unsigned i = blockIdx.x - p.n_full; vb = p.n_full + i / p.split; part = i % p.split; nparts = p.split; }
-  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
-  const long b = bh / p.heads, h = bh % p.heads;
-  const long q0 = qb * AB_QB + wv * 32;
-  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
-  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
-  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
-  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
-
-  v8 qf[KS];
-  {
-    const long qr = q0 + l31;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-      if (qr < p.sq) raw = *reinterpret_cast<const u32x4*>(Q + qr * p.q_ss + ks * 16 + hi * 8);
-      qf[ks] = __builtin_bit_cast(v8, raw);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(to_f32(qf[ks][e]) * p.scale_log2);
-    }
-  }
-
-  // fragment addresses of k-step 0 / O^T block 0; the others are this ^ (ks << 5) / ^ (d << 6): the swizzle terms only touch those bits
-  int kaddr0 = l31 * ROWB + ((hi ^ (l31 & 15)) << 4);
-  int vaddr0;
-  {
-    const int ti = lane & 15, g1 = (lane >> 4) & 1;
-    const int vrow = hi * 4 + (ti >> 2);
-    vaddr0 = vrow * ROWB + (((2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
-  }
-
-  const long ntiles_all = (p.sk + AB_KV - 1) / AB_KV;
-  const long t_begin = part * ntiles_all / nparts, t_end = (part + 1) * ntiles_all / nparts;
-  const long nt = t_end - t_begin;
-  const long kv_last = t_end == ntiles_all ? p.sk - (ntiles_all - 1) * AB_KV : AB_KV;
-
-  // ---- LDS-DMA: piece j of this wave = rows 4 (wv + 8 j) .. + 3 of a tile; lane l -> row (l >> 4) of the piece, LDS chunk l & 15, which
-  // holds the row's chunk (l & 15) ^ swizzle(row).  The tile position travels in the lane offset (inside the descriptor's range check:
-  // rows >= sk read as zeros).
-  const BufView kbuf = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
-  const BufView vbuf = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
-  unsigned kofs[2], vofs[2];
-  auto first_tile_offsets = [&]() {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const unsigned row = 4u * (unsigned)(wv + 8 * j) + ((unsigned)lane >> 4), c = (unsigned)lane & 15u;
-      kofs[j] = (((unsigned)t_begin * AB_KV + row) * (unsigned)p.k_ss + ((c ^ (row & 15u)) << 3)) * (unsigned)sizeof(T);
-      vofs[j] = (((unsigned)t_begin * AB_KV + row) * (unsigned)p.v_ss + ((c ^ ((row & 3u) << 2)) << 3)) * (unsigned)sizeof(T);
-#ifndef MTX_EMU
-      // opaque 32-bit lane values from here on: left to itself the optimiser keeps 64-bit bases + a scalar induction variable, spills the
-      // bases and reloads them in front of every DMA issue — with the vmcnt(0) such a reload brings (one exposed round trip per tile)
-      asm volatile("" : "+v"(kofs[j]), "+v"(vofs[j]));
-#endif
-    }
-  };
-  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
-  auto dma_k = [&](int stage) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { buf_load16_lds(kbuf, kofs[j], 0u, smem + stage * 2 * TILE_B + (wvs + 8 * j) * 1024); kofs[j] += k_step; AX_PIN(kofs[j]); }
-  };
-  auto dma_v = [&](int stage) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { buf_load16_lds(vbuf, vofs[j], 0u, smem + stage * 2 * TILE_B + TILE_B + (wvs + 8 * j) * 1024); vofs[j] += v_step; AX_PIN(vofs[j]); }
-  };
-
-  // AX_STAGED: the default kernel's transport instead — global -> registers at the start of a tile (phase A), registers -> LDS at its end (phase B)
-  constexpr int CPR = DP / 8, NLD = AB_KV * CPR / 512;
-  unsigned kvoff[NLD], vvoff[NLD];
-  int ksw[NLD], vsw[NLD];
-  u32x4 rk[NLD], rv[NLD];
-  unsigned tile_next = 0;
-  if (STAGED) {
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      const int idx = tid + it * 512;
-      const int ch = idx % CPR, row = idx / CPR;
-      kvoff[it] = (unsigned)((row * p.k_ss + ch * 8) * sizeof(T));
-      vvoff[it] = (unsigned)((row * p.v_ss + ch * 8) * sizeof(T));
-      ksw[it] = row * ROWB + ((ch ^ (row & 15)) << 4);
-      vsw[it] = TILE_B + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4);
-    }
-  }
-  auto load_tile = [&]() {
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      rk[it] = buf_load16(kbuf, kvoff[it], tile_next * k_step);
-      rv[it] = buf_load16(vbuf, vvoff[it], tile_next * v_step);
-    }
-    ++tile_next;
-  };
-  auto store_tile = [&](int stage) {
-#pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      *reinterpret_cast<u32x4*>(smem + stage * 2 * TILE_B + ksw[it]) = rk[it];
-      *reinterpret_cast<u32x4*>(smem + stage * 2 * TILE_B + vsw[it]) = rv[it];
-    }
-  };
-  // transport hooks of the tile loop.  One barrier per tile: `tile_begin(next stage)` ... `tile_end(next stage)`; staggered: phase A
-  // (`a_begin` ... `a_end`) and phase B (`b_begin` ... `b_end`) of the same tile
-  auto tile_begin = [&](int st) { if (STAGED) load_tile(); else { dma_k(st); dma_v(st); } };
-  auto lds_bar = [&]() {
-#ifndef MTX_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    MTX_LDS_BARRIER();
-#ifndef MTX_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-  };
-  auto tile_end = [&](int st) { if (STAGED) { store_tile(st); lds_bar(); } else AX_BAR(0); };
-  auto a_begin = [&](int st) { if (STAGED) load_tile(); else dma_k(st); };
-  auto a_end = [&]() { if (STAGED) lds_bar(); else AX_BAR(2); };
-  auto b_begin = [&](int st) { if (!STAGED) dma_v(st); };
-  auto b_end = [&](int st) { if (STAGED) { store_tile(st); lds_bar(); } else AX_BAR(2); };
-
-  f32x16 oacc[DB], lacc, minit, sacc[2];
-  float M, lsum;
-  bool first;
-  if (tid == 0) redo_flag = 0;
-
-  auto run_block = [&](auto exact_c) {
-    constexpr bool EXACT = decltype(exact_c)::value;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { if (MATSUM) lacc[r] = 0.f; minit[r] = 0.f; }
-    AX_PIN(minit);
-    M = 0.f; lsum = 0.f; first = true;
-    first_tile_offsets();
-#define AX_S(ST) attn_x_scores<T, DP, ST, DEEP>(smem, qf, sacc, minit, kaddr0)
-#define AX_PV(ST, RAG, KV) attn_x_softmax_pv<T, DP, ST, RAG, MATSUM, EXACT, DEEP>(smem, sacc, oacc, lacc, M, lsum, minit, first, vaddr0, KV, hi)
-#define AX_PV_LAST(ST) do { if (kv_last < AB_KV) AX_PV(ST, true, kv_last); else AX_PV(ST, false, AB_KV); } while (0)
-    if (STAGED) { tile_next = (unsigned)t_begin; load_tile(); store_tile(0); }
-    else { dma_k(0); dma_v(0); MTX_WAIT_VMEM(); }
-    __syncthreads();
-    if (!STAGGER) {
-      // one barrier per tile: tile u + 1 flies into the other stage behind tile u's S^T, softmax and P V
-      long u = 0;
-      for (; u + 2 < nt; u += 2) {
-        tile_begin(1); AX_S(0); AX_PV(0, false, AB_KV); tile_end(1);
-        tile_begin(0); AX_S(1); AX_PV(1, false, AB_KV); tile_end(0);
-      }
-      if (nt - u == 2) {
-        tile_begin(1); AX_S(0); AX_PV(0, false, AB_KV); tile_end(1);
-        AX_S(1); AX_PV_LAST(1);
-      } else {
-        AX_S(0); AX_PV_LAST(0);
-      }
-    } else if (wvs < 4) {
-      // group 0: phase A_u = S^T(u), phase B_u = softmax + P V (u)
-      long u = 0;
-      for (; u + 2 < nt; u += 2) {
-        a_begin(1); AX_S(0); a_end();
-        b_begin(1); AX_PV(0, false, AB_KV); b_end(1);
-        a_begin(0); AX_S(1); a_end();
-        b_begin(0); AX_PV(1, false, AB_KV); b_end(0);
-      }
-      if (nt - u == 2) {
-        a_begin(1); AX_S(0); a_end();
-        b_begin(1); AX_PV(0, false, AB_KV); b_end(1);
-        a_begin(0); AX_S(1); a_end();
-        b_begin(0); AX_PV_LAST(1); b_end(0);
-      } else {
-        a_begin(1); AX_S(0); a_end();
-        b_begin(1); AX_PV_LAST(0); b_end(1);
-      }
-    } else {
-      // group 1, half a tile behind: phase A_u = softmax + P V (u - 1), phase B_u = S^T(u); the last P V runs after the last barrier
-      a_begin(1); a_end();
-      b_begin(1); AX_S(0); b_end(1);
-      long u = 1;
-      for (; u + 1 < nt; u += 2) {
-        a_begin(0); AX_PV(0, false, AB_KV); a_end();
-        b_begin(0); AX_S(1); b_end(0);
-        a_begin(1); AX_PV(1, false, AB_KV); a_end();
-        b_begin(1); AX_S(0); b_end(1);
-      }
-      if (u < nt) {
-        a_begin(0); AX_PV(0, false, AB_KV); a_end();
-        b_begin(0); AX_S(1); b_end(0);
-        AX_PV_LAST(1);
-      } else {
-        AX_PV_LAST(0);
-      }
-    }
-    MTX_WAIT_VMEM();      // pieces issued past the last tile (they land in a stage nobody reads again) retire before the stages are refilled or the wave ends
-#undef AX_S
-#undef AX_PV
-#undef AX_PV_LAST
-  };
-
-  run_block(std::false_type());
-  float l = MATSUM ? lacc[0] : half_sum(lsum);
-  if (MATSUM) {
-    // a row sum that left the safe range means the first tile's maximum was too stale for this block: once more, classic online softmax
-    const bool bad = !(l < 1.0e30f);
-    if (__any(bad) && lane == 0) redo_flag = 1;
-    __syncthreads();
-    if (redo_flag) {
-      run_block(std::true_type());
-      l = lacc[0];
-    }
-  }
-
-  if (nparts > 1) {
-    const unsigned slot = blockIdx.x - p.n_full;
-    const int row = wv * 32 + l31;
-    float* PO = p.part_o + ((size_t)slot * AB_QB + row) * DP;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 o = {oacc[d][g * 4 + 0], oacc[d][g * 4 + 1], oacc[d][g * 4 + 2], oacc[d][g * 4 + 3]};
-        *reinterpret_cast<f32x4*>(PO + d * 32 + g * 8 + hi * 4) = o;
-      }
-    if (hi == 0) { p.part_ml[((size_t)slot * AB_QB + row) * 2] = M / p.scale_log2; p.part_ml[((size_t)slot * AB_QB + row) * 2 + 1] = l; }
-    return;
-  }
-
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  const long qr = q0 + l31;
-  if (WIDE) {
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        v4 x, y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { x[r] = from_f32<T>(oacc[d][gp * 8 + r] * inv); y[r] = from_f32<T>(oacc[d][gp * 8 + 4 + r] * inv); }
-        u32x2 xw = __builtin_bit_cast(u32x2, x), yw = __builtin_bit_cast(u32x2, y);
-        uint32_t x0 = xw[0], x1 = xw[1], y0 = yw[0], y1 = yw[1];
-        half_pair_exchange(x0, y0);
-        half_pair_exchange(x1, y1);
-        if (qr < p.sq) *reinterpret_cast<u32x4*>(O + qr * p.o_ss + d * 32 + gp * 16 + hi * 8) = u32x4{x0, x1, y0, y1};
-      }
-  } else if (qr < p.sq) {
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(oacc[d][g * 4 + r] * inv);
-        *reinterpret_cast<v4*>(O + qr * p.o_ss + d * 32 + g * 8 + hi * 4) = o;
-      }
-  }
-}
 
 // merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
 template <typename T, int DP>
@@ -1208,62 +622,20 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     if (split < 2 || p.part_o == nullptr) { p.n_full = total; p.split = 1; }
     else { p.n_full = total - rem; p.split = split; }
     const unsigned g = p.n_full + (total - p.n_full) * p.split;
-    // schedules tried against this one and dropped (DESIGN.md §9 keeps the numbers): half-tile staggered wave groups, fragment reads
-    // pinned 2-4 k-steps ahead, an S^T-pipelined LDS-DMA ring, 4 waves x 64 rows, two 128-query workgroups per CU — all equal or slower
+    // What was tried against these kernels and dropped (docs/experiments.md keeps the numbers, the sources are in the history of this file up to
+    // round 5): half-tile staggered wave groups, an S^T-pipelined LDS-DMA ring, 4 waves x 64 rows, two 128-query workgroups per CU, K / V by
+    // LDS-DMA (-17 %), row sums on the matrix pipe (-6.7 %), a half-tile pipelined softmax (does not fit 256 registers).  What stayed: fragment
+    // reads four steps ahead of the MFMAs (order pinned with sched_group_barrier; +1.5 ... 2.5 %) and 16-byte row stores (+0.3 %), identical bytes.
     if (p.q8 != nullptr) {
-      // (pre-scaled q: fragment reads four steps ahead since round 5, identical bytes; schedule 67 = the round-4 loop, for A/Bs)
-      if (p.prescaled && p.schedule != 67) MTX_LAUNCH((attn_mma32_q8d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
-      else if (p.prescaled) MTX_LAUNCH((attn_mma32_q8_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+      if (p.prescaled) MTX_LAUNCH((attn_mma32_q8d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
       else MTX_LAUNCH((attn_mma32_q8_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
       if (p.split > 1) MTX_LAUNCH((attn_merge_q8_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
       return MTX_OK;
     }
-    // Measured in one process on MI355X at T = 8812, 24 heads (round 5, profiles/r05_visit_b / _c / _d_attention_*.log; default 0.827-0.835 ms):
-    //   16-byte row stores on this kernel (schedule 65)  0.832 vs 0.835 ms (+0.3 %, four rounds of four)      -> the default from here on;
-    //   matrix-pipe row sums on this kernel (66)          0.890 (-6.7 %: 22 % fewer vector instructions, 12.5 % more MFMAs; the kernel is
-    //                                                     bound by its LDS-read -> MFMA dependency chains, not by vector issue slots);
-    //   attn_x_kernel (schedules 1..64: the same loop rebuilt with the transport / schedule as template switches)
-    //     K / V by LDS-DMA  0.967 (-17 %: four 1 KB pieces per wave and tile cost more issue time than 8 loads + 8 ds_write_b128);
-    //     half-tile stagger of the two wave groups  0.966 with LDS-DMA (no change), 1.222 with register staging;
-    //     register staging  0.983; + matrix-pipe sums 0.903; + 16-byte stores 0.970; both 0.894.
-    //   fragment reads four steps ahead of the MFMAs, order pinned with sched_group_barrier (68): +9 % on attn_x (0.905 vs 0.984 / 0.991), on this kernel
-    //     0.802 vs 0.814 ms (+1.5 %; T = 13 312 +2.5 %, T = 4 096 +1.3 %; four rounds, profiles/r05_visit_j_*.log), identical bytes -> the default, also for the
-    //     MX-fp8-output form.  With the stagger it loses (1.069 / 1.087).
-    //     Other depths (K k-steps | V MFMAs ahead: 3 | 4, 6 | 4, 4 | 6, 4 | 8, 4 | 2) all land within 0.8 % of 4 | 4 (0.812 ... 0.819 ms, profiles/r05_visit_l_*.log).
-    //   softmax of a tile's second 32 keys placed in the issue gaps of the P V MFMAs of its first 32 (half-tile checks of the row sums, order pinned):
-    //     2.05 ms — it does not fit the 256 registers of two waves per SIMD next to the prefetched fragments; the q fragments spill into the S^T MFMA
-    //     chain (profiles/r05_visit_k_*.log).  Removed again.
-    // schedule 67 = this kernel with its round-4 loop and epilogue (8-byte stores), 65 = 16-byte stores only.
     const bool wide_ok = p.o_ss % 8 == 0 && p.o_hs % 8 == 0 && p.o_bs % 8 == 0 && ((size_t)p.o & 15) == 0;
-    bool launched = false;
-    if ((p.schedule == 0 || p.schedule == 68) && p.prescaled && wide_ok) {      // the default since round 5: 16-byte stores + fragment reads four steps ahead
-      MTX_LAUNCH((attn_mma32_d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true;
-    } else if ((p.schedule == 65 || p.schedule == 66) && p.prescaled && wide_ok) {
-      if constexpr (std::is_same<T, __bf16>::value) {
-        if (p.schedule == 66) { MTX_LAUNCH((attn_mma32_ms_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true; }
-      }
-      if (!launched) { MTX_LAUNCH((attn_mma32_w_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p); launched = true; }
-    } else if (p.schedule > 0 && p.schedule <= 64 && p.prescaled) {
-      if constexpr (std::is_same<T, __bf16>::value) {      // (f16 probabilities saturate: matrix-pipe sums would not notice a stale maximum; the measurement kernels are bf16)
-        int var = p.schedule - 1;
-        if (!wide_ok) var &= ~AX_WIDE;
-#define MTX_AX(V) case V: MTX_LAUNCH((attn_x_kernel<T, 128, V>), dim3(g), dim3(512), 0, stream, p); break
-#ifdef AX_ONLY
-        switch (var) { MTX_AX(AX_ONLY); default: return MTX_ERR_INVALID; }
-#else
-        switch (var) { MTX_AX(0); MTX_AX(1); MTX_AX(2); MTX_AX(3); MTX_AX(4); MTX_AX(5); MTX_AX(6); MTX_AX(7);
-                       MTX_AX(8); MTX_AX(9); MTX_AX(10); MTX_AX(11); MTX_AX(12); MTX_AX(13); MTX_AX(14); MTX_AX(15);
-                       MTX_AX(16); MTX_AX(17); MTX_AX(20); MTX_AX(21); MTX_AX(24); MTX_AX(25); MTX_AX(28); MTX_AX(29);      // + AX_DEEP (no matrix-pipe sums)
-                       default: return MTX_ERR_INVALID; }
-#endif
-#undef MTX_AX
-        launched = true;
-      }
-    }
-    if (!launched) {
-      if (p.prescaled) MTX_LAUNCH((attn_mma32_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
-      else MTX_LAUNCH((attn_mma32_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
-    }
+    if (p.prescaled && wide_ok) MTX_LAUNCH((attn_mma32_d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);      // the FLUX graphs' form
+    else if (p.prescaled) MTX_LAUNCH((attn_mma32_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+    else MTX_LAUNCH((attn_mma32_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
     if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
     return MTX_OK;
   }
@@ -1292,7 +664,6 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   p.q_bs = a->q_bs; p.q_ss = a->q_ss; p.q_hs = a->q_hs; p.k_bs = a->k_bs; p.k_ss = a->k_ss; p.k_hs = a->k_hs;
   p.v_bs = a->v_bs; p.v_ss = a->v_ss; p.v_hs = a->v_hs; p.o_bs = a->o_bs; p.o_ss = a->o_ss; p.o_hs = a->o_hs;
   p.prescaled = (a->flags & MTX_ATTN_Q_PRESCALED) ? 1 : 0;
-  p.schedule = (a->flags >> MTX_ATTN_SCHEDULE_SHIFT) & 127;
   p.scale_log2 = p.prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
   p.n_full = 0; p.split = 1; p.part_o = nullptr; p.part_ml = nullptr;

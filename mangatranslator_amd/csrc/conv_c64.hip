@@ -24,7 +24,6 @@
 // Same LDS swizzle and MFMA operand swap as conv.hip.
 #include "mtx_device.h"
 #include <cstdlib>
-#include <type_traits>
 
 namespace mtx {
 
@@ -556,413 +555,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(ConvC64Params p) {
   }
 }
 
-// =====================================================================================================
-// Round 6: the LOCK-STEP form of the same convolution (the default; the two-group form above stays selectable for one round of A/Bs:
-// MTX_CONV_C64_FORM=0).  What the stamps and counters of the two-group form said (profiles/r06_visit_a...log): a slot lasts as long as
-// ONE group's memory phase — 8 600 shader clocks against 5 400 for the other group's 288 MFMAs per wave — and that phase is not bound by
-// bytes or by instruction count (160 vector instructions, 11 DMA pieces, 8 stores) but by being ALONE: four waves issue a tile's whole
-// traffic back to back (DMA -> epilogue -> stores -> wait for the DMA) while the other four issue none, 8.5 bytes per clock and CU, and the
-// matrix pipe has one wave per SIMD (nobody covers its LDS round trips: 5 400 clocks for 4 608 of MFMA).  Here all eight waves work on
-// the SAME tile:
-//   * wave (rq, ch) owns tile rows 4 rq .. 4 rq + 3 and output channels 32 ch .. 32 ch + 31: 4 x 2 accumulator fragments, 144 MFMAs per
-//     tile; the two waves of a SIMD run the same loop and cover each other's fragment reads;
-//   * the two halo buffers serve CONSECUTIVE tiles of one stream: tile k + 1's DMA is issued behind the barrier that opens tile k and has
-//     the whole tile time to land (it used to be issued and awaited inside one memory phase);
-//   * two accumulator sets: the epilogue of tile k - 1 (bias / activation / scale / residual / pack / 16-byte stores, one tile row at a
-//     time) is issued between the MFMA steps of tile k — vector ALU work under the partner wave's MFMAs, stores and the next halo in
-//     flight for the whole tile time instead of one phase in two;
-//   * one LDS barrier per tile; every wait on the vector-memory counter is counted (the DMA of the next tile and the stores of the
-//     previous one are never waited for where they are not needed).
-// Fragment addressing, LDS images, swizzles, epilogue arithmetic and rounding order are those of the two-group kernel.
-#ifdef MTX_EMU
-template <typename T> __device__ __forceinline__ void mfma_first(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) {
-  c = Traits<T>::mfma(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
-}
-#define C64_SCHED_FENCE() ((void)0)
-#else
-// c = a b (the accumulator is written, not read: no zeroing pass in front of a tile)
-template <typename T> __device__ __forceinline__ void mfma_first(f32x4& c, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b);
-template <> __device__ __forceinline__ void mfma_first<_Float16>(f32x4& c, const f16x8& a, const f16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-}
-template <> __device__ __forceinline__ void mfma_first<__bf16>(f32x4& c, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-}
-#define C64_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-
-// "all but the youngest n": n is wave-uniform and one of a handful of values (see the counts in the kernel); anything else waits for everything
-__device__ __forceinline__ void c64_wait_vmem_but(int n) {
-#ifndef MTX_EMU
-  switch (n) {
-    case 4: MTX_WAIT_VMEM_BUT(4); break;
-    case 5: MTX_WAIT_VMEM_BUT(5); break;
-    case 6: MTX_WAIT_VMEM_BUT(6); break;
-    case 8: MTX_WAIT_VMEM_BUT(8); break;
-    case 12: MTX_WAIT_VMEM_BUT(12); break;
-    case 16: MTX_WAIT_VMEM_BUT(16); break;
-    default: MTX_WAIT_VMEM(); break;
-  }
-#endif
-}
-
-// probe builds (tools/probes/conv_probe.hip defines C64_LS_STAMPS): shader-clock stamps of waves 0 and 5 of workgroups 0 and 97 at the phase
-// boundaries of every iteration, into chan_sum viewed as uint64 [2 workgroups][2 waves][32 iterations][8 events]
-#ifdef C64_LS_STAMPS
-#define C64_LS_STAMP(k_, ev_) do { if (!SUM && p.chan_sum != nullptr && (blockIdx.x == 0 || blockIdx.x == 97) && (wv == 0 || wv == 5) && lane == 0 && (k_) < 32) \
-    reinterpret_cast<unsigned long long*>(p.chan_sum)[((((blockIdx.x ? 1 : 0) * 2 + (wv ? 1 : 0)) * 32 + (k_)) * 8) + (ev_)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define C64_LS_STAMP(k_, ev_) ((void)0)
-#endif
-constexpr int C64_LS_NDMA_W = (C64_NDMA_C + 7) / 8;      // DMA pieces per wave and halo: 6 for wave 0, 5 for the others (41 in all)
-
-template <typename T, int ACT, bool SUM, bool RES>
-__global__ __launch_bounds__(512) void conv3x3_c64_ls_kernel(ConvC64Params p) {
-  constexpr int nks_c = 2;
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[C64_SMEM];
-  unsigned char* wts = smem;
-  unsigned char* halo0 = smem + C64_W_BYTES;
-  float* bias_s = reinterpret_cast<float*>(smem + C64_W_BYTES + 2 * C64_HALO_BYTES);      // [64] bias, then two out_scale rows [64] (by tile parity)
-
-  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
-#ifdef MTX_EMU
-  const int wv = tid >> 6;
-#else
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
-  const int rq = wv & 3, ch = wv >> 2;             // tile rows 4 rq .. 4 rq + 3, output channels 32 ch .. 32 ch + 31
-  const unsigned tiles_per_img = (unsigned)(p.tiles_x * p.tiles_y);
-  const unsigned total = tiles_per_img * (unsigned)p.n;
-
-  // ---- filters + bias: once per workgroup ---------------------------------------------------------
-  for (int idx = tid; idx < 9 * 64 * 8; idx += 512) {
-    const int c = idx & 7, row = idx >> 3;            // row = tap*64 + co
-    const int tap = row >> 6, co = row & 63;
-    const int chn = c * 8;
-    u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (co < p.cout && chn < p.cin)
-      v = *reinterpret_cast<const u32x4*>(p.w + (((size_t)co * 9 + tap) * (size_t)p.cin + chn) * sizeof(T));
-    *reinterpret_cast<u32x4*>(wts + row * 128 + ((c ^ (co & 7)) << 4)) = v;
-  }
-  const int co0 = ch * 32 + q * 4;                    // this lane's channels: co0 + 16 j + r
-  // bias and output factors live in LDS and are read per tile row (eight registers for the length of one row instead of sixteen for the
-  // whole kernel: with two accumulator sets the register file is the scarce thing here); rows 1 / 2 of the factor table go by tile parity
-  if (tid < 64) bias_s[tid] = (p.bias != nullptr && tid < p.cout) ? p.bias[tid] : 0.f;
-  if (tid >= 64 && tid < 192) bias_s[tid] = p.out_scale == nullptr ? 1.f : ((tid & 63) < p.cout ? p.out_scale[tid & 63] : 0.f);      // image 0 in both rows (several images: per tile, below)
-  const int vh = p.valid_hw ? p.valid_hw[0] : p.h, vw = p.valid_hw ? p.valid_hw[1] : p.w_in;
-  const BufView ybuf = make_buf(p.y, p.y_bytes);
-  const BufView xbuf = make_buf(p.x, p.x_bytes);
-  const BufView rbuf = make_buf(RES ? p.res : p.x, p.res_bytes);
-  unsigned dma_off[C64_LS_NDMA_W];
-#pragma unroll
-  for (int it = 0; it < C64_LS_NDMA_W; ++it) {
-    const int slot = (wv + it * 8) * 64 + lane;
-    const int hp = slot >> 3, hy = hp / C64_HW, hx = hp - hy * C64_HW, chn = (((slot & 7) ^ (hx & 7))) * 8;
-    dma_off[it] = (hp < C64_HPIX && chn < p.cin) ? (unsigned)(((hy * p.w_in + hx) * p.ldx + chn) * (int)sizeof(T)) : p.x_bytes;   // out of range: zeros
-  }
-  // 16-byte stores / residual loads: the lanes q, q ^ 1 of a pixel trade two dwords so that each holds 16 contiguous bytes (8 channels) of the
-  // pixel's 64-byte half line of this wave's 32 channels; a chunk at or beyond cout (cout % 8 == 0) is never stored.  One lane offset for tile
-  // row 0, the row as a scalar offset; pixels outside the image pass an out-of-range offset (dropped by the descriptor's range check), so a wave
-  // always issues exactly one store per tile row — the counted waits below stay exact on border tiles.
-  const unsigned chunk_off = ((q & 1) ? 32u + 8u * (unsigned)(q - 1) : 8u * (unsigned)q) + 64u * (unsigned)ch;
-  const bool chunk_ok = (int)(chunk_off / sizeof(T)) < p.cout;
-  const unsigned st_off = (unsigned)((rq * 4 * p.w_in + l15) * p.ldy * (int)sizeof(T)) + chunk_off;          // tile row i: + i * st_row (scalar)
-  const unsigned res_off = (unsigned)((rq * 4 * p.w_in + l15) * p.ldres * (int)sizeof(T)) + chunk_off;
-  const unsigned st_row = (unsigned)(p.w_in * p.ldy * (int)sizeof(T)), res_row = (unsigned)(p.w_in * p.ldres * (int)sizeof(T));
-
-  const unsigned char* wa[2];
-  const unsigned char* xa[3][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    wa[ks] = wts + (ch * 2) * 2048 + l15 * 128 + (((ks * 4 + q) ^ (l15 & 7)) << 4);
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int hx = l15 + kx;
-      xa[kx][ks] = halo0 + ((rq * 4) * C64_HW + hx) * 128 + (((ks * 4 + q) ^ (hx & 7)) << 4);
-    }
-  }
-
-  // tile k of this workgroup (or ~0u past the end): XCD-contiguous order when the grid is a multiple of 8 — the 32 workgroups of an XCD
-  // then work on 32 consecutive tiles (neighbouring halos meet in that XCD's L2) and a workgroup's images come in increasing order
-  auto tile_of = [&](unsigned k) -> unsigned {
-    const unsigned pid = blockIdx.x + k * gridDim.x;
-    if (pid >= total) return ~0u;
-    return (gridDim.x % 8u == 0u) ? xcd_remap(pid, total) : pid;
-  };
-  unsigned K = 0;
-  for (unsigned pid = blockIdx.x; pid < total; pid += gridDim.x) ++K;
-
-  // Halo of a tile -> halo buffer `buf` by LDS-DMA through the descriptor, ONE PIECE per call (the pieces of the next tile are issued between
-  // the first MFMA steps of the current one: issued in one block — eight waves, 41 KB of requests at once — they took 800 - 2 200 shader
-  // clocks of every iteration with the matrix pipe idle, profiles/r06_visit_d...log).  DMA instruction m fills LDS rows 8m .. 8m+7 of the
-  // halo; lane l -> row 8m + l/8, 16-byte slot l%8, which must hold chunk (slot ^ (halo column & 7)) of that pixel — the swizzle is applied on
-  // the per-lane SOURCE offset.  Out-of-image pixels pass an out-of-range offset (zeros).  Wave w issues pieces w, w + 8, ...: 6 (wave 0) or 5.
-  struct HaloSrc { bool interior; unsigned sbase; int iy0, ix0; unsigned img_off; };
-  auto halo_src = [&](unsigned lin_in) -> HaloSrc {
-#ifdef MTX_EMU
-    const unsigned lin = lin_in;
-#else
-    const unsigned lin = (unsigned)__builtin_amdgcn_readfirstlane((int)lin_in);
-#endif
-    HaloSrc h;
-    const int img = (int)(lin / tiles_per_img);
-    const int tile = (int)(lin % tiles_per_img);
-    h.iy0 = (tile / p.tiles_x) * C64_T - 1; h.ix0 = (tile % p.tiles_x) * C64_T - 1;
-    h.img_off = (unsigned)img * (unsigned)(p.h * p.w_in);
-    h.interior = h.iy0 >= 0 && h.ix0 >= 0 && h.iy0 + C64_HW <= p.h && h.ix0 + C64_HW <= p.w_in;
-    h.sbase = h.interior ? (h.img_off + (unsigned)(h.iy0 * p.w_in + h.ix0)) * (unsigned)p.ldx * (unsigned)sizeof(T) : 0u;
-    return h;
-  };
-  auto dma_piece = [&](const HaloSrc& h, int it, int buf) -> int {      // interior tiles: scalar base + invariant lane offsets
-    const int m = wv + it * 8;
-    if (m >= C64_NDMA_C) return 0;
-    buf_load16_lds(xbuf, dma_off[it], h.sbase, halo0 + buf * C64_HALO_BYTES + m * 1024);
-    return 1;
-  };
-  // border tiles (1 in 20 at page size): all pieces of this wave in one block, one at a time (not unrolled, and not between the MFMA steps: six
-  // copies of this address arithmetic inside the loop set the kernel's register peak)
-  auto dma_border = [&](const HaloSrc& h, int buf) -> int {
-    int issued = 0;
-#pragma nounroll
-    for (int m = wv; m < C64_NDMA_C; m += 8) {
-      const int slot = m * 64 + lane;
-      const int hp = slot >> 3;
-      const int hy = hp / C64_HW, hx = hp - hy * C64_HW;
-      const int c = (slot & 7) ^ (hx & 7);
-      const int gy = h.iy0 + hy, gx = h.ix0 + hx, chn = c * 8;
-      const bool ok = hp < C64_HPIX && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_in && chn < p.cin;
-      const unsigned voff = ok ? ((h.img_off + (unsigned)(gy * p.w_in + gx)) * (unsigned)p.ldx + (unsigned)chn) * (unsigned)sizeof(T) : p.x_bytes;
-      buf_load16_lds(xbuf, voff, 0u, halo0 + buf * C64_HALO_BYTES + m * 1024);
-      ++issued;
-    }
-    return issued;
-  };
-
-  // fused channel sums: one partial row per WAVE and image, chan_sum[img][blockIdx.x * 8 + wave][C]; a wave sums its own 32 channels and
-  // writes zeros into the other 32 (the reader adds the rows); written exactly once per image, zeros for images the wave never touched
-  float csum[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
-  int sum_img = -1;
-  auto sum_row = [&](int img_) -> float* { return p.chan_sum + ((size_t)img_ * (gridDim.x * 8) + blockIdx.x * 8 + (tid >> 6)) * p.cout; };
-  auto zero_rows = [&](int from, int to) {
-    for (int im = from; im < to; ++im)
-      for (int c = lane; c < p.cout; c += 64) sum_row(im)[c] = 0.f;
-  };
-  auto flush_sums = [&](int img_) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = csum[j][r];
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-        const int co = co0 + j * 16 + r, other = co ^ 32;
-        if (l15 == 0 && co < p.cout) sum_row(img_)[co] = v;
-        if (l15 == 0 && other < p.cout) sum_row(img_)[other] = 0.f;
-        csum[j][r] = 0.f;
-      }
-  };
-
-  // ---- prologue: tile 0's halo on its way, filters in LDS ---------------------------------------------
-  {
-    const unsigned t0 = tile_of(0);
-    if (t0 != ~0u) {
-      const HaloSrc h0 = halo_src(t0);
-      if (h0.interior) {
-#pragma unroll
-        for (int it = 0; it < C64_LS_NDMA_W; ++it) dma_piece(h0, it, 0);
-      } else dma_border(h0, 0);
-    }
-  }
-
-  f32x4 accA[4][2], accB[4][2];
-  u32x4 rv[4];                    // residual of the tile whose epilogue comes next: 16-byte chunks in the exchanged layout of the stores
-#pragma unroll
-  for (int i = 0; i < 4; ++i) rv[i] = u32x4{0u, 0u, 0u, 0u};
-  int ns_prev = 0;                // stores issued after the DMA in flight (younger than it on the in-order counter)
-  int sc_img = 0; unsigned sc_sel = 0;      // image whose output factors the current factor row holds (both rows start as image 0's)
-
-  // one tile row of the epilogue of tile `lin` from accumulator set `acc`: one 16-byte store per lane
-  auto epi_row = [&](f32x4 (&acc)[4][2], int i, unsigned lin, const float* sc_row) {
-    const int img = (int)(lin / tiles_per_img);
-    const int tile = (int)(lin % tiles_per_img);
-    const int ty0 = (tile / p.tiles_x) * C64_T, tx0 = (tile % p.tiles_x) * C64_T;
-    const int oy = ty0 + rq * 4 + i, ox = tx0 + l15;
-    const bool in_canvas = oy < p.h && ox < p.w_in;          // stored at all
-    const bool in_valid = oy < vh && ox < vw;                // inside the image (bucket plans: the canvas is larger; pixels beyond are written as zero and left out of the sums)
-    const unsigned sbase = (unsigned)((((size_t)img * p.h + ty0) * p.w_in + tx0) * (size_t)p.ldy * sizeof(T));
-    f32x4 b4[2], scv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      b4[j] = *reinterpret_cast<const f32x4*>(bias_s + co0 + j * 16);
-      if (RES) scv[j] = *reinterpret_cast<const f32x4*>(sc_row + co0 + j * 16);
-    }
-    u32x2 o[2];
-    uint32_t g0 = rv[i][0], g1 = rv[i][1], g2 = rv[i][2], g3 = rv[i][3];
-    if (RES) { row_pair_exchange(g0, g2); row_pair_exchange(g1, g3); }      // back to this lane's two quads: j = 0 in (g0, g1), j = 1 in (g2, g3)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      v4 ov;
-      if (!RES) {
-        ov = epi_pack<T, ACT>(acc[i][j] + b4[j], p.act, p.act_param);
-      } else {       // y = out_scale * act(conv + bias) + res_scale * res, in fp32 with one rounding
-        f32x4 v = acc[i][j] + b4[j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(v[r], p.act, p.act_param);
-        v = v * scv[j];
-        const v4 g4 = __builtin_bit_cast(v4, j == 0 ? u32x2{g0, g1} : u32x2{g2, g3});
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p.res_scale * to_f32(g4[r]);
-        ov = epi_pack<T, MTX_ACT_NONE>(v, 0, 0.f);
-      }
-      u32x2 od = __builtin_bit_cast(u32x2, ov);
-      od[0] = in_valid ? od[0] : 0u; od[1] = in_valid ? od[1] : 0u;
-      if (SUM) {                                   // pooled statistics of the values as stored (rounded to T; zeros outside the image add nothing)
-        const v4 sv = __builtin_bit_cast(v4, od);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) csum[j][r] += to_f32(sv[r]);
-      }
-      o[j] = od;
-    }
-    uint32_t a0 = o[0][0], a1 = o[0][1], c0 = o[1][0], c1 = o[1][1];
-    row_pair_exchange(a0, c0);
-    row_pair_exchange(a1, c1);
-    buf_store16(ybuf, (in_canvas && chunk_ok) ? st_off : p.y_bytes, u32x4{a0, a1, c0, c1}, sbase + (unsigned)i * st_row);
-  };
-
-  // residual of tile `lin`, tile row i, into rv[i]: a 16-byte descriptor load in the exchanged layout (rows / pixels outside the image: zeros).
-  // Uncounted (inline asm): the compiler must not wait for it itself — it would drain the halo DMA in flight with it.
-  auto load_res_row = [&](unsigned lin, int i) {
-    const int img = (int)(lin / tiles_per_img);
-    const int tile = (int)(lin % tiles_per_img);
-    const int ty0 = (tile / p.tiles_x) * C64_T, tx0 = (tile % p.tiles_x) * C64_T;
-    const unsigned sbase = (unsigned)((((size_t)img * p.h + ty0) * p.w_in + tx0) * (size_t)p.ldres * sizeof(T));
-    const bool ok = tx0 + l15 < p.w_in && chunk_ok && ty0 + rq * 4 + i < p.h;
-    buf_load16_uncounted(rv[i], rbuf, ok ? res_off : p.res_bytes, sbase + (unsigned)i * res_row);
-  };
-
-  // iteration k: MFMAs of tile k into `cur` (halo buffer BUF) with the epilogue of tile k - 1 from `prev` between the steps
-  auto iteration = [&](auto buf_c, unsigned k, f32x4 (&cur)[4][2], f32x4 (&prev)[4][2]) {
-    constexpr int BUF = decltype(buf_c)::value;
-    const unsigned lin = k < K ? tile_of(k) : ~0u;
-    const unsigned lin_prev = k >= 1 ? tile_of(k - 1) : ~0u;
-    C64_LS_STAMP(k, 0);
-    // several images with output factors: when the tile whose epilogue comes next belongs to another image than the last one, its factors go
-    // into the OTHER factor row (waves still in the previous iteration read the old one) — a global load and a full wait, once per image change
-    if (RES && p.out_scale != nullptr && p.n > 1 && lin_prev != ~0u && (int)(lin_prev / tiles_per_img) != sc_img) {
-      sc_img = (int)(lin_prev / tiles_per_img); sc_sel ^= 1;
-      if (tid < 64) bias_s[64 + sc_sel * 64 + tid] = tid < p.cout ? p.out_scale[(size_t)sc_img * p.cout + tid] : 0.f;
-    }
-    // (a) this wave's pieces of halo k have landed: everything but what was issued after them in the previous iteration — that tile's four
-    //     stores and, in the residual variant, the four residual loads of tile k - 1
-    if (lin != ~0u) c64_wait_vmem_but(ns_prev + ((RES && lin_prev != ~0u) ? 4 : 0));
-    C64_LS_STAMP(k, 1);
-    MTX_LDS_BARRIER();
-    C64_LS_STAMP(k, 2);
-    // (b) the next tile's halo goes into the buffer tile k - 1 was read from (every wave is past its last read of it), one piece behind each
-    //     of the first MFMA steps
-    const unsigned lin_next = k + 1 < K ? tile_of(k + 1) : ~0u;
-    HaloSrc hn = {};
-    if (lin_next != ~0u) hn = halo_src(lin_next);
-    int nd_next = 0;
-    if (lin_next != ~0u && !hn.interior) nd_next = dma_border(hn, 1 - BUF);
-    const bool dma_in_loop = lin_next != ~0u && hn.interior;
-    C64_LS_STAMP(k, 3);
-    const float* sc_row = bias_s + 64 + sc_sel * 64;      // the previous tile's output factors (several images: written before the barrier, above)
-    if (lin_prev != ~0u) {
-      const int img_prev = (int)(lin_prev / tiles_per_img);
-      if (SUM && img_prev != sum_img) {
-        if (sum_img >= 0) flush_sums(sum_img);
-        zero_rows(sum_img + 1, img_prev);
-        sum_img = img_prev;
-      }
-    }
-    int stores = 0;
-    auto epilogue_row = [&](int i) {
-      if (lin_prev == ~0u) return;
-      C64_SCHED_FENCE();
-      if (RES && i == 0) { c64_wait_vmem_but(nd_next); vmem_landed(rv[0], rv[1], rv[2], rv[3]); }      // the residual (issued at the end of the previous iteration: older than this iteration's DMA pieces; no store issued yet) is here
-      epi_row(prev, i, lin_prev, sc_row);
-      ++stores;
-      C64_SCHED_FENCE();
-    };
-    if (lin != ~0u) {
-      auto load_w = [&](int st, v8 (&wf)[2]) {           // st = (kx * NKS + ks) * 3 + ky
-        const int g = st / 3, ky = st - g * 3, kx = g / nks_c, ks = g - kx * nks_c, tap = ky * 3 + kx;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const v8*>(wa[ks] + tap * 8192 + j * 2048);
-      };
-      // Halo-row fragments of a (kx, ks) group: row r of group g lives in slot (r + 6 g) & 7 of EIGHT register sets (not two times six): a
-      // group's rows die one by one — row 0 after its step 0, row 1 after step 1, rows 2 .. 5 with the group — and the next group's rows take
-      // the freed slots: rows 0, 1 (the two spare slots) and this group's own rows 4, 5 (first needed by step 1) behind step 0, row 2 behind
-      // step 1, row 3 behind step 2.  16 registers fewer than double buffering; every index below is a compile-time constant.
-      v8 wf[2][2], xs[8];
-      constexpr int NG = 3 * nks_c, NST = NG * 3;
-      auto xrow = [&](int g, int r) -> const v8* {
-        const int kx = g / nks_c, ks = g - kx * nks_c;
-        return reinterpret_cast<const v8*>(xa[kx][ks] + BUF * C64_HALO_BYTES + r * (C64_HW * 128));
-      };
-#pragma unroll
-      for (int r = 0; r < 6; ++r) xs[r] = *xrow(0, r);
-      load_w(0, wf[0]);
-#pragma unroll
-      for (int st = 0; st < NST; ++st) {
-        const int g = st / 3, ky = st - g * 3;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (st == 0) mfma_first<T>(cur[i][j], wf[0][j], xs[(i + ky) & 7]);
-            else mfma_inplace<T>(cur[i][j], wf[st & 1][j], xs[(i + ky + 6 * g) & 7]);
-            const int rd = j * 4 + i;                          // which read goes out behind this MFMA
-            if (rd < 2 && st + 1 < NST) {                      // the next step's two filter fragments
-              C64_FENCE();
-              const int s1 = st + 1, g1 = s1 / 3, ky1 = s1 - g1 * 3, kx1 = g1 / nks_c, ks1 = g1 - kx1 * nks_c, tap1 = ky1 * 3 + kx1;
-              wf[s1 & 1][rd] = *reinterpret_cast<const v8*>(wa[ks1] + tap1 * 8192 + rd * 2048);
-              C64_FENCE();
-            } else if (ky == 0 && rd >= 2 && rd < 4 && g + 1 < NG) {      // rows 0, 1 of the next group -> the spare slots
-              C64_FENCE();
-              xs[(rd - 2 + 6 * (g + 1)) & 7] = *xrow(g + 1, rd - 2);
-              C64_FENCE();
-            } else if (ky == 0 && rd >= 4 && rd < 6 && g >= 1) {           // this group's rows 4, 5 -> the slots of the previous group's rows 2, 3
-              C64_FENCE();
-              xs[(rd + 6 * g) & 7] = *xrow(g, rd);
-              C64_FENCE();
-            } else if (ky >= 1 && rd == 2 && g + 1 < NG) {                 // rows 2 / 3 of the next group -> the slot of this group's row 0 / 1 (dead)
-              C64_FENCE();
-              xs[(ky + 1 + 6 * (g + 1)) & 7] = *xrow(g + 1, ky + 1);
-              C64_FENCE();
-            }
-          }
-        if (st < C64_LS_NDMA_W && dma_in_loop) { C64_SCHED_FENCE(); nd_next += dma_piece(hn, st, 1 - BUF); C64_SCHED_FENCE(); }      // the next halo, piece by piece, behind steps 0 .. 5
-        if ((st & 3) == 1 && st >= 5) epilogue_row((st - 5) >> 2);      // tile rows 0 .. 3 of the previous tile behind steps 5, 9, 13, 17
-        if (RES && st >= NST - 4) { C64_SCHED_FENCE(); load_res_row(lin, st - (NST - 4)); C64_SCHED_FENCE(); }      // this tile's residual for the NEXT iteration's epilogue: the youngest operations on the counter
-      }
-      C64_MFMA_DRAIN();
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) epilogue_row(i);
-    }
-    C64_LS_STAMP(k, 4);
-    ns_prev = stores;
-  };
-  typedef std::integral_constant<int, 0> B0;
-  typedef std::integral_constant<int, 1> B1;
-  MTX_WAIT_VMEM();                                   // (the filter fetches; tile 0's halo with them — once per launch)
-  for (unsigned k = 0; k <= K; k += 2) {
-    iteration(B0(), k, accA, accB);
-    if (k + 1 <= K) iteration(B1(), k + 1, accB, accA);
-  }
-  if (SUM) {
-    if (sum_img >= 0) flush_sums(sum_img);
-    zero_rows(sum_img + 1, p.n);
-  }
-}
-
 static int g_num_cus = 0;
 
 static int c64_num_cus(const char** err) {
@@ -979,17 +571,11 @@ static int c64_num_cus(const char** err) {
   return g_num_cus;
 }
 
-// MTX_CONV_C64_FORM=0: the two-group kernel of rounds 1-5 (one round of same-process A/Bs; read once)
-static bool c64_lockstep() {
-  static const bool ls = [] { const char* e = getenv("MTX_CONV_C64_FORM"); return !(e && e[0] == '0'); }();
-  return ls;
-}
-
 static unsigned c64_grid(int n, int h, int w) {
   const long total = (long)((w + C64_T - 1) / C64_T) * ((h + C64_T - 1) / C64_T) * n;
-  const long units = c64_lockstep() ? total : (total + 1) / 2;      // a workgroup walks tiles (lock-step form) or pairs of tiles (two-group form)
+  const long npairs = (total + 1) / 2;
   const int cus = c64_num_cus(nullptr);
-  return (unsigned)(units < cus ? units : cus);
+  return (unsigned)(npairs < cus ? npairs : cus);
 }
 
 // rows of the chan_sum buffer per image = one partial per wave of the persistent launch
@@ -1005,15 +591,6 @@ static unsigned long long conv_c64_out_bytes(const mtx_conv2d_args* a) {
 
 bool conv_c64_applicable(const mtx_conv2d_args* a) {
   if (a->act_after_res) return false;
-  if (c64_lockstep()) {
-    // the lock-step kernel stores 16-byte chunks of 8 channels under a descriptor: no pixel shuffle, whole chunks, the residual per image and under
-    // 4 GB, output factors only in the residual variant (the RCAB's second conv) — anything else is the generic kernel's (conv.hip)
-    if (a->pixel_shuffle != 0 || a->cout % 8 != 0 || a->ldy % 8 != 0) return false;
-    if (a->res != nullptr && (a->res_broadcast_n || a->ldres % 8 != 0 ||
-                              (unsigned long long)a->n * a->h * a->w_in * a->ldres * 2 >= 0xFFFFFFF0ull)) return false;
-    if (a->out_scale != nullptr && a->res == nullptr) return false;
-    if (a->act != MTX_ACT_NONE && a->act != MTX_ACT_RELU && a->act != MTX_ACT_SILU) return false;      // compiled-in activations only (a runtime switch in the interleaved epilogue spills)
-  }
   if (a->chan_sum != nullptr && a->res != nullptr) return false;        // no variant carries both register sets
   if (conv_c64_out_bytes(a) >= 0xFFFFFFF0ull) return false;   // 32-bit store offsets
   if ((unsigned long long)a->n * a->h * a->w_in * a->ldx * 2 >= 0xFFFFFFF0ull) return false;
@@ -1039,11 +616,9 @@ int conv_c64_launch(const mtx_conv2d_args* a, void* stream, const char** err) {
   p.tiles_y = (a->h + C64_T - 1) / C64_T;
   if (c64_num_cus(err) < 0) return MTX_ERR_HIP;
   const unsigned grid = c64_grid(a->n, a->h, a->w_in);
-#define C64_GO(TT, AB, AC, SM, RS) do { if (c64_lockstep()) MTX_LAUNCH((conv3x3_c64_ls_kernel<TT, AC, SM, RS>), dim3(grid), dim3(512), 0, stream, p); \
-                                         else MTX_LAUNCH((conv3x3_c64_kernel<TT, AB, AC, SM, RS>), dim3(grid), dim3(512), 0, stream, p); } while (0)
+#define C64_GO(TT, AB, AC, SM, RS) MTX_LAUNCH((conv3x3_c64_kernel<TT, AB, AC, SM, RS>), dim3(grid), dim3(512), 0, stream, p)
 #define C64_ACT(TT, SM, RS) do { if (a->act == MTX_ACT_NONE) C64_GO(TT, 0, MTX_ACT_NONE, SM, RS); else if (a->act == MTX_ACT_RELU) C64_GO(TT, 0, MTX_ACT_RELU, SM, RS); \
-                                 else if (c64_lockstep()) MTX_LAUNCH((conv3x3_c64_ls_kernel<TT, MTX_ACT_SILU, SM, RS>), dim3(grid), dim3(512), 0, stream, p); \
-                                 else MTX_LAUNCH((conv3x3_c64_kernel<TT, 0, -1, SM, RS>), dim3(grid), dim3(512), 0, stream, p); } while (0)
+                                 else C64_GO(TT, 0, -1, SM, RS); } while (0)
 #define C64_VAR(TT) do { if (sum) C64_ACT(TT, true, false); else if (a->res != nullptr) C64_ACT(TT, false, true); else C64_ACT(TT, false, false); } while (0)
   const bool sum = a->chan_sum != nullptr;
   if (a->dtype == MTX_BF16) C64_VAR(__bf16);

@@ -407,10 +407,10 @@ int norm_f32_launch(const mtx_norm_args* a, void* stream, const char** err) {
   if (a->kind != 0 || a->mod_scale || a->mod_shift || a->q) { *err = "norm f32: LayerNorm without modulation / fp8 twin only"; return MTX_ERR_UNSUPPORTED; }
   if (a->rows < 1 || a->c < 1) return MTX_OK;
   const dim3 grid((unsigned)((a->rows + 3) / 4));
-  if (a->out_dtype == 0 || a->out_dtype == MTX_F32) MTX_LAUNCH(norm_f32_kernel<float>, grid, dim3(256), 0, stream, *a);
+  if (a->out_dtype == MTX_F32) MTX_LAUNCH(norm_f32_kernel<float>, grid, dim3(256), 0, stream, *a);
   else if (a->out_dtype == MTX_BF16) MTX_LAUNCH(norm_f32_kernel<__bf16>, grid, dim3(256), 0, stream, *a);
   else if (a->out_dtype == MTX_F16) MTX_LAUNCH(norm_f32_kernel<_Float16>, grid, dim3(256), 0, stream, *a);
-  else { *err = "norm f32: out_dtype must be 0, f32, bf16 or f16"; return MTX_ERR_INVALID; }
+  else { *err = "norm f32: out_dtype must be f32, bf16 or f16"; return MTX_ERR_INVALID; }
   return MTX_OK;
 }
 

@@ -25,7 +25,6 @@ struct GemmParams {
   long m, n, k, lda, ldw, ldc, ldres, ldgate, a_bs, w_bs, c_bs, res_bs;
   int gate_rows_per, act; float act_param, alpha;
   int out_f32;
-  int serial_epilogue;      // MTX_GEMM_SERIAL_EPILOGUE: the 256-tile kernels' epilogue with its memory requests one at a time (A/B yardstick)
   unsigned tiles_m, tiles_n;
   // whole tiles [0, n_full) go to the tile kernel, tiles [n_full, tiles) to the K-slice tail; fp32 partials in `part`
   unsigned n_full; float* part;
@@ -301,64 +300,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_STAGE = (G2_BM + G2_BN) * 128;      // 64 KB
 
-// Epilogue of the 256-tile kernels as it was through round 5's first half (MTX_GEMM_SERIAL_EPILOGUE: the yardstick of the batched form below).
-// acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
-template <typename T, int ACT>
-__device__ __forceinline__ void gemm256_epilogue_serial(const GemmParams& p, f32x16 (&acc)[4][2], unsigned char* smem, T* Cp,
-                                                 long m0, long n0, long bz, int wv, int lane) {
-  typedef typename Traits<T>::v4 v4;
-  const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 2, wn = wv & 3;
-  unsigned char* outs = smem + wv * 16384;          // [128 rows m][8 chunks of 16 B], chunk ^= (row & 7)
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nl = j * 32 + g * 8 + hi * 4;         // local n of this lane's 4 values
-      float b[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long n = n0 + wn * 64 + nl + r;
-        b[r] = (p.bias != nullptr && n < p.n) ? p.bias[n] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = i * 32 + l31;
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act_t<ACT>(acc[i][j][g * 4 + r] * p.alpha + b[r], p.act, p.act_param));
-        *reinterpret_cast<v4*>(outs + row * 128 + ((((nl >> 3)) ^ (row & 7)) << 4) + ((nl & 4) << 1)) = o;
-      }
-    }
-  // a wave only re-reads its own region: no workgroup barrier needed, just its own LDS writes
-#ifdef MTX_EMU
-  emu::wave_sync();
-#else
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-  const T* G = reinterpret_cast<const T*>(p.gate);
-  const T* R = reinterpret_cast<const T*>(p.res);
-  const int oc = lane & 7;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 8 + (lane >> 3);
-    const long m = m0 + wm * 128 + row, n = n0 + wn * 64 + oc * 8;
-    if (m >= p.m || n >= p.n) continue;
-    u32x4 raw = *reinterpret_cast<const u32x4*>(outs + row * 128 + ((oc ^ (row & 7)) << 4));
-    if (G != nullptr || R != nullptr) {
-      float f[8];
-      unpack8<T>(raw, f);
-      if (G) { float g8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(G + (size_t)(m / p.gate_rows_per) * p.ldgate + n), g8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] *= g8[e]; }
-      if (R) { float r8[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)bz * p.res_bs + (size_t)m * p.ldres + n), r8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += r8[e]; }
-      raw = pack8<T>(f);
-    }
-    *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + n) = raw;
-  }
-}
-
 // Epilogue of the 256-tile kernels, run by the 8 MFMA waves (wv = 0..7).
 // acc[i][j][r]: m = m0 + wm*128 + i*32 + l31, n = n0 + wn*64 + j*32 + 8*(r>>2) + 4*hi + (r&3)
 // Round 5 (late): memory requests in batches.  Read as ISA, the form above asked for its bias values one dword at a time under per-element
@@ -366,11 +307,11 @@ __device__ __forceinline__ void gemm256_epilogue_serial(const GemmParams& p, f32
 // iteration — gate, wait, residual, wait, store, sixteen times per wave: ~40 dependent memory round trips per tile on a CU that has
 // nothing else resident (one 128 KB workgroup).  Here the bias leaves as eight 16-byte loads in one batch, and — the accumulators being
 // dead once staged — all sixteen gate and residual chunks of a lane are requested (clamped addresses, no branches) before the first is
-// used.  Same arithmetic, same rounding order (the gate product and the residual sum stay two roundings): identical bytes.
+// used.  Same arithmetic, same rounding order (the gate product and the residual sum stay two roundings): identical bytes to the one-at-a-time
+// form of rounds 1-5a (compared on hardware in round 5, profiles/r05_visit_q_...log; that form is in this file's history).
 template <typename T, int ACT>
 __device__ __forceinline__ void gemm256_epilogue(const GemmParams& p, f32x16 (&acc)[4][2], unsigned char* smem, T* Cp,
                                                  long m0, long n0, long bz, int wv, int lane) {
-  if (p.serial_epilogue) { gemm256_epilogue_serial<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane); return; }
   typedef typename Traits<T>::v4 v4;
   const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 2, wn = wv & 3;
   unsigned char* outs = smem + wv * 16384;          // [128 rows m][8 chunks of 16 B], chunk ^= (row & 7)
@@ -644,10 +585,6 @@ __device__ __forceinline__ void mfma_mx_f8(f32x16& c, i32x8 a, i32x8 b, unsigned
 #endif
 }
 
-// WIDE (round 5, measured against the form above in one process): a segment is a whole k-step — all six fragments read, then eight MFMAs
-// (512 cycles of the pipe) — so a K tile has two segments and four barriers instead of four and eight, and a load segment has 512 cycles
-// of the other group's matrix work to hide four DMA pieces and twelve fragment reads behind.  Same accumulation order per accumulator.
-template <bool WIDE>
 __device__ __forceinline__ void gemm256_f8_loop(const GemmParams& p, unsigned char* smem, const unsigned char* A, const unsigned char* W,
                                                 long m0, long n0, long kbeg, long kend, f32x16 (&acc)[4][2]) {
   constexpr int BK = 128;
@@ -717,53 +654,6 @@ __device__ __forceinline__ void gemm256_f8_loop(const GemmParams& p, unsigned ch
 #pragma unroll
     for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(sw[j]));
 #endif
-    if constexpr (WIDE) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        i32x8 wfw[2], afw[4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + waddr[S][ks][0] + j * 4096);
-          const u32x4 hi4 = *reinterpret_cast<const u32x4*>(smem + waddr[S][ks][1] + j * 4096);
-          wfw[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + aaddr[S][ks][0] + i * 4096);
-          const u32x4 hi4 = *reinterpret_cast<const u32x4*>(smem + aaddr[S][ks][1] + i * 4096);
-          afw[i] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
-        }
-        if (more && ks == 0) load_scales(kt + 1);
-        if (more) {
-          const long k0 = (kt + 1) * BK;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) piece(ks * 4 + i, 1 - S, k0);
-        }
-#ifndef MTX_EMU
-        if (ks == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-        if (ks == 1 && grp == 1) MTX_WAIT_VMEM();
-        G2_BAR();
-#ifndef MTX_EMU
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (ks == 0) mfma_mx_f8<0>(acc[i][j], wfw[j], afw[i], sw[j], sa[i]); else mfma_mx_f8<2>(acc[i][j], wfw[j], afw[i], sw[j], sa[i]);
-          }
-#ifndef MTX_EMU
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (ks == 1 && grp == 0) MTX_WAIT_VMEM();
-        G2_BAR();
-      }
-      return;
-    }
     i32x8 wf[2];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -828,7 +718,7 @@ __device__ __forceinline__ void gemm256_f8_loop(const GemmParams& p, unsigned ch
   if (grp == 0) G2_BAR();
 }
 
-template <typename T, int ACT, bool WIDE = false>
+template <typename T, int ACT>
 __global__ __launch_bounds__(512) void gemm256_f8_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G2_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -842,7 +732,7 @@ __global__ __launch_bounds__(512) void gemm256_f8_kernel(GemmParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  gemm256_f8_loop<WIDE>(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
+  gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
   __syncthreads();
   gemm256_epilogue<T, ACT>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
 }
@@ -867,7 +757,7 @@ __global__ __launch_bounds__(512) void gemm256_f8_glu_kernel(GemmParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  gemm256_f8_loop<false>(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
+  gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, 0, p.k / 128, acc);
   __syncthreads();
   if (n0 < p.glu_col0) {                                  // (workgroup-uniform: glu_col0 is a multiple of the tile width)
     gemm256_epilogue<T, MTX_ACT_NONE>(p, acc, smem, reinterpret_cast<T*>(p.c), m0, n0, 0, wv, lane);
@@ -948,7 +838,7 @@ __global__ __launch_bounds__(512) void gemm256_slice_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (kend > kbeg) {
-    if (F8) gemm256_f8_loop<false>(p, smem, p.a, p.w, m0, n0, kbeg, kend, acc);
+    if (F8) gemm256_f8_loop(p, smem, p.a, p.w, m0, n0, kbeg, kend, acc);
     else gemm256_pp_buf_loop<T>(p, smem, reinterpret_cast<const T*>(p.a), reinterpret_cast<const T*>(p.w), m0, n0, kbeg, kend, acc);
   }
   // slot layout: [wave][block = (i, j, g)][lane] x 16 bytes
@@ -1013,11 +903,9 @@ static int gemm_num_cus() {
   return cus;
 }
 
-static thread_local bool g_f8_wide = false;      // MTX_GEMM_F8_WIDE of the launch being issued (a measurement switch)
 template <typename T, bool F8>
 static void launch_gemm256_tiles(const GemmParams& p, dim3 grid, void* stream) {
-#define MTX_G256(ACTV) do { if (F8 && g_f8_wide) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV, true>), grid, dim3(512), 0, stream, p); \
-                            else if (F8) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV, false>), grid, dim3(512), 0, stream, p); \
+#define MTX_G256(ACTV) do { if (F8) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); \
                             else MTX_LAUNCH((gemm256_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); } while (0)
   switch (p.act) {
     case MTX_ACT_NONE: MTX_G256(MTX_ACT_NONE); break;
@@ -1163,8 +1051,6 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.gate_rows_per = a->gate_rows_per > 0 ? a->gate_rows_per : 1;
   p.act = a->act; p.act_param = a->act_param; p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.out_f32 = a->out_dtype == MTX_F32 && a->dtype != MTX_F32;
-  static const bool env_serial = [] { const char* e = getenv("MTX_GEMM_SERIAL_EPILOGUE"); return e && e[0] == '1'; }();      // whole-page A/Bs (tools/gpu_visit_r05_r.sh)
-  p.serial_epilogue = ((a->flags & MTX_GEMM_SERIAL_EPILOGUE) || env_serial) ? 1 : 0;
   p.n_full = 0; p.slices = 1; p.slice_len = 0;
   p.part = (a->workspace && a->workspace_bytes >= (int64_t)MTX_GEMM_WORKSPACE_BYTES) ? reinterpret_cast<float*>(a->workspace) : nullptr;
   p.tickets = p.part ? reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a->workspace) + MTX_GEMM_WORKSPACE_BYTES - G2_TICKET_BYTES) : nullptr;
@@ -1177,7 +1063,6 @@ int gemm_launch(const mtx_gemm_args* a, void* stream, const char** err) {
   p.tiles_n = (unsigned)((a->n + GBN - 1) / GBN);
   const long batch = a->batch > 0 ? a->batch : 1;
   const bool force = (a->flags & MTX_GEMM_FORCE_TILE256) != 0, nosplit = (a->flags & MTX_GEMM_NO_SPLIT) != 0;
-  g_f8_wide = (a->flags & MTX_GEMM_F8_WIDE) != 0;
   const unsigned forced_slices = ((unsigned)a->flags >> 8) & 0xffu;
   // large, aligned problems: the 256 x 256 LDS-DMA kernel (needs whole K tiles and 16-byte rows everywhere)
   const long t256 = ((a->m + G2_BM - 1) / G2_BM) * ((a->n + G2_BN - 1) / G2_BN) * batch;

@@ -242,7 +242,7 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 }
 
 // the xor butterfly through the LDS crossbar (ds_bpermute per level): what `wave_sum` was through round 4; kept as the yardstick the
-// register-only form below is held to (norm_kernel, mtx_norm_form(0))
+// register-only form below was held to on hardware (round 5); the simulator's form
 __device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

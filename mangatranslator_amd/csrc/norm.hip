@@ -13,113 +13,23 @@ namespace mtx {
 
 constexpr int NORM_MAXCH = 12;   // chunks of 8 per lane -> C <= 6144
 
-// NCH = 16-byte chunks per lane the row needs (C <= 512 NCH): the row lives in NCH x 8 registers between the passes, and the kernel is
-// latency-bound (one wave per row: a load, two wave reductions, a store) — with the width a template parameter a 3072-wide row takes 48
-// value registers instead of the 96 the widest row needs, twice the waves fit a SIMD and twice the bytes are in flight (round 4).
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void norm_kernel(mtx_norm_args p) {
-#pragma clang fp contract(off)      // every product and sum rounded on its own: what this kernel's code has always been (packed multiplies, then adds); the packed-row kernel is held to the same bytes
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= p.rows) return;
-  const long nch = p.c / 8;
-  const T* X = reinterpret_cast<const T*>(p.x) + row * p.ldx;
-  T* Y = reinterpret_cast<T*>(p.y) + row * p.ldy;
-  float v[NCH][8];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const long ch = lane + (long)i * 64;
-    if (ch < nch) {
-      unpack8<T>(*reinterpret_cast<const u32x4*>(X + ch * 8), v[i]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[i][e];
-    }
-  }
-  float mean = 0.f;
-  if (p.kind == 0) { s = wave_sum_shfl(s); mean = s / (float)p.c; }
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const long ch = lane + (long)i * 64;
-    if (ch < nch) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss += d * d; }
-    }
-  }
-  ss = wave_sum_shfl(ss);
-  const float rstd = 1.0f / sqrtf(ss / (float)p.c + p.eps);
-  const T* MS = reinterpret_cast<const T*>(p.mod_scale);
-  const T* MH = reinterpret_cast<const T*>(p.mod_shift);
-  const long mrow = p.rows_per > 0 ? row / p.rows_per : 0;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const long ch = lane + (long)i * 64;
-    if (ch < nch) {
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (v[i][e] - mean) * rstd;
-        if (p.gamma) t *= p.gamma[ch * 8 + e];
-        if (p.beta) t += p.beta[ch * 8 + e];
-        o[e] = t;
-      }
-      if (MS) { float g[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(MS + mrow * p.ldmod + ch * 8), g);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] *= (1.f + g[e]); }
-      if (MH) { float g[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(MH + mrow * p.ldmod + ch * 8), g);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += g[e]; }
-      if (p.act != MTX_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = apply_act(o[e], p.act, 0.f);
-      }
-      if (p.y != nullptr) *reinterpret_cast<u32x4*>(Y + ch * 8) = pack8<T>(o);
-      if (p.q != nullptr) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[i][e] = to_f32(from_f32<T>(o[e]));      // what the quantiser would read back from y: rounded to T
-      }
-    }
-  }
-  if (p.q != nullptr) {
-    // MX fp8 twin of the row (mtx_quant_args' format) straight from the registers: the fp8 linears that follow read nothing else, so the
-    // separate quantiser pass (2 B read + 1 B written per element) — and, without a 16-bit consumer, the 16-bit store — disappear.
-    // C % 128 == 0 (checked by the launcher): chunk ch = lane + 64 i is valid for a whole 16-lane group or not at all.
-    unsigned char* Q = reinterpret_cast<unsigned char*>(p.q) + row * p.ldq;
-    unsigned* S = reinterpret_cast<unsigned*>(p.q_scale);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const long ch = lane + (long)i * 64;
-      if ((long)i * 64 < nch) {                     // wave-uniform
-        float f[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = ch < nch ? v[i][e] : 0.f;
-        unsigned w0, w1, word;
-        mx_quantize_chunk(f, ch, w0, w1, word);
-        if (ch < nch) {
-          *reinterpret_cast<u32x2*>(Q + ch * 8) = u32x2{w0, w1};
-          if ((ch & 15) == 0) S[(ch >> 4) * p.lds_q + row] = word;
-        }
-      }
-    }
-  }
-}
-
-// Round 5: the same row normalisation with the row kept PACKED between the passes (NCH x 4 registers instead of NCH x 8 fp32 values) and
-// unpacked again where each pass needs it — a 16-bit -> fp32 unpack is one shift / convert per element, and the kernel has nothing but
-// latency to hide: a 3072-wide row takes 74 VGPRs instead of 105 (6 waves per SIMD instead of 4); with the modulation rows requested up
-// front (PRE) 98 — 4 waves again, but every memory request of a row is in flight at once, which is what pays (19.0 against 21.3 us).  The
-// additions and products run in the same order as in `norm_kernel` and nothing is fused, so the bytes are identical (tests compare them).  NORM_PIN keeps the optimiser from carrying the unpacked values across the passes (which would undo the point).
+// (rounds 1-4 kept the row as fp32 values in NCH x 8 registers — `norm_kernel`, in this file's history; round 5's packed-row kernel below gives
+// the same bytes in 19.0 instead of 30.1 us on the adaLN rows of a FLUX block: profiles/r05_visit_o / _p logs)
+// FULL: every lane owns NCH valid chunks (C == 512 NCH), no gamma / beta / activation — the adaLN rows of the FLUX blocks: straight-line
+// code, no per-chunk exec masks, no per-element affine loads.  PRE (with FULL): the modulation rows are requested together with x instead of
+// after the two reductions (their L2 latency leaves the critical path at the price of 8 NCH more registers).
+// Round 5: the row kept PACKED between the passes (NCH x 4 registers instead of NCH x 8 fp32 values) and unpacked again where each pass needs
+// it — a 16-bit -> fp32 unpack is one shift / convert per element, and the kernel has nothing but latency to hide: a 3072-wide row takes 74
+// VGPRs instead of 105; with the modulation rows requested up front (PRE) 98 — every memory request of a row is in flight at once, which is
+// what pays (19.0 against 21.3 us).  Additions and products run in the order of the rounds-1-4 kernel and nothing is fused (identical bytes,
+// compared on hardware in round 5).  NORM_PIN keeps the optimiser from carrying the unpacked values across the passes.
 #ifdef MTX_EMU
 #define NORM_PIN(x) do { } while (0)
 #else
 #define NORM_PIN(x) asm volatile("" : "+v"(x))
 #endif
-// FULL: every lane owns NCH valid chunks (C == 512 NCH), no gamma / beta / activation — the adaLN rows of the FLUX blocks: straight-line
-// code, no per-chunk exec masks, no per-element affine loads.  PRE (with FULL): the modulation rows are requested together with x instead of
-// after the two reductions (their L2 latency leaves the critical path at the price of 8 NCH more registers).
-template <typename T, int NCH, bool FULL, bool PRE, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void norm_packed_kernel(mtx_norm_args p) {
+template <typename T, int NCH, bool FULL, bool PRE>
+__global__ __launch_bounds__(256) void norm_packed_kernel(mtx_norm_args p) {
 #pragma clang fp contract(off)      // as in norm_kernel: no fused multiply-adds, so both kernels round alike (hardware visit o: the fused variance differed in the last bit of some rows)
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -248,15 +158,6 @@ __global__ __launch_bounds__(256, MINW) void norm_packed_kernel(mtx_norm_args p)
   }
 }
 
-// which form norm_launch uses (MTX_NORM_FORM / mtx_norm_form: same-process A/Bs and the test that holds all forms to identical bytes)
-static int norm_form() {
-  static int form = -1;
-  if (form < 0) { const char* e = getenv("MTX_NORM_FORM"); form = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 2; }
-  return form;
-}
-static thread_local int g_norm_form_override = -1;
-void norm_set_form(int form) { g_norm_form_override = form; }
-
 int norm_f32_launch(const mtx_norm_args* a, void* stream, const char** err);      // f32ops.hip
 int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
   if (a->dtype == MTX_F32) return norm_f32_launch(a, stream, err);
@@ -269,16 +170,12 @@ int norm_launch(const mtx_norm_args* a, void* stream, const char** err) {
   const unsigned blocks = (unsigned)((a->rows + 3) / 4);
   if (a->dtype != MTX_BF16 && a->dtype != MTX_F16) { *err = "norm: dtype must be bf16 or f16"; return MTX_ERR_INVALID; }
   const long per_lane = (a->c / 8 + 63) / 64;
-  // forms: 0 = fp32-register kernel (rounds 1-4), 1 = packed rows, 2 = packed rows with the modulation requested up front (default), 3 = the
-  // same held to 96 registers (5 waves per SIMD, 20 bytes of scratch).  MI355X, 8 812 x 3 072 bf16 with adaLN modulation, same process
-  // (profiles/r05_visit_o_*.log): 29.7 / 21.6 / 18.8 / 23.1 us; with the MX fp8 twin instead of the 16-bit store 35.6 / 26.3 / 23.4 / 26.4.
-  const int form = g_norm_form_override >= 0 ? g_norm_form_override : norm_form();
+  // straight-line form (rows of whole 512-chunks without affine / activation: the adaLN rows of the FLUX blocks, with the modulation rows requested
+  // together with x) or the general one.  Round 5 measured two more forms (modulation after the reductions: 21.6 against 18.8 us; held to 96
+  // registers: 23.1) — dropped, profiles/r05_visit_o_*.log.
   const bool full = a->c % 512 == 0 && (per_lane == 2 || per_lane == 4 || per_lane == 6 || per_lane == NORM_MAXCH) && !a->gamma && !a->beta && a->act == MTX_ACT_NONE;
-#define MTX_NORM_T(TT, N) do { if (form == 0) MTX_LAUNCH((norm_kernel<TT, N>), dim3(blocks), dim3(256), 0, stream, *a); \
-                               else if (!full) MTX_LAUNCH((norm_packed_kernel<TT, N, false, false>), dim3(blocks), dim3(256), 0, stream, *a); \
-                               else if (form == 2) MTX_LAUNCH((norm_packed_kernel<TT, N, true, true>), dim3(blocks), dim3(256), 0, stream, *a); \
-                               else if (form == 3) MTX_LAUNCH((norm_packed_kernel<TT, N, true, true, (N <= 6 ? 5 : 1)>), dim3(blocks), dim3(256), 0, stream, *a); \
-                               else MTX_LAUNCH((norm_packed_kernel<TT, N, true, false>), dim3(blocks), dim3(256), 0, stream, *a); } while (0)
+#define MTX_NORM_T(TT, N) do { if (!full) MTX_LAUNCH((norm_packed_kernel<TT, N, false, false>), dim3(blocks), dim3(256), 0, stream, *a); \
+                               else MTX_LAUNCH((norm_packed_kernel<TT, N, true, true>), dim3(blocks), dim3(256), 0, stream, *a); } while (0)
 #define MTX_NORM(N) do { if (a->dtype == MTX_BF16) MTX_NORM_T(__bf16, N); else MTX_NORM_T(_Float16, N); } while (0)
   if (per_lane <= 2) MTX_NORM(2);
   else if (per_lane <= 4) MTX_NORM(4);

@@ -50,7 +50,7 @@ class GemmArgs(C.Structure):
                 ("w_lo", vp), ("res_dtype", i32)]
 
 
-GEMM_FORCE_TILE256, GEMM_NO_SPLIT, GEMM_F8_WIDE, GEMM_SERIAL_EPILOGUE = 1, 2, 4, 8
+GEMM_FORCE_TILE256, GEMM_NO_SPLIT = 1, 2
 GEMM_WORKSPACE_BYTES = 2 * 320 * 256 * 256 * 4
 
 
@@ -64,7 +64,6 @@ class AttnArgs(C.Structure):
 
 
 ATTN_Q_PRESCALED = 1
-ATTN_SCHEDULE_SHIFT = 8      # bits 8..14 of AttnArgs.flags: schedule of the long-sequence kernel (include/mtx_hip.h)
 ATTN_WORKSPACE_BYTES = 256 * (256 * 128 * 4 + 256 * 2 * 4)
 
 
@@ -203,7 +202,7 @@ UNION_FIELD = {OP_CONV2D: "conv", OP_GEMM: "gemm", OP_ATTN: "attn", OP_NORM: "no
 # every symbol include/mtx_hip.h declares (tests check the built library exports all of them)
 EXPORTS = [
     "mtx_abi_version", "mtx_abi_sizeof", "mtx_last_error", "mtx_init", "mtx_device_info",
-    "mtx_conv2d", "mtx_conv2d_tiles", "mtx_gemm", "mtx_gemm_last_split", "mtx_attention", "mtx_norm", "mtx_norm_form", "mtx_groupnorm",
+    "mtx_conv2d", "mtx_conv2d_tiles", "mtx_gemm", "mtx_gemm_last_split", "mtx_attention", "mtx_norm", "mtx_groupnorm",
     "mtx_elementwise", "mtx_channel_attention", "mtx_image_convert", "mtx_resize_threshold",
     "mtx_mask_select", "mtx_preprocess", "mtx_yolo_decode", "mtx_detr", "mtx_quantize_mx", "mtx_page_tail", "mtx_bubble_clean", "mtx_host_text_mask", "mtx_host_chamfer_l2_5x5", "mtx_host_mask_outline", "mtx_host_png_encode",
     "mtx_plan_create", "mtx_plan_run", "mtx_plan_run_graph", "mtx_plan_num_ops",

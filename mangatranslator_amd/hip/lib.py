@@ -57,7 +57,6 @@ class MtxLibrary:
         d.mtx_host_png_encode.restype = C.c_int64
         d.mtx_conv2d_tiles.argtypes = [C.POINTER(abi.ConvArgs)]
         d.mtx_gemm_last_split.argtypes = [C.POINTER(C.c_int)] * 3
-        d.mtx_norm_form.argtypes = [C.c_int]
         d.mtx_plan_create.argtypes = [C.POINTER(abi.Op), C.c_int, C.POINTER(C.c_void_p)]
         d.mtx_plan_run.argtypes = [C.c_void_p, C.c_void_p]
         d.mtx_plan_run_graph.argtypes = [C.c_void_p, C.c_void_p]

@@ -353,11 +353,11 @@ class PlanBuilder:
         return out
 
     def attention(self, q, k, v, o, batch, heads, sq, sk, d, q_str, k_str, v_str, o_str, scale,
-                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False, q8=None, schedule=0):
+                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False, q8=None):
         """q8 = (q bytes [sq, ldq], scale plane [ldq / 128, lds], ldq, lds, byte column offset): the rows leave as the MX fp8 operand of the
         next linear instead of (o None) or beside 16-bit values — long-sequence kernel only (mtx_attn_args.q8)"""
         a = abi.AttnArgs()
-        a.flags = (abi.ATTN_Q_PRESCALED if q_prescaled else 0) | (int(schedule) << abi.ATTN_SCHEDULE_SHIFT)
+        a.flags = abi.ATTN_Q_PRESCALED if q_prescaled else 0
         a.q, a.k, a.v, a.o = _ptr(q, q_off), _ptr(k, k_off), _ptr(v, v_off), (_ptr(o, o_off) if o is not None else None)
         if q8 is not None:
             q8q, q8s, ldq, lds8, col = q8
@@ -377,8 +377,8 @@ class PlanBuilder:
 
     def norm(self, x, y, rows, c, ldx=None, ldy=None, gamma=None, beta=None, eps=1e-6, kind=0,
              mod_scale=None, mod_shift=None, rows_per=0, ldmod=0, x_off=0, y_off=0, act=abi.ACT_NONE,
-             label="norm", q8=None, q_row_off=0, lds_q=0, dtype=None, out_dtype=0):
-        """out_dtype (dtype = abi.F32 only): the type y is written in — 0 = fp32, abi.BF16 / abi.F16 = rounded once to the next linear's operand type.
+             label="norm", q8=None, q_row_off=0, lds_q=0, dtype=None, out_dtype=None):
+        """out_dtype (dtype = abi.F32 only): the type y is written in — None = fp32, abi.BF16 / abi.F16 = rounded once to the next linear's operand type.
         q8 = (q bytes [R, c], scale plane [c / 128, lds_q]): also (or, with y None, only) the MX fp8 twin of the result, rows landing
         at q_row_off (include/mtx_hip.h mtx_norm_args.q)"""
         a = abi.NormArgs()
@@ -391,7 +391,7 @@ class PlanBuilder:
         a.rows, a.c, a.ldx, a.ldy = rows, c, (ldx or c), (ldy or c)
         a.rows_per, a.ldmod = rows_per, ldmod
         a.eps, a.kind, a.dtype, a.act = eps, kind, (self.dtype if dtype is None else dtype), act      # dtype = abi.F32: an fp32 op inside a 16-bit plan
-        a.out_dtype = out_dtype
+        a.out_dtype = a.dtype if out_dtype is None else out_dtype
         self._add(abi.OP_NORM, a, label)
         return y
 

@@ -148,15 +148,6 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
         plan.run()
         _sync(lib)
         assert torch.equal(out, first), "a second run of the same plan differs (stale scratch read, or an order-dependent sum)"
-    if not out_f32:
-        # the 256-tile kernels' epilogue with its bias / gate / residual requests in batches against the one-at-a-time form: identical bytes
-        pb2 = PlanBuilder(lib, dev, dtype)
-        out2 = pb2.gemm(at, wt, m, n, k, bias=pb2.const(b) if b is not None else None, act=act,
-                        res=pb2.const(res) if res is not None else None,
-                        gate=pb2.const(gate) if gate is not None else None, gate_rows_per=rows_per,
-                        alpha=alpha, batch=batch, a_bs=m * k, w_bs=n * k, c_bs=m * n, flags=flags | abi.GEMM_SERIAL_EPILOGUE)
-        _run(pb2)
-        assert torch.equal(out2.view(torch.int16), first.view(torch.int16)), "gemm: the batched and the serial epilogue differ"
     return err
 
 
@@ -182,7 +173,7 @@ def check_gemm_huge_rows(lib, dtype, m, n, k, seed=0):
         assert err < TOL[dtype], f"gemm rows {rows} mismatch rel err {err}"
 
 
-def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, prescaled=False, schedule=0, late_keys=None):
+def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, prescaled=False, late_keys=None):
     """prescaled: q carries scale * log2(e) before its rounding to the storage type (MTX_ATTN_Q_PRESCALED): the reference is the
     base-2 softmax of q k^T, i.e. SDPA with scale = ln 2 on the very same rounded q"""
     g = torch.Generator().manual_seed(seed)
@@ -202,10 +193,10 @@ def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, presc
     o = pb.buf((batch, sq, heads, d), td, zero=True)
     pb.attention(qt, kt, vt, o, batch, heads, sq, sk, d,
                  (sq * heads * d, heads * d, d), (sk * heads * d, heads * d, d),
-                 (sk * heads * d, heads * d, d), (sq * heads * d, heads * d, d), scale, q_prescaled=prescaled, schedule=schedule)
+                 (sk * heads * d, heads * d, d), (sq * heads * d, heads * d, d), scale, q_prescaled=prescaled)
     _run(pb)
     err = _relerr(o.cpu(), ref)
-    assert err < TOL[dtype] * 1.5, f"attention mismatch rel err {err} (schedule {schedule})"
+    assert err < TOL[dtype] * 1.5, f"attention mismatch rel err {err}"
     return err
 
 
@@ -276,18 +267,6 @@ def check_norm(lib, dtype, rows, c, kind=0, affine=True, modulate=False, seed=0)
     plan = _run(pb)
     err = _relerr(y.cpu(), ref)
     assert err < TOL[dtype], f"norm mismatch rel err {err}"
-    # the packed-row kernel (default) and the fp32-register form of rounds 1-4 add in the same order: identical bytes
-    packed = y.clone()
-    try:
-        for form in (0, 1, 3):
-            lib.check(lib.mtx_norm_form(form), "mtx_norm_form")
-            y.zero_()
-            _sync(lib)
-            plan.run()
-            _sync(lib)
-            assert torch.equal(y.view(torch.int16), packed.view(torch.int16)), f"norm: kernel form {form} and the default differ"
-    finally:
-        lib.check(lib.mtx_norm_form(-1), "mtx_norm_form")
     return err
 
 
@@ -543,16 +522,6 @@ def check_fused_quantisers(lib, dtype, rows, c, hid, seed=0):
                 swiglu_b=abt, b_off=hid, ldb=2 * hid, y=sw1, ldy=hid)
     plan = _run(pb)
     assert torch.equal(y1, y2), "16-bit norm output changed"
-    keep = [t.clone() for t in (y1, q1, s1, q1b, s1b)]
-    try:
-        for form in (0, 1, 3):                                      # the other norm kernels: same bytes, 16-bit and fp8 twin
-            lib.check(lib.mtx_norm_form(form), "mtx_norm_form")
-            plan.run()
-            _sync(lib)
-            for t, k, what in zip((y1, q1, s1, q1b, s1b), keep, ("y", "q", "scales", "q (no y)", "scales (no y)")):
-                assert torch.equal(t.view(torch.uint8), k.view(torch.uint8)), f"norm kernel form {form} differs in {what}"
-    finally:
-        lib.check(lib.mtx_norm_form(-1), "mtx_norm_form")
     for a_, b_, what in ((q1, q2, "norm bytes"), (s1, s2, "norm scales"), (q1b, q2, "norm bytes (no 16-bit output)"), (s1b, s2, "norm scales (no 16-bit output)"),
                          (qs1, qs2, "SwiGLU bytes"), (ss1, ss2, "SwiGLU scales")):
         assert torch.equal(a_, b_), f"{what}: {(a_ != b_).sum().item()} differ"
@@ -612,17 +581,9 @@ def check_gemm_f8(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_re
     out = pb.gemm(aq, wq, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
                   res=pb.const(res) if res is not None else None, gate=pb.const(gate) if gate is not None else None,
                   gate_rows_per=rows_per, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=flags)
-    # the one-segment-per-k-step form of the whole-tile kernel (MTX_GEMM_F8_WIDE, round 5): same accumulation order, identical bytes
-    wide = pb.gemm(aq, wq, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
-                   res=pb.const(res) if res is not None else None, gate=pb.const(gate) if gate is not None else None,
-                   gate_rows_per=rows_per, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=flags | abi.GEMM_F8_WIDE | abi.GEMM_NO_SPLIT)
-    plain = pb.gemm(aq, wq, m, n, k, bias=pb.const(b) if b is not None else None, act=act,
-                    res=pb.const(res) if res is not None else None, gate=pb.const(gate) if gate is not None else None,
-                    gate_rows_per=rows_per, f8=(asc, lds_a, wsc, lds_w, 0, 0), flags=flags | abi.GEMM_NO_SPLIT)
     _run(pb)
     err = _relerr(out.cpu().view(m, n), ref)
     assert err < TOL[dtype], f"fp8 gemm mismatch rel err {err}"
-    assert torch.equal(wide.cpu(), plain.cpu()), "fp8 gemm: wide segments differ from the four-segment loop"
     return err, qerr
 
 
@@ -903,7 +864,7 @@ def check_hi_lo_weights(lib, dtype=abi.F16, m=300, n=96, k=144, seed=0):
     _run(pb)
     e_fast, e_high = _relerr(fast.cpu(), ref), _relerr(high.cpu(), ref)
     assert e_high < e_fast / 20 and e_high < 1e-5, (e_fast, e_high)          # what is left is fp32 accumulation over K (2.3e-6 at K = 1152 on the simulator)
-    assert _relerr(high.cpu(), high2k.cpu()) < 2e-6
+    assert _relerr(high.cpu(), high2k.cpu()) < 1e-5          # (two fp32 summation orders of the same products: noise grows with K)
     assert _relerr(high16.cpu(), F.gelu(ref + b)) < TOL[dtype]
     assert _relerr(closed.cpu(), ref + b + r32) < 1e-5
     return e_fast, e_high

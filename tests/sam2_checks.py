@@ -6,6 +6,9 @@ from mangatranslator_amd.core.ml.sam2 import Sam2Hip
 from oracle import sam2_ref as sr
 
 
+last = {}
+
+
 def make_page(h, w, seed):
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:h, 0:w]
@@ -62,6 +65,7 @@ def check_sam2(lib, device, size="tiny_test", h=300, w=200, n_boxes=3, seed=0, l
         finally:
             md._dynamic_multimask_via_stability = orig
     hipm = Sam2Hip(model.state_dict(), cfg, device=device, lib=lib, **hip_kw)
+    last["hip"] = hipm                      # (tools/sam_frontier.py times the plans of the model it has just checked)
     masks, low, iou, sel = hipm.segment(page, boxes, return_logits=True)
     if calibrated:
         thresh = md.dynamic_multimask_stability_thresh

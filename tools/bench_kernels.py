@@ -20,21 +20,20 @@ def _time(plan, iters):
     return min(plan.time(iters) for _ in range(3))
 
 
-def attn(T, heads=24, d=128, iters=10, schedule=0):
-    """schedule > 0: attn_x_kernel<schedule - 1> (mtx_attn_args.flags bits 8..11): 1 = K / V by LDS-DMA, + 1 stagger, + 2 matrix-pipe row sums, + 4 wide stores"""
+def attn(T, heads=24, d=128, iters=10):
     pb = PlanBuilder(lib, dev, abi.BF16)
     D = heads * d
     qkv = pb.buf((T, 3 * D), torch.bfloat16); qkv.normal_()
     o = pb.buf((T, D), torch.bfloat16)
     qkv[:, :D] *= d ** -0.5 * 1.4426950408889634         # the FLUX graphs' form: q pre-multiplied by scale * log2(e)
     pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D,
-                 q_prescaled=True, schedule=schedule)
+                 q_prescaled=True)
     ms = _time(pb.build(), iters)
-    print(f"attn T={T} heads={heads} schedule={schedule}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
+    print(f"attn T={T} heads={heads}: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
     return ms
 
 
-def attn_q8(T, heads=24, d=128, iters=10, fused=True, schedule=0):
+def attn_q8(T, heads=24, d=128, iters=10, fused=True):
     """FLUX.2 form: the rows leave as the MX fp8 operand of the next linear (fused: mtx_attn_args.q8; else attention + quantiser launch)"""
     pb = PlanBuilder(lib, dev, abi.BF16)
     D = heads * d
@@ -45,13 +44,13 @@ def attn_q8(T, heads=24, d=128, iters=10, fused=True, schedule=0):
     sc = pb.buf((D // 128, lds), torch.int32, zero=True)
     strides = ((0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d))
     if fused:
-        pb.attention(qkv, qkv, qkv, None, 1, heads, T, T, d, *strides, d ** -0.5, k_off=D, v_off=2 * D, q_prescaled=True, q8=(q8, sc, D, lds, 0), schedule=schedule)
+        pb.attention(qkv, qkv, qkv, None, 1, heads, T, T, d, *strides, d ** -0.5, k_off=D, v_off=2 * D, q_prescaled=True, q8=(q8, sc, D, lds, 0))
     else:
         o = pb.buf((T, D), torch.bfloat16)
         pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, *strides, d ** -0.5, k_off=D, v_off=2 * D, q_prescaled=True)
         pb.quantize(o, T, D, q=q8, scale=sc, lds=lds, ldq=D)
     ms = _time(pb.build(), iters)
-    print(f"attn -> MX fp8 T={T} heads={heads} schedule={schedule} [{'fused epilogue' if fused else 'attention + quantiser launch'}]: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
+    print(f"attn -> MX fp8 T={T} heads={heads} [{'fused epilogue' if fused else 'attention + quantiser launch'}]: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
 def gemm8_glu(M, hid, K, col0=0, iters=20, fused=True):
@@ -97,8 +96,6 @@ def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0, act=0):
     ms = _time(pb.build(), iters)
     split = lib.gemm_last_split()
     tag = " [whole tiles only]" if flags & abi.GEMM_NO_SPLIT else f" [whole tiles, K slices, pieces = {split}]"
-    if flags & abi.GEMM_F8_WIDE:
-        tag += " [wide segments]"
     if act:
         tag += " [bias + tanh-GELU epilogue]"
     print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K}{f' ld+{pad}' if pad else ''}{tag}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.0f} TFLOP/s", flush=True)
@@ -106,40 +103,30 @@ def gemm(M, N, K, iters=20, f8=False, pad=0, flags=0, act=0):
 
 def gemm_epi(M, N, K, kind, f8=False, reps=3, iters=20):
     """The 256-tile kernels with the epilogue a FLUX linear really has — kind "b": bias; "g": bias + tanh-GELU; "r": bias + gate + residual
-    (attention / MLP output projections) — with the epilogue's memory requests in batches (default) against one at a time
-    (MTX_GEMM_SERIAL_EPILOGUE), alternating in one process; the outputs must be the same bytes."""
-    outs, best = {}, {}
-    plans = {}
-    for serial in (0, 1):
-        pb = PlanBuilder(lib, dev, abi.BF16)
-        g = torch.Generator(device=dev).manual_seed(5)
-        a = pb.buf((M, K), torch.bfloat16); a.normal_(generator=g)
-        w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5, generator=g)
-        bias = pb.buf((N,), torch.float32); bias.normal_(generator=g)
-        gate = res = None
-        if kind == "r":
-            gate = pb.buf((2, N), torch.bfloat16); gate.normal_(generator=g)
-            res = pb.buf((M, N), torch.bfloat16); res.normal_(generator=g)
-        fl = abi.GEMM_SERIAL_EPILOGUE if serial else 0
-        kw = dict(bias=bias, act=abi.ACT_GELU_TANH if kind == "g" else 0, res=res, gate=gate, gate_rows_per=(M + 1) // 2, flags=fl)
-        if f8:
-            q = PlanBuilder(lib, dev, abi.BF16)
-            aq, asc, la = q.quantize(a, M, K)
-            wq, wsc, lw = q.quantize(w, N, K)
-            q.build().run(); torch.cuda.synchronize()
-            pb.keep += [aq, asc, wq, wsc]
-            outs[serial] = pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0), **kw)
-        else:
-            outs[serial] = pb.gemm(a, w, M, N, K, **kw)
-        plans[serial] = pb.build()
-    for _ in range(reps):
-        for serial in (0, 1):
-            ms = _time(plans[serial], iters)
-            best[serial] = min(best.get(serial, 1e9), ms)
-    same = torch.equal(outs[0], outs[1])
+    (attention / MLP output projections).  (Round 5 compared the batched epilogue with the one-at-a-time form here: profiles/r05_visit_q_*.log.)"""
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = pb.buf((M, K), torch.bfloat16); a.normal_(generator=g)
+    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5, generator=g)
+    bias = pb.buf((N,), torch.float32); bias.normal_(generator=g)
+    gate = res = None
+    if kind == "r":
+        gate = pb.buf((2, N), torch.bfloat16); gate.normal_(generator=g)
+        res = pb.buf((M, N), torch.bfloat16); res.normal_(generator=g)
+    kw = dict(bias=bias, act=abi.ACT_GELU_TANH if kind == "g" else 0, res=res, gate=gate, gate_rows_per=(M + 1) // 2)
+    if f8:
+        q = PlanBuilder(lib, dev, abi.BF16)
+        aq, asc, la = q.quantize(a, M, K)
+        wq, wsc, lw = q.quantize(w, N, K)
+        q.build().run(); torch.cuda.synchronize()
+        pb.keep += [aq, asc, wq, wsc]
+        pb.gemm(aq, wq, M, N, K, f8=(asc, la, wsc, lw, 0, 0), **kw)
+    else:
+        pb.gemm(a, w, M, N, K, **kw)
+    plan = pb.build()
+    best = min(_time(plan, iters) for _ in range(reps))
     what = {"b": "bias", "g": "bias + tanh-GELU", "r": "bias + gate + residual"}[kind]
-    print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K} [{what}]: batched epilogue {best[0]:.3f} ms ({2 * M * N * K / best[0] / 1e9:.0f} TFLOP/s), "
-          f"serial {best[1]:.3f} ms ({2 * M * N * K / best[1] / 1e9:.0f})  {100 * (best[1] / best[0] - 1):+.1f} %  same bytes: {same}", flush=True)
+    print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K} [{what}]: {best:.3f} ms ({2 * M * N * K / best / 1e9:.0f} TFLOP/s)", flush=True)
 
 
 def gemm_strips(M, N, K, f8=False, reps=3, iters=20, kind="b"):
@@ -198,8 +185,8 @@ def conv(H, W, iters=20):
 
 
 def norm(rows, c, reps=3, iters=50, q8=False):
-    """adaLN LayerNorm rows of a FLUX block (no affine, modulation rows per stream) under every mtx_norm_form, REPS rounds in one process;
-    q8: the FLUX.2 form (MX fp8 twin from the registers, no 16-bit store).  Also: all forms give identical bytes on this chip."""
+    """adaLN LayerNorm rows of a FLUX block (no affine, modulation rows per stream); q8: the FLUX.2 form (MX fp8 twin from the registers, no
+    16-bit store).  (Round 5 compared four kernel forms here: profiles/r05_visit_o / _p logs.)"""
     pb = PlanBuilder(lib, dev, abi.BF16)
     x = pb.buf((rows, c), torch.bfloat16); x.normal_()
     ms_, mh_ = pb.buf((2, c), torch.bfloat16), pb.buf((2, c), torch.bfloat16)
@@ -209,28 +196,13 @@ def norm(rows, c, reps=3, iters=50, q8=False):
     if q8:
         q, sc = pb.buf((rows, c), torch.uint8, zero=True), pb.buf((c // 128, lds), torch.int32, zero=True)
         pb.norm(x, None, rows, c, eps=1e-6, kind=0, mod_scale=ms_, mod_shift=mh_, rows_per=rows_per, ldmod=c, q8=(q, sc), lds_q=lds)
-        outs = (q, sc)
     else:
         y = pb.buf((rows, c), torch.bfloat16)
         pb.norm(x, y, rows, c, eps=1e-6, kind=0, mod_scale=ms_, mod_shift=mh_, rows_per=rows_per, ldmod=c)
-        outs = (y,)
     plan = pb.build()
-    best, ref = {}, None
-    for _ in range(reps):
-        for form in (0, 1, 2, 3):
-            lib.check(lib.mtx_norm_form(form), "mtx_norm_form")
-            for t in outs:
-                t.zero_()
-            t_ms = _time(plan, iters)
-            got = [t.clone() for t in outs]
-            if ref is None:
-                ref = got
-            same = all(torch.equal(a, b) for a, b in zip(got, ref))
-            best[form] = min(best.get(form, 1e9), t_ms)
-            byts = rows * c * (2 + (1 if q8 else 2))
-            print(f"norm {rows}x{c} {'-> MX fp8' if q8 else 'bf16'} form {form}: {t_ms * 1e3:.1f} us  {byts / t_ms / 1e6:.0f} GB/s  bytes equal to form 0: {same}", flush=True)
-    lib.check(lib.mtx_norm_form(-1), "mtx_norm_form")
-    print("norm best of", reps, {f: round(v * 1e3, 1) for f, v in best.items()}, flush=True)
+    t_ms = min(_time(plan, iters) for _ in range(reps))
+    byts = rows * c * (2 + (1 if q8 else 2))
+    print(f"norm {rows}x{c} {'-> MX fp8' if q8 else 'bf16'}: {t_ms * 1e3:.1f} us  {byts / t_ms / 1e6:.0f} GB/s", flush=True)
 
 
 if __name__ == "__main__":
@@ -238,17 +210,8 @@ if __name__ == "__main__":
     while args:
         if args[0] == "attn":
             attn(int(args[1])); args = args[2:]
-        elif args[0] == "attnx":                       # attnx T s1,s2,...  REPS: the listed schedules in turn, REPS rounds in one process
-            T, scheds, reps = int(args[1]), [int(v) for v in args[2].split(",")], int(args[3])
-            best = {}
-            for _ in range(reps):
-                for sc in scheds:
-                    ms = attn(T, schedule=sc)
-                    best[sc] = min(best.get(sc, 1e9), ms)
-            print("attnx best of", reps, {sc: round(v, 4) for sc, v in best.items()}, flush=True)
-            args = args[4:]
-        elif args[0] in ("attnq", "attnqs", "attnq67"):          # attention with MX fp8 output: fused epilogue / separate quantiser / the round-4 loop
-            attn_q8(int(args[1]), fused=args[0] != "attnqs", schedule=67 if args[0] == "attnq67" else 0); args = args[2:]
+        elif args[0] in ("attnq", "attnqs"):          # attention with MX fp8 output: fused epilogue / separate quantiser
+            attn_q8(int(args[1]), fused=args[0] != "attnqs"); args = args[2:]
         elif args[0] in ("glu", "glus"):              # glu M hid K col0
             gemm8_glu(int(args[1]), int(args[2]), int(args[3]), int(args[4]), fused=args[0] == "glu"); args = args[5:]
         elif args[0] in ("norm", "normq"):              # norm ROWS C: every norm kernel form in turn
@@ -257,7 +220,7 @@ if __name__ == "__main__":
             quant(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] == "conv":
             conv(int(args[1]), int(args[2])); args = args[3:]
-        elif args[0] in ("gemmeb", "gemmeg", "gemmer", "gemm8eb", "gemm8er"):      # gemmeK M N K: epilogue A/B (K = b / g / r), fp8 with gemm8eK
+        elif args[0] in ("gemmeb", "gemmeg", "gemmer", "gemm8eb", "gemm8er"):      # gemmeK M N K: with a real epilogue (K = b / g / r), fp8 with gemm8eK
             gemm_epi(int(args[1]), int(args[2]), int(args[3]), args[0][-1], f8=args[0].startswith("gemm8")); args = args[4:]
         elif args[0] in ("gemmst", "gemm8st", "gemmgst"):     # strip-count A/B of the 256-tile kernels' tile map
             gemm_strips(int(args[1]), int(args[2]), int(args[3]), f8=args[0] == "gemm8st", kind="g" if args[0] == "gemmgst" else "b"); args = args[4:]
@@ -265,7 +228,7 @@ if __name__ == "__main__":
             gemm(int(args[1]), int(args[2]), int(args[3]), act=abi.ACT_GELU_TANH); args = args[4:]
         elif args[0] == "gemmp":
             gemm(int(args[1]), int(args[2]), int(args[3]), pad=int(args[4])); args = args[5:]
-        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmn", "gemm8n", "gemms", "gemm8s", "gemmfs", "gemm8fs", "gemm8w"):
+        elif args[0].rstrip("0123456789") in ("gemm", "gemm8", "gemmn", "gemm8n", "gemms", "gemm8s", "gemmfs", "gemm8fs"):
             # ...n: no split at all, ...sN: exactly N K slices (e.g. gemms4, gemm8s2)
             name = args[0].rstrip("0123456789")
             fl = abi.GEMM_NO_SPLIT if name.endswith("n") else 0
@@ -273,8 +236,6 @@ if __name__ == "__main__":
                 fl = int(args[0][len(name):]) << 8
             if name.endswith("fs"):                    # gemmfsN: N slices also where the launcher would not slice (K shorter than 64 iterations)
                 fl |= abi.GEMM_FORCE_TILE256
-            if name.endswith("w"):                     # gemm8w: fp8 whole-tile kernel with one segment per k-step (MTX_GEMM_F8_WIDE)
-                fl |= abi.GEMM_F8_WIDE
             gemm(int(args[1]), int(args[2]), int(args[3]), f8=args[0].startswith("gemm8"), flags=fl); args = args[4:]
         else:
             raise SystemExit(f"unknown benchmark {args[0]}")

@@ -3,7 +3,6 @@
 //   paths also on interior tiles); the what-ifs of round 2 (profiles/r02_conv_probe_visit_n.log) are no longer in the kernel source
 //   ABL 7: shader-clock stamps at the phase boundaries of every slot, for wave 0 of both groups of workgroups 0 and 97
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/conv_probe.hip -o tools/probes/conv_probe
-#define C64_LS_STAMPS 1
 #include "../../mangatranslator_amd/csrc/conv_c64.hip"
 #include <cstdio>
 #include <vector>
@@ -16,18 +15,6 @@ template <int ABL, int VAR = 0> static float run(ConvC64Params p, unsigned grid,
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv3x3_c64_kernel<_Float16, ABL, ACT, VAR == 1, VAR == 2>), dim3(grid), dim3(512), 0, 0, p);
   hipEventRecord(a, 0);
   for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv3x3_c64_kernel<_Float16, ABL, ACT, VAR == 1, VAR == 2>), dim3(grid), dim3(512), 0, 0, p);
-  hipEventRecord(b, 0); hipEventSynchronize(b);
-  float ms = 0; hipEventElapsedTime(&ms, a, b);
-  return ms / iters * 1e3f;
-}
-
-// the lock-step form (round 6): VAR as above
-template <int VAR> static float run_ls(ConvC64Params p, unsigned grid, int iters) {
-  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  constexpr int ACT = VAR == 2 ? MTX_ACT_NONE : MTX_ACT_RELU;
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv3x3_c64_ls_kernel<_Float16, ACT, VAR == 1, VAR == 2>), dim3(grid), dim3(512), 0, 0, p);
-  hipEventRecord(a, 0);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv3x3_c64_ls_kernel<_Float16, ACT, VAR == 1, VAR == 2>), dim3(grid), dim3(512), 0, 0, p);
   hipEventRecord(b, 0); hipEventSynchronize(b);
   float ms = 0; hipEventElapsedTime(&ms, a, b);
   return ms / iters * 1e3f;
@@ -71,38 +58,6 @@ int main(int argc, char** argv) {
   t = run<4, 2>(p2, grid, 20); printf("   no epilogue / stores       %7.1f us\n", t);
   t = run<1, 2>(p2, grid, 20); printf("   no MFMA                    %7.1f us\n", t);
   t = run<0>(p, grid, 20); printf("ABL 0 again                   %7.1f us\n", t);
-  {
-    const unsigned total = (unsigned)(((W + 15) / 16) * ((H + 15) / 16));
-    const unsigned gls = total < 256u ? total : 256u;
-    ConvC64Params q1 = p1; q1.chan_sum = nullptr; hipMalloc((void**)&q1.chan_sum, (size_t)gls * 8 * 64 * 4);
-    for (int rep = 0; rep < 3; ++rep) {
-      const float a0 = run<0, 0>(p, grid, 20), b0 = run_ls<0>(p, gls, 20);
-      const float a1 = run<0, 1>(p1, grid, 20), b1 = run_ls<1>(q1, gls, 20);
-      const float a2 = run<0, 2>(p2, grid, 20), b2 = run_ls<2>(p2, gls, 20);
-      if (rep == 2) {      // stamps of the lock-step kernel (plain and residual forms): one launch each
-        for (int var = 0; var < 3; var += 2) {
-          ConvC64Params ps = var == 2 ? p2 : p; ps.chan_sum = (float*)dst;
-          hipMemset(dst, 0, 2 * 2 * 64 * 8 * 8);
-          if (var == 0) run_ls<0>(ps, gls, 1); else run_ls<2>(ps, gls, 1);
-          std::vector<unsigned long long> st(2 * 2 * 32 * 8);
-          hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost);
-          printf("---- lock-step stamps, variant %d: per iteration, shader clocks since its top [own DMA landed | past barrier | next DMA issued | loop + epilogue done] and the period\n", var);
-          for (int wg = 0; wg < 2; ++wg) for (int w = 0; w < 2; ++w) {
-            printf("workgroup %d wave %d:", wg ? 97 : 0, w ? 5 : 0);
-            for (int k = 0; k < 26; ++k) {
-              const unsigned long long* e = &st[((wg * 2 + w) * 32 + k) * 8];
-              if (!e[0]) continue;
-              const unsigned long long* en = &st[((wg * 2 + w) * 32 + k + 1) * 8];
-              printf("  [%d: %lld %lld %lld %lld | %lld]", k, (long long)(e[1] - e[0]), (long long)(e[2] - e[0]), (long long)(e[3] - e[0]), (long long)(e[4] - e[0]), en[0] ? (long long)(en[0] - e[0]) : -1LL);
-            }
-            printf("\n");
-          }
-        }
-      }
-      printf("round %d  two-group / lock-step [us]:  ReLU %6.1f / %6.1f   ReLU + sums %6.1f / %6.1f   scale + residual %6.1f / %6.1f   | lock-step GB/s %5.0f %5.0f %5.0f\n", rep, a0, b0, a1, b1, a2, b2,
-             bytes / b0 / 1e3, bytes / b1 / 1e3, (bytes + px * 128.0) / b2 / 1e3);
-    }
-  }
   for (int var = 0; var < 3; ++var) {
   hipMemset(dst, 0, 2 * 2 * 64 * 8 * 8);
   ConvC64Params ps = var == 2 ? p2 : p; ps.chan_sum = (float*)dst;       // the stamps go where the sums would (ABL 7 never flushes sums into it: SUM rows are per wave, the stamp area is separate for var 1 below)
