@@ -103,8 +103,7 @@ def parse():
     ap.add_argument("--with-traffic", action="store_true", help=argparse.SUPPRESS)       # (round 3's opt-in; the counter child now runs by default)
     ap.add_argument("--sam-precision", choices=("fast", "high"), default=None,
                     help="SAM-2.1 arithmetic: high = hi + lo trunk weights, fp32 residual stream and an fp32 mask decoder (core/ml/sam2.py); fast = 16-bit "
-                         "storage throughout.  Default: the product's rule (core/pipeline.py resolve_sam_precision) — high when inpainting or upscaling "
-                         "follows the masks (configs 3, 4, 5), fast for detect / segment / clean-only stage sets (configs 1, 2)")
+                         "storage throughout.  Default: the product's rule (core/pipeline.py resolve_sam_precision) — high for every stage set since round 6")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the counter child that fills roofline.traffic: after the timed region rank 0 (at --gpus 1) re-executes this command's inpaint "
                          "(or upscale) stage under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (two passes, --kernel-trace only) on a DiT cut to "
@@ -149,7 +148,7 @@ def parse():
         a.inpaint_steps = 20 if a.inpainter == "kontext" else 8
     a.sam_precision_rule = a.sam_precision is None
     if a.sam_precision is None:
-        a.sam_precision = "high" if {"inpaint", "upscale"} & {x.strip() for x in a.stages.split(",")} else "fast"
+        a.sam_precision = "high"                      # the product's rule since round 6: every batch, segment-only ones included
     return a
 
 
@@ -902,12 +901,16 @@ def run_extra_children():
     barrier discipline and prints its own JSON line, of which the figures are kept:
       config5  8 pages at 2048x3072, FLUX.2-Klein-4B with MX-fp8 block linears, 8 steps, + 2x upscale (BASELINE configs[4]; the reference's DEFAULT inpainter)
       config2  64 pages, detect + segment only (BASELINE configs[1]), two front halves in flight on sixteen hardware queues
-      first_block_cache  3 pages of config 3 with the OSB stage configured for the reference's nunchaku backend (first-block cache on)"""
+      first_block_cache  3 pages of config 3 with the OSB stage configured for the reference's nunchaku backend (first-block cache on)
+      upscale_model_lite_assumed_shape  the upscale stage alone with the reference's CLI-default upscaler, shape assumed (VERDICT r05 missing #3)"""
     import subprocess
     me = [sys.executable, str(Path(__file__).resolve()), "--no-cpu-baseline", "--no-traffic", "--extra-child"]
     jobs = {"config5": ["--config", "5", "--steps", "8", "--warmup", "2"],
             "config2": ["--config", "2", "--steps", "64", "--warmup", "4"],
-            "first_block_cache": ["--config", "3", "--steps", "3", "--warmup", "1", "--kontext-backend", "nunchaku"]}
+            "first_block_cache": ["--config", "3", "--steps", "3", "--warmup", "1", "--kontext-backend", "nunchaku"],
+            # the reference's CLI-default upscaler (core/config.py:185 image_upscale_model = "model_lite", the Fast_RCAN_PU file): ASSUMED shape
+            # (4 groups x 8 blocks x 64 features, pixel-unshuffle 2) — the real hyper-parameters come from the checkpoint's header, which is not here
+            "upscale_model_lite_assumed_shape": ["--stages", "upscale", "--upscale-model", "model_lite", "--steps", "10", "--warmup", "3"]}
     out = {}
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}          # each child picks its own queue count (see _early_hw_queues)
     for name, extra_args in jobs.items():
@@ -925,7 +928,7 @@ def run_extra_children():
             for k in ("roofline", "roofline_attention", "roofline_gemm_fp8", "roofline_gemm_bf16", "roofline_upscale_conv"):
                 if k in d:
                     keep[k] = {kk: vv for kk, vv in d[k].items() if kk not in ("traffic_detail", "per_conv")}
-            for k in ("stage_wall_ms_one_page", "front_replicas", "hw_queues", "segment_ms", "detect_net_ms", "upscale_ms", "first_block_cache", "inpainter"):
+            for k in ("stage_wall_ms_one_page", "front_replicas", "hw_queues", "segment_ms", "detect_net_ms", "upscale_ms", "first_block_cache", "inpainter", "segmenter", "upscaler"):
                 if k in c:
                     keep[k] = c[k]
             if "inpaint" in c:

@@ -115,11 +115,13 @@ class UnifiedCache:
         return _sha(f"yolo_{self._hash_image(image)}_{_sha(model_path.encode(), 16)}_conf{confidence:.3f}".encode())
 
     def get_sam_cache_key(self, image, yolo_boxes, seg_model: str = "yolo", conjoined_detection: bool = True,
-                          conjoined_confidence: float = 0.35) -> str:
+                          conjoined_confidence: float = 0.35, arithmetic: str = "") -> str:
+        """`arithmetic` (this package only; "" = the reference's key): the precision / storage type the SAM graphs were built with — masks
+        remembered under one arithmetic are not served to a batch that asked for another"""
         boxes = yolo_boxes.cpu().numpy() if hasattr(yolo_boxes, "cpu") else np.array(yolo_boxes)
         model = _sha(_SEG_MODEL_IDS.get(seg_model, "yolo").encode(), 8)
         return _sha((f"sam_{self._hash_image(image)}_{self._hash_numpy(boxes)}_{model}_seg{seg_model}"
-                     f"_conjoined{int(conjoined_detection)}_conf{conjoined_confidence:.3f}").encode())
+                     f"_conjoined{int(conjoined_detection)}_conf{conjoined_confidence:.3f}" + (f"_arith{arithmetic}" if arithmetic else "")).encode())
 
     def get_upscale_cache_key(self, image, factor: float, model_type: str = "model") -> str:
         return _sha(f"upscale_{self._hash_image(image)}_factor{factor:.3f}_model{model_type}".encode())

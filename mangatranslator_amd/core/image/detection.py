@@ -282,7 +282,8 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
         log_message("SAM disabled, using YOLO segmentation masks", verbose=verbose)
         return assemble(None), text_free_boxes
     try:
-        sam_key = cache.get_sam_cache_key(image_pil, primary_boxes, seg_model, conjoined_detection, conjoined_confidence)
+        sam_key = cache.get_sam_cache_key(image_pil, primary_boxes, seg_model, conjoined_detection, conjoined_confidence,
+                                          arithmetic=f"{getattr(manager, 'sam_precision', 'high')}-{getattr(manager, 'sam_storage', 'auto')}")
         remembered = cache.get_sam_masks(sam_key)
         if remembered is not None:
             log_message("Using cached SAM masks", verbose=verbose)

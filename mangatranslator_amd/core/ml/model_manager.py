@@ -639,7 +639,7 @@ class ModelManager:
             slot = self._slot(ModelType.SAM2)
             if self.is_loaded(slot):
                 loaded = self.models[slot][1].hip
-                if slot is not ModelType.SAM2 or ("high" if loaded.high else "fast") == getattr(self, "sam_precision", "high"):
+                if slot is not ModelType.SAM2 or loaded.precision == getattr(self, "sam_precision", "high"):
                     return self.models[slot]
                 self.unload_model(ModelType.SAM2, force_gc=False, verbose=verbose)      # `sam_precision` changed since the load: build the other arithmetic
             from .sam2 import Sam2Hip
@@ -656,7 +656,7 @@ class ModelManager:
             if slot is not ModelType.SAM2 and self.is_loaded(ModelType.SAM2):
                 # a replica takes the storage type set 0 settled on (its probe compared the two): one more model, no second probe
                 first = self.models[ModelType.SAM2][1].hip
-                hip = Sam2Hip(sd, config, device=self.device, dtype=first.dtype, precision="high" if first.high else "fast")
+                hip = Sam2Hip(sd, config, device=self.device, dtype=first.dtype, precision=first.precision)
                 self.models[slot] = (_Sam2ProcessorShim(), _Sam2ModelShim(hip, self.dtype))
                 return self.models[slot]
             # f16 storage (8x smaller logit error than bf16 against the fp32 reference: the `> 0` masks are what the page flow keeps)

@@ -456,15 +456,12 @@ _PIL_FORMAT_BY_SUFFIX = {".png": "PNG", ".jpg": "JPEG", ".jpeg": "JPEG", ".webp"
 
 
 def resolve_sam_precision(config) -> str:
-    """SAM-2.1 arithmetic of a batch: what `config.detection.sam_precision` pins ("fast" / "high"), otherwise "high" whenever the masks feed
-    inpainting or upscaling (+ 11.6 ms of GPU time on a page that takes hundreds: 5.1e-5 of the mask pixels differ from the fp32 reference
-    instead of 1.8e-4) and "fast" for detect / segment / clean-only batches (37.9 against 27.6 pages/s, profiles/r05_bench_config2_sam_*.json)"""
+    """SAM-2.1 arithmetic of a batch: what `config.detection.sam_precision` pins ("fast" / "high"), otherwise "high" — for every batch since
+    round 6, segment-only ones included (there the mask IS the product): weight pairs in one GEMM, the fp32 residual added in the GEMM epilogue
+    and an fp32 -> 16-bit LayerNorm brought its encoder from 20.3 to 13.8 ms (11.6 for "fast"), 4.9e-5 of the mask pixels differ from the fp32
+    reference instead of 1.8e-4, BASELINE config 2 runs 34.9 against 38.3 pages/s (profiles/r06_sam_frontier.json, r06_visit_f_...log)"""
     pinned = getattr(getattr(config, "detection", None), "sam_precision", None)
-    if pinned in ("fast", "high"):
-        return pinned
-    osb = getattr(config, "outside_text", None)
-    heavy_back = bool(getattr(osb, "enabled", False)) or bool(getattr(getattr(config, "output", None), "upscale_final_image", False))
-    return "high" if heavy_back else "fast"
+    return pinned if pinned in ("fast", "high") else "high"
 
 
 def default_front_workers(config) -> int:
@@ -490,7 +487,8 @@ def batch_vision_images(input_dir, config, output_dir=None, preserve_structure: 
     verbose = bool(getattr(config, "verbose", False))
     from .ml.model_manager import get_model_manager
     manager = get_model_manager()
-    manager.sam_precision = resolve_sam_precision(config)
+    previous_precision = getattr(manager, "sam_precision", "high")
+    manager.sam_precision = resolve_sam_precision(config)      # for this batch only: restored below (the manager is a process-wide singleton)
 
     def front(page, path):
         # worker thread: whatever it still has to load lazily is read locally — collectives belong to the main thread (preload below)
@@ -501,5 +499,8 @@ def batch_vision_images(input_dir, config, output_dir=None, preserve_structure: 
         return process_page_vision_back(state)[0]
 
     n = default_front_workers(config) if front_workers is None else max(1, int(front_workers))
-    return batch_process_images(input_dir, config, output_dir, preserve_structure, io_threads=io_threads, process_front=front, process_back=back,
-                                front_workers=n, preload=lambda: manager.preload_for_config(config, verbose))
+    try:
+        return batch_process_images(input_dir, config, output_dir, preserve_structure, io_threads=io_threads, process_front=front, process_back=back,
+                                    front_workers=n, preload=lambda: manager.preload_for_config(config, verbose))
+    finally:
+        manager.sam_precision = previous_precision

@@ -275,12 +275,12 @@ def test_preload_order_worker_thread_reads_and_legacy_names(manager, monkeypatch
 
 
 def test_sam_precision_of_a_batch():
-    """`resolve_sam_precision`: "high" when inpainting or upscaling follows the masks, "fast" for detect / segment / clean batches, a pin wins"""
+    """`resolve_sam_precision`: "high" for every batch since round 6 (segment-only ones included: there the mask is the product), a pin wins"""
     import types
     from mangatranslator_amd.core.pipeline import resolve_sam_precision
     ns = types.SimpleNamespace
     cfg = lambda osb, up, pin=None: ns(detection=ns(sam_precision=pin), outside_text=ns(enabled=osb), output=ns(upscale_final_image=up))
-    assert resolve_sam_precision(cfg(False, False)) == "fast"
+    assert resolve_sam_precision(cfg(False, False)) == "high"
     assert resolve_sam_precision(cfg(True, False)) == "high"
     assert resolve_sam_precision(cfg(False, True)) == "high"
     assert resolve_sam_precision(cfg(False, False, "high")) == "high"
