@@ -82,17 +82,26 @@ def gpu_local_cpus(device_index: int, n_devices: Optional[int] = None, sys_root:
     (one NUMA node, numa_node = -1): the caller then leaves the affinity alone."""
     from pathlib import Path
     addrs = gpu_pci_addresses(sys_root)
+    visible = None
     if torch.cuda.is_available() and sys_root == "/sys":
-        try:                                           # the runtime's own answer for this index, when it exposes it
-            pr = torch.cuda.get_device_properties(device_index)
-            if hasattr(pr, "pci_bus_id") and hasattr(pr, "pci_device_id"):
-                want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-                if want in addrs:
-                    device_index = addrs.index(want)
+        # the runtime's own answer: the PCI address of EVERY visible device, in the runtime's order — HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES may
+        # select any subset (GPUs 4-7 of 8): the share among the GPUs of one NUMA node is computed over the devices this process set can see
+        try:
+            vis = []
+            for i in range(torch.cuda.device_count()):
+                pr = torch.cuda.get_device_properties(i)
+                if not (hasattr(pr, "pci_bus_id") and hasattr(pr, "pci_device_id")):
+                    vis = None
+                    break
+                vis.append(f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0")
+            if vis and all(a in addrs for a in vis):
+                visible = vis
         except Exception:      # noqa: BLE001
-            pass
-    if n_devices is not None and len(addrs) > n_devices:
-        addrs = addrs[:n_devices]
+            visible = None
+    if visible is not None:
+        addrs = visible                                  # index = the runtime's device index; nothing to truncate
+    elif n_devices is not None and len(addrs) > n_devices:
+        addrs = addrs[:n_devices]                        # sysfs-order fallback (no PCI ids from the runtime): the first n in bus order
     if not (0 <= device_index < len(addrs)):
         return None
     base = Path(sys_root) / "bus" / "pci" / "devices"
@@ -115,7 +124,9 @@ def gpu_local_cpus(device_index: int, n_devices: Optional[int] = None, sys_root:
 
 
 def pin_host_threads_to_gpu(device_index: int, n_devices: Optional[int] = None, sys_root: str = "/sys") -> dict:
-    """`os.sched_setaffinity` of the calling thread (threads started afterwards inherit it) to `gpu_local_cpus`: a page's host work — NMS, mask
+    """`os.sched_setaffinity` of the calling thread to `gpu_local_cpus` — threads started AFTERWARDS inherit it, thread pools that already exist
+    (torch / OpenMP workers) stay where they were: call this before the first torch operation of the rank (bench.py and
+    integration.pin_rank_to_gpu_cpus() do).  What it is for: a page's host work — NMS, mask
     logic, PNG codecs, the launches themselves — then runs on the socket its GPU is attached to instead of wherever the scheduler put the
     rank.  At configs 1 / 2 speeds (tens of pages per second and GPU) eight ranks are host-bound.  -> what was done."""
     cpus = gpu_local_cpus(device_index, n_devices, sys_root)

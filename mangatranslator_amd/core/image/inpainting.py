@@ -186,7 +186,13 @@ class FluxKontextInpainter:
         self.pipeline = self.manager.load_flux_kontext_sdnq(low_vram=self.low_vram, verbose=True)
         if self.pipeline is not None:
             self.manager.set_flux_residual_diff_threshold(self.residual_diff_threshold)
-            self.pipeline.residual_diff_threshold = self.manager.flux_residual_diff_threshold if self.backend == "nunchaku" else 0.0
+            # the first-block-cache threshold travels with every call (`_cache_threshold`), not on the pipeline object the manager shares between
+            # inpainter instances: a second instance with another backend / threshold must not change what this one's memo keys record
+
+    @property
+    def _cache_threshold(self) -> float:
+        """residual_diff_threshold of this instance's pipeline calls: the reference turns the first-block cache on for its nunchaku backend only"""
+        return float(self.residual_diff_threshold) if self.backend == "nunchaku" else 0.0
 
     def unload_models(self):
         self.pipeline = None
@@ -282,7 +288,7 @@ class FluxKontextInpainter:
                     gen = torch.Generator(device="cpu").manual_seed(seed)
                     out = self.pipeline(image=scaled, width=inf_w, height=inf_h, num_inference_steps=self.num_inference_steps,
                                         guidance_scale=self.guidance_scale, generator=gen, output_type="pt",
-                                        max_area=inf_w * inf_h, **self._prompt_kwargs())
+                                        max_area=inf_w * inf_h, residual_diff_threshold=self._cache_threshold, **self._prompt_kwargs())
                     img = torch.nan_to_num(out.images[0].float(), nan=0.0, posinf=1.0, neginf=0.0).clamp_(0, 1)
                     patch_dev = img.mul(255).round().to(torch.uint8).permute(1, 2, 0).contiguous()
             patch_dev = tail.resize(patch_dev, (w, h), "lanczos")
@@ -307,7 +313,7 @@ class FluxKontextInpainter:
                 gen = torch.Generator(device="cpu").manual_seed(seed)
                 out = self.pipeline(image=scaled, width=inf_w, height=inf_h, num_inference_steps=self.num_inference_steps,
                                     guidance_scale=self.guidance_scale, generator=gen, output_type="pt",
-                                    max_area=inf_w * inf_h, **self._prompt_kwargs())
+                                    max_area=inf_w * inf_h, residual_diff_threshold=self._cache_threshold, **self._prompt_kwargs())
                 # sanitise / quantise where the tensor lives (on the GPU these are microseconds; on the host 100 ms of fp32 passes
                 # over 3 MP) and download the uint8 HWC image — the same IEEE operations in the same order, so the bytes are identical
                 img = torch.nan_to_num(out.images[0].float(), nan=0.0, posinf=1.0, neginf=0.0).clamp_(0, 1)

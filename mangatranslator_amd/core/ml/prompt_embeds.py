@@ -50,7 +50,7 @@ def export_kontext(repo: Path, out: Path, device: str, sdnq: bool, prompt: str =
         ids2 = tok2([prompt], padding="max_length", max_length=512, truncation=True, return_tensors="pt").input_ids.to(device)
         seq = t5(ids2, output_hidden_states=False)[0][0]
     out.parent.mkdir(parents=True, exist_ok=True)
-    save_file({"prompt_embeds": seq.to(torch.bfloat16).cpu().contiguous(), "pooled_prompt_embeds": pooled.to(torch.bfloat16).cpu().contiguous()}, str(out),
+    _save_atomically({"prompt_embeds": seq.to(torch.bfloat16).cpu().contiguous(), "pooled_prompt_embeds": pooled.to(torch.bfloat16).cpu().contiguous()}, out,
               metadata={"prompt": prompt, "max_sequence_length": "512", "encoders": "CLIP-L pooler_output + T5-XXL last_hidden_state"})
     return {"prompt_embeds": tuple(seq.shape), "pooled_prompt_embeds": tuple(pooled.shape)}
 
@@ -70,11 +70,35 @@ def export_klein(repo: Path, out: Path, device: str, sdnq: bool, prompt: str = N
         seq = torch.stack([hs[k] for k in QWEN3_LAYERS], dim=1)[0]                   # [3, L, H]
         seq = seq.permute(1, 0, 2).reshape(seq.shape[1], -1)                          # [L, 3 H]
     out.parent.mkdir(parents=True, exist_ok=True)
-    save_file({"prompt_embeds": seq.to(torch.bfloat16).cpu().contiguous()}, str(out),
+    _save_atomically({"prompt_embeds": seq.to(torch.bfloat16).cpu().contiguous()}, out,
               metadata={"prompt": prompt, "max_sequence_length": "512", "encoders": f"Qwen3 hidden states of layers {QWEN3_LAYERS}"})
     return {"prompt_embeds": tuple(seq.shape)}
 
 
+
+
+def _save_atomically(tensors: dict, out: Path, metadata: dict):
+    """write beside the target, then rename into place: a crash mid-write leaves no truncated prompt_embeds.safetensors behind that every
+    later load would take for the finished file; the temporary name carries the pid so that two writers never share it"""
+    import os
+    from safetensors.torch import save_file
+    tmp = out.with_name(f".{out.name}.{os.getpid()}.tmp")
+    try:
+        save_file(tensors, str(tmp), metadata=metadata)
+        os.replace(tmp, out)
+    finally:
+        if tmp.exists():
+            tmp.unlink()
+
+
+def _readable(out: Path) -> bool:
+    """a finished safetensors file: the header parses and names `prompt_embeds` (an unreadable file counts as absent and is re-encoded)"""
+    try:
+        from safetensors import safe_open
+        with safe_open(str(out), framework="pt") as f:
+            return "prompt_embeds" in f.keys()
+    except Exception:      # noqa: BLE001
+        return False
 
 
 def _sdnq_packed(folder: Path) -> bool:
@@ -96,10 +120,27 @@ def ensure_prompt_embeds(repo: Path, pipeline: str, device="cpu", log=None) -> b
     inpainting.py:846-873 / :1110-1124), the file is written, the encoders are dropped.  Absent and nothing to make it from: False — the
     pipeline's `encode_prompt` then raises the ModelError that names `tools/export_prompt_embeds.py`.  Called by rank 0 only."""
     out = repo / "prompt_embeds.safetensors"
-    if out.exists():
+    if out.exists() and _readable(out):
         return True
     if not encoders_staged(repo, pipeline):
         return False
+    # one encoder at a time per snapshot: under ModelManager.thread_local_reads every rank counts as rank 0 here, so a lock file (O_EXCL) picks
+    # the writer; the others wait for the finished file (the rename above makes its appearance atomic)
+    import os, time
+    lock = repo / ".prompt_embeds.lock"
+    try:
+        fd = os.open(str(lock), os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        os.close(fd)
+    except FileExistsError:
+        for _ in range(1800):
+            if out.exists() and _readable(out):
+                return True
+            if not lock.exists():
+                break
+            time.sleep(1.0)
+        return out.exists() and _readable(out)
+    except OSError:
+        pass                                    # read-only snapshot folder: encode anyway (the save will say so)
     try:
         sdnq = _sdnq_packed(repo / "text_encoder") or (pipeline == "kontext" and _sdnq_packed(repo / "text_encoder_2"))
         shapes = export_kontext(repo, out, str(device), sdnq) if pipeline == "kontext" else export_klein(repo, out, str(device), sdnq)
@@ -110,3 +151,8 @@ def ensure_prompt_embeds(repo: Path, pipeline: str, device="cpu", log=None) -> b
         if log is not None:
             log(f"could not encode the prompt from {repo}: {type(e).__name__}: {e}")
         return False
+    finally:
+        try:
+            lock.unlink()
+        except OSError:
+            pass

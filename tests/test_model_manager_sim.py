@@ -108,8 +108,11 @@ def test_load_flux_kontext_and_inpaint(manager):
     cached = FluxKontextInpainter(num_inference_steps=3, backend="nunchaku", residual_diff_threshold=0.4)
     cached.PREFERED_KONTEXT_RESOLUTIONS = [(48, 32), (32, 48), (32, 32)]
     out2 = cached.inpaint_mask(page, mask, seed=1)
-    assert pipe.residual_diff_threshold == 0.4 and manager.flux_residual_diff_threshold == 0.4
+    # the threshold travels with the call, not on the shared pipeline object: the sdnq instance above keeps running every block
+    assert pipe.residual_diff_threshold == 0.0 and cached._cache_threshold == 0.4 and inp._cache_threshold == 0.0 and manager.flux_residual_diff_threshold == 0.4
     assert out2.size == page.size and len(pipe.last["skipped"]) == 3 and pipe.last["skipped"][0] is False
+    out3 = inp.inpaint_mask(page, mask, seed=2)                      # the first instance again, after the cached one used the same pipeline object
+    assert out3.size == page.size and pipe.last["skipped"] == []     # no cache decisions: every step ran every block
     manager.unload_flux_kontext_sdnq_models()
     assert not manager.is_loaded(ModelType.FLUX_KONTEXT_SDNQ_PIPELINE)
 
