@@ -326,6 +326,11 @@ typedef struct mtx_yolo_decode_args {
   const void* level[4]; int32_t lh[4], lw[4], lld[4], lstride[4];
   int32_t n_levels, nc, nm, reg_max; float* out; int32_t dtype;
   int32_t cls_off, mc_off;       /* channel offsets of the class / mask-coefficient slices (0 -> packed) */
+  /* ABI 8.  box_f32[l] (optional): the 4 * reg_max DFL logits of level l as fp32 rows [lh * lw][4 * reg_max] — the box branch's last 1x1
+   * convolution written by an fp32-output GEMM; the box channels of level[l] are then not read.  The reference runs this branch in fp32 end
+   * to end (ultralytics behind core/image/detection.py:1337-1345) and its boxes feed IoU > 0.7 / IoA > 0.9 index decisions: the logits'
+   * rounding to 16 bits alone is 0.03 bin = 1 px at stride 32. */
+  const float* box_f32[4];
 } mtx_yolo_decode_args;
 
 /* ---- bubble cleaning, pixel half (replaces the cv2 chain of reference core/image/cleaning.py:296-337 ------

@@ -254,11 +254,11 @@ class Yolo11Hip(YoloSegHip):
             n4 = self._a2c2f(pb, self._cat(pb, [self._conv(pb, h3, "model.15", 2), h4], "cat16"), 17, 1)
             n5 = self._c3k2(pb, self._cat(pb, [self._conv(pb, n4, "model.18", 2), p5], "cat19"), 20)
         hi, nb, ncp, nm = a["head"], 4 * a["reg_max"], 8, a["nm"]
-        heads = []
+        heads, box32 = [], []
         for l, f in enumerate((h3, n4, n5)):
             hb = pb.act(1, f.h, f.w, nb + ncp + nm)
             t = self._conv(pb, self._conv(pb, f, f"model.{hi}.cv2.{l}.0"), f"model.{hi}.cv2.{l}.1")
-            self._conv(pb, t, f"model.{hi}.cv2.{l}.2", act=abi.ACT_NONE, out=hb.slice(0, nb))
+            box32.append(self._box_logits_f32(pb, t, f"model.{hi}.cv2.{l}.2", nb))       # (hb's first nb channels stay unwritten: the decode reads the fp32 logits)
             t = f
             for s in range(2):            # (depthwise 3x3, SiLU) -> (1x1, SiLU), twice
                 w, b, k = self.DW[f"model.{hi}.cv3.{l}.{s}.0"]
@@ -270,7 +270,7 @@ class Yolo11Hip(YoloSegHip):
             heads.append(hb)
         anchors = sum(hb.h * hb.w for hb in heads)
         decoded = pb.buf((anchors, 4 + a["nc"] + nm), torch.float32)
-        pb.yolo_decode(heads, [8, 16, 32], a["nc"], nm, a["reg_max"], decoded, cls_off=nb, mc_off=nb + ncp)
+        pb.yolo_decode(heads, [8, 16, 32], a["nc"], nm, a["reg_max"], decoded, cls_off=nb, mc_off=nb + ncp, box_f32=box32)
         proto = None
         if nm:
             t = self._conv(pb, h3, f"model.{hi}.proto.cv1")

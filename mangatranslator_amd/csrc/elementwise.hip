@@ -980,11 +980,12 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(mtx_yolo_decode_args p
   const int y = off / p.lw[l], x = off % p.lw[l];
   const T* src = reinterpret_cast<const T*>(p.level[l]) + (size_t)off * p.lld[l];
   float d4[4];
+  const float* b32 = p.box_f32[l] != nullptr ? p.box_f32[l] + (size_t)off * 4 * p.reg_max : nullptr;      // fp32 DFL logits (round 6): see mtx_yolo_decode_args.box_f32
   for (int s = 0; s < 4; ++s) {          // DFL: expectation of softmax over reg_max bins
     float m = -1e30f;
-    for (int k = 0; k < p.reg_max; ++k) { const float v = to_f32(src[s * p.reg_max + k]); m = v > m ? v : m; }
+    for (int k = 0; k < p.reg_max; ++k) { const float v = b32 ? b32[s * p.reg_max + k] : to_f32(src[s * p.reg_max + k]); m = v > m ? v : m; }
     float se = 0.f, sw = 0.f;
-    for (int k = 0; k < p.reg_max; ++k) { const float e = __expf(to_f32(src[s * p.reg_max + k]) - m); se += e; sw += e * (float)k; }
+    for (int k = 0; k < p.reg_max; ++k) { const float e = expf((b32 ? b32[s * p.reg_max + k] : to_f32(src[s * p.reg_max + k])) - m); se += e; sw += e * (float)k; }
     d4[s] = sw / se;
   }
   const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)p.lstride[l];

@@ -130,7 +130,7 @@ class PreprocArgs(C.Structure):
 class YoloDecodeArgs(C.Structure):
     _fields_ = [("level", vp * 4), ("lh", i32 * 4), ("lw", i32 * 4), ("lld", i32 * 4), ("lstride", i32 * 4),
                 ("n_levels", i32), ("nc", i32), ("nm", i32), ("reg_max", i32), ("out", vp), ("dtype", i32),
-                ("cls_off", i32), ("mc_off", i32)]
+                ("cls_off", i32), ("mc_off", i32), ("box_f32", vp * 4)]
 
 
 class MemsetArgs(C.Structure):

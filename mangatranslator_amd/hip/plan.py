@@ -580,10 +580,13 @@ class PlanBuilder:
         self._add(abi.OP_PREPROC, a, label)
         return dst
 
-    def yolo_decode(self, levels, strides, nc, nm, reg_max, out, cls_off=0, mc_off=0, label="yolo_decode"):
+    def yolo_decode(self, levels, strides, nc, nm, reg_max, out, cls_off=0, mc_off=0, label="yolo_decode", box_f32=None):
+        """box_f32: per level an fp32 [h * w, 4 * reg_max] matrix of DFL logits (mtx_yolo_decode_args.box_f32) read instead of the level's box channels"""
         a = abi.YoloDecodeArgs()
         for i, (lv, st) in enumerate(zip(levels, strides)):
             a.level[i], a.lh[i], a.lw[i], a.lld[i], a.lstride[i] = lv.ptr, lv.h, lv.w, lv.ld, st
+            if box_f32 is not None:
+                a.box_f32[i] = _ptr(box_f32[i])
         a.n_levels, a.nc, a.nm, a.reg_max, a.out, a.dtype = len(levels), nc, nm, reg_max, _ptr(out), self.dtype
         a.cls_off, a.mc_off = cls_off, mc_off
         self._add(abi.OP_YOLO_DECODE, a, label)

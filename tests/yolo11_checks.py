@@ -71,7 +71,9 @@ def check(lib, device, family="11", scale="n", seg=False, h=96, w=64, imgsz=64, 
     stats.update(box_err_px=box_err, box_median_px=box_med, box_p999_px=box_p999, box_err_bins_by_stride=dict(zip(strides, [round(v, 4) for v in lvl_bins])))
     print(f"YOLO{family}{scale}{'-seg' if seg else ''} @{lp['W']}x{lp['H']}: decoded boxes max {box_err:.3f} px (median {box_med:.4f}, 99.9 % {box_p999:.3f}; "
           f"worst anchor per level {', '.join(f'{v:.3f} bin @ stride {st}' for st, v in zip(strides, lvl_bins))}), class score abs err {e_cls:.4f}")
-    assert max(lvl_bins) < 0.08 and box_p999 < 1.5 and box_med < 0.05 and e_cls < tol
+    # round 6: the box branch's last convolution and the DFL expectation run on fp32 logits (mtx_yolo_decode_args.box_f32), and the flat bound on
+    # the worst anchor of any level is back beside the per-level one
+    assert box_err < 2.0 and max(lvl_bins) < 0.08 and box_p999 < 1.5 and box_med < 0.05 and e_cls < tol
     if seg:
         e_mc = ((dec[4 + nc:] - want[4 + nc:]).abs().max() / want[4 + nc:].abs().max()).item()
         assert e_mc < 2 * tol, e_mc
