@@ -26,7 +26,6 @@ struct AttnParams {
   // key-split tail of the long-sequence kernel: workgroups [0, n_full) cover whole key ranges; the remaining query
   // blocks are cut into `split` key ranges each and merged from the partials (unnormalised O^T, running max, sum)
   unsigned n_full, split;
-  unsigned block0;               // added to blockIdx.x (the key-split tail blocks launched on their own behind the one-wave-per-SIMD kernel)
   float* part_o; float* part_ml;
   int prescaled;                 // q carries scale * log2(e): scale_log2 == 1
   // MX fp8 output of the long-sequence kernel (mtx_attn_args.q8): bytes [sq][ldq8] (head h at byte column h * d), scale words [heads * d / 128][lds_q8]
@@ -246,15 +245,6 @@ constexpr int AB_KV = 64;
 #define MTX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0x0476)
 #endif
 constexpr int AB_QB = 256;
-// pins a plain LDS read between two `asm volatile` MFMAs (the compiler still places and counts the s_waitcnt in front of the consumer);
-// W64_SLOT ends a MFMA gap for the scheduler: what was written between two of them stays between them
-#ifdef MTX_EMU
-#define MTX_ASM_FENCE() ((void)0)
-#define W64_SLOT() ((void)0)
-#else
-#define MTX_ASM_FENCE() asm volatile("" ::: "memory")
-#define W64_SLOT() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 // One K/V tile of the main loop.  STAGE is a compile-time constant so every LDS address is
 // (loop-invariant VGPR) + (immediate offset).
@@ -535,383 +525,6 @@ __device__ __forceinline__ void half_pair_exchange(uint32_t& a, uint32_t& b) {
 #undef ATTN_MMA32_WIDE
 #undef ATTN_MMA32_Q8
 
-// =====================================================================================================
-// Round 6: the long-sequence kernel with ONE wave per SIMD.  A workgroup is four waves, a wave owns 64 query rows as two
-// 32-row STREAMS and the whole 512-register file (O^T of both streams and the Q^T fragments in the accumulator registers, S^T / P / fragments
-// in the vector registers).  The two streams are what the two waves of a SIMD were in the 8-wave kernel — but interleaved STATICALLY, in one
-// instruction stream whose order is the issue order (`asm volatile` MFMAs):
-//
-//      period t:   S(t, 0)          | P(t-1, 1)        | S(t, 1)           | P(t, 0)            16 MFMAs each
-//      beside it:  X(t-1, 1) 2nd half, check | X(t, 0) 1st half | X(t, 0) 2nd half, check | X(t, 1) 1st half       2 - 3 vector instructions per MFMA gap
-//                  + the K fragment reads  | + V^T reads      | + K reads         | + V^T reads        two MFMAs ahead of their use
-//
-// S = the S^T tile of a stream (seeded with minus its running maximum), X = exp2 / row sum / pack of its 32 values per lane, P = P V.  A
-// stream's softmax lies between its S and its P phase — under the OTHER stream's MFMAs.  K / V tiles arrive by LDS-DMA into a ring of three
-// stages (tile t + 1 lands while tile t is computed and tile t - 1's V is still read): one barrier per tile, the DMA waited for in front of
-// it.  Maximum handling is the 8-wave kernel's: taken on the first tile, afterwards only when a partial row sum leaves the safe range (then
-// the stream's 32 values are redone after the refresh — rare, not overlapped).  Keys past the end of the sequence are zero rows (descriptor
-// range check): their scores are exactly minus the running maximum, their V rows zero, and their share of the row sum is subtracted at the end.
-// d = 128, pre-scaled q, 16-byte aligned output rows (the FLUX graphs); whole key ranges only (the key-split tail blocks stay with the 8-wave kernel).
-#ifdef MTX_EMU
-template <typename T> __device__ __forceinline__ void w64_seed(f32x16& d, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b, const f32x16& c) { d = Mma32<T>::mfma(a, b, c); }
-template <typename T> __device__ __forceinline__ void w64_s(f32x16& d, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) { d = Mma32<T>::mfma(a, b, d); }
-template <typename T> __device__ __forceinline__ void w64_o(f32x16& d, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b) { d = Mma32<T>::mfma(a, b, d); }
-#define W64_DRAIN() ((void)0)
-#else
-template <typename T> __device__ __forceinline__ void w64_seed(f32x16& d, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b, const f32x16& c);
-template <typename T> __device__ __forceinline__ void w64_s(f32x16& d, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b);
-template <typename T> __device__ __forceinline__ void w64_o(f32x16& d, const typename Traits<T>::v8& a, const typename Traits<T>::v8& b);
-// S^T in vector registers (the softmax reads it), its B operand (Q^T) in accumulator registers; O^T in accumulator registers
-template <> __device__ __forceinline__ void w64_seed<__bf16>(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c)); }
-template <> __device__ __forceinline__ void w64_s<__bf16>(f32x16& d, const bf16x8& a, const bf16x8& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b)); }
-template <> __device__ __forceinline__ void w64_o<__bf16>(f32x16& d, const bf16x8& a, const bf16x8& b) { asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
-template <> __device__ __forceinline__ void w64_seed<_Float16>(f32x16& d, const f16x8& a, const f16x8& b, const f32x16& c) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c)); }
-template <> __device__ __forceinline__ void w64_s<_Float16>(f32x16& d, const f16x8& a, const f16x8& b) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b)); }
-template <> __device__ __forceinline__ void w64_o<_Float16>(f32x16& d, const f16x8& a, const f16x8& b) { asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
-// the asm form hides the MFMAs from the hazard recogniser: their results are read by other instructions next
-#define W64_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
-#endif
-
-constexpr int W64_TILE_B = AB_KV * 256;            // one K or V tile: 16 KB
-constexpr int W64_QB = 256;                        // query rows per workgroup (4 waves x 64)
-#ifndef W64_LOOKAHEAD
-#define W64_LOOKAHEAD 4                           // fragment reads in flight ahead of the MFMA that uses them
-#endif
-
-template <typename T>
-__global__ __launch_bounds__(256) void attn_w64_kernel(AttnParams p) {
-  typedef typename Traits<T>::v8 v8;
-  typedef typename Traits<T>::v4 v4;
-  constexpr int DP = 128, ROWB = 256;
-  // LDS: the K tiles of the three stages, then the V tiles: every fragment address is (one vector register per k-step / d-block) + an immediate
-  // below 64 KB whatever the stage (96 KB in one piece would put stage 2 beyond the reach of a ds offset: an address add per read)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[6 * W64_TILE_B + 16];      // (+ the workgroup's redo flag: ONE LDS object)
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-#ifdef MTX_EMU
-  const int wv = tid >> 6;
-#else
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
-  const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-  const long bh = vb / p.qblocks, qb = vb % p.qblocks;
-  const long b = bh / p.heads, h = bh % p.heads;
-  const long q0 = qb * W64_QB + wv * 64;
-  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
-  const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
-  const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
-  T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + h * p.o_hs;
-
-  v8 qf0[8], qf1[8];             // Q^T fragments of the two streams (accumulator registers: the B operand of the S^T MFMAs)
-  f32x16 oa0[4], oa1[4];         // O^T (accumulator registers)
-  f32x16 sa0[2], sa1[2];         // S^T of the tile in flight, per 32-key half
-  u32x4 pq0[4], pq1[4];          // P^T operands, packed pairs: word w of quad g = values 8 g + 2 w, 8 g + 2 w + 1 of the stream's 32 (a quad = the B operand of one 16-key step, one register tuple: no copy in front of the MFMA)
-  f32x16 mi0, mi1;               // minus the running maximum (log2 units), the seed of S^T
-  float M0 = 0.f, M1 = 0.f, ls0 = 0.f, ls1 = 0.f, ts0 = 0.f, ts1 = 0.f;
-  {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const long qr0 = q0 + l31, qr1 = q0 + 32 + l31;
-      u32x4 r0 = u32x4{0u, 0u, 0u, 0u}, r1 = u32x4{0u, 0u, 0u, 0u};
-      if (qr0 < p.sq) r0 = *reinterpret_cast<const u32x4*>(Q + qr0 * p.q_ss + ks * 16 + hi * 8);
-      if (qr1 < p.sq) r1 = *reinterpret_cast<const u32x4*>(Q + qr1 * p.q_ss + ks * 16 + hi * 8);
-      qf0[ks] = __builtin_bit_cast(v8, r0); qf1[ks] = __builtin_bit_cast(v8, r1);
-#ifndef MTX_EMU
-      asm volatile("" : "+a"(qf0[ks]), "+a"(qf1[ks]));      // accumulator-register values from here on (not vector registers the allocator parks there and copies back per use)
-#endif
-    }
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oa0[d][r] = 0.f; oa1[d][r] = 0.f; }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { mi0[r] = 0.f; mi1[r] = 0.f; }
-  }
-
-  // ---- K / V tiles by LDS-DMA: piece i of a tile = rows 4 i .. 4 i + 3 (1 KB); lane l -> row 4 i + l / 16, 16-byte slot l % 16, which must hold
-  // chunk (slot ^ swizzle(row)) of that row — the swizzle is applied on the per-lane SOURCE offset.  Wave w moves pieces 4 w .. 4 w + 3 of K and of V.
-  const BufView kb_ = make_buf(K, (unsigned)(((p.sk - 1) * p.k_ss + DP) * sizeof(T)));
-  const BufView vb_ = make_buf(V, (unsigned)(((p.sk - 1) * p.v_ss + DP) * sizeof(T)));
-  unsigned kvoff[4], vvoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wv * 4 + i) * 4 + (lane >> 4), slot = lane & 15;
-    kvoff[i] = (unsigned)((row * p.k_ss + ((slot ^ (row & 15)) * 8)) * sizeof(T));
-    vvoff[i] = (unsigned)((row * p.v_ss + ((slot ^ ((row & 3) << 2)) * 8)) * sizeof(T));
-  }
-  const unsigned k_step = (unsigned)(AB_KV * p.k_ss * sizeof(T)), v_step = (unsigned)(AB_KV * p.v_ss * sizeof(T));
-  auto dma_tile = [&](long t, int stage) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      buf_load16_lds(kb_, kvoff[i], (unsigned)t * k_step, smem + stage * W64_TILE_B + (wv * 4 + i) * 1024);
-      buf_load16_lds(vb_, vvoff[i], (unsigned)t * v_step, smem + (3 + stage) * W64_TILE_B + (wv * 4 + i) * 1024);
-    }
-  };
-
-  // ---- loop-invariant LDS fragment addresses, as in the 8-wave kernel: K relative to the K region, V^T relative to the V region
-  const unsigned char* kaddr[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = smem + l31 * ROWB + (((2 * ks + hi) ^ (l31 & 15)) << 4);
-  const unsigned char* vaddr[4];
-  {
-    const int ti = lane & 15, g1 = (lane >> 4) & 1;
-    const int vrow = hi * 4 + (ti >> 2);
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-      vaddr[d] = smem + 3 * W64_TILE_B + vrow * ROWB + (((4 * d + 2 * g1 + ((ti & 3) >> 1)) ^ ((ti >> 2) << 2)) << 4) + (ti & 1) * 8;
-  }
-
-  // one value of a stream's softmax: c = 16 kb + r
-  // (packed at once, pair by pair: left to itself the compiler keeps all 32 exponentials of a stream as fp32 until a whole operand can be packed —
-  // 64 registers that do not exist here)
-  // Issue order inside a gap matters with one wave per SIMD: v_exp_f32 is a transcendental (its result wants a wait state before it is read), so
-  // the exponential of value c is ADDED one value later and PACKED with its partner two values later; `xflush` settles what is pending after
-  // value 31.  The add is inline asm: left to itself the compiler pairs the two streams' adds into v_pk_add_f32, which costs more beside MFMAs
-  // than the two plain adds (MI355X_MICROARCH.md, price of a filler).
-  typedef __attribute__((ext_vector_type(2))) T v2;
-  float pe0a = 0.f, pe0b = 0.f, pe1a = 0.f, pe1b = 0.f;       // the last two exponentials of each stream (a = older)
-  auto add1 = [&](float& acc, float v) {
-#ifdef MTX_EMU
-    acc += v;
-#else
-    asm("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(v));
-#endif
-  };
-  auto x0 = [&](int c) {
-    const float e = fast_exp2(sa0[c >> 4][c & 15]);
-    if (c >= 1) add1(ts0, pe0b);
-    if (c >= 2 && !(c & 1)) pq0[(c - 2) >> 3][((c - 2) >> 1) & 3] = __builtin_bit_cast(uint32_t, v2{from_f32<T>(pe0a), from_f32<T>(pe0b)});
-    pe0a = pe0b; pe0b = e;
-  };
-  auto x1 = [&](int c) {
-    const float e = fast_exp2(sa1[c >> 4][c & 15]);
-    if (c >= 1) add1(ts1, pe1b);
-    if (c >= 2 && !(c & 1)) pq1[(c - 2) >> 3][((c - 2) >> 1) & 3] = __builtin_bit_cast(uint32_t, v2{from_f32<T>(pe1a), from_f32<T>(pe1b)});
-    pe1a = pe1b; pe1b = e;
-  };
-  // the same values where no MFMA separates them (prologue, drain, redo): plain C++, so that every exponential's reader gets its wait state from
-  // the compiler (two v_exp_f32 back to back and an inline-asm add of the first one's result: wrong sums in lanes 0-3, 8-11, ... on hardware)
-  auto xs0 = [&](int c0, int c1) {
-#pragma unroll
-    for (int c = c0; c < c1; c += 2) {
-      const float ea = fast_exp2(sa0[c >> 4][c & 15]), eb = fast_exp2(sa0[(c + 1) >> 4][(c + 1) & 15]);
-      ts0 += ea; ts0 += eb;
-      pq0[c >> 3][(c >> 1) & 3] = __builtin_bit_cast(uint32_t, v2{from_f32<T>(ea), from_f32<T>(eb)});
-    }
-  };
-  auto xs1 = [&](int c0, int c1) {
-#pragma unroll
-    for (int c = c0; c < c1; c += 2) {
-      const float ea = fast_exp2(sa1[c >> 4][c & 15]), eb = fast_exp2(sa1[(c + 1) >> 4][(c + 1) & 15]);
-      ts1 += ea; ts1 += eb;
-      pq1[c >> 3][(c >> 1) & 3] = __builtin_bit_cast(uint32_t, v2{from_f32<T>(ea), from_f32<T>(eb)});
-    }
-  };
-  // (plain adds here: the value flushed was written by a v_exp_f32 one instruction ago, and only the compiler's own instructions get the wait
-  // state a transcendental's result needs — an inline-asm add read it early in the lane groups the unit had not finished: wrong row sums in lanes
-  // 0-3, 8-11, ... on hardware, never on the simulator)
-  auto xflush0 = [&]() { ts0 += pe0b; pq0[3][3] = __builtin_bit_cast(uint32_t, v2{from_f32<T>(pe0a), from_f32<T>(pe0b)}); };
-  auto xflush1 = [&]() { ts1 += pe1b; pq1[3][3] = __builtin_bit_cast(uint32_t, v2{from_f32<T>(pe1a), from_f32<T>(pe1b)}); };
-  // the exact path: a stream's maximum is refreshed from the tile in its S^T registers (first tile: set), everything that depends on it is rescaled
-  auto refresh = [&](f32x16 (&sa)[2], f32x16 (&oa)[4], f32x16& mi, float& M, float& ls, bool first) {
-    float tmax = fmaxf(sa[0][0], sa[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sa[0][r]), sa[1][r]);
-    tmax = half_max(tmax);
-    const float delta = first ? tmax : fmaxf(tmax, 0.f);
-    const float alpha = fast_exp2(-delta);
-    M += delta;
-    ls *= alpha;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oa[d][r] *= alpha;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mi[r] = -M;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sa[kb][r] -= delta;
-  };
-  // end of a stream's softmax on the fast path: a partial row sum outside the safe range (inf / nan included) means the first tile's maximum was
-  // too stale for this block — remembered, and the whole block is redone at the end with the maximum taken every tile (never on real data; the
-  // refresh itself — 64 accumulator registers through the vector ALU — stays out of the pipelined loop and out of its register allocation)
-  // the first tile sets the maximum (nothing to rescale yet)
-  auto first_max = [&](f32x16 (&sa)[2], f32x16& mi, float& M) {
-    float tmax = fmaxf(sa[0][0], sa[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sa[0][r]), sa[1][r]);
-    tmax = half_max(tmax);
-    M = tmax;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mi[r] = -tmax;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sa[kb][r] -= tmax;
-  };
-  bool bad = false;
-  auto check0 = [&]() { xflush0(); bad = bad || !(ts0 < AttnSumLimit<T>::v); ls0 += ts0; ts0 = 0.f; };
-  auto check1 = [&]() { xflush1(); bad = bad || !(ts1 < AttnSumLimit<T>::v); ls1 += ts1; ts1 = 0.f; };
-  // S phase of a stream on the K tile of stage STG: 16 MFMAs, the fragment of MFMA m + 2 read behind MFMA m's predecessor, one softmax value of
-  // the other stream (XJ, values X0 + m) per MFMA gap (XJ < 0: none)
-  auto phase_s = [&](auto stg_c, auto j_c, auto xj_c, auto x0_c) {
-    constexpr int STG = decltype(stg_c)::value, J = decltype(j_c)::value, XJ = decltype(xj_c)::value, XB = decltype(x0_c)::value;
-    constexpr int LA = W64_LOOKAHEAD, RING = LA + 1;
-    v8 kf[RING];
-    auto rd = [&](int m) { kf[m % RING] = *reinterpret_cast<const v8*>(kaddr[m >> 1] + STG * W64_TILE_B + (m & 1) * 32 * ROWB); };
-#pragma unroll
-    for (int m = 0; m < LA; ++m) rd(m);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      if (m + LA < 16) { MTX_ASM_FENCE(); rd(m + LA); MTX_ASM_FENCE(); }
-      if (J == 0) { if (m < 2) w64_seed<T>(sa0[m & 1], kf[m % RING], qf0[0], mi0); else w64_s<T>(sa0[m & 1], kf[m % RING], qf0[m >> 1]); }
-      else { if (m < 2) w64_seed<T>(sa1[m & 1], kf[m % RING], qf1[0], mi1); else w64_s<T>(sa1[m & 1], kf[m % RING], qf1[m >> 1]); }
-      if (XJ >= 0) { W64_SLOT(); if (XJ == 0) x0(XB + m); else x1(XB + m); W64_SLOT(); }
-    }
-  };
-  // P phase of a stream on the V tile of stage STG
-  auto phase_p = [&](auto stg_c, auto j_c, auto xj_c, auto x0_c) {
-    constexpr int STG = decltype(stg_c)::value, J = decltype(j_c)::value, XJ = decltype(xj_c)::value, XB = decltype(x0_c)::value;
-    constexpr int LA = W64_LOOKAHEAD, RING = LA + 1;
-    v8 vf[RING];
-    auto rd = [&](int m) {
-      const int g = m >> 2, d = m & 3;
-      const unsigned char* a = vaddr[d] + STG * W64_TILE_B + ((g >> 1) * 32 + (g & 1) * 16) * ROWB;
-      const v4 lo = lds_read_tr16<T>(a);
-      const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
-      v8& f = vf[m % RING];
-      f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hv[0]; f[5] = hv[1]; f[6] = hv[2]; f[7] = hv[3];
-    };
-#pragma unroll
-    for (int m = 0; m < LA; ++m) rd(m);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      if (m + LA < 16) { MTX_ASM_FENCE(); rd(m + LA); MTX_ASM_FENCE(); }
-      const int g = m >> 2;
-      if (J == 0) w64_o<T>(oa0[m & 3], vf[m % RING], __builtin_bit_cast(v8, pq0[g]));
-      else w64_o<T>(oa1[m & 3], vf[m % RING], __builtin_bit_cast(v8, pq1[g]));
-      if (XJ >= 0) { W64_SLOT(); if (XJ == 0) x0(XB + m); else x1(XB + m); W64_SLOT(); }
-    }
-  };
-  typedef std::integral_constant<int, 0> I0;
-  typedef std::integral_constant<int, 1> I1;
-  typedef std::integral_constant<int, 2> I2;
-  typedef std::integral_constant<int, 16> I16;
-  typedef std::integral_constant<int, -1> IN;
-
-  const long ntiles = (p.sk + AB_KV - 1) / AB_KV;
-  // ---- prologue: tiles 0 and 1 on their way; tile 0: S of both streams, the exact maximum, stream 0 through its P phase, stream 1 half way through its softmax
-  dma_tile(0, 0);
-  if (ntiles > 1) dma_tile(1, 1);
-  MTX_WAIT_VMEM();
-  MTX_LDS_BARRIER();
-  phase_s(I0(), I0(), IN(), I0());
-  phase_s(I0(), I1(), IN(), I0());
-  W64_DRAIN();
-  first_max(sa0, mi0, M0);
-  xs0(0, 32);
-  bad = bad || !(ts0 < AttnSumLimit<T>::v); ls0 += ts0; ts0 = 0.f;
-  first_max(sa1, mi1, M1);
-  phase_p(I0(), I0(), I1(), I0());            // P(0, 0) with X(0, 1) values 0 .. 15 beside it
-
-  // ---- steady state, period t >= 1 (the tile's stage t % 3 a compile-time constant: three periods per trip)
-  auto period = [&](auto stg_c, long t) {
-    constexpr int STG = decltype(stg_c)::value;
-    typedef std::integral_constant<int, STG> SC;
-    typedef std::integral_constant<int, (STG + 2) % 3> SP;
-    if (t + 1 < ntiles) dma_tile(t + 1, (STG + 1) % 3);       // stage NEXT was last read by P(t - 2, 1), a barrier ago
-    phase_s(SC(), I0(), I1(), I16());          // S(t, 0)     | X(t - 1, 1) values 16 .. 31
-    check1();
-    phase_p(SP(), I1(), I0(), I0());           // P(t - 1, 1) | X(t, 0) values 0 .. 15
-    phase_s(SC(), I1(), I0(), I16());          // S(t, 1)     | X(t, 0) values 16 .. 31
-    check0();
-    phase_p(SC(), I0(), I1(), I0());           // P(t, 0)     | X(t, 1) values 0 .. 15
-    MTX_WAIT_VMEM();
-    MTX_LDS_BARRIER();
-  };
-  long t = 1;
-  for (; t + 2 < ntiles; t += 3) { period(I1(), t); period(I2(), t + 1); period(I0(), t + 2); }
-  if (t < ntiles) { period(I1(), t); ++t; }      // (t % 3 == 1 on leaving the loop)
-  if (t < ntiles) { period(I2(), t); ++t; }
-  // ---- drain: stream 1 of the last tile
-  // (values 0 .. 15 went through the pipelined form beside the last P(t, 0): value 15's exponential is still pending there)
-  ts1 += pe1b; pq1[1][3] = __builtin_bit_cast(uint32_t, v2{from_f32<T>(pe1a), from_f32<T>(pe1b)});
-  xs1(16, 32);
-  bad = bad || !(ts1 < AttnSumLimit<T>::v); ls1 += ts1; ts1 = 0.f;
-  {
-    const int lst = (int)((ntiles - 1) % 3);
-    if (lst == 0) phase_p(I0(), I1(), IN(), I0());
-    else if (lst == 1) phase_p(I1(), I1(), IN(), I0());
-    else phase_p(I2(), I1(), IN(), I0());
-  }
-  W64_DRAIN();
-
-  // ---- the rare redo: some row sum of this workgroup left the safe range.  Once more, tile by tile on stage 0, nothing overlapped, the maximum of
-  // both streams refreshed on every tile (the classic online softmax).
-  {
-    int* flag = reinterpret_cast<int*>(smem + 6 * W64_TILE_B);
-    MTX_LDS_BARRIER();
-    if (tid == 0) *flag = 0;
-    MTX_LDS_BARRIER();
-    if ((__any(bad) || (p.block0 & 1u)) && lane == 0) *flag = 1;      // (block0 bit 0: debug — force the redo)
-    MTX_LDS_BARRIER();
-    if (*flag) {
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { oa0[d][r] = 0.f; oa1[d][r] = 0.f; }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { mi0[r] = 0.f; mi1[r] = 0.f; }
-      M0 = M1 = ls0 = ls1 = ts0 = ts1 = 0.f;
-      for (long tt = 0; tt < ntiles; ++tt) {
-        MTX_LDS_BARRIER();
-        dma_tile(tt, 0);
-        MTX_WAIT_VMEM();
-        MTX_LDS_BARRIER();
-        phase_s(I0(), I0(), IN(), I0());
-        phase_s(I0(), I1(), IN(), I0());
-        W64_DRAIN();
-        refresh(sa0, oa0, mi0, M0, ls0, tt == 0);
-        refresh(sa1, oa1, mi1, M1, ls1, tt == 0);
-        xs0(0, 32); xs1(0, 32);
-        ls0 += ts0; ls1 += ts1; ts0 = ts1 = 0.f;
-        phase_p(I0(), I0(), IN(), I0());
-        phase_p(I0(), I1(), IN(), I0());
-        W64_DRAIN();
-      }
-    }
-  }
-
-  // ---- finish.  Keys past the end of the sequence: zero K rows, i.e. scores of exactly minus the running maximum — exp2(minit) each, in the row sum
-  // only (their V rows are zero): out again.  Then the two lane halves of a row add their sums; 16-byte stores as in the 8-wave kernel.
-  const long kv_last = p.sk - (ntiles - 1) * AB_KV;
-  int n_oob = 0;
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) n_oob += (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kv_last) ? 1 : 0;
-  auto finish = [&](f32x16 (&oa)[4], float ls, const f32x16& mi, long qr) {
-    ls -= (float)n_oob * fast_exp2(mi[0]);
-    const float l = half_sum(ls);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        v4 x, y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { x[r] = from_f32<T>(oa[d][gp * 8 + r] * inv); y[r] = from_f32<T>(oa[d][gp * 8 + 4 + r] * inv); }
-        const u32x2 xw = __builtin_bit_cast(u32x2, x), yw = __builtin_bit_cast(u32x2, y);
-        uint32_t a0 = xw[0], a1 = xw[1], b0 = yw[0], b1 = yw[1];
-        half_pair_exchange(a0, b0);
-        half_pair_exchange(a1, b1);
-        if (qr < p.sq) *reinterpret_cast<u32x4*>(O + qr * p.o_ss + d * 32 + gp * 16 + hi * 8) = u32x4{a0, a1, b0, b1};
-      }
-  };
-  finish(oa0, ls0, mi0, q0 + l31);
-  finish(oa1, ls1, mi1, q0 + 32 + l31);
-}
-
 // merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
 template <typename T, int DP>
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
@@ -1020,12 +633,7 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
       return MTX_OK;
     }
     const bool wide_ok = p.o_ss % 8 == 0 && p.o_hs % 8 == 0 && p.o_bs % 8 == 0 && ((size_t)p.o & 15) == 0;
-    const bool w64 = [] { const char* e = getenv("MTX_ATTN_W64"); return e && e[0] == '1'; }();         // MTX_ATTN_W64=1: the one-wave-per-SIMD kernel (experiment, off by default; read per launch)
-    if (p.prescaled && wide_ok && w64 && p.n_full > 0) {
-      // whole key ranges: one wave per SIMD, two statically interleaved 32-row streams per wave; the key-split tail blocks: the 8-wave kernel
-      { AttnParams pw = p; const char* e = getenv("MTX_ATTN_W64_DBG"); pw.block0 = e ? (unsigned)atoi(e) : 0u; MTX_LAUNCH((attn_w64_kernel<T>), dim3(p.n_full), dim3(256), 0, stream, pw); }
-      if (g > p.n_full) { AttnParams pt = p; pt.block0 = p.n_full; MTX_LAUNCH((attn_mma32_d_kernel<T, 128, true>), dim3(g - p.n_full), dim3(512), 0, stream, pt); }
-    } else if (p.prescaled && wide_ok) MTX_LAUNCH((attn_mma32_d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);      // the FLUX graphs' form
+    if (p.prescaled && wide_ok) MTX_LAUNCH((attn_mma32_d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);      // the FLUX graphs' form
     else if (p.prescaled) MTX_LAUNCH((attn_mma32_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
     else MTX_LAUNCH((attn_mma32_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
     if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
@@ -1058,7 +666,7 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   p.prescaled = (a->flags & MTX_ATTN_Q_PRESCALED) ? 1 : 0;
   p.scale_log2 = p.prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
-  p.n_full = 0; p.split = 1; p.block0 = 0; p.part_o = nullptr; p.part_ml = nullptr;
+  p.n_full = 0; p.split = 1; p.part_o = nullptr; p.part_ml = nullptr;
   p.q8 = reinterpret_cast<unsigned char*>(a->q8); p.q8_scale = reinterpret_cast<unsigned*>(a->q8_scale); p.ldq8 = a->ldq8; p.lds_q8 = a->lds_q8;
   if (a->workspace && a->workspace_bytes >= (int64_t)MTX_ATTN_WORKSPACE_BYTES) {      // 256 slots of [256][128] fp32 + [256][2] fp32
     p.part_o = reinterpret_cast<float*>(a->workspace);

@@ -423,22 +423,6 @@ __device__ __forceinline__ u32x4 buf_load16(const BufView& b, unsigned voff, uns
 #endif
 }
 
-// The same load as inline asm: the compiler neither counts it nor waits for it (cdna_hip_programming.md §5.7 item 1, form (ii)).  For a
-// load that must stay in flight beside LDS-DMA pieces and stores: hipcc waits vmcnt(0) at the first use of a load it can see whenever it
-// cannot count the operations issued since (branches, a loop back edge) — which drains the DMA with it.  The CALLER waits — a counted
-// s_waitcnt vmcnt(n) — and then passes every destination through vmem_landed() before the first use, in the same basic block.
-__device__ __forceinline__ void buf_load16_uncounted(u32x4& dst, const BufView& b, unsigned voff, unsigned soff) {
-#ifdef MTX_EMU
-  dst = buf_load16(b, voff, soff);
-#else
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(b.rsrc), "s"(soff) : "memory");
-#endif
-}
-__device__ __forceinline__ void vmem_landed(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-#ifndef MTX_EMU
-  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
-#endif
-}
 
 __device__ __forceinline__ u32x2 buf_load8(const BufView& b, unsigned voff, unsigned soff) {
 #ifdef MTX_EMU
