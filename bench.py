@@ -117,6 +117,9 @@ def parse():
     ap.add_argument("--no-glu-epilogue", action="store_true",
                     help="FLUX.2-Klein fp8 path, for A/Bs: separate SwiGLU / attention-output quantiser launches instead of the epilogue fusions "
                          "(mtx_gemm_args.glu_*, mtx_attn_args.q8) that are the default since round 4")
+    ap.add_argument("--attn-qk-f8", action="store_true",
+                    help="FLUX.2-Klein fp8 path, experiment: attention scores from e4m3 q and k on the fp8 matrix instruction (Flux2DiTHip(attn_qk_f8=True), "
+                         "mtx_attn_args.q_f8 / k_f8).  Changes the result; NOT the configuration `value` is quoted on — reported in config.attn_qk_f8")
     ap.add_argument("--front-replicas", type=int, default=None,
                     help="instances of the detect-stage models (detectors + SAM) per rank; with N > 1 the front halves of N pages run at once, "
                          "each on its own instance (a model's plan has one set of buffers).  Default: 2 for the stage sets without diffusion / "
@@ -351,7 +354,8 @@ def main():
             dcfg = f2.KLEIN_9B_DIT_CFG if args.inpainter == "klein_9b" else f2.KLEIN_4B_DIT_CFG
             if args.traffic_child:      # counter pass: same kernels, shapes and double : single launch mix on a fraction of the depth
                 dcfg = dict(dcfg, layers=max(1, dcfg["layers"] // 5), single_layers=max(1, dcfg["single_layers"] // 5))
-            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8, fused_quant=not args.no_fused_quant, glu_epilogue=not args.no_glu_epilogue, attn_q8=not args.no_glu_epilogue)
+            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8, fused_quant=not args.no_fused_quant, glu_epilogue=not args.no_glu_epilogue, attn_q8=not args.no_glu_epilogue,
+                                  attn_qk_f8=args.attn_qk_f8)
             vae = f2.Flux2VAEHip(fx.synthetic_provider(f2.vae_param_shapes(f2.KLEIN_VAE_CFG), device, 22, broadcast=world > 1), f2.KLEIN_VAE_CFG, device, lib=lib)
             flux = f2.Flux2KleinHip(dit, vae, graph=graph)
             flux.set_prompt_embeds(torch.randn(512, dcfg["joint_dim"], generator=torch.Generator().manual_seed(23)))     # cached Qwen3 states (stand-ins)
@@ -729,6 +733,8 @@ def main():
     cfg = result["config"]
     if batch_io is not None:
         cfg["batch_io"] = batch_io
+    if klein and flux is not None:
+        cfg["attn_qk_f8"] = bool(args.attn_qk_f8)      # True: scores from e4m3 q / k (an experiment that changes the result; never the headline configuration)
     if flux is not None and not klein:
         st_ = getattr(flux, "cache_stats", {"steps": 0, "skipped": 0})
         on_ = args.kontext_backend == "nunchaku" and args.residual_diff_threshold > 0

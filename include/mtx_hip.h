@@ -157,6 +157,11 @@ typedef struct mtx_attn_args {
    * mtx_quantize_mx makes of the 16-bit output (rounded to `dtype` first); `o` may then be NULL.  (Hardware-verified in round 4 —
    * tests/test_ops_gpu.py::test_attention_mx_fp8_output — and the default of the FLUX.2 graphs since.) */
   void* q8; void* q8_scale; int64_t ldq8, lds_q8;
+  /* fp8 scores (ABI 8; long-sequence kernel with MTX_ATTN_Q_PRESCALED only, d = 128, batch 1): plain e4m3 copies of the query and key rows —
+   * q_f8[row * qf8_ss + head * 128 + ..], k_f8[row * kf8_ss + head * 128 + ..], strides in BYTES, 16-byte aligned — as the rotary kernel
+   * writes them (mtx_ew_args.y8).  The base-2 logits are 2^qk_f8_exp * sum_d q_f8 k_f8 on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the
+   * 16-bit rate); q and k are then not read.  P V stays 16-bit.  NULL = 16-bit scores. */
+  const void* q_f8; const void* k_f8; int64_t qf8_ss, kf8_ss; int32_t qk_f8_exp;
 } mtx_attn_args;
 /* q already carries scale * log2(e) (folded into the producer, e.g. the pre-scaled rotary table of MTX_EW_QK_NORM_ROPE): `scale`
  * is ignored, scores are used as base-2 logits as they come out of the matrix pipe.  The long-sequence kernel then seeds its score
@@ -240,6 +245,9 @@ typedef struct mtx_ew_args {
   int64_t n, h, w, c;          /* logical INPUT dims (h*w = rows per sample) */
   int64_t lda, ldb, ldy, lds;  /* per-pixel strides; lds = per-sample stride of s */
   int32_t kind; int32_t act; float act_param; int32_t i0, i1; int32_t dtype;
+  /* ABI 8, MTX_EW_QK_NORM_ROPE only: an e4m3 twin of the result, y8[row * ldy8 + column] (bytes; ldy8 % 16 == 0), values of the heads < i1
+   * (the q slice) multiplied by y8_mul first, saturated at +-448 — the operands of mtx_attn_args.q_f8 / k_f8.  NULL = none. */
+  void* y8; int64_t ldy8; float y8_mul;
 } mtx_ew_args;
 
 /* RCAN channel attention squeeze/excite: s[n, c] = sigmoid(W2 relu(W1 mean + b1) + b2),

@@ -82,7 +82,7 @@ class _W:
 
 
 class Flux2DiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=True, attn_q8=True):
+    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=True, attn_q8=True, attn_qk_f8=False):
         """provider(name) -> tensor with diffusers' Flux2Transformer2DModel parameter of that name.
         fp8: False, True (= every block linear) or a tuple of names out of FP8_ALL."""
         self.lib = lib if lib is not None else get_library()
@@ -104,6 +104,10 @@ class Flux2DiTHip:
         # attn_q8: the joint attention writes the MX fp8 operand of the output projections itself (mtx_attn_args.q8; long-sequence kernel, so only
         # for T >= 1024 and head dim 128) — with glu_epilogue no quantiser launch is left in a step (tests/test_ops_gpu.py::test_attention_mx_fp8_output).
         self.attn_q8 = bool(attn_q8) and all(k in self.fp8 for k in ("out", "single_out")) and self.hd == 128
+        # attn_qk_f8: the rotary kernel also leaves q and k as plain e4m3 rows (q times 8: the pre-scaled q is ~N(0, 0.13), below e4m3's normal range) and
+        # the joint attention takes its scores from them on the fp8 matrix instruction (mtx_attn_args.q_f8 / k_f8, logits 2^-3 * q k); P V stays 16-bit.
+        # Changes the result (3 mantissa bits under the scores) — off unless asked for; tests/test_flux2_gpu.py holds the image-level comparison.
+        self.attn_qk_f8 = bool(attn_qk_f8) and bool(self.fp8) and self.hd == 128
         if self.fp8 and (D % 128 or self.hid % 128):
             raise ModelError("FLUX.2 DiT fp8 path: d and the MLP width must be multiples of 128")
         g = lambda n, dt=None: provider(n).detach().to(self.device, dt if dt is not None else self.tdt).contiguous()
@@ -252,13 +256,17 @@ class Flux2DiTHip:
             e.n, e.h, e.w, e.c = 1, 1, r1 - r0, 2 * D
             e.lda, e.ldb, e.ldy, e.lds = ld, T * hd, ld, 0
             e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 0, 1e-6, hd, H, self.dtype
+            if qk8 is not None:
+                e.y8, e.ldy8, e.y8_mul = qk8.data_ptr() + r0 * 2 * D, 2 * D, 8.0
             pb._add(abi.OP_EW, e, label)
 
         aq8 = self.attn_q8 and f8 and T >= 1024
+        qk8 = pb.buf((T, 2 * D), torch.uint8, zero=True) if (self.attn_qk_f8 and T >= 1024) else None      # [token][q heads | k heads] e4m3
 
         def attention(src, ld, out_t, out_ld, label, q8=None):
             pb.attention(src, src, src, None if q8 is not None else out_t, 1, H, T, T, hd, (0, ld, hd), (0, ld, hd), (0, ld, hd), (0, out_ld, hd),
-                         1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True, q8=q8)
+                         1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True, q8=q8,
+                         qk_f8=(qk8, 0, D, 2 * D, -3) if qk8 is not None else None)
 
         def swiglu(src, ld, c0, r0, r1, dst, dst_ld, dst_c0, label, dst8=None, consumers=()):
             """silu(a) * b of the two halves of a fused projection.  With fp8 consumers: one pass that writes their MX fp8 operand

@@ -30,6 +30,8 @@ struct AttnParams {
   int prescaled;                 // q carries scale * log2(e): scale_log2 == 1
   // MX fp8 output of the long-sequence kernel (mtx_attn_args.q8): bytes [sq][ldq8] (head h at byte column h * d), scale words [heads * d / 128][lds_q8]
   unsigned char* q8; unsigned* q8_scale; long ldq8, lds_q8;
+  // fp8 scores (mtx_attn_args.q_f8 / k_f8): plain e4m3 rows, strides in bytes, head h at byte column h * 128; logits = 2^qk_f8_exp * sum q k
+  const unsigned char* qf8; const unsigned char* kf8; long qf8_ss, kf8_ss; int qk_f8_exp;
 };
 
 constexpr int AT_KV = 64;      // keys per tile
@@ -489,6 +491,106 @@ __device__ __forceinline__ void attn_bias_tile(unsigned char* smem, const typena
         oacc[d] = Mma32<T>::mfma(vf, pb[kb][s2], oacc[d]);
       }
 }
+// The fp8-score form of attn_bias_tile<.., NOMAX = true, DEEP> (round 6): S^T = K Q^T from plain e4m3 rows on v_mfma_scale_f32_32x32x64_f8f6f4 —
+// two k-steps of 64 instead of eight of 16, at twice the rate per k — block scales 2^0 (K) and 2^qk_f8_exp (Q).  Softmax and P V as above.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ f32x16 mfma_f8_scores(i32x8 a, i32x8 b, f32x16 c, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, sb);
+}
+template <typename T, int DP, int STAGE, bool RAGGED, int DEEP>
+__device__ __forceinline__ void attn_bias_tile_k8(unsigned char* smem, const i32x8 (&qf)[2], f32x16 (&oacc)[DP / 32],
+                                                  float& M, float& lsum, f32x16& minit, bool& first,
+                                                  const int (&kaddr)[4], const int (&vaddr)[DP / 32], const long kvalid, const int hi, const int sb) {
+  typedef typename Traits<T>::v8 v8;
+  typedef typename Traits<T>::v4 v4;
+  constexpr int DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  static_assert(DP == 128, "two k-steps of 64 bytes");
+  const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
+  const unsigned char* Vs = Ks + TILE_B;
+  f32x16 sacc[2];
+  {
+    i32x8 kf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(Ks + kaddr[2 * ks] + kb * 32 * 128);
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(Ks + kaddr[2 * ks + 1] + kb * 32 * 128);
+        kf[ks][kb] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hv[0], (int)hv[1], (int)hv[2], (int)hv[3]};
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma_f8_scores(kf[ks][kb], qf[ks], ks == 0 ? minit : sacc[kb], sb);
+    MTX_SCHED_GROUP(0x100, 8);
+    MTX_SCHED_GROUP(0x008, 4);
+  }
+  if (RAGGED) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) sacc[kb][r] = -1.0e30f;
+  }
+  v8 pb[2][2];
+  float tsum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = fast_exp2(sacc[kb][r]);
+      tsum += pv;
+      pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
+    }
+  if (first || __any(!(tsum < AttnSumLimit<T>::v))) {
+    float tmax = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
+    tmax = half_max(tmax);
+    const float delta = first ? tmax : fmaxf(tmax, 0.f);
+    const float alpha = fast_exp2(-delta);
+    M += delta;
+    lsum *= alpha;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) minit[r] = -M;
+    tsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(sacc[kb][r] - delta);
+        tsum += pv;
+        pb[kb][r >> 3][r & 7] = from_f32<T>(pv);
+      }
+    first = false;
+  }
+  lsum += tsum;
+  v8 vfd[4][DB];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const unsigned char* a = Vs + vaddr[d] + ((g >> 1) * 32 + (g & 1) * 16) * ROWB;
+      const v4 lo = lds_read_tr16<T>(a);
+      const v4 hv = lds_read_tr16<T>(a + 8 * ROWB);
+      vfd[g][d][0] = lo[0]; vfd[g][d][1] = lo[1]; vfd[g][d][2] = lo[2]; vfd[g][d][3] = lo[3];
+      vfd[g][d][4] = hv[0]; vfd[g][d][5] = hv[1]; vfd[g][d][6] = hv[2]; vfd[g][d][7] = hv[3];
+    }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) oacc[d] = Mma32<T>::mfma(vfd[g][d], pb[g >> 1][g & 1], oacc[d]);
+  constexpr int VD = DEEP >> 4;
+  static_assert(VD >= 1 && VD <= 16, "V prefetch depth");
+  MTX_SCHED_GROUP(0x100, 2 * VD);
+#pragma unroll
+  for (int i = 0; i < 16 - VD; ++i) { MTX_SCHED_GROUP(0x008, 1); MTX_SCHED_GROUP(0x100, 2); }
+  MTX_SCHED_GROUP(0x008, VD);
+}
 // a and b of lanes l / l ^ 32: afterwards the lower lane holds (its a, the upper lane's a), the upper lane (the lower lane's b, its b)
 __device__ __forceinline__ void half_pair_exchange(uint32_t& a, uint32_t& b) {
 #ifdef MTX_EMU
@@ -521,8 +623,18 @@ __device__ __forceinline__ void half_pair_exchange(uint32_t& a, uint32_t& b) {
 #define ATTN_MMA32_NAME attn_mma32_d_kernel
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
-#undef ATTN_MMA32_DEEP
+#define ATTN_MMA32_K8 1
+#define ATTN_MMA32_NAME attn_mma32_k8_kernel
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
 #undef ATTN_MMA32_WIDE
+#undef ATTN_MMA32_Q8
+#define ATTN_MMA32_Q8 1
+#define ATTN_MMA32_NAME attn_mma32_k8q_kernel
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_K8
+#undef ATTN_MMA32_DEEP
 #undef ATTN_MMA32_Q8
 
 // merges the `split` key-range partials of every tail query block: O = sum_i 2^((m_i - M) c) O_i / sum_i 2^((m_i - M) c) l_i
@@ -626,6 +738,15 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     // round 5): half-tile staggered wave groups, an S^T-pipelined LDS-DMA ring, 4 waves x 64 rows, two 128-query workgroups per CU, K / V by
     // LDS-DMA (-17 %), row sums on the matrix pipe (-6.7 %), a half-tile pipelined softmax (does not fit 256 registers).  What stayed: fragment
     // reads four steps ahead of the MFMAs (order pinned with sched_group_barrier; +1.5 ... 2.5 %) and 16-byte row stores (+0.3 %), identical bytes.
+    if (p.kf8 != nullptr) {                      // fp8 scores (validated in attn_launch: pre-scaled q; a 16-bit output needs 16-byte rows)
+      if (p.q8 != nullptr) MTX_LAUNCH((attn_mma32_k8q_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+      else MTX_LAUNCH((attn_mma32_k8_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+      if (p.split > 1) {
+        if (p.q8 != nullptr) MTX_LAUNCH((attn_merge_q8_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
+        else MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
+      }
+      return MTX_OK;
+    }
     if (p.q8 != nullptr) {
       if (p.prescaled) MTX_LAUNCH((attn_mma32_q8d_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
       else MTX_LAUNCH((attn_mma32_q8_kernel<T, 128, false>), dim3(g), dim3(512), 0, stream, p);
@@ -639,7 +760,7 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     if (p.split > 1) MTX_LAUNCH((attn_merge_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
     return MTX_OK;
   }
-  if (p.q8 != nullptr) return MTX_ERR_UNSUPPORTED;
+  if (p.q8 != nullptr || p.kf8 != nullptr) return MTX_ERR_UNSUPPORTED;
   const unsigned grid = (unsigned)(p.batch * p.heads) * p.qblocks;
   if (p.d <= 32) MTX_LAUNCH((attn_kernel<T, 32>), dim3(grid), dim3(256), 0, stream, p);
   else if (p.d <= 64) MTX_LAUNCH((attn_kernel<T, 64>), dim3(grid), dim3(256), 0, stream, p);
@@ -654,6 +775,12 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   if (!a->q || !a->k || !a->v || (!a->o && !a->q8)) { *err = "attention: null operand"; return MTX_ERR_INVALID; }
   if (a->q8 != nullptr && (!a->q8_scale || a->batch != 1 || a->d != 128 || a->sq < 1024 || a->sk < 256 || a->ldq8 % 16 || ((size_t)a->q8 & 15) || a->lds_q8 < a->sq)) {
     *err = "attention (MX fp8 output): long-sequence kernel only (d = 128, sq >= 1024, sk >= 256, batch 1), ldq8 % 16 == 0, lds_q8 >= sq"; return MTX_ERR_INVALID; }
+  if ((a->q_f8 != nullptr) != (a->k_f8 != nullptr)) { *err = "attention (fp8 scores): q_f8 and k_f8 come together"; return MTX_ERR_INVALID; }
+  if (a->k_f8 != nullptr && (!(a->flags & MTX_ATTN_Q_PRESCALED) || a->batch != 1 || a->d != 128 || a->sq < 1024 || a->sk < 256 || a->qf8_ss % 16 || a->kf8_ss % 16 ||
+                             (((size_t)a->q_f8 | (size_t)a->k_f8) & 15) || a->qf8_ss < a->heads * 128 || a->kf8_ss < a->heads * 128 || a->qk_f8_exp < -64 || a->qk_f8_exp > 64 ||
+                             (a->q8 == nullptr && (a->o_ss % 8 || a->o_hs % 8 || ((size_t)a->o & 15))))) {
+    *err = "attention (fp8 scores): long-sequence kernel with pre-scaled q only (d = 128, sq >= 1024, sk >= 256, batch 1), 16-byte aligned fp8 rows of >= heads * 128 bytes, 16-byte output rows";
+    return MTX_ERR_INVALID; }
   if (a->d < 8 || a->d > 128 || a->d % 8) { *err = "attention: head dim must be a multiple of 8, <= 128"; return MTX_ERR_INVALID; }
   if (a->d % 4 || a->q_ss % 8 || a->k_ss % 8 || a->v_ss % 8 || a->o_ss % 4 || a->q_hs % 8 || a->k_hs % 8 || a->v_hs % 8 || a->o_hs % 4 ||
       a->q_bs % 8 || a->k_bs % 8 || a->v_bs % 8 || a->o_bs % 4) { *err = "attention: strides must keep 16-byte alignment"; return MTX_ERR_INVALID; }
@@ -667,6 +794,7 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   p.scale_log2 = p.prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
   p.n_full = 0; p.split = 1; p.part_o = nullptr; p.part_ml = nullptr;
+  p.qf8 = reinterpret_cast<const unsigned char*>(a->q_f8); p.kf8 = reinterpret_cast<const unsigned char*>(a->k_f8); p.qf8_ss = a->qf8_ss; p.kf8_ss = a->kf8_ss; p.qk_f8_exp = a->qk_f8_exp;
   p.q8 = reinterpret_cast<unsigned char*>(a->q8); p.q8_scale = reinterpret_cast<unsigned*>(a->q8_scale); p.ldq8 = a->ldq8; p.lds_q8 = a->lds_q8;
   if (a->workspace && a->workspace_bytes >= (int64_t)MTX_ATTN_WORKSPACE_BYTES) {      // 256 slots of [256][128] fp32 + [256][2] fp32
     p.part_o = reinterpret_cast<float*>(a->workspace);

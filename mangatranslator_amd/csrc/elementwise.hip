@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(mtx_ew_args p) {
   float gm[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) gm[e] = gamma ? gamma[part * 8 + e] : 1.f;
+  const float y8m = (split_at > 0 && hd < split_at) ? p.y8_mul : 1.0f;
   for (unsigned r0 = blockIdx.y * QR_U; r0 < rows; r0 += gridDim.y * QR_U) {
     u32x4 raw[QR_U];
 #pragma unroll
@@ -304,6 +305,16 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(mtx_ew_args p) {
         o[2 * k + 1] = x1 * c_[k] + x0 * s_[k];
       }
       if (col_ok && r0 + u < rows) *reinterpret_cast<u32x4*>(Y + (size_t)r * p.ldy + chc * 8) = pack8<T>(o);
+      if (p.y8 != nullptr) {                     // e4m3 twin of the values as stored (rounded to T first), q heads times y8_mul: the fp8 score operands of the attention
+        float f8[8];
+        unpack8<T>(pack8<T>(o), f8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = f8[e] * y8m; f8[e] = v > 448.f ? 448.f : (v < -448.f ? -448.f : v); }
+        unsigned w0 = 0, w1 = 0;
+        w0 = cvt_pk_fp8<false>(f8[0], f8[1], w0); w0 = cvt_pk_fp8<true>(f8[2], f8[3], w0);
+        w1 = cvt_pk_fp8<false>(f8[4], f8[5], w1); w1 = cvt_pk_fp8<true>(f8[6], f8[7], w1);
+        if (col_ok && r0 + u < rows) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.y8) + (size_t)r * p.ldy8 + chc * 8) = u32x2{w0, w1};
+      }
     }
   }
 }
@@ -339,6 +350,7 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
   if (a->kind == MTX_EW_QK_NORM_ROPE) {
     const int d = a->i0;
     if (!a->a || !a->y || !a->b || (d != 64 && d != 128) || a->c % d || a->lda % 8 || a->ldy % 8) { *err = "qk_norm_rope: head dim must be 64 or 128"; return MTX_ERR_INVALID; }
+    if (a->y8 != nullptr && (a->ldy8 % 16 || ((size_t)a->y8 & 15) || a->ldy8 < a->c)) { *err = "qk_norm_rope: y8 needs 16-byte aligned rows of at least c bytes"; return MTX_ERR_INVALID; }
     const long rows = a->n * a->h * a->w;
     if (rows < 1) return MTX_OK;
     if (rows >= (1L << 31) || a->c / 8 >= (1L << 24)) { *err = "qk_norm_rope: problem too large"; return MTX_ERR_INVALID; }

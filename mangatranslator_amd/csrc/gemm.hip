@@ -918,7 +918,7 @@ static void launch_gemm256_tiles(const GemmParams& p, dim3 grid, void* stream) {
 
 // measured on MI355X (tools/bench_kernels.py, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the 3/3/2/0
 // piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
-// specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
+// specialised DMA) were 2-15 % behind on every shape and are gone (docs/experiments.md keeps the numbers).
 static thread_local int g_last_split[3] = {0, 0, 0};           // whole tiles, K slices, tail pieces of this thread's last 256-tile launch
 void gemm_last_split(int* out) { out[0] = g_last_split[0]; out[1] = g_last_split[1]; out[2] = g_last_split[2]; }
 
@@ -973,7 +973,7 @@ static void launch_gemm256_slices(const GemmParams& p, unsigned pieces, void* st
 
 // measured on MI355X (tools/bench_kernels.py, FLUX shapes, random data): the ping-pong loop with descriptor DMA and the 3/3/2/0
 // piece spread runs 1119-1341 TFLOP/s in bf16; the schedules it replaced (flat-address ping-pong, one-barrier, K = 32 ring, wave
-// specialised DMA) were 2-15 % behind on every shape and are gone (DESIGN.md §9 keeps the numbers).
+// specialised DMA) were 2-15 % behind on every shape and are gone (docs/experiments.md keeps the numbers).
 // Strip width of the tile map.  Measured on MI355X (same process, identical bytes: profiles/r06_visit_a / _b logs): with ONE strip every
 // XCD walks all tile columns from column 0 at the same time, i.e. eight L2s pull the same W panel over the fabric at once; two strips put
 // XCDs 0-3 and 4-7 on different halves of W.  The MX-fp8 kernel (half the time per byte of the 16-bit one) gains on the wide problems —

@@ -60,7 +60,8 @@ class AttnArgs(C.Structure):
                 ("q_bs", i64), ("q_ss", i64), ("q_hs", i64), ("k_bs", i64), ("k_ss", i64), ("k_hs", i64),
                 ("v_bs", i64), ("v_ss", i64), ("v_hs", i64), ("o_bs", i64), ("o_ss", i64), ("o_hs", i64),
                 ("scale", f32), ("dtype", i32), ("workspace", vp), ("workspace_bytes", i64), ("flags", i32),
-                ("q8", vp), ("q8_scale", vp), ("ldq8", i64), ("lds_q8", i64)]
+                ("q8", vp), ("q8_scale", vp), ("ldq8", i64), ("lds_q8", i64),
+                ("q_f8", vp), ("k_f8", vp), ("qf8_ss", i64), ("kf8_ss", i64), ("qk_f8_exp", i32)]
 
 
 ATTN_Q_PRESCALED = 1
@@ -84,7 +85,8 @@ class EwArgs(C.Structure):
     _fields_ = [("a", vp), ("b", vp), ("s", vp), ("y", vp),
                 ("n", i64), ("h", i64), ("w", i64), ("c", i64),
                 ("lda", i64), ("ldb", i64), ("ldy", i64), ("lds", i64),
-                ("kind", i32), ("act", i32), ("act_param", f32), ("i0", i32), ("i1", i32), ("dtype", i32)]
+                ("kind", i32), ("act", i32), ("act_param", f32), ("i0", i32), ("i1", i32), ("dtype", i32),
+                ("y8", vp), ("ldy8", i64), ("y8_mul", f32)]
 
 
 class CaArgs(C.Structure):

@@ -353,9 +353,11 @@ class PlanBuilder:
         return out
 
     def attention(self, q, k, v, o, batch, heads, sq, sk, d, q_str, k_str, v_str, o_str, scale,
-                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False, q8=None):
+                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False, q8=None, qk_f8=None):
         """q8 = (q bytes [sq, ldq], scale plane [ldq / 128, lds], ldq, lds, byte column offset): the rows leave as the MX fp8 operand of the
-        next linear instead of (o None) or beside 16-bit values — long-sequence kernel only (mtx_attn_args.q8)"""
+        next linear instead of (o None) or beside 16-bit values — long-sequence kernel only (mtx_attn_args.q8).
+        qk_f8 = (e4m3 bytes [rows, ld], q byte column, k byte column, ld, exponent): the scores are 2^exponent * q_f8 k_f8^T on the fp8
+        matrix instruction (mtx_attn_args.q_f8 / k_f8; the rotary kernel's y8) — pre-scaled q, long-sequence kernel only"""
         a = abi.AttnArgs()
         a.flags = abi.ATTN_Q_PRESCALED if q_prescaled else 0
         a.q, a.k, a.v, a.o = _ptr(q, q_off), _ptr(k, k_off), _ptr(v, v_off), (_ptr(o, o_off) if o is not None else None)
@@ -363,6 +365,10 @@ class PlanBuilder:
             q8q, q8s, ldq, lds8, col = q8
             assert col % 128 == 0 and o is None
             a.q8, a.q8_scale, a.ldq8, a.lds_q8 = q8q.data_ptr() + col, q8s.data_ptr() + 4 * (col // 128) * lds8, ldq, lds8
+        if qk_f8 is not None:
+            t8, qc, kc, ld8, ex = qk_f8
+            assert q_prescaled and t8.dtype == torch.uint8
+            a.q_f8, a.k_f8, a.qf8_ss, a.kf8_ss, a.qk_f8_exp = t8.data_ptr() + qc, t8.data_ptr() + kc, ld8, ld8, ex
         a.batch, a.heads, a.sq, a.sk, a.d = batch, heads, sq, sk, d
         a.q_bs, a.q_ss, a.q_hs = q_str
         a.k_bs, a.k_ss, a.k_hs = k_str

@@ -174,6 +174,31 @@ def check_klein(lib, device, h=64, w=96, t_txt=16, steps=3, fp8=False, **kw):
     return e, p, out
 
 
+def check_klein_fp8_scores(lib, device, h=384, w=512, t_txt=32, steps=4, **kw):
+    """fp8 attention scores (Flux2DiTHip(attn_qk_f8=True): q and k as e4m3 rows, scores on the fp8 matrix instruction) at a size that takes the
+    long-sequence kernel: image PSNR against the bf16 pipeline of the same weights, beside the PSNR of the fp8-linears-only pipeline"""
+    from PIL import Image
+    t, v = models(**kw)
+    g = torch.Generator().manual_seed(1)
+    img = (torch.rand(h, w, 3, generator=g) * 255).to(torch.uint8).numpy()
+    pe = torch.randn(t_txt, t.cfg["joint_dim"], generator=g).to(torch.bfloat16).float()
+    noise = torch.randn(1, t.cfg["in_channels"], h // 16, w // 16, generator=g)
+    outs = []
+    for fp8, scores in ((False, False), (True, False), (True, True)):
+        dit, vae = hip_models(t, v, lib, device, fp8=fp8, attn_qk_f8=scores)
+        assert dit.attn_qk_f8 == scores
+        pipe = f2.Flux2KleinHip(dit, vae)
+        outs.append(pipe(image=Image.fromarray(img), width=w, height=h, num_inference_steps=steps, prompt_embeds=pe[None], latents=noise,
+                         output_type="pt").images[0].cpu())
+        if scores:
+            from mangatranslator_amd.hip import abi
+            plan = next(iter(dit._plans._d.values()))
+            assert plan.T >= 1024 and any(o.kind == abi.OP_ATTN and o.u.attn.k_f8 for o in plan.ops), "the step does not run the fp8-score kernel"
+    p_lin, p_sc, p_between = psnr(outs[1], outs[0]), psnr(outs[2], outs[0]), psnr(outs[2], outs[1])
+    print(f"Klein {steps} steps {w}x{h}: vs bf16: fp8 linears {p_lin:.1f} dB, + fp8 scores {p_sc:.1f} dB; fp8 scores vs fp8 linears {p_between:.1f} dB")
+    return p_lin, p_sc, p_between
+
+
 def check_klein_fp8_vs_bf16(lib, device, h=64, w=96, t_txt=16, steps=4, fp8=True, **kw):
     """the judge's bar for the fp8 path: image PSNR of the fp8 pipeline against the bf16 pipeline of the same weights"""
     from PIL import Image

@@ -200,6 +200,76 @@ def check_attention(lib, dtype, batch, heads, sq, sk, d, seed=0, qmul=1.0, presc
     return err
 
 
+def check_attention_f8_scores(lib, dtype, heads, sq, sk, seed=0, exponent=-3, qmul=1.0, late_keys=None):
+    """the long-sequence kernel with fp8 scores (mtx_attn_args.q_f8 / k_f8): q and k as plain e4m3 rows, logits 2^exponent * q k^T.  The
+    reference is the base-2 softmax of exactly those products (e4m3 products are exact in fp32) times the 16-bit v; and the same rows
+    through the MX fp8 output form must give the bytes of the two launches it replaces."""
+    d = 128
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    D = heads * d
+    q8 = (torch.randn(sq, heads, d, generator=g) * qmul).clamp(-448, 448).to(torch.float8_e4m3fn)
+    k = torch.randn(sk, heads, d, generator=g)
+    if late_keys is not None:
+        k[late_keys[0]:] *= late_keys[1]
+    k8 = k.clamp(-448, 448).to(torch.float8_e4m3fn)
+    v = torch.randn(1, sk, heads, d, generator=g).to(td)
+    logits = torch.einsum("qhd,khd->hqk", q8.float(), k8.float()) * (2.0 ** exponent)
+    ref = torch.einsum("hqk,khd->qhd", torch.softmax(logits * math.log(2.0), dim=-1), v[0].float())
+    rows = max(sq, sk)
+    packed = torch.zeros(rows, 2 * D, dtype=torch.uint8)                      # [row][q bytes | k bytes]: the layout the rotary kernel leaves
+    packed[:sq, :D] = q8.view(torch.uint8).reshape(sq, D)
+    packed[:sk, D:] = k8.view(torch.uint8).reshape(sk, D)
+    pb = PlanBuilder(lib, dev, dtype)
+    unused = pb.buf((1, rows, heads, d), td, zero=True)                      # q / k are not read in this form
+    vt, pk = pb.const(v), pb.const(packed)
+    o = pb.buf((1, sq, heads, d), td, zero=True)
+    strides = ((rows * D, D, d), (rows * D, D, d), (sk * D, D, d), (sq * D, D, d))
+    pb.attention(unused, unused, vt, o, 1, heads, sq, sk, d, *strides, 1.0, q_prescaled=True, qk_f8=(pk, 0, D, 2 * D, exponent))
+    lds = (sq + 63) // 64 * 64
+    o8a, sca = pb.buf((sq, D), torch.uint8, zero=True), pb.buf((D // 128, lds), torch.int32, zero=True)
+    o8b, scb = pb.buf((sq, D), torch.uint8, zero=True), pb.buf((D // 128, lds), torch.int32, zero=True)
+    pb.attention(unused, unused, vt, None, 1, heads, sq, sk, d, *strides, 1.0, q_prescaled=True, qk_f8=(pk, 0, D, 2 * D, exponent), q8=(o8a, sca, D, lds, 0))
+    pb.quantize(o, sq, D, q=o8b, scale=scb, lds=lds, ldq=D)
+    _run(pb)
+    err = _relerr(o.cpu()[0], ref)
+    assert err < TOL[dtype] * 1.5, f"attention with fp8 scores: rel err {err}"
+    a, b = o8a.cpu().numpy(), o8b.cpu().numpy()
+    assert a.any() and np.array_equal(a, b), f"fp8 scores + fp8 output: {(a != b).sum()} of {a.size} e4m3 bytes differ from attention + quantiser"
+    assert np.array_equal(sca.cpu().numpy(), scb.cpu().numpy())
+    return err
+
+
+def check_rope_f8_twin(lib, dtype, rows, heads, seed=0, q_mul=8.0):
+    """MTX_EW_QK_NORM_ROPE with mtx_ew_args.y8: the e4m3 twin is RNE_e4m3(clamp(y * (q_mul on the q heads))) of the 16-bit values the
+    same launch stores, byte for byte"""
+    d = 128
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    c = 2 * heads * d
+    x = (torch.randn(rows, c, generator=g) * 3.0).to(td)
+    gamma = torch.randn(2 * d, generator=g).abs() + 0.5
+    ang = torch.rand(rows, d // 2, generator=g) * 6.28
+    cs = torch.cat([torch.cos(ang), torch.sin(ang)], 1).contiguous()          # [rows][2][d/2]
+    pb = PlanBuilder(lib, dev, dtype)
+    xt, gt, ct = pb.const(x), pb.const(gamma), pb.const(torch.cat([cs, cs * 0.1275], 0))
+    y8 = pb.buf((rows, c), torch.uint8, zero=True)
+    e = abi.EwArgs()
+    e.a, e.b, e.s, e.y = xt.data_ptr(), ct.data_ptr(), gt.data_ptr(), xt.data_ptr()
+    e.n, e.h, e.w, e.c = 1, 1, rows, c
+    e.lda, e.ldb, e.ldy, e.lds = c, rows * d, c, 0
+    e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_QK_NORM_ROPE, 0, 1e-6, d, heads, dtype
+    e.y8, e.ldy8, e.y8_mul = y8.data_ptr(), c, q_mul
+    pb._add(abi.OP_EW, e, "rope")
+    _run(pb)
+    y = xt.cpu().float()
+    assert torch.isfinite(y).all() and y.abs().max() > 0.1
+    y[:, :heads * d] *= q_mul
+    want = y.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got = y8.cpu().numpy()
+    assert np.array_equal(got, want), f"rotary fp8 twin: {(got != want).sum()} of {got.size} bytes differ"
+
+
 def check_attention_q8(lib, dtype, heads, sq, sk, seed=0, prescaled=True, col_off=0, extra_cols=0):
     """the long-sequence attention kernel with MX fp8 output (mtx_attn_args.q8) against the two launches it replaces — the same kernel
     into a 16-bit [sq, heads * 128] matrix, then mtx_quantize_mx — on the same operands: e4m3 bytes and scale words IDENTICAL, also for

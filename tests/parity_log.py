@@ -1,10 +1,10 @@
-"""Every GPU parity check drops the figures it measured into gpurun_out/r05_parity.json (merged back from the GPU box by gpurun; the
-round's copy is committed as profiles/r05_parity.json), so each number DESIGN.md quotes can be traced to a file."""
+"""Every GPU parity check drops the figures it measured into gpurun_out/r06_parity.json (merged back from the GPU box by gpurun; the
+round's copy is committed as profiles/r06_parity.json), so each number DESIGN.md quotes can be traced to a file."""
 import json
 import os
 from pathlib import Path
 
-_PATH = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent)) / "gpurun_out" / "r05_parity.json"
+_PATH = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent)) / "gpurun_out" / "r06_parity.json"
 
 
 def record(name: str, **values):

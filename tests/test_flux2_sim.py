@@ -39,3 +39,25 @@ def test_flux2_vae_token_count_not_multiple_of_8(emu_lib):
 
 def test_flux2_klein_pipeline(emu_lib):
     fc.check_klein(emu_lib, "cpu", h=32, w=48, t_txt=8, steps=2)
+
+
+def test_flux2_step_with_fp8_attention_scores(emu_lib):
+    """Flux2DiTHip(attn_qk_f8=True) at T >= 1024: the rotary launches carry the e4m3 twin, every attention launch the fp8 operands, and the step
+    stays close to the step with 16-bit scores (the op-level test holds the exact comparison)"""
+    import torch
+    from mangatranslator_amd.hip import abi
+    kw = dict(d=128, heads=1, layers=1, single_layers=1, joint_dim=64, axes_dim=(32, 32, 32, 32))
+    t, v = fc.models(**kw)
+    lat, pe = fc.step_inputs(t, 22, 24, 22, 24, 16)
+    vels = []
+    for scores in (False, True):
+        dit, _ = fc.hip_models(t, v, emu_lib, "cpu", fp8=True, attn_qk_f8=scores)
+        vel, plan = fc.run_step(dit, lat, pe, 22, 24, 22, 24, 0.7, "cpu")
+        assert plan.T >= 1024
+        attn = [o for o in plan.ops if o.kind == abi.OP_ATTN]
+        rope = [o for o in plan.ops if o.kind == abi.OP_EW and o.u.ew.kind == abi.EW_QK_NORM_ROPE]
+        assert attn and rope and all(bool(o.u.attn.k_f8) == scores for o in attn) and all(bool(o.u.ew.y8) == scores for o in rope)
+        vels.append(vel)
+    e = fc.rel(vels[1], vels[0])
+    print(f"fp8 attention scores vs 16-bit scores, one step: velocity rel diff {e:.4f}")
+    assert torch.isfinite(vels[1]).all() and 0 < e < 0.1

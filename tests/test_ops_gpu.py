@@ -218,6 +218,18 @@ def test_gemm_f8_glu_epilogue(hip_lib, cfg):
     oc.check_gemm_f8_glu(hip_lib, abi.BF16, **cfg)
 
 
+def test_attention_fp8_scores(hip_lib):
+    """attn_mma32_k8_kernel / _k8q_kernel (mtx_attn_args.q_f8 / k_f8): scores from e4m3 q and k on the MX-scaled fp8 matrix instruction —
+    against the exact softmax of the same e4m3 products; with the MX fp8 output form: the bytes of attention + quantiser.  The rotary
+    kernel's e4m3 twin (mtx_ew_args.y8) byte for byte."""
+    oc.check_attention_f8_scores(hip_lib, abi.BF16, heads=3, sq=2100, sk=2100)
+    oc.check_attention_f8_scores(hip_lib, abi.BF16, heads=24, sq=8704, sk=8704, seed=3)          # Klein shape at 2048 x 3072 incl. the key-split tail
+    oc.check_attention_f8_scores(hip_lib, abi.F16, heads=2, sq=1100, sk=449, exponent=-2, seed=1)
+    oc.check_attention_f8_scores(hip_lib, abi.BF16, heads=2, sq=1024, sk=320, qmul=4.0, late_keys=(200, 6.0), seed=2)      # a forced stale maximum
+    oc.check_rope_f8_twin(hip_lib, abi.BF16, rows=8704, heads=24)
+    oc.check_rope_f8_twin(hip_lib, abi.F16, rows=333, heads=3, q_mul=1.0, seed=1)
+
+
 @pytest.mark.parametrize("cfg", [
     dict(heads=24, sq=8512, sk=8512),                                           # key-split tail blocks included
     dict(heads=24, sq=8652, sk=8652, extra_cols=9216, seed=1),                  # into the single blocks' concatenation buffer

@@ -116,6 +116,16 @@ def test_first_block_cache_probe(emu_lib):
     oc.check_residual_dist(emu_lib, abi.F16, rows=33, c=136, ld_extra=24, seed=1)
 
 
+def test_attention_fp8_scores(emu_lib):
+    """attn_mma32_k8_kernel / _k8q_kernel (mtx_attn_args.q_f8 / k_f8): scores from e4m3 q and k on the MX-scaled fp8 matrix instruction;
+    the rotary kernel's e4m3 twin (mtx_ew_args.y8)"""
+    oc.check_attention_f8_scores(emu_lib, abi.BF16, heads=2, sq=1030, sk=330)
+    oc.check_attention_f8_scores(emu_lib, abi.F16, heads=1, sq=1024, sk=256, exponent=-2, seed=1)
+    oc.check_attention_f8_scores(emu_lib, abi.BF16, heads=1, sq=1024, sk=320, qmul=4.0, late_keys=(200, 6.0), seed=2)      # a forced stale maximum
+    oc.check_rope_f8_twin(emu_lib, abi.BF16, rows=70, heads=2)
+    oc.check_rope_f8_twin(emu_lib, abi.F16, rows=33, heads=1, q_mul=1.0, seed=1)
+
+
 def test_attention_fp8_output(emu_lib):
     """the long-sequence kernel writing the MX fp8 operand of the next linear (mtx_attn_args.q8) == the same kernel -> mtx_quantize_mx, byte
     for byte and scale word for scale word; 10 query blocks on 3 simulated CUs: one goes through the key-split tail + the quantising merge"""

@@ -53,6 +53,23 @@ def attn_q8(T, heads=24, d=128, iters=10, fused=True):
     print(f"attn -> MX fp8 T={T} heads={heads} [{'fused epilogue' if fused else 'attention + quantiser launch'}]: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
+def attn_f8_scores(T, heads=24, d=128, iters=10, out8=True):
+    """the fp8-score form (mtx_attn_args.q_f8 / k_f8): q and k as plain e4m3 rows; out8: rows leave as MX fp8 (the Klein graph's form), else 16-bit"""
+    pb = PlanBuilder(lib, dev, abi.BF16)
+    D = heads * d
+    qkv = pb.buf((T, 3 * D), torch.bfloat16); qkv.normal_()
+    qk8 = pb.buf((T, 2 * D), torch.uint8)
+    qk8.copy_(qkv[:, :2 * D].float().clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+    lds = (T + 63) // 64 * 64
+    q8 = pb.buf((T, D), torch.uint8, zero=True)
+    sc = pb.buf((D // 128, lds), torch.int32, zero=True)
+    o = None if out8 else pb.buf((T, D), torch.bfloat16)
+    pb.attention(qkv, qkv, qkv, o, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D,
+                 q_prescaled=True, q8=(q8, sc, D, lds, 0) if out8 else None, qk_f8=(qk8, 0, D, 2 * D, -3))
+    ms = _time(pb.build(), iters)
+    print(f"attn, fp8 scores T={T} heads={heads} [{'MX fp8 rows out' if out8 else '16-bit rows out'}]: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
+
+
 def gemm8_glu(M, hid, K, col0=0, iters=20, fused=True):
     """FLUX.2 MLP-in: fp8 GEMM [M, col0 + 2 hid] whose gated half leaves as silu(a) * b in MX fp8 (fused: mtx_gemm_args.glu_*; else GEMM + SwiGLU quantiser)"""
     from mangatranslator_amd.hip.plan import glu_interleave
@@ -210,6 +227,8 @@ if __name__ == "__main__":
     while args:
         if args[0] == "attn":
             attn(int(args[1])); args = args[2:]
+        elif args[0] in ("attn8", "attn8w"):          # fp8 scores: MX fp8 rows out / 16-bit rows out
+            attn_f8_scores(int(args[1]), out8=args[0] == "attn8"); args = args[2:]
         elif args[0] in ("attnq", "attnqs"):          # attention with MX fp8 output: fused epilogue / separate quantiser
             attn_q8(int(args[1]), fused=args[0] != "attnqs"); args = args[2:]
         elif args[0] in ("glu", "glus"):              # glu M hid K col0

@@ -1,7 +1,7 @@
 """Static look at the gfx950 ISA of every kernel in csrc/ for memory requests that cannot overlap: a load followed by `s_waitcnt vmcnt(0)` before
 the next load is issued is one dependent memory round trip of the wave (≈ 0.5 µs from the L2, 1–2 µs from HBM).  A kernel whose epilogue or
 row loop is a chain of those is latency-bound however few bytes it moves — round 5 found the row-normalisation kernel (12 per row) and the
-256-tile GEMM epilogue (≈ 40 per tile) that way.  No GPU needed: hipcc cross-compiles.
+256-tile GEMM epilogue (≈ 40 per tile) that way (docs/experiments.md, round 5).  No GPU needed: hipcc cross-compiles.
 
     python tools/isa_audit.py [--min 6] [file.hip ...]        # default: every .hip under mangatranslator_amd/csrc
 
