@@ -50,12 +50,12 @@ def test_klein_fp8_vs_bf16_psnr(hip_lib):
 
 def test_klein_fp8_attention_scores_psnr(hip_lib):
     """the fp8-score experiment (Flux2DiTHip(attn_qk_f8=True)): 4 Klein steps at Klein-4B's depth and a token count that takes the
-    long-sequence kernel (T = 1568), image PSNR against the bf16 pipeline — recorded beside the fp8-linears-only pipeline's.  Off by default in the product:
-    the assertion here is the floor under which the option would be withdrawn, the 40 dB bar for shipping it as default is reported, not asserted."""
+    long-sequence kernel (T = 1568), image PSNR against the bf16 pipeline — recorded beside the fp8-linears-only pipeline's.  The option is the fp8 path's
+    default, so BASELINE.json's 40 dB bar is asserted on it (first measured: 41.9 dB; fp8 linears alone 41.8)."""
     p_lin, p_sc, p_between = f2c.check_klein_fp8_scores(hip_lib, "cuda:0", h=384, w=512, t_txt=32, steps=4, **DEEP)
     record("flux2.klein.4steps.klein_depth.T1568.fp8_scores", psnr_fp8_linears_vs_bf16_db=p_lin, psnr_fp8_linears_and_scores_vs_bf16_db=p_sc,
            psnr_fp8_scores_vs_fp8_linears_db=p_between)
-    assert p_sc >= 30.0
+    assert p_sc >= f2c.PSNR_MIN_DB and p_lin >= f2c.PSNR_MIN_DB
 
 
 def test_full_width_blocks_flux1(hip_lib):
