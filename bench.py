@@ -834,6 +834,8 @@ def main():
                 how_ = "+".join(sorted(how_))
                 idx_ = range(n_l)
                 peak_ = FP8_PEAK_TFLOPS if kind_ == "gemm_fp8" else MFMA_PEAK_TFLOPS
+                if kind_ == "attention" and getattr(flux.transformer, "attn_qk_f8", False):
+                    peak_ = 2.0 / (1.0 / FP8_PEAK_TFLOPS + 1.0 / MFMA_PEAK_TFLOPS)      # Q K^T on the fp8 instruction, P V on the 16-bit one (see roofline_attention)
                 rows.append({"kernel": kind_, "m": m_, "n": n_, "k": k_, "launches_per_step": len(idx_), "mean_ms": ms_ / len(idx_), "timing": how_,
                              "timing_detail": info_, "tflops": flops_ * len(idx_) / ms_ / 1e9, "frac_of_peak": flops_ * len(idx_) / ms_ / 1e9 / peak_})
                 t_ = tot.setdefault(kind_, [0.0, 0.0, 0])

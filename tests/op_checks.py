@@ -103,7 +103,7 @@ def check_conv(lib, dtype, n, h, w, cin, cout, ksize, stride, act=abi.ACT_NONE, 
 
 
 def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=False, with_gate=False,
-               out_f32=False, batch=1, alpha=1.0, seed=0, flags=0, runs=1, expect_split=None):
+               out_f32=False, batch=1, alpha=1.0, seed=0, flags=0, runs=1, expect_split=None, keep=None):
     """runs > 1: the same plan is run again over a poisoned output — a K-slice launch must not depend on what an earlier launch left in its
     scratch (and must leave its tickets at zero).  expect_split = (whole tiles, K slices, tail pieces) the launch must report
     (mtx_gemm_last_split): the test shape really went through the path it is meant to cover."""
@@ -143,6 +143,8 @@ def check_gemm(lib, dtype, m, n, k, act=abi.ACT_NONE, with_bias=True, with_res=F
     err = _relerr(out.cpu().view(batch, m, n), ref)
     assert err < TOL[dtype], f"gemm mismatch rel err {err}"
     first = out.clone()
+    if keep is not None:                    # the caller compares the bytes of several launch forms
+        keep.append(first.cpu())
     for _ in range(runs - 1):
         out.fill_(float("nan"))
         plan.run()

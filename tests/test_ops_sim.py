@@ -2,6 +2,7 @@
 checked op by op against torch fp32.  Validates indexing (halo tiles, swizzles, MFMA fragment
 maps, epilogues) where no GPU exists; the same checks run on hardware in test_ops_gpu.py."""
 import pytest
+import torch
 
 import op_checks as oc
 from mangatranslator_amd.hip import abi
@@ -141,6 +142,23 @@ def test_gemm_256_tile_map_strips(emu_lib, monkeypatch):
         monkeypatch.setenv("MTX_GEMM_STRIPS", str(st))
         oc.check_gemm(emu_lib, abi.BF16, m=700, n=1200, k=128, with_res=True, flags=f)
         oc.check_gemm(emu_lib, abi.F16, m=1100, n=600, k=64, act=abi.ACT_SILU, flags=f, seed=st)
+
+
+def test_gemm_256_persistent_kernel(emu_lib, monkeypatch):
+    """round 6: gemm256_persist_kernel (one workgroup per CU walks its tiles; the next tile's first stage is requested in front of the epilogue, which
+    runs through 4 KiB per wave behind the stages) gives the bytes of the plain launch: 3 x 5 tiles on 3 simulated CUs (five iterations per
+    workgroup), 7 tiles (ragged last round), gate + residual + GELU, K-slice tail behind the whole waves"""
+    f = abi.GEMM_FORCE_TILE256
+    cases = [dict(dtype=abi.BF16, m=700, n=1200, k=128, with_res=True, with_gate=True, act=abi.ACT_GELU_TANH),
+             dict(dtype=abi.F16, m=1700, n=250 // 8 * 8, k=192, act=abi.ACT_SILU, seed=1),
+             dict(dtype=abi.BF16, m=700, n=600, k=64, with_bias=False, alpha=0.5, seed=2),
+             dict(dtype=abi.BF16, m=1792, n=256, k=4160, with_res=True, seed=3, expect_split=(6, "sliced", None))]
+    for c in cases:
+        outs = []
+        for on in ("0", "1"):
+            monkeypatch.setenv("MTX_GEMM_PERSIST", on)
+            oc.check_gemm(emu_lib, c["dtype"], **{k: v for k, v in c.items() if k != "dtype"}, flags=f, keep=outs)
+        assert torch.equal(outs[0], outs[1]), f"persistent 256-tile kernel changes bytes: {c}"
 
 
 def test_gemm_256_tile_kernel(emu_lib):
