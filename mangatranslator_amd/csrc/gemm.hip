@@ -28,6 +28,7 @@ struct GemmParams {
   unsigned tiles_m, tiles_n;
   // whole tiles [0, n_full) go to the tile kernel, tiles [n_full, tiles) to the K-slice tail; fp32 partials in `part`
   unsigned n_full; float* part;
+  int persist_mode;              // gemm256_persist_kernel: 1 = the next tile's first stage in front of the epilogue, 2 = requested by the loop (A/B)
   // K-slice tail (round 4): tiles [n_full, tiles) x `slices` equal K ranges of `slice_len` iterations; piece (slice j, tail tile t) keeps
   // its fp32 partial in slot j * rem + t of `part`; `tickets[t]` counts the finished slices of tile t (zero between launches)
   unsigned slices, slice_len; unsigned* tickets;
@@ -716,8 +717,8 @@ __global__ __launch_bounds__(512) void gemm256_persist_kernel(GemmParams p) {
     gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, 0, p.k / G2_BK, acc, issued);
     __syncthreads();                                  // every wave is past its last fragment read: the stages are free
     const long pm0 = m0, pn0 = n0;
-    issued = vb + gridDim.x < total;
-    if (issued) gemm256_tile_origin(p, xcd_remap(vb + gridDim.x, total), m0, n0);
+    issued = vb + gridDim.x < total && p.persist_mode != 2;            // (mode 2, measurement only: persistent walk, first stage requested by the loop as in the plain kernel)
+    if (vb + gridDim.x < total) gemm256_tile_origin(p, xcd_remap(vb + gridDim.x, total), m0, n0);
     gemm256_epilogue_small<T, ACT>(p, acc, smem + 2 * G2_STAGE + wv * 4096, Cp, pm0, pn0, bz, wv, lane,
                                    [&]() __attribute__((always_inline)) { if (issued) gemm256_issue_first_stage<T>(p, smem, A, W, m0, n0); });
   }
@@ -1070,16 +1071,17 @@ static int gemm_num_cus() {
 }
 
 // MTX_GEMM_PERSIST (environment, read per launch): 1 = the persistent 16-bit kernel wherever a CU gets at least two tiles, 0 = never
-static bool gemm256_want_persist() {
+static int gemm256_want_persist() {
   const char* e = getenv("MTX_GEMM_PERSIST");
-  return e ? e[0] == '1' : false;
+  return e ? atoi(e) : 0;
 }
 template <typename T, bool F8>
 static void launch_gemm256_tiles(const GemmParams& p0, dim3 grid, void* stream) {
   GemmParams p = p0;
   if constexpr (!F8) {
     const unsigned cus = (unsigned)gemm_num_cus();
-    if (gemm256_want_persist() && grid.x >= 2 * cus) {
+    if (gemm256_want_persist() > 0 && grid.x >= 2 * cus) {
+      p.persist_mode = gemm256_want_persist();
       p.n_full = grid.x;                              // (the kernel's tile count; the K-slice launch that may follow sets its own copy)
       const dim3 pg(cus, grid.y);
 #define MTX_G256P(ACTV) MTX_LAUNCH((gemm256_persist_kernel<T, ACTV>), pg, dim3(512), 0, stream, p)

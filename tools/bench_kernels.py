@@ -163,7 +163,7 @@ def gemm_persist(M, N, K, reps=3, iters=20, kind="b"):
     plan = pb.build()
     best, ref, same = {}, None, True
     for _ in range(reps):
-        for on in ("0", "1"):
+        for on in ("0", "1", "2"):
             os.environ["MTX_GEMM_PERSIST"] = on
             out.zero_()
             ms = _time(plan, iters)
@@ -173,7 +173,8 @@ def gemm_persist(M, N, K, reps=3, iters=20, kind="b"):
             same = same and torch.equal(out, ref)
     os.environ.pop("MTX_GEMM_PERSIST", None)
     print(f"gemm M={M} N={N} K={K} [{ {'b': 'bias', 'g': 'bias + GELU', 'r': 'bias, gate, residual'}[kind] }] plain {best['0']:.4f} ms ({2 * M * N * K / best['0'] / 1e9:.0f} TF)  "
-          f"persistent {best['1']:.4f} ms ({2 * M * N * K / best['1'] / 1e9:.0f} TF)  {100 * (best['0'] / best['1'] - 1):+.1f} %  same bytes: {same}  split {lib.gemm_last_split()}", flush=True)
+          f"persistent {best['1']:.4f} ms ({2 * M * N * K / best['1'] / 1e9:.0f} TF)  {100 * (best['0'] / best['1'] - 1):+.1f} %  "
+          f"persistent walk, first stage by the loop {best['2']:.4f} ms  {100 * (best['0'] / best['2'] - 1):+.1f} %  same bytes: {same}  split {lib.gemm_last_split()}", flush=True)
 
 
 def gemm_strips(M, N, K, f8=False, reps=3, iters=20, kind="b"):
