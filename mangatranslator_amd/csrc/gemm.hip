@@ -28,7 +28,6 @@ struct GemmParams {
   unsigned tiles_m, tiles_n;
   // whole tiles [0, n_full) go to the tile kernel, tiles [n_full, tiles) to the K-slice tail; fp32 partials in `part`
   unsigned n_full; float* part;
-  int persist_mode;              // gemm256_persist_kernel: 1 = the next tile's first stage in front of the epilogue, 2 = requested by the loop (A/B)
   // K-slice tail (round 4): tiles [n_full, tiles) x `slices` equal K ranges of `slice_len` iterations; piece (slice j, tail tile t) keeps
   // its fp32 partial in slot j * rem + t of `part`; `tickets[t]` counts the finished slices of tile t (zero between launches)
   unsigned slices, slice_len; unsigned* tickets;
@@ -425,12 +424,6 @@ __device__ __forceinline__ void gemm256_tile_origin(const GemmParams& p, unsigne
   n0 = (long)(col0 + (rest % per_group) / gsz) * G2_BN;
 }
 
-// keeps memory operations written before it in front of those written after it in the instruction stream (no instruction of its own)
-#ifdef MTX_EMU
-#define MTX_ASM_ORDER() ((void)0)
-#else
-#define MTX_ASM_ORDER() asm volatile("" ::: "memory")
-#endif
 #ifdef MTX_EMU
 #define G2_BAR() __syncthreads()
 #else
@@ -450,7 +443,7 @@ __device__ __forceinline__ void gemm256_tile_origin(const GemmParams& p, unsigne
 // The caller provides a workgroup barrier between two calls (the stages are reused).
 template <typename T>
 __device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigned char* smem, const T* A, const T* W, long m0, long n0,
-                                                    long kbeg, long kend, f32x16 (&acc)[4][2], const bool prologue_issued = false) {
+                                                    long kbeg, long kend, f32x16 (&acc)[4][2]) {
   typedef typename Traits<T>::v8 v8;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wm = wv >> 2, wn = wv & 3, grp = wv >> 2;
@@ -486,10 +479,8 @@ __device__ __forceinline__ void gemm256_pp_buf_loop(const GemmParams& p, unsigne
       waddr[st_][ks] = st_ * G2_STAGE + wr0 * 128 + (((2 * ks + hi) ^ ((wr0 >> 1) & 7)) << 4);
     }
 
-  if (!prologue_issued) {                  // (the persistent kernel issues a tile's first stage in front of the previous tile's epilogue)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) piece(i, (int)(kbeg & 1), kbeg * G2_BK);
-  }
+  for (int i = 0; i < 8; ++i) piece(i, (int)(kbeg & 1), kbeg * G2_BK);
   MTX_WAIT_VMEM();
   __syncthreads();
   if (grp == 1) G2_BAR();
@@ -564,164 +555,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, 0, p.k / G2_BK, acc);
   __syncthreads();
   gemm256_epilogue<T, ACT>(p, acc, smem, Cp, m0, n0, bz, wv, lane);
-}
-
-// ---- persistent form of the kernel above (round 6, VERDICT r05 #4b) ---------------------------------------------------------------------
-// One workgroup per CU walks tiles b, b + G, b + 2 G, ... of the same grouped order (the tile a CU got in wave w of the plain launch is the
-// tile it takes in iteration w here).  What it buys: the first stage of tile i + 1 is requested (8 DMA pieces per wave) BEFORE the epilogue
-// of tile i starts, and the epilogue no longer lives in the stages — it goes through a 4 KiB region per wave behind them (160 KiB of LDS in
-// all), one 32-row block of the wave's 128 at a time — so the DMA lands while the CU converts, stages and stores; the plain launch left the
-// CU idle from the last MFMA of a tile to the first landed stage of the next workgroup.  Same arithmetic and rounding order per element:
-// identical bytes to gemm256_kernel.
-template <typename T>
-__device__ __forceinline__ void gemm256_issue_first_stage(const GemmParams& p, unsigned char* smem, const T* A, const T* W, long m0, long n0) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int wvs = wv;
-#ifndef MTX_EMU
-  wvs = __builtin_amdgcn_readfirstlane(wv);
-#endif
-  const long mrows = p.m - m0 < G2_BM ? p.m - m0 : G2_BM, nrows = p.n - n0 < G2_BN ? p.n - n0 : G2_BN;
-  const BufView abuf = make_buf(A + (size_t)m0 * p.lda, (unsigned)((((size_t)mrows - 1) * p.lda + p.k) * sizeof(T)));
-  const BufView wbuf = make_buf(W + (size_t)n0 * p.ldw, (unsigned)((((size_t)nrows - 1) * p.ldw + p.k) * sizeof(T)));
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = (i * 8 + wv) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    const unsigned voff = i < 4 ? (unsigned)(((size_t)row * p.lda + c * 8) * sizeof(T)) : (unsigned)(((size_t)(row - G2_BM) * p.ldw + c * 8) * sizeof(T));
-    buf_load16_lds(i < 4 ? abuf : wbuf, voff, 0u, smem + (i * 8 + wvs) * 1024);
-  }
-}
-
-// gemm256_epilogue through a 4 KiB staging region per wave: [32 rows m][8 chunks of 16 B], chunk ^= (row & 7); block i of the wave's four
-// 32-row blocks at a time (a wave's LDS operations are executed in order: block i + 1's writes follow block i's reads)
-// `issue_next` (the next tile's first-stage DMA) runs once the bias and block 0's gate / residual chunks are REQUESTED: loads return in issue
-// order, so everything requested behind the 64 KiB of DMA waits for it to land — block 0 must not.
-template <typename T, int ACT, typename F>
-__device__ __forceinline__ void gemm256_epilogue_small(const GemmParams& p, f32x16 (&acc)[4][2], unsigned char* outs, T* Cp,
-                                                       long m0, long n0, long bz, int wv, int lane, F&& issue_next) {
-  typedef typename Traits<T>::v4 v4;
-  const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 2, wn = wv & 3;
-  f32x4 bv[2][4];
-  if (p.bias != nullptr && ((size_t)p.bias & 15) == 0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const long n = n0 + wn * 64 + j * 32 + g * 8 + hi * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p.bias + (n < p.n ? n : 0));
-        bv[j][g] = n < p.n ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long n = n0 + wn * 64 + j * 32 + g * 8 + hi * 4 + r;
-          bv[j][g][r] = (p.bias != nullptr && n < p.n) ? p.bias[n] : 0.f;
-        }
-  }
-  const T* G = reinterpret_cast<const T*>(p.gate);
-  const T* R = reinterpret_cast<const T*>(p.res);
-  const int oc = lane & 7;
-  const long nn = n0 + wn * 64 + oc * 8;
-  const bool n_ok = nn < p.n;
-  const long nc = n_ok ? nn : 0;
-  // gate row = m / rows_per (see gemm256_epilogue); the accumulators stay live across the four blocks here, so a block's gate and residual
-  // chunks are requested at the top of that block (4 + 4 registers of 16 bytes) instead of all sixteen up front
-  const unsigned per = G != nullptr ? (unsigned)p.gate_rows_per : 1u, mb = (unsigned)(m0 + wm * 128 < p.m ? m0 + wm * 128 : p.m - 1);
-  const unsigned q0 = mb / per, next = (q0 + 1) * per;
-  const bool one_step = per >= 128;
-  u32x4 gq[2][4], rq[2][4];
-  auto request = [&](int i, u32x4 (&gqi)[4], u32x4 (&rqi)[4]) __attribute__((always_inline)) {       // block i's gate / residual chunks
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const long m = m0 + wm * 128 + i * 32 + s4 * 8 + (lane >> 3);
-      const unsigned mc = (unsigned)(m < p.m ? m : p.m - 1);
-      if (G != nullptr) {
-        const unsigned gr = one_step ? q0 + (mc >= next ? 1u : 0u) : mc / per;
-        gqi[s4] = *reinterpret_cast<const u32x4*>(G + (size_t)gr * p.ldgate + nc);
-      }
-      if (R != nullptr) rqi[s4] = *reinterpret_cast<const u32x4*>(R + (size_t)bz * p.res_bs + (size_t)mc * p.ldres + nc);
-    }
-  };
-  request(0, gq[0], rq[0]);
-  MTX_ASM_ORDER();
-  issue_next();
-  MTX_ASM_ORDER();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < 3) request(i + 1, gq[(i + 1) & 1], rq[(i + 1) & 1]);          // the next block's chunks travel while this block is staged and stored
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + g * 8 + hi * 4;
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act_t<ACT>(acc[i][j][g * 4 + r] * p.alpha + bv[j][g][r], p.act, p.act_param));
-        *reinterpret_cast<v4*>(outs + l31 * 128 + ((((nl >> 3)) ^ (l31 & 7)) << 4) + ((nl & 4) << 1)) = o;
-      }
-#ifdef MTX_EMU
-    emu::wave_sync();
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int lr = s4 * 8 + (lane >> 3);          // row inside the block
-      const long m = m0 + wm * 128 + i * 32 + lr;
-      u32x4 raw = *reinterpret_cast<const u32x4*>(outs + lr * 128 + ((oc ^ (lr & 7)) << 4));
-      if (G != nullptr || R != nullptr) {
-#pragma clang fp contract(off)
-        float f[8];
-        unpack8<T>(raw, f);
-        if (G != nullptr) { float g8[8]; unpack8<T>(gq[i & 1][s4], g8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = f[e] * g8[e]; }
-        if (R != nullptr) { float r8[8]; unpack8<T>(rq[i & 1][s4], r8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = f[e] + r8[e]; }
-        raw = pack8<T>(f);
-      }
-      if (m < p.m && n_ok) *reinterpret_cast<u32x4*>(Cp + (size_t)m * p.ldc + nn) = raw;
-    }
-#ifdef MTX_EMU
-    emu::wave_sync();
-#endif
-  }
-}
-
-constexpr int G2_PERSIST_SMEM = 2 * G2_STAGE + 8 * 4096;       // 160 KiB: the two stages + 4 KiB of epilogue staging per wave
-template <typename T, int ACT>
-__global__ __launch_bounds__(512) void gemm256_persist_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[G2_PERSIST_SMEM];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long bz = blockIdx.y;
-  const T* A = reinterpret_cast<const T*>(p.a) + (size_t)bz * p.a_bs;
-  const T* W = reinterpret_cast<const T*>(p.w) + (size_t)bz * p.w_bs;
-  T* Cp = reinterpret_cast<T*>(p.c) + (size_t)bz * p.c_bs;
-  const unsigned total = p.n_full;                    // tiles of this launch (all of them, or the whole waves in front of a K-slice tail)
-  long m0, n0;
-  gemm256_tile_origin(p, xcd_remap(blockIdx.x, total), m0, n0);
-  bool issued = false;
-  for (unsigned vb = blockIdx.x; vb < total; vb += gridDim.x) {
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    gemm256_pp_buf_loop<T>(p, smem, A, W, m0, n0, 0, p.k / G2_BK, acc, issued);
-    __syncthreads();                                  // every wave is past its last fragment read: the stages are free
-    const long pm0 = m0, pn0 = n0;
-    issued = vb + gridDim.x < total && p.persist_mode != 2;            // (mode 2, measurement only: persistent walk, first stage requested by the loop as in the plain kernel)
-    if (vb + gridDim.x < total) gemm256_tile_origin(p, xcd_remap(vb + gridDim.x, total), m0, n0);
-    gemm256_epilogue_small<T, ACT>(p, acc, smem + 2 * G2_STAGE + wv * 4096, Cp, pm0, pn0, bz, wv, lane,
-                                   [&]() __attribute__((always_inline)) { if (issued) gemm256_issue_first_stage<T>(p, smem, A, W, m0, n0); });
-  }
 }
 
 // =====================================================================================================
@@ -1070,31 +903,8 @@ static int gemm_num_cus() {
   return cus;
 }
 
-// MTX_GEMM_PERSIST (environment, read per launch): 1 = the persistent 16-bit kernel wherever a CU gets at least two tiles, 0 = never
-static int gemm256_want_persist() {
-  const char* e = getenv("MTX_GEMM_PERSIST");
-  return e ? atoi(e) : 0;
-}
 template <typename T, bool F8>
-static void launch_gemm256_tiles(const GemmParams& p0, dim3 grid, void* stream) {
-  GemmParams p = p0;
-  if constexpr (!F8) {
-    const unsigned cus = (unsigned)gemm_num_cus();
-    if (gemm256_want_persist() > 0 && grid.x >= 2 * cus) {
-      p.persist_mode = gemm256_want_persist();
-      p.n_full = grid.x;                              // (the kernel's tile count; the K-slice launch that may follow sets its own copy)
-      const dim3 pg(cus, grid.y);
-#define MTX_G256P(ACTV) MTX_LAUNCH((gemm256_persist_kernel<T, ACTV>), pg, dim3(512), 0, stream, p)
-      switch (p.act) {
-        case MTX_ACT_NONE: MTX_G256P(MTX_ACT_NONE); break;
-        case MTX_ACT_SILU: MTX_G256P(MTX_ACT_SILU); break;
-        case MTX_ACT_GELU_TANH: MTX_G256P(MTX_ACT_GELU_TANH); break;
-        default: MTX_G256P(-1); break;
-      }
-#undef MTX_G256P
-      return;
-    }
-  }
+static void launch_gemm256_tiles(const GemmParams& p, dim3 grid, void* stream) {
 #define MTX_G256(ACTV) do { if (F8) MTX_LAUNCH((gemm256_f8_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); \
                             else MTX_LAUNCH((gemm256_kernel<T, ACTV>), grid, dim3(512), 0, stream, p); } while (0)
   switch (p.act) {

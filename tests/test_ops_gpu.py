@@ -218,20 +218,6 @@ def test_gemm_f8_glu_epilogue(hip_lib, cfg):
     oc.check_gemm_f8_glu(hip_lib, abi.BF16, **cfg)
 
 
-def test_gemm_256_persistent_kernel(hip_lib, monkeypatch):
-    """gemm256_persist_kernel against the plain 256-tile launch on FLUX shapes (five whole rounds + K-slice tail; gate + residual; GELU; ragged M):
-    identical bytes"""
-    import torch
-    cases = [dict(m=8812, n=9216, k=3072), dict(m=8812, n=3072, k=3072, with_res=True, with_gate=True), dict(m=8300, n=12288, k=3072, act=abi.ACT_GELU_TANH),
-             dict(m=8812, n=3072, k=15360, with_res=True, with_gate=True, expect_split=(256, "sliced", None))]
-    for c in cases:
-        outs = []
-        for on in ("0", "1"):
-            monkeypatch.setenv("MTX_GEMM_PERSIST", on)
-            oc.check_gemm(hip_lib, abi.BF16, **c, keep=outs)
-        assert torch.equal(outs[0], outs[1]), f"persistent 256-tile kernel changes bytes: {c}"
-
-
 def test_attention_fp8_scores(hip_lib):
     """attn_mma32_k8_kernel / _k8q_kernel (mtx_attn_args.q_f8 / k_f8): scores from e4m3 q and k on the MX-scaled fp8 matrix instruction —
     against the exact softmax of the same e4m3 products; with the MX fp8 output form: the bytes of attention + quantiser.  The rotary

@@ -144,23 +144,6 @@ def test_gemm_256_tile_map_strips(emu_lib, monkeypatch):
         oc.check_gemm(emu_lib, abi.F16, m=1100, n=600, k=64, act=abi.ACT_SILU, flags=f, seed=st)
 
 
-def test_gemm_256_persistent_kernel(emu_lib, monkeypatch):
-    """round 6: gemm256_persist_kernel (one workgroup per CU walks its tiles; the next tile's first stage is requested in front of the epilogue, which
-    runs through 4 KiB per wave behind the stages) gives the bytes of the plain launch: 3 x 5 tiles on 3 simulated CUs (five iterations per
-    workgroup), 7 tiles (ragged last round), gate + residual + GELU, K-slice tail behind the whole waves"""
-    f = abi.GEMM_FORCE_TILE256
-    cases = [dict(dtype=abi.BF16, m=700, n=1200, k=128, with_res=True, with_gate=True, act=abi.ACT_GELU_TANH),
-             dict(dtype=abi.F16, m=1700, n=250 // 8 * 8, k=192, act=abi.ACT_SILU, seed=1),
-             dict(dtype=abi.BF16, m=700, n=600, k=64, with_bias=False, alpha=0.5, seed=2),
-             dict(dtype=abi.BF16, m=1792, n=256, k=4160, with_res=True, seed=3, expect_split=(6, "sliced", None))]
-    for c in cases:
-        outs = []
-        for on in ("0", "1"):
-            monkeypatch.setenv("MTX_GEMM_PERSIST", on)
-            oc.check_gemm(emu_lib, c["dtype"], **{k: v for k, v in c.items() if k != "dtype"}, flags=f, keep=outs)
-        assert torch.equal(outs[0], outs[1]), f"persistent 256-tile kernel changes bytes: {c}"
-
-
 def test_gemm_256_tile_kernel(emu_lib):
     """the 256 x 256 LDS-DMA kernel (normally used from 24 tiles up) on ragged small problems: ping-pong loop with descriptor-based
     LDS-DMA (range-checked zero fill), pieces spread 3/3/2/0"""

@@ -146,37 +146,6 @@ def gemm_epi(M, N, K, kind, f8=False, reps=3, iters=20):
     print(f"gemm{'8' if f8 else ''} M={M} N={N} K={K} [{what}]: {best:.3f} ms ({2 * M * N * K / best / 1e9:.0f} TFLOP/s)", flush=True)
 
 
-def gemm_persist(M, N, K, reps=3, iters=20, kind="b"):
-    """Round 6: the persistent 256-tile kernel (MTX_GEMM_PERSIST=1) against the plain launch, alternating in one process; kind "b": bias,
-    "g": bias + tanh-GELU, "r": gate + residual (the FLUX output projections); the outputs must be the same bytes."""
-    pb = PlanBuilder(lib, dev, abi.BF16)
-    g = torch.Generator(device=dev).manual_seed(5)
-    a = pb.buf((M, K), torch.bfloat16); a.normal_(generator=g)
-    w = pb.buf((N, K), torch.bfloat16); w.normal_(0, K ** -0.5, generator=g)
-    bias = pb.buf((N,), torch.float32); bias.normal_(generator=g)
-    kw = dict(bias=bias, act=abi.ACT_GELU_TANH if kind == "g" else 0)
-    if kind == "r":
-        res = pb.buf((M, N), torch.bfloat16); res.normal_(generator=g)
-        gate = pb.buf((1, N), torch.bfloat16); gate.normal_(generator=g)
-        kw.update(res=res, gate=gate, gate_rows_per=M)
-    out = pb.gemm(a, w, M, N, K, **kw)
-    plan = pb.build()
-    best, ref, same = {}, None, True
-    for _ in range(reps):
-        for on in ("0", "1", "2"):
-            os.environ["MTX_GEMM_PERSIST"] = on
-            out.zero_()
-            ms = _time(plan, iters)
-            best[on] = min(best.get(on, 1e9), ms)
-            if ref is None:
-                ref = out.clone()
-            same = same and torch.equal(out, ref)
-    os.environ.pop("MTX_GEMM_PERSIST", None)
-    print(f"gemm M={M} N={N} K={K} [{ {'b': 'bias', 'g': 'bias + GELU', 'r': 'bias, gate, residual'}[kind] }] plain {best['0']:.4f} ms ({2 * M * N * K / best['0'] / 1e9:.0f} TF)  "
-          f"persistent {best['1']:.4f} ms ({2 * M * N * K / best['1'] / 1e9:.0f} TF)  {100 * (best['0'] / best['1'] - 1):+.1f} %  "
-          f"persistent walk, first stage by the loop {best['2']:.4f} ms  {100 * (best['0'] / best['2'] - 1):+.1f} %  same bytes: {same}  split {lib.gemm_last_split()}", flush=True)
-
-
 def gemm_strips(M, N, K, f8=False, reps=3, iters=20, kind="b"):
     """Round 6: the workgroup -> tile map of the 256-tile kernels with 1 (rounds 1-5), 2, 4, 8 column strips and the launcher's own choice (0),
     alternating in one process (the launcher reads MTX_GEMM_STRIPS per launch); the outputs must be the same bytes."""
@@ -272,8 +241,6 @@ if __name__ == "__main__":
             conv(int(args[1]), int(args[2])); args = args[3:]
         elif args[0] in ("gemmeb", "gemmeg", "gemmer", "gemm8eb", "gemm8er"):      # gemmeK M N K: with a real epilogue (K = b / g / r), fp8 with gemm8eK
             gemm_epi(int(args[1]), int(args[2]), int(args[3]), args[0][-1], f8=args[0].startswith("gemm8")); args = args[4:]
-        elif args[0] in ("gemmp", "gemmpg", "gemmpr"):        # persistent 256-tile kernel A/B: bias / bias + GELU / gate + residual
-            gemm_persist(int(args[1]), int(args[2]), int(args[3]), kind={"gemmp": "b", "gemmpg": "g", "gemmpr": "r"}[args[0]]); args = args[4:]
         elif args[0] in ("gemmst", "gemm8st", "gemmgst"):     # strip-count A/B of the 256-tile kernels' tile map
             gemm_strips(int(args[1]), int(args[2]), int(args[3]), f8=args[0] == "gemm8st", kind="g" if args[0] == "gemmgst" else "b"); args = args[4:]
         elif args[0] == "gemmg":                       # bf16 GEMM with the bias + tanh-GELU epilogue (FLUX ff1 / proj_mlp)
