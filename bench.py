@@ -120,6 +120,9 @@ def parse():
     ap.add_argument("--no-attn-qk-f8", action="store_true",
                     help="FLUX.2-Klein fp8 path, for A/Bs: 16-bit attention scores instead of the scores from e4m3 q and k on the fp8 matrix instruction "
                          "(Flux2DiTHip(attn_qk_f8=True), mtx_attn_args.q_f8 / k_f8) that are the fp8 path's default since round 6; reported in config.attn_qk_f8")
+    ap.add_argument("--detector-batch", type=int, default=1,
+                    help="pages per graph replay of the panel / outside-text detectors (imgsz 640): > 1 shares ONE batching wrapper per detector between the "
+                         "front halves that run side by side (needs --front-replicas >= 2 to ever fill a batch); 1 = a detector instance per front half")
     ap.add_argument("--front-replicas", type=int, default=None,
                     help="instances of the detect-stage models (detectors + SAM) per rank; with N > 1 the front halves of N pages run at once, "
                          "each on its own instance (a model's plan has one set of buffers).  Default: 2 for the stage sets without diffusion / "
@@ -319,6 +322,12 @@ def main():
             if not args.no_aux_detectors:
                 make_aux = [("panel", seeded_y11("11", "l", False, 17), 0.25), ("osb_text", seeded_y11("12", "x", False, 19), 0.4)]
                 aux_detectors = [(n_, mk_(), c_) for n_, mk_, c_ in make_aux]
+                if args.detector_batch > 1 and not args.serial_detectors:
+                    # one batching wrapper per 640-px detector, SHARED by every front half (core/ml/detector_batch.py): the pages whose front
+                    # halves run side by side go through one graph replay; their results are the one-page call's, byte for byte
+                    from mangatranslator_amd.core.ml.detector_batch import DetectorBatcher
+                    aux_detectors = [(n_, DetectorBatcher(d_, args.detector_batch), c_) for n_, d_, c_ in aux_detectors]
+                    make_aux = [(n_, (lambda w_=d_: w_), c_) for n_, d_, c_ in aux_detectors]
         # secondary detector of the same stage: RT-DETR-v2 R50 @640 (reference detection.py:1401-1407, on by default)
         from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
         rcfg = synth.rtdetr_r50_config()
@@ -721,6 +730,9 @@ def main():
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
                    "detector_calls": ("one after the other" if args.serial_detectors else "submitted together, one HIP stream per model, collected afterwards") if yolo is not None else None,
                    "front_replicas": n_front,
+                   "detector_batch": ({"pages_per_replay_max": args.detector_batch,
+                                       **{n_: {"pages": d_.stats["pages"], "graph_replays": d_.stats["launches"]} for n_, d_, _c in (aux_detectors or []) if hasattr(d_, "stats")}}
+                                      if args.detector_batch > 1 and aux_detectors else None),
                    "stage_wall_ms_one_page": {k_: round(v_, 2) for k_, v_ in stage_wall.items()},
                    "page_pipeline": ("two pages in flight: detectors (+ SAM encoder) of page i+1 on a worker thread beside the SAM mask decoder of page i" if seg_in_b else
                                      "two pages in flight: detect / segment / OSB prepare of page i+1 on a worker thread beside inpaint / upscale / clean of page i"
@@ -751,7 +763,9 @@ def main():
             cfg["segment_ms"] = {"preprocess": pre.time(5), "encoder": enc.time(5), "decoder": dec.time(5), "upsample_threshold": post.time(5)}
         if yolo is not None:
             cfg["detect_net_ms"] = yolo._plans[(H_, W_, 1600)][0].time(5)
-            cfg["detect_aux_ms"] = {name_: det_._plans[(H_, W_, 640)][0].time(5) for name_, det_, _ in aux_detectors}
+            # (a batching wrapper: one replay of its batched graph, divided by the pages it carries when full — what a page costs in a full batch)
+            cfg["detect_aux_ms"] = {name_: (det_._sets[(H_, W_, 640)][0].plan.time(5) / det_.batch if hasattr(det_, "_sets") else det_._plans[(H_, W_, 640)][0].time(5))
+                                    for name_, det_, _ in aux_detectors}
             ra, rb = rtdetr.plans(640, 640)
             cfg["detect_rtdetr_ms"] = {"backbone_encoder": ra.time(5), "decoder": rb.time(5)}
         # wall clock of a stage (one page, synchronised) against the GPU time of its graphs: what is left is host work (NMS, prompt set-up,

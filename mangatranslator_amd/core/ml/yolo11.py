@@ -158,11 +158,12 @@ class Yolo11Hip(YoloSegHip):
         nh, hd, kd = self.W[p + ".qkv#geo"]
         C, N = nh * hd, x.h * x.w
         qkv = self._conv(pb, x, p + ".qkv", act=abi.ACT_NONE)                          # [1, h, w, 3C]: Q | K | V blocks
-        o = pb.act(1, x.h, x.w, C)
+        o = pb.act(x.n, x.h, x.w, C)
         if N % area:
             raise ModelError(f"area attention: {N} positions do not split into {area} areas")
         nb = N // area
-        pb.attention(qkv.t, qkv.t, qkv.t, o.t, area, nh, nb, nb, hd, (nb * 3 * C, 3 * C, hd), (nb * 3 * C, 3 * C, hd), (nb * 3 * C, 3 * C, hd),
+        # (a batch of images: image b's areas are launch batches b * area .. — an image is `area` consecutive chunks of nb positions)
+        pb.attention(qkv.t, qkv.t, qkv.t, o.t, x.n * area, nh, nb, nb, hd, (nb * 3 * C, 3 * C, hd), (nb * 3 * C, 3 * C, hd), (nb * 3 * C, 3 * C, hd),
                      (nb * C, C, hd), float(kd) ** -0.5, k_off=C, v_off=2 * C, label=p + ".sdpa")
         w, b, k = self.DW[p + ".pe"]
         pe = pb.dwconv(qkv.slice(2 * C, C), w, b, k, label=p + ".pe")
@@ -205,7 +206,7 @@ class Yolo11Hip(YoloSegHip):
             res = pb.act(x.n, x.h, x.w, out.c)
             e = abi.EwArgs()
             e.a, e.b, e.s, e.y = out.ptr, x.ptr, g.data_ptr(), res.ptr
-            e.n, e.h, e.w, e.c = 1, 1, x.h * x.w, out.c
+            e.n, e.h, e.w, e.c = 1, 1, x.n * x.h * x.w, out.c
             e.lda, e.ldb, e.ldy, e.lds = out.ld, x.ld, res.ld, 0
             e.kind, e.act, e.act_param, e.i0, e.i1, e.dtype = abi.EW_GATE_RES, 0, 0.0, 0, 0, self.dtype
             pb._add(abi.OP_EW, e, p + ".gamma_res")
@@ -223,19 +224,22 @@ class Yolo11Hip(YoloSegHip):
 
     def _sppf(self, pb, x, i):
         ch = self.W[f"model.{i}.cv1"][2]
-        sp = pb.act(1, x.h, x.w, 4 * ch)
+        sp = pb.act(x.n, x.h, x.w, 4 * ch)
         self._conv(pb, x, f"model.{i}.cv1", out=sp.slice(0, ch))
         for k in range(3):
             pb.ew(abi.EW_MAXPOOL, sp.slice(k * ch, ch), out=sp.slice((k + 1) * ch, ch), i0=5, i1=1, label=f"sppf.pool{k}")
         return self._conv(pb, sp, f"model.{i}.cv2")
 
-    def _build(self, lp):
+    def _build(self, lp, batch=1):
+        """batch > 1: `batch` letterboxed images through one graph (core/ml/detector_batch.py) — every activation carries the image index as its
+        outermost dimension, every kernel treats images independently (same tiles, same arithmetic per image as the batch-1 plan), and the
+        head is decoded image by image into plan.decoded[b]"""
         a = self.a
         pb = PlanBuilder(self.lib, self.device, self.dtype)
         H, W = lp["H"], lp["W"]
         if H % 32 or W % 32:
             raise ModelError(f"letterboxed input {W}x{H} must be a multiple of 32")
-        img = pb.act(1, H, W, 8)
+        img = pb.act(batch, H, W, 8)
         up = lambda t, lab: pb.ew(abi.EW_UPSAMPLE2X, t, label=lab)
         x = self._conv(pb, self._conv(pb, img, "model.0", 2), "model.1", 2)
         p3 = self._c3k2(pb, self._conv(pb, self._c3k2(pb, x, 2), "model.3", 2), 4)
@@ -256,7 +260,7 @@ class Yolo11Hip(YoloSegHip):
         hi, nb, ncp, nm = a["head"], 4 * a["reg_max"], 8, a["nm"]
         heads, box32 = [], []
         for l, f in enumerate((h3, n4, n5)):
-            hb = pb.act(1, f.h, f.w, nb + ncp + nm)
+            hb = pb.act(batch, f.h, f.w, nb + ncp + nm)
             t = self._conv(pb, self._conv(pb, f, f"model.{hi}.cv2.{l}.0"), f"model.{hi}.cv2.{l}.1")
             box32.append(self._box_logits_f32(pb, t, f"model.{hi}.cv2.{l}.2", nb))       # (hb's first nb channels stay unwritten: the decode reads the fp32 logits)
             t = f
@@ -269,8 +273,16 @@ class Yolo11Hip(YoloSegHip):
                 self._conv(pb, t, f"model.{hi}.cv4.{l}.2", act=abi.ACT_NONE, out=hb.slice(nb + ncp, nm))
             heads.append(hb)
         anchors = sum(hb.h * hb.w for hb in heads)
-        decoded = pb.buf((anchors, 4 + a["nc"] + nm), torch.float32)
-        pb.yolo_decode(heads, [8, 16, 32], a["nc"], nm, a["reg_max"], decoded, cls_off=nb, mc_off=nb + ncp, box_f32=box32)
+        if batch == 1:
+            decoded = pb.buf((anchors, 4 + a["nc"] + nm), torch.float32)
+            pb.yolo_decode(heads, [8, 16, 32], a["nc"], nm, a["reg_max"], decoded, cls_off=nb, mc_off=nb + ncp, box_f32=box32)
+        else:
+            if nm:
+                raise ModelError("batched plans exist for the detect-only heads (panel / outside-text detectors)")
+            decoded = pb.buf((batch, anchors, 4 + a["nc"] + nm), torch.float32)
+            for b in range(batch):
+                pb.yolo_decode(heads, [8, 16, 32], a["nc"], nm, a["reg_max"], decoded[b], cls_off=nb, mc_off=nb + ncp, box_f32=box32, image=b,
+                               label=f"yolo_decode.{b}")
         proto = None
         if nm:
             t = self._conv(pb, h3, f"model.{hi}.proto.cv1")

@@ -586,13 +586,14 @@ class PlanBuilder:
         self._add(abi.OP_PREPROC, a, label)
         return dst
 
-    def yolo_decode(self, levels, strides, nc, nm, reg_max, out, cls_off=0, mc_off=0, label="yolo_decode", box_f32=None):
-        """box_f32: per level an fp32 [h * w, 4 * reg_max] matrix of DFL logits (mtx_yolo_decode_args.box_f32) read instead of the level's box channels"""
+    def yolo_decode(self, levels, strides, nc, nm, reg_max, out, cls_off=0, mc_off=0, label="yolo_decode", box_f32=None, image=0):
+        """box_f32: per level an fp32 [n * h * w, 4 * reg_max] matrix of DFL logits (mtx_yolo_decode_args.box_f32) read instead of the level's box channels;
+        image: which image of a batched head [n, h, w, ld] this launch decodes (one launch per image)"""
         a = abi.YoloDecodeArgs()
         for i, (lv, st) in enumerate(zip(levels, strides)):
-            a.level[i], a.lh[i], a.lw[i], a.lld[i], a.lstride[i] = lv.ptr, lv.h, lv.w, lv.ld, st
+            a.level[i], a.lh[i], a.lw[i], a.lld[i], a.lstride[i] = lv.ptr + image * lv.h * lv.w * lv.ld * lv.t.element_size(), lv.h, lv.w, lv.ld, st
             if box_f32 is not None:
-                a.box_f32[i] = _ptr(box_f32[i])
+                a.box_f32[i] = _ptr(box_f32[i]) + image * lv.h * lv.w * 4 * reg_max * 4
         a.n_levels, a.nc, a.nm, a.reg_max, a.out, a.dtype = len(levels), nc, nm, reg_max, _ptr(out), self.dtype
         a.cls_off, a.mc_off = cls_off, mc_off
         self._add(abi.OP_YOLO_DECODE, a, label)

@@ -27,3 +27,12 @@ def test_yolo11m_seg_bubble_detector_geometry(hip_lib):
     """`yolo_2` call: imgsz 1600 on a 1024 x 1536 page (1088 x 1600 letterbox), retina masks"""
     be, ce = yc.check(hip_lib, "cuda:0", "11", "m", True, h=1536, w=1024, imgsz=1600, seed=7, n_det=20)
     record("yolo11.m.seg.1024x1536.imgsz1600", box_err_px=be, class_abs_err=ce)
+
+
+def test_detector_batcher_matches_single_calls(hip_lib):
+    """cross-page batches through one detector graph (core/ml/detector_batch.py) at the product geometry — YOLO11-L and YOLO12x, 1024 x 1536 pages at
+    imgsz 640 — 4 pages in one replay, and 6 pages from their own threads in batches of 4: decoded rows and boxes are the one-page call's bytes"""
+    s1 = yc.check_batched(hip_lib, "cuda:0", family="11", scale="l", h=1536, w=1024, imgsz=640, pages=4, batch=4)
+    s2 = yc.check_batched(hip_lib, "cuda:0", family="12", scale="x", h=1536, w=1024, imgsz=640, pages=3, batch=4, seed=1)
+    s3 = yc.check_batched(hip_lib, "cuda:0", family="11", scale="n", h=1536, w=1024, imgsz=640, pages=6, batch=4, seed=2, threads=True)
+    record("detector_batch.640px", yolo11l=s1, yolo12x=s2, yolo11n_threads=s3)

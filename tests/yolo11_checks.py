@@ -101,3 +101,46 @@ def check(lib, device, family="11", scale="n", seg=False, h=96, w=64, imgsz=64, 
         assert len(mism) >= max(1, n_ref // 2), (len(mism), n_ref)
         assert max(mism) < mask_tol, f"mask mismatch {max(mism):.4%}"
     return box_err, e_cls
+
+
+def check_batched(lib, device, family="11", scale="n", h=96, w=64, imgsz=64, pages=3, batch=4, seed=0, threads=False):
+    """core/ml/detector_batch.py: `pages` different pages through ONE batched graph replay (DetectorBatcher) give, page by page, the bytes of the
+    one-image call — decoded head rows and final boxes / scores / classes.  threads: every page submitted and collected by its own thread (the
+    way the front halves of a batch run share a detector); otherwise all submits, then all collects, on this thread."""
+    from mangatranslator_amd.core.ml.detector_batch import DetectorBatcher
+    net = yr.make_model(family, scale, 1, False, seed=seed)
+    from oracle import yolo_ref
+    x, _ = yolo_ref.letterbox(make_page(h, w, seed + 1), imgsz)
+    yr.calibrate(net, x)
+    hip = Yolo11Hip(net.state_dict(), device=device, lib=lib)
+    imgs = [make_page(h, w, seed + 1 + i) for i in range(pages)]
+    singles, rows = [], []
+    for im in imgs:
+        r = hip(im, conf=0.05, imgsz=imgsz)[0]
+        plan, _ = hip._plans[(h, w, imgsz)]
+        singles.append(r)
+        rows.append(plan.decoded.clone())
+    bat = DetectorBatcher(hip, batch=batch)
+    if threads:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=pages) as ex:
+            got = list(ex.map(lambda im: bat(im, conf=0.05, imgsz=imgsz)[0], imgs))
+    else:
+        tickets = [bat.submit(im, conf=0.05, imgsz=imgsz) for im in imgs]
+        held = [(t.batch, t.slot) for t in tickets]
+        got = []
+        for i, t in enumerate(tickets):
+            b_, s_ = held[i]
+            got.append(bat.collect(t)[0])
+            assert torch.equal(b_.plan.decoded[s_], rows[i]), f"page {i}: decoded rows of the batched graph differ from the one-image graph"
+        assert bat.stats["launches"] == (pages + batch - 1) // batch, bat.stats
+    assert bat.stats["pages"] == pages
+    n_boxes = 0
+    for i, (a, b) in enumerate(zip(singles, got)):
+        assert (a.boxes is None) == (b.boxes is None), f"page {i}"
+        if a.boxes is not None:
+            for f in ("xyxy", "conf", "cls"):
+                assert torch.equal(getattr(a.boxes, f), getattr(b.boxes, f)), f"page {i}: boxes.{f} differ between the batched and the one-image call"
+            n_boxes += len(a.boxes)
+    assert n_boxes > 0, "no page produced a box: the comparison is empty"
+    return bat.stats
