@@ -120,9 +120,9 @@ def parse():
     ap.add_argument("--no-attn-qk-f8", action="store_true",
                     help="FLUX.2-Klein fp8 path, for A/Bs: 16-bit attention scores instead of the scores from e4m3 q and k on the fp8 matrix instruction "
                          "(Flux2DiTHip(attn_qk_f8=True), mtx_attn_args.q_f8 / k_f8) that are the fp8 path's default since round 6; reported in config.attn_qk_f8")
-    ap.add_argument("--detector-batch", type=int, default=1,
+    ap.add_argument("--detector-batch", type=int, default=0,
                     help="pages per graph replay of the panel / outside-text detectors (imgsz 640): > 1 shares ONE batching wrapper per detector between the "
-                         "front halves that run side by side (needs --front-replicas >= 2 to ever fill a batch); 1 = a detector instance per front half")
+                         "front halves that run side by side; 1 = a detector instance per front half; 0 (default) = as many as there are front halves")
     ap.add_argument("--front-replicas", type=int, default=None,
                     help="instances of the detect-stage models (detectors + SAM) per rank; with N > 1 the front halves of N pages run at once, "
                          "each on its own instance (a model's plan has one set of buffers).  Default: 2 for the stage sets without diffusion / "
@@ -275,6 +275,15 @@ def main():
     graph = not args.no_graph
     want = [x.strip() for x in args.stages.split(",")]
     stages = [st for st in ("detect", "segment", "inpaint", "upscale", "clean") if st in want]
+    # front halves in flight (page i uses model set i % N): decided here because the batching wrapper of the 640-px detectors is sized by it
+    n_front = args.front_replicas
+    if n_front is None:
+        # (without SAM in the front half — config 1 — four pages' detect stages; with it two: a third SAM encoder beside two costs more than it hides, r06_visit_p)
+        light_back = "detect" in stages and "inpaint" not in stages and "upscale" not in stages and not args.no_overlap and not args.serial_detectors
+        n_front = (2 if "segment" in stages else 4) if light_back else 1
+    n_front = max(1, n_front)
+    if args.detector_batch <= 0:
+        args.detector_batch = n_front
     t_load0 = time.perf_counter()
     first = rank == 0 or world == 1
 
@@ -451,10 +460,6 @@ def main():
             clean_args.append((torch.from_numpy(np.stack(bm)).to(device), [tuple(int(v) for v in b_) for b_ in page_boxes[k_]]))
 
     # ---- instances of the front half's models: page i uses set i % N, so N pages' detect stages can be in flight at once --------------
-    n_front = args.front_replicas
-    if n_front is None:
-        n_front = 2 if (yolo is not None and inpainter is None and upscaler is None and not args.no_overlap and not args.serial_detectors) else 1
-    n_front = max(1, n_front)
     front_sets = [dict(yolo=yolo, aux=aux_detectors, rtdetr=rtdetr, sam=sam)]
     for _ in range(1, n_front):
         front_sets.append(dict(yolo=make_yolo() if make_yolo else None, aux=[(n_, mk_(), c_) for n_, mk_, c_ in make_aux],

@@ -44,6 +44,13 @@ class _Batch:
         self.size, self.lp = size, lp
         self.filled = self.collected = 0
         self.launched = False
+        # the first graph replay of a plan CAPTURES it, and a capture must not run beside other threads' GPU work (another front half's allocation or
+        # synchronising read ends it: "hipStreamBeginCapture: the operation cannot be performed in the present state", first hardware run).  Sets
+        # are built where a model's other plans are — on the first page of a size, i.e. during the sequential set-up pages of a batch run.
+        with model._lane.enter():
+            self.plan.run(graph=model._graph)
+        if model._lane.on:
+            model._lane.stream.synchronize()
 
     def close(self):
         for p in [self.plan] + self.pre:
@@ -82,11 +89,15 @@ class DetectorBatcher:
     by the front halves that run side by side.  Pages of another size than the batch being filled start their own batch."""
 
     WAIT_S = 120.0
+    # `model(page)` — the reference's call shape: submit and collect in one go — would launch every batch with one page.  With `peers` > 1 front
+    # halves sharing the wrapper the call lingers this long for companions before it launches what it has (a third of one replay; pages that
+    # left a batch together reach the next detector together, so after the first few pages the wait is rarely used up)
+    LINGER_S = 0.0015
 
-    def __init__(self, model, batch: int = 4):
+    def __init__(self, model, batch: int = 4, peers: int = 1):
         if model.a["nm"]:
             raise ValueError("DetectorBatcher: detect-only heads (the segmentation head's masks are per page)")
-        self.model, self.batch = model, max(1, int(batch))
+        self.model, self.batch, self.peers = model, max(1, int(batch)), max(1, int(peers))
         self.names = model.names
         self._lane = model._lane
         self._cv = threading.Condition()
@@ -96,7 +107,12 @@ class DetectorBatcher:
 
     # ---- the reference's call shape ----------------------------------------------------------------------------------------------------
     def __call__(self, image_bgr, conf=0.25, device=None, verbose=False, imgsz=640, iou=0.7, max_det=300, **_kw):
-        return self.collect(self.submit(image_bgr, conf=conf, imgsz=imgsz, iou=iou, max_det=max_det))
+        ticket = self.submit(image_bgr, conf=conf, imgsz=imgsz, iou=iou, max_det=max_det)
+        if self.peers > 1:
+            with self._cv:
+                want = min(ticket.batch.size, self.peers)
+                self._cv.wait_for(lambda: ticket.batch.launched or ticket.batch.filled >= want, timeout=self.LINGER_S)
+        return self.collect(ticket)
 
     @torch.no_grad()
     def submit(self, image_bgr, conf=0.25, imgsz=640, iou=0.7, max_det=300, **_kw):
@@ -118,6 +134,7 @@ class DetectorBatcher:
                 if b.filled == b.size:
                     self._launch(b, key)
             self.stats["pages"] += 1
+            self._cv.notify_all()
         return BatchTicket(self, b, slot, key=key, hw=(h0, w0), conf=conf, iou=iou, max_det=max_det)
 
     @torch.no_grad()

@@ -205,6 +205,8 @@ class ModelManager:
             # would degrade masks without a NaN — ADVICE r04), "bf16" = the reference's own GPU dtype, no probe, "f16" = no probe either
             self.sam_storage = "auto"
             self._failed_reads = {}                 # checkpoint path -> the error all ranks were told (multi-rank only; see _read_safetensors_with_metadata)
+            self.detector_batch = 1                 # pages per graph replay of the panel / outside-text detectors (see _maybe_batched)
+            self._batchers = {}
             self._initialized = True
             log_message(f"Model Manager initialized on device: {self.device}", always_print=True)
 
@@ -296,10 +298,27 @@ class ModelManager:
     def current_front_replica(self) -> int:
         return getattr(self._tls, "replica", 0)
 
+    # the 640-pixel detect-only networks that can carry several pages per graph replay (core/ml/detector_batch.py)
+    BATCHED_DETECTOR_TYPES = frozenset({ModelType.YOLO_OSBTEXT, ModelType.YOLO_PANEL})
+
     def _slot(self, model_type: ModelType):
         """key of `self.models` this thread's loader call uses"""
         r = self.current_front_replica()
+        if self.detector_batch > 1 and model_type in self.BATCHED_DETECTOR_TYPES:
+            return model_type            # every front half shares the one instance behind the batching wrapper
         return (model_type, r) if r and model_type in self.FRONT_MODEL_TYPES else model_type
+
+    def _maybe_batched(self, slot, model):
+        """`detector_batch` > 1 (set by `batch_vision_images(front_workers=N)`): the panel / outside-text detector is handed out behind ONE
+        DetectorBatcher per slot — the pages whose front halves run side by side share a graph replay, each page's results are the one-page
+        call's bytes.  Models that are not this package's detect-only YOLO11 / YOLO12 graphs (a test double, a segmentation head) pass through."""
+        if self.detector_batch <= 1 or not hasattr(model, "_build") or getattr(model, "a", {}).get("nm", 1):
+            return model
+        from .detector_batch import DetectorBatcher
+        w = self._batchers.get(slot)
+        if w is None or w.model is not model or w.batch != self.detector_batch:
+            w = self._batchers[slot] = DetectorBatcher(model, self.detector_batch, peers=self.detector_batch)
+        return w
 
     # ---- bookkeeping -------------------------------------------------------------------------------
     def is_loaded(self, model_type) -> bool:
@@ -562,7 +581,7 @@ class ModelManager:
         with self._lock:
             slot = self._slot(ModelType.YOLO_OSBTEXT)
             if self.is_loaded(slot):
-                return self.models[slot]
+                return self._maybe_batched(slot, self.models[slot])
             try:
                 sd, md = self._read_safetensors_with_metadata(self.model_paths[ModelType.YOLO_OSBTEXT], local=slot is not ModelType.YOLO_OSBTEXT)
                 model = self._detector_from_state_dict(sd, {0: "text"}, md)
@@ -572,7 +591,7 @@ class ModelManager:
                 raise ModelError(f"Failed to load OSB Text model: {e}") from e
             self.models[slot] = model
             log_message("OSB text detector loaded.", verbose=verbose)
-            return model
+            return self._maybe_batched(slot, model)
 
     def load_yolo_panel(self, verbose: bool = False):
         """Panel detector (YOLO11-L, reference :810-838) as a libmtx_hip graph (core/ml/yolo11.py); ModelError when the checkpoint is not
@@ -580,7 +599,7 @@ class ModelManager:
         with self._lock:
             slot = self._slot(ModelType.YOLO_PANEL)
             if self.is_loaded(slot):
-                return self.models[slot]
+                return self._maybe_batched(slot, self.models[slot])
             try:
                 sd, md = self._read_safetensors_with_metadata(self.model_paths[ModelType.YOLO_PANEL], local=slot is not ModelType.YOLO_PANEL)
                 model = self._detector_from_state_dict(sd, {0: "frame"}, md)
@@ -590,7 +609,7 @@ class ModelManager:
                 raise ModelError(f"Failed to load panel detection model: {e}") from e
             self.models[slot] = model
             log_message("Panel detector loaded.", verbose=verbose)
-            return model
+            return self._maybe_batched(slot, model)
 
     def get_manga_ocr(self, verbose: bool = False):
         """manga-ocr recogniser slot (reference :856-904).  The OCR side is outside the MI355X hot path: whatever recogniser object a

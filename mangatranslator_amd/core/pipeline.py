@@ -499,8 +499,11 @@ def batch_vision_images(input_dir, config, output_dir=None, preserve_structure: 
         return process_page_vision_back(state)[0]
 
     n = default_front_workers(config) if front_workers is None else max(1, int(front_workers))
+    # front halves that run side by side share the panel / outside-text detectors' graph replays (core/ml/detector_batch.py; same bytes per page)
+    previous_batch, manager.detector_batch = manager.detector_batch, (n if n > 1 else 1)
     try:
         return batch_process_images(input_dir, config, output_dir, preserve_structure, io_threads=io_threads, process_front=front, process_back=back,
                                     front_workers=n, preload=lambda: manager.preload_for_config(config, verbose))
     finally:
         manager.sam_precision = previous_precision
+        manager.detector_batch = previous_batch

@@ -172,3 +172,88 @@ def test_batch_with_two_front_halves_in_flight(hip_lib, monkeypatch, tmp_path):
         assert np.array_equal(a, b), i
         changed += int(not np.array_equal(a[..., :3], np.asarray(Image.open(root / f"p{i}.png").convert("RGB"))))
     assert changed >= 1, "cleaning changed at least one page (the calibrated threshold lets detections through)"
+
+
+def test_batch_front_halves_share_detector_batches(hip_lib, monkeypatch, tmp_path):
+    """`batch_vision_images(front_workers=2)` hands the panel detector out behind ONE DetectorBatcher (core/ml/detector_batch.py): the front halves
+    that run side by side share its graph replays, and every page's panels — and the written page — equal the one-front-half run's (no wrapper, one
+    page per replay) exactly (VERDICT r05 #9)"""
+    from oracle import rtdetr_ref, sam2_ref, yolo11_ref, yolo_ref
+    from mangatranslator_amd.core import pipeline
+    from mangatranslator_amd.core.ml import model_manager as mm
+    from mangatranslator_amd.core.ml.detector_batch import DetectorBatcher
+    from mangatranslator_amd.core.ml.rtdetr import RTDetrHip
+    from mangatranslator_amd.core.ml.sam2 import Sam2Hip
+    from mangatranslator_amd.core.ml.yolo import YoloSegHip
+    from mangatranslator_amd.core.ml.yolo11 import Yolo11Hip
+    from mangatranslator_amd.utils.synthetic_pages import make_page
+    dev = torch.device("cuda:0")
+    mgr = mm.get_model_manager()
+    monkeypatch.setattr(mgr, "device", dev)
+    ynet = yolo_ref.make_model("n", 1, seed=3)
+    with torch.no_grad():
+        for l in range(3):
+            ynet.model[22].cv3[l][2].weight.mul_(0.05); ynet.model[22].cv3[l][2].bias.fill_(-1.0)
+            ynet.model[22].cv2[l][2].weight.mul_(0.1)
+    rmodel, rcfg = rtdetr_ref.make_model("tiny_test", seed=5)
+    smodel, scfg = sam2_ref.make_model("tiny_test", seed=2)
+    for r in range(2):
+        yolo = YoloSegHip(ynet.state_dict(), device=dev, lib=hip_lib, names={0: "speech_bubble"})
+        rtdetr = RTDetrHip(rmodel.state_dict(), rcfg, device=dev, lib=hip_lib, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
+        sam = Sam2Hip(smodel.state_dict(), scfg, device=dev, lib=hip_lib)
+        if r == 0:
+            first_yolo = yolo
+        for mt, obj in [(mm.ModelType.YOLO_SPEECH_BUBBLE, yolo), (mm.ModelType.RTDETR_CONJOINED_BUBBLE, rtdetr),
+                        (mm.ModelType.SAM2, (mm._Sam2ProcessorShim(), mm._Sam2ModelShim(sam, torch.bfloat16)))]:
+            monkeypatch.setitem(mgr.models, mt if r == 0 else (mt, r), obj)
+    panel = Yolo11Hip(yolo11_ref.make_model("11", "n", 1, False, seed=7).state_dict(), device=dev, lib=hip_lib, names={0: "frame"})
+    monkeypatch.setitem(mgr.models, mm.ModelType.YOLO_PANEL, panel)
+    monkeypatch.setattr(mgr, "_batchers", {})
+    W, H = 512, 768
+    root = tmp_path / "in"
+    root.mkdir()
+    n = 8
+    for i in range(n):
+        pg, _boxes, _regions = make_page(40 + i, W, H, bubbles=8, osb_regions=0)
+        Image.fromarray(pg).save(root / f"p{i}.png")
+        if i == 0:
+            first_yolo(np.ascontiguousarray(pg[..., ::-1]), conf=0.0, imgsz=640, max_det=1)
+            plan0, _ = next(iter(first_yolo._plans.values()))
+            sc = plan0.decoded[:, 4].float().sort(descending=True).values
+            conf = float(sc[min(12, len(sc) - 1)])
+            panel(np.ascontiguousarray(pg[..., ::-1]), conf=0.0, imgsz=640, max_det=1)
+            pplan, _ = next(iter(panel._plans.values()))
+            ps = pplan.decoded[:, 4].float().sort(descending=True).values
+            panel_conf = float(ps[min(6, len(ps) - 1)])
+    cfg = _config(conf, None)
+    cfg.detection.use_panel_sorting, cfg.detection.panel_confidence = True, panel_conf
+    cfg.outside_text.enabled = False
+    cfg.output = types.SimpleNamespace(upscale_final_image=False, image_upscale_factor=1.0, image_upscale_model="model_lite", output_format="png",
+                                       jpeg_quality=95, png_compression=2)
+    cfg.verbose = False
+    seen = {}
+    from pathlib import Path
+    from mangatranslator_amd.core.image import detection as detection_mod
+    real_panels = detection_mod.detect_panels
+
+    def recording_panels(image_path, *a, **k):
+        out = real_panels(image_path, *a, **k)
+        seen.setdefault(mgr.detector_batch, {})[Path(str(image_path)).name] = out
+        return out
+    monkeypatch.setattr(detection_mod, "detect_panels", recording_panels)      # (the page flow imports it at call time)
+    two = pipeline.batch_vision_images(root, cfg, tmp_path / "two", front_workers=2)
+    wrapper = mgr._batchers.get(mm.ModelType.YOLO_PANEL)
+    assert two["success_count"] == n and isinstance(wrapper, DetectorBatcher) and wrapper.model is panel
+    assert wrapper.stats["pages"] == n and 1 <= wrapper.stats["launches"] <= n
+    assert mgr.detector_batch == 1, "the batch run restores the manager's setting"
+    one = pipeline.batch_vision_images(root, cfg, tmp_path / "one", front_workers=1)
+    assert one["success_count"] == n and wrapper.stats["pages"] == n, "one front half: the detector is called directly"
+    assert set(seen) == {1, 2} and len(seen[1]) == n and len(seen[2]) == n
+    assert sum(len(v or []) for v in seen[1].values()) > 0, "no page produced a panel: the comparison is empty"
+    for name in seen[1]:
+        assert seen[1][name] == seen[2][name], f"{name}: panels differ between the batched and the one-page call"
+    for i in range(n):
+        a = np.asarray(Image.open(tmp_path / "two" / f"p{i}_translated.png").convert("RGBA"))
+        b = np.asarray(Image.open(tmp_path / "one" / f"p{i}_translated.png").convert("RGBA"))
+        assert np.array_equal(a, b), i
+    print(f"panel detector: {wrapper.stats['pages']} pages in {wrapper.stats['launches']} graph replays")
