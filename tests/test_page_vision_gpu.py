@@ -132,7 +132,7 @@ def test_batch_with_two_front_halves_in_flight(hip_lib, monkeypatch, tmp_path):
     for r in range(2):
         yolo = YoloSegHip(ynet.state_dict(), device=dev, lib=hip_lib, names={0: "speech_bubble"})
         rtdetr = RTDetrHip(rmodel.state_dict(), rcfg, device=dev, lib=hip_lib, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
-        sam = Sam2Hip(smodel.state_dict(), scfg, device=dev, lib=hip_lib)
+        sam = Sam2Hip(smodel.state_dict(), scfg, device=dev, lib=hip_lib, precision="high")      # what the batch run asks the manager for (a "fast" instance would be unloaded and re-read from disk)
         sets.append((yolo, rtdetr, sam))
         for mt, obj in [(mm.ModelType.YOLO_SPEECH_BUBBLE, yolo), (mm.ModelType.RTDETR_CONJOINED_BUBBLE, rtdetr),
                         (mm.ModelType.SAM2, (mm._Sam2ProcessorShim(), mm._Sam2ModelShim(sam, torch.bfloat16)))]:
@@ -163,6 +163,7 @@ def test_batch_with_two_front_halves_in_flight(hip_lib, monkeypatch, tmp_path):
     monkeypatch.setattr(pipeline, "process_page_vision_front", counting_front)
     two = pipeline.batch_vision_images(root, cfg, tmp_path / "two", front_workers=2)
     assert two["success_count"] == n and two["io"]["pages_in_flight"] == 3 and used[0] > 0 and used[1] > 0
+    assert mgr.models[mm.ModelType.SAM2][1].hip is sets[0][2], "the batch kept the staged SAM instance (no reload, no fallback to the detector's masks)"
     one = pipeline.batch_vision_images(root, cfg, tmp_path / "one", front_workers=1)
     assert one["success_count"] == n
     changed = 0
@@ -200,7 +201,7 @@ def test_batch_front_halves_share_detector_batches(hip_lib, monkeypatch, tmp_pat
     for r in range(2):
         yolo = YoloSegHip(ynet.state_dict(), device=dev, lib=hip_lib, names={0: "speech_bubble"})
         rtdetr = RTDetrHip(rmodel.state_dict(), rcfg, device=dev, lib=hip_lib, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
-        sam = Sam2Hip(smodel.state_dict(), scfg, device=dev, lib=hip_lib)
+        sam = Sam2Hip(smodel.state_dict(), scfg, device=dev, lib=hip_lib, precision="high")      # what the batch run asks the manager for (a "fast" instance would be unloaded and re-read from disk)
         if r == 0:
             first_yolo = yolo
         for mt, obj in [(mm.ModelType.YOLO_SPEECH_BUBBLE, yolo), (mm.ModelType.RTDETR_CONJOINED_BUBBLE, rtdetr),
