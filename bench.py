@@ -278,9 +278,10 @@ def main():
     # front halves in flight (page i uses model set i % N): decided here because the batching wrapper of the 640-px detectors is sized by it
     n_front = args.front_replicas
     if n_front is None:
-        # (without SAM in the front half — config 1 — four pages' detect stages; with it two: a third SAM encoder beside two costs more than it hides, r06_visit_p)
+        # (measured with the front halves sharing detector batches, profiles/r06_visit_r_...log: config 2 — SAM in the front half — 34.8 pages/s with 2 front
+        # halves and no batches (round 5's arrangement), 35.7 with 2 + batches of 2, 41.3-42.4 with 3 + 3, 40.1-40.3 with 4 + 4; config 1: 68.6 -> 77.6-78.4 with 4 + 4)
         light_back = "detect" in stages and "inpaint" not in stages and "upscale" not in stages and not args.no_overlap and not args.serial_detectors
-        n_front = (2 if "segment" in stages else 4) if light_back else 1
+        n_front = (3 if "segment" in stages else 4) if light_back else 1
     n_front = max(1, n_front)
     if args.detector_batch <= 0:
         args.detector_batch = n_front

@@ -324,10 +324,36 @@ def _detect_speech_bubbles(image_path, model_path, confidence, verbose, device, 
         return assemble(None), text_free_boxes
 
 
-def detect_panels(image_path, confidence: float = 0.25, device=None, verbose: bool = False, image_override: Optional[Image.Image] = None):
+def submit_panels(image_pil: Image.Image, confidence: float = 0.25):
+    """First half of `detect_panels` for a page flow that knows early that it will want panels: the panel network is queued on its own stream
+    NOW and runs beside the page's other detectors; `detect_panels(..., ticket=...)` later only collects.  With front halves running side by
+    side (`batch_vision_images(front_workers=N)`) this is also the window in which their panel calls meet in one graph replay
+    (core/ml/detector_batch.py).  Returns None — and `detect_panels` then does everything itself, as the reference does — when the loaded
+    model has no submit half or anything at all goes wrong here."""
+    try:
+        model = get_model_manager().load_yolo_panel()
+        if not hasattr(model, "submit"):
+            return None
+        if image_pil.mode != "RGB":
+            image_pil = image_pil.convert("RGB")
+        bgr = np.ascontiguousarray(np.asarray(image_pil)[..., ::-1])
+        return (model, model.submit(bgr, conf=confidence, imgsz=640))
+    except Exception:      # noqa: BLE001 — the collect side reports failures the way the reference does
+        return None
+
+
+def detect_panels(image_path, confidence: float = 0.25, device=None, verbose: bool = False, image_override: Optional[Image.Image] = None, ticket=None):
     """Panel rectangles `(x1, y1, x2, y2)` (ints via round()) of the detections whose class is "frame" — every detection when the
     model names no such class (reference `detect_panels`, :1817-1915).  Image and loader failures raise ImageProcessingError / ModelError;
-    a failure while running the model degrades to `[]`, as there."""
+    a failure while running the model degrades to `[]`, as there.  `ticket` = what `submit_panels` returned for this page (same confidence)."""
+    if ticket is not None:
+        model, tk = ticket
+        try:
+            res = model.collect(tk)[0]
+            return _panels_of(model, res, verbose)
+        except Exception as e:
+            log_message(f"Panel detection failed: {e}. Proceeding without panel information.", always_print=True)
+            return []
     try:
         image_pil = image_override if image_override is not None else _open_like_imread(image_path)
         if image_pil.mode != "RGB":
@@ -343,17 +369,21 @@ def detect_panels(image_path, confidence: float = 0.25, device=None, verbose: bo
         raise ModelError(f"Error loading panel model: {e}") from e
     try:
         res = model(bgr, conf=confidence, device=device, verbose=False, imgsz=640)[0]
-        boxes = res.boxes.xyxy if res.boxes is not None else torch.zeros((0, 4))
-        classes = res.boxes.cls if res.boxes is not None else torch.zeros((0,))
-        if len(boxes) == 0:
-            log_message("No panels detected", verbose=verbose)
-            return []
-        frame_id = next((cid for cid, name in getattr(model, "names", {}).items() if name.lower() == "frame"), None)
-        panels = []
-        for box, cid in zip(boxes.tolist(), classes.tolist()):
-            if frame_id is None or int(cid) == frame_id:
-                panels.append(tuple(int(round(v)) for v in box))
-        return panels
+        return _panels_of(model, res, verbose)
     except Exception as e:
         log_message(f"Panel detection failed: {e}. Proceeding without panel information.", always_print=True)
         return []
+
+
+def _panels_of(model, res, verbose):
+    boxes = res.boxes.xyxy if res.boxes is not None else torch.zeros((0, 4))
+    classes = res.boxes.cls if res.boxes is not None else torch.zeros((0,))
+    if len(boxes) == 0:
+        log_message("No panels detected", verbose=verbose)
+        return []
+    frame_id = next((cid for cid, name in getattr(model, "names", {}).items() if name.lower() == "frame"), None)
+    panels = []
+    for box, cid in zip(boxes.tolist(), classes.tolist()):
+        if frame_id is None or int(cid) == frame_id:
+            panels.append(tuple(int(round(v)) for v in box))
+    return panels

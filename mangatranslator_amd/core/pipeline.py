@@ -383,6 +383,12 @@ def process_page_vision_front(page, config, image_path="page.png", image_format:
     info["processing_scale"] = scale
     get_cache().set_current_image(page, verbose)       # :774 — a new page drops what the stage memo holds for the previous one
     det = config.detection
+    # the panel network does not depend on the bubbles: queued now, it runs beside the page's other detectors and is collected where the
+    # reference calls `detect_panels` (and meets the other front halves' panel calls in one graph replay: core/ml/detector_batch.py)
+    panel_ticket = None
+    if getattr(det, "use_panel_sorting", False):
+        from .image.detection import submit_panels
+        panel_ticket = submit_panels(page, det.panel_confidence)
     try:
         bubbles, text_free = detect_speech_bubbles(image_path, getattr(config, "yolo_model_path", None), det.confidence, verbose=verbose,
                                                    device=config.device, seg_model=det.seg_model, conjoined_detection=det.conjoined_detection,
@@ -398,7 +404,8 @@ def process_page_vision_front(page, config, image_path="page.png", image_format:
     panels = None
     if getattr(det, "use_panel_sorting", False):                  # :804-831 — the OSB stage keeps its render boxes inside the panel
         try:
-            panels = detect_panels(image_path, confidence=det.panel_confidence, device=config.device, verbose=verbose, image_override=page)
+            panels = detect_panels(image_path, confidence=det.panel_confidence, device=config.device, verbose=verbose, image_override=page,
+                                   **({"ticket": panel_ticket} if panel_ticket is not None else {}))       # (the reference's signature when nothing was queued early)
             log_message(f"Detected {len(panels)} panels" if panels else "No panels detected", always_print=bool(panels), verbose=verbose)
         except Exception as e:      # noqa: BLE001
             log_message(f"Panel detection failed: {e}. Using global sorting.", always_print=True)

@@ -225,7 +225,7 @@ def test_batch_front_halves_share_detector_batches(hip_lib, monkeypatch, tmp_pat
             panel(np.ascontiguousarray(pg[..., ::-1]), conf=0.0, imgsz=640, max_det=1)
             pplan, _ = next(iter(panel._plans.values()))
             ps = pplan.decoded[:, 4].float().sort(descending=True).values
-            panel_conf = float(ps[min(6, len(ps) - 1)])
+            panel_conf = float(ps[len(ps) // 3])          # a third of the anchors pass on this page (the page flow may rescale pages: a threshold at the very top would pass nothing)
     cfg = _config(conf, None)
     cfg.detection.use_panel_sorting, cfg.detection.panel_confidence = True, panel_conf
     cfg.outside_text.enabled = False
