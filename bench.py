@@ -123,6 +123,7 @@ def parse():
     ap.add_argument("--detector-batch", type=int, default=0,
                     help="pages per graph replay of the panel / outside-text detectors (imgsz 640): > 1 shares ONE batching wrapper per detector between the "
                          "front halves that run side by side; 1 = a detector instance per front half; 0 (default) = as many as there are front halves")
+    ap.add_argument("--no-rtdetr-batch", action="store_true", help="for A/Bs: keep an RT-DETR instance per front half while the 640-px YOLO detectors share batches")
     ap.add_argument("--front-replicas", type=int, default=None,
                     help="instances of the detect-stage models (detectors + SAM) per rank; with N > 1 the front halves of N pages run at once, "
                          "each on its own instance (a model's plan has one set of buffers).  Default: 2 for the stage sets without diffusion / "
@@ -346,6 +347,12 @@ def main():
             rsd = broadcast_state_dict(rsd, rank, world, device)
         make_rtdetr = lambda: RTDetrHip(rsd, rcfg, device=device, lib=lib, graph=graph, names={0: "bubble", 1: "text_bubble", 2: "text_free"})
         rtdetr = make_rtdetr()
+        if args.detector_batch > 1 and not args.serial_detectors and not args.no_rtdetr_batch:
+            # the secondary detector too: ONE instance behind a batching wrapper shared by the front halves (backbone + encoder once per batch, the
+            # decoder image by image: core/ml/detector_batch.py RTDetrBatcher)
+            from mangatranslator_amd.core.ml.detector_batch import RTDetrBatcher
+            rtdetr = RTDetrBatcher(rtdetr, args.detector_batch)
+            make_rtdetr = (lambda w_=rtdetr: w_)
     sam = None
     if "segment" in want:
         from mangatranslator_amd.core.ml.sam2 import Sam2Hip
@@ -737,7 +744,8 @@ def main():
                    "detector_calls": ("one after the other" if args.serial_detectors else "submitted together, one HIP stream per model, collected afterwards") if yolo is not None else None,
                    "front_replicas": n_front,
                    "detector_batch": ({"pages_per_replay_max": args.detector_batch,
-                                       **{n_: {"pages": d_.stats["pages"], "graph_replays": d_.stats["launches"]} for n_, d_, _c in (aux_detectors or []) if hasattr(d_, "stats")}}
+                                       **{n_: {"pages": d_.stats["pages"], "graph_replays": d_.stats["launches"]} for n_, d_, _c in (aux_detectors or []) if hasattr(d_, "stats")},
+                                       **({"rtdetr": {"pages": rtdetr.stats["pages"], "graph_replays": rtdetr.stats["launches"]}} if hasattr(rtdetr, "stats") else {})}
                                       if args.detector_batch > 1 and aux_detectors else None),
                    "stage_wall_ms_one_page": {k_: round(v_, 2) for k_, v_ in stage_wall.items()},
                    "page_pipeline": ("two pages in flight: detectors (+ SAM encoder) of page i+1 on a worker thread beside the SAM mask decoder of page i" if seg_in_b else
@@ -772,8 +780,12 @@ def main():
             # (a batching wrapper: one replay of its batched graph, divided by the pages it carries when full — what a page costs in a full batch)
             cfg["detect_aux_ms"] = {name_: (det_._sets[(H_, W_, 640)][0].plan.time(5) / det_.batch if hasattr(det_, "_sets") else det_._plans[(H_, W_, 640)][0].time(5))
                                     for name_, det_, _ in aux_detectors}
-            ra, rb = rtdetr.plans(640, 640)
-            cfg["detect_rtdetr_ms"] = {"backbone_encoder": ra.time(5), "decoder": rb.time(5)}
+            if hasattr(rtdetr, "_sets"):          # batching wrapper: the batched encoder replay divided by its pages, the decoder per page as it runs
+                set0 = rtdetr._sets[(640, 640, "rtdetr")][0]
+                cfg["detect_rtdetr_ms"] = {"backbone_encoder": set0.enc.time(5) / rtdetr.batch, "decoder": set0.dec.time(5)}
+            else:
+                ra, rb = rtdetr.plans(640, 640)
+                cfg["detect_rtdetr_ms"] = {"backbone_encoder": ra.time(5), "decoder": rb.time(5)}
         # wall clock of a stage (one page, synchronised) against the GPU time of its graphs: what is left is host work (NMS, prompt set-up,
         # downloads) — the share the page pipeline hides behind the next page's GPU work
         split = {}

@@ -95,7 +95,7 @@ class DetectorBatcher:
     LINGER_S = 0.0015
 
     def __init__(self, model, batch: int = 4, peers: int = 1):
-        if model.a["nm"]:
+        if getattr(model, "a", None) is not None and model.a["nm"]:
             raise ValueError("DetectorBatcher: detect-only heads (the segmentation head's masks are per page)")
         self.model, self.batch, self.peers = model, max(1, int(batch)), max(1, int(peers))
         self.names = model.names
@@ -159,7 +159,7 @@ class DetectorBatcher:
         if b is not None and not b.launched and b.filled < b.size:
             return b
         if key not in self._sets:
-            self._sets[key] = [_Batch(self.model, key, lp, self.batch), _Batch(self.model, key, lp, self.batch)]
+            self._sets[key] = [self._new_set(key, lp), self._new_set(key, lp)]
         sets = self._sets[key]
         ok = self._cv.wait_for(lambda: any(s.filled == 0 for s in sets), timeout=self.WAIT_S)
         if not ok:
@@ -168,12 +168,18 @@ class DetectorBatcher:
         self._filling[key] = b
         return b
 
+    def _new_set(self, key, lp):
+        return _Batch(self.model, key, lp, self.batch)
+
     def _launch(self, b, key):
-        b.plan.run(graph=self.model._graph)
+        self._run(b)
         b.launched = True
         self.stats["launches"] += 1
         if self._filling.get(key) is b:
             del self._filling[key]
+
+    def _run(self, b):
+        b.plan.run(graph=self.model._graph)
 
     def _slot_done(self, b):
         with self._cv:
@@ -182,3 +188,113 @@ class DetectorBatcher:
                 b.filled = b.collected = 0
                 b.launched = False
                 self._cv.notify_all()
+
+
+class _RTDetrBatch:
+    """one buffer set of the RT-DETR batcher: the batched backbone + encoder plan, ONE decoder plan that the images of a batch go through one after
+    the other on the wrapper's stream, and the per-slot results of the last launch"""
+
+    def __init__(self, model, size, hw):
+        H, W = hw
+        self.enc = model._build(H, W, batch=size)
+        self.dec = model._build_decoder(self.enc.shapes, self.enc.S)
+        self.size = size
+        self.filled = self.collected = 0
+        self.launched = False
+        self.meta = [None] * size          # per slot: (original height, width, confidence)
+        self.out = [None] * size           # per slot after the launch: the ticket fields of RTDetrHip.submit
+        with model._lane.enter():          # capture both graphs now (see _Batch)
+            self.enc.run(graph=model._graph)
+            self.dec.run(graph=model._graph)
+        if model._lane.on:
+            model._lane.stream.synchronize()
+
+    def close(self):
+        for p in (self.enc, self.dec):
+            if hasattr(p, "close"):
+                p.close()
+
+
+class RTDetrBatcher(DetectorBatcher):
+    """The same sharing for the RT-DETR-v2 secondary detector (`core/ml/rtdetr.py`): the backbone + hybrid encoder — two thirds of its GPU time, all
+    small convolutions — runs once for the pages of a batch (`RTDetrHip._build(H, W, batch=B)`); query selection and the six decoder layers then
+    follow image by image on the same stream with the model's own arithmetic (`_enqueue`'s second half), so each page's boxes are the one-page call's."""
+
+    def __init__(self, model, batch: int = 4, peers: int = 1):
+        super().__init__(model, batch, peers)
+
+    @torch.no_grad()
+    def submit(self, source, conf: float = 0.35, imgsz=None, **_kw):
+        from PIL import Image
+        m = self.model
+        if isinstance(source, Image.Image):
+            pil = source.convert("RGB") if source.mode != "RGB" else source
+        elif isinstance(source, np.ndarray):
+            arr = source
+            if arr.ndim == 2:
+                arr = np.stack([arr] * 3, -1)
+            pil = Image.fromarray(np.ascontiguousarray(arr[..., :3][..., ::-1]))      # cv2 BGR -> RGB, as the adapter does
+        else:
+            pil = Image.open(source).convert("RGB")
+        ow, oh = pil.size
+        size = int(imgsz) if imgsz is not None else 640
+        img = np.asarray(pil.resize((size, size), resample=Image.Resampling.BILINEAR))        # RTDetrImageProcessor: resize + 1/255 (host side, like the model's own submit)
+        key = (size, size, "rtdetr")
+        with self._cv:
+            b = self._take_slot(key, None)
+            slot = b.filled
+            b.filled += 1
+            b.meta[slot] = (oh, ow, float(conf))
+            with self._lane.enter():
+                b.enc.src[slot].copy_(torch.from_numpy(np.array(img, dtype=np.uint8)).to(m.device, non_blocking=True))
+                if b.filled == b.size:
+                    self._launch(b, key)
+            self.stats["pages"] += 1
+            self._cv.notify_all()
+        return BatchTicket(self, b, slot, key=key)
+
+    @torch.no_grad()
+    def collect(self, ticket):
+        from .rtdetr import _Boxes
+        b = ticket.batch
+        try:
+            with self._cv:
+                if not b.launched:
+                    with self._lane.enter():
+                        self._launch(b, ticket["key"])
+            with self._lane.resume():
+                t = b.out[ticket.slot]
+                keep = t["keep"]
+                res = [SimpleNamespace(boxes=_Boxes(t["xyxy"][keep].float(), t["top_s"][keep].float(), t["labels"][keep].float()), names=self.model.names,
+                                       orig_shape=t["hw"], masks=None)]
+            self._lane.hand_over(*result_tensors(res))
+            return res
+        finally:
+            ticket.close()
+
+    def _new_set(self, key, lp):
+        return _RTDetrBatch(self.model, self.batch, key[:2])
+
+    def _run(self, b):
+        """on the wrapper's stream: the batched encoder graph, then per filled slot what `RTDetrHip._enqueue` / `submit` queue for one image"""
+        m, a, d = self.model, b.enc, b.dec
+        cfg = m.cfg
+        nc, Q, S = cfg.num_labels, cfg.num_queries, a.S
+        a.run(graph=m._graph)
+        for slot in range(b.filled):
+            rows = slice(slot * S, (slot + 1) * S)
+            top = a.scores[rows, :nc].max(-1).values.topk(Q, dim=0).indices
+            d.mem.copy_(a.mem[rows])
+            d.h0.copy_(a.om[rows].index_select(0, top))
+            d.ref_logit.copy_((a.boxes[rows] + a.anchors).index_select(0, top))
+            d.run(graph=m._graph)
+            logits, boxes = d.logits[:, :nc].clone(), d.boxes[:, :4].clone()
+            oh, ow, conf = b.meta[slot]
+            scores = logits.sigmoid()
+            k = min(Q, scores.numel())
+            top_s, idx = scores.flatten().topk(k)
+            labels, qi = idx % nc, idx // nc
+            cx, cy, w, h = boxes[qi].unbind(-1)
+            scale = torch.tensor([ow, oh, ow, oh], dtype=boxes.dtype).to(boxes.device, non_blocking=True)
+            xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1) * scale
+            b.out[slot] = dict(xyxy=xyxy, top_s=top_s, labels=labels, keep=top_s > conf, hw=(oh, ow), logits=logits, boxes=boxes)

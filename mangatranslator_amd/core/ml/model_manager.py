@@ -299,7 +299,7 @@ class ModelManager:
         return getattr(self._tls, "replica", 0)
 
     # the 640-pixel detect-only networks that can carry several pages per graph replay (core/ml/detector_batch.py)
-    BATCHED_DETECTOR_TYPES = frozenset({ModelType.YOLO_OSBTEXT, ModelType.YOLO_PANEL})
+    BATCHED_DETECTOR_TYPES = frozenset({ModelType.YOLO_OSBTEXT, ModelType.YOLO_PANEL, ModelType.RTDETR_CONJOINED_BUBBLE})
 
     def _slot(self, model_type: ModelType):
         """key of `self.models` this thread's loader call uses"""
@@ -312,12 +312,18 @@ class ModelManager:
         """`detector_batch` > 1 (set by `batch_vision_images(front_workers=N)`): the panel / outside-text detector is handed out behind ONE
         DetectorBatcher per slot — the pages whose front halves run side by side share a graph replay, each page's results are the one-page
         call's bytes.  Models that are not this package's detect-only YOLO11 / YOLO12 graphs (a test double, a segmentation head) pass through."""
-        if self.detector_batch <= 1 or not hasattr(model, "_build") or getattr(model, "a", {}).get("nm", 1):
+        if self.detector_batch <= 1 or not hasattr(model, "_build"):
             return model
-        from .detector_batch import DetectorBatcher
+        from .detector_batch import DetectorBatcher, RTDetrBatcher
+        if hasattr(model, "_build_decoder"):            # RT-DETR: backbone + encoder per batch, decoder per image
+            cls = RTDetrBatcher
+        elif getattr(model, "a", {}).get("nm", 1) == 0:  # detect-only YOLO11 / YOLO12 head
+            cls = DetectorBatcher
+        else:
+            return model
         w = self._batchers.get(slot)
         if w is None or w.model is not model or w.batch != self.detector_batch:
-            w = self._batchers[slot] = DetectorBatcher(model, self.detector_batch, peers=self.detector_batch)
+            w = self._batchers[slot] = cls(model, self.detector_batch, peers=self.detector_batch)
         return w
 
     # ---- bookkeeping -------------------------------------------------------------------------------
@@ -634,7 +640,7 @@ class ModelManager:
         with self._lock:
             slot = self._slot(mt)
             if self.is_loaded(slot):
-                return self.models[slot]
+                return self._maybe_batched(slot, self.models[slot])
             from .rtdetr import RTDetrHip
             root = self.model_paths[mt]
             if slot is mt:
@@ -650,7 +656,7 @@ class ModelManager:
                 raise ModelError(f"Failed to load RT-DETR conjoined model: {e}") from e
             self.models[slot] = model
             log_message("RT-DETR conjoined bubble model loaded.", verbose=verbose)
-            return model
+            return self._maybe_batched(slot, model)
 
     def load_sam2(self, verbose: bool = False):
         """-> (processor, model) like the reference (:982-1010), backed by the HIP graph."""

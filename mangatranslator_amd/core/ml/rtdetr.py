@@ -185,8 +185,9 @@ class RTDetrHip:
         w, b, n, kk = self.W[name]
         return pb.gemm(a, w, m, n, k or kk, bias=b, act=act, res=res, out=out, label=name)
 
-    def _mha(self, pb, x, pos, tag, rows, heads, D):
-        """post-norm transformer self-attention block: LN(x + O(attn((x+pos)Wq, (x+pos)Wk, xWv)))"""
+    def _mha(self, pb, x, pos, tag, rows, heads, D, images=1):
+        """post-norm transformer self-attention block: LN(x + O(attn((x+pos)Wq, (x+pos)Wk, xWv))).  images > 1 (the batched encoder plan): x and
+        pos hold `images` sequences of rows / images positions back to back; every sequence attends to itself only (the launch's batch dimension)"""
         a2 = lambda t: Act(t.view(1, 1, rows, D), 1, 1, rows, D)
         qk_in = pb.ew(abi.EW_ADD, a2(x), b=a2(pos), label=tag + ".addpos")
         wqk, bqk = self.W[tag + ".qk"]
@@ -194,7 +195,8 @@ class RTDetrHip:
         v = self._lin(pb, x, tag + ".v", rows)
         o = pb.buf((rows, D), self.tdt)
         hd = D // heads
-        pb.attention(qk, qk, v, o, 1, heads, rows, rows, hd, (0, 2 * D, hd), (0, 2 * D, hd), (0, D, hd), (0, D, hd), hd ** -0.5,
+        per = rows // images
+        pb.attention(qk, qk, v, o, images, heads, per, per, hd, (per * 2 * D, 2 * D, hd), (per * 2 * D, 2 * D, hd), (per * D, D, hd), (per * D, D, hd), hd ** -0.5,
                      k_off=D, label=tag + ".attn")
         y = self._lin(pb, o, tag + ".o", rows, res=x)
         g, b = self.W[tag + ".ln1"]
@@ -207,13 +209,17 @@ class RTDetrHip:
         h = self._conv(pb, h, tag + ".rep1")
         return self._conv(pb, h, tag + ".rep2", res=c2)          # act(conv) + conv2(x): the CSP sum
 
-    def _build(self, H, W):
+    def _build(self, H, W, batch=1):
+        """backbone + hybrid encoder + the encoder's proposal head.  batch = B > 1 (core/ml/detector_batch.py RTDetrBatcher): B resized images through one
+        graph — every activation carries the image index outermost, AIFI attends per image, the decoder memory / proposal scores / boxes come out as
+        B blocks of S rows (image b: rows b * S .. ) — with the same arithmetic per image as the one-image plan"""
         cfg = self.cfg
         D, heads = cfg.d_model, cfg.encoder_attention_heads
+        B = int(batch)
         pb = PlanBuilder(self.lib, self.device, self.dtype)
-        src = pb.buf((1, H, W, 3), torch.uint8)
-        x = pb.act(1, H, W, 8)
-        pb.image_convert(abi.IMG_HWC_U8_TO_NHWC, src, x.t, 1, H, W, 8, mul=1.0, label="rescale")
+        src = pb.buf((B, H, W, 3), torch.uint8)
+        x = pb.act(B, H, W, 8)
+        pb.image_convert(abi.IMG_HWC_U8_TO_NHWC, src, x.t, B, H, W, 8, mul=1.0, label="rescale")
         x = self._conv(pb, x, "stem0", stride=2)
         x = self._conv(pb, x, "stem1")
         x = self._conv(pb, x, "stem2")
@@ -234,23 +240,23 @@ class RTDetrHip:
                 feats.append(x)
         shapes = [(f.h, f.w) for f in feats]
         # concat buffers of the top-down pass: [upsampled top | backbone projection]
-        cat_fpn = [pb.act(1, h, w, 2 * D) for (h, w) in shapes[:2]]
+        cat_fpn = [pb.act(B, h, w, 2 * D) for (h, w) in shapes[:2]]
         self._conv(pb, feats[0], "enc_proj0", out=cat_fpn[0].slice(D, D))
         self._conv(pb, feats[1], "enc_proj1", out=cat_fpn[1].slice(D, D))
         top = self._conv(pb, feats[2], "enc_proj2")
         # AIFI on the stride-32 map
         h5, w5 = shapes[2]
-        rows = h5 * w5
-        pos = pb.const(sincos_2d(h5, w5, D, cfg.positional_encoding_temperature), self.tdt)
+        rows = B * h5 * w5
+        pos = pb.const(sincos_2d(h5, w5, D, cfg.positional_encoding_temperature).repeat(B, 1), self.tdt)
         t = top.t.view(rows, D)
-        y = self._mha(pb, t, pos, "aifi", rows, heads, D)
+        y = self._mha(pb, t, pos, "aifi", rows, heads, D, images=B)
         f1 = self._lin(pb, y, "aifi.fc1", rows, act={"gelu": abi.ACT_GELU, "relu": abi.ACT_RELU, "silu": abi.ACT_SILU}[cfg.encoder_activation_function])
         f2 = self._lin(pb, f1, "aifi.fc2", rows, res=y)
         g, b = self.W["aifi.ln2"]
         top_t = pb.norm(f2, pb.buf((rows, D), self.tdt), rows, D, gamma=g, beta=b, eps=cfg.layer_norm_eps, label="aifi.ln2")
-        top = Act(top_t.view(1, h5, w5, D), 1, h5, w5, D)
+        top = Act(top_t.view(B, h5, w5, D), B, h5, w5, D)
         # CCFM top-down
-        cat_pan = [pb.act(1, h, w, 2 * D) for (h, w) in shapes[1:]]        # [downsampled | lateral output]
+        cat_pan = [pb.act(B, h, w, 2 * D) for (h, w) in shapes[1:]]        # [downsampled | lateral output]
         lat0 = self._conv(pb, top, "lateral0", out=cat_pan[1].slice(D, D))
         pb.ew(abi.EW_UPSAMPLE2X, lat0, out=cat_fpn[1].slice(0, D), label="fpn0.up")
         p4 = self._csp(pb, cat_fpn[1], "fpn0")
@@ -264,27 +270,34 @@ class RTDetrHip:
         n5 = self._csp(pb, cat_pan[1], "pan1")
         # decoder memory: the three projected maps back to back as token rows
         S = sum(h * w for h, w in shapes)
-        mem = pb.buf((S, D), self.tdt)
+        R = B * S                                   # rows of the proposal head: image b's S tokens at rows b * S ..
+        mem = pb.buf((R, D), self.tdt)
         start = 0
         for i, (f, (h, w)) in enumerate(zip((p3, n4, n5), shapes)):
-            self._conv(pb, f, f"dec_proj{i}", out=Act(mem[start:start + h * w].view(1, h, w, D), 1, h, w, D))
+            if B == 1:
+                self._conv(pb, f, f"dec_proj{i}", out=Act(mem[start:start + h * w].view(1, h, w, D), 1, h, w, D))
+            else:           # the convolution writes [B, h, w, D] densely; an image's level then moves to its place among that image's S rows
+                lvl = self._conv(pb, f, f"dec_proj{i}")
+                for b_ in range(B):
+                    pb.ew(abi.EW_COPY, Act(lvl.t[b_:b_ + 1], 1, h, w, D), out=Act(mem[b_ * S + start:b_ * S + start + h * w].view(1, h, w, D), 1, h, w, D),
+                          label=f"dec_proj{i}.place{b_}")
             start += h * w
         anchors, valid = make_anchors(shapes)
-        mask = pb.const(valid.float().expand(S, D).contiguous(), self.tdt)
-        a2 = lambda t_, c: Act(t_.view(1, 1, S, c), 1, 1, S, c)
+        mask = pb.const(valid.float().expand(S, D).repeat(B, 1).contiguous(), self.tdt)
+        a2 = lambda t_, c: Act(t_.view(1, 1, R, c), 1, 1, R, c)
         masked = pb.ew(abi.EW_MUL, a2(mem, D), b=a2(mask, D), label="valid_mask")
-        eo = self._lin(pb, masked.t.view(S, D), "enc_out", S)
+        eo = self._lin(pb, masked.t.view(R, D), "enc_out", R)
         g, b = self.W["enc_out_ln"]
-        om = pb.norm(eo, pb.buf((S, D), self.tdt), S, D, gamma=g, beta=b, eps=cfg.layer_norm_eps, label="enc_out_ln")
+        om = pb.norm(eo, pb.buf((R, D), self.tdt), R, D, gamma=g, beta=b, eps=cfg.layer_norm_eps, label="enc_out_ln")
         w, bias, ncp, _ = self.W["enc_score"]
-        scores = pb.gemm(om, w, S, ncp, D, bias=bias, out_f32=True, label="enc_score")
-        bx = self._lin(pb, om, "enc_bbox0", S, act=abi.ACT_RELU)
-        bx = self._lin(pb, bx, "enc_bbox1", S, act=abi.ACT_RELU)
+        scores = pb.gemm(om, w, R, ncp, D, bias=bias, out_f32=True, label="enc_score")
+        bx = self._lin(pb, om, "enc_bbox0", R, act=abi.ACT_RELU)
+        bx = self._lin(pb, bx, "enc_bbox1", R, act=abi.ACT_RELU)
         w, bias, _, _ = self.W["enc_bbox2"]
-        boxes = pb.gemm(bx, w, S, 8, D, bias=bias, out_f32=True, label="enc_bbox2")
+        boxes = pb.gemm(bx, w, R, 8, D, bias=bias, out_f32=True, label="enc_bbox2")
         plan = pb.build()
         plan.src, plan.mem, plan.om, plan.scores, plan.boxes = src, mem, om, scores, boxes
-        plan.shapes, plan.S = shapes, S
+        plan.shapes, plan.S, plan.images = shapes, S, B
         a8 = torch.zeros(S, 8)
         a8[:, :4] = torch.where(valid, anchors, torch.full((), torch.finfo(torch.float32).max))
         plan.anchors = a8.to(self.device)

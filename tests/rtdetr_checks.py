@@ -76,3 +76,32 @@ def check_call_shape(lib, device, size="tiny_test", seed=1):
     assert abs(float(res.boxes.conf[0]) - float(want[1][0])) < 2e-2          # best score agrees
     assert len(model(bgr, conf=1.1, imgsz=96)[0].boxes) == 0
     return n
+
+
+def check_batched(lib, device, size="tiny_test", imgsz=96, pages=3, batch=4, seed=1, threads=False, graph=False):
+    """core/ml/detector_batch.py RTDetrBatcher: pages whose backbone + encoder share ONE graph replay get, page by page, the bytes of the one-page
+    call: decoder logits and boxes, final boxes / scores / classes"""
+    from mangatranslator_amd.core.ml.detector_batch import RTDetrBatcher
+    m, cfg = rr.make_model(size, seed)
+    model = RTDetrHip(m.state_dict(), cfg, device, lib=lib, graph=graph, names={0: "a", 1: "b", 2: "c"})
+    rng = np.random.default_rng(5 + seed)
+    imgs = [(rng.random((100, 140, 3)) * 255).astype(np.uint8) for _ in range(pages)]
+    singles = [model(im, conf=0.2, imgsz=imgsz)[0] for im in imgs]
+    bat = RTDetrBatcher(model, batch=batch)
+    if threads:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=pages) as ex:
+            got = list(ex.map(lambda im: bat(im, conf=0.2, imgsz=imgsz)[0], imgs))
+    else:
+        tickets = [bat.submit(im, conf=0.2, imgsz=imgsz) for im in imgs]
+        got = [bat.collect(t)[0] for t in tickets]
+        assert bat.stats["launches"] == (pages + batch - 1) // batch, bat.stats
+    assert bat.stats["pages"] == pages
+    n = 0
+    for i, (a, b) in enumerate(zip(singles, got)):
+        for f in ("xyxy", "conf", "cls"):
+            assert torch.equal(getattr(a.boxes, f), getattr(b.boxes, f)), f"page {i}: boxes.{f} differ between the batched and the one-page call"
+        assert a.orig_shape == b.orig_shape and b.names == a.names
+        n += len(a.boxes)
+    assert n > 0, "no page produced a box: the comparison is empty"
+    return bat.stats

@@ -246,6 +246,9 @@ def test_batch_front_halves_share_detector_batches(hip_lib, monkeypatch, tmp_pat
     wrapper = mgr._batchers.get(mm.ModelType.YOLO_PANEL)
     assert two["success_count"] == n and isinstance(wrapper, DetectorBatcher) and wrapper.model is panel
     assert wrapper.stats["pages"] == n and 1 <= wrapper.stats["launches"] <= n
+    from mangatranslator_amd.core.ml.detector_batch import RTDetrBatcher
+    rwrap = mgr._batchers.get(mm.ModelType.RTDETR_CONJOINED_BUBBLE)
+    assert isinstance(rwrap, RTDetrBatcher) and rwrap.stats["pages"] == n and 1 <= rwrap.stats["launches"] <= n, "the secondary detector is shared the same way"
     assert mgr.detector_batch == 1, "the batch run restores the manager's setting"
     one = pipeline.batch_vision_images(root, cfg, tmp_path / "one", front_workers=1)
     assert one["success_count"] == n and wrapper.stats["pages"] == n, "one front half: the detector is called directly"
@@ -257,4 +260,4 @@ def test_batch_front_halves_share_detector_batches(hip_lib, monkeypatch, tmp_pat
         a = np.asarray(Image.open(tmp_path / "two" / f"p{i}_translated.png").convert("RGBA"))
         b = np.asarray(Image.open(tmp_path / "one" / f"p{i}_translated.png").convert("RGBA"))
         assert np.array_equal(a, b), i
-    print(f"panel detector: {wrapper.stats['pages']} pages in {wrapper.stats['launches']} graph replays")
+    print(f"panel detector: {wrapper.stats['pages']} pages in {wrapper.stats['launches']} graph replays; RT-DETR: {rwrap.stats['pages']} in {rwrap.stats['launches']}")

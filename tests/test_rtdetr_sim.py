@@ -31,3 +31,11 @@ def test_oracle_pre_post_matches_reference_adapter():
         assert labels.tolist() == [int(c) for c in run["cls"]], tag
         assert torch.allclose(xyxy, torch.tensor(run["xyxy"]).reshape(-1, 4), atol=2e-3), tag
     assert len(g["runs"]["bgr_mid"]["scores"]) == 10 and g["runs"]["bgr_lo"]["xyxy"] == g["runs"]["pil_lo"]["xyxy"]
+
+
+def test_rtdetr_batcher_matches_single_calls(emu_lib):
+    """RT-DETR's backbone + encoder shared by the pages of a batch (core/ml/detector_batch.py RTDetrBatcher): 3 pages in a batch of 4, 4 pages in
+    batches of 2, 5 pages from their own threads — boxes, scores and classes are the one-page call's bytes"""
+    rc.check_batched(emu_lib, "cpu")
+    rc.check_batched(emu_lib, "cpu", pages=4, batch=2, seed=2)
+    rc.check_batched(emu_lib, "cpu", pages=5, batch=2, seed=3, threads=True)
