@@ -78,7 +78,7 @@ def check_call_shape(lib, device, size="tiny_test", seed=1):
     return n
 
 
-def check_batched(lib, device, size="tiny_test", imgsz=96, pages=3, batch=4, seed=1, threads=False, graph=False):
+def check_batched(lib, device, size="tiny_test", imgsz=96, pages=3, batch=4, seed=1, threads=False, graph=False, conf=0.2):
     """core/ml/detector_batch.py RTDetrBatcher: pages whose backbone + encoder share ONE graph replay get, page by page, the bytes of the one-page
     call: decoder logits and boxes, final boxes / scores / classes"""
     from mangatranslator_amd.core.ml.detector_batch import RTDetrBatcher
@@ -86,14 +86,14 @@ def check_batched(lib, device, size="tiny_test", imgsz=96, pages=3, batch=4, see
     model = RTDetrHip(m.state_dict(), cfg, device, lib=lib, graph=graph, names={0: "a", 1: "b", 2: "c"})
     rng = np.random.default_rng(5 + seed)
     imgs = [(rng.random((100, 140, 3)) * 255).astype(np.uint8) for _ in range(pages)]
-    singles = [model(im, conf=0.2, imgsz=imgsz)[0] for im in imgs]
+    singles = [model(im, conf=conf, imgsz=imgsz)[0] for im in imgs]
     bat = RTDetrBatcher(model, batch=batch)
     if threads:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=pages) as ex:
-            got = list(ex.map(lambda im: bat(im, conf=0.2, imgsz=imgsz)[0], imgs))
+            got = list(ex.map(lambda im: bat(im, conf=conf, imgsz=imgsz)[0], imgs))
     else:
-        tickets = [bat.submit(im, conf=0.2, imgsz=imgsz) for im in imgs]
+        tickets = [bat.submit(im, conf=conf, imgsz=imgsz) for im in imgs]
         got = [bat.collect(t)[0] for t in tickets]
         assert bat.stats["launches"] == (pages + batch - 1) // batch, bat.stats
     assert bat.stats["pages"] == pages
