@@ -282,7 +282,9 @@ def main():
         # (measured with the front halves sharing detector batches, profiles/r06_visit_r_...log: config 2 — SAM in the front half — 34.8 pages/s with 2 front
         # halves and no batches (round 5's arrangement), 35.7 with 2 + batches of 2, 41.3-42.4 with 3 + 3, 40.1-40.3 with 4 + 4; config 1: 68.6 -> 77.6-78.4 with 4 + 4)
         light_back = "detect" in stages and "inpaint" not in stages and "upscale" not in stages and not args.no_overlap and not args.serial_detectors
-        n_front = (3 if "segment" in stages else 4) if light_back else 1
+        # (with RT-DETR behind the batching wrapper as well — profiles/r06_visit_u_...log, three alternating rounds — config 2: 38.7-41.8 with 3 front halves,
+        # 47.6-48.2 with 4, 43.3-43.8 with 5; config 1: 67 / 80 / 85 with 2 / 3 / 4)
+        n_front = 4 if light_back else 1
     n_front = max(1, n_front)
     if args.detector_batch <= 0:
         args.detector_batch = n_front
@@ -614,10 +616,11 @@ def main():
         step(k)                      # shapes it will meet (the FLUX crop resolution depends on where the text block sits) exist
     run_steps(args.warmup)
     barrier()
-    t0 = time.perf_counter()
+    t0, cpu0 = time.perf_counter(), time.process_time()
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    host_cpu_ms_per_page = 1e3 * (time.process_time() - cpu0) / max(1, args.steps)      # CPU time of every thread of this process over the timed region
     if flux is not None:          # every page sent its R regions through FLUX (none classified as solid, none dropped)
         want_calls = (setup_pages + args.warmup + args.steps) * args.regions
         assert flux.calls == want_calls, f"expected {want_calls} FLUX calls, saw {flux.calls}"
@@ -743,6 +746,8 @@ def main():
                    "upscaler": ({"arch": "RCAN", **rcan_cfg, "weights": "seeded random"} if upscaler is not None else None),
                    "detector_calls": ("one after the other" if args.serial_detectors else "submitted together, one HIP stream per model, collected afterwards") if yolo is not None else None,
                    "front_replicas": n_front,
+                   "host_cpu_ms_per_page": round(host_cpu_ms_per_page, 2),      # all threads; near ms_per_step = the Python side of the page loop is what the pages wait for
+
                    "detector_batch": ({"pages_per_replay_max": args.detector_batch,
                                        **{n_: {"pages": d_.stats["pages"], "graph_replays": d_.stats["launches"]} for n_, d_, _c in (aux_detectors or []) if hasattr(d_, "stats")},
                                        **({"rtdetr": {"pages": rtdetr.stats["pages"], "graph_replays": rtdetr.stats["launches"]}} if hasattr(rtdetr, "stats") else {})}
