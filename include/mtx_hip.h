@@ -162,6 +162,10 @@ typedef struct mtx_attn_args {
    * writes them (mtx_ew_args.y8).  The base-2 logits are 2^qk_f8_exp * sum_d q_f8 k_f8 on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the
    * 16-bit rate); q and k are then not read.  P V stays 16-bit.  NULL = 16-bit scores. */
   const void* q_f8; const void* k_f8; int64_t qf8_ss, kf8_ss; int32_t qk_f8_exp;
+  /* fp8 P V (ABI 8; only together with q_f8 / k_f8 and the MX fp8 output q8): v_f8t = the values as MTX_EW_V_F8T writes them — e4m3 [head][128][vf8_ld]
+   * — and the probabilities of a tile are rounded to e4m3 as well: O^T += V^T P on the fp8 matrix instruction, one MFMA of K = 64 per 32 x 32
+   * block instead of four of K = 16; `v` is then not read.  NULL = 16-bit P V. */
+  const void* v_f8t; int64_t vf8_ld;
 } mtx_attn_args;
 /* q already carries scale * log2(e) (folded into the producer, e.g. the pre-scaled rotary table of MTX_EW_QK_NORM_ROPE): `scale`
  * is ignored, scores are used as base-2 logits as they come out of the matrix pipe.  The long-sequence kernel then seeds its score
@@ -229,6 +233,10 @@ typedef enum mtx_ew_kind {
   MTX_EW_RESIDUAL_DIST = 20, /* first-block cache probe: r = a - b rounded to the 16-bit type, prev = s (same layout, row stride lds); y = fp32
                                 [2 * MTX_RESDIST_PARTS]: y[2 g] = part g of sum |prev - r|, y[2 g + 1] = part g of sum |prev| (fixed summation order; the
                                 caller adds the parts in index order)                                                                          */
+  MTX_EW_V_F8T = 21,      /* the value operand of the attention with fp8 P V (mtx_attn_args.v_f8t): a = v rows [rows][c = heads * 128] (16-bit, row stride lda)
+                             -> y8 = e4m3 bytes [head][128 d][ldy8 keys], ldy8 = rows padded to a multiple of 64, zero beyond `rows`.  Inside every 64-key
+                             tile the keys of a d-row are stored in the order the score accumulators hold them (byte j of the tile: key
+                             32 (j >> 5) + (j & 3) + 8 ((j & 15) >> 2) + 4 ((j >> 4) & 1)), so that the probabilities need no shuffle.  Saturated at +-448. */
   MTX_EW_QK_NORM_ROPE = 12 /* FLUX attention prep, in place friendly: for every token r and head hd (c = heads*d,
                              i0 = d): x <- RMSNorm_d(x) * gamma[d] (s = fp32 gamma, eps = act_param), then
                              rotary on interleaved pairs with b = fp32 [rows][d] cos|sin table laid out as

@@ -82,7 +82,7 @@ class _W:
 
 
 class Flux2DiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=True, attn_q8=True, attn_qk_f8=True):
+    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=True, attn_q8=True, attn_qk_f8=True, attn_pv_f8=False):
         """provider(name) -> tensor with diffusers' Flux2Transformer2DModel parameter of that name.
         fp8: False, True (= every block linear) or a tuple of names out of FP8_ALL."""
         self.lib = lib if lib is not None else get_library()
@@ -109,6 +109,9 @@ class Flux2DiTHip:
         # Changes the result (3 mantissa bits under the scores): 4 Klein steps at T = 1568 stay at 41.9 dB against the bf16 pipeline (fp8 linears alone: 41.8;
         # tests/test_flux2_gpu.py::test_klein_fp8_attention_scores_psnr), the launch takes 0.603 ms instead of 0.783 at T = 8704 — on with the fp8 linears, never without.
         self.attn_qk_f8 = bool(attn_qk_f8) and bool(self.fp8) and self.hd == 128
+        # attn_pv_f8 (experiment, off by default): P V on the fp8 instruction as well — the values as e4m3 V^T in accumulator key order (MTX_EW_V_F8T, one
+        # small launch per attention), the tile's probabilities rounded to e4m3 in registers (mtx_attn_args.v_f8t).  Needs attn_qk_f8 and attn_q8.
+        self.attn_pv_f8 = bool(attn_pv_f8) and self.attn_qk_f8 and self.attn_q8
         if self.fp8 and (D % 128 or self.hid % 128):
             raise ModelError("FLUX.2 DiT fp8 path: d and the MLP width must be multiples of 128")
         g = lambda n, dt=None: provider(n).detach().to(self.device, dt if dt is not None else self.tdt).contiguous()
@@ -264,10 +267,15 @@ class Flux2DiTHip:
         aq8 = self.attn_q8 and f8 and T >= 1024
         qk8 = pb.buf((T, 2 * D), torch.uint8, zero=True) if (self.attn_qk_f8 and T >= 1024) else None      # [token][q heads | k heads] e4m3
 
+        vt8 = pb.buf((D, (T + 63) // 64 * 64), torch.uint8, zero=True) if (self.attn_pv_f8 and qk8 is not None and aq8) else None      # e4m3 V^T, reused by every block
+
         def attention(src, ld, out_t, out_ld, label, q8=None):
+            pv = None
+            if vt8 is not None and q8 is not None:
+                pv = pb.v_f8t(src, T, H, ld, v_off=2 * D, out=vt8, label=label + ".v_f8t")
             pb.attention(src, src, src, None if q8 is not None else out_t, 1, H, T, T, hd, (0, ld, hd), (0, ld, hd), (0, ld, hd), (0, out_ld, hd),
                          1.0 / math.sqrt(hd), k_off=D, v_off=2 * D, label=label, q_prescaled=True, q8=q8,
-                         qk_f8=(qk8, 0, D, 2 * D, -3) if qk8 is not None else None)
+                         qk_f8=(qk8, 0, D, 2 * D, -3) if qk8 is not None else None, pv_f8=pv)
 
         def swiglu(src, ld, c0, r0, r1, dst, dst_ld, dst_c0, label, dst8=None, consumers=()):
             """silu(a) * b of the two halves of a fused projection.  With fp8 consumers: one pass that writes their MX fp8 operand

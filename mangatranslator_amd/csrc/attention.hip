@@ -32,6 +32,8 @@ struct AttnParams {
   unsigned char* q8; unsigned* q8_scale; long ldq8, lds_q8;
   // fp8 scores (mtx_attn_args.q_f8 / k_f8): plain e4m3 rows, strides in bytes, head h at byte column h * 128; logits = 2^qk_f8_exp * sum q k
   const unsigned char* qf8; const unsigned char* kf8; long qf8_ss, kf8_ss; int qk_f8_exp;
+  // fp8 P V (mtx_attn_args.v_f8t): e4m3 V^T [head][128][vf8_ld], keys in accumulator order inside every 64-key tile
+  const unsigned char* vf8; long vf8_ld;
 };
 
 constexpr int AT_KV = 64;      // keys per tile
@@ -591,6 +593,91 @@ __device__ __forceinline__ void attn_bias_tile_k8(unsigned char* smem, const i32
   for (int i = 0; i < 16 - VD; ++i) { MTX_SCHED_GROUP(0x008, 1); MTX_SCHED_GROUP(0x100, 2); }
   MTX_SCHED_GROUP(0x008, VD);
 }
+// fp8 scores AND fp8 P V (round 6): the tile's probabilities are rounded to e4m3 where they stand — lane (query, half) holds its 32 keys in exactly
+// the order MTX_EW_V_F8T stores a V^T row's bytes — and O^T += V^T P runs as ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32-row block of d.
+// A probability must fit e4m3 (448): the stale-maximum path is left as soon as a lane's partial sum reaches 240.
+template <typename T, int DP, int STAGE, bool RAGGED>
+__device__ __forceinline__ void attn_bias_tile_k8v8(unsigned char* smem, const i32x8 (&qf)[2], f32x16 (&oacc)[DP / 32],
+                                                    float& M, float& lsum, f32x16& minit, bool& first,
+                                                    const int (&kaddr)[4], const int (&vaddr)[2], const long kvalid, const int hi, const int sb) {
+  constexpr int DB = DP / 32, ROWB = DP * 2, TILE_B = AB_KV * ROWB;
+  static_assert(DP == 128, "two k-steps of 64 bytes");
+  const unsigned char* Ks = smem + STAGE * 2 * TILE_B;
+  const unsigned char* Vs = Ks + TILE_B;
+  f32x16 sacc[2];
+  {
+    i32x8 kf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(Ks + kaddr[2 * ks] + kb * 32 * 128);
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(Ks + kaddr[2 * ks + 1] + kb * 32 * 128);
+        kf[ks][kb] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hv[0], (int)hv[1], (int)hv[2], (int)hv[3]};
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma_f8_scores(kf[ks][kb], qf[ks], ks == 0 ? minit : sacc[kb], sb);
+    MTX_SCHED_GROUP(0x100, 8);
+    MTX_SCHED_GROUP(0x008, 4);
+  }
+  if (RAGGED) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= kvalid) sacc[kb][r] = -1.0e30f;
+  }
+  float pv[2][16];
+  float tsum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pv[kb][r] = fast_exp2(sacc[kb][r]); tsum += pv[kb][r]; }
+  if (first || __any(!(tsum < 240.0f))) {
+    float tmax = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);
+    tmax = half_max(tmax);
+    const float delta = first ? tmax : fmaxf(tmax, 0.f);
+    const float alpha = fast_exp2(-delta);
+    M += delta;
+    lsum *= alpha;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) minit[r] = -M;
+    tsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pv[kb][r] = fast_exp2(sacc[kb][r] - delta); tsum += pv[kb][r]; }
+    first = false;
+  }
+  lsum += tsum;
+  i32x8 pb8;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      unsigned w = 0;
+      w = cvt_pk_fp8<false>(pv[kb][4 * g], pv[kb][4 * g + 1], w);
+      w = cvt_pk_fp8<true>(pv[kb][4 * g + 2], pv[kb][4 * g + 3], w);
+      pb8[kb * 4 + g] = (int)w;
+    }
+  i32x8 vf[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(Vs + vaddr[0] + d * 32 * 64);
+    const u32x4 hv = *reinterpret_cast<const u32x4*>(Vs + vaddr[1] + d * 32 * 64);
+    vf[d] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hv[0], (int)hv[1], (int)hv[2], (int)hv[3]};
+  }
+#pragma unroll
+  for (int d = 0; d < DB; ++d) oacc[d] = mfma_f8_scores(vf[d], pb8, oacc[d], 127);
+}
 // a and b of lanes l / l ^ 32: afterwards the lower lane holds (its a, the upper lane's a), the upper lane (the lower lane's b, its b)
 __device__ __forceinline__ void half_pair_exchange(uint32_t& a, uint32_t& b) {
 #ifdef MTX_EMU
@@ -633,6 +720,11 @@ __device__ __forceinline__ void half_pair_exchange(uint32_t& a, uint32_t& b) {
 #define ATTN_MMA32_NAME attn_mma32_k8q_kernel
 #include "attn_mma32_body.inc"
 #undef ATTN_MMA32_NAME
+#define ATTN_MMA32_V8 1
+#define ATTN_MMA32_NAME attn_mma32_k8v8q_kernel
+#include "attn_mma32_body.inc"
+#undef ATTN_MMA32_NAME
+#undef ATTN_MMA32_V8
 #undef ATTN_MMA32_K8
 #undef ATTN_MMA32_DEEP
 #undef ATTN_MMA32_Q8
@@ -739,7 +831,8 @@ static int launch_attn_t(const AttnParams& p0, void* stream) {
     // LDS-DMA (-17 %), row sums on the matrix pipe (-6.7 %), a half-tile pipelined softmax (does not fit 256 registers).  What stayed: fragment
     // reads four steps ahead of the MFMAs (order pinned with sched_group_barrier; +1.5 ... 2.5 %) and 16-byte row stores (+0.3 %), identical bytes.
     if (p.kf8 != nullptr) {                      // fp8 scores (validated in attn_launch: pre-scaled q; a 16-bit output needs 16-byte rows)
-      if (p.q8 != nullptr) MTX_LAUNCH((attn_mma32_k8q_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
+      if (p.vf8 != nullptr) MTX_LAUNCH((attn_mma32_k8v8q_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);      // (validated: comes with q8)
+      else if (p.q8 != nullptr) MTX_LAUNCH((attn_mma32_k8q_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
       else MTX_LAUNCH((attn_mma32_k8_kernel<T, 128, true>), dim3(g), dim3(512), 0, stream, p);
       if (p.split > 1) {
         if (p.q8 != nullptr) MTX_LAUNCH((attn_merge_q8_kernel<T, 128>), dim3((total - p.n_full) * 8), dim3(256), 0, stream, p);
@@ -781,6 +874,9 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
                              (a->q8 == nullptr && (a->o_ss % 8 || a->o_hs % 8 || ((size_t)a->o & 15))))) {
     *err = "attention (fp8 scores): long-sequence kernel with pre-scaled q only (d = 128, sq >= 1024, sk >= 256, batch 1), 16-byte aligned fp8 rows of >= heads * 128 bytes, 16-byte output rows";
     return MTX_ERR_INVALID; }
+  if (a->v_f8t != nullptr && (a->k_f8 == nullptr || a->q8 == nullptr || a->vf8_ld % 64 || a->vf8_ld < (a->sk + 63) / 64 * 64 || ((size_t)a->v_f8t & 15))) {
+    *err = "attention (fp8 P V): needs q_f8 / k_f8 and the MX fp8 output q8; v_f8t as MTX_EW_V_F8T writes it (vf8_ld a multiple of 64 that covers sk, 16-byte aligned)";
+    return MTX_ERR_INVALID; }
   if (a->d < 8 || a->d > 128 || a->d % 8) { *err = "attention: head dim must be a multiple of 8, <= 128"; return MTX_ERR_INVALID; }
   if (a->d % 4 || a->q_ss % 8 || a->k_ss % 8 || a->v_ss % 8 || a->o_ss % 4 || a->q_hs % 8 || a->k_hs % 8 || a->v_hs % 8 || a->o_hs % 4 ||
       a->q_bs % 8 || a->k_bs % 8 || a->v_bs % 8 || a->o_bs % 4) { *err = "attention: strides must keep 16-byte alignment"; return MTX_ERR_INVALID; }
@@ -794,6 +890,7 @@ int attn_launch(const mtx_attn_args* a, void* stream, const char** err) {
   p.scale_log2 = p.prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.qblocks = (unsigned)((a->sq + AT_QB - 1) / AT_QB);
   p.n_full = 0; p.split = 1; p.part_o = nullptr; p.part_ml = nullptr;
+  p.vf8 = reinterpret_cast<const unsigned char*>(a->v_f8t); p.vf8_ld = a->vf8_ld;
   p.qf8 = reinterpret_cast<const unsigned char*>(a->q_f8); p.kf8 = reinterpret_cast<const unsigned char*>(a->k_f8); p.qf8_ss = a->qf8_ss; p.kf8_ss = a->kf8_ss; p.qk_f8_exp = a->qk_f8_exp;
   p.q8 = reinterpret_cast<unsigned char*>(a->q8); p.q8_scale = reinterpret_cast<unsigned*>(a->q8_scale); p.ldq8 = a->ldq8; p.lds_q8 = a->lds_q8;
   if (a->workspace && a->workspace_bytes >= (int64_t)MTX_ATTN_WORKSPACE_BYTES) {      // 256 slots of [256][128] fp32 + [256][2] fp32

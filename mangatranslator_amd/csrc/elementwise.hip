@@ -319,6 +319,45 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(mtx_ew_args p) {
   }
 }
 
+// ---- MTX_EW_V_F8T: v rows -> e4m3 V^T of one head and one 64-key tile per workgroup ---------------------------------------------------
+// in: 64 keys x 128 d (16-bit) of head blockIdx.y, tile blockIdx.x; out: 128 d-rows x 64 bytes, byte j of a row = key
+// 32 (j >> 5) + (j & 3) + 8 ((j & 15) >> 2) + 4 ((j >> 4) & 1) — the order in which lane (query, half) of the S^T accumulators holds its 32 keys.
+template <typename T>
+__global__ __launch_bounds__(256) void v_f8t_kernel(mtx_ew_args p) {
+  __shared__ unsigned char tile[64][128 + 16];                   // [key][d] e4m3, rows padded against bank conflicts of the column gathers
+  const long rows = p.n * p.h * p.w;
+  const long k0 = (long)blockIdx.x * 64, head = blockIdx.y;
+  const T* X = reinterpret_cast<const T*>(p.a) + head * 128;
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {              // 16 chunks of 8 values per key row
+    const int key = i >> 4, ch = i & 15;
+    float f[8];
+    if (k0 + key < rows) unpack8<T>(*reinterpret_cast<const u32x4*>(X + (size_t)(k0 + key) * p.lda + ch * 8), f);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = f[e] > 448.f ? 448.f : (f[e] < -448.f ? -448.f : f[e]);
+    unsigned w0 = 0, w1 = 0;
+    w0 = cvt_pk_fp8<false>(f[0], f[1], w0); w0 = cvt_pk_fp8<true>(f[2], f[3], w0);
+    w1 = cvt_pk_fp8<false>(f[4], f[5], w1); w1 = cvt_pk_fp8<true>(f[6], f[7], w1);
+    *reinterpret_cast<u32x2*>(&tile[key][ch * 8]) = u32x2{w0, w1};
+  }
+  __syncthreads();
+  unsigned char* Y = reinterpret_cast<unsigned char*>(p.y8) + ((size_t)head * 128) * p.ldy8 + k0;
+  for (int i = threadIdx.x; i < 128 * 4; i += 256) {              // 4 chunks of 16 keys per d-row
+    const int d = i >> 2, c = i & 3;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int j = c * 16 + b;
+      const int key = 32 * (j >> 5) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * ((j >> 4) & 1);
+      w[b >> 2] |= (unsigned)tile[key][d] << (8 * (b & 3));
+    }
+    *reinterpret_cast<u32x4*>(Y + (size_t)d * p.ldy8 + c * 16) = u32x4{w[0], w[1], w[2], w[3]};
+  }
+}
+
 int ew_f32_launch(const mtx_ew_args* a, void* stream, const char** err);      // f32ops.hip
 int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
   if (a->dtype == MTX_F32) return ew_f32_launch(a, stream, err);
@@ -345,6 +384,17 @@ int ew_launch(const mtx_ew_args* a, void* stream, const char** err) {
     if (a->dtype == MTX_BF16) MTX_LAUNCH((transpose_kernel<__bf16>), grid, dim3(256), 0, stream, *a);
     else if (a->dtype == MTX_F16) MTX_LAUNCH((transpose_kernel<_Float16>), grid, dim3(256), 0, stream, *a);
     else { *err = "transpose: dtype"; return MTX_ERR_INVALID; }
+    return MTX_OK;
+  }
+  if (a->kind == MTX_EW_V_F8T) {
+    const long rows = a->n * a->h * a->w;
+    if (!a->a || !a->y8 || a->c % 128 || a->lda % 8 || a->ldy8 % 64 || a->ldy8 < (rows + 63) / 64 * 64 || ((size_t)a->y8 & 15)) {
+      *err = "v_f8t: c must be heads * 128, lda % 8 == 0, ldy8 a multiple of 64 that covers the rows, y8 16-byte aligned"; return MTX_ERR_INVALID; }
+    if (rows < 1) return MTX_OK;
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)(a->c / 128));
+    if (a->dtype == MTX_BF16) MTX_LAUNCH((v_f8t_kernel<__bf16>), grid, dim3(256), 0, stream, *a);
+    else if (a->dtype == MTX_F16) MTX_LAUNCH((v_f8t_kernel<_Float16>), grid, dim3(256), 0, stream, *a);
+    else { *err = "v_f8t: dtype"; return MTX_ERR_INVALID; }
     return MTX_OK;
   }
   if (a->kind == MTX_EW_QK_NORM_ROPE) {

@@ -11,6 +11,7 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_GELU_TANH, ACT_SIGMOID, ACT_LEAKY = 
  EW_ROW_GATHER, EW_IM2COL, EW_SOFTMAX_ROWS, EW_TRANSPOSE, EW_QK_NORM_ROPE, EW_AVGPOOL2, EW_SWIGLU, EW_DWCONV) = range(16)
 EW_SHUFFLE2_ADD, EW_CVT_F32, EW_CVT_16 = 16, 17, 18            # fp32 ops only (csrc/f32ops.hip)
 EW_SUB, EW_RESIDUAL_DIST = 19, 20                              # y = a - b; the first-block cache probe (include/mtx_hip.h)
+EW_V_F8T = 21                                                  # v -> e4m3 [head][128][keys], keys in accumulator order per 64-key tile (mtx_attn_args.v_f8t)
 RESDIST_PARTS = 256
 IMG_NCHW_F32_TO_NHWC, IMG_NHWC_TO_NCHW_F32, IMG_NHWC_TO_HWC_U8, IMG_HWC_U8_TO_NHWC = range(4)
 (OP_CONV2D, OP_GEMM, OP_ATTN, OP_NORM, OP_GROUPNORM, OP_EW, OP_CA, OP_IMG, OP_RESIZE_THRESH,
@@ -61,7 +62,8 @@ class AttnArgs(C.Structure):
                 ("v_bs", i64), ("v_ss", i64), ("v_hs", i64), ("o_bs", i64), ("o_ss", i64), ("o_hs", i64),
                 ("scale", f32), ("dtype", i32), ("workspace", vp), ("workspace_bytes", i64), ("flags", i32),
                 ("q8", vp), ("q8_scale", vp), ("ldq8", i64), ("lds_q8", i64),
-                ("q_f8", vp), ("k_f8", vp), ("qf8_ss", i64), ("kf8_ss", i64), ("qk_f8_exp", i32)]
+                ("q_f8", vp), ("k_f8", vp), ("qf8_ss", i64), ("kf8_ss", i64), ("qk_f8_exp", i32),
+                ("v_f8t", vp), ("vf8_ld", i64)]
 
 
 ATTN_Q_PRESCALED = 1

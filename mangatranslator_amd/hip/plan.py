@@ -353,7 +353,7 @@ class PlanBuilder:
         return out
 
     def attention(self, q, k, v, o, batch, heads, sq, sk, d, q_str, k_str, v_str, o_str, scale,
-                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False, q8=None, qk_f8=None):
+                  q_off=0, k_off=0, v_off=0, o_off=0, label="attn", q_prescaled=False, q8=None, qk_f8=None, pv_f8=None):
         """q8 = (q bytes [sq, ldq], scale plane [ldq / 128, lds], ldq, lds, byte column offset): the rows leave as the MX fp8 operand of the
         next linear instead of (o None) or beside 16-bit values — long-sequence kernel only (mtx_attn_args.q8).
         qk_f8 = (e4m3 bytes [rows, ld], q byte column, k byte column, ld, exponent): the scores are 2^exponent * q_f8 k_f8^T on the fp8
@@ -369,6 +369,10 @@ class PlanBuilder:
             t8, qc, kc, ld8, ex = qk_f8
             assert q_prescaled and t8.dtype == torch.uint8
             a.q_f8, a.k_f8, a.qf8_ss, a.kf8_ss, a.qk_f8_exp = t8.data_ptr() + qc, t8.data_ptr() + kc, ld8, ld8, ex
+        if pv_f8 is not None:            # (e4m3 V^T [heads * 128, ld] as `v_f8t` writes it, ld): P V on the fp8 instruction too (mtx_attn_args.v_f8t)
+            vt8, ld_v = pv_f8
+            assert qk_f8 is not None and q8 is not None and vt8.dtype == torch.uint8
+            a.v_f8t, a.vf8_ld = vt8.data_ptr(), ld_v
         a.batch, a.heads, a.sq, a.sk, a.d = batch, heads, sq, sk, d
         a.q_bs, a.q_ss, a.q_hs = q_str
         a.k_bs, a.k_ss, a.k_hs = k_str
@@ -380,6 +384,19 @@ class PlanBuilder:
             a.workspace, a.workspace_bytes = ws.data_ptr(), abi.ATTN_WORKSPACE_BYTES
         self._add(abi.OP_ATTN, a, label)
         return o
+
+    def v_f8t(self, v, rows, heads, ldv, v_off=0, out=None, label="v_f8t"):
+        """MTX_EW_V_F8T: the value rows [rows, heads * 128] (16-bit, row stride ldv) as e4m3 V^T [heads * 128, ld] with ld = rows padded to 64, keys in
+        accumulator order inside every 64-key tile — the operand of `attention(pv_f8=...)`.  -> (tensor, ld)"""
+        ld = (rows + 63) // 64 * 64
+        if out is None:
+            out = self.buf((heads * 128, ld), torch.uint8, zero=True)
+        e = abi.EwArgs()
+        e.a, e.y8, e.ldy8 = _ptr(v, v_off), out.data_ptr(), ld
+        e.n, e.h, e.w, e.c = 1, 1, rows, heads * 128
+        e.lda, e.kind, e.dtype = ldv, abi.EW_V_F8T, self.dtype
+        self._add(abi.OP_EW, e, label)
+        return out, ld
 
     def norm(self, x, y, rows, c, ldx=None, ldy=None, gamma=None, beta=None, eps=1e-6, kind=0,
              mod_scale=None, mod_shift=None, rows_per=0, ldmod=0, x_off=0, y_off=0, act=abi.ACT_NONE,

@@ -184,9 +184,9 @@ def check_klein_fp8_scores(lib, device, h=384, w=512, t_txt=32, steps=4, **kw):
     pe = torch.randn(t_txt, t.cfg["joint_dim"], generator=g).to(torch.bfloat16).float()
     noise = torch.randn(1, t.cfg["in_channels"], h // 16, w // 16, generator=g)
     outs = []
-    for fp8, scores in ((False, False), (True, False), (True, True)):
-        dit, vae = hip_models(t, v, lib, device, fp8=fp8, attn_qk_f8=scores)
-        assert dit.attn_qk_f8 == scores
+    for fp8, scores, values in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+        dit, vae = hip_models(t, v, lib, device, fp8=fp8, attn_qk_f8=scores, attn_pv_f8=values)
+        assert dit.attn_qk_f8 == scores and dit.attn_pv_f8 == values
         pipe = f2.Flux2KleinHip(dit, vae)
         outs.append(pipe(image=Image.fromarray(img), width=w, height=h, num_inference_steps=steps, prompt_embeds=pe[None], latents=noise,
                          output_type="pt").images[0].cpu())
@@ -194,9 +194,12 @@ def check_klein_fp8_scores(lib, device, h=384, w=512, t_txt=32, steps=4, **kw):
             from mangatranslator_amd.hip import abi
             plan = next(iter(dit._plans._d.values()))
             assert plan.T >= 1024 and any(o.kind == abi.OP_ATTN and o.u.attn.k_f8 for o in plan.ops), "the step does not run the fp8-score kernel"
+            assert any(o.kind == abi.OP_ATTN and o.u.attn.v_f8t for o in plan.ops) == values
     p_lin, p_sc, p_between = psnr(outs[1], outs[0]), psnr(outs[2], outs[0]), psnr(outs[2], outs[1])
-    print(f"Klein {steps} steps {w}x{h}: vs bf16: fp8 linears {p_lin:.1f} dB, + fp8 scores {p_sc:.1f} dB; fp8 scores vs fp8 linears {p_between:.1f} dB")
-    return p_lin, p_sc, p_between
+    p_pv, p_pv_between = psnr(outs[3], outs[0]), psnr(outs[3], outs[2])
+    print(f"Klein {steps} steps {w}x{h}: vs bf16: fp8 linears {p_lin:.1f} dB, + fp8 scores {p_sc:.1f} dB; fp8 scores vs fp8 linears {p_between:.1f} dB; "
+          f"+ fp8 P V {p_pv:.1f} dB vs bf16 ({p_pv_between:.1f} dB vs fp8 scores alone)")
+    return p_lin, p_sc, p_between, p_pv
 
 
 def check_klein_fp8_vs_bf16(lib, device, h=64, w=96, t_txt=16, steps=4, fp8=True, **kw):

@@ -242,6 +242,68 @@ def check_attention_f8_scores(lib, dtype, heads, sq, sk, seed=0, exponent=-3, qm
     return err
 
 
+def v_f8t_ref(v: torch.Tensor):
+    """MTX_EW_V_F8T restated: v [rows, heads, 128] -> uint8 [heads * 128, ld], ld = rows padded to 64, byte j of a 64-key tile = key
+    32 (j >> 5) + (j & 3) + 8 ((j & 15) >> 2) + 4 ((j >> 4) & 1), zeros past the rows"""
+    rows, heads, d = v.shape
+    ld = (rows + 63) // 64 * 64
+    q = torch.zeros(ld, heads, d, dtype=torch.uint8)
+    q[:rows] = v.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    j = torch.arange(64)
+    key = 32 * (j >> 5) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * ((j >> 4) & 1)
+    tiles = q.view(ld // 64, 64, heads, d)[:, key]                      # [tile, byte j, head, d]
+    return tiles.permute(2, 3, 0, 1).reshape(heads * d, ld).contiguous(), ld
+
+
+def check_attention_f8_pv(lib, dtype, heads, sq, sk, seed=0, exponent=-3, qmul=1.0, late_keys=None, tol=0.045):
+    """fp8 scores + fp8 P V (mtx_attn_args.v_f8t): the V^T operand the producer kernel writes is byte-identical to its restatement; the output rows —
+    MX fp8, dequantised here — are compared with the exact softmax over the e4m3 products times the values (which are e4m3-representable in this
+    test, so both P V forms see the same numbers) by their rms error relative to the rms of the reference.  The rows' own e4m3 rounding is 2-3 % by that
+    measure (the 16-bit-P-V kernel's figure, asserted beside it); the probabilities' rounding to e4m3 may add at most 1.5 points."""
+    d = 128
+    g = torch.Generator().manual_seed(seed)
+    dev, td = _dev(lib), TD[dtype]
+    D = heads * d
+    q8 = (torch.randn(sq, heads, d, generator=g) * qmul).clamp(-448, 448).to(torch.float8_e4m3fn)
+    k = torch.randn(sk, heads, d, generator=g)
+    if late_keys is not None:
+        k[late_keys[0]:] *= late_keys[1]
+    k8 = k.clamp(-448, 448).to(torch.float8_e4m3fn)
+    v = torch.randn(sk, heads, d, generator=g).to(torch.float8_e4m3fn).float().to(td)          # e4m3-representable values in the 16-bit type
+    logits = torch.einsum("qhd,khd->hqk", q8.float(), k8.float()) * (2.0 ** exponent)
+    ref = torch.einsum("hqk,khd->qhd", torch.softmax(logits * math.log(2.0), dim=-1), v.float())
+    rows = max(sq, sk)
+    packed = torch.zeros(rows, 2 * D, dtype=torch.uint8)
+    packed[:sq, :D] = q8.view(torch.uint8).reshape(sq, D)
+    packed[:sk, D:] = k8.view(torch.uint8).reshape(sk, D)
+    lds = (sq + 63) // 64 * 64
+    errs = []
+    for fp8_pv in (False, True):
+        pb = PlanBuilder(lib, dev, dtype)
+        unused = pb.buf((1, rows, heads, d), td, zero=True)
+        vt, pk = pb.const(v.view(1, sk, heads, d)), pb.const(packed)
+        vt8, ldv = pb.v_f8t(vt, sk, heads, D)
+        o8, sc = pb.buf((sq, D), torch.uint8, zero=True), pb.buf((D // 128, lds), torch.int32, zero=True)
+        strides = ((rows * D, D, d), (rows * D, D, d), (sk * D, D, d), (sq * D, D, d))
+        pb.attention(unused, unused, vt, None, 1, heads, sq, sk, d, *strides, 1.0, q_prescaled=True, qk_f8=(pk, 0, D, 2 * D, exponent), q8=(o8, sc, D, lds, 0),
+                     pv_f8=(vt8, ldv) if fp8_pv else None)
+        _run(pb)
+        if fp8_pv:
+            want_vt, ld_ref = v_f8t_ref(v)
+            assert ld_ref == ldv and np.array_equal(vt8.cpu().numpy(), want_vt.numpy()), "MTX_EW_V_F8T: bytes differ from the restatement"
+        # dequantise the MX fp8 rows: byte * 2^(scale byte - 127), scale word [head][row], one byte per 32-column block of the head
+        ob = o8.cpu().view(torch.float8_e4m3fn).float().view(sq, heads, 4, 32)
+        sw = sc.cpu().numpy().astype(np.uint32)[:, :sq]                                           # [heads, sq]
+        eb = np.stack([(sw >> (8 * i)) & 0xff for i in range(4)], -1).astype(np.int32)            # [heads, sq, 4]
+        scale = torch.from_numpy(np.exp2((eb - 127).astype(np.float32))).permute(1, 0, 2)          # [sq, heads, 4]
+        got = (ob * scale[..., None]).view(sq, heads, d)
+        assert torch.isfinite(got).all()
+        errs.append(float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()))
+    assert errs[0] < 0.035, f"fp8 scores, 16-bit P V, MX fp8 rows: rms rel err {errs[0]}"
+    assert errs[1] < tol and errs[1] < errs[0] + 0.015, f"fp8 P V: rms rel err {errs[1]} against {errs[0]} with 16-bit P V"
+    return errs
+
+
 def check_rope_f8_twin(lib, dtype, rows, heads, seed=0, q_mul=8.0):
     """MTX_EW_QK_NORM_ROPE with mtx_ew_args.y8: the e4m3 twin is RNE_e4m3(clamp(y * (q_mul on the q heads))) of the 16-bit values the
     same launch stores, byte for byte"""

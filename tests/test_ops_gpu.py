@@ -230,6 +230,18 @@ def test_attention_fp8_scores(hip_lib):
     oc.check_rope_f8_twin(hip_lib, abi.F16, rows=333, heads=3, q_mul=1.0, seed=1)
 
 
+def test_attention_fp8_scores_and_values(hip_lib):
+    """attn_mma32_k8v8q_kernel (mtx_attn_args.v_f8t, an experiment of the FLUX.2 fp8 path) + MTX_EW_V_F8T: V^T bytes equal the restatement; output rows
+    within 1.5 points (rms, relative) of the 16-bit-P-V kernel's distance to the exact softmax — Klein's shape incl. the key-split tail, a ragged key count,
+    a forced stale maximum"""
+    e1 = oc.check_attention_f8_pv(hip_lib, abi.BF16, heads=24, sq=8704, sk=8704, seed=3)
+    e2 = oc.check_attention_f8_pv(hip_lib, abi.BF16, heads=3, sq=2100, sk=2100)
+    e3 = oc.check_attention_f8_pv(hip_lib, abi.F16, heads=2, sq=1100, sk=449, exponent=-2, seed=1)
+    e4 = oc.check_attention_f8_pv(hip_lib, abi.BF16, heads=2, sq=1024, sk=320, qmul=4.0, late_keys=(200, 6.0), seed=2)
+    from parity_log import record
+    record("attention.fp8_pv.rms_rel_err_16bit_pv_vs_fp8_pv", T8704=e1, T2100=e2, ragged_449=e3, stale_max=e4)
+
+
 @pytest.mark.parametrize("cfg", [
     dict(heads=24, sq=8512, sk=8512),                                           # key-split tail blocks included
     dict(heads=24, sq=8652, sk=8652, extra_cols=9216, seed=1),                  # into the single blocks' concatenation buffer

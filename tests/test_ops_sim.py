@@ -127,6 +127,14 @@ def test_attention_fp8_scores(emu_lib):
     oc.check_rope_f8_twin(emu_lib, abi.F16, rows=33, heads=1, q_mul=1.0, seed=1)
 
 
+def test_attention_fp8_scores_and_values(emu_lib):
+    """attn_mma32_k8v8q_kernel (mtx_attn_args.v_f8t) + MTX_EW_V_F8T: P V on the fp8 instruction as well — ragged key counts, the key-split tail, a forced
+    stale maximum (the stale-maximum path must be left before a probability leaves e4m3's range)"""
+    oc.check_attention_f8_pv(emu_lib, abi.BF16, heads=2, sq=1030, sk=330)
+    oc.check_attention_f8_pv(emu_lib, abi.F16, heads=1, sq=1024, sk=256, exponent=-2, seed=1)
+    oc.check_attention_f8_pv(emu_lib, abi.BF16, heads=1, sq=1024, sk=320, qmul=4.0, late_keys=(200, 6.0), seed=2)
+
+
 def test_attention_fp8_output(emu_lib):
     """the long-sequence kernel writing the MX fp8 operand of the next linear (mtx_attn_args.q8) == the same kernel -> mtx_quantize_mx, byte
     for byte and scale word for scale word; 10 query blocks on 3 simulated CUs: one goes through the key-split tail + the quantising merge"""

@@ -53,6 +53,29 @@ def attn_q8(T, heads=24, d=128, iters=10, fused=True):
     print(f"attn -> MX fp8 T={T} heads={heads} [{'fused epilogue' if fused else 'attention + quantiser launch'}]: {ms:.3f} ms  {4 * T * T * D / ms / 1e9:.0f} TFLOP/s", flush=True)
 
 
+def attn_f8_pv(T, heads=24, d=128, iters=10):
+    """fp8 scores + fp8 P V (mtx_attn_args.v_f8t), MX fp8 rows out; the V^T producer launch (MTX_EW_V_F8T) timed with it and alone"""
+    D = heads * d
+    lds = (T + 63) // 64 * 64
+    def build(with_attn, with_prod):
+        pb = PlanBuilder(lib, dev, abi.BF16)
+        qkv = pb.buf((T, 3 * D), torch.bfloat16); qkv.normal_()
+        qk8 = pb.buf((T, 2 * D), torch.uint8)
+        qk8.copy_(qkv[:, :2 * D].float().clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+        q8 = pb.buf((T, D), torch.uint8, zero=True)
+        sc = pb.buf((D // 128, lds), torch.int32, zero=True)
+        vt8 = pb.buf((D, lds), torch.uint8, zero=True)
+        if with_prod:
+            pb.v_f8t(qkv, T, heads, 3 * D, v_off=2 * D, out=vt8)
+        if with_attn:
+            pb.attention(qkv, qkv, qkv, None, 1, heads, T, T, d, (0, 3 * D, d), (0, 3 * D, d), (0, 3 * D, d), (0, D, d), d ** -0.5, k_off=D, v_off=2 * D,
+                         q_prescaled=True, q8=(q8, sc, D, lds, 0), qk_f8=(qk8, 0, D, 2 * D, -3), pv_f8=(vt8, lds))
+        return pb.build()
+    both, prod = _time(build(True, True), iters), _time(build(False, True), iters)
+    print(f"attn, fp8 scores + fp8 P V T={T} heads={heads} [MX fp8 rows out]: {both - prod:.3f} ms  {4 * T * T * D / (both - prod) / 1e9:.0f} TFLOP/s; "
+          f"with the V^T producer launch {both:.3f} ms (producer alone {prod * 1e3:.1f} us)", flush=True)
+
+
 def attn_f8_scores(T, heads=24, d=128, iters=10, out8=True):
     """the fp8-score form (mtx_attn_args.q_f8 / k_f8): q and k as plain e4m3 rows; out8: rows leave as MX fp8 (the Klein graph's form), else 16-bit"""
     pb = PlanBuilder(lib, dev, abi.BF16)
@@ -227,6 +250,8 @@ if __name__ == "__main__":
     while args:
         if args[0] == "attn":
             attn(int(args[1])); args = args[2:]
+        elif args[0] == "attn88":                       # fp8 scores + fp8 P V
+            attn_f8_pv(int(args[1])); args = args[2:]
         elif args[0] in ("attn8", "attn8w"):          # fp8 scores: MX fp8 rows out / 16-bit rows out
             attn_f8_scores(int(args[1]), out8=args[0] == "attn8"); args = args[2:]
         elif args[0] in ("attnq", "attnqs"):          # attention with MX fp8 output: fused epilogue / separate quantiser
