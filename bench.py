@@ -117,9 +117,9 @@ def parse():
     ap.add_argument("--no-glu-epilogue", action="store_true",
                     help="FLUX.2-Klein fp8 path, for A/Bs: separate SwiGLU / attention-output quantiser launches instead of the epilogue fusions "
                          "(mtx_gemm_args.glu_*, mtx_attn_args.q8) that are the default since round 4")
-    ap.add_argument("--attn-pv-f8", action="store_true",
-                    help="FLUX.2-Klein fp8 path, experiment: P V of the joint attention on the fp8 matrix instruction as well (Flux2DiTHip(attn_pv_f8=True)); "
-                         "changes the result, NOT the configuration `value` is quoted on; reported in config.attn_pv_f8")
+    ap.add_argument("--no-attn-pv-f8", action="store_true",
+                    help="FLUX.2-Klein fp8 path, for A/Bs: 16-bit P V in the joint attention instead of the fp8 path's default since round 6 (values as e4m3 V^T, "
+                         "probabilities rounded to e4m3: Flux2DiTHip(attn_pv_f8=True), mtx_attn_args.v_f8t); reported in config.attn_pv_f8")
     ap.add_argument("--no-attn-qk-f8", action="store_true",
                     help="FLUX.2-Klein fp8 path, for A/Bs: 16-bit attention scores instead of the scores from e4m3 q and k on the fp8 matrix instruction "
                          "(Flux2DiTHip(attn_qk_f8=True), mtx_attn_args.q_f8 / k_f8) that are the fp8 path's default since round 6; reported in config.attn_qk_f8")
@@ -386,7 +386,7 @@ def main():
             if args.traffic_child:      # counter pass: same kernels, shapes and double : single launch mix on a fraction of the depth
                 dcfg = dict(dcfg, layers=max(1, dcfg["layers"] // 5), single_layers=max(1, dcfg["single_layers"] // 5))
             dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8, fused_quant=not args.no_fused_quant, glu_epilogue=not args.no_glu_epilogue, attn_q8=not args.no_glu_epilogue,
-                                  attn_qk_f8=not args.no_attn_qk_f8, attn_pv_f8=args.attn_pv_f8)
+                                  attn_qk_f8=not args.no_attn_qk_f8, attn_pv_f8=not args.no_attn_pv_f8)
             vae = f2.Flux2VAEHip(fx.synthetic_provider(f2.vae_param_shapes(f2.KLEIN_VAE_CFG), device, 22, broadcast=world > 1), f2.KLEIN_VAE_CFG, device, lib=lib)
             flux = f2.Flux2KleinHip(dit, vae, graph=graph)
             flux.set_prompt_embeds(torch.randn(512, dcfg["joint_dim"], generator=torch.Generator().manual_seed(23)))     # cached Qwen3 states (stand-ins)
@@ -768,7 +768,7 @@ def main():
     if batch_io is not None:
         cfg["batch_io"] = batch_io
     if klein and flux is not None:
-        cfg["attn_pv_f8"] = bool(getattr(flux.transformer, "attn_pv_f8", False))      # experiment flag (--attn-pv-f8)
+        cfg["attn_pv_f8"] = bool(getattr(flux.transformer, "attn_pv_f8", False))      # P V on the fp8 instruction too (fp8 path only; 41.8 dB against the bf16 pipeline)
         cfg["attn_qk_f8"] = bool(getattr(flux.transformer, "attn_qk_f8", False))      # scores from e4m3 q / k (fp8 path only; 41.9 dB against the bf16 pipeline, tests/test_flux2_gpu.py)
     if flux is not None and not klein:
         st_ = getattr(flux, "cache_stats", {"steps": 0, "skipped": 0})
@@ -899,11 +899,12 @@ def main():
                     # half of the flops (Q K^T) run on the fp8 matrix instruction at FP8_PEAK, half (P V) on the 16-bit one: the launch's ideal time is
                     # F/2 / FP8_PEAK + F/2 / MFMA_PEAK, i.e. the peak it is priced against is the harmonic mix (3 333 TFLOP/s), not 2 500
                     mix_ = 2.0 / (1.0 / FP8_PEAK_TFLOPS + 1.0 / MFMA_PEAK_TFLOPS)
-                    if getattr(flux.transformer, "attn_pv_f8", False):      # the experiment with P V on the fp8 instruction too: every flop at the fp8 rate
+                    if getattr(flux.transformer, "attn_pv_f8", False):      # P V on the fp8 instruction too: every flop at the fp8 rate
                         mix_ = FP8_PEAK_TFLOPS
-                    roofs["attention"] = roof("attention", f"attn_mma32_k8q_kernel<bf16, 128> (scores from e4m3 q / k on v_mfma_scale_f32_32x32x64_f8f6f4, P V 16-bit) "
+                    roofs["attention"] = roof("attention", (f"attn_mma32_k8v8q_kernel<bf16, 128> (scores from e4m3 q / k AND P V from e4m3 p / v on v_mfma_scale_f32_32x32x64_f8f6f4) " if getattr(flux.transformer, "attn_pv_f8", False) else
+                                                            f"attn_mma32_k8q_kernel<bf16, 128> (scores from e4m3 q / k on v_mfma_scale_f32_32x32x64_f8f6f4, P V 16-bit) ") + 
                                                            f"{flux.transformer.cfg['heads']} heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)", mix_)
-                    roofs["attention"]["peak_note"] = "harmonic mix of the fp8 (Q K^T) and 16-bit (P V) dense peaks"
+                    roofs["attention"]["peak_note"] = ("the fp8 dense peak (both products)" if getattr(flux.transformer, "attn_pv_f8", False) else "harmonic mix of the fp8 (Q K^T) and 16-bit (P V) dense peaks")
                 else:
                     roofs["attention"] = roof("attention", f"attn_mma32_kernel<bf16, 128> {flux.transformer.cfg['heads']} heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)", MFMA_PEAK_TFLOPS)
             if "gemm_bf16" in tot:

@@ -82,7 +82,7 @@ class _W:
 
 
 class Flux2DiTHip:
-    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=True, attn_q8=True, attn_qk_f8=True, attn_pv_f8=False):
+    def __init__(self, provider, cfg: dict, device, lib=None, fp8=False, fused_quant=True, glu_epilogue=True, attn_q8=True, attn_qk_f8=True, attn_pv_f8=True):
         """provider(name) -> tensor with diffusers' Flux2Transformer2DModel parameter of that name.
         fp8: False, True (= every block linear) or a tuple of names out of FP8_ALL."""
         self.lib = lib if lib is not None else get_library()
@@ -109,8 +109,10 @@ class Flux2DiTHip:
         # Changes the result (3 mantissa bits under the scores): 4 Klein steps at T = 1568 stay at 41.9 dB against the bf16 pipeline (fp8 linears alone: 41.8;
         # tests/test_flux2_gpu.py::test_klein_fp8_attention_scores_psnr), the launch takes 0.603 ms instead of 0.783 at T = 8704 — on with the fp8 linears, never without.
         self.attn_qk_f8 = bool(attn_qk_f8) and bool(self.fp8) and self.hd == 128
-        # attn_pv_f8 (experiment, off by default): P V on the fp8 instruction as well — the values as e4m3 V^T in accumulator key order (MTX_EW_V_F8T, one
-        # small launch per attention), the tile's probabilities rounded to e4m3 in registers (mtx_attn_args.v_f8t).  Needs attn_qk_f8 and attn_q8.
+        # attn_pv_f8: P V on the fp8 instruction as well — the values as e4m3 V^T in accumulator key order (MTX_EW_V_F8T, one 15 us launch per attention),
+        # the tile's probabilities rounded to e4m3 in registers (mtx_attn_args.v_f8t).  Needs attn_qk_f8 and attn_q8.  Measured like the scores: the launch
+        # 0.62 -> 0.48 ms at T = 8704, 4 Klein steps at T = 1568 41.8 dB against the bf16 pipeline (fp8 linears alone 41.8, + fp8 scores 41.9) — the rows
+        # leave as MX fp8 for the next linear anyway, the values' rounding is of that order.  On with the fp8 linears, never without.
         self.attn_pv_f8 = bool(attn_pv_f8) and self.attn_qk_f8 and self.attn_q8
         if self.fp8 and (D % 128 or self.hid % 128):
             raise ModelError("FLUX.2 DiT fp8 path: d and the MLP width must be multiples of 128")

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
   timeout 900 python -m pytest tests/test_flux2_gpu.py -q -x -s -p no:cacheprovider -k "fp8_attention_scores" 2>&1 | grep -E "Klein|passed|failed|^E " | head
   echo "== config 5, alternating"
   for r in 1 2 3; do
-    for f in "" "--attn-pv-f8"; do
+    for f in "--no-attn-pv-f8" ""; do
       timeout 600 python bench.py --config 5 --steps 6 --warmup 2 --no-cpu-baseline --no-traffic --no-extra $f > gpurun_out/c5.out 2> gpurun_out/c5.err
       python - "$f" <<'PY'
 import json, sys
@@ -20,7 +20,7 @@ if not l:
     print("no line", open("gpurun_out/c5.err").read()[-600:]); sys.exit()
 d = json.loads(l[-1]); c = d["config"]
 ra = d.get("roofline_attention", {})
-print(f"config 5 [{sys.argv[1] or 'default (fp8 scores, 16-bit P V)'}]: {d['value']:.4f} pages/s {d['ms_per_step']:.1f} ms/page | dit_step_ms", round(c.get("inpaint", {}).get("dit_step_ms", 0), 2),
+print(f"config 5 [{sys.argv[1] or 'default (fp8 scores and fp8 P V)'}]: {d['value']:.4f} pages/s {d['ms_per_step']:.1f} ms/page | dit_step_ms", round(c.get("inpaint", {}).get("dit_step_ms", 0), 2),
       "| attention", {k: round(v, 4) if isinstance(v, float) else v for k, v in ra.items() if k in ("frac", "achieved", "peak", "avg_launch_ms", "share_of_step_ms")}, "| attn_pv_f8", c.get("attn_pv_f8"))
 PY
     done
