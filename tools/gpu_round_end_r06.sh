@@ -63,10 +63,10 @@ print(round(d["value"], 4), d["unit"], round(d["ms_per_step"], 1), "ms/page |", 
 PY
   } > gpurun_out/r06_end_config5prof.log 2>&1; cat gpurun_out/r06_end_config5prof.log ;;
 pmc)
-  { ARGS="gemm 8812 9216 3072 gemm 8812 3072 15360 attn 8812 attn8 8704 conv 1536 1024 gemm8 8512 27648 3072 glu 8512 9216 3072 9216"
+  { ARGS="gemm 8812 9216 3072 gemm 8812 3072 15360 attn 8812 attn8 8704 attn88 8704 conv 1536 1024 gemm8 8512 27648 3072 glu 8512 9216 3072 9216"
     rm -rf /tmp/pmc_a; mkdir -p /tmp/pmc_a
     (cd /tmp && timeout 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_a -o k -- python $R/tools/bench_kernels.py $ARGS 2>&1 | grep -v "^[WE]2026" | tail -6)
     python tools/summarize_pmc.py "$(find /tmp/pmc_a -name '*counter_collection.csv' | head -1)" "$(find /tmp/pmc_a -name '*kernel_trace.csv' | head -1)" "$ARGS" gpurun_out/r06_pmc_mfma_util.json
-    bash tools/pmc_traffic.sh conv 1536 1024 attn 8812 attn8 8704 gemm 8812 9216 3072 gemm 8812 3072 15360 gemm8 8512 27648 3072; cp gpurun_out/r02_pmc_traffic.json gpurun_out/r06_pmc_traffic.json 2>/dev/null
+    bash tools/pmc_traffic.sh conv 1536 1024 attn 8812 attn8 8704 attn88 8704 gemm 8812 9216 3072 gemm 8812 3072 15360 gemm8 8512 27648 3072; cp gpurun_out/r02_pmc_traffic.json gpurun_out/r06_pmc_traffic.json 2>/dev/null
   } > gpurun_out/r06_end_pmc.log 2>&1; cat gpurun_out/r06_end_pmc.log ;;
 esac
