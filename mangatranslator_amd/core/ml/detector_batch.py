@@ -125,14 +125,18 @@ class DetectorBatcher:
             b = self._take_slot(key, letterbox_params(h0, w0, imgsz))
             slot = b.filled
             b.filled += 1
-            if on_device:
-                self._lane.adopt(image_bgr)
-            with self._lane.enter():
-                pp = b.pre[slot]
-                pp.page.copy_(img if on_device else torch.from_numpy(img).to(m.device, non_blocking=True))
-                pp.run()
-                if b.filled == b.size:
-                    self._launch(b, key)
+            try:
+                if on_device:
+                    self._lane.adopt(image_bgr)
+                with self._lane.enter():
+                    pp = b.pre[slot]
+                    pp.page.copy_(img if on_device else torch.from_numpy(img).to(m.device, non_blocking=True))
+                    pp.run()
+                    if b.filled == b.size:
+                        self._launch(b, key)
+            except BaseException:
+                self._slot_done(b)           # the slot was taken but no ticket will ever give it back: count it as dropped, or the buffer set stays busy for good
+                raise
             self.stats["pages"] += 1
             self._cv.notify_all()
         return BatchTicket(self, b, slot, key=key, hw=(h0, w0), conf=conf, iou=iou, max_det=max_det)
@@ -146,7 +150,7 @@ class DetectorBatcher:
                     with self._lane.enter():
                         self._launch(b, ticket["key"])
             with self._lane.resume():
-                view = SimpleNamespace(decoded=b.plan.decoded[ticket.slot], proto=None)
+                view = SimpleNamespace(decoded=b.plan.decoded[ticket.slot] if b.size > 1 else b.plan.decoded, proto=None)      # (a one-image plan has no image axis)
                 res = self.model._finish(view, b.lp, ticket["hw"], ticket["conf"], ticket["iou"], ticket["max_det"])
             self._lane.hand_over(*result_tensors(res))
             return res
@@ -245,10 +249,14 @@ class RTDetrBatcher(DetectorBatcher):
             slot = b.filled
             b.filled += 1
             b.meta[slot] = (oh, ow, float(conf))
-            with self._lane.enter():
-                b.enc.src[slot].copy_(torch.from_numpy(np.array(img, dtype=np.uint8)).to(m.device, non_blocking=True))
-                if b.filled == b.size:
-                    self._launch(b, key)
+            try:
+                with self._lane.enter():
+                    b.enc.src[slot].copy_(torch.from_numpy(np.array(img, dtype=np.uint8)).to(m.device, non_blocking=True))
+                    if b.filled == b.size:
+                        self._launch(b, key)
+            except BaseException:
+                self._slot_done(b)
+                raise
             self.stats["pages"] += 1
             self._cv.notify_all()
         return BatchTicket(self, b, slot, key=key)

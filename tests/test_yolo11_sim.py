@@ -21,3 +21,34 @@ def test_detector_batcher_matches_single_calls(emu_lib):
     yc.check_batched(emu_lib, "cpu", family="11")
     yc.check_batched(emu_lib, "cpu", family="12", pages=4, batch=2, seed=1)
     yc.check_batched(emu_lib, "cpu", family="11", pages=5, batch=2, seed=2, threads=True)
+
+
+def test_detector_batcher_survives_a_failed_submit(emu_lib):
+    """a submit that fails after it took its slot (here: the launch of a full batch raises) gives the slot back — the next pages go through and get the
+    one-page call's results"""
+    import numpy as np
+    import pytest
+    import torch
+    from mangatranslator_amd.core.ml.detector_batch import DetectorBatcher
+    from mangatranslator_amd.core.ml.yolo11 import Yolo11Hip
+    from oracle import yolo11_ref as yr
+    net = yr.make_model("11", "n", 1, False, seed=4)
+    hip = Yolo11Hip(net.state_dict(), device="cpu", lib=emu_lib)
+    pages = [yc.make_page(96, 64, 9 + i) for i in range(2)]
+    want = [hip(p, conf=0.05, imgsz=64)[0] for p in pages]
+    bat = DetectorBatcher(hip, batch=1)
+    real, state = bat._run, {"fail": True}
+
+    def flaky(b):
+        if state.pop("fail", False):
+            raise RuntimeError("injected launch failure")
+        return real(b)
+    bat._run = flaky
+    with pytest.raises(RuntimeError, match="injected"):
+        bat.submit(pages[0], conf=0.05, imgsz=64)
+    for p, w in zip(pages, want):          # both buffer sets are usable afterwards
+        got = bat(p, conf=0.05, imgsz=64)[0]
+        assert (w.boxes is None) == (got.boxes is None)
+        if w.boxes is not None:
+            assert torch.equal(w.boxes.xyxy, got.boxes.xyxy) and torch.equal(w.boxes.conf, got.boxes.conf)
+    assert all(s.filled == 0 and not s.launched for s in bat._sets[(96, 64, 64)])
