@@ -86,7 +86,8 @@ def parse():
                     help="call the page's detectors one after the other, each returning finished results (the reference's order of calls); default: "
                          "submit all of them, then collect — their graphs run side by side on their own streams")
     ap.add_argument("--no-lanes", action="store_true", help="FLUX.1: keep the text stream's ops in line with the image stream's (one lane)")
-    ap.add_argument("--no-fused-quant", action="store_true", help="Klein fp8: separate quantiser passes behind the norms and SwiGLU (round 2's form) instead of producers that write the fp8 operands themselves")
+    ap.add_argument("--no-fused-quant", action="store_true",
+                    help="Klein fp8: separate quantiser passes behind the norms and SwiGLU (round 2's form) instead of producers that write the fp8 operands themselves")
     ap.add_argument("--no-fp8", action="store_true", help="Klein: keep the block linears in bf16 instead of the MX-fp8 matrix path")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the stages of a page strictly one after another; default: two pages in flight — detect / segment / OSB prepare of "
@@ -370,7 +371,8 @@ def main():
             sam_sd = {k: torch.empty(shp) for k, shp in synth_sam.sam2_shapes(sam_cfg).items()}
         if world > 1:
             sam_sd = broadcast_state_dict(sam_sd, rank, world, device)
-        make_sam = lambda: Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph, dtype=abi_f16, precision=args.sam_precision)        # f16 storage: what ModelManager.load_sam2 serves (bf16 only when a checkpoint leaves the f16 range)
+        # f16 storage: what ModelManager.load_sam2 serves (bf16 only when a checkpoint leaves the f16 range)
+        make_sam = lambda: Sam2Hip(sam_sd, sam_cfg, device=device, lib=lib, graph=graph, dtype=abi_f16, precision=args.sam_precision)
         sam = make_sam()
     inpainter, flux = None, None
     klein = args.inpainter.startswith("klein")
@@ -385,7 +387,8 @@ def main():
             dcfg = f2.KLEIN_9B_DIT_CFG if args.inpainter == "klein_9b" else f2.KLEIN_4B_DIT_CFG
             if args.traffic_child:      # counter pass: same kernels, shapes and double : single launch mix on a fraction of the depth
                 dcfg = dict(dcfg, layers=max(1, dcfg["layers"] // 5), single_layers=max(1, dcfg["single_layers"] // 5))
-            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib, fp8=not args.no_fp8, fused_quant=not args.no_fused_quant, glu_epilogue=not args.no_glu_epilogue, attn_q8=not args.no_glu_epilogue,
+            dit = f2.Flux2DiTHip(fx.synthetic_provider(f2.dit_param_shapes(dcfg), device, 21, broadcast=world > 1), dcfg, device, lib=lib,
+                                  fp8=not args.no_fp8, fused_quant=not args.no_fused_quant, glu_epilogue=not args.no_glu_epilogue, attn_q8=not args.no_glu_epilogue,
                                   attn_qk_f8=not args.no_attn_qk_f8, attn_pv_f8=not args.no_attn_pv_f8)
             vae = f2.Flux2VAEHip(fx.synthetic_provider(f2.vae_param_shapes(f2.KLEIN_VAE_CFG), device, 22, broadcast=world > 1), f2.KLEIN_VAE_CFG, device, lib=lib)
             flux = f2.Flux2KleinHip(dit, vae, graph=graph)
@@ -904,7 +907,8 @@ def main():
                     roofs["attention"] = roof("attention", (f"attn_mma32_k8v8q_kernel<bf16, 128> (scores from e4m3 q / k AND P V from e4m3 p / v on v_mfma_scale_f32_32x32x64_f8f6f4) " if getattr(flux.transformer, "attn_pv_f8", False) else
                                                             f"attn_mma32_k8q_kernel<bf16, 128> (scores from e4m3 q / k on v_mfma_scale_f32_32x32x64_f8f6f4, P V 16-bit) ") + 
                                                            f"{flux.transformer.cfg['heads']} heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)", mix_)
-                    roofs["attention"]["peak_note"] = ("the fp8 dense peak (both products)" if getattr(flux.transformer, "attn_pv_f8", False) else "harmonic mix of the fp8 (Q K^T) and 16-bit (P V) dense peaks")
+                    roofs["attention"]["peak_note"] = ("the fp8 dense peak (both products)" if getattr(flux.transformer, "attn_pv_f8", False)
+                                                       else "harmonic mix of the fp8 (Q K^T) and 16-bit (P V) dense peaks")
                 else:
                     roofs["attention"] = roof("attention", f"attn_mma32_kernel<bf16, 128> {flux.transformer.cfg['heads']} heads, {fl['tokens']}x{fl['tokens']} tokens (MMDiT joint attention)", MFMA_PEAK_TFLOPS)
             if "gemm_bf16" in tot:
@@ -1024,7 +1028,8 @@ def measure_traffic(kernel_desc: str):
     # only the stage that owns the kernel, and ONE denoising step: every launch of a group moves the same bytes, and a counter pass costs
     # tens of milliseconds per dispatch (a whole 20-step page under --pmc ran past 25 minutes, r03)
     base += ["--stages", "upscale"] if want == "conv3x3_c64" else ["--stages", "inpaint", "--inpaint-steps", "1"]
-    child = [sys.executable, str(Path(__file__).resolve())] + base + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-overlap", "--no-graph", "--traffic-child"]          # eager launches: rocprofv3's counter mode segfaulted on hipGraph replays (r03); the kernels and their arguments are the same
+    # eager launches: rocprofv3's counter mode segfaulted on hipGraph replays (r03); the kernels and their arguments are the same
+    child = [sys.executable, str(Path(__file__).resolve())] + base + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-overlap", "--no-graph", "--traffic-child"]
     per = {}
     import types as types_
     detail = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py " + " ".join(child[2:]), "kernels": {}}
